@@ -1,0 +1,133 @@
+/*
+ * xrdslam_hip.h — C-ABI of the MI355X (gfx950) tracking/mapping engine.
+ *
+ * Drop-in boundary for the render/optimise hot path of openxrlab/xrdslam
+ * (SURVEY.md §8b).  Plain C: raw device pointers, sizes, a hipStream_t passed
+ * as void*; no torch types.  Every entry point returns XRD_OK (0) or an error
+ * code and never calls exit() (the reference's CUDA_CHECK_ERRORS does,
+ * third_party/sparse_voxels/include/cuda_utils.h:37-48).  Tensors are owned by
+ * the caller; the engine borrows them for the duration of the launch.
+ *
+ * Each block cites the reference interface it replaces (paths relative to the
+ * reference root).
+ */
+#ifndef XRDSLAM_HIP_H
+#define XRDSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* xrd_stream_t; /* hipStream_t */
+
+enum {
+  XRD_OK = 0,
+  XRD_ERR_ARG = 1,         /* bad argument (null pointer, bad size)          */
+  XRD_ERR_LAUNCH = 2,      /* hip launch / runtime error                     */
+  XRD_ERR_UNSUPPORTED = 3  /* configuration outside what the kernels cover   */
+};
+
+/* library/ABI version; bumps when a signature changes */
+int xrd_abi_version(void);
+/* last hip error string for XRD_ERR_LAUNCH (thread-unsafe, diagnostic only) */
+const char* xrd_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * NICE-SLAM fused render  (replaces, per iteration, the chain
+ *   slam/models/conv_onet.py:377-524   ConvOnet.render_batch_ray
+ *   slam/models/conv_onet.py:339-375   ConvOnet.eval_points
+ *   slam/model_components/decoder_nice.py:386-414  NICE.forward (+ MLP,
+ *       MLP_no_xyz, GaussianFourierFeatureTransform, F.grid_sample lookups)
+ *   slam/model_components/utils.py:189-244  raw2outputs_nerf_color
+ * and their autograd backward).
+ * ---------------------------------------------------------------------- */
+enum { XRD_STAGE_COARSE = 0, XRD_STAGE_MIDDLE = 1, XRD_STAGE_FINE = 2,
+       XRD_STAGE_COLOR = 3 };
+/* decoder kinds: MLP_no_xyz coarse, MLP(c_dim 32,out 1) middle,
+ * MLP(c_dim 64,out 1) fine, MLP(c_dim 32,out 4) color */
+enum { XRD_DEC_COARSE = 0, XRD_DEC_MIDDLE = 1, XRD_DEC_FINE = 2,
+       XRD_DEC_COLOR = 3 };
+
+typedef struct {
+  /* bounding box AFTER ConvOnet.load_bound (conv_onet.py:324-337), float64 as
+   * the reference holds it: x0,x1,y0,y1,z0,z1 */
+  double bound[6];
+  /* feature grids coarse,middle,fine,color; CHANNEL-LAST [Z][Y][X][32] f32,
+   * i.e. the reference's [1,32,Z,Y,X] tensor (feature_grid_nice.py:4-12) in
+   * torch.channels_last_3d memory format.  NULL when the stage does not use
+   * the grid. */
+  const float* grid[4];
+  int32_t gdim[12]; /* Z,Y,X for each of the four grids */
+  /* decoders in the packed MFMA-fragment layout produced by gathering the
+   * flat state_dict-ordered parameter vector through xrd_nice_pack_index */
+  const float* dec[4];
+  int32_t n_samples;       /* rendering_n_samples  (conv_onet.py:46) */
+  int32_t n_surface;       /* rendering_n_surface  (conv_onet.py:47) */
+  const float* t_uniform;  /* [n_samples] torch.linspace(0,1,n) f32           */
+  const double* t_surface; /* [n_surface] torch.linspace(0,1,n).double()      */
+  double coarse_enlarge;   /* model_coarse_bound_enlarge (conv_onet.py:36)    */
+} xrd_nice_scene;
+
+/* number of floats of the flat (state_dict order) / packed parameter vector */
+int xrd_nice_flat_len(int dec_kind);
+int xrd_nice_pack_len(int dec_kind);
+/* HOST function: idx[pack_len]; packed[i] = idx[i] < 0 ? 0 : flat[idx[i]] */
+int xrd_nice_pack_index(int dec_kind, int32_t* idx_host);
+
+/* Forward.  n_rays rays; S = n_samples + (gt_depth && stage!=coarse ?
+ * n_surface : 0) samples per ray (S must be 32 or 48).
+ *   rays_o, rays_d [n,3] f32; gt_depth [n] f32 or NULL; dmax: device scalar =
+ *   max(gt_depth) (conv_onet.py:418,455), ignored when gt_depth is NULL.
+ * Outputs depth,var [n] f64 (the reference returns float64 here), rgb [n,3]
+ * f32; raw_out [n,S,4] (rgb_raw, occupancy logit after the out-of-bound
+ * override) may be NULL — it is what the backward needs besides the inputs. */
+int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        double* depth, double* var, float* rgb, float* raw_out,
+                        xrd_stream_t stream);
+
+/* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
+ * NULL = zero).  Requested gradients (each may be NULL = not needed):
+ *   g_rays_o, g_rays_d [n,3] f32 (overwritten);
+ *   g_grid[4] channel-last like the grids (ACCUMULATED with atomics: caller
+ *     zeroes);
+ *   g_dec[4]  flat state_dict-ordered decoder gradients (overwritten;
+ *     deterministic two-stage reduction through `ws`).  Only XRD_DEC_COLOR is
+ *     supported in this version (mapping_fix_fine=True default,
+ *     conv_onet.py:62,190-195); others -> XRD_ERR_UNSUPPORTED.
+ *   ws: float workspace of xrd_nice_bwd_ws_floats(n_rays) floats (needed only
+ *     when a g_dec is requested). */
+int64_t xrd_nice_bwd_ws_floats(int n_rays);
+int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        const float* raw, const double* g_depth,
+                        const double* g_var, const float* g_rgb,
+                        float* g_rays_o, float* g_rays_d,
+                        float* const g_grid[4], float* const g_dec[4],
+                        float* ws, xrd_stream_t stream);
+
+/* Fused Adam over a subset of 32-float cells of a channel-last grid
+ * (frustum feature selection: conv_onet.py:94-130,187-211 optimise
+ * val[mask] as a 1-D Parameter and write it back every iteration; here the
+ * masked cells are updated in place).  cell_idx [n_cells] int32 lists the
+ * selected cells (NULL = all n_cells cells); m, v are the Adam moments with
+ * the grid's layout.  Matches torch.optim.Adam (no amsgrad, no weight decay):
+ * step is the 1-based step count.  zero_grad != 0 clears g after use. */
+int xrd_adam_cells(float* param, float* g, float* m, float* v,
+                   const int32_t* cell_idx, int64_t n_cells, int cell_floats,
+                   float lr, float beta1, float beta2, float eps, int step,
+                   int zero_grad, xrd_stream_t stream);
+
+/* self test of the MFMA operand/accumulator lane mapping the kernels rely on
+ * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
+int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,
+                      xrd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRDSLAM_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of the C-ABI shared library (include/xrdslam_hip.h).
+
+The product path has NO CPU fallback: if ``libxrdslam_hip.so`` is missing or a
+kernel launch fails, an exception is raised.  Build with
+``python -m xrdslam_amd.build`` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxrdslam_hip.so')
+
+_lib = None
+
+c_float_p = C.c_void_p  # raw device pointers are passed as integers
+i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class XrdError(RuntimeError):
+    pass
+
+
+class NiceScene(C.Structure):
+    """mirror of ``xrd_nice_scene``"""
+    _fields_ = [('bound', f64 * 6), ('grid', vp * 4), ('gdim', i32 * 12),
+                ('dec', vp * 4), ('n_samples', i32), ('n_surface', i32),
+                ('t_uniform', vp), ('t_surface', vp),
+                ('coarse_enlarge', f64)]
+
+
+_SIGS = {
+    'xrd_abi_version': (C.c_int, []),
+    'xrd_last_error': (C.c_char_p, []),
+    'xrd_nice_flat_len': (C.c_int, [C.c_int]),
+    'xrd_nice_pack_len': (C.c_int, [C.c_int]),
+    'xrd_nice_pack_index': (C.c_int, [C.c_int, vp]),
+    'xrd_nice_render_fwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
+                                      vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
+    'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
+                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                      C.POINTER(vp * 4), C.POINTER(vp * 4), vp,
+                                      vp]),
+    'xrd_adam_cells': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32, f32,
+                                 f32, f32, C.c_int, C.c_int, vp]),
+    'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
+}
+
+
+def declared_symbols():
+    """every entry point include/xrdslam_hip.h declares (kept in sync by
+    tests/test_abi.py, which parses the header)."""
+    return sorted(_SIGS)
+
+
+def register(name, restype, argtypes):
+    _SIGS[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XrdError(
+                f'{LIB_PATH} not found: the HIP engine is not built. Run '
+                '`python -m xrdslam_amd.build` (there is no CPU fallback).')
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = {1: 'bad argument', 2: 'HIP launch/runtime error',
+               3: 'unsupported configuration'}.get(rc, f'error {rc}')
+        detail = lib().xrd_last_error()
+        raise XrdError(f'{what}: {msg}'
+                       f'{" (" + detail.decode() + ")" if detail and rc == 2 else ""}')
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None) as void*"""
+    if t is None:
+        return None
+    assert t.is_contiguous() or t.numel() == 0, 'engine tensors must be dense'
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

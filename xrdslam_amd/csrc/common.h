@@ -1,0 +1,85 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xrdslam_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact f32 fma chain.
+// lane l: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D reg r: row=(l>>4)*4+r col=l&15
+#define XRD_MFMA4(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace xrd {
+
+extern thread_local const char* g_last_error;
+int check_launch(const char* what);
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over the 4 lane groups (l>>4) that hold the same point (l&15)
+__device__ __forceinline__ float group4_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+// sum over the 16 lanes of a row (same l>>4)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// make LDS writes of this wave visible to its own later LDS reads
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// sin/cos with a 3-constant Cody-Waite reduction (fma): < 1e-7 absolute error
+// for |x| < 1e5 (checked against float64 in tests/test_host_math.py).  The
+// Fourier-feature arguments p.B reach ~1e3 rad (B ~ N(0, 25^2),
+// decoder_nice.py:20-38), so the fast __sinf is not usable, while ocml's sinf
+// carries a Payne-Hanek path that costs ~10x the registers/instructions.
+__device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
+  const float k = rintf(x * 0.636619772367581f);
+  float r = fmaf(k, -1.57079601e+00f, x);
+  r = fmaf(k, -3.13916473e-07f, r);
+  r = fmaf(k, -5.39030253e-15f, r);
+  const float s = r * r;
+  float ps = fmaf(s, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(s, ps, -1.6666654611e-1f);
+  const float sr = fmaf(r * s, ps, r);
+  float pc = fmaf(s, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(s, pc, 4.166664568298827e-2f);
+  const float cr = fmaf(s * s, pc, fmaf(s, -0.5f, 1.0f));
+  const int n = (int)k & 3;
+  const float a = (n & 1) ? cr : sr;
+  const float b = (n & 1) ? sr : cr;
+  sn = (n & 2) ? -a : a;
+  cs = ((n + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ float sin_cw(float x) {
+  float s, c;
+  sincos_cw(x, s, c);
+  return s;
+}
+__device__ __forceinline__ float cos_cw(float x) {
+  float s, c;
+  sincos_cw(x, s, c);
+  return c;
+}
+
+}  // namespace xrd

@@ -1,0 +1,1450 @@
+// NICE-SLAM fused render for gfx950 (MI355X): one wave = one 16-sample tile of a ray.
+//
+//   sample z (f64, depth-guided 32 uniform + 16 near-surface, rank-sorted)
+//   -> trilinear lookup in the channel-last feature grids
+//   -> three tiny MLP decoders evaluated as an in-register chain of
+//      v_mfma_f32_16x16x4_f32 (exact f32): rows = output features, columns =
+//      16 points of a tile; the accumulator of layer i is directly the B
+//      operand of layer i+1 (nice_layout.h)
+//   -> occupancy compositing with wave shuffles (exclusive product scan).
+//
+// Reference behaviour restated (never copied): slam/models/conv_onet.py:339-524,
+// slam/model_components/decoder_nice.py:195-234,297-320,386-414,
+// slam/model_components/utils.py:189-244, torch grid_sample (bilinear, border,
+// align_corners=True) semantics.  Parity oracle: oracle/nice_oracle.py.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+#include "nice_layout.h"
+
+namespace xrd {
+namespace {
+
+constexpr int PTS = 17;
+// scheduling fence: keeps hipcc from hoisting a whole phase's weight-fragment
+// loads (and their VGPRs) across phases
+#define XRD_SB() __builtin_amdgcn_sched_barrier(0)  // padded point stride of transposed LDS tiles
+
+// ---------------------------------------------------------------------------
+// host: packed <- flat index tables
+// ---------------------------------------------------------------------------
+template <int CD, int OD>
+void build_mlp_index(int32_t* idx) {
+  using F = MlpFlat<CD, OD>;
+  using P = MlpPack<CD, OD>;
+  for (int i = 0; i < P::LEN; ++i) idx[i] = -1;
+  for (int k = 0; k < kEmbK; ++k)
+    for (int a = 0; a < 3; ++a) idx[P::EMB + k * 4 + a] = F::EB + a * kEmbK + k;
+  for (int jt = 0; jt < 2; ++jt)
+    for (int s = 0; s < kEmbS; ++s)
+      for (int l = 0; l < 64; ++l) {
+        int j = 16 * jt + (l & 15), k = emap(s, l >> 4);
+        if (k < kEmbK) {
+          idx[P::W0 + (jt * kEmbS + s) * 64 + l] = F::P0W + j * kEmbK + k;
+          idx[P::W3E + (jt * kEmbS + s) * 64 + l] =
+              F::P3W + j * (kEmbK + 32) + k;
+        }
+      }
+  for (int i = 1; i <= 4; ++i)
+    for (int jt = 0; jt < 2; ++jt)
+      for (int s = 0; s < 8; ++s)
+        for (int l = 0; l < 64; ++l) {
+          int j = 16 * jt + (l & 15), k = kmap(s, l >> 4);
+          idx[P::wh(i) + (jt * 8 + s) * 64 + l] =
+              F::pw(i) + j * F::pstride(i) + F::pcol(i) + k;
+          // transposed: rows = input feature k, k-slots = output feature j
+          int kk = 16 * jt + (l & 15), jj = kmap(s, l >> 4);
+          idx[P::wht(i) + (jt * 8 + s) * 64 + l] =
+              F::pw(i) + jj * F::pstride(i) + F::pcol(i) + kk;
+        }
+  for (int i = 0; i < 5; ++i) {
+    for (int jt = 0; jt < 2; ++jt)
+      for (int s = 0; s < P::KC; ++s)
+        for (int l = 0; l < 64; ++l) {
+          int j = 16 * jt + (l & 15), k = kmap(s, l >> 4);
+          idx[P::wc(i) + (jt * P::KC + s) * 64 + l] = F::fcw(i) + j * CD + k;
+        }
+    for (int kt = 0; kt < P::KTC; ++kt)
+      for (int s = 0; s < 8; ++s)
+        for (int l = 0; l < 64; ++l) {
+          int k = 16 * kt + (l & 15), j = kmap(s, l >> 4);
+          idx[P::wct(i) + (kt * 8 + s) * 64 + l] = F::fcw(i) + j * CD + k;
+        }
+    for (int j = 0; j < 32; ++j) {
+      idx[P::B + i * 32 + j] = F::pb(i) + j;
+      idx[P::BC + i * 32 + j] = F::fcb(i) + j;
+    }
+  }
+  for (int o = 0; o < OD; ++o) {
+    for (int j = 0; j < 32; ++j) idx[P::WOUT + o * 32 + j] = F::OW + o * 32 + j;
+    idx[P::BOUT + o] = F::OB + o;
+  }
+  for (int kt = 0; kt < 6; ++kt)
+    for (int s = 0; s < 8; ++s)
+      for (int l = 0; l < 64; ++l) {
+        int k = emapT(kt, l & 15), j = kmap(s, l >> 4);
+        if (k < kEmbK) {
+          idx[P::W0T + (kt * 8 + s) * 64 + l] = F::P0W + j * kEmbK + k;
+          idx[P::W3ET + (kt * 8 + s) * 64 + l] = F::P3W + j * (kEmbK + 32) + k;
+        }
+      }
+}
+
+void build_noxyz_index(int32_t* idx) {
+  using F = NoXyzFlat;
+  using P = NoXyzPack;
+  for (int i = 0; i < P::LEN; ++i) idx[i] = -1;
+  for (int i = 0; i < 5; ++i) {
+    const int ks = P::ks(i);
+    for (int jt = 0; jt < 2; ++jt)
+      for (int s = 0; s < ks; ++s)
+        for (int l = 0; l < 64; ++l) {
+          int j = 16 * jt + (l & 15);
+          int k = (s >= 8 ? 32 : 0) + kmap(s & 7, l >> 4);
+          idx[P::w(i) + (jt * ks + s) * 64 + l] = F::pw(i) + j * F::pstride(i) + k;
+        }
+    const int kts = (i == 3 ? 4 : 2);
+    for (int kt = 0; kt < kts; ++kt)
+      for (int s = 0; s < 8; ++s)
+        for (int l = 0; l < 64; ++l) {
+          int k = 16 * kt + (l & 15), j = kmap(s, l >> 4);
+          idx[P::wt(i) + (kt * 8 + s) * 64 + l] = F::pw(i) + j * F::pstride(i) + k;
+        }
+    for (int j = 0; j < 32; ++j) idx[P::B + i * 32 + j] = F::pb(i) + j;
+  }
+  for (int j = 0; j < 32; ++j) idx[P::WOUT + j] = F::OW + j;
+  idx[P::BOUT] = F::OB;
+}
+
+// ---------------------------------------------------------------------------
+// device: trilinear lookup (torch grid_sample bilinear/border/align_corners)
+// ---------------------------------------------------------------------------
+struct Tri {
+  int off[8];     // float offset of the 8 corners (cell * 32)
+  float w[8];     // corner weights, torch order tnw,tne,tsw,tse,bnw,bne,bsw,bse
+  float wa[3][2]; // per-axis weights (x,y,z)(lo,hi)
+  float mult[3];  // d(grid coord)/d(normalised coord), 0 when clipped
+  double inv[3];  // d(normalised)/d(world) = 2/(b1-b0)
+};
+
+__device__ __forceinline__ void axis_prepare(double p, double b0, double b1,
+                                             int N, int& i0, int& i1,
+                                             float& w0, float& w1,
+                                             float& mult, double& inv) {
+  const double ext = b1 - b0;
+  inv = 2.0 / ext;
+  float xn = (float)(((p - b0) / ext) * 2.0 - 1.0);
+  float ix = ((xn + 1.f) / 2.f) * (float)(N - 1);
+  float gm = (float)(N - 1) / 2.f;
+  const float mx = (float)(N - 1);
+  if (!(ix > 0.f)) {
+    ix = 0.f;
+    gm = 0.f;
+  } else if (ix >= mx) {
+    ix = mx;
+    gm = 0.f;
+  }
+  const float f = floorf(ix);
+  i0 = (int)f;
+  i1 = i0 + 1;
+  w1 = ix - f;
+  w0 = (f + 1.f) - ix;
+  if (i1 > N - 1) {  // torch skips the out-of-range corner (its weight is 0)
+    i1 = N - 1;
+    w1 = 0.f;
+  }
+  mult = gm;
+}
+
+__device__ __forceinline__ void tri_prepare(const double (&p)[3],
+                                            const double* bd, double scale,
+                                            const int* dim, Tri& t) {
+  const int Z = dim[0], Y = dim[1], X = dim[2];
+  int x0, x1, y0, y1, z0, z1;
+  axis_prepare(p[0], bd[0] * scale, bd[1] * scale, X, x0, x1, t.wa[0][0],
+               t.wa[0][1], t.mult[0], t.inv[0]);
+  axis_prepare(p[1], bd[2] * scale, bd[3] * scale, Y, y0, y1, t.wa[1][0],
+               t.wa[1][1], t.mult[1], t.inv[1]);
+  axis_prepare(p[2], bd[4] * scale, bd[5] * scale, Z, z0, z1, t.wa[2][0],
+               t.wa[2][1], t.mult[2], t.inv[2]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int xi = (c & 1) ? x1 : x0, yi = (c & 2) ? y1 : y0,
+              zi = (c & 4) ? z1 : z0;
+    t.off[c] = ((zi * Y + yi) * X + xi) * 32;
+    t.w[c] = (t.wa[0][c & 1] * t.wa[1][(c >> 1) & 1]) * t.wa[2][(c >> 2) & 1];
+  }
+}
+
+// gather the lane's 8 channels (16*kt + 4*q + r) of a 32-channel cell
+__device__ __forceinline__ void tri_gather(const float* __restrict__ grid,
+                                           const Tri& t, int q,
+                                           f32x4 (&c)[2]) {
+  c[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  c[1] = c[0];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(grid + t.off[k] + 4 * q);
+    const f32x4 b =
+        *reinterpret_cast<const f32x4*>(grid + t.off[k] + 16 + 4 * q);
+    c[0] += a * t.w[k];
+    c[1] += b * t.w[k];
+  }
+}
+
+// backward of one lookup: scatter gc into g_grid (atomics) and/or accumulate
+// d(loss)/d(world p) (summed over this lane's 8 channels only; the caller
+// reduces over the 4 lane groups).
+template <bool NEED_DP>
+__device__ __forceinline__ void tri_backward(const float* __restrict__ grid,
+                                             float* __restrict__ ggrid,
+                                             const Tri& t, int q,
+                                             const f32x4 (&gc)[2],
+                                             double (&gp)[3]) {
+  float gi[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (ggrid != nullptr && t.w[k] != 0.f) {
+      float* dst = ggrid + t.off[k] + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(dst + r, t.w[k] * gc[0][r]);
+        atomicAdd(dst + 16 + r, t.w[k] * gc[1][r]);
+      }
+    }
+    if (NEED_DP) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(grid + t.off[k] + 4 * q);
+      const f32x4 b =
+          *reinterpret_cast<const f32x4*>(grid + t.off[k] + 16 + 4 * q);
+      float dot = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot += a[r] * gc[0][r] + b[r] * gc[1][r];
+      const float sx = (k & 1) ? 1.f : -1.f, sy = (k & 2) ? 1.f : -1.f,
+                  sz = (k & 4) ? 1.f : -1.f;
+      // torch skips corners that were out of range; those have weight 0 on
+      // their own axis and the coordinate gradient multiplier is 0 there.
+      gi[0] += sx * dot * t.wa[1][(k >> 1) & 1] * t.wa[2][(k >> 2) & 1];
+      gi[1] += sy * dot * t.wa[0][k & 1] * t.wa[2][(k >> 2) & 1];
+      gi[2] += sz * dot * t.wa[0][k & 1] * t.wa[1][(k >> 1) & 1];
+    }
+  }
+  if (NEED_DP) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      gp[a] += (double)(t.mult[a] * gi[a]) * t.inv[a];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// device: MLP decoder forward (decoder_nice.py:207-234)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float embed_arg(const float (&p)[3], const f32x4 b) {
+  float a = p[0] * b[0];
+  a = fmaf(p[1], b[1], a);
+  a = fmaf(p[2], b[2], a);
+  return a;
+}
+
+template <int NT, int CD, int OD, bool SAVE_MASK, bool SAVE_H>
+__device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
+                                        const float (&p)[NT][3],
+                                        const f32x4 (&c)[NT][CD / 16],
+                                        float (&out)[NT][OD],
+                                        uint64_t (&mask)[NT],
+                                        f32x4 (&hs)[5][NT][2]) {
+  using P = MlpPack<CD, OD>;
+  const int q = lane >> 4;
+  f32x4 acc[NT][2], acc3[NT][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const f32x4 b0 =
+        *reinterpret_cast<const f32x4*>(pk + P::B + 0 * 32 + 16 * jt + 4 * q);
+    const f32x4 b3 =
+        *reinterpret_cast<const f32x4*>(pk + P::B + 3 * 32 + 16 * jt + 4 * q);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t][jt] = b0;
+      acc3[t][jt] = b3;
+    }
+  }
+  // Fourier embedding feeds layer 0 and the skip part of layer 3
+#pragma unroll 4
+  for (int s = 0; s < kEmbS; ++s) {
+    const f32x4 bk =
+        *reinterpret_cast<const f32x4*>(pk + P::EMB + emap(s, q) * 4);
+    float a0[2], a3[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      a0[jt] = pk[P::W0 + (jt * kEmbS + s) * 64 + lane];
+      a3[jt] = pk[P::W3E + (jt * kEmbS + s) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float e = sin_cw(embed_arg(p[t], bk));
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        acc[t][jt] = XRD_MFMA4(a0[jt], e, acc[t][jt]);
+        acc3[t][jt] = XRD_MFMA4(a3[jt], e, acc3[t][jt]);
+      }
+    }
+  }
+  f32x4 h[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mask[t] = 0;
+#pragma unroll 1
+  for (int i = 0; i < 5; ++i) {
+    // cc = fc_c[i](c)
+    f32x4 cc[NT][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x4 bc = *reinterpret_cast<const f32x4*>(pk + P::BC + i * 32 +
+                                                       16 * jt + 4 * q);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cc[t][jt] = bc;
+    }
+#pragma unroll
+    for (int s = 0; s < P::KC; ++s) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const float a = pk[P::wc(i) + (jt * P::KC + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          cc[t][jt] = XRD_MFMA4(a, c[t][s >> 2][s & 3], cc[t][jt]);
+      }
+      if ((s & 7) == 7) XRD_SB();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[t][jt][r];
+          if (SAVE_MASK && a > 0.f)
+            mask[t] |= (uint64_t)1 << (i * 8 + jt * 4 + r);
+          h[t][jt][r] = fmaxf(a, 0.f) + cc[t][jt][r];
+        }
+        if (SAVE_H) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (i == k) hs[k][t][jt] = h[t][jt];
+        }
+      }
+    if (i < 4) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(
+            pk + P::B + (i + 1) * 32 + 16 * jt + 4 * q);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t][jt] = (i + 1 == 3) ? acc3[t][jt] : b;
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const float a = pk[P::wh(i + 1) + (jt * 8 + s) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t][jt] = XRD_MFMA4(a, h[t][s >> 2][s & 3], acc[t][jt]);
+        }
+      }
+      XRD_SB();
+    }
+  }
+  // output layer on the VALU + reduction over the 4 lane groups
+#pragma unroll
+  for (int o = 0; o < OD; ++o) {
+    const f32x4 w0 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 4 * q);
+    const f32x4 w1 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 16 + 4 * q);
+    const float bo = pk[P::BOUT + o];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v += w0[r] * h[t][0][r] + w1[r] * h[t][1][r];
+      out[t][o] = group4_sum(v) + bo;
+    }
+  }
+}
+
+// MLP_no_xyz (coarse, decoder_nice.py:308-320): h=c; 5x(Linear+ReLU), skip
+// cat[c,h] after layer 2; Linear(32,1).
+template <int NT, bool SAVE_MASK>
+__device__ __forceinline__ void noxyz_fwd(const float* __restrict__ pk,
+                                          int lane, const f32x4 (&c)[NT][2],
+                                          float (&out)[NT],
+                                          uint64_t (&mask)[NT]) {
+  using P = NoXyzPack;
+  const int q = lane >> 4;
+  f32x4 h[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    h[t][0] = c[t][0];
+    h[t][1] = c[t][1];
+    mask[t] = 0;
+  }
+#pragma unroll 1
+  for (int i = 0; i < 5; ++i) {
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x4 b =
+          *reinterpret_cast<const f32x4*>(pk + P::B + i * 32 + 16 * jt + 4 * q);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][jt] = b;
+    }
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int ks = P::ks(i);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s < ks) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const float a = pk[P::w(i) + (jt * ks + s) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            // layer 3: K-steps 0..7 read c, 8..15 read h
+            const float b = (i == 3 && s < 8) ? c[t][(s & 7) >> 2][s & 3]
+                                              : h[t][(s & 7) >> 2][s & 3];
+            acc[t][jt] = XRD_MFMA4(a, b, acc[t][jt]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[t][jt][r];
+          if (SAVE_MASK && a > 0.f)
+            mask[t] |= (uint64_t)1 << (i * 8 + jt * 4 + r);
+          h[t][jt][r] = fmaxf(a, 0.f);
+        }
+  }
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(pk + P::WOUT + 4 * q);
+  const f32x4 w1 = *reinterpret_cast<const f32x4*>(pk + P::WOUT + 16 + 4 * q);
+  const float bo = pk[P::BOUT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v += w0[r] * h[t][0][r] + w1[r] * h[t][1][r];
+    out[t] = group4_sum(v) + bo;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// device: MLP decoder backward
+// ---------------------------------------------------------------------------
+// per-wave LDS scratch used by the weight-gradient path
+struct DwLds {
+  float* G;    // [32][PTS] transposed gradient tile
+  float* H;    // [32][PTS] transposed layer input
+  float* C;    // [32][PTS] transposed grid features
+  float* ps;   // [64][4]   f32 sample positions
+  float* acc;  // block accumulator, flat layout (shared by the 4 waves)
+};
+
+template <int NT>
+__device__ __forceinline__ void lds_put(float* dst, int lane,
+                                        const f32x4 (&v)[NT][2]) {
+  const int q = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dst[(16 * jt + 4 * q + r) * PTS + 16 * t + i] = v[t][jt][r];
+}
+
+// acc[base + j*stride + k] += sum_pts G[j][pt] * Hin[k][pt]  (32x32 block)
+template <int NT>
+__device__ __forceinline__ void dw_block(const float* G, const float* Hin,
+                                         float* acc, int base, int stride,
+                                         int lane) {
+  const int q = lane >> 4, m = lane & 15;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NT * 4; ++s)
+        d = XRD_MFMA4(G[(16 * jt + m) * PTS + 4 * s + q],
+                      Hin[(16 * kt + m) * PTS + 4 * s + q], d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(acc + base + (16 * jt + 4 * q + r) * stride + 16 * kt + m,
+                  d[r]);
+    }
+}
+
+template <int NT, int CD, int OD, bool NEED_E, bool NEED_DP, bool NEED_DW>
+__device__ __forceinline__ void mlp_bwd(
+    const float* __restrict__ pk, int lane, const float (&p)[NT][3],
+    const f32x4 (&c)[NT][CD / 16], const float (&gout)[NT][OD],
+    const uint64_t (&mask)[NT], const f32x4 (&hs)[5][NT][2],
+    f32x4 (&gc)[NT][CD / 16], float (&gp)[NT][3], const DwLds& L) {
+  using P = MlpPack<CD, OD>;
+  using F = MlpFlat<CD, OD>;
+  static_assert(!NEED_DW || CD == 32, "weight grads: c_dim 32 decoders only");
+  const int q = lane >> 4, m = lane & 15;
+  f32x4 gh[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    gh[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gh[t][1] = gh[t][0];
+#pragma unroll
+    for (int kt = 0; kt < CD / 16; ++kt) gc[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int o = 0; o < OD; ++o) {
+    const f32x4 w0 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 4 * q);
+    const f32x4 w1 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 16 + 4 * q);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      gh[t][0] += w0 * gout[t][o];
+      gh[t][1] += w1 * gout[t][o];
+    }
+    if (NEED_DW) {
+      // d output_linear.weight[o][j], d bias[o]
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      float sb = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        s0 += hs[4][t][0] * gout[t][o];
+        s1 += hs[4][t][1] * gout[t][o];
+        sb += gout[t][o];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = row16_sum(s0[r]), v1 = row16_sum(s1[r]);
+        if (m == 0) {
+          atomicAdd(L.acc + F::OW + o * 32 + 4 * q + r, v0);
+          atomicAdd(L.acc + F::OW + o * 32 + 16 + 4 * q + r, v1);
+        }
+      }
+      sb = row16_sum(sb);
+      if (lane == 0) atomicAdd(L.acc + F::OB + o, sb);
+    }
+  }
+  f32x4 ge[NT][NEED_E ? 6 : 1];
+  if (NEED_E) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt) ge[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (NEED_DW) {
+    // transposed grid features for d fc_c.weight
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          L.C[(16 * kt + 4 * q + r) * PTS + 16 * t + (lane & 15)] =
+              c[t][kt][r];
+  }
+#pragma unroll 1
+  for (int i = 4; i >= 0; --i) {
+    f32x4 ga[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ga[t][jt][r] = ((mask[t] >> (i * 8 + jt * 4 + r)) & 1)
+                             ? gh[t][jt][r]
+                             : 0.f;
+    if (NEED_DW) {
+      // bias grads: sum over points
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = 0.f, sa = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            sc += gh[t][jt][r];
+            sa += ga[t][jt][r];
+          }
+          sc = row16_sum(sc);
+          sa = row16_sum(sa);
+          if (m == 0) {
+            atomicAdd(L.acc + F::fcb(i) + 16 * jt + 4 * q + r, sc);
+            atomicAdd(L.acc + F::pb(i) + 16 * jt + 4 * q + r, sa);
+          }
+        }
+      // d fc_c[i].weight = gh (x) c
+      wave_lds_sync();
+      lds_put<NT>(L.G, lane, gh);
+      wave_lds_sync();
+      dw_block<NT>(L.G, L.C, L.acc, F::fcw(i), CD, lane);
+      wave_lds_sync();
+      lds_put<NT>(L.G, lane, ga);
+      if (i >= 1) {
+        f32x4 hp[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            hp[t][jt] = hs[0][t][jt];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+              if (i - 1 == k) hp[t][jt] = hs[k][t][jt];
+          }
+        lds_put<NT>(L.H, lane, hp);
+      }
+      wave_lds_sync();
+      if (i >= 1)
+        dw_block<NT>(L.G, L.H, L.acc, F::pw(i) + F::pcol(i), F::pstride(i),
+                     lane);
+      if (i == 3 || i == 0) {
+        // d W[:, :93] = ga (x) sin(p B): recompute the embedding directly in
+        // B-operand layout (point 4s+q, feature 16kt+m)
+        const int wbase = (i == 0) ? F::P0W : F::P3W;
+        const int wstride = (i == 0) ? kEmbK : kEmbK + 32;
+#pragma unroll 1
+        for (int kt = 0; kt < 6; ++kt) {
+          const int k = 16 * kt + m;
+          const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
+          f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+          for (int s = 0; s < NT * 4; ++s) {
+            const f32x4 pp =
+                *reinterpret_cast<const f32x4*>(L.ps + (4 * s + q) * 4);
+            const float pv[3] = {pp[0], pp[1], pp[2]};
+            const float e = sin_cw(embed_arg(pv, bk));
+            d0 = XRD_MFMA4(L.G[m * PTS + 4 * s + q], e, d0);
+            d1 = XRD_MFMA4(L.G[(16 + m) * PTS + 4 * s + q], e, d1);
+          }
+          if (k < kEmbK) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              atomicAdd(L.acc + wbase + (4 * q + r) * wstride + k, d0[r]);
+              atomicAdd(L.acc + wbase + (16 + 4 * q + r) * wstride + k, d1[r]);
+            }
+          }
+        }
+      }
+    }
+    // g_c += Wc_i^T gh
+#pragma unroll
+    for (int kt = 0; kt < P::KTC; ++kt)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float a = pk[P::wct(i) + (kt * 8 + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          gc[t][kt] = XRD_MFMA4(a, gh[t][s >> 2][s & 3], gc[t][kt]);
+        if (s == 7) XRD_SB();
+      }
+    if (NEED_E && (i == 3 || i == 0)) {
+      const int base = (i == 3) ? P::W3ET : P::W0T;
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float a = pk[base + (kt * 8 + s) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            ge[t][kt] = XRD_MFMA4(a, ga[t][s >> 2][s & 3], ge[t][kt]);
+          if (s == 7) XRD_SB();
+        }
+    }
+    if (i >= 1) {
+      f32x4 gprev[NT][2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        gprev[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gprev[t][1] = gprev[t][0];
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float a = pk[P::wht(i) + (kt * 8 + s) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            gprev[t][kt] = XRD_MFMA4(a, ga[t][s >> 2][s & 3], gprev[t][kt]);
+          if (s == 7) XRD_SB();
+        }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        gh[t][0] = gprev[t][0];
+        gh[t][1] = gprev[t][1];
+      }
+    }
+  }
+  if (NEED_E) {
+    // through sin(p.B): lane group q owns feature k = emap(4kt+r, q)
+#pragma unroll
+    for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = emap(4 * kt + r, q);
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
+        float db[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float garg = ge[t][kt][r] * cos_cw(embed_arg(p[t], bk));
+          if (NEED_DP) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gp[t][a] += garg * bk[a];
+          }
+          if (NEED_DW) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) db[a] += garg * p[t][a];
+          }
+        }
+        if (NEED_DW) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float v = row16_sum(db[a]);
+            if (m == 0 && k < kEmbK) atomicAdd(L.acc + F::EB + a * kEmbK + k, v);
+          }
+        }
+        XRD_SB();  // keep the inlined cosf bodies from being interleaved
+      }
+  }
+}
+
+// coarse decoder backward: only d/d(c) is needed (grid_coarse is the only
+// parameter optimised in the coarse stage; no pose gradient, no decoder grads)
+template <int NT>
+__device__ __forceinline__ void noxyz_bwd(const float* __restrict__ pk,
+                                          int lane, const float (&gout)[NT],
+                                          const uint64_t (&mask)[NT],
+                                          f32x4 (&gc)[NT][2]) {
+  using P = NoXyzPack;
+  const int q = lane >> 4;
+  f32x4 gh[NT][2];
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(pk + P::WOUT + 4 * q);
+  const f32x4 w1 = *reinterpret_cast<const f32x4*>(pk + P::WOUT + 16 + 4 * q);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    gh[t][0] = w0 * gout[t];
+    gh[t][1] = w1 * gout[t];
+    gc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gc[t][1] = gc[t][0];
+  }
+#pragma unroll 1
+  for (int i = 4; i >= 0; --i) {
+    f32x4 ga[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ga[t][jt][r] = ((mask[t] >> (i * 8 + jt * 4 + r)) & 1)
+                             ? gh[t][jt][r]
+                             : 0.f;
+    f32x4 gprev[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      gprev[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gprev[t][1] = gprev[t][0];
+    }
+    // layer 3: tiles 0,1 -> c part, tiles 2,3 -> h part
+    const int kts = (i == 3) ? 4 : 2;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt < kts) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float a = pk[P::wt(i) + (kt * 8 + s) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (i == 3 && kt < 2)
+              gc[t][kt] = XRD_MFMA4(a, ga[t][s >> 2][s & 3], gc[t][kt]);
+            else
+              gprev[t][kt & 1] =
+                  XRD_MFMA4(a, ga[t][s >> 2][s & 3], gprev[t][kt & 1]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      gh[t][0] = gprev[t][0];
+      gh[t][1] = gprev[t][1];
+    }
+  }
+  // layer 0 consumes c directly
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    gc[t][0] += gh[t][0];
+    gc[t][1] += gh[t][1];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-ray sampling (conv_onet.py:391-484)
+// ---------------------------------------------------------------------------
+struct RayCtx {
+  float o[3], d[3];
+  float gd;     // sensor depth of the ray (0 = invalid)
+  bool has_d;   // depth-guided sampling active
+};
+
+// returns this lane's sorted z (lane < S) through LDS arrays zu/zs [64]
+template <int S>
+__device__ __forceinline__ double sample_z(const xrd_nice_scene& sc,
+                                           const RayCtx& rc, float dmax,
+                                           int lane, double* zu, double* zs) {
+  double far = 1e300;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double t0 = (sc.bound[2 * a] - (double)rc.o[a]) / (double)rc.d[a];
+    const double t1 = (sc.bound[2 * a + 1] - (double)rc.o[a]) / (double)rc.d[a];
+    far = fmin(far, fmax(t0, t1));
+  }
+  far += 0.01;
+  if (rc.has_d) far = fmin(fmax(far, 0.0), (double)(dmax * 1.2f));
+  const int nu = sc.n_samples;
+  double z = 1e300;
+  if (lane < nu) {
+    const float nearf = rc.has_d ? rc.gd * 0.01f : 0.01f;
+    const float tv = sc.t_uniform[lane];
+    z = (double)(nearf * (1.f - tv)) + far * (double)tv;
+  } else if (lane < S) {
+    const double ts = sc.t_surface[lane - nu];
+    if (rc.gd > 0.f)
+      z = (double)(0.95f * rc.gd) * (1.0 - ts) + (double)(1.05f * rc.gd) * ts;
+    else
+      z = 0.001 * (1.0 - ts) + (double)dmax * ts;
+  }
+  zu[lane] = z;
+  wave_lds_sync();
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < S; ++j) {
+    const double zj = zu[j];
+    rank += (zj < z || (zj == z && j < lane)) ? 1 : 0;
+  }
+  if (lane < S) zs[rank] = z;
+  wave_lds_sync();
+  return lane < S ? zs[lane] : 0.0;
+}
+
+__device__ __forceinline__ bool in_bound(const double (&p)[3],
+                                         const double* bd) {
+  return p[0] < bd[1] && p[0] > bd[0] && p[1] < bd[3] && p[1] > bd[2] &&
+         p[2] < bd[5] && p[2] > bd[4];
+}
+
+template <int NT>
+__device__ __forceinline__ float pick_tile(const float (&v)[NT], int q) {
+  float r = v[0];
+#pragma unroll
+  for (int t = 1; t < NT; ++t) r = (q == t) ? v[t] : r;
+  return r;
+}
+
+
+// ---------------------------------------------------------------------------
+// kernels: one wave = one 16-sample tile of one ray; a block holds RPB rays
+// (RPB*NT waves).  Waves of a ray meet in LDS for the compositing scan.
+// ---------------------------------------------------------------------------
+constexpr int RPB = 2;   // rays per block (forward)
+constexpr int RPBB = 1;  // rays per block (backward: register heavy)
+constexpr int kColorFlat = MlpFlat<32, 4>::LEN;
+constexpr int kMaxBwdBlocks = 1024;
+
+struct TileGeom {
+  double p64[3];
+  float p32[3];
+  double z;
+  bool inb;
+};
+
+__device__ __forceinline__ void tile_geom(const RayCtx& rc, double z,
+                                          const double* bd, TileGeom& g) {
+  g.z = z;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    g.p64[a] = (double)rc.o[a] + (double)rc.d[a] * z;
+    g.p32[a] = (float)g.p64[a];
+  }
+  g.inb = in_bound(g.p64, bd);
+}
+
+__device__ __forceinline__ void load_ray(const float* __restrict__ rays_o,
+                                         const float* __restrict__ rays_d,
+                                         const float* __restrict__ gt_depth,
+                                         int ray, bool use_depth, RayCtx& rc) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    rc.o[a] = rays_o[ray * 3 + a];
+    rc.d[a] = rays_d[ray * 3 + a];
+  }
+  rc.has_d = use_depth;
+  rc.gd = use_depth ? gt_depth[ray] : 0.f;
+}
+
+template <int STAGE, int NT>
+__global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ dmax_p, double* __restrict__ depth,
+    double* __restrict__ var, float* __restrict__ rgb,
+    float* __restrict__ raw_out) {
+  constexpr int S = NT * 16;
+  constexpr int NW = RPB * NT;
+  __shared__ double zbuf[NW][2][64];
+  __shared__ __attribute__((aligned(16))) float rawbuf[RPB][64][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  const int slot = wave / NT, tile = wave % NT;
+  const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * RPB + slot);
+  const bool active = ray < n;
+  const bool use_depth = (gt_depth != nullptr) && STAGE != XRD_STAGE_COARSE;
+  double zl = 0.0;
+  if (active) {
+    RayCtx rc;
+    load_ray(rays_o, rays_d, gt_depth, ray, use_depth, rc);
+    const float dmax = use_depth ? dmax_p[0] : 0.f;
+    zl = sample_z<S>(sc, rc, dmax, lane, zbuf[wave][0], zbuf[wave][1]);
+    TileGeom tg;
+    tile_geom(rc, zbuf[wave][1][16 * tile + li], sc.bound, tg);
+    const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
+    float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
+    uint64_t mdummy[1];
+    f32x4 hdummy[5][1][2];
+    Tri tr;
+    if (STAGE == XRD_STAGE_COARSE) {
+      f32x4 c_a[1][2];
+      float o1[1];
+      tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+      tri_gather(sc.grid[0], tr, q, c_a[0]);
+      noxyz_fwd<1, false>(sc.dec[0], lane, c_a, o1, mdummy);
+      occ = o1[0];
+    } else {
+      f32x4 c_m[1][2];
+      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+      tri_gather(sc.grid[1], tr, q, c_m[0]);
+      {
+        float om[1][1];
+        mlp_fwd<1, 32, 1, false, false>(sc.dec[1], lane, p32, c_m, om, mdummy,
+                                        hdummy);
+        occ = om[0][0];
+      }
+      if (STAGE >= XRD_STAGE_FINE) {
+        f32x4 c_f[1][4], cf[2];
+        float of[1][1];
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        tri_gather(sc.grid[2], tr, q, cf);
+        c_f[0][0] = cf[0];
+        c_f[0][1] = cf[1];
+        c_f[0][2] = c_m[0][0];
+        c_f[0][3] = c_m[0][1];
+        mlp_fwd<1, 64, 1, false, false>(sc.dec[2], lane, p32, c_f, of, mdummy,
+                                        hdummy);
+        occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
+      }
+      if (STAGE == XRD_STAGE_COLOR) {
+        f32x4 c_c[1][2];
+        float oc[1][4];
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        tri_gather(sc.grid[3], tr, q, c_c[0]);
+        mlp_fwd<1, 32, 4, false, false>(sc.dec[3], lane, p32, c_c, oc, mdummy,
+                                        hdummy);
+        col[0] = oc[0][0];
+        col[1] = oc[0][1];
+        col[2] = oc[0][2];
+      }
+    }
+    if (!tg.inb) occ = 100.f;  // conv_onet.py:370
+    if (q == 0)
+      *reinterpret_cast<f32x4*>(&rawbuf[slot][16 * tile + li][0]) =
+          f32x4{col[0], col[1], col[2], occ};
+  }
+  __syncthreads();
+  if (!active || tile != 0) return;
+  // compositing: lane l (< S) is sample l of the ray
+  const bool valid = lane < S;
+  f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+  if (valid) rw = *reinterpret_cast<const f32x4*>(&rawbuf[slot][lane][0]);
+  if (raw_out != nullptr && valid)
+    *reinterpret_cast<f32x4*>(raw_out + ((size_t)ray * S + lane) * 4) = rw;
+  const float alpha = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
+  const float f = valid ? (1.f - alpha + 1e-10f) : 1.f;
+  float incl = f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float u = __shfl_up(incl, o);
+    if (lane >= o) incl *= u;
+  }
+  float T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.f;
+  const float w = alpha * T;
+  const float R = wave_sum(w * rw[0]), G = wave_sum(w * rw[1]),
+              B = wave_sum(w * rw[2]);
+  const double dep = wave_sum(valid ? (double)w * zl : 0.0);
+  const double tmp = zl - dep;
+  const double vr = wave_sum(valid ? (double)w * tmp * tmp : 0.0);
+  if (lane == 0) {
+    depth[ray] = dep;
+    var[ray] = vr;
+    rgb[ray * 3 + 0] = R;
+    rgb[ray * 3 + 1] = G;
+    rgb[ray * 3 + 2] = B;
+  }
+}
+
+template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
+__global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ dmax_p, const float* __restrict__ raw,
+    const double* __restrict__ g_depth, const double* __restrict__ g_var,
+    const float* __restrict__ g_rgb, float* __restrict__ g_rays_o,
+    float* __restrict__ g_rays_d, float* gg_coarse, float* gg_middle,
+    float* gg_fine, float* gg_color, float* __restrict__ ws) {
+  constexpr int S = NT * 16;
+  constexpr int NW = RPBB * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  const int slot = wave / NT, tile = wave % NT;
+  // LDS carve-up: [NW][128] f64 z | [NW][8] f64 ray-grad partials |
+  //               [NW][64] f32 ps | [NW][3][32][PTS] f32 dW tiles | acc
+  double* zbuf = reinterpret_cast<double*>(smem_raw) + wave * 128;
+  double* gpart = reinterpret_cast<double*>(smem_raw) + NW * 128;
+  float* fbase = reinterpret_cast<float*>(gpart + NW * 8);
+  DwLds L;
+  L.ps = fbase + wave * 64;
+  float* fdw = fbase + NW * 64;
+  L.G = fdw + wave * (3 * 32 * PTS);
+  L.H = L.G + 32 * PTS;
+  L.C = L.H + 32 * PTS;
+  L.acc = fdw + NW * (3 * 32 * PTS);
+  if (NEED_DW) {
+    for (int i = threadIdx.x; i < kColorFlat; i += NW * 64) L.acc[i] = 0.f;
+    __syncthreads();
+  }
+  const bool use_depth = (gt_depth != nullptr) && STAGE != XRD_STAGE_COARSE;
+  const int ngroups = (n + RPBB - 1) / RPBB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * RPBB + slot);
+    const bool active = ray < n;
+    double gsum[6] = {0, 0, 0, 0, 0, 0};
+    if (active) {
+      RayCtx rc;
+      load_ray(rays_o, rays_d, gt_depth, ray, use_depth, rc);
+      const float dmax = use_depth ? dmax_p[0] : 0.f;
+      const double zl = sample_z<S>(sc, rc, dmax, lane, zbuf, zbuf + 64);
+      const bool valid = lane < S;
+      // ---- compositing backward (utils.py:189-244) from the saved raw ----
+      f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+      if (valid)
+        rw = *reinterpret_cast<const f32x4*>(raw +
+                                             ((size_t)ray * S + lane) * 4);
+      const float alpha = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
+      const float f = valid ? (1.f - alpha + 1e-10f) : 1.f;
+      float incl = f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(incl, o);
+        if (lane >= o) incl *= u;
+      }
+      float T = __shfl_up(incl, 1);
+      if (lane == 0) T = 1.f;
+      const float w = alpha * T;
+      const double dep = wave_sum(valid ? (double)w * zl : 0.0);
+      const double tmp = zl - dep;
+      const double gd_in = g_depth ? g_depth[ray] : 0.0;
+      const double gv_in = g_var ? g_var[ray] : 0.0;
+      float grgb[3] = {0.f, 0.f, 0.f};
+      if (g_rgb) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) grgb[a] = g_rgb[ray * 3 + a];
+      }
+      const double sw_tmp = wave_sum(valid ? (double)w * tmp : 0.0);
+      const double gdep = gd_in - 2.0 * gv_in * sw_tmp;
+      float gw = 0.f;
+      if (valid)
+        gw = (float)(gdep * zl) + (float)(gv_in * tmp * tmp) +
+             (grgb[0] * rw[0] + grgb[1] * rw[1] + grgb[2] * rw[2]);
+      float suf = valid ? gw * w : 0.f;  // inclusive suffix sum of gw*w
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_down(suf, o);
+        if (lane + o < 64) suf += u;
+      }
+      float sexc = __shfl_down(suf, 1);
+      if (lane == 63) sexc = 0.f;
+      const float galpha = valid ? (gw * T - sexc / f) : 0.f;
+      const float gocc_s = galpha * 10.f * alpha * (1.f - alpha);
+      // ---- this wave's tile ---------------------------------------------
+      const int src = 16 * tile + li;
+      TileGeom tg;
+      tile_geom(rc, zbuf[64 + src], sc.bound, tg);
+      float gocc = __shfl(gocc_s, src);
+      if (!tg.inb) gocc = 0.f;  // occupancy was overridden to 100
+      const float wsrc = __shfl(w, src);
+      const float gcol[3] = {grgb[0] * wsrc, grgb[1] * wsrc, grgb[2] * wsrc};
+      const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
+      if (NEED_DW && q == 0)
+        *reinterpret_cast<f32x4*>(L.ps + li * 4) =
+            f32x4{tg.p32[0], tg.p32[1], tg.p32[2], 0.f};
+      double gp64[3] = {0.0, 0.0, 0.0};
+      float gp32[1][3] = {{0.f, 0.f, 0.f}};
+      uint64_t mask[1];
+      f32x4 hdummy[5][1][2];
+      Tri tr;
+      if (STAGE == XRD_STAGE_COARSE) {
+        f32x4 c_a[1][2], gc[1][2];
+        float o1[1];
+        const float go[1] = {gocc};
+        tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+        tri_gather(sc.grid[0], tr, q, c_a[0]);
+        noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
+        noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
+        tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+        tri_backward<NEED_DP>(sc.grid[0], gg_coarse, tr, q, gc[0], gp64);
+      } else {
+        f32x4 c_m[1][2];
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+        tri_gather(sc.grid[1], tr, q, c_m[0]);
+        {
+          float om[1][1];
+          const float go[1][1] = {{gocc}};
+          f32x4 gc[1][2];
+          mlp_fwd<1, 32, 1, true, false>(sc.dec[1], lane, p32, c_m, om, mask,
+                                         hdummy);
+          mlp_bwd<1, 32, 1, NEED_DP, NEED_DP, false>(
+              sc.dec[1], lane, p32, c_m, go, mask, hdummy, gc, gp32, L);
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+          tri_backward<NEED_DP>(sc.grid[1], gg_middle, tr, q, gc[0], gp64);
+        }
+        if (STAGE >= XRD_STAGE_FINE) {
+          f32x4 c_f[1][4], gc[1][4], cf[2];
+          float of[1][1];
+          const float go[1][1] = {{gocc}};
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+          tri_gather(sc.grid[2], tr, q, cf);
+          c_f[0][0] = cf[0];
+          c_f[0][1] = cf[1];
+          c_f[0][2] = c_m[0][0];
+          c_f[0][3] = c_m[0][1];
+          mlp_fwd<1, 64, 1, true, false>(sc.dec[2], lane, p32, c_f, of, mask,
+                                         hdummy);
+          mlp_bwd<1, 64, 1, NEED_DP, NEED_DP, false>(
+              sc.dec[2], lane, p32, c_f, go, mask, hdummy, gc, gp32, L);
+          const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+          tri_backward<NEED_DP>(sc.grid[2], gg_fine, tr, q, g2, gp64);
+        }
+        if (STAGE == XRD_STAGE_COLOR) {
+          f32x4 c_c[1][2], gc[1][2];
+          f32x4 hs[5][1][2];
+          float oc[1][4];
+          // channel 3 is overwritten by fine+middle occupancy -> no gradient
+          const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+          tri_gather(sc.grid[3], tr, q, c_c[0]);
+          mlp_fwd<1, 32, 4, true, NEED_DW>(sc.dec[3], lane, p32, c_c, oc, mask,
+                                           hs);
+          mlp_bwd<1, 32, 4, (NEED_DP || NEED_DW), NEED_DP, NEED_DW>(
+              sc.dec[3], lane, p32, c_c, go, mask, hs, gc, gp32, L);
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+          tri_backward<NEED_DP>(sc.grid[3], gg_color, tr, q, gc[0], gp64);
+        }
+      }
+      if (NEED_DP) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const double g = gp64[a] + (double)gp32[0][a];
+          gsum[a] = wave_sum(g);
+          gsum[3 + a] = wave_sum(g * tg.z);
+        }
+      }
+    }
+    if (NEED_DP) {
+      // deterministic sum over the NT waves of the ray
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) gpart[wave * 8 + a] = gsum[a];
+      }
+      __syncthreads();
+      if (active && tile == 0 && lane < 6) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s += gpart[(wave + t) * 8 + lane];
+        if (lane < 3)
+          g_rays_o[ray * 3 + lane] = (float)s;
+        else
+          g_rays_d[ray * 3 + lane - 3] = (float)s;
+      }
+      __syncthreads();
+    }
+  }
+  if (NEED_DW) {
+    __syncthreads();
+    float* dst = ws + (size_t)blockIdx.x * kColorFlat;
+    for (int i = threadIdx.x; i < kColorFlat; i += NW * 64) dst[i] = L.acc[i];
+  }
+}
+
+
+__global__ void reduce_partials_kernel(const float* __restrict__ ws, int nb,
+                                       int len, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += ws[(size_t)b * len + i];
+  out[i] = s;
+}
+
+__global__ void mfma_selftest_kernel(const float* a, const float* b,
+                                     float* out) {
+  const int l = threadIdx.x;
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  d = XRD_MFMA4(a[(l & 15) * 4 + (l >> 4)], b[(l >> 4) * 16 + (l & 15)], d);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[((l >> 4) * 4 + r) * 16 + (l & 15)] = d[r];
+}
+
+size_t bwd_lds_bytes(int nt, bool dw) {
+  const size_t nw = (size_t)RPBB * nt;
+  size_t b = nw * 128 * sizeof(double) + nw * 8 * sizeof(double) +
+             nw * 64 * sizeof(float);
+  if (dw) b += (nw * 3 * 32 * PTS + kColorFlat) * sizeof(float);
+  return b;
+}
+
+}  // namespace
+}  // namespace xrd
+
+using namespace xrd;
+
+extern "C" {
+
+int xrd_nice_flat_len(int kind) {
+  switch (kind) {
+    case XRD_DEC_COARSE: return NoXyzFlat::LEN;
+    case XRD_DEC_MIDDLE: return MlpFlat<32, 1>::LEN;
+    case XRD_DEC_FINE: return MlpFlat<64, 1>::LEN;
+    case XRD_DEC_COLOR: return MlpFlat<32, 4>::LEN;
+  }
+  return -1;
+}
+
+int xrd_nice_pack_len(int kind) {
+  switch (kind) {
+    case XRD_DEC_COARSE: return NoXyzPack::LEN;
+    case XRD_DEC_MIDDLE: return MlpPack<32, 1>::LEN;
+    case XRD_DEC_FINE: return MlpPack<64, 1>::LEN;
+    case XRD_DEC_COLOR: return MlpPack<32, 4>::LEN;
+  }
+  return -1;
+}
+
+int xrd_nice_pack_index(int kind, int32_t* idx) {
+  if (idx == nullptr) return XRD_ERR_ARG;
+  switch (kind) {
+    case XRD_DEC_COARSE: build_noxyz_index(idx); return XRD_OK;
+    case XRD_DEC_MIDDLE: build_mlp_index<32, 1>(idx); return XRD_OK;
+    case XRD_DEC_FINE: build_mlp_index<64, 1>(idx); return XRD_OK;
+    case XRD_DEC_COLOR: build_mlp_index<32, 4>(idx); return XRD_OK;
+  }
+  return XRD_ERR_ARG;
+}
+
+static int nice_check(const xrd_nice_scene* sc, int stage, int n,
+                      const float* gt_depth, int* nt) {
+  if (sc == nullptr || n < 0 || stage < 0 || stage > 3) return XRD_ERR_ARG;
+  const bool has_d = gt_depth != nullptr && stage != XRD_STAGE_COARSE;
+  const int S = sc->n_samples + (has_d ? sc->n_surface : 0);
+  if (S != 32 && S != 48) return XRD_ERR_UNSUPPORTED;
+  if (sc->t_uniform == nullptr || (has_d && sc->n_surface > 0 &&
+                                   sc->t_surface == nullptr))
+    return XRD_ERR_ARG;
+  const int need[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 1, 1, 0}, {0, 1, 1, 1}};
+  for (int g = 0; g < 4; ++g)
+    if (need[stage][g] && (sc->grid[g] == nullptr || sc->dec[g] == nullptr))
+      return XRD_ERR_ARG;
+  *nt = S / 16;
+  return XRD_OK;
+}
+
+#define FWD_CASE(ST, NTV)                                                     \
+  hipLaunchKernelGGL((nice_fwd_kernel<ST, NTV>),                              \
+                     dim3((n_rays + RPB - 1) / RPB), dim3(RPB * NTV * 64), 0, st, *scene, n_rays, rays_o, rays_d,        \
+                     gt_depth, dmax, depth, var, rgb, raw_out)
+
+int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        double* depth, double* var, float* rgb, float* raw_out,
+                        xrd_stream_t stream) {
+  int nt = 0;
+  int rc = nice_check(scene, stage, n_rays, gt_depth, &nt);
+  if (rc != XRD_OK) return rc;
+  if (!rays_o || !rays_d || !depth || !var || !rgb) return XRD_ERR_ARG;
+  if (gt_depth && stage != XRD_STAGE_COARSE && !dmax) return XRD_ERR_ARG;
+  if (n_rays == 0) return XRD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (stage == XRD_STAGE_COARSE) gt_depth = nullptr;
+  switch (stage * 4 + nt) {
+    case XRD_STAGE_COARSE * 4 + 2: FWD_CASE(XRD_STAGE_COARSE, 2); break;
+    case XRD_STAGE_MIDDLE * 4 + 2: FWD_CASE(XRD_STAGE_MIDDLE, 2); break;
+    case XRD_STAGE_MIDDLE * 4 + 3: FWD_CASE(XRD_STAGE_MIDDLE, 3); break;
+    case XRD_STAGE_FINE * 4 + 2: FWD_CASE(XRD_STAGE_FINE, 2); break;
+    case XRD_STAGE_FINE * 4 + 3: FWD_CASE(XRD_STAGE_FINE, 3); break;
+    case XRD_STAGE_COLOR * 4 + 2: FWD_CASE(XRD_STAGE_COLOR, 2); break;
+    case XRD_STAGE_COLOR * 4 + 3: FWD_CASE(XRD_STAGE_COLOR, 3); break;
+    default: return XRD_ERR_UNSUPPORTED;
+  }
+  return check_launch("xrd_nice_render_fwd");
+}
+
+int64_t xrd_nice_bwd_ws_floats(int n_rays) {
+  int nb = (n_rays + RPBB - 1) / RPBB;
+  if (nb > kMaxBwdBlocks) nb = kMaxBwdBlocks;
+  if (nb < 1) nb = 1;
+  return (int64_t)nb * kColorFlat;
+}
+
+}  // extern "C"
+
+template <int ST, int NTV, bool DP, bool DW>
+static int launch_bwd(const xrd_nice_scene* scene, int n, const float* rays_o,
+                      const float* rays_d, const float* gt_depth,
+                      const float* dmax, const float* raw,
+                      const double* g_depth, const double* g_var,
+                      const float* g_rgb, float* g_rays_o, float* g_rays_d,
+                      float* const g_grid[4], float* ws, int nb,
+                      hipStream_t st) {
+  auto kern = nice_bwd_kernel<ST, NTV, DP, DW>;
+  const size_t lds = bwd_lds_bytes(NTV, DW);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(RPBB * NTV * 64), lds, st, *scene, n, rays_o,
+                     rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb,
+                     g_rays_o, g_rays_d, g_grid[0], g_grid[1], g_grid[2],
+                     g_grid[3], ws);
+  return check_launch("xrd_nice_render_bwd");
+}
+
+#define BWD_CASE(ST, NTV, DP, DW)                                             \
+  return launch_bwd<ST, NTV, DP, DW>(scene, n_rays, rays_o, rays_d, gt_depth, \
+                                     dmax, raw, g_depth, g_var, g_rgb,        \
+                                     g_rays_o, g_rays_d, gg, ws, nb, st)
+
+static int bwd_dispatch(const xrd_nice_scene* scene, int stage, int nt,
+                        bool dp, bool dw, int n_rays, const float* rays_o,
+                        const float* rays_d, const float* gt_depth,
+                        const float* dmax, const float* raw,
+                        const double* g_depth, const double* g_var,
+                        const float* g_rgb, float* g_rays_o, float* g_rays_d,
+                        float* const gg[4], float* ws, int nb, hipStream_t st) {
+  if (stage == XRD_STAGE_COARSE) {
+    if (nt != 2) return XRD_ERR_UNSUPPORTED;
+    BWD_CASE(XRD_STAGE_COARSE, 2, false, false);
+  }
+  if (stage == XRD_STAGE_MIDDLE) {
+    if (nt == 3) {
+      if (dp) BWD_CASE(XRD_STAGE_MIDDLE, 3, true, false);
+      BWD_CASE(XRD_STAGE_MIDDLE, 3, false, false);
+    }
+    if (dp) BWD_CASE(XRD_STAGE_MIDDLE, 2, true, false);
+    BWD_CASE(XRD_STAGE_MIDDLE, 2, false, false);
+  }
+  if (stage == XRD_STAGE_FINE) {
+    if (nt == 3) {
+      if (dp) BWD_CASE(XRD_STAGE_FINE, 3, true, false);
+      BWD_CASE(XRD_STAGE_FINE, 3, false, false);
+    }
+    if (dp) BWD_CASE(XRD_STAGE_FINE, 2, true, false);
+    BWD_CASE(XRD_STAGE_FINE, 2, false, false);
+  }
+  if (nt == 3) {
+    if (dp && dw) BWD_CASE(XRD_STAGE_COLOR, 3, true, true);
+    if (dp) BWD_CASE(XRD_STAGE_COLOR, 3, true, false);
+    if (dw) BWD_CASE(XRD_STAGE_COLOR, 3, false, true);
+    BWD_CASE(XRD_STAGE_COLOR, 3, false, false);
+  }
+  if (dp && dw) BWD_CASE(XRD_STAGE_COLOR, 2, true, true);
+  if (dp) BWD_CASE(XRD_STAGE_COLOR, 2, true, false);
+  if (dw) BWD_CASE(XRD_STAGE_COLOR, 2, false, true);
+  BWD_CASE(XRD_STAGE_COLOR, 2, false, false);
+}
+
+extern "C" {
+
+int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        const float* raw, const double* g_depth,
+                        const double* g_var, const float* g_rgb,
+                        float* g_rays_o, float* g_rays_d,
+                        float* const g_grid[4], float* const g_dec[4],
+                        float* ws, xrd_stream_t stream) {
+  int nt = 0;
+  int rc = nice_check(scene, stage, n_rays, gt_depth, &nt);
+  if (rc != XRD_OK) return rc;
+  if (!rays_o || !rays_d || !raw) return XRD_ERR_ARG;
+  if ((g_rays_o == nullptr) != (g_rays_d == nullptr)) return XRD_ERR_ARG;
+  if (gt_depth && stage != XRD_STAGE_COARSE && !dmax) return XRD_ERR_ARG;
+  float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (g_grid)
+    for (int g = 0; g < 4; ++g) gg[g] = g_grid[g];
+  bool dw = false;
+  if (g_dec) {
+    if (g_dec[XRD_DEC_COARSE] || g_dec[XRD_DEC_MIDDLE] || g_dec[XRD_DEC_FINE])
+      return XRD_ERR_UNSUPPORTED;
+    dw = g_dec[XRD_DEC_COLOR] != nullptr;
+  }
+  if (dw && (stage != XRD_STAGE_COLOR || ws == nullptr)) return XRD_ERR_ARG;
+  const bool dp = g_rays_o != nullptr;
+  if (stage == XRD_STAGE_COARSE && dp) return XRD_ERR_UNSUPPORTED;
+  if (n_rays == 0) return XRD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (stage == XRD_STAGE_COARSE) gt_depth = nullptr;
+  int nb = (n_rays + RPBB - 1) / RPBB;
+  if (nb > kMaxBwdBlocks && dw) nb = kMaxBwdBlocks;
+  if (nb > 65535 * 16) nb = 65535 * 16;
+  rc = bwd_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d, gt_depth,
+                    dmax, raw, g_depth, g_var, g_rgb, g_rays_o, g_rays_d, gg,
+                    ws, nb, st);
+  if (rc != XRD_OK) return rc;
+  if (dw) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((kColorFlat + 255) / 256),
+                       dim3(256), 0, st, ws, nb, kColorFlat,
+                       g_dec[XRD_DEC_COLOR]);
+    return check_launch("xrd_nice_render_bwd/reduce");
+  }
+  return XRD_OK;
+}
+
+int xrd_selftest_mfma(const float* a, const float* b, float* out,
+                      xrd_stream_t stream) {
+  if (!a || !b || !out) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, a, b, out);
+  return check_launch("xrd_selftest_mfma");
+}
+
+}  // extern "C"

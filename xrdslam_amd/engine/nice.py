@@ -1,0 +1,279 @@
+"""Host side of the fused NICE-SLAM render (autograd wrapper over the C-ABI).
+
+Replaces ``ConvOnet.render_batch_ray`` + ``eval_points`` + ``NICE.forward`` +
+``raw2outputs_nerf_color`` of the reference (slam/models/conv_onet.py:339-524,
+slam/model_components/decoder_nice.py:386-414,
+slam/model_components/utils.py:189-244) by two kernel launches
+(``xrd_nice_render_fwd`` / ``xrd_nice_render_bwd``).
+
+PyTorch is plumbing here: it owns the device memory and the stream and carries
+the gradient between the plugin's loss and the kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+STAGES = {'coarse': 0, 'middle': 1, 'fine': 2, 'color': 3}
+DEC_KINDS = {'coarse': 0, 'middle': 1, 'fine': 2, 'color': 3}
+GRID_KEYS = ('grid_coarse', 'grid_middle', 'grid_fine', 'grid_color')
+
+# parameter order of the flat vectors = the reference's state_dict order
+# (decoder_nice.py:145-186 for MLP, :273-288 for MLP_no_xyz)
+
+
+def mlp_param_shapes(c_dim: int, out_dim: int, emb: int = 93, hidden: int = 32):
+    shapes = []
+    for i in range(5):
+        shapes += [(f'fc_c.{i}.weight', (hidden, c_dim)),
+                   (f'fc_c.{i}.bias', (hidden, ))]
+    shapes += [('embedder._B', (3, emb))]
+    ins = [emb, hidden, hidden, hidden + emb, hidden]
+    for i in range(5):
+        shapes += [(f'pts_linears.{i}.weight', (hidden, ins[i])),
+                   (f'pts_linears.{i}.bias', (hidden, ))]
+    shapes += [('output_linear.weight', (out_dim, hidden)),
+               ('output_linear.bias', (out_dim, ))]
+    return shapes
+
+
+def noxyz_param_shapes(c_dim: int = 32, hidden: int = 32):
+    shapes = []
+    ins = [hidden, hidden, hidden, hidden + c_dim, hidden]
+    for i in range(5):
+        shapes += [(f'pts_linears.{i}.weight', (hidden, ins[i])),
+                   (f'pts_linears.{i}.bias', (hidden, ))]
+    shapes += [('output_linear.weight', (1, hidden)),
+               ('output_linear.bias', (1, ))]
+    return shapes
+
+
+def param_shapes(kind: str):
+    return {'coarse': noxyz_param_shapes(),
+            'middle': mlp_param_shapes(32, 1),
+            'fine': mlp_param_shapes(64, 1),
+            'color': mlp_param_shapes(32, 4)}[kind]
+
+
+def flatten_state_dict(sd: Dict[str, torch.Tensor], kind: str) -> torch.Tensor:
+    """state dict (reference key names) -> flat f32 vector"""
+    parts = []
+    for name, shape in param_shapes(kind):
+        t = sd[name]
+        assert tuple(t.shape) == tuple(shape), (name, t.shape, shape)
+        parts.append(t.reshape(-1).float())
+    return torch.cat(parts)
+
+
+_pack_index_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def pack_index(kind: str, device) -> torch.Tensor:
+    """int64 gather index: packed = cat([flat, 0])[index]"""
+    key = (kind, str(device))
+    if key not in _pack_index_cache:
+        lib = _lib.lib()
+        k = DEC_KINDS[kind]
+        n = lib.xrd_nice_pack_len(k)
+        flat_len = lib.xrd_nice_flat_len(k)
+        idx = np.empty(n, dtype=np.int32)
+        _lib.check(lib.xrd_nice_pack_index(k, idx.ctypes.data_as(C.c_void_p)),
+                   'xrd_nice_pack_index')
+        idx64 = idx.astype(np.int64)
+        idx64[idx64 < 0] = flat_len  # slot holding 0
+        _pack_index_cache[key] = torch.from_numpy(idx64).to(device)
+    return _pack_index_cache[key]
+
+
+def pack_decoder(flat: torch.Tensor, kind: str) -> torch.Tensor:
+    lib = _lib.lib()
+    assert flat.numel() == lib.xrd_nice_flat_len(DEC_KINDS[kind]), \
+        (kind, flat.numel())
+    ext = torch.cat([flat.detach().float().reshape(-1),
+                     flat.new_zeros(1, dtype=torch.float32)])
+    return ext[pack_index(kind, flat.device)].contiguous()
+
+
+def to_channels_last_grid(val: torch.Tensor) -> torch.Tensor:
+    """[1,32,Z,Y,X] tensor -> same logical tensor stored [Z][Y][X][32]"""
+    assert val.dim() == 5 and val.shape[0] == 1 and val.shape[1] == 32
+    return val.contiguous(memory_format=torch.channels_last_3d)
+
+
+def _is_cl(val):
+    return val.permute(0, 2, 3, 4, 1).is_contiguous()
+
+
+class NiceScene:
+    """Everything the kernels need that is not per-call: bound, grids, packed
+    decoders, sampling constants.  Grids are the live parameter tensors
+    (channels_last_3d); packed decoders are refreshed with ``set_decoder``."""
+
+    def __init__(self, bound: torch.Tensor, n_samples=32, n_surface=16,
+                 coarse_enlarge=2, device='cuda:0'):
+        self.device = torch.device(device)
+        self.bound = bound.detach().double().cpu().reshape(3, 2).clone()
+        self.n_samples, self.n_surface = int(n_samples), int(n_surface)
+        self.coarse_enlarge = float(coarse_enlarge)
+        self.grids: Dict[str, Optional[torch.Tensor]] = {k: None
+                                                          for k in GRID_KEYS}
+        self.packed: Dict[str, Optional[torch.Tensor]] = {
+            k: None for k in DEC_KINDS}
+        self.dec_flat: Dict[str, Optional[torch.Tensor]] = {
+            k: None for k in DEC_KINDS}
+        # exactly the tensors the reference builds (conv_onet.py:443-444,463)
+        self.t_uniform = torch.linspace(0., 1., steps=self.n_samples).to(
+            self.device)
+        self.t_surface = torch.linspace(
+            0., 1., steps=max(self.n_surface, 1)).double().to(self.device)
+
+    def set_grid(self, key: str, val: torch.Tensor):
+        assert key in GRID_KEYS
+        assert val.is_cuda and val.dtype == torch.float32 and _is_cl(val), \
+            f'{key}: need a CUDA f32 channels_last_3d [1,32,Z,Y,X] tensor'
+        self.grids[key] = val
+
+    def set_decoder(self, kind: str, flat: torch.Tensor):
+        """flat: state_dict-ordered parameter vector (may require grad)"""
+        self.dec_flat[kind] = flat
+        self.packed[kind] = pack_decoder(flat, kind)
+
+    def c_struct(self) -> _lib.NiceScene:
+        s = _lib.NiceScene()
+        b = self.bound.reshape(-1).tolist()
+        for i in range(6):
+            s.bound[i] = b[i]
+        for gi, k in enumerate(GRID_KEYS):
+            g = self.grids[k]
+            s.grid[gi] = g.data_ptr() if g is not None else None
+            if g is not None:
+                s.gdim[3 * gi + 0], s.gdim[3 * gi + 1], s.gdim[3 * gi + 2] = \
+                    g.shape[2], g.shape[3], g.shape[4]
+        for ki, k in enumerate(DEC_KINDS):
+            p = self.packed[k]
+            s.dec[ki] = p.data_ptr() if p is not None else None
+        s.n_samples, s.n_surface = self.n_samples, self.n_surface
+        s.t_uniform = self.t_uniform.data_ptr()
+        s.t_surface = self.t_surface.data_ptr()
+        s.coarse_enlarge = self.coarse_enlarge
+        return s
+
+    def n_total(self, stage: str, has_depth: bool) -> int:
+        return self.n_samples + (self.n_surface
+                                 if has_depth and stage != 'coarse' else 0)
+
+
+def _grid_grad_buffer(g: torch.Tensor) -> torch.Tensor:
+    """persistent dense gradient buffer the kernel accumulates into"""
+    if g.grad is None:
+        g.grad = torch.zeros_like(g, memory_format=torch.preserve_format)
+    assert _is_cl(g.grad)
+    return g.grad
+
+
+class _NiceRenderFn(torch.autograd.Function):
+    """depth(f64), var(f64), rgb(f32) = render(rays_o, rays_d, dec_color_flat)
+
+    Grid gradients are accumulated IN PLACE into ``grid.grad`` (atomics) and
+    not returned through autograd — the grids are 87 MiB and the reference
+    itself only ever optimises a masked subset of them."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, dec_color_flat, g_coarse, g_middle,
+                g_fine, g_color, scene: NiceScene, stage: str, gt_depth):
+        lib = _lib.lib()
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        rays_o = rays_o.detach().float().contiguous()
+        rays_d = rays_d.detach().float().contiguous()
+        has_d = gt_depth is not None and stage != 'coarse'
+        gd = gt_depth.detach().float().reshape(-1).contiguous() if has_d \
+            else None
+        dmax = gd.max().reshape(1) if has_d else None
+        S = scene.n_total(stage, has_d)
+        depth = torch.empty(n, dtype=torch.float64, device=dev)
+        var = torch.empty(n, dtype=torch.float64, device=dev)
+        rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        grid_grads = any(ctx.needs_input_grad[3:7])
+        need_bwd = any(ctx.needs_input_grad[:7])
+        raw = torch.empty(n, S, 4, dtype=torch.float32, device=dev) \
+            if need_bwd else None
+        cs = scene.c_struct()
+        _lib.check(lib.xrd_nice_render_fwd(
+            C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o), _lib.ptr(rays_d),
+            _lib.ptr(gd), _lib.ptr(dmax), _lib.ptr(depth), _lib.ptr(var),
+            _lib.ptr(rgb), _lib.ptr(raw), _lib.stream_ptr(dev)),
+            'xrd_nice_render_fwd')
+        ctx.scene, ctx.stage, ctx.grid_grads = scene, stage, grid_grads
+        ctx.save_for_backward(rays_o, rays_d, gd, dmax, raw)
+        ctx.mark_non_differentiable()
+        return depth, var, rgb
+
+    @staticmethod
+    def backward(ctx, g_depth, g_var, g_rgb):
+        lib = _lib.lib()
+        rays_o, rays_d, gd, dmax, raw = ctx.saved_tensors
+        scene, stage = ctx.scene, ctx.stage
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        need_rays = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_dec = ctx.needs_input_grad[2] and stage == 'color'
+        if need_rays and stage == 'coarse':
+            need_rays = False  # coarse stage never reaches the pose
+        g_o = torch.zeros(n, 3, dtype=torch.float32, device=dev) \
+            if need_rays else None
+        g_d = torch.zeros(n, 3, dtype=torch.float32, device=dev) \
+            if need_rays else None
+        gg = (C.c_void_p * 4)()
+        if ctx.grid_grads:
+            used = {'coarse': (0, ), 'middle': (1, ), 'fine': (1, 2),
+                    'color': (1, 2, 3)}[stage]
+            for gi in used:
+                g = scene.grids[GRID_KEYS[gi]]
+                if g is not None and g.requires_grad:
+                    gg[gi] = _grid_grad_buffer(g).data_ptr()
+        gdec = (C.c_void_p * 4)()
+        g_flat = ws = None
+        if need_dec:
+            g_flat = torch.empty(lib.xrd_nice_flat_len(3), dtype=torch.float32,
+                                 device=dev)
+            ws = torch.empty(lib.xrd_nice_bwd_ws_floats(n),
+                             dtype=torch.float32, device=dev)
+            gdec[3] = g_flat.data_ptr()
+        gdp = g_depth.double().contiguous() if g_depth is not None else None
+        gvr = g_var.double().contiguous() if g_var is not None else None
+        grg = g_rgb.float().contiguous() if g_rgb is not None else None
+        cs = scene.c_struct()
+        _lib.check(lib.xrd_nice_render_bwd(
+            C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o), _lib.ptr(rays_d),
+            _lib.ptr(gd), _lib.ptr(dmax), _lib.ptr(raw), _lib.ptr(gdp),
+            _lib.ptr(gvr), _lib.ptr(grg), _lib.ptr(g_o), _lib.ptr(g_d),
+            C.byref(gg), C.byref(gdec), _lib.ptr(ws), _lib.stream_ptr(dev)),
+            'xrd_nice_render_bwd')
+        return g_o, g_d, g_flat, None, None, None, None, None, None, None
+
+
+def nice_render(scene: NiceScene, stage: str, rays_o: torch.Tensor,
+                rays_d: torch.Tensor, gt_depth: Optional[torch.Tensor] = None,
+                grid_grads: bool = False):
+    """Fused render.  Returns (depth f64 [n], uncertainty f64 [n], rgb [n,3]).
+
+    ``grid_grads=True`` accumulates d(loss)/d(grid) into ``grid.grad`` of every
+    grid of the stage that has ``requires_grad``; decoder-colour gradients flow
+    to ``scene.dec_flat['color']`` through autograd when it requires grad."""
+    if not rays_o.is_cuda:
+        raise _lib.XrdError('nice_render needs CUDA tensors (no CPU fallback)')
+    flat = scene.dec_flat.get('color')
+    if flat is None or stage != 'color':
+        flat = rays_o.new_zeros(0)
+    used = {'coarse': (0, ), 'middle': (1, ), 'fine': (1, 2),
+            'color': (1, 2, 3)}[stage]
+    empty = rays_o.new_zeros(0)
+    gl = [scene.grids[GRID_KEYS[i]] if i in used else empty for i in range(4)]
+    return _NiceRenderFn.apply(rays_o, rays_d, flat, gl[0], gl[1], gl[2],
+                               gl[3], scene, stage, gt_depth)
