@@ -1,0 +1,236 @@
+"""bench.py — tracking+mapping FPS of the MI355X-native NICE-SLAM hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): NICE-SLAM, Replica/office0 bounds,
+640x480 synthetic RGB-D (analytic room), reference default
+hyper-parameters (slam/configs/input_config.py:45-156): 10 tracking iterations
+x 200 rays per frame; every 5th frame a mapping call of 60 iterations x 1000
+rays (stages middle/fine/color) + 60 coarse iterations; 48 samples per ray.
+A STEP = one frame (tracking, plus the mapping call when the frame is a map
+frame).  The first-frame initialisation (mapping_first_n_iters=1500) runs in
+the untimed set-up.  value = frames / second of the whole job.
+
+N > 1: one process per GPU; tracking is replicated, the mapping rays are
+sharded over ranks and the selected-cell/decoder gradients are summed with one
+RCCL all-reduce per iteration (engine/dist.py) -> "strong" scaling of one
+frame stream.
+
+The JSON line also carries
+  roofline     for the dominant kernel of the timed region (per-launch HIP-event
+               timing on the launch stream; algorithmic bytes from SURVEY §8d)
+  cpu_baseline the CPU oracle (oracle/nice_oracle.py, a port of the reference's
+               PyTorch path) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BOUND = [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]]  # office0, input_config.py:66
+CAM = dict(fx=320.0, fy=320.0, cx=319.5, cy=239.5, width=640, height=480)
+# algorithmic HBM bytes per ray sample: 8 corners x 32 ch x 4 B
+# per distinct grid lookup; backward read-modify-writes the same cells.
+GRIDS_PER_STAGE = {'coarse': 1, 'middle': 1, 'fine': 2, 'color': 3}
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
+
+
+def algorithmic_bytes(kernel, stage, n_rays, grid_grads):
+    S = 32 if stage == 'coarse' else 48
+    per_sample = GRIDS_PER_STAGE[stage] * 8 * 32 * 4
+    if kernel == 'nice_bwd' and grid_grads:
+        per_sample *= 2  # mapping: cells read + gradient read-modify-write
+    return n_rays * S * per_sample
+
+
+def cpu_baseline(threads):
+    """oracle timed on the host: 1 tracking iteration (200 rays, colour stage,
+    fwd+bwd) and 1 mapping iteration per stage (1000 rays) + 1 coarse, with
+    office0-sized grids; converted to frames/s with the reference's iteration
+    counts (10 tracking it/frame; (24 middle + 12 fine + 24 color + 60 coarse)
+    mapping it / 5 frames)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import nice_oracle as no
+    from xrdslam_amd.engine import nice as en
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    bound = torch.tensor([[-5.5, 6.0199995], [-6.7, 5.4599998],
+                          [-4.7, 5.5399998]], dtype=torch.float64)
+    shapes = {'grid_coarse': (10, 12, 11), 'grid_middle': (31, 37, 35),
+              'grid_fine': (63, 75, 71), 'grid_color': (63, 75, 71)}
+    grids = {k: (torch.randn(1, 32, *s, generator=g) * 0.01).requires_grad_()
+             for k, s in shapes.items()}
+    decs = {kind: {n: (torch.randn(*s, generator=g) *
+                       (25. if n == 'embedder._B' else 0.2)).requires_grad_()
+                   for n, s in en.param_shapes(kind)}
+            for kind in ('coarse', 'middle', 'fine', 'color')}
+
+    def one(n, stage, is_mapping):
+        o = ((torch.rand(n, 3, generator=g) - 0.5) * 2).requires_grad_()
+        d = torch.randn(n, 3, generator=g)
+        d = (d / d.norm(dim=1, keepdim=True)).requires_grad_()
+        dep = 1.0 + 2.0 * torch.rand(n, 1, generator=g)
+        col = torch.rand(n, 3, generator=g)
+        t0 = time.perf_counter()
+        out = no.render_batch_ray(o, d, dep, grids, decs, bound, stage)
+        loss = sum(no.loss_dict(out, dep, col, is_mapping, stage).values())
+        loss.backward()
+        return time.perf_counter() - t0
+
+    one(50, 'color', True)  # warm up the allocator / threads
+    t_track = one(200, 'color', False)
+    t_mid, t_fine, t_col = (one(1000, s, True)
+                            for s in ('middle', 'fine', 'color'))
+    t_coarse = one(1000, 'coarse', True)
+    per_frame = 10 * t_track + (24 * t_mid + 12 * t_fine + 24 * t_col +
+                                60 * t_coarse) / 5.0
+    return {
+        'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': threads,
+        'kind': 'port',
+        'sample': ('1 tracking iter (200 rays) + 1 mapping iter per stage '
+                   '(1000 rays: middle/fine/color/coarse), fwd+bwd, office0 '
+                   'grids; scaled by the reference iteration counts; '
+                   f'iter seconds track={t_track:.3f} middle={t_mid:.3f} '
+                   f'fine={t_fine:.3f} color={t_col:.3f} '
+                   f'coarse={t_coarse:.3f}')}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--first-iters', type=int, default=None,
+                    help='override mapping_first_n_iters (untimed set-up)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP engine has no CPU '
+                         'fallback')
+    dev = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=dev)
+
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.engine import dist as xdist
+    from xrdslam_amd.engine import nice as en
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import (cadence,
+                                                       nice_slam_config)
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+
+    torch.manual_seed(0)  # identical on all ranks: tracking stays in lock-step
+    np.random.seed(0)
+    cfg = nice_slam_config(BOUND)
+    if args.first_iters is not None:
+        cfg.mapping_first_n_iters = args.first_iters
+    cam = Camera(**CAM)
+    algo = cfg.setup(camera=cam, device=str(dev))
+    xdist.state.setup(dev, seed=0)
+    n_frames = args.warmup + args.steps + 1
+    data = SyntheticRoom(BOUND, H=cam.height, W=cam.width, fx=cam.fx,
+                         fy=cam.fy, cx=cam.cx, cy=cam.cy,
+                         n_frames=max(n_frames, 200), device=dev)
+    cad = cadence['nice-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device=str(dev))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- untimed set-up: frame 0 (initialisation mapping) + warm-up ------
+    slam.step(0)
+    for k in range(1, 1 + args.warmup):
+        slam.step(k)
+    # ---- timed region ------------------------------------------------------
+    en.PROFILE = {}
+    slam.t_track = slam.t_map = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
+        slam.step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, en.PROFILE = en.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # per-kernel launch statistics of the timed region
+        stats = []
+        for key, evs in prof.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            stats.append((sum(ms), key, len(ms), sum(ms) / len(ms)))
+        stats.sort(reverse=True)
+        total_ms, key, calls, avg_ms = stats[0]
+        kernel, stage, n_rays, need_pose, need_dec, grid_grads = key
+        abytes = algorithmic_bytes(kernel, stage, n_rays, grid_grads)
+        achieved = abytes / (avg_ms * 1e-3) / 1e9
+        roofline = {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9,
+            'unit': 'GB/s', 'frac': achieved * 1e9 / HBM_PEAK,
+            'traffic': None,
+            'kernel': f'{kernel}[stage={stage},rays={n_rays},pose_grad='
+                      f'{int(need_pose)},decoder_grad={int(need_dec)},'
+                      f'grid_grad={int(grid_grads)}]',
+            'avg_launch_us': avg_ms * 1e3, 'launches': calls,
+            'algorithmic_bytes_per_launch': abytes,
+            'share_of_kernel_time': total_ms / sum(s[0] for s in stats),
+            'kernel_time_ms_per_step': sum(s[0] for s in stats) / args.steps,
+        }
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(os.cpu_count() or 1)
+        fps = args.steps / elapsed
+        out = {
+            'metric': 'tracking+mapping FPS @640x480', 'value': fps,
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': 'NICE-SLAM Replica/office0-shaped 640x480 RGB-D: '
+                            '10 tracking it x 200 rays/frame + every 5th '
+                            'frame 60 mapping it x 1000 rays + 60 coarse it, '
+                            '48 samples/ray, coarse/middle/fine/color grids',
+                'parallelism': 'replicated tracking, ray-sharded mapping, '
+                               'all-reduce of selected-cell gradients'
+                               if world > 1 else 'single GPU',
+                'track_ms_per_frame': slam.t_track / args.steps * 1e3,
+                'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+                'ate_rmse_m': slam.ate_rmse()},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -63,6 +63,10 @@ typedef struct {
   /* decoders in the packed MFMA-fragment layout produced by gathering the
    * flat state_dict-ordered parameter vector through xrd_nice_pack_index */
   const float* dec[4];
+  /* optional per-cell byte masks (frustum feature selection,
+   * slam/model_components/utils.py:298-375): the backward only accumulates
+   * gradients into cells whose mask byte is non-zero.  NULL = every cell. */
+  const uint8_t* gmask[4];
   int32_t n_samples;       /* rendering_n_samples  (conv_onet.py:46) */
   int32_t n_surface;       /* rendering_n_surface  (conv_onet.py:47) */
   const float* t_uniform;  /* [n_samples] torch.linspace(0,1,n) f32           */
@@ -114,8 +118,8 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
  * (frustum feature selection: conv_onet.py:94-130,187-211 optimise
  * val[mask] as a 1-D Parameter and write it back every iteration; here the
  * masked cells are updated in place).  cell_idx [n_cells] int32 lists the
- * selected cells (NULL = all n_cells cells); m, v are the Adam moments with
- * the grid's layout.  Matches torch.optim.Adam (no amsgrad, no weight decay):
+ * selected cells (NULL = all n_cells cells); m, v are the Adam moments,
+ * COMPACT [n_cells][cell_floats] (row i belongs to cell_idx[i]).  Matches torch.optim.Adam (no amsgrad, no weight decay):
  * step is the 1-based step count.  zero_grad != 0 clears g after use. */
 int xrd_adam_cells(float* param, float* g, float* m, float* v,
                    const int32_t* cell_idx, int64_t n_cells, int cell_floats,

@@ -162,8 +162,8 @@ def test_adam_cells_matches_torch():
     p_ref = p0[idx.long()].clone().requires_grad_(True)
     opt = torch.optim.Adam([p_ref], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
     p = p0.clone()
-    m = torch.zeros_like(p)
-    v = torch.zeros_like(p)
+    m = torch.zeros(idx.numel(), cf, device=dev)  # compact moments
+    v = torch.zeros(idx.numel(), cf, device=dev)
     for step in range(1, 6):
         gfull = torch.randn(ncell, cf, device=dev)
         p_ref.grad = gfull[idx.long()].clone()

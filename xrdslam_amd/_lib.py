@@ -23,7 +23,7 @@ class XrdError(RuntimeError):
 class NiceScene(C.Structure):
     """mirror of ``xrd_nice_scene``"""
     _fields_ = [('bound', f64 * 6), ('grid', vp * 4), ('gdim', i32 * 12),
-                ('dec', vp * 4), ('n_samples', i32), ('n_surface', i32),
+                ('dec', vp * 4), ('gmask', vp * 4), ('n_samples', i32), ('n_surface', i32),
                 ('t_uniform', vp), ('t_surface', vp),
                 ('coarse_enlarge', f64)]
 

@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
     const int64_t c = cell_idx ? (int64_t)cell_idx[cell] : cell;
     const int64_t off = (c * vec_per_cell + sub) * 4;
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
-    f32x4 mv = *reinterpret_cast<const f32x4*>(m + off);
-    f32x4 vv = *reinterpret_cast<const f32x4*>(v + off);
+    const int64_t soff = i * 4;  // moments are compact: [n_cells][cell_floats]
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + soff);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + soff);
     f32x4 pv = *reinterpret_cast<const f32x4*>(p + off);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
       const float denom = sqrtf(vv[k]) * inv_bc2_sqrt + eps;
       pv[k] = pv[k] - step_size * (mv[k] / denom);
     }
-    *reinterpret_cast<f32x4*>(m + off) = mv;
-    *reinterpret_cast<f32x4*>(v + off) = vv;
+    *reinterpret_cast<f32x4*>(m + soff) = mv;
+    *reinterpret_cast<f32x4*>(v + soff) = vv;
     *reinterpret_cast<f32x4*>(p + off) = pv;
     if (zero_grad)
       *reinterpret_cast<f32x4*>(g + off) = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -194,47 +194,98 @@ __device__ __forceinline__ void tri_gather(const float* __restrict__ grid,
   }
 }
 
-// backward of one lookup: scatter gc into g_grid (atomics) and/or accumulate
-// d(loss)/d(world p) (summed over this lane's 8 channels only; the caller
-// reduces over the 4 lane groups).
-template <bool NEED_DP>
-__device__ __forceinline__ void tri_backward(const float* __restrict__ grid,
-                                             float* __restrict__ ggrid,
-                                             const Tri& t, int q,
-                                             const f32x4 (&gc)[2],
-                                             double (&gp)[3]) {
+// backward of one lookup, coordinate part: accumulates d(loss)/d(world p)
+// (summed over this lane's 8 channels only; the caller reduces over the 4
+// lane groups).  The scatter into the grid gradient is grid_scatter().
+__device__ __forceinline__ void tri_backward_dp(const float* __restrict__ grid,
+                                                const Tri& t, int q,
+                                                const f32x4 (&gc)[2],
+                                                double (&gp)[3]) {
   float gi[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    if (ggrid != nullptr && t.w[k] != 0.f) {
-      float* dst = ggrid + t.off[k] + 4 * q;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(grid + t.off[k] + 4 * q);
+    const f32x4 b =
+        *reinterpret_cast<const f32x4*>(grid + t.off[k] + 16 + 4 * q);
+    float dot = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        atomicAdd(dst + r, t.w[k] * gc[0][r]);
-        atomicAdd(dst + 16 + r, t.w[k] * gc[1][r]);
+    for (int r = 0; r < 4; ++r) dot += a[r] * gc[0][r] + b[r] * gc[1][r];
+    const float sx = (k & 1) ? 1.f : -1.f, sy = (k & 2) ? 1.f : -1.f,
+                sz = (k & 4) ? 1.f : -1.f;
+    // torch skips corners that were out of range; those have weight 0 on
+    // their own axis and the coordinate gradient multiplier is 0 there.
+    gi[0] += sx * dot * t.wa[1][(k >> 1) & 1] * t.wa[2][(k >> 2) & 1];
+    gi[1] += sy * dot * t.wa[0][k & 1] * t.wa[2][(k >> 2) & 1];
+    gi[2] += sz * dot * t.wa[0][k & 1] * t.wa[1][(k >> 1) & 1];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gp[a] += (double)(t.mult[a] * gi[a]) * t.inv[a];
+}
+
+// Scatter-add of a tile's feature gradients into the channel-last grid.
+// Measured on MI355X (tools/ubench/atomics.hip): f32 atomics issued as
+// "32 consecutive channels of one cell per half-wave" run 4-6x faster than the
+// accumulator's native (4 lanes x strided dwords per point) pattern, and
+// consecutive samples of a ray share cells, so: transpose the tile through
+// LDS, then each half-wave walks 8 consecutive points, merges runs that hit
+// the same cell in registers and issues one fully coalesced 128-B atomic per
+// (run, corner).
+struct ScatterLds {
+  float* gt;   // [16][33] transposed gradients (point-major)
+  int* off;    // [16][8]
+  float* w;    // [16][8]
+};
+constexpr int kScatterFloats = 16 * 33 + 16 * 8 + 16 * 8;
+
+__device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
+                                             const uint8_t* __restrict__ cmask,
+                                             const Tri& t, int lane,
+                                             const f32x4 (&gc)[2],
+                                             const ScatterLds& S) {
+  if (ggrid == nullptr) return;
+  const int q = lane >> 4, i = lane & 15;
+  wave_lds_sync();
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.gt[i * 33 + 16 * kt + 4 * q + r] = gc[kt][r];
+  if (q == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      S.off[i * 8 + k] = t.off[k];
+      S.w[i * 8 + k] = t.w[k];
+    }
+  }
+  wave_lds_sync();
+  const int half = lane >> 5, ch = lane & 31;
+  int cur[8];
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    cur[k] = -1;
+    acc[k] = 0.f;
+  }
+#pragma unroll 1
+  for (int j = 0; j < 8; ++j) {
+    const int pt = half * 8 + j;
+    const float v = S.gt[pt * 33 + ch];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int o = S.off[pt * 8 + k];
+      const float wk = S.w[pt * 8 + k];
+      if (o != cur[k]) {
+        if (cur[k] >= 0 && acc[k] != 0.f && (!cmask || cmask[cur[k] >> 5]))
+          atomicAdd(ggrid + cur[k] + ch, acc[k]);
+        cur[k] = o;
+        acc[k] = 0.f;
       }
-    }
-    if (NEED_DP) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(grid + t.off[k] + 4 * q);
-      const f32x4 b =
-          *reinterpret_cast<const f32x4*>(grid + t.off[k] + 16 + 4 * q);
-      float dot = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dot += a[r] * gc[0][r] + b[r] * gc[1][r];
-      const float sx = (k & 1) ? 1.f : -1.f, sy = (k & 2) ? 1.f : -1.f,
-                  sz = (k & 4) ? 1.f : -1.f;
-      // torch skips corners that were out of range; those have weight 0 on
-      // their own axis and the coordinate gradient multiplier is 0 there.
-      gi[0] += sx * dot * t.wa[1][(k >> 1) & 1] * t.wa[2][(k >> 2) & 1];
-      gi[1] += sy * dot * t.wa[0][k & 1] * t.wa[2][(k >> 2) & 1];
-      gi[2] += sz * dot * t.wa[0][k & 1] * t.wa[1][(k >> 1) & 1];
+      acc[k] = fmaf(wk, v, acc[k]);
     }
   }
-  if (NEED_DP) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-      gp[a] += (double)(t.mult[a] * gi[a]) * t.inv[a];
-  }
+  for (int k = 0; k < 8; ++k)
+    if (cur[k] >= 0 && acc[k] != 0.f && (!cmask || cmask[cur[k] >> 5]))
+      atomicAdd(ggrid + cur[k] + ch, acc[k]);
 }
 
 // ---------------------------------------------------------------------------
@@ -863,7 +914,7 @@ __device__ __forceinline__ float pick_tile(const float (&v)[NT], int q) {
 constexpr int RPB = 2;   // rays per block (forward)
 constexpr int RPBB = 1;  // rays per block (backward: register heavy)
 constexpr int kColorFlat = MlpFlat<32, 4>::LEN;
-constexpr int kMaxBwdBlocks = 1024;
+constexpr int kMaxBwdBlocks = 256;  // persistent blocks when dW is reduced
 
 struct TileGeom {
   double p64[3];
@@ -1022,13 +1073,18 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
   const int q = lane >> 4, li = lane & 15;
   const int slot = wave / NT, tile = wave % NT;
   // LDS carve-up: [NW][128] f64 z | [NW][8] f64 ray-grad partials |
-  //               [NW][64] f32 ps | [NW][3][32][PTS] f32 dW tiles | acc
+  //   [NW][64] f32 ps | [NW][kScatterFloats] scatter tiles |
+  //   [NW][3][32][PTS] f32 dW tiles | acc
   double* zbuf = reinterpret_cast<double*>(smem_raw) + wave * 128;
   double* gpart = reinterpret_cast<double*>(smem_raw) + NW * 128;
   float* fbase = reinterpret_cast<float*>(gpart + NW * 8);
   DwLds L;
   L.ps = fbase + wave * 64;
-  float* fdw = fbase + NW * 64;
+  ScatterLds SL;
+  SL.gt = fbase + NW * 64 + wave * kScatterFloats;
+  SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
+  SL.w = SL.gt + 16 * 33 + 16 * 8;
+  float* fdw = fbase + NW * (64 + kScatterFloats);
   L.G = fdw + wave * (3 * 32 * PTS);
   L.H = L.G + 32 * PTS;
   L.C = L.H + 32 * PTS;
@@ -1116,7 +1172,8 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
         noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
         noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
         tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
-        tri_backward<NEED_DP>(sc.grid[0], gg_coarse, tr, q, gc[0], gp64);
+        if (NEED_DP) tri_backward_dp(sc.grid[0], tr, q, gc[0], gp64);
+        grid_scatter(gg_coarse, sc.gmask[0], tr, lane, gc[0], SL);
       } else {
         f32x4 c_m[1][2];
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
@@ -1130,7 +1187,8 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
           mlp_bwd<1, 32, 1, NEED_DP, NEED_DP, false>(
               sc.dec[1], lane, p32, c_m, go, mask, hdummy, gc, gp32, L);
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
-          tri_backward<NEED_DP>(sc.grid[1], gg_middle, tr, q, gc[0], gp64);
+          if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
+          grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
         }
         if (STAGE >= XRD_STAGE_FINE) {
           f32x4 c_f[1][4], gc[1][4], cf[2];
@@ -1148,7 +1206,8 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
               sc.dec[2], lane, p32, c_f, go, mask, hdummy, gc, gp32, L);
           const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
-          tri_backward<NEED_DP>(sc.grid[2], gg_fine, tr, q, g2, gp64);
+          if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
+          grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
         }
         if (STAGE == XRD_STAGE_COLOR) {
           f32x4 c_c[1][2], gc[1][2];
@@ -1163,7 +1222,8 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
           mlp_bwd<1, 32, 4, (NEED_DP || NEED_DW), NEED_DP, NEED_DW>(
               sc.dec[3], lane, p32, c_c, go, mask, hs, gc, gp32, L);
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
-          tri_backward<NEED_DP>(sc.grid[3], gg_color, tr, q, gc[0], gp64);
+          if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
+          grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
         }
       }
       if (NEED_DP) {
@@ -1202,13 +1262,18 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
 }
 
 
-__global__ void reduce_partials_kernel(const float* __restrict__ ws, int nb,
-                                       int len, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len) return;
+// out[i] = sum_b ws[b][i]; block = 64 elements x 4 partial stripes
+__global__ __launch_bounds__(256) void reduce_partials_kernel(
+    const float* __restrict__ ws, int nb, int len, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + x;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += ws[(size_t)b * len + i];
-  out[i] = s;
+  if (i < len)
+    for (int b = y; b < nb; b += 4) s += ws[(size_t)b * len + i];
+  red[y][x] = s;
+  __syncthreads();
+  if (y == 0 && i < len) out[i] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
 }
 
 __global__ void mfma_selftest_kernel(const float* a, const float* b,
@@ -1223,7 +1288,7 @@ __global__ void mfma_selftest_kernel(const float* a, const float* b,
 size_t bwd_lds_bytes(int nt, bool dw) {
   const size_t nw = (size_t)RPBB * nt;
   size_t b = nw * 128 * sizeof(double) + nw * 8 * sizeof(double) +
-             nw * 64 * sizeof(float);
+             nw * (64 + kScatterFloats) * sizeof(float);
   if (dw) b += (nw * 3 * 32 * PTS + kColorFlat) * sizeof(float);
   return b;
 }
@@ -1431,7 +1496,7 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
                     ws, nb, st);
   if (rc != XRD_OK) return rc;
   if (dw) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((kColorFlat + 255) / 256),
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((kColorFlat + 63) / 64),
                        dim3(256), 0, st, ws, nb, kColorFlat,
                        g_dec[XRD_DEC_COLOR]);
     return check_launch("xrd_nice_render_bwd/reduce");

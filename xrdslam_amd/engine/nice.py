@@ -72,6 +72,27 @@ def flatten_state_dict(sd: Dict[str, torch.Tensor], kind: str) -> torch.Tensor:
 
 _pack_index_cache: Dict[tuple, torch.Tensor] = {}
 
+# optional per-launch timing (bench.py): {(kernel, stage, n_rays): [(ev0, ev1)]}
+# torch events are recorded on the current stream, which is the stream the
+# kernels are launched on (_lib.stream_ptr).
+PROFILE: Optional[Dict[tuple, list]] = None
+
+
+class _Timed:
+    def __init__(self, key):
+        self.key = key if PROFILE is not None else None
+
+    def __enter__(self):
+        if self.key is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.key is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1))
+
 
 def pack_index(kind: str, device) -> torch.Tensor:
     """int64 gather index: packed = cat([flat, 0])[index]"""
@@ -126,6 +147,9 @@ class NiceScene:
             k: None for k in DEC_KINDS}
         self.dec_flat: Dict[str, Optional[torch.Tensor]] = {
             k: None for k in DEC_KINDS}
+        # optional uint8 [Z*Y*X] per-cell masks: gradients only reach cells
+        # with a non-zero byte (frustum feature selection)
+        self.gmask: Dict[str, Optional[torch.Tensor]] = {}
         # exactly the tensors the reference builds (conv_onet.py:443-444,463)
         self.t_uniform = torch.linspace(0., 1., steps=self.n_samples).to(
             self.device)
@@ -157,6 +181,9 @@ class NiceScene:
         for ki, k in enumerate(DEC_KINDS):
             p = self.packed[k]
             s.dec[ki] = p.data_ptr() if p is not None else None
+        for gi, k in enumerate(GRID_KEYS):
+            m = self.gmask.get(k)
+            s.gmask[gi] = m.data_ptr() if m is not None else None
         s.n_samples, s.n_surface = self.n_samples, self.n_surface
         s.t_uniform = self.t_uniform.data_ptr()
         s.t_surface = self.t_surface.data_ptr()
@@ -204,11 +231,12 @@ class _NiceRenderFn(torch.autograd.Function):
         raw = torch.empty(n, S, 4, dtype=torch.float32, device=dev) \
             if need_bwd else None
         cs = scene.c_struct()
-        _lib.check(lib.xrd_nice_render_fwd(
-            C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o), _lib.ptr(rays_d),
-            _lib.ptr(gd), _lib.ptr(dmax), _lib.ptr(depth), _lib.ptr(var),
-            _lib.ptr(rgb), _lib.ptr(raw), _lib.stream_ptr(dev)),
-            'xrd_nice_render_fwd')
+        with _Timed(('nice_fwd', stage, n, False, False, False)):
+            _lib.check(lib.xrd_nice_render_fwd(
+                C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o),
+                _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dmax),
+                _lib.ptr(depth), _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(raw),
+                _lib.stream_ptr(dev)), 'xrd_nice_render_fwd')
         ctx.scene, ctx.stage, ctx.grid_grads = scene, stage, grid_grads
         ctx.save_for_backward(rays_o, rays_d, gd, dmax, raw)
         ctx.mark_non_differentiable()
@@ -237,6 +265,7 @@ class _NiceRenderFn(torch.autograd.Function):
                 g = scene.grids[GRID_KEYS[gi]]
                 if g is not None and g.requires_grad:
                     gg[gi] = _grid_grad_buffer(g).data_ptr()
+                    g._xrd_grad_fresh = True  # torch.Adam skips grad=None
         gdec = (C.c_void_p * 4)()
         g_flat = ws = None
         if need_dec:
@@ -249,12 +278,14 @@ class _NiceRenderFn(torch.autograd.Function):
         gvr = g_var.double().contiguous() if g_var is not None else None
         grg = g_rgb.float().contiguous() if g_rgb is not None else None
         cs = scene.c_struct()
-        _lib.check(lib.xrd_nice_render_bwd(
-            C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o), _lib.ptr(rays_d),
-            _lib.ptr(gd), _lib.ptr(dmax), _lib.ptr(raw), _lib.ptr(gdp),
-            _lib.ptr(gvr), _lib.ptr(grg), _lib.ptr(g_o), _lib.ptr(g_d),
-            C.byref(gg), C.byref(gdec), _lib.ptr(ws), _lib.stream_ptr(dev)),
-            'xrd_nice_render_bwd')
+        with _Timed(('nice_bwd', stage, n, bool(need_rays), bool(need_dec),
+                     bool(ctx.grid_grads))):
+            _lib.check(lib.xrd_nice_render_bwd(
+                C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o),
+                _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dmax), _lib.ptr(raw),
+                _lib.ptr(gdp), _lib.ptr(gvr), _lib.ptr(grg), _lib.ptr(g_o),
+                _lib.ptr(g_d), C.byref(gg), C.byref(gdec), _lib.ptr(ws),
+                _lib.stream_ptr(dev)), 'xrd_nice_render_bwd')
         return g_o, g_d, g_flat, None, None, None, None, None, None, None
 
 

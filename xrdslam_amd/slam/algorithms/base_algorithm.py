@@ -1,0 +1,271 @@
+"""``Algorithm`` — the optimiser loop shared by tracking and mapping, with the
+reference's hooks and semantics (slam/algorithms/base_algorithm.py:44-302):
+
+* plugin hooks: get_model_input / get_loss / pre_precessing / post_processing /
+  render_img / get_mesh / get_cloud / optimizer_config_update;
+* ``optimize_update``: pre_precessing(last frame) -> fresh ``Optimizers`` ->
+  n_iters x (zero_grad, loss, backward, post_processing, step, scheduler);
+  tracking returns the pose that had the LOWEST loss evaluated BEFORE its Adam
+  step (:262-265);
+* ``setup_optimizers``: tracking optimises the (first) frame's pose group(s);
+  mapping the model groups, plus the poses of all window frames but the oldest
+  when bundle adjustment is on (:160-209);
+* pose/keyframe bookkeeping under one re-entrant lock (:51,106-158).
+
+MI355X-side difference: the best-loss pose is tracked on the device and read
+back once per call, instead of one ``loss.cpu().item()`` host sync per tracking
+iteration — same result, no per-iteration stall.
+"""
+from __future__ import annotations
+
+import random
+from abc import abstractmethod
+from dataclasses import dataclass, field
+from typing import Any, Dict, Type
+
+import torch
+
+from ..common.common import keyframe_selection_overlap
+from ..configs.base_config import InstantiateConfig
+from ..engine.optimizers import OptimizerConfig, Optimizers
+from ..models.base_model import ModelConfig
+
+
+@dataclass
+class AlgorithmConfig(InstantiateConfig):
+    _target: Type = field(default_factory=lambda: Algorithm)
+    model: ModelConfig = field(default_factory=ModelConfig)
+    keyframe_selection_method: str = 'overlap'
+    keyframe_use_ray_sample: bool = True
+    tracking_n_iters: int = 10
+    mapping_n_iters: int = 60
+    mapping_first_n_iters: int = 200
+    coarse: bool = False
+    mapping_window_size: int = 5
+    separate_LR: bool = False
+    rot_rep: str = 'quat'
+    retain_graph: bool = False
+    optimizers: Dict[str, Any] = field(default_factory=lambda: {
+        'model': {'optimizer': OptimizerConfig(lr=1e-2)},
+        'tracking_pose': {'optimizer': OptimizerConfig(lr=1e-2)},
+        'mapping_pose': {'optimizer': OptimizerConfig(lr=1e-3)},
+    })
+
+
+class Algorithm:
+    def __init__(self, config: AlgorithmConfig, camera, device: str) -> None:
+        self.config, self.camera = config, camera
+        self.initialized = False
+        self.finished = False
+        self.lock = torch.multiprocessing.RLock()
+        self.gt_c2w_list = []
+        self.gt_c2w_list_ori = []
+        self.estimate_c2w_list = []
+        self.keyframe_graph = []
+        self.bundle_adjust = False
+
+    # ---- hooks ----------------------------------------------------------
+    @abstractmethod
+    def get_model_input(self, optimize_frames, is_mapping):
+        pass
+
+    @abstractmethod
+    def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
+                 coarse=False):
+        pass
+
+    @abstractmethod
+    def pre_precessing(self, cur_frame, is_mapping):
+        pass
+
+    @abstractmethod
+    def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
+        pass
+
+    @abstractmethod
+    def render_img(self, c2w, gt_depth=None, idx=None):
+        return None, None
+
+    @abstractmethod
+    def update_mesh(self):
+        pass
+
+    @abstractmethod
+    def get_mesh(self):
+        return None
+
+    @abstractmethod
+    def get_cloud(self, c2w_np, gt_depth_np):
+        return None
+
+    @abstractmethod
+    def optimizer_config_update(self, max_iters, coarse=False):
+        pass
+
+    @property
+    def device(self):
+        return self.model.device
+
+    # ---- shared state (manager-process RPC surface) -----------------------
+    def add_framepose(self, c2w, gt_c2w, gt_c2w_ori):
+        with self.lock:
+            self.estimate_c2w_list.append(c2w)
+            self.gt_c2w_list.append(gt_c2w)
+            self.gt_c2w_list_ori.append(gt_c2w_ori)
+
+    def update_framepose(self, idx, c2w):
+        with self.lock:
+            self.estimate_c2w_list[idx] = c2w
+
+    def get_estimate_c2w_list(self):
+        with self.lock:
+            return self.estimate_c2w_list
+
+    def get_gt_c2w_list(self):
+        with self.lock:
+            return self.gt_c2w_list
+
+    def get_gt_c2w_list_ori(self):
+        with self.lock:
+            return self.gt_c2w_list_ori
+
+    def get_keyframes(self):
+        with self.lock:
+            return self.keyframe_graph
+
+    def add_keyframe(self, keyframe):
+        with self.lock:
+            self.keyframe_graph.append(keyframe)
+
+    def is_separate_LR(self):
+        with self.lock:
+            return self.config.separate_LR
+
+    def get_rot_rep(self):
+        with self.lock:
+            return self.config.rot_rep
+
+    def is_initialized(self):
+        with self.lock:
+            return self.initialized
+
+    def set_initialized(self):
+        with self.lock:
+            self.initialized = True
+
+    def is_finished(self):
+        with self.lock:
+            return self.finished
+
+    def set_finished(self):
+        with self.lock:
+            self.finished = True
+
+    # ---- optimiser construction -------------------------------------------
+    def _pose_groups(self, frames, prefix):
+        if self.config.separate_LR:
+            groups = {f'{prefix}_r': [], f'{prefix}_t': []}
+            for f in frames:
+                r, t = f.get_params()
+                groups[f'{prefix}_r'].append(r)
+                groups[f'{prefix}_t'].append(t)
+            return groups
+        groups = {prefix: []}
+        for f in frames:
+            groups[prefix].extend(f.get_params())
+        return groups
+
+    def setup_optimizers(self, n_iters, optimize_frames, is_mapping=True,
+                         coarse=False) -> Optimizers:
+        self.optimizer_config_update(n_iters, coarse)
+        cfg = dict(self.config.optimizers)
+        if not is_mapping:
+            # the reference returns inside its loop: only the first frame's
+            # pose is optimised (base_algorithm.py:176,181)
+            return Optimizers(cfg, self._pose_groups(optimize_frames[:1],
+                                                     'tracking_pose'))
+        model_groups = self.model.get_param_groups()
+        if not self.bundle_adjust or len(optimize_frames) == 1:
+            return Optimizers(cfg, {**model_groups})
+        oldest = min(f.fid for f in optimize_frames)
+        free = [f for f in optimize_frames if f.fid != oldest]
+        return Optimizers(cfg, {**self._pose_groups(free, 'mapping_pose'),
+                                **model_groups})
+
+    # ---- tracking / mapping -------------------------------------------------
+    def do_tracking(self, cur_frame):
+        if self.is_initialized():
+            return self.optimize_update(self.config.tracking_n_iters,
+                                        [cur_frame], is_mapping=False)
+
+    def do_mapping(self, cur_frame):
+        n_iters = self.config.mapping_n_iters if self.is_initialized() \
+            else self.config.mapping_first_n_iters
+        with torch.no_grad():
+            frames = self.select_optimize_frames(
+                cur_frame, self.config.keyframe_selection_method)
+        self.optimize_update(n_iters, frames, is_mapping=True, coarse=False)
+        if not self.is_initialized():
+            self.set_initialized()
+
+    def optimize_update(self, n_iters, optimize_frames, is_mapping,
+                        coarse=False):
+        with self.lock:
+            self.pre_precessing(optimize_frames[-1], is_mapping)
+            optimizers = self.setup_optimizers(n_iters, optimize_frames,
+                                               is_mapping, coarse=coarse)
+            # multi-GPU: mapping gradients are summed over ranks (engine/dist)
+            optimizers.allreduce = bool(is_mapping)
+            best_loss = None
+            best_c2w = None
+            for step in range(n_iters):
+                optimizers.zero_grad_all()
+                loss = self.get_loss(optimize_frames, is_mapping, step,
+                                     n_iters, coarse=coarse)
+                if not is_mapping:
+                    # keep the pose that produced the lowest loss, on device
+                    cur = optimize_frames[-1].get_pose().detach()
+                    lval = loss.detach().to(cur.device)
+                    if best_loss is None:
+                        better = lval < 10000000000.
+                        best_loss = torch.where(
+                            better, lval, torch.full_like(lval, 10000000000.))
+                        best_c2w = cur.clone()
+                        self._track_valid = better
+                    else:
+                        better = lval < best_loss
+                        best_loss = torch.where(better, lval, best_loss)
+                        best_c2w = torch.where(better, cur, best_c2w)
+                        self._track_valid = self._track_valid | better
+                loss.backward(
+                    retain_graph=(self.config.retain_graph and is_mapping))
+                self.post_processing(step, is_mapping, optimizers.optimizers,
+                                     coarse=coarse)
+                optimizers.optimizer_step_all(step=step)
+                optimizers.scheduler_step_all()
+            if is_mapping or best_c2w is None or \
+                    not bool(self._track_valid.item()):
+                return None
+            return best_c2w.cpu().numpy()
+
+    def select_optimize_frames(self, cur_frame, keyframe_selection_method):
+        """window of keyframes to optimise with (base_algorithm.py:277-302)"""
+        kfs = self.keyframe_graph
+        window = self.config.mapping_window_size
+        if len(kfs) <= window:
+            frames = kfs[:]
+        elif keyframe_selection_method == 'random':
+            frames = random.sample(kfs[:-1], window - 2) + [kfs[-1]]
+        elif keyframe_selection_method == 'overlap':
+            frames = keyframe_selection_overlap(
+                camera=self.camera, cur_frame=cur_frame,
+                keyframes_graph=kfs[:-1], k=window - 2,
+                use_ray_sample=self.config.keyframe_use_ray_sample,
+                device=self.device) + [kfs[-1]]
+        elif keyframe_selection_method == 'all':
+            frames = kfs.copy()
+        else:
+            frames = []
+        if cur_frame is not None:
+            frames = frames + [cur_frame]
+        return frames

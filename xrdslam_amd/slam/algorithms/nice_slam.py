@@ -1,0 +1,199 @@
+"""``NiceSLAM`` algorithm plugin (reference: slam/algorithms/nice_slam.py):
+stage schedule middle -> fine -> color over a mapping call, optional coarse
+pass, per-frame pixel sampling with bbox pre-filtering, colour refinement on
+the final frame, LR-factor plumbing into the stage schedulers.  The model call
+inside ``get_loss`` is the fused HIP render."""
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass, field
+from typing import List, Type
+
+import numpy as np
+import torch
+
+from ...engine import dist as _dist
+from ..common.common import get_rays, get_samples
+from ..models.conv_onet import ConvOnetConfig
+from .base_algorithm import Algorithm, AlgorithmConfig
+
+
+@dataclass
+class NiceSLAMConfig(AlgorithmConfig):
+    _target: Type = field(default_factory=lambda: NiceSLAM)
+    model: ConvOnetConfig = field(default_factory=ConvOnetConfig)
+    mapping_sample: int = 2048
+    min_sample_pixels: int = 100
+    tracking_sample: int = 1024
+    ray_batch_size: int = 3000
+    marching_cubes_bound: List[List[float]] = field(
+        default_factory=lambda: [[-3.5, 3], [-3, 3], [-3, 3]])
+    mapping_bound: List[List[float]] = field(
+        default_factory=lambda: [[-3.5, 3], [-3, 3], [-3, 3]])
+    tracking_Wedge: int = 100
+    tracking_Hedge: int = 100
+    mapping_middle_iter_ratio: float = 0.4
+    mapping_fine_iter_ratio: float = 0.6
+    mapping_lr_factor: float = 1.0
+    mapping_lr_first_factor: float = 5.0
+    mapping_color_refine: bool = True
+
+
+class NiceSLAM(Algorithm):
+    config: NiceSLAMConfig
+
+    def __init__(self, config: NiceSLAMConfig, camera, device: str) -> None:
+        super().__init__(config, camera, device)
+        self.stage = 'color'
+        self.marching_cube_bound = torch.from_numpy(
+            np.array(config.marching_cubes_bound))
+        self.bounding_box = torch.from_numpy(np.array(config.mapping_bound))
+        config.model.coarse = config.coarse
+        self.model = config.model.setup(camera=camera,
+                                        bounding_box=self.bounding_box)
+        self.model.to(device)
+        self.cur_mesh = None
+
+    def do_mapping(self, cur_frame):
+        cfg = self.config
+        n_iters = cfg.mapping_n_iters if self.is_initialized() \
+            else cfg.mapping_first_n_iters
+        outer = 1
+        if cur_frame.is_final_frame and cfg.mapping_color_refine:
+            # colour refinement on the last frame (nice_slam.py:79-87)
+            outer = 5
+            cfg.mapping_window_size *= 2
+            cfg.mapping_middle_iter_ratio = 0.0
+            cfg.mapping_fine_iter_ratio = 0.0
+            self.model.config.mapping_fix_color = True
+            self.model.config.mapping_frustum_feature_selection = False
+        for _ in range(outer):
+            with torch.no_grad():
+                frames = self.select_optimize_frames(
+                    cur_frame, cfg.keyframe_selection_method)
+            self.optimize_update(n_iters, frames, is_mapping=True,
+                                 coarse=False)
+        if cfg.coarse:
+            frames = self.select_optimize_frames(cur_frame, 'random')
+            self.optimize_update(n_iters, frames, is_mapping=True, coarse=True)
+        if not self.is_initialized():
+            self.set_initialized()
+
+    def optimizer_config_update(self, max_iters, coarse=False):
+        """nice_slam.py:114-132: BA once >4 keyframes (never in the coarse
+        pass); base LR = lr factor (x5 before initialisation, except poses);
+        schedulers get the iteration budget and stage ratios."""
+        cfg = self.config
+        self.bundle_adjust = len(self.keyframe_graph) > 4 and not coarse
+        for name, params in cfg.optimizers.items():
+            sch = params.get('scheduler')
+            if sch is None:
+                continue
+            first = not (self.is_initialized() or 'pose' in name)
+            params['optimizer'].lr = cfg.mapping_lr_first_factor if first \
+                else cfg.mapping_lr_factor
+            sch.max_steps = max_iters
+            sch.coarse = coarse
+            sch.middle_iter_ratio = cfg.mapping_middle_iter_ratio
+            sch.fine_iter_ratio = cfg.mapping_fine_iter_ratio
+
+    def pre_precessing(self, cur_frame, is_mapping):
+        if is_mapping:
+            self.model.pre_precessing(cur_frame)
+        else:
+            self.model.scene()
+            self.model.set_grids_trainable(False)
+
+    def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
+        if is_mapping:
+            self.model.post_processing(coarse)
+
+    def get_model_input(self, optimize_frames, is_mapping):
+        cfg = self.config
+        dev = self.model.device
+        n_pix, Hedge, Wedge = cfg.tracking_sample, cfg.tracking_Hedge, \
+            cfg.tracking_Wedge
+        if is_mapping:
+            n_pix = max(cfg.mapping_sample // len(optimize_frames),
+                        cfg.min_sample_pixels)
+            Hedge = Wedge = 0
+            n_pix = _dist.state.shard_count(n_pix)  # this rank's ray shard
+            gen = _dist.state.shard_generator
+        else:
+            gen = None
+        ro, rd, gd, gc = [], [], [], []
+        for frame in optimize_frames:
+            o, d, dep, col = get_samples(self.camera, n_pix, frame.get_pose(),
+                                         frame.depth, frame.rgb, device=dev,
+                                         Hedge=Hedge, Wedge=Wedge, frame=frame,
+                                         generator=gen)
+            ro.append(o.float())
+            rd.append(d.float())
+            gd.append(dep.float())
+            gc.append(col.float())
+        rays_o, rays_d = torch.cat(ro), torch.cat(rd)
+        depth, color = torch.cat(gd), torch.cat(gc)
+        # drop rays whose sensor depth lies beyond the bound (nice_slam.py:181-194)
+        with torch.no_grad():
+            bb = self.bounding_box.to(dev)
+            t = (bb.unsqueeze(0) - rays_o.detach().unsqueeze(-1)) / \
+                rays_d.detach().unsqueeze(-1)
+            t_exit = t.max(dim=2)[0].min(dim=1)[0]
+            keep = t_exit >= depth.squeeze(-1)
+        return {'rays_o': rays_o[keep], 'rays_d': rays_d[keep],
+                'target_s': color[keep], 'target_d': depth[keep],
+                'stage': self.stage}
+
+    def set_stage(self, is_mapping, step, n_iters, coarse=False):
+        cfg = self.config
+        if not is_mapping:
+            self.stage = 'color'
+        elif self.model.config.coarse and coarse:
+            self.stage = 'coarse'
+        elif step <= cfg.mapping_middle_iter_ratio * n_iters:
+            self.stage = 'middle'
+        elif step <= cfg.mapping_fine_iter_ratio * n_iters:
+            self.stage = 'fine'
+        else:
+            self.stage = 'color'
+
+    def get_loss(self, optimize_frames, is_mapping, step, n_iters,
+                 coarse=False):
+        self.set_stage(is_mapping, step, n_iters, coarse=coarse)
+        if is_mapping:
+            self.model.grid_processing(coarse=coarse)
+        model_input = self.get_model_input(optimize_frames, is_mapping)
+        outputs = self.model(model_input)
+        losses = self.model.get_loss_dict(outputs, model_input, is_mapping,
+                                          self.stage)
+        return functools.reduce(torch.add, losses.values())
+
+    def render_img(self, c2w, gt_depth=None, idx=None):
+        """full-image render in ray_batch_size chunks (nice_slam.py:234-279);
+        like the reference this runs under no_grad without taking the lock."""
+        with torch.no_grad():
+            dev = self.model.device
+            rays_o, rays_d = get_rays(self.camera, c2w, device=dev)
+            rays_o = rays_o.reshape(-1, 3).float().contiguous()
+            rays_d = rays_d.reshape(-1, 3).float().contiguous()
+            if gt_depth is not None:
+                gt_depth = torch.as_tensor(gt_depth).to(dev).reshape(-1, 1)
+            depths, colors = [], []
+            bs = self.config.ray_batch_size
+            for i in range(0, rays_d.shape[0], bs):
+                out = self.model({
+                    'rays_o': rays_o[i:i + bs], 'rays_d': rays_d[i:i + bs],
+                    'target_s': None,
+                    'target_d': None if gt_depth is None
+                    else gt_depth[i:i + bs],
+                    'stage': 'color'})
+                depths.append(out['depth'].double())
+                colors.append(out['rgb'])
+            H, W = self.camera.height, self.camera.width
+            depth = torch.cat(depths).reshape(H, W)
+            color = torch.cat(colors).reshape(H, W, 3)
+            return color.cpu().numpy(), depth.cpu().numpy()
+
+    def get_mesh(self):
+        raise NotImplementedError('mesh extraction is out of the hot-path '
+                                  'scope (SURVEY.md §8f #3)')

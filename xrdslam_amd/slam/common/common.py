@@ -1,0 +1,133 @@
+"""Pixel -> ray sampling and keyframe overlap selection (the A1/A2 rows of
+SURVEY.md §8a; reference: slam/common/common.py:39-122,188-227,288-310,342-426).
+
+Same functions and argument meaning as the reference; differences are
+MI355X-side plumbing only: frames keep a device-resident copy of depth/colour
+(the reference re-uploads the whole image per call, common.py:67-68), the pixel
+meshgrid is computed arithmetically from the drawn index instead of being
+materialised, and the overlap test for all keyframes runs as one batched device
+computation.  Random draws use the global torch / numpy RNGs like the
+reference, or an explicit ``generator`` when the caller wants reproducibility.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def get_rays_from_uv(i, j, c2w, fx, fy, cx, cy, device):
+    """rays for pixel columns ``i`` and rows ``j`` (common.py:39-53): OpenGL
+    camera, direction NOT normalised, gradient flows to ``c2w``."""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w)
+    c2w = c2w.to(device)
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)],
+                       -1).to(device)
+    rays_d = (dirs.reshape(-1, 1, 3) * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def _device_images(depth, color, device, frame=None):
+    if frame is not None:
+        return frame.device_images(device)
+    d = torch.as_tensor(depth, dtype=torch.float32).to(device).reshape(-1, 1)
+    c = torch.as_tensor(color, dtype=torch.float32).to(device).reshape(-1, 3)
+    return d, c
+
+
+def get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0',
+                  full_width=None, frame=None, generator=None):
+    """draw n pixels (with replacement) from rows [H0,H1) x cols [W0,W1)
+    (common.py:109-122 + select_uv :56-71).  Index k of the cropped row-major
+    meshgrid is pixel (row H0 + k // (W1-W0), col W0 + k % (W1-W0))."""
+    w = W1 - W0
+    cnt = (H1 - H0) * w
+    idx = torch.randint(cnt, (n, ), device=device, generator=generator)
+    rows = H0 + torch.div(idx, w, rounding_mode='floor')
+    cols = W0 + idx % w
+    W = full_width if full_width is not None else (
+        depth.shape[1] if hasattr(depth, 'shape') else None)
+    d, c = _device_images(depth, color, device, frame)
+    flat = rows * W + cols
+    return cols.float(), rows.float(), d[flat], c[flat]
+
+
+def get_samples(camera, n, c2w, depth, color, device, Hedge=0, Wedge=0,
+                depth_filter=False, return_index=False, depth_limit=None,
+                frame=None, generator=None):
+    """n rays of one frame (common.py:188-227); ``frame`` (optional) supplies
+    the cached device images."""
+    i, j, sd, sc = get_sample_uv(Hedge, camera.height - Hedge, Wedge,
+                                 camera.width - Wedge, n, depth, color,
+                                 device=device, full_width=camera.width,
+                                 frame=frame, generator=generator)
+    rays_o, rays_d = get_rays_from_uv(i, j, c2w, camera.fx, camera.fy,
+                                      camera.cx, camera.cy, device)
+    if depth_filter:
+        sd = sd.reshape(-1)
+        mask = sd > 0
+        if depth_limit is not None:
+            mask = mask & (sd < depth_limit)
+        rays_o, rays_d, sd, sc = rays_o[mask], rays_d[mask], sd[mask], sc[mask]
+        i, j = i[mask], j[mask]
+    if return_index:
+        return rays_o, rays_d, sd, sc, i.to(torch.int64), j.to(torch.int64)
+    return rays_o, rays_d, sd, sc
+
+
+def get_rays(camera, c2w, device):
+    """rays of the full image, [H,W,3] each (common.py:288-310)"""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w)
+    c2w = c2w.to(device)
+    cols = torch.arange(camera.width, device=device, dtype=torch.float32)
+    rows = torch.arange(camera.height, device=device, dtype=torch.float32)
+    j, i = torch.meshgrid(rows, cols, indexing='ij')
+    dirs = torch.stack([(i - camera.cx) / camera.fx,
+                        -(j - camera.cy) / camera.fy, -torch.ones_like(i)], -1)
+    rays_d = (dirs[..., None, :] * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+@torch.no_grad()
+def keyframe_selection_overlap(camera, cur_frame, keyframes_graph, k,
+                               N_samples=16, pixs_per_image=100,
+                               use_ray_sample=True, device='cuda:0'):
+    """keyframes whose view contains part of the current frustum, then a random
+    k of them (common.py:342-426, ray-sample branch).  Points: 16 samples in
+    [0.8 d, d+0.5] along 100 valid-depth rays; a keyframe counts a point when
+    it projects >20 px inside the image and lies in front of the camera."""
+    if not use_ray_sample:
+        raise NotImplementedError('only the ray-sample overlap test is built')
+    if len(keyframes_graph) == 0:
+        return []
+    H, W = camera.height, camera.width
+    rays_o, rays_d, gd, _ = get_samples(camera, pixs_per_image,
+                                        cur_frame.get_pose(), cur_frame.depth,
+                                        cur_frame.rgb, device,
+                                        depth_filter=True, frame=cur_frame)
+    gd = gd.reshape(-1, 1).repeat(1, N_samples)
+    t = torch.linspace(0., 1., steps=N_samples, device=device)
+    z = gd * 0.8 * (1. - t) + (gd + 0.5) * t
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]).reshape(
+        -1, 3)
+    c2ws = torch.stack([kf.get_pose().detach().to(device)
+                        for kf in keyframes_graph])
+    w2c = torch.linalg.inv(c2ws.double())
+    homo = torch.cat([pts.double(), torch.ones_like(pts[:, :1]).double()], 1)
+    cam = torch.einsum('kij,nj->kni', w2c, homo)[..., :3]
+    cam[..., 0] *= -1  # x flip: pixel u grows to the right
+    u = camera.fx * cam[..., 0] + camera.cx * cam[..., 2]
+    v = camera.fy * cam[..., 1] + camera.cy * cam[..., 2]
+    zc = cam[..., 2] + 1e-5
+    u, v = (u / zc).float(), (v / zc).float()
+    edge = 20
+    inside = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge) & \
+        (zc < 0)
+    percent = inside.float().mean(1).cpu().numpy()
+    order = np.argsort(-percent, kind='stable')
+    selected = [keyframes_graph[a] for a in order if percent[a] > 0.0]
+    perm = np.random.permutation(len(selected))[:k]
+    return [selected[a] for a in perm]

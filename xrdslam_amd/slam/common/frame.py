@@ -1,0 +1,67 @@
+"""``Frame``: one RGB-D observation + its optimisable pose (reference:
+slam/common/frame.py:10-74).  ``rgb``/``depth`` stay numpy like the reference
+hands them over; the engine keeps a device-resident copy per frame
+(``device_images``) so that the per-iteration whole-image H2D copy of
+slam/common/common.py:67-68 happens once per frame."""
+from typing import List
+
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from ..utils.opt_pose import OptimizablePose
+
+
+class Frame(nn.Module):
+    def __init__(self, fid, rgb, depth, init_pose=None, gt_pose=None,
+                 separate_LR=False, rot_rep='axis_angle',
+                 device='cpu') -> None:
+        super().__init__()
+        self.fid = fid
+        self.h, self.w = (depth.shape if depth is not None else rgb.shape[:2])
+        self.rgb, self.depth, self.gt_pose = rgb, depth, gt_pose
+        self.separate_LR, self.rot_rep = separate_LR, rot_rep
+        self.is_final_frame = False
+        self.pose_device = device
+        self._dev_cache = None
+        self.pose = None
+        if init_pose is not None:
+            self.set_pose(init_pose, separate_LR, rot_rep)
+            Rt = torch.as_tensor(init_pose, dtype=torch.float32)
+            if not torch.allclose(Rt, self.pose.matrix().detach().cpu(),
+                                  atol=1e-3):
+                raise ValueError('Transformation inconsistency detected!', Rt,
+                                 self.pose.matrix())
+
+    def set_pose(self, pose_np, separate_LR=False, rot_rep='axis_angle'):
+        Rt = torch.as_tensor(pose_np, dtype=torch.float32).to(
+            self.pose_device)
+        self.pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,
+                                                rot_rep=rot_rep)
+
+    def get_pose(self):
+        return self.pose.matrix()
+
+    def get_translation(self):
+        return self.pose.translation()
+
+    def get_rotation(self):
+        return self.pose.rotation()
+
+    def get_params(self) -> List[Parameter]:
+        if self.pose is None:
+            return []
+        if self.separate_LR:
+            r = self.pose.data_q if self.rot_rep == 'quat' else \
+                self.pose.data_r
+            return [r, self.pose.data_t]
+        return list(self.pose.parameters())
+
+    def device_images(self, device):
+        """(depth [H*W,1] f32, rgb [H*W,3] f32) on ``device``, uploaded once"""
+        if self._dev_cache is None or self._dev_cache[0].device != \
+                torch.device(device):
+            d = torch.as_tensor(self.depth, dtype=torch.float32).to(device)
+            c = torch.as_tensor(self.rgb, dtype=torch.float32).to(device)
+            self._dev_cache = (d.reshape(-1, 1), c.reshape(-1, 3))
+        return self._dev_cache

@@ -1,0 +1,65 @@
+"""Per-algorithm default configurations with the reference's field names and
+values (slam/configs/input_config.py:45-493).  Only the hot-path algorithms are
+registered; tracker/mapper cadence values that the benchmark loop needs are
+kept next to the algorithm config."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict
+
+from ..algorithms.nice_slam import NiceSLAMConfig
+from ..engine.optimizers import AdamOptimizerConfig
+from ..engine.schedulers import LRconfig, NiceSLAMSchedulerConfig
+from ..models.conv_onet import ConvOnetConfig
+
+
+@dataclass
+class PipelineCadence:
+    """the TrackerConfig/MapperConfig numbers the loop depends on"""
+    map_every: int = 5
+    keyframe_every: int = 50
+    render_freq: int = 50
+    use_relative_pose: bool = False
+
+
+def _sched(**lr):
+    return NiceSLAMSchedulerConfig(stage_lr=LRconfig(**lr))
+
+
+def nice_slam_config(bound=None) -> NiceSLAMConfig:
+    """algorithm_configs['nice-slam'] (input_config.py:45-156), office0"""
+    bound = bound or [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]]
+    z = dict(coarse=0.0, middle=0.0, fine=0.0, color=0.0)
+    return NiceSLAMConfig(
+        coarse=True, tracking_n_iters=10, mapping_n_iters=60,
+        mapping_first_n_iters=1500, mapping_window_size=5,
+        tracking_sample=200, mapping_sample=1000, min_sample_pixels=200,
+        ray_batch_size=100000, tracking_Wedge=100, tracking_Hedge=100,
+        mapping_bound=[list(b) for b in bound],
+        marching_cubes_bound=[list(b) for b in bound],
+        mapping_middle_iter_ratio=0.4, mapping_fine_iter_ratio=0.6,
+        mapping_lr_factor=1.0, mapping_lr_first_factor=5.0,
+        model=ConvOnetConfig(points_batch_size=100000,
+                             mapping_frustum_feature_selection=True),
+        optimizers={
+            'decoder': {'optimizer': AdamOptimizerConfig(),
+                        'scheduler': _sched(**{**z, 'color': 0.005})},
+            'grid_coarse': {'optimizer': AdamOptimizerConfig(),
+                            'scheduler': _sched(**{**z, 'coarse': 0.001})},
+            'grid_middle': {'optimizer': AdamOptimizerConfig(),
+                            'scheduler': _sched(coarse=0.0, middle=0.1,
+                                                fine=0.005, color=0.005)},
+            'grid_fine': {'optimizer': AdamOptimizerConfig(),
+                          'scheduler': _sched(coarse=0.0, middle=0.0,
+                                              fine=0.005, color=0.005)},
+            'grid_color': {'optimizer': AdamOptimizerConfig(),
+                           'scheduler': _sched(**{**z, 'color': 0.005})},
+            'tracking_pose': {'optimizer': AdamOptimizerConfig(lr=1e-3),
+                              'scheduler': None},
+            'mapping_pose': {'optimizer': AdamOptimizerConfig(),
+                             'scheduler': _sched(**{**z, 'color': 0.001})},
+        })
+
+
+algorithm_configs: Dict[str, object] = {'nice-slam': nice_slam_config}
+cadence: Dict[str, PipelineCadence] = {'nice-slam': PipelineCadence()}

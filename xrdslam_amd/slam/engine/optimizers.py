@@ -1,0 +1,164 @@
+"""``Optimizers``: one optimizer (+ optional scheduler) per parameter group, with
+the reference's interface and semantics (slam/engine/optimizers.py:63-171):
+group names must exist in the config (RuntimeError otherwise), ``accum_step``
+gradient accumulation, ``max_norm`` clipping, fresh Adam state per instance.
+
+MI355X addition: a parameter that carries ``_xrd_cells`` (an int32 list of
+selected 32-float cells of a channel-last feature grid; ``None`` = every cell)
+is stepped by the fused ``xrd_adam_cells`` kernel in place — arithmetically the
+same as the reference's Adam over the 1-D ``val[mask]`` parameter plus its two
+whole-grid ``index_put`` round trips per iteration (conv_onet.py:94-114).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple, Type
+
+import torch
+from torch.nn.parameter import Parameter
+
+from ..configs.base_config import PrintableConfig
+
+
+@dataclass
+class OptimizerConfig(PrintableConfig):
+    _target: Type = torch.optim.Adam
+    lr: float = 0.0005
+    eps: float = 1e-08
+    betas: Tuple[float, float] = (0.9, 0.999)
+    max_norm: Optional[float] = None
+    accum_step: Optional[int] = None
+
+    def setup(self, params) -> torch.optim.Optimizer:
+        kwargs = {k: v for k, v in vars(self).items()
+                  if k not in ('_target', 'max_norm', 'accum_step')}
+        if len(params) == 1 and hasattr(params[0], '_xrd_cells') and \
+                self._target is torch.optim.Adam and \
+                not kwargs.get('weight_decay', 0):
+            return FusedCellAdam(params, lr=self.lr, betas=self.betas,
+                                 eps=self.eps)
+        return self._target(params, **kwargs)
+
+
+@dataclass
+class AdamOptimizerConfig(OptimizerConfig):
+    _target: Type = torch.optim.Adam
+    weight_decay: float = 0
+
+
+@dataclass
+class RAdamOptimizerConfig(OptimizerConfig):
+    _target: Type = torch.optim.RAdam
+    weight_decay: float = 0
+
+
+class FusedCellAdam(torch.optim.Optimizer):
+    """Adam over the selected cells of ONE channel-last grid parameter, in
+    place, through ``xrd_adam_cells``.  Like torch.optim.Adam it does nothing
+    while the parameter has received no gradient (``p.grad is None`` there,
+    ``_xrd_grad_fresh`` unset here), so the per-parameter step count starts
+    when the stage that feeds the grid starts."""
+
+    def __init__(self, params, lr, betas, eps):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._t = 0
+        self._m = self._v = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        # the kernel clears the used gradient cells itself
+        for g in self.param_groups:
+            for p in g['params']:
+                p._xrd_grad_fresh = False
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from ... import _lib
+        grp = self.param_groups[0]
+        p = grp['params'][0]
+        if not getattr(p, '_xrd_grad_fresh', False) or p.grad is None:
+            return
+        cells = p._xrd_cells
+        cf = p.shape[1]
+        n = int(cells.numel()) if cells is not None else p.numel() // cf
+        if self._m is None:
+            self._m = torch.zeros(n * cf, dtype=torch.float32, device=p.device)
+            self._v = torch.zeros_like(self._m)
+        self._t += 1
+        b1, b2 = grp['betas']
+        _lib.check(_lib.lib().xrd_adam_cells(
+            _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
+            _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
+            float(b1), float(b2), float(grp['eps']), self._t, 1,
+            _lib.stream_ptr(p.device)), 'xrd_adam_cells')
+        p._xrd_grad_fresh = False
+
+
+class Optimizers:
+    def __init__(self, config: Dict[str, Any] = None,
+                 param_groups: Dict[str, List[Parameter]] = None,
+                 optimizers: Dict[str, Any] = None) -> None:
+        self.config = config
+        self.schedulers = {}
+        if optimizers:
+            self.optimizers = optimizers
+            return
+        self.optimizers = {}
+        self.parameters = {}
+        for name, params in param_groups.items():
+            if name not in config:
+                raise RuntimeError(
+                    f"Optimizer config for '{name}' not found in config file. "
+                    'Make sure you specify an optimizer for each parameter '
+                    f'group. Provided configs were: {config.keys()}')
+            ocfg = config[name]['optimizer']
+            self.optimizers[name] = ocfg.setup(params=params)
+            self.parameters[name] = params
+            if config[name].get('scheduler'):
+                self.schedulers[name] = config[name]['scheduler'].setup(
+                ).get_scheduler(optimizer=self.optimizers[name],
+                                lr_init=ocfg.lr)
+
+    def __add__(self, other: 'Optimizers') -> 'Optimizers':
+        # only used by Co-SLAM (persistent model optimizer + pose optimizers)
+        return Optimizers(config={**self.config, **other.config},
+                          optimizers={**self.optimizers, **other.optimizers})
+
+    def optimizer_step(self, param_group_name: str) -> None:
+        self.optimizers[param_group_name].step()
+
+    def scheduler_step(self, param_group_name: str) -> None:
+        if param_group_name in self.schedulers:
+            self.schedulers[param_group_name].step()
+
+    def zero_grad_all(self) -> None:
+        for name, opt in self.optimizers.items():
+            if self.config[name]['optimizer'].accum_step is None:
+                opt.zero_grad(set_to_none=True)
+
+    def optimizer_step_all(self, step: int) -> None:
+        from ...engine import dist as _dist
+        if _dist.state.enabled and getattr(self, 'parameters', None) and \
+                getattr(self, 'allreduce', False):
+            _dist.allreduce_param_grads(self.parameters)
+        for name, opt in self.optimizers.items():
+            ocfg = self.config[name]['optimizer']
+            if ocfg.max_norm is not None:
+                torch.nn.utils.clip_grad_norm_(self.parameters[name],
+                                               ocfg.max_norm)
+            if ocfg.accum_step is None:
+                opt.step()
+            elif (step + 1) % ocfg.accum_step == 0:
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+
+    def scheduler_step_all(self) -> None:
+        for sch in self.schedulers.values():
+            sch.step()
+
+    def load_optimizers(self, loaded_state: Dict[str, Any]) -> None:
+        for k, v in loaded_state.items():
+            self.optimizers[k].load_state_dict(v)
+
+    def load_schedulers(self, loaded_state: Dict[str, Any]) -> None:
+        for k, v in loaded_state.items():
+            self.schedulers[k].load_state_dict(v)

@@ -1,0 +1,91 @@
+"""In-process tracking/mapping driver with the per-frame sequence of the
+reference's Tracker.spin / Mapper.spin (slam/pipeline/tracker.py:52-199,
+slam/pipeline/mapper.py:20-46).  The reference runs tracker, mapper and the
+Algorithm in separate processes that alternate strictly through two events
+(tracking and mapping never overlap); here the same sequence runs in one
+process, which is what the benchmark and the parity tests drive:
+
+    init pose by constant velocity -> Frame -> do_tracking -> set pose ->
+    add_framepose -> [map frame?] do_mapping -> update_framepose ->
+    [keyframe?] add_keyframe
+
+The multi-process plumbing itself (BaseManager, queues, viewer) is outside the
+hot-path scope.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from .common.frame import Frame
+
+
+def predict_current_pose(frame_id, gt_c2w_np, estimate_c2w_list):
+    """constant-velocity motion model (tracker.py:185-199)"""
+    if frame_id < 1:
+        return gt_c2w_np
+    prev = estimate_c2w_list[frame_id - 1].detach().cpu().numpy()
+    if frame_id == 1:
+        return prev
+    prev2 = estimate_c2w_list[frame_id - 2].detach().cpu().numpy()
+    return (prev @ np.linalg.inv(prev2)) @ prev
+
+
+class SequentialSLAM:
+    def __init__(self, algorithm, dataset, map_every=5, keyframe_every=50,
+                 lazy_start=-1, pose_device='cpu'):
+        self.algorithm, self.dataset = algorithm, dataset
+        self.map_every, self.keyframe_every = map_every, keyframe_every
+        self.lazy_start = lazy_start
+        self.pose_device = pose_device
+        self.t_track = 0.0
+        self.t_map = 0.0
+
+    def is_mapframe(self, fid):
+        every = 1 if fid <= self.lazy_start else self.map_every
+        return every != -1 and (fid % every == 0 or
+                                fid == len(self.dataset) - 1)
+
+    def step(self, idx: int, sync: Optional[Callable[[], None]] = None):
+        """process frame ``idx``: track, then (if it is a map frame) map"""
+        alg = self.algorithm
+        data = self.dataset[idx]
+        gt_c2w = data['c2w'].astype(np.float32)
+        init = predict_current_pose(idx, gt_c2w, alg.get_estimate_c2w_list())
+        frame = Frame(fid=idx, rgb=data['rgb'], depth=data['depth'],
+                      gt_pose=gt_c2w, init_pose=init,
+                      separate_LR=alg.is_separate_LR(),
+                      rot_rep=alg.get_rot_rep(), device=self.pose_device)
+        t0 = time.perf_counter()
+        cand = alg.do_tracking(frame)
+        if alg.is_initialized() and cand is not None:
+            frame.set_pose(cand, separate_LR=alg.is_separate_LR(),
+                           rot_rep=alg.get_rot_rep())
+        if sync:
+            sync()
+        t1 = time.perf_counter()
+        g = torch.from_numpy(gt_c2w)
+        alg.add_framepose(frame.get_pose().detach(), g, g.clone())
+        if self.is_mapframe(idx):
+            frame.is_final_frame = idx == len(self.dataset) - 1
+            alg.do_mapping(frame)
+            alg.update_framepose(idx, frame.get_pose().detach())
+            if idx % self.keyframe_every == 0:
+                alg.add_keyframe(frame)
+            if sync:
+                sync()
+        t2 = time.perf_counter()
+        self.t_track += t1 - t0
+        self.t_map += t2 - t1
+        return frame
+
+    def ate_rmse(self):
+        """translation RMSE between estimated and GT poses (no alignment: the
+        synthetic runs start from the GT pose of frame 0)"""
+        est = torch.stack([p[:3, 3].cpu() for p in
+                           self.algorithm.get_estimate_c2w_list()])
+        gt = torch.stack([p[:3, 3] for p in self.algorithm.get_gt_c2w_list()])
+        return float(((est - gt)**2).sum(1).mean().sqrt())
