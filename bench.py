@@ -110,6 +110,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true',
+                    help='run every iteration eagerly (no hipGraph capture)')
     ap.add_argument('--first-iters', type=int, default=None,
                     help='override mapping_first_n_iters (untimed set-up)')
     args = ap.parse_args()
@@ -145,6 +147,7 @@ def main():
         cfg.mapping_first_n_iters = args.first_iters
     cam = Camera(**CAM)
     algo = cfg.setup(camera=cam, device=str(dev))
+    algo.use_graphs = not args.no_graphs
     xdist.state.setup(dev, seed=0)
     n_frames = args.warmup + args.steps + 1
     data = SyntheticRoom(BOUND, H=cam.height, W=cam.width, fx=cam.fx,
@@ -204,7 +207,9 @@ def main():
         }
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(os.cpu_count() or 1)
+            # torch CPU ops on these small tensors stop scaling (and collapse)
+            # beyond a few tens of threads: use at most 16 host cores
+            cpu = cpu_baseline(min(16, os.cpu_count() or 1))
         fps = args.steps / elapsed
         out = {
             'metric': 'tracking+mapping FPS @640x480', 'value': fps,

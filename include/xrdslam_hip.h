@@ -126,6 +126,18 @@ int xrd_adam_cells(float* param, float* g, float* m, float* v,
                    float lr, float beta1, float beta2, float eps, int step,
                    int zero_grad, xrd_stream_t stream);
 
+/* same, with the 1-based step count read from device memory at execution time
+ * (hipGraph replay: a preceding node increments *step_dev) */
+int xrd_adam_cells_devstep(float* param, float* g, float* m, float* v,
+                           const int32_t* cell_idx, int64_t n_cells,
+                           int cell_floats, float lr, float beta1, float beta2,
+                           float eps, const int32_t* step_dev, int zero_grad,
+                           xrd_stream_t stream);
+
+/* one-time set-up of kernel attributes (dynamic LDS sizes); call once per
+ * process before capturing launches into a hipGraph */
+int xrd_nice_warmup(void);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

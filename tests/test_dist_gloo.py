@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the data-parallel mapping plumbing
+(xrdslam_amd/engine/dist.py): shard sizes, the flat-bucket all-reduce, and the
+selected-cell gradient exchange for grid parameters."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xrdslam_amd.engine import dist as xd
+    xd.state.setup('cpu', seed=3)
+    assert xd.state.enabled and xd.state.world == world
+    assert xd.state.shard_count(1000) == 500 and xd.state.shard_count(7) == 4
+    # different ranks draw different shard pixels
+    draw = torch.randint(10**6, (4, ), generator=xd.state.shard_generator)
+    # dense parameter + a "grid" parameter with selected cells
+    dense = torch.nn.Parameter(torch.zeros(5))
+    dense.grad = torch.full((5, ), float(rank + 1))
+    grid = torch.zeros(1, 32, 2, 2, 3).contiguous(
+        memory_format=torch.channels_last_3d).requires_grad_(True)
+    grid.grad = torch.full_like(grid, float(rank + 1),
+                                memory_format=torch.preserve_format)
+    grid._xrd_cells = torch.tensor([1, 7, 8], dtype=torch.int32)
+    grid._xrd_grad_fresh = True
+    stale = torch.zeros(1, 32, 1, 1, 2).contiguous(
+        memory_format=torch.channels_last_3d).requires_grad_(True)
+    stale.grad = torch.full_like(stale, 5.0,
+                                 memory_format=torch.preserve_format)
+    stale._xrd_cells = None
+    stale._xrd_grad_fresh = False  # no gradient this iteration: not exchanged
+    xd.allreduce_param_grads({'a': [dense], 'g': [grid], 's': [stale]})
+    cells = grid.grad.permute(0, 2, 3, 4, 1).reshape(-1, 32)
+    out[rank] = (dense.grad.clone(), cells.clone(), stale.grad.clone(),
+                 draw.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_param_grads_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        dense, cells, stale, _ = out[r]
+        assert torch.equal(dense, torch.full((5, ), 3.0))  # 1 + 2
+        sel = torch.zeros(12, dtype=torch.bool)
+        sel[[1, 7, 8]] = True
+        assert torch.equal(cells[sel], torch.full((3, 32), 3.0))
+        assert torch.equal(cells[~sel], torch.full((9, 32), float(r + 1)))
+        assert torch.equal(stale, torch.full_like(stale, 5.0))
+    assert not torch.equal(out[0][3], out[1][3])

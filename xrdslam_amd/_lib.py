@@ -43,6 +43,9 @@ _SIGS = {
                                       vp]),
     'xrd_adam_cells': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32, f32,
                                  f32, f32, C.c_int, C.c_int, vp]),
+    'xrd_adam_cells_devstep': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32,
+                                         f32, f32, f32, vp, C.c_int, vp]),
+    'xrd_nice_warmup': (C.c_int, []),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 
@@ -87,7 +90,10 @@ def ptr(t):
     """device/host pointer of a torch tensor (or None) as void*"""
     if t is None:
         return None
-    assert t.is_contiguous() or t.numel() == 0, 'engine tensors must be dense'
+    import torch
+    dense = t.numel() == 0 or t.is_contiguous() or (
+        t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d))
+    assert dense, 'engine tensors must be dense'
     return C.c_void_p(t.data_ptr())
 
 

@@ -288,6 +288,22 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
       atomicAdd(ggrid + cur[k] + ch, acc[k]);
 }
 
+// Staging buffers for the colour-decoder weight gradients.  The backward
+// kernel stores, per sample point, what the dW contraction needs; a separate
+// split-K MFMA kernel (nice_dw_kernel) then contracts over all points.  This
+// keeps the per-tile backward free of LDS accumulators and atomics.
+struct DwSave {
+  float* gh;      // [5][P][32]  d loss / d h_i (before the ReLU mask)
+  float* hs;      // [5][P][32]  h_i (layer outputs)
+  uint32_t* mk;   // [5][P]      ReLU masks, bit f = feature f active
+  float* c;       // [P][32]     grid features
+  float* go;      // [P][4]      d loss / d decoder output
+  float* pp;      // [P][4]      f32 sample position
+  float* ge;      // [P][96]     d loss / d (p.B) per Fourier feature
+  int64_t P;      // number of points
+};
+constexpr int kDwFloatsPerPoint = 5 * 32 + 5 * 32 + 5 + 32 + 4 + 4 + 96;
+
 // ---------------------------------------------------------------------------
 // device: MLP decoder forward (decoder_nice.py:207-234)
 // ---------------------------------------------------------------------------
@@ -303,8 +319,8 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
                                         const float (&p)[NT][3],
                                         const f32x4 (&c)[NT][CD / 16],
                                         float (&out)[NT][OD],
-                                        uint64_t (&mask)[NT],
-                                        f32x4 (&hs)[5][NT][2]) {
+                                        uint64_t (&mask)[NT], const DwSave& W,
+                                        const int64_t (&pt)[NT]) {
   using P = MlpPack<CD, OD>;
   const int q = lane >> 4;
   f32x4 acc[NT][2], acc3[NT][2];
@@ -377,11 +393,9 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
             mask[t] |= (uint64_t)1 << (i * 8 + jt * 4 + r);
           h[t][jt][r] = fmaxf(a, 0.f) + cc[t][jt][r];
         }
-        if (SAVE_H) {
-#pragma unroll
-          for (int k = 0; k < 5; ++k)
-            if (i == k) hs[k][t][jt] = h[t][jt];
-        }
+        if (SAVE_H)
+          *reinterpret_cast<f32x4*>(W.hs + ((int64_t)i * W.P + pt[t]) * 32 +
+                                    16 * jt + 4 * q) = h[t][jt];
       }
     if (i < 4) {
 #pragma unroll
@@ -495,60 +509,16 @@ __device__ __forceinline__ void noxyz_fwd(const float* __restrict__ pk,
 // ---------------------------------------------------------------------------
 // device: MLP decoder backward
 // ---------------------------------------------------------------------------
-// per-wave LDS scratch used by the weight-gradient path
-struct DwLds {
-  float* G;    // [32][PTS] transposed gradient tile
-  float* H;    // [32][PTS] transposed layer input
-  float* C;    // [32][PTS] transposed grid features
-  float* ps;   // [64][4]   f32 sample positions
-  float* acc;  // block accumulator, flat layout (shared by the 4 waves)
-};
-
-template <int NT>
-__device__ __forceinline__ void lds_put(float* dst, int lane,
-                                        const f32x4 (&v)[NT][2]) {
-  const int q = lane >> 4, i = lane & 15;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dst[(16 * jt + 4 * q + r) * PTS + 16 * t + i] = v[t][jt][r];
-}
-
-// acc[base + j*stride + k] += sum_pts G[j][pt] * Hin[k][pt]  (32x32 block)
-template <int NT>
-__device__ __forceinline__ void dw_block(const float* G, const float* Hin,
-                                         float* acc, int base, int stride,
-                                         int lane) {
-  const int q = lane >> 4, m = lane & 15;
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NT * 4; ++s)
-        d = XRD_MFMA4(G[(16 * jt + m) * PTS + 4 * s + q],
-                      Hin[(16 * kt + m) * PTS + 4 * s + q], d);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomicAdd(acc + base + (16 * jt + 4 * q + r) * stride + 16 * kt + m,
-                  d[r]);
-    }
-}
-
 template <int NT, int CD, int OD, bool NEED_E, bool NEED_DP, bool NEED_DW>
 __device__ __forceinline__ void mlp_bwd(
     const float* __restrict__ pk, int lane, const float (&p)[NT][3],
     const f32x4 (&c)[NT][CD / 16], const float (&gout)[NT][OD],
-    const uint64_t (&mask)[NT], const f32x4 (&hs)[5][NT][2],
-    f32x4 (&gc)[NT][CD / 16], float (&gp)[NT][3], const DwLds& L) {
+    const uint64_t (&mask)[NT], f32x4 (&gc)[NT][CD / 16], float (&gp)[NT][3],
+    const DwSave& W, const int64_t (&pt)[NT]) {
   using P = MlpPack<CD, OD>;
-  using F = MlpFlat<CD, OD>;
-  static_assert(!NEED_DW || CD == 32, "weight grads: c_dim 32 decoders only");
-  const int q = lane >> 4, m = lane & 15;
+  static_assert(!NEED_DW || (CD == 32 && OD == 4),
+                "weight grads: colour decoder only");
+  const int q = lane >> 4;
   f32x4 gh[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -568,27 +538,23 @@ __device__ __forceinline__ void mlp_bwd(
       gh[t][0] += w0 * gout[t][o];
       gh[t][1] += w1 * gout[t][o];
     }
-    if (NEED_DW) {
-      // d output_linear.weight[o][j], d bias[o]
-      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-      float sb = 0.f;
+  }
+  if (NEED_DW && q == 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        s0 += hs[4][t][0] * gout[t][o];
-        s1 += hs[4][t][1] * gout[t][o];
-        sb += gout[t][o];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v0 = row16_sum(s0[r]), v1 = row16_sum(s1[r]);
-        if (m == 0) {
-          atomicAdd(L.acc + F::OW + o * 32 + 4 * q + r, v0);
-          atomicAdd(L.acc + F::OW + o * 32 + 16 + 4 * q + r, v1);
-        }
-      }
-      sb = row16_sum(sb);
-      if (lane == 0) atomicAdd(L.acc + F::OB + o, sb);
+    for (int t = 0; t < NT; ++t) {
+      *reinterpret_cast<f32x4*>(W.go + pt[t] * 4) =
+          f32x4{gout[t][0], gout[t][1], gout[t][2], gout[t][OD - 1]};
+      *reinterpret_cast<f32x4*>(W.pp + pt[t] * 4) =
+          f32x4{p[t][0], p[t][1], p[t][2], 0.f};
     }
+  }
+  if (NEED_DW) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        *reinterpret_cast<f32x4*>(W.c + pt[t] * 32 + 16 * kt + 4 * q) =
+            c[t][kt];
   }
   f32x4 ge[NT][NEED_E ? 6 : 1];
   if (NEED_E) {
@@ -597,99 +563,28 @@ __device__ __forceinline__ void mlp_bwd(
 #pragma unroll
       for (int kt = 0; kt < 6; ++kt) ge[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (NEED_DW) {
-    // transposed grid features for d fc_c.weight
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          L.C[(16 * kt + 4 * q + r) * PTS + 16 * t + (lane & 15)] =
-              c[t][kt][r];
-  }
 #pragma unroll 1
   for (int i = 4; i >= 0; --i) {
     f32x4 ga[NT][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ga[t][jt][r] = ((mask[t] >> (i * 8 + jt * 4 + r)) & 1)
-                             ? gh[t][jt][r]
-                             : 0.f;
-    if (NEED_DW) {
-      // bias grads: sum over points
+    for (int t = 0; t < NT; ++t) {
+      uint32_t word = 0;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sc = 0.f, sa = 0.f;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            sc += gh[t][jt][r];
-            sa += ga[t][jt][r];
-          }
-          sc = row16_sum(sc);
-          sa = row16_sum(sa);
-          if (m == 0) {
-            atomicAdd(L.acc + F::fcb(i) + 16 * jt + 4 * q + r, sc);
-            atomicAdd(L.acc + F::pb(i) + 16 * jt + 4 * q + r, sa);
-          }
+          const bool on = (mask[t] >> (i * 8 + jt * 4 + r)) & 1;
+          ga[t][jt][r] = on ? gh[t][jt][r] : 0.f;
+          if (NEED_DW && on) word |= 1u << (16 * jt + 4 * q + r);
         }
-      // d fc_c[i].weight = gh (x) c
-      wave_lds_sync();
-      lds_put<NT>(L.G, lane, gh);
-      wave_lds_sync();
-      dw_block<NT>(L.G, L.C, L.acc, F::fcw(i), CD, lane);
-      wave_lds_sync();
-      lds_put<NT>(L.G, lane, ga);
-      if (i >= 1) {
-        f32x4 hp[NT][2];
+      if (NEED_DW) {
+        word |= __shfl_xor((int)word, 16);
+        word |= __shfl_xor((int)word, 32);
+        if (q == 0) W.mk[(int64_t)i * W.P + pt[t]] = word;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int jt = 0; jt < 2; ++jt) {
-            hp[t][jt] = hs[0][t][jt];
-#pragma unroll
-            for (int k = 1; k < 4; ++k)
-              if (i - 1 == k) hp[t][jt] = hs[k][t][jt];
-          }
-        lds_put<NT>(L.H, lane, hp);
-      }
-      wave_lds_sync();
-      if (i >= 1)
-        dw_block<NT>(L.G, L.H, L.acc, F::pw(i) + F::pcol(i), F::pstride(i),
-                     lane);
-      if (i == 3 || i == 0) {
-        // d W[:, :93] = ga (x) sin(p B): recompute the embedding directly in
-        // B-operand layout (point 4s+q, feature 16kt+m)
-        const int wbase = (i == 0) ? F::P0W : F::P3W;
-        const int wstride = (i == 0) ? kEmbK : kEmbK + 32;
-#pragma unroll 1
-        for (int kt = 0; kt < 6; ++kt) {
-          const int k = 16 * kt + m;
-          const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
-          f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-#pragma unroll
-          for (int s = 0; s < NT * 4; ++s) {
-            const f32x4 pp =
-                *reinterpret_cast<const f32x4*>(L.ps + (4 * s + q) * 4);
-            const float pv[3] = {pp[0], pp[1], pp[2]};
-            const float e = sin_cw(embed_arg(pv, bk));
-            d0 = XRD_MFMA4(L.G[m * PTS + 4 * s + q], e, d0);
-            d1 = XRD_MFMA4(L.G[(16 + m) * PTS + 4 * s + q], e, d1);
-          }
-          if (k < kEmbK) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              atomicAdd(L.acc + wbase + (4 * q + r) * wstride + k, d0[r]);
-              atomicAdd(L.acc + wbase + (16 + 4 * q + r) * wstride + k, d1[r]);
-            }
-          }
-        }
+        for (int jt = 0; jt < 2; ++jt)
+          *reinterpret_cast<f32x4*>(W.gh + ((int64_t)i * W.P + pt[t]) * 32 +
+                                    16 * jt + 4 * q) = gh[t][jt];
       }
     }
     // g_c += Wc_i^T gh
@@ -748,7 +643,6 @@ __device__ __forceinline__ void mlp_bwd(
       for (int r = 0; r < 4; ++r) {
         const int k = emap(4 * kt + r, q);
         const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
-        float db[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const float garg = ge[t][kt][r] * cos_cw(embed_arg(p[t], bk));
@@ -756,20 +650,224 @@ __device__ __forceinline__ void mlp_bwd(
 #pragma unroll
             for (int a = 0; a < 3; ++a) gp[t][a] += garg * bk[a];
           }
-          if (NEED_DW) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) db[a] += garg * p[t][a];
-          }
+          if (NEED_DW) W.ge[pt[t] * 96 + k] = garg;
         }
-        if (NEED_DW) {
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const float v = row16_sum(db[a]);
-            if (m == 0 && k < kEmbK) atomicAdd(L.acc + F::EB + a * kEmbK + k, v);
-          }
-        }
-        XRD_SB();  // keep the inlined cosf bodies from being interleaved
+        XRD_SB();  // keep the inlined cos bodies from being interleaved
       }
+  }
+}
+
+// Weight-gradient contraction of the colour decoder: dW = sum over points of
+// (gradient) x (layer input), as v_mfma_f32_16x16x4_f32 with the POINTS on the
+// K dimension.  256 persistent blocks x 4 waves; each wave owns a slice of the
+// flat gradient (accumulated in registers over all of the block's 16-point
+// chunks) and writes it once to the block's partial vector.
+//   wave 0: fc_c.{0..4} weight+bias      wave 1: pts_linears hidden parts+bias
+//   wave 2: pts_linears.0 (Fourier)      wave 3: pts_linears.3 Fourier part,
+//                                                output_linear, embedder._B
+__global__ __launch_bounds__(256) void nice_dw_kernel(
+    const float* __restrict__ pk, DwSave W, float* __restrict__ partial) {
+  using F = MlpFlat<32, 4>;
+  using P = MlpPack<32, 4>;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, m = lane & 15;
+  float* out = partial + (size_t)blockIdx.x * F::LEN;
+  const int64_t Pn = W.P;
+  const int64_t nchunks = (Pn + 15) / 16;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+    f32x4 acc[5][2][2];
+    float bs[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        acc[i][jt][0] = z4;
+        acc[i][jt][1] = z4;
+        bs[i][jt] = 0.f;
+      }
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+      float cb[2][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int64_t pt = ch * 16 + 4 * s + q;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          cb[kt][s] = pt < Pn ? W.c[pt * 32 + 16 * kt + m] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int64_t pt = ch * 16 + 4 * s + q;
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const float a =
+                pt < Pn ? W.gh[((int64_t)i * Pn + pt) * 32 + 16 * jt + m] : 0.f;
+            bs[i][jt] += a;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+              acc[i][jt][kt] = XRD_MFMA4(a, cb[kt][s], acc[i][jt][kt]);
+          }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            out[F::fcw(i) + (16 * jt + 4 * q + r) * 32 + 16 * kt + m] =
+                acc[i][jt][kt][r];
+        const float b = group4_sum(bs[i][jt]);
+        if (q == 0) out[F::fcb(i) + 16 * jt + m] = b;
+      }
+  } else if (wave == 1) {
+    f32x4 acc[4][2][2];
+    float bs[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (i < 4) {
+          acc[i][jt][0] = z4;
+          acc[i][jt][1] = z4;
+        }
+        bs[i][jt] = 0.f;
+      }
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int64_t pt = ch * 16 + 4 * s + q;
+          const bool ok = pt < Pn;
+          const uint32_t word = ok ? W.mk[(int64_t)i * Pn + pt] : 0u;
+          float hb[2] = {0.f, 0.f};
+          if (i >= 1 && ok) {
+            hb[0] = W.hs[((int64_t)(i - 1) * Pn + pt) * 32 + m];
+            hb[1] = W.hs[((int64_t)(i - 1) * Pn + pt) * 32 + 16 + m];
+          }
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            float a = 0.f;
+            if (ok && ((word >> (16 * jt + m)) & 1))
+              a = W.gh[((int64_t)i * Pn + pt) * 32 + 16 * jt + m];
+            bs[i][jt] += a;
+            if (i >= 1) {
+#pragma unroll
+              for (int kt = 0; kt < 2; ++kt)
+                acc[i - 1 < 0 ? 0 : i - 1][jt][kt] = XRD_MFMA4(
+                    a, hb[kt], acc[i - 1 < 0 ? 0 : i - 1][jt][kt]);
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (i >= 1) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              out[F::pw(i) + (16 * jt + 4 * q + r) * F::pstride(i) +
+                  F::pcol(i) + 16 * kt + m] = acc[i - 1 < 0 ? 0 : i - 1][jt][kt][r];
+        }
+        const float b = group4_sum(bs[i][jt]);
+        if (q == 0) out[F::pb(i) + 16 * jt + m] = b;
+      }
+  } else {
+    // Fourier-feature weights: wave 2 -> layer 0, wave 3 -> layer 3
+    const int li = (wave == 2) ? 0 : 3;
+    const int wbase = (wave == 2) ? F::P0W : F::P3W;
+    const int wstride = (wave == 2) ? kEmbK : kEmbK + 32;
+    f32x4 acc[2][6], accO[2], accB[6];
+    float bo = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 6; ++kt) {
+      acc[0][kt] = z4;
+      acc[1][kt] = z4;
+      accB[kt] = z4;
+    }
+    accO[0] = z4;
+    accO[1] = z4;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int64_t pt = ch * 16 + 4 * s + q;
+        const bool ok = pt < Pn;
+        const uint32_t word = ok ? W.mk[(int64_t)li * Pn + pt] : 0u;
+        float a[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          a[jt] = (ok && ((word >> (16 * jt + m)) & 1))
+                      ? W.gh[((int64_t)li * Pn + pt) * 32 + 16 * jt + m]
+                      : 0.f;
+        f32x4 pp = z4;
+        if (ok) pp = *reinterpret_cast<const f32x4*>(W.pp + pt * 4);
+        const float pv[3] = {pp[0], pp[1], pp[2]};
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt) {
+          const f32x4 bk =
+              *reinterpret_cast<const f32x4*>(pk + P::EMB + (16 * kt + m) * 4);
+          const float e = ok ? sin_cw(embed_arg(pv, bk)) : 0.f;
+          acc[0][kt] = XRD_MFMA4(a[0], e, acc[0][kt]);
+          acc[1][kt] = XRD_MFMA4(a[1], e, acc[1][kt]);
+        }
+        if (wave == 3) {
+          // output_linear: rows = output o (lane m < 4), cols = h4 features
+          const float ao = (ok && m < 4) ? W.go[pt * 4 + m] : 0.f;
+          bo += ao;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const float hb =
+                ok ? W.hs[((int64_t)4 * Pn + pt) * 32 + 16 * kt + m] : 0.f;
+            accO[kt] = XRD_MFMA4(ao, hb, accO[kt]);
+          }
+          // embedder._B: rows = axis a (lane m < 3), cols = Fourier feature
+          const float ap = (ok && m < 3) ? pv[m] : 0.f;
+#pragma unroll
+          for (int kt = 0; kt < 6; ++kt) {
+            const float gb = ok ? W.ge[pt * 96 + 16 * kt + m] : 0.f;
+            accB[kt] = XRD_MFMA4(ap, gb, accB[kt]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * kt + m;
+          if (k < kEmbK)
+            out[wbase + (16 * jt + 4 * q + r) * wstride + k] =
+                acc[jt][kt][r];
+        }
+    if (wave == 3) {
+      if (q == 0) {  // rows 0..3 of the accumulator live in lane group 0
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+            out[F::OW + r * 32 + 16 * kt + m] = accO[kt][r];
+          if (r < 3) {
+#pragma unroll
+            for (int kt = 0; kt < 6; ++kt) {
+              const int k = 16 * kt + m;
+              if (k < kEmbK) out[F::EB + r * kEmbK + k] = accB[kt][r];
+            }
+          }
+        }
+      }
+      const float b = group4_sum(bo);
+      if (q == 0 && m < 4) out[F::OB + m] = b;
+    }
   }
 }
 
@@ -914,7 +1012,7 @@ __device__ __forceinline__ float pick_tile(const float (&v)[NT], int q) {
 constexpr int RPB = 2;   // rays per block (forward)
 constexpr int RPBB = 1;  // rays per block (backward: register heavy)
 constexpr int kColorFlat = MlpFlat<32, 4>::LEN;
-constexpr int kMaxBwdBlocks = 256;  // persistent blocks when dW is reduced
+constexpr int kMaxBwdBlocks = 1 << 20;
 
 struct TileGeom {
   double p64[3];
@@ -975,7 +1073,8 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
     const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
     float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
     uint64_t mdummy[1];
-    f32x4 hdummy[5][1][2];
+    const DwSave wdummy = {};
+    const int64_t ptd[1] = {0};
     Tri tr;
     if (STAGE == XRD_STAGE_COARSE) {
       f32x4 c_a[1][2];
@@ -991,7 +1090,7 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
       {
         float om[1][1];
         mlp_fwd<1, 32, 1, false, false>(sc.dec[1], lane, p32, c_m, om, mdummy,
-                                        hdummy);
+                                        wdummy, ptd);
         occ = om[0][0];
       }
       if (STAGE >= XRD_STAGE_FINE) {
@@ -1004,7 +1103,7 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
         c_f[0][2] = c_m[0][0];
         c_f[0][3] = c_m[0][1];
         mlp_fwd<1, 64, 1, false, false>(sc.dec[2], lane, p32, c_f, of, mdummy,
-                                        hdummy);
+                                        wdummy, ptd);
         occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
       }
       if (STAGE == XRD_STAGE_COLOR) {
@@ -1013,7 +1112,7 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
         tri_gather(sc.grid[3], tr, q, c_c[0]);
         mlp_fwd<1, 32, 4, false, false>(sc.dec[3], lane, p32, c_c, oc, mdummy,
-                                        hdummy);
+                                        wdummy, ptd);
         col[0] = oc[0][0];
         col[1] = oc[0][1];
         col[2] = oc[0][2];
@@ -1073,25 +1172,26 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
   const int q = lane >> 4, li = lane & 15;
   const int slot = wave / NT, tile = wave % NT;
   // LDS carve-up: [NW][128] f64 z | [NW][8] f64 ray-grad partials |
-  //   [NW][64] f32 ps | [NW][kScatterFloats] scatter tiles |
-  //   [NW][3][32][PTS] f32 dW tiles | acc
+  //   [NW][kScatterFloats] scatter tiles
   double* zbuf = reinterpret_cast<double*>(smem_raw) + wave * 128;
   double* gpart = reinterpret_cast<double*>(smem_raw) + NW * 128;
   float* fbase = reinterpret_cast<float*>(gpart + NW * 8);
-  DwLds L;
-  L.ps = fbase + wave * 64;
   ScatterLds SL;
-  SL.gt = fbase + NW * 64 + wave * kScatterFloats;
+  SL.gt = fbase + wave * kScatterFloats;
   SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
   SL.w = SL.gt + 16 * 33 + 16 * 8;
-  float* fdw = fbase + NW * (64 + kScatterFloats);
-  L.G = fdw + wave * (3 * 32 * PTS);
-  L.H = L.G + 32 * PTS;
-  L.C = L.H + 32 * PTS;
-  L.acc = fdw + NW * (3 * 32 * PTS);
+  DwSave W = {};
   if (NEED_DW) {
-    for (int i = threadIdx.x; i < kColorFlat; i += NW * 64) L.acc[i] = 0.f;
-    __syncthreads();
+    // staging arrays live in the caller's workspace
+    const int64_t Pn = (int64_t)n * S;
+    W.P = Pn;
+    W.gh = ws;
+    W.hs = W.gh + 5 * Pn * 32;
+    W.mk = reinterpret_cast<uint32_t*>(W.hs + 5 * Pn * 32);
+    W.c = reinterpret_cast<float*>(W.mk + 5 * Pn);
+    W.go = W.c + Pn * 32;
+    W.pp = W.go + Pn * 4;
+    W.ge = W.pp + Pn * 4;
   }
   const bool use_depth = (gt_depth != nullptr) && STAGE != XRD_STAGE_COARSE;
   const int ngroups = (n + RPBB - 1) / RPBB;
@@ -1155,13 +1255,10 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
       const float wsrc = __shfl(w, src);
       const float gcol[3] = {grgb[0] * wsrc, grgb[1] * wsrc, grgb[2] * wsrc};
       const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
-      if (NEED_DW && q == 0)
-        *reinterpret_cast<f32x4*>(L.ps + li * 4) =
-            f32x4{tg.p32[0], tg.p32[1], tg.p32[2], 0.f};
+      const int64_t ptg[1] = {(int64_t)ray * S + src};
       double gp64[3] = {0.0, 0.0, 0.0};
       float gp32[1][3] = {{0.f, 0.f, 0.f}};
       uint64_t mask[1];
-      f32x4 hdummy[5][1][2];
       Tri tr;
       if (STAGE == XRD_STAGE_COARSE) {
         f32x4 c_a[1][2], gc[1][2];
@@ -1183,9 +1280,9 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
           const float go[1][1] = {{gocc}};
           f32x4 gc[1][2];
           mlp_fwd<1, 32, 1, true, false>(sc.dec[1], lane, p32, c_m, om, mask,
-                                         hdummy);
+                                         W, ptg);
           mlp_bwd<1, 32, 1, NEED_DP, NEED_DP, false>(
-              sc.dec[1], lane, p32, c_m, go, mask, hdummy, gc, gp32, L);
+              sc.dec[1], lane, p32, c_m, go, mask, gc, gp32, W, ptg);
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
           if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
           grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
@@ -1201,9 +1298,9 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
           c_f[0][2] = c_m[0][0];
           c_f[0][3] = c_m[0][1];
           mlp_fwd<1, 64, 1, true, false>(sc.dec[2], lane, p32, c_f, of, mask,
-                                         hdummy);
+                                         W, ptg);
           mlp_bwd<1, 64, 1, NEED_DP, NEED_DP, false>(
-              sc.dec[2], lane, p32, c_f, go, mask, hdummy, gc, gp32, L);
+              sc.dec[2], lane, p32, c_f, go, mask, gc, gp32, W, ptg);
           const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
           if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
@@ -1211,16 +1308,15 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
         }
         if (STAGE == XRD_STAGE_COLOR) {
           f32x4 c_c[1][2], gc[1][2];
-          f32x4 hs[5][1][2];
           float oc[1][4];
           // channel 3 is overwritten by fine+middle occupancy -> no gradient
           const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
           tri_gather(sc.grid[3], tr, q, c_c[0]);
           mlp_fwd<1, 32, 4, true, NEED_DW>(sc.dec[3], lane, p32, c_c, oc, mask,
-                                           hs);
+                                           W, ptg);
           mlp_bwd<1, 32, 4, (NEED_DP || NEED_DW), NEED_DP, NEED_DW>(
-              sc.dec[3], lane, p32, c_c, go, mask, hs, gc, gp32, L);
+              sc.dec[3], lane, p32, c_c, go, mask, gc, gp32, W, ptg);
           tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
           if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
           grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
@@ -1254,13 +1350,7 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
       __syncthreads();
     }
   }
-  if (NEED_DW) {
-    __syncthreads();
-    float* dst = ws + (size_t)blockIdx.x * kColorFlat;
-    for (int i = threadIdx.x; i < kColorFlat; i += NW * 64) dst[i] = L.acc[i];
-  }
 }
-
 
 // out[i] = sum_b ws[b][i]; block = 64 elements x 4 partial stripes
 __global__ __launch_bounds__(256) void reduce_partials_kernel(
@@ -1286,12 +1376,13 @@ __global__ void mfma_selftest_kernel(const float* a, const float* b,
 }
 
 size_t bwd_lds_bytes(int nt, bool dw) {
+  (void)dw;
   const size_t nw = (size_t)RPBB * nt;
-  size_t b = nw * 128 * sizeof(double) + nw * 8 * sizeof(double) +
-             nw * (64 + kScatterFloats) * sizeof(float);
-  if (dw) b += (nw * 3 * 32 * PTS + kColorFlat) * sizeof(float);
-  return b;
+  return nw * 128 * sizeof(double) + nw * 8 * sizeof(double) +
+         nw * kScatterFloats * sizeof(float);
 }
+
+constexpr int kDwBlocks = 256;
 
 }  // namespace
 }  // namespace xrd
@@ -1380,10 +1471,9 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
 }
 
 int64_t xrd_nice_bwd_ws_floats(int n_rays) {
-  int nb = (n_rays + RPBB - 1) / RPBB;
-  if (nb > kMaxBwdBlocks) nb = kMaxBwdBlocks;
-  if (nb < 1) nb = 1;
-  return (int64_t)nb * kColorFlat;
+  // staging arrays for n_rays * 48 points + the per-block partial gradients
+  return (int64_t)n_rays * 48 * kDwFloatsPerPoint +
+         (int64_t)kDwBlocks * kColorFlat + 64;
 }
 
 }  // extern "C"
@@ -1406,6 +1496,7 @@ static int launch_bwd(const xrd_nice_scene* scene, int n, const float* rays_o,
       return check_launch("hipFuncSetAttribute");
     attr_set = true;
   }
+  if (n == 0) return XRD_OK;  // warm-up call: attributes only
   hipLaunchKernelGGL(kern, dim3(nb), dim3(RPBB * NTV * 64), lds, st, *scene, n, rays_o,
                      rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb,
                      g_rays_o, g_rays_d, g_grid[0], g_grid[1], g_grid[2],
@@ -1489,18 +1580,49 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
   hipStream_t st = (hipStream_t)stream;
   if (stage == XRD_STAGE_COARSE) gt_depth = nullptr;
   int nb = (n_rays + RPBB - 1) / RPBB;
-  if (nb > kMaxBwdBlocks && dw) nb = kMaxBwdBlocks;
+
   if (nb > 65535 * 16) nb = 65535 * 16;
   rc = bwd_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d, gt_depth,
                     dmax, raw, g_depth, g_var, g_rgb, g_rays_o, g_rays_d, gg,
                     ws, nb, st);
   if (rc != XRD_OK) return rc;
   if (dw) {
+    DwSave W = {};
+    const int64_t Pn = (int64_t)n_rays * (nt * 16);
+    W.P = Pn;
+    W.gh = ws;
+    W.hs = W.gh + 5 * Pn * 32;
+    W.mk = reinterpret_cast<uint32_t*>(W.hs + 5 * Pn * 32);
+    W.c = reinterpret_cast<float*>(W.mk + 5 * Pn);
+    W.go = W.c + Pn * 32;
+    W.pp = W.go + Pn * 4;
+    W.ge = W.pp + Pn * 4;
+    float* partial = W.ge + Pn * 96;
+    hipLaunchKernelGGL(nice_dw_kernel, dim3(kDwBlocks), dim3(256), 0, st,
+                       scene->dec[XRD_DEC_COLOR], W, partial);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((kColorFlat + 63) / 64),
-                       dim3(256), 0, st, ws, nb, kColorFlat,
+                       dim3(256), 0, st, partial, kDwBlocks, kColorFlat,
                        g_dec[XRD_DEC_COLOR]);
-    return check_launch("xrd_nice_render_bwd/reduce");
+    return check_launch("xrd_nice_render_bwd/dw");
   }
+  return XRD_OK;
+}
+
+int xrd_nice_warmup(void) {
+  float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
+  xrd_nice_scene sc = {};
+  for (int stage = 0; stage < 4; ++stage)
+    for (int nt = 2; nt <= 3; ++nt)
+      for (int dp = 0; dp < 2; ++dp)
+        for (int dw = 0; dw < 2; ++dw) {
+          if (stage == XRD_STAGE_COARSE && (nt != 2 || dp || dw)) continue;
+          if (stage != XRD_STAGE_COLOR && dw) continue;
+          int rc = bwd_dispatch(&sc, stage, nt, dp, dw, 0, nullptr, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, nullptr, nullptr, gg, nullptr, 1,
+                                nullptr);
+          if (rc != XRD_OK) return rc;
+        }
   return XRD_OK;
 }
 

@@ -80,7 +80,8 @@ PROFILE: Optional[Dict[tuple, list]] = None
 
 class _Timed:
     def __init__(self, key):
-        self.key = key if PROFILE is not None else None
+        self.key = key if PROFILE is not None and \
+            not torch.cuda.is_current_stream_capturing() else None
 
     def __enter__(self):
         if self.key is not None:
@@ -155,6 +156,7 @@ class NiceScene:
             self.device)
         self.t_surface = torch.linspace(
             0., 1., steps=max(self.n_surface, 1)).double().to(self.device)
+        _lib.check(_lib.lib().xrd_nice_warmup(), 'xrd_nice_warmup')
 
     def set_grid(self, key: str, val: torch.Tensor):
         assert key in GRID_KEYS
@@ -212,7 +214,8 @@ class _NiceRenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, dec_color_flat, g_coarse, g_middle,
-                g_fine, g_color, scene: NiceScene, stage: str, gt_depth):
+                g_fine, g_color, scene: NiceScene, stage: str, gt_depth,
+                dmax_in=None):
         lib = _lib.lib()
         n = rays_o.shape[0]
         dev = rays_o.device
@@ -221,7 +224,11 @@ class _NiceRenderFn(torch.autograd.Function):
         has_d = gt_depth is not None and stage != 'coarse'
         gd = gt_depth.detach().float().reshape(-1).contiguous() if has_d \
             else None
-        dmax = gd.max().reshape(1) if has_d else None
+        if has_d:
+            dmax = (dmax_in.detach().float().reshape(1) if dmax_in is not None
+                    else gd.max().reshape(1))
+        else:
+            dmax = None
         S = scene.n_total(stage, has_d)
         depth = torch.empty(n, dtype=torch.float64, device=dev)
         var = torch.empty(n, dtype=torch.float64, device=dev)
@@ -286,12 +293,13 @@ class _NiceRenderFn(torch.autograd.Function):
                 _lib.ptr(gdp), _lib.ptr(gvr), _lib.ptr(grg), _lib.ptr(g_o),
                 _lib.ptr(g_d), C.byref(gg), C.byref(gdec), _lib.ptr(ws),
                 _lib.stream_ptr(dev)), 'xrd_nice_render_bwd')
-        return g_o, g_d, g_flat, None, None, None, None, None, None, None
+        return (g_o, g_d, g_flat, None, None, None, None, None, None, None,
+                None)
 
 
 def nice_render(scene: NiceScene, stage: str, rays_o: torch.Tensor,
                 rays_d: torch.Tensor, gt_depth: Optional[torch.Tensor] = None,
-                grid_grads: bool = False):
+                dmax: Optional[torch.Tensor] = None):
     """Fused render.  Returns (depth f64 [n], uncertainty f64 [n], rgb [n,3]).
 
     ``grid_grads=True`` accumulates d(loss)/d(grid) into ``grid.grad`` of every
@@ -302,9 +310,11 @@ def nice_render(scene: NiceScene, stage: str, rays_o: torch.Tensor,
     flat = scene.dec_flat.get('color')
     if flat is None or stage != 'color':
         flat = rays_o.new_zeros(0)
+    elif not getattr(scene, 'decoder_trainable', True):
+        flat = flat.detach()  # tracking / mapping_fix_color: no weight grads
     used = {'coarse': (0, ), 'middle': (1, ), 'fine': (1, 2),
             'color': (1, 2, 3)}[stage]
     empty = rays_o.new_zeros(0)
     gl = [scene.grids[GRID_KEYS[i]] if i in used else empty for i in range(4)]
     return _NiceRenderFn.apply(rays_o, rays_d, flat, gl[0], gl[1], gl[2],
-                               gl[3], scene, stage, gt_depth)
+                               gl[3], scene, stage, gt_depth, dmax)

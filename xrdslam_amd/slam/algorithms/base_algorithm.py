@@ -12,9 +12,12 @@ reference's hooks and semantics (slam/algorithms/base_algorithm.py:44-302):
   when bundle adjustment is on (:160-209);
 * pose/keyframe bookkeeping under one re-entrant lock (:51,106-158).
 
-MI355X-side difference: the best-loss pose is tracked on the device and read
+MI355X-side differences: the best-loss pose is tracked on the device and read
 back once per call, instead of one ``loss.cpu().item()`` host sync per tracking
-iteration — same result, no per-iteration stall.
+iteration — same result, no per-iteration stall; and with
+``use_graphs`` the iterations of one stage segment are captured once into a
+hipGraph and replayed (launch-bound inner loop, ~100 small launches per
+iteration otherwise).
 """
 from __future__ import annotations
 
@@ -208,45 +211,183 @@ class Algorithm:
         if not self.is_initialized():
             self.set_initialized()
 
+    # ---- the optimiser loop ------------------------------------------------
+    use_graphs = False  # capture each stage segment into a hipGraph (MI355X)
+    persistent_track_graph = True  # one tracking graph reused across frames
+
+    def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
+        """iterations with equal keys run identical device work (same stage,
+        same learning rates) and may share one captured graph"""
+        return 0
+
+    def _graphs_ok(self, optimizers, is_mapping):
+        from ...engine import dist as _dist
+        if not self.use_graphs or not torch.cuda.is_available():
+            return False
+        if torch.device(self.device).type != 'cuda':
+            return False
+        if is_mapping and _dist.state.enabled:
+            return False  # sharded mapping issues collectives: stay eager
+        for name in optimizers.optimizers:
+            if self.config.optimizers[name]['optimizer'].accum_step is not None \
+                    or self.config.optimizers[name]['optimizer'].max_norm \
+                    is not None:
+                return False
+        for params in optimizers.parameters.values():
+            if any(not p.is_cuda for p in params):
+                return False
+        return not (self.config.retain_graph and is_mapping)
+
+    def _iteration(self, optimizers, optimize_frames, is_mapping, step,
+                   n_iters, coarse, track):
+        optimizers.zero_grad_all()
+        loss = self.get_loss(optimize_frames, is_mapping, step, n_iters,
+                             coarse=coarse)
+        if not is_mapping:
+            # keep the pose that produced the lowest loss (evaluated before
+            # its Adam step, base_algorithm.py:262-265), on the device
+            cur = optimize_frames[-1].get_pose().detach()
+            lval = loss.detach().to(cur.device, torch.float64)
+            better = lval < track['loss']
+            track['c2w'].copy_(torch.where(better, cur, track['c2w']))
+            track['loss'].copy_(torch.where(better, lval, track['loss']))
+            track['valid'].logical_or_(better)
+        loss.backward(retain_graph=(self.config.retain_graph and is_mapping))
+        self.post_processing(step, is_mapping, optimizers.optimizers,
+                             coarse=coarse)
+        optimizers.optimizer_step_all(step=step)
+
+    # ---- persistent tracking graph ---------------------------------------
+    def _track_slot_run(self, n_iters, frame):
+        """Tracking through ONE hipGraph kept across frames.  The graph is
+        captured over an internal slot frame with static device buffers; each
+        new frame is copied into the slot (images, initial pose), the Adam
+        state is re-zeroed (the reference builds a fresh Adam per frame,
+        base_algorithm.py:160-181) and the graph is replayed n_iters times.
+        The caller replaces the frame's pose by the returned best pose
+        (tracker.py:107-112), so optimising a copy is equivalent."""
+        from ..common.frame import Frame
+        dev = self.device
+        slot = getattr(self, '_track_slot', None)
+        shape_key = (frame.h, frame.w, frame.separate_LR, frame.rot_rep,
+                     n_iters)
+        if slot is not None and slot['key'] != shape_key:
+            slot = None
+        init = frame.get_pose().detach()
+        if slot is None:
+            sf = Frame(-1, frame.rgb, frame.depth,
+                       init_pose=init.cpu().numpy(), gt_pose=None,
+                       separate_LR=frame.separate_LR, rot_rep=frame.rot_rep,
+                       device=str(dev))
+            sf.device_images(dev)  # static image buffers
+            slot = {'key': shape_key, 'frame': sf, 'graph': None,
+                    'opt': None, 'track': None}
+            self._track_slot = slot
+        sf = slot['frame']
+        d_dev, c_dev = sf.device_images(dev)
+        d_dev.copy_(torch.as_tensor(frame.depth, dtype=torch.float32)
+                    .reshape(-1, 1), non_blocking=True)
+        c_dev.copy_(torch.as_tensor(frame.rgb, dtype=torch.float32)
+                    .reshape(-1, 3), non_blocking=True)
+        with torch.no_grad():
+            for ps, pf in zip(sf.get_params(), frame.get_params()):
+                ps.copy_(pf.detach().to(ps.device))
+        self.pre_precessing(sf, False)
+        if slot['opt'] is None:
+            slot['opt'] = self.setup_optimizers(n_iters, [sf],
+                                                is_mapping=False)
+            slot['opt'].allreduce = False
+            slot['track'] = {
+                'loss': torch.full((), 10000000000., dtype=torch.float64,
+                                   device=dev),
+                'c2w': torch.zeros(4, 4, device=dev),
+                'valid': torch.zeros((), dtype=torch.bool, device=dev)}
+        else:
+            self.optimizer_config_update(n_iters, False)
+            for opt in slot['opt'].optimizers.values():
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            slot['track']['loss'].fill_(10000000000.)
+            slot['track']['c2w'].zero_()
+            slot['track']['valid'].fill_(False)
+        opt, track = slot['opt'], slot['track']
+        self.fixed_shape_batches = True
+        for step in range(n_iters):
+            if slot['graph'] is None and step == 0:
+                self._iteration(opt, [sf], False, step, n_iters, False, track)
+            elif slot['graph'] is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._iteration(opt, [sf], False, step, n_iters, False,
+                                    track)
+                slot['graph'] = g
+                g.replay()
+            else:
+                slot['graph'].replay()
+        self.fixed_shape_batches = False
+        if not bool(track['valid'].item()):
+            return None
+        return track['c2w'].cpu().numpy()
+
     def optimize_update(self, n_iters, optimize_frames, is_mapping,
                         coarse=False):
         with self.lock:
+            if not is_mapping and self.use_graphs and \
+                    self.persistent_track_graph and len(optimize_frames) == 1 \
+                    and torch.device(self.device).type == 'cuda' and \
+                    all(self.config.optimizers[k]['optimizer'].accum_step is
+                        None and not self.config.optimizers[k].get('scheduler')
+                        for k in self.config.optimizers if
+                        k.startswith('tracking_pose')):
+                return self._track_slot_run(n_iters, optimize_frames[0])
             self.pre_precessing(optimize_frames[-1], is_mapping)
             optimizers = self.setup_optimizers(n_iters, optimize_frames,
                                                is_mapping, coarse=coarse)
             # multi-GPU: mapping gradients are summed over ranks (engine/dist)
             optimizers.allreduce = bool(is_mapping)
-            best_loss = None
-            best_c2w = None
+            track = None
+            if not is_mapping:
+                pdev = optimize_frames[-1].get_pose().device
+                track = {
+                    'loss': torch.full((), 10000000000., dtype=torch.float64,
+                                       device=pdev),
+                    'c2w': torch.zeros(4, 4, device=pdev),
+                    'valid': torch.zeros((), dtype=torch.bool, device=pdev)}
+            graphed = self._graphs_ok(optimizers, is_mapping)
+            self.fixed_shape_batches = graphed
+            seg_key, seg_iter, graph = None, 0, None
             for step in range(n_iters):
-                optimizers.zero_grad_all()
-                loss = self.get_loss(optimize_frames, is_mapping, step,
-                                     n_iters, coarse=coarse)
-                if not is_mapping:
-                    # keep the pose that produced the lowest loss, on device
-                    cur = optimize_frames[-1].get_pose().detach()
-                    lval = loss.detach().to(cur.device)
-                    if best_loss is None:
-                        better = lval < 10000000000.
-                        best_loss = torch.where(
-                            better, lval, torch.full_like(lval, 10000000000.))
-                        best_c2w = cur.clone()
-                        self._track_valid = better
+                if graphed:
+                    key = self.graph_segment_key(is_mapping, step, n_iters,
+                                                 coarse)
+                    if key != seg_key:
+                        seg_key, seg_iter, graph = key, 0, None
+                    if seg_iter == 0:
+                        # first iteration of a segment runs eagerly: lazy
+                        # state (Adam moments, cached frames) gets created
+                        self._iteration(optimizers, optimize_frames,
+                                        is_mapping, step, n_iters, coarse,
+                                        track)
+                    elif graph is None:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            self._iteration(optimizers, optimize_frames,
+                                            is_mapping, step, n_iters, coarse,
+                                            track)
+                        graph.replay()
                     else:
-                        better = lval < best_loss
-                        best_loss = torch.where(better, lval, best_loss)
-                        best_c2w = torch.where(better, cur, best_c2w)
-                        self._track_valid = self._track_valid | better
-                loss.backward(
-                    retain_graph=(self.config.retain_graph and is_mapping))
-                self.post_processing(step, is_mapping, optimizers.optimizers,
-                                     coarse=coarse)
-                optimizers.optimizer_step_all(step=step)
+                        graph.replay()
+                    seg_iter += 1
+                else:
+                    self._iteration(optimizers, optimize_frames, is_mapping,
+                                    step, n_iters, coarse, track)
                 optimizers.scheduler_step_all()
-            if is_mapping or best_c2w is None or \
-                    not bool(self._track_valid.item()):
+            self.fixed_shape_batches = False
+            if is_mapping or not bool(track['valid'].item()):
                 return None
-            return best_c2w.cpu().numpy()
+            return track['c2w'].cpu().numpy()
 
     def select_optimize_frames(self, cur_frame, keyframe_selection_method):
         """window of keyframes to optimise with (base_algorithm.py:277-302)"""

@@ -123,7 +123,10 @@ class NiceSLAM(Algorithm):
             gen = None
         ro, rd, gd, gc = [], [], [], []
         for frame in optimize_frames:
-            o, d, dep, col = get_samples(self.camera, n_pix, frame.get_pose(),
+            c2w = frame.get_pose()
+            if is_mapping and not self.bundle_adjust:
+                c2w = c2w.detach()
+            o, d, dep, col = get_samples(self.camera, n_pix, c2w,
                                          frame.depth, frame.rgb, device=dev,
                                          Hedge=Hedge, Wedge=Wedge, frame=frame,
                                          generator=gen)
@@ -131,15 +134,24 @@ class NiceSLAM(Algorithm):
             rd.append(d.float())
             gd.append(dep.float())
             gc.append(col.float())
+        # poses that no optimiser owns need no gradient (BA off / other frames)
         rays_o, rays_d = torch.cat(ro), torch.cat(rd)
         depth, color = torch.cat(gd), torch.cat(gc)
         # drop rays whose sensor depth lies beyond the bound (nice_slam.py:181-194)
         with torch.no_grad():
-            bb = self.bounding_box.to(dev)
+            if getattr(self, '_bb_dev', None) is None or \
+                    self._bb_dev.device != torch.device(dev):
+                self._bb_dev = self.bounding_box.to(dev)
+            bb = self._bb_dev
             t = (bb.unsqueeze(0) - rays_o.detach().unsqueeze(-1)) / \
                 rays_d.detach().unsqueeze(-1)
             t_exit = t.max(dim=2)[0].min(dim=1)[0]
             keep = t_exit >= depth.squeeze(-1)
+        if getattr(self, 'fixed_shape_batches', False):
+            # no compaction (no host sync, hipGraph friendly): the mask
+            # travels with the batch and is applied in the loss
+            return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': color,
+                    'target_d': depth, 'stage': self.stage, 'ray_mask': keep}
         return {'rays_o': rays_o[keep], 'rays_d': rays_d[keep],
                 'target_s': color[keep], 'target_d': depth[keep],
                 'stage': self.stage}
@@ -156,6 +168,12 @@ class NiceSLAM(Algorithm):
             self.stage = 'fine'
         else:
             self.stage = 'color'
+
+    def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
+        saved = self.stage
+        self.set_stage(is_mapping, step, n_iters, coarse=coarse)
+        key, self.stage = self.stage, saved
+        return key
 
     def get_loss(self, optimize_frames, is_mapping, step, n_iters,
                  coarse=False):

@@ -37,6 +37,10 @@ class OptimizerConfig(PrintableConfig):
                 not kwargs.get('weight_decay', 0):
             return FusedCellAdam(params, lr=self.lr, betas=self.betas,
                                  eps=self.eps)
+        if self._target is torch.optim.Adam and len(params) > 0 and \
+                all(p.is_cuda for p in params):
+            # device-side step counter: the step can be replayed from a graph
+            kwargs['capturable'] = True
         return self._target(params, **kwargs)
 
 
@@ -61,11 +65,12 @@ class FusedCellAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr, betas, eps):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._t = 0
-        self._m = self._v = None
+        self._m = self._v = self._step_dev = None
 
     def zero_grad(self, set_to_none: bool = True):
         # the kernel clears the used gradient cells itself
+        if torch.cuda.is_current_stream_capturing():
+            return
         for g in self.param_groups:
             for p in g['params']:
                 p._xrd_grad_fresh = False
@@ -83,14 +88,17 @@ class FusedCellAdam(torch.optim.Optimizer):
         if self._m is None:
             self._m = torch.zeros(n * cf, dtype=torch.float32, device=p.device)
             self._v = torch.zeros_like(self._m)
-        self._t += 1
+            self._step_dev = torch.zeros(1, dtype=torch.int32,
+                                         device=p.device)
+        self._step_dev += 1  # on the stream: replayable from a hipGraph
         b1, b2 = grp['betas']
-        _lib.check(_lib.lib().xrd_adam_cells(
+        _lib.check(_lib.lib().xrd_adam_cells_devstep(
             _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
             _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
-            float(b1), float(b2), float(grp['eps']), self._t, 1,
-            _lib.stream_ptr(p.device)), 'xrd_adam_cells')
-        p._xrd_grad_fresh = False
+            float(b1), float(b2), float(grp['eps']), _lib.ptr(self._step_dev),
+            1, _lib.stream_ptr(p.device)), 'xrd_adam_cells_devstep')
+        if not torch.cuda.is_current_stream_capturing():
+            p._xrd_grad_fresh = False
 
 
 class Optimizers:

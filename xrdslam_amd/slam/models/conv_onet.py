@@ -211,6 +211,9 @@ class ConvOnet(Model):
         for g in self.grid_c.values():
             if g.is_leaf:
                 g.requires_grad_(flag)
+        if self._scene is not None:
+            self._scene.decoder_trainable = bool(flag) and \
+                not self.config.mapping_fix_color
 
     def grid_processing(self, coarse):
         """no-op: the grids are optimised in place (the reference writes the
@@ -249,8 +252,15 @@ class ConvOnet(Model):
     def get_outputs(self, input) -> Dict[str, Union[torch.Tensor, List]]:
         stage = input['stage']
         target_d = None if stage == 'coarse' else input['target_d']
+        dmax = None
+        keep = input.get('ray_mask')
+        if keep is not None and target_d is not None:
+            # un-compacted batch: rays with ray_mask=False are rendered but
+            # take no part in max(gt_depth) (conv_onet.py:418,455) or the loss
+            dmax = torch.where(keep, target_d.reshape(-1),
+                               torch.zeros_like(target_d.reshape(-1))).max()
         depth, var, rgb = _en.nice_render(self.scene(), stage, input['rays_o'],
-                                          input['rays_d'], target_d)
+                                          input['rays_d'], target_d, dmax=dmax)
         return {'rgb': rgb, 'depth': depth, 'uncertainty': var}
 
     def get_loss_dict(self, outputs, inputs, is_mapping,
@@ -265,6 +275,10 @@ class ConvOnet(Model):
         d, c = outputs['depth'], outputs['rgb']
         unc = outputs['uncertainty'].detach()
         losses = {}
+        rmask = inputs.get('ray_mask')
+        if rmask is not None:
+            return self._masked_loss_dict(gt_d, gt_c, d, c, unc, rmask,
+                                          is_mapping, stage)
         if not is_mapping:
             res = (gt_d - d).abs() / torch.sqrt(unc + 1e-10)
             keep = gt_d > 0
@@ -280,6 +294,41 @@ class ConvOnet(Model):
             if stage == 'color':
                 losses['rgb_loss'] = cfg.mapping_w_color_loss * \
                     (gt_c - c).abs().sum()
+        return losses
+
+    def _masked_loss_dict(self, gt_d, gt_c, d, c, unc, rmask, is_mapping,
+                          stage):
+        """the same losses on an un-compacted batch (fixed shapes, no host
+        sync: usable inside a captured hipGraph).  ``rmask`` marks the rays
+        the reference would have kept (nice_slam.py:181-194); the median is
+        the lower median of the kept residuals like torch.median."""
+        cfg = self.config
+        losses = {}
+        zero = torch.zeros((), dtype=d.dtype, device=d.device)
+        if not is_mapping:
+            res = (gt_d - d).abs() / torch.sqrt(unc + 1e-10)
+            keep = (gt_d > 0) & rmask
+            if cfg.tracking_handle_dynamic:
+                inf = torch.full_like(res, float('inf'))
+                srt = torch.sort(torch.where(rmask, res, inf)).values
+                cnt = rmask.sum()
+                mid = torch.div((cnt - 1).clamp(min=0), 2,
+                                rounding_mode='floor').reshape(1)
+                med = srt.gather(0, mid).reshape(())
+                keep = (res < 10 * med) & keep
+            losses['depth_loss'] = torch.where(keep, res, zero).sum()
+            if cfg.tracking_use_color_in_tracking:
+                losses['rgb_loss'] = cfg.tracking_w_color_loss * torch.where(
+                    keep[:, None], (gt_c - c).abs(),
+                    torch.zeros((), dtype=c.dtype, device=c.device)).sum()
+        else:
+            keep = (gt_d > 0) & rmask
+            losses['depth_loss'] = torch.where(keep, (gt_d - d).abs(),
+                                               zero).sum()
+            if stage == 'color':
+                losses['rgb_loss'] = cfg.mapping_w_color_loss * torch.where(
+                    rmask[:, None], (gt_c - c).abs(),
+                    torch.zeros((), dtype=c.dtype, device=c.device)).sum()
         return losses
 
     # -- mesher hooks (conv_onet.py:213-240): next row, not built yet -------
