@@ -138,6 +138,41 @@ int xrd_adam_cells_devstep(float* param, float* g, float* m, float* v,
  * process before capturing launches into a hipGraph */
 int xrd_nice_warmup(void);
 
+/* ------------------------------------------------------------------------
+ * Co-SLAM encodings — replace the tiny-cuda-nn modules the reference
+ * instantiates in slam/model_components/encodings_coslam.py:43-53 (HashGrid,
+ * 16 levels x 2 features) and :68-75 (OneBlob, 16 bins); used by
+ * slam/models/joint_encoding.py:212-234,439-481.  fp32 parameters
+ * (dtype=torch.float).  tiny-cuda-nn is an unvendored dependency of the
+ * reference: arithmetic per SURVEY.md Appendix C.1 / C.2.
+ * ---------------------------------------------------------------------- */
+/* HOST: per-level table of a multi-resolution grid.  scale_l =
+ * exp2f(l*log2f(per_level_scale))*base_resolution - 1; res_l = ceilf(scale)+1;
+ * size_l = min(align8(res_l^3), 2^log2_hashmap_size) (dense != 0: no cap);
+ * offsets are in entries (each entry = 2 floats). */
+int xrd_hashgrid_levels(int n_levels, int base_resolution,
+                        float per_level_scale, int log2_hashmap_size,
+                        int dense, float* scales, uint32_t* res,
+                        uint32_t* sizes, uint32_t* offsets,
+                        uint32_t* total_entries);
+/* y[n,2*L] = encode(x[n,3] in [0,1]); level table arrays are HOST pointers */
+int xrd_hashgrid_fwd(int n_levels, const float* scales, const uint32_t* res,
+                     const uint32_t* sizes, const uint32_t* offsets,
+                     int64_t n_points, const float* x, const float* params,
+                     float* y, xrd_stream_t stream);
+/* dparams (ACCUMULATED, atomics; may be NULL), dx[n,3] (overwritten; may be
+ * NULL) from dy[n,2*L] */
+int xrd_hashgrid_bwd(int n_levels, const float* scales, const uint32_t* res,
+                     const uint32_t* sizes, const uint32_t* offsets,
+                     int64_t n_points, const float* x, const float* params,
+                     const float* dy, float* dparams, float* dx,
+                     xrd_stream_t stream);
+/* OneBlob: y[n,dims*n_bins] (dimension-major), quartic kernel, periodic */
+int xrd_oneblob_fwd(int64_t n_points, int dims, int n_bins, const float* x,
+                    float* y, xrd_stream_t stream);
+int xrd_oneblob_bwd(int64_t n_points, int dims, int n_bins, const float* x,
+                    const float* dy, float* dx, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

@@ -46,6 +46,14 @@ _SIGS = {
     'xrd_adam_cells_devstep': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32,
                                          f32, f32, f32, vp, C.c_int, vp]),
     'xrd_nice_warmup': (C.c_int, []),
+    'xrd_hashgrid_levels': (C.c_int, [C.c_int, C.c_int, f32, C.c_int, C.c_int,
+                                      vp, vp, vp, vp, vp]),
+    'xrd_hashgrid_fwd': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, vp, vp,
+                                   vp]),
+    'xrd_hashgrid_bwd': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, vp, vp,
+                                   vp, vp, vp]),
+    'xrd_oneblob_fwd': (C.c_int, [i64, C.c_int, C.c_int, vp, vp, vp]),
+    'xrd_oneblob_bwd': (C.c_int, [i64, C.c_int, C.c_int, vp, vp, vp, vp]),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

@@ -1,0 +1,280 @@
+// Multi-resolution hash-grid and OneBlob encodings for gfx950 — the two
+// tiny-cuda-nn encodings Co-SLAM instantiates
+// (slam/model_components/encodings_coslam.py:43-53, 68-75).  tiny-cuda-nn is
+// not vendored in the reference; the arithmetic follows SURVEY.md App. C.1/C.2
+// (oracle: oracle/tcnn_oracle.py, parity unpinned by the reference).
+//
+// HBM/cache-bound gathers: 16 levels x 8 corners x 8 B per point.  Lane
+// mapping: 16 consecutive lanes = the 16 levels of ONE point, so the [N,32]
+// output row (and dL/dy) is one coalesced 128-B line per point and the three
+// coordinates are a broadcast load.
+#include "common.h"
+
+namespace xrd {
+namespace {
+
+struct HashLevel {
+  float scale;
+  uint32_t res;
+  uint32_t size;    // entries in this level
+  uint32_t offset;  // first entry
+};
+constexpr int kMaxLevels = 32;
+struct HashMeta {
+  HashLevel lv[kMaxLevels];
+  int n_levels;
+};
+
+__device__ __forceinline__ uint32_t grid_index(const HashLevel& L, uint32_t cx,
+                                               uint32_t cy, uint32_t cz) {
+  // tcnn grid_index: dense strides while stride <= size, otherwise the
+  // coherent prime hash; always modulo the level size
+  uint64_t stride = 1;
+  uint32_t idx = 0;
+  const uint32_t c[3] = {cx, cy, cz};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (stride <= L.size) {
+      idx += c[d] * (uint32_t)stride;
+      stride *= L.res;
+    }
+  }
+  if ((uint64_t)L.size < stride)
+    idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+  return idx % L.size;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void hashgrid_kernel(
+    HashMeta M, int64_t n, const float* __restrict__ x,
+    const float* __restrict__ params, float* __restrict__ y,
+    const float* __restrict__ dy, float* __restrict__ dparams,
+    float* __restrict__ dx) {
+  const int L = M.n_levels;  // <= 16 levels per 16-lane group per pass
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lvl_lane = threadIdx.x & 15;
+  const int64_t pt = gid >> 4;
+  const bool pvalid = pt < n;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (pvalid) {
+    px = x[pt * 3 + 0];
+    py = x[pt * 3 + 1];
+    pz = x[pt * 3 + 2];
+  }
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  for (int lvl = lvl_lane; lvl < L; lvl += 16) {
+    if (!pvalid) break;
+    const HashLevel lv = M.lv[lvl];
+    const float fx = fmaf(lv.scale, px, 0.5f), fy = fmaf(lv.scale, py, 0.5f),
+                fz = fmaf(lv.scale, pz, 0.5f);
+    const float ffx = floorf(fx), ffy = floorf(fy), ffz = floorf(fz);
+    const uint32_t cx = (uint32_t)(int)ffx, cy = (uint32_t)(int)ffy,
+                   cz = (uint32_t)(int)ffz;
+    const float wx = fx - ffx, wy = fy - ffy, wz = fz - ffz;
+    float2 acc = {0.f, 0.f};
+    float2 g = {0.f, 0.f};
+    if (BWD) g = *reinterpret_cast<const float2*>(dy + pt * (2 * L) + 2 * lvl);
+    float dgx = 0.f, dgy = 0.f, dgz = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+      const float ax = bx ? wx : 1.f - wx, ay = by ? wy : 1.f - wy,
+                  az = bz ? wz : 1.f - wz;
+      const uint32_t idx = lv.offset + grid_index(lv, cx + bx, cy + by, cz + bz);
+      const float2 v = *reinterpret_cast<const float2*>(params + 2 * (size_t)idx);
+      if (!BWD) {
+        const float w = ax * ay * az;
+        acc.x = fmaf(w, v.x, acc.x);
+        acc.y = fmaf(w, v.y, acc.y);
+      } else {
+        const float w = ax * ay * az;
+        if (dparams != nullptr) {
+          atomicAdd(dparams + 2 * (size_t)idx, w * g.x);
+          atomicAdd(dparams + 2 * (size_t)idx + 1, w * g.y);
+        }
+        if (dx != nullptr) {
+          const float dv = v.x * g.x + v.y * g.y;
+          dgx += (bx ? 1.f : -1.f) * ay * az * dv;
+          dgy += (by ? 1.f : -1.f) * ax * az * dv;
+          dgz += (bz ? 1.f : -1.f) * ax * ay * dv;
+        }
+      }
+    }
+    if (!BWD) {
+      *reinterpret_cast<float2*>(y + pt * (2 * L) + 2 * lvl) = acc;
+    } else {
+      gx = fmaf(lv.scale, dgx, gx);
+      gy = fmaf(lv.scale, dgy, gy);
+      gz = fmaf(lv.scale, dgz, gz);
+    }
+  }
+  if (BWD && dx != nullptr) {
+    // sum over the 16 level lanes of the point
+    gx = row16_sum(gx);
+    gy = row16_sum(gy);
+    gz = row16_sum(gz);
+    if (pvalid && lvl_lane == 0) {
+      dx[pt * 3 + 0] = gx;
+      dx[pt * 3 + 1] = gy;
+      dx[pt * 3 + 2] = gz;
+    }
+  }
+}
+
+__device__ __forceinline__ float quartic_cdf(float x, float inv_r) {
+  const float u = x * inv_r, u2 = u * u, u4 = u2 * u2;
+  return fminf(fmaxf((15.f / 16.f) * u * (1.f - (2.f / 3.f) * u2 +
+                                          (1.f / 5.f) * u4) + 0.5f, 0.f), 1.f);
+}
+__device__ __forceinline__ float quartic_pdf(float x, float inv_r) {
+  const float u = x * inv_r;
+  if (fabsf(u) >= 1.f) return 0.f;
+  const float t = 1.f - u * u;
+  return (15.f / 16.f) * t * t * inv_r;
+}
+
+// one thread per (point, dim); writes/reads n_bins contiguous values
+template <bool BWD>
+__global__ __launch_bounds__(256) void oneblob_kernel(
+    int64_t n, int dims, int n_bins, const float* __restrict__ x,
+    float* __restrict__ y, const float* __restrict__ dy,
+    float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dims) return;
+  const float v = x[i];
+  const float nb = (float)n_bins;
+  const int64_t base = i * n_bins;  // [N][dims][n_bins]
+  if (!BWD) {
+    float left = quartic_cdf(-v, nb) + quartic_cdf(-v - 1.f, nb) +
+                 quartic_cdf(-v + 1.f, nb);
+    for (int k = 0; k < n_bins; ++k) {
+      const float rb = (float)(k + 1) / nb - v;
+      const float right = quartic_cdf(rb, nb) + quartic_cdf(rb - 1.f, nb) +
+                          quartic_cdf(rb + 1.f, nb);
+      y[base + k] = right - left;
+      left = right;
+    }
+  } else {
+    // d/dx cdf(t - x) = -pdf(t - x)
+    float left = quartic_pdf(-v, nb) + quartic_pdf(-v - 1.f, nb) +
+                 quartic_pdf(-v + 1.f, nb);
+    float g = 0.f;
+    for (int k = 0; k < n_bins; ++k) {
+      const float rb = (float)(k + 1) / nb - v;
+      const float right = quartic_pdf(rb, nb) + quartic_pdf(rb - 1.f, nb) +
+                          quartic_pdf(rb + 1.f, nb);
+      g += dy[base + k] * (-(right - left));
+      left = right;
+    }
+    dx[i] = g;
+  }
+}
+
+int fill_meta(HashMeta& M, int n_levels, const float* scales,
+              const uint32_t* res, const uint32_t* sizes,
+              const uint32_t* offsets) {
+  if (n_levels < 1 || n_levels > kMaxLevels || !scales || !res || !sizes ||
+      !offsets)
+    return XRD_ERR_ARG;
+  M.n_levels = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    if (sizes[l] == 0 || res[l] == 0) return XRD_ERR_ARG;
+    M.lv[l] = HashLevel{scales[l], res[l], sizes[l], offsets[l]};
+  }
+  return XRD_OK;
+}
+
+}  // namespace
+}  // namespace xrd
+
+using namespace xrd;
+
+extern "C" {
+
+int xrd_hashgrid_levels(int n_levels, int base_resolution,
+                        float per_level_scale, int log2_hashmap_size,
+                        int dense, float* scales, uint32_t* res,
+                        uint32_t* sizes, uint32_t* offsets,
+                        uint32_t* total_entries) {
+  if (n_levels < 1 || n_levels > kMaxLevels || !scales || !res || !sizes ||
+      !offsets || !total_entries)
+    return XRD_ERR_ARG;
+  const float log2_pls = log2f(per_level_scale);
+  uint64_t off = 0;
+  const uint64_t cap = 1ull << log2_hashmap_size;
+  for (int l = 0; l < n_levels; ++l) {
+    const float scale = exp2f((float)l * log2_pls) * (float)base_resolution - 1.0f;
+    const uint32_t r = (uint32_t)ceilf(scale) + 1u;
+    uint64_t n = (uint64_t)r * r * r;
+    n = (n + 7) / 8 * 8;
+    if (!dense && n > cap) n = cap;
+    if (n > 0xffffffffull || off + n > 0xffffffffull) return XRD_ERR_UNSUPPORTED;
+    scales[l] = scale;
+    res[l] = r;
+    sizes[l] = (uint32_t)n;
+    offsets[l] = (uint32_t)off;
+    off += n;
+  }
+  *total_entries = (uint32_t)off;
+  return XRD_OK;
+}
+
+int xrd_hashgrid_fwd(int n_levels, const float* scales, const uint32_t* res,
+                     const uint32_t* sizes, const uint32_t* offsets,
+                     int64_t n_points, const float* x, const float* params,
+                     float* y, xrd_stream_t stream) {
+  HashMeta M;
+  int rc = fill_meta(M, n_levels, scales, res, sizes, offsets);
+  if (rc != XRD_OK) return rc;
+  if (n_points < 0 || (n_points > 0 && (!x || !params || !y))) return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  const int64_t threads = n_points * 16;
+  hipLaunchKernelGGL((hashgrid_kernel<false>), dim3((unsigned)((threads + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, M, n_points, x, params,
+                     y, nullptr, nullptr, nullptr);
+  return check_launch("xrd_hashgrid_fwd");
+}
+
+int xrd_hashgrid_bwd(int n_levels, const float* scales, const uint32_t* res,
+                     const uint32_t* sizes, const uint32_t* offsets,
+                     int64_t n_points, const float* x, const float* params,
+                     const float* dy, float* dparams, float* dx,
+                     xrd_stream_t stream) {
+  HashMeta M;
+  int rc = fill_meta(M, n_levels, scales, res, sizes, offsets);
+  if (rc != XRD_OK) return rc;
+  if (n_points < 0 || (n_points > 0 && (!x || !params || !dy))) return XRD_ERR_ARG;
+  if (n_points == 0 || (!dparams && !dx)) return XRD_OK;
+  const int64_t threads = n_points * 16;
+  hipLaunchKernelGGL((hashgrid_kernel<true>), dim3((unsigned)((threads + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, M, n_points, x, params,
+                     nullptr, dy, dparams, dx);
+  return check_launch("xrd_hashgrid_bwd");
+}
+
+int xrd_oneblob_fwd(int64_t n_points, int dims, int n_bins, const float* x,
+                    float* y, xrd_stream_t stream) {
+  if (n_points < 0 || dims < 1 || n_bins < 1 || (n_points > 0 && (!x || !y)))
+    return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  const int64_t t = n_points * dims;
+  hipLaunchKernelGGL((oneblob_kernel<false>), dim3((unsigned)((t + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, n_points, dims, n_bins,
+                     x, y, nullptr, nullptr);
+  return check_launch("xrd_oneblob_fwd");
+}
+
+int xrd_oneblob_bwd(int64_t n_points, int dims, int n_bins, const float* x,
+                    const float* dy, float* dx, xrd_stream_t stream) {
+  if (n_points < 0 || dims < 1 || n_bins < 1 ||
+      (n_points > 0 && (!x || !dy || !dx)))
+    return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  const int64_t t = n_points * dims;
+  hipLaunchKernelGGL((oneblob_kernel<true>), dim3((unsigned)((t + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, n_points, dims, n_bins,
+                     x, nullptr, dy, dx);
+  return check_launch("xrd_oneblob_bwd");
+}
+
+}  // extern "C"
