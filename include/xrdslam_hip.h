@@ -173,6 +173,35 @@ int xrd_oneblob_fwd(int64_t n_points, int dims, int n_bins, const float* x,
 int xrd_oneblob_bwd(int64_t n_points, int dims, int n_bins, const float* x,
                     const float* dy, float* dx, xrd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Vox-Fusion sparse voxel octree (HOST) — replaces the TorchScript class
+ * torch.classes.svo.Octree (third_party/sparse_octree/src/bindings.cpp:8-31,
+ * src/octree.cpp).  Node ids are the creation order of a PROCESS-GLOBAL
+ * counter like the reference's static Octant::next_index_ (octree.cpp:9);
+ * xrd_octree_reset_id_counter() is what the reference's unpickle constructor
+ * does (octree.cpp:22).  Not thread-safe (the reference neither: callers hold
+ * SparseVoxel.map_lock).  voxels are int32 [n,3] HOST arrays.
+ * ---------------------------------------------------------------------- */
+void* xrd_octree_create(int grid_dim, int feat_dim, double voxel_size);
+void xrd_octree_destroy(void* tree);
+void xrd_octree_reset_id_counter(void);
+/* insert(Tensor[N,3] int32): *created_any = 1 when a node was created */
+int xrd_octree_insert(void* tree, const int32_t* voxels, int64_t n,
+                      int* created_any);
+/* try_insert: fraction of the batch's corner keys already in the tree */
+double xrd_octree_try_insert(void* tree, const int32_t* voxels, int64_t n);
+int xrd_octree_has_voxel(void* tree, const int32_t* xyz);
+int64_t xrd_octree_count_nodes(void* tree);
+int64_t xrd_octree_count_leaf_nodes(void* tree);
+/* get_centres_and_children: voxels f32[T,4], children f32[T,8] (ids, -1),
+ * features i32[T,8] (corner-leaf ids of SURFACE leaves), T = count_nodes */
+int xrd_octree_export(void* tree, float* voxels, float* children,
+                      int32_t* features);
+/* get_voxels / get_leaf_voxels: return the row count; fill up to cap_rows */
+int64_t xrd_octree_get_voxels(void* tree, float* out_xyzs, int64_t cap_rows);
+int64_t xrd_octree_get_leaf_voxels(void* tree, float* out_xyz,
+                                   int64_t cap_rows);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

@@ -154,9 +154,70 @@ def make_nice():
     print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
 
 
-MAKERS = {'nice': make_nice}
+# ---------------------------------------------------------------------------
+# Vox-Fusion octree: golden from the COMPILED reference (oracle/_ref)
+# ---------------------------------------------------------------------------
+def _octree_scenario(which):
+    """voxel batches for one scenario (seeded)"""
+    rng = np.random.default_rng(100 + which)
+    if which == 0:
+        # clustered random voxels, three batches with duplicates
+        base = rng.integers(40, 90, size=(2000, 3))
+        b0 = base[:900]
+        b1 = np.concatenate([base[600:1500], base[:50]])
+        b2 = base[1200:]
+        return [b0, b1, b2]
+    # a wall seen by a 'camera': many duplicate voxels per batch + offset 10 m
+    u, v = np.meshgrid(np.arange(0, 64), np.arange(0, 48))
+    pts = np.stack([50 + (u * 0.13).astype(int), 50 + (v * 0.17).astype(int),
+                    np.full_like(u, 62) + (u // 40)], -1).reshape(-1, 3)
+    return [pts, pts[::-1].copy(), pts + np.array([3, 0, 1])]
+
+
+def _run_octree_scenario(which, out_path):
+    import build_ref_octree
+    Octree = build_ref_octree.load()
+    tree = Octree()
+    tree.init(256, 16, 0.2)
+    out = {}
+    batches = _octree_scenario(which)
+    rng = np.random.default_rng(7 + which)
+    for bi, b in enumerate(batches):
+        bt = torch.from_numpy(b.astype(np.int32)).contiguous()
+        out[f'batch{bi}'] = b.astype(np.int32)
+        out[f'try{bi}'] = np.float64(tree.try_insert(bt))
+        tree.insert(bt)
+        vox, ch, ft = tree.get_centres_and_children()
+        out[f'voxels{bi}'] = vox.numpy()
+        out[f'children{bi}'] = ch.numpy()
+        out[f'features{bi}'] = ft.numpy()
+        out[f'count{bi}'] = np.int64(tree.count_nodes())
+        out[f'leaves{bi}'] = np.int64(tree.count_leaf_nodes())
+    q = np.concatenate([batches[0][:20] + rng.integers(-1, 2, size=(20, 3)),
+                        rng.integers(0, 255, size=(20, 3))]).astype(np.int32)
+    out['query'] = q
+    out['has'] = np.array([tree.has_voxel(torch.from_numpy(x)) for x in q])
+    out['get_voxels'] = tree.get_voxels().numpy()
+    out['get_leaf_voxels'] = tree.get_leaf_voxels().numpy()
+    np.savez_compressed(out_path, **out)
+
+
+def make_octree():
+    import subprocess
+    for which in (0, 1):
+        path = os.path.join(GOLD, f'octree_{which}.npz')
+        # one process per scenario: node ids come from a process-global counter
+        subprocess.check_call([sys.executable, os.path.abspath(__file__),
+                               '_octree_scenario', str(which), path])
+        print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+MAKERS = {'nice': make_nice, 'octree': make_octree}
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == '_octree_scenario':
+        _run_octree_scenario(int(sys.argv[2]), sys.argv[3])
+        sys.exit(0)
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     os.makedirs(GOLD, exist_ok=True)
     for k, fn in MAKERS.items():

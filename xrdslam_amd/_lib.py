@@ -54,6 +54,17 @@ _SIGS = {
                                    vp, vp, vp]),
     'xrd_oneblob_fwd': (C.c_int, [i64, C.c_int, C.c_int, vp, vp, vp]),
     'xrd_oneblob_bwd': (C.c_int, [i64, C.c_int, C.c_int, vp, vp, vp, vp]),
+    'xrd_octree_create': (vp, [C.c_int, C.c_int, f64]),
+    'xrd_octree_destroy': (None, [vp]),
+    'xrd_octree_reset_id_counter': (None, []),
+    'xrd_octree_insert': (C.c_int, [vp, vp, i64, vp]),
+    'xrd_octree_try_insert': (f64, [vp, vp, i64]),
+    'xrd_octree_has_voxel': (C.c_int, [vp, vp]),
+    'xrd_octree_count_nodes': (i64, [vp]),
+    'xrd_octree_count_leaf_nodes': (i64, [vp]),
+    'xrd_octree_export': (C.c_int, [vp, vp, vp, vp]),
+    'xrd_octree_get_voxels': (i64, [vp, vp, i64]),
+    'xrd_octree_get_leaf_voxels': (i64, [vp, vp, i64]),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 
