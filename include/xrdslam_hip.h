@@ -202,6 +202,37 @@ int64_t xrd_octree_get_voxels(void* tree, float* out_xyzs, int64_t cap_rows);
 int64_t xrd_octree_get_leaf_voxels(void* tree, float* out_xyz,
                                    int64_t cap_rows);
 
+/* ------------------------------------------------------------------------
+ * Vox-Fusion ray/octree kernels — replace the two live functions of the
+ * pybind module `grid` (third_party/sparse_voxels/src/binding.cpp:10-21):
+ *   svo_intersect        (src/intersect.cpp:83-112, intersect_gpu.cu:191-270)
+ *   inverse_cdf_sampling (src/sample.cpp:56-95,     sample_gpu.cu:133-239)
+ * Same shapes, hit order, sentinels and quirks; voxel ids bit-exact.
+ * ---------------------------------------------------------------------- */
+/* ray_start, ray_dir [B,M,3] f32; points [B,N,3] f32 node centres, children
+ * [B,N,9] i32 (8 child ids, side) — or ONE tree [N,..] shared by all batches
+ * when tree_shared != 0 (the reference needs B replicas); out idx [B,M,n_max]
+ * i32 (-1 padded, DFS hit order), min_depth/max_depth [B,M,n_max] f32 (only
+ * hit slots are written: pre-zero like intersect.cpp:98-106).  overflow_flag
+ * (optional device int) is set if a ray's DFS stack exceeded 128 entries
+ * (the reference asserts < 256; 256^3 trees need 57). */
+int xrd_svo_intersect(int b, int n_nodes, int m_rays, float voxelsize,
+                      int n_max, int tree_shared, const float* ray_start,
+                      const float* ray_dir, const float* points,
+                      const int32_t* children, int32_t* idx, float* min_depth,
+                      float* max_depth, int32_t* overflow_flag,
+                      xrd_stream_t stream);
+/* pts_idx [G,R,P] i32, min/max_depth, probs [G,R,P] f32, steps [G,R] f32,
+ * uniform_noise [G,R,S] f32 -> sampled_idx i32, sampled_depth, sampled_dists
+ * f32 [G,R,S]; outputs must be pre-filled (-1, 0, 0) like sample.cpp:77-86. */
+int xrd_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
+                             float fixed_step_size, const int32_t* pts_idx,
+                             const float* min_depth, const float* max_depth,
+                             const float* uniform_noise, const float* probs,
+                             const float* steps, int32_t* sampled_idx,
+                             float* sampled_depth, float* sampled_dists,
+                             xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

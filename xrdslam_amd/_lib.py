@@ -65,6 +65,12 @@ _SIGS = {
     'xrd_octree_export': (C.c_int, [vp, vp, vp, vp]),
     'xrd_octree_get_voxels': (i64, [vp, vp, i64]),
     'xrd_octree_get_leaf_voxels': (i64, [vp, vp, i64]),
+    'xrd_svo_intersect': (C.c_int, [C.c_int, C.c_int, C.c_int, f32, C.c_int,
+                                    C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                    vp]),
+    'xrd_inverse_cdf_sampling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int,
+                                           f32, vp, vp, vp, vp, vp, vp, vp,
+                                           vp, vp, vp]),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

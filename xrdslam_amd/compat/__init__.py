@@ -8,6 +8,7 @@ import sys
 
 _NAMES = {
     'tinycudann': 'xrdslam_amd.compat.tinycudann',
+    'grid': 'xrdslam_amd.compat.grid',
 }
 
 
