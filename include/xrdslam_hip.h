@@ -233,6 +233,64 @@ int xrd_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
                              float* sampled_depth, float* sampled_dists,
                              xrd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * SplaTAM Gaussian rasteriser — replaces the unvendored CUDA module
+ * diff_gaussian_rasterization (-w-depth @ cb65e4b): GaussianRasterizer(
+ * raster_settings)(means3D, means2D, opacities, colors_precomp, scales,
+ * rotations) -> (color[3,H,W], radii[N], depth[1,H,W]); reference call sites
+ * slam/model_components/gaussian_cloud_splatam.py:63-69,267-268 and
+ * slam/common/common.py:592-619 (GaussianRasterizationSettings).
+ * The pipeline is exposed phase by phase; the inclusive scan of
+ * tiles_touched and the 64-bit key sort between phases are the caller's
+ * (rocPRIM via torch.cumsum / torch.sort in the Python shim).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t image_height, image_width;
+  float tanfovx, tanfovy;
+  float bg[3];
+  float scale_modifier;
+  float viewmatrix[16]; /* w2c TRANSPOSED, as common.py:599 passes it */
+  float projmatrix[16]; /* (proj @ w2c) TRANSPOSED, common.py:605       */
+} xrd_gs_camera;
+
+/* per Gaussian: view depth, pixel centre xy[N,2], conic+opacity[N,4], 3-sigma
+ * radius (0 = culled), tile rectangle rect[N,4]=(x0,y0,x1,y1), tile count */
+int xrd_gs_preprocess(const xrd_gs_camera* cam, int n, const float* means3D,
+                      const float* scales, const float* rotations,
+                      const float* opacities, float* depths, float* xy,
+                      float* conic_opacity, int32_t* radii, int32_t* rect,
+                      int32_t* tiles_touched, xrd_stream_t stream);
+/* keys[i] = (tile_id << 32) | float_bits(depth), values[i] = Gaussian id, at
+ * the offsets given by the INCLUSIVE scan of tiles_touched */
+int xrd_gs_duplicate_keys(int n, int image_width, const int32_t* rect,
+                          const int64_t* offsets_inclusive,
+                          const float* depths, int64_t* keys, int32_t* values,
+                          xrd_stream_t stream);
+/* ranges[tile] = [start,end) in the sorted list; pre-zero ranges */
+int xrd_gs_tile_ranges(int64_t n_keys, const int64_t* sorted_keys,
+                       int32_t* ranges, xrd_stream_t stream);
+int xrd_gs_render_fwd(const xrd_gs_camera* cam, const int32_t* ranges,
+                      const int32_t* point_list, const float* xy,
+                      const float* colors, const float* conic_opacity,
+                      const float* depths, float* out_color, float* out_depth,
+                      float* final_T, int32_t* n_contrib, xrd_stream_t stream);
+/* per-Gaussian gradients are ACCUMULATED (pre-zero): dL_dmean2D[N,2] (w.r.t.
+ * ndc, i.e. what the CUDA module reports as means2D.grad), dL_dconic[N,3]
+ * (true partials w.r.t. conic a,b,c), dL_dopacity[N], dL_dcolors[N,3] */
+int xrd_gs_render_bwd(const xrd_gs_camera* cam, const int32_t* ranges,
+                      const int32_t* point_list, const float* xy,
+                      const float* conic_opacity, const float* colors,
+                      const float* final_T, const int32_t* n_contrib,
+                      const float* dL_dcolor, float* dL_dmean2D,
+                      float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
+                      xrd_stream_t stream);
+int xrd_gs_preprocess_bwd(const xrd_gs_camera* cam, int n,
+                          const float* means3D, const float* scales,
+                          const float* rotations, const int32_t* radii,
+                          const float* dL_dmean2D, const float* dL_dconic,
+                          float* dL_dmeans3D, float* dL_dscales,
+                          float* dL_drotations, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

@@ -71,8 +71,23 @@ _SIGS = {
     'xrd_inverse_cdf_sampling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int,
                                            f32, vp, vp, vp, vp, vp, vp, vp,
                                            vp, vp, vp]),
+    'xrd_gs_preprocess': (C.c_int, [vp, C.c_int] + [vp] * 11),
+    'xrd_gs_duplicate_keys': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp,
+                                        vp]),
+    'xrd_gs_tile_ranges': (C.c_int, [i64, vp, vp, vp]),
+    'xrd_gs_render_fwd': (C.c_int, [vp] * 12),
+    'xrd_gs_render_bwd': (C.c_int, [vp] * 14),
+    'xrd_gs_preprocess_bwd': (C.c_int, [vp, C.c_int] + [vp] * 10),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
+
+
+class GsCamera(C.Structure):
+    """mirror of ``xrd_gs_camera``"""
+    _fields_ = [('image_height', i32), ('image_width', i32),
+                ('tanfovx', f32), ('tanfovy', f32), ('bg', f32 * 3),
+                ('scale_modifier', f32), ('viewmatrix', f32 * 16),
+                ('projmatrix', f32 * 16)]
 
 
 def declared_symbols():

@@ -9,6 +9,8 @@ import sys
 _NAMES = {
     'tinycudann': 'xrdslam_amd.compat.tinycudann',
     'grid': 'xrdslam_amd.compat.grid',
+    'diff_gaussian_rasterization':
+    'xrdslam_amd.compat.diff_gaussian_rasterization',
 }
 
 

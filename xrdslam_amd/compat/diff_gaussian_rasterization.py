@@ -1,0 +1,172 @@
+"""``diff_gaussian_rasterization``-compatible module backed by the HIP
+rasteriser (csrc/gs_raster.hip).
+
+Interface used by the reference (slam/common/common.py:606-618,
+slam/model_components/gaussian_cloud_splatam.py:63-69,267-268):
+
+    settings = GaussianRasterizationSettings(image_height, image_width,
+        tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
+        sh_degree, campos, prefiltered)
+    color, radii, depth = GaussianRasterizer(raster_settings=settings)(
+        means3D=..., means2D=..., opacities=..., colors_precomp=...,
+        scales=..., rotations=...)
+
+autograd reaches means3D, colors_precomp, opacities, scales, rotations and the
+dummy ``means2D`` (its gradient = d loss / d ndc.xy, read by SplaTAM's
+densification statistics, slam_external_splatam.py:99-103).  The depth output
+carries no gradient (SplaTAM renders (z,1,z^2) as colours for that).  Only the
+``colors_precomp`` / ``scales+rotations`` path is built (sh_degree 0,
+no cov3D_precomp), which is what the reference uses."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+
+
+def _camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
+    cam = _lib.GsCamera()
+    cam.image_height, cam.image_width = int(rs.image_height), \
+        int(rs.image_width)
+    cam.tanfovx, cam.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    bg = rs.bg.detach().float().cpu().reshape(-1).tolist()
+    vm = rs.viewmatrix.detach().float().cpu().reshape(-1).tolist()
+    pm = rs.projmatrix.detach().float().cpu().reshape(-1).tolist()
+    for i in range(3):
+        cam.bg[i] = bg[i]
+    cam.scale_modifier = float(rs.scale_modifier)
+    for i in range(16):
+        cam.viewmatrix[i] = vm[i]
+        cam.projmatrix[i] = pm[i]
+    return cam
+
+
+class _RasterizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, colors, scales, rotations,
+                rs):
+        lib = _lib.lib()
+        dev = means3D.device
+        st = _lib.stream_ptr(dev)
+        cam = _camera(rs)
+        H, W = cam.image_height, cam.image_width
+        n = means3D.shape[0]
+        m3 = means3D.detach().float().contiguous()
+        sc = scales.detach().float().contiguous()
+        rt = rotations.detach().float().contiguous()
+        op = opacities.detach().float().contiguous()
+        cl = colors.detach().float().contiguous()
+        f = dict(dtype=torch.float32, device=dev)
+        i = dict(dtype=torch.int32, device=dev)
+        depths = torch.zeros(n, **f)
+        xy = torch.zeros(n, 2, **f)
+        conic_o = torch.zeros(n, 4, **f)
+        radii = torch.zeros(n, **i)
+        rect = torch.zeros(n, 4, **i)
+        tiles = torch.zeros(n, **i)
+        _lib.check(lib.xrd_gs_preprocess(
+            C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
+            _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy), _lib.ptr(conic_o),
+            _lib.ptr(radii), _lib.ptr(rect), _lib.ptr(tiles), st),
+            'xrd_gs_preprocess')
+        offsets = torch.cumsum(tiles.long(), 0)
+        total = int(offsets[-1].item()) if n > 0 else 0
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        ranges = torch.zeros(gx * gy, 2, **i)
+        if total > 0:
+            keys = torch.empty(total, dtype=torch.int64, device=dev)
+            vals = torch.empty(total, **i)
+            _lib.check(lib.xrd_gs_duplicate_keys(
+                n, W, _lib.ptr(rect), _lib.ptr(offsets), _lib.ptr(depths),
+                _lib.ptr(keys), _lib.ptr(vals), st), 'xrd_gs_duplicate_keys')
+            keys, order = torch.sort(keys, stable=True)
+            plist = vals[order].contiguous()
+            _lib.check(lib.xrd_gs_tile_ranges(total, _lib.ptr(keys),
+                                              _lib.ptr(ranges), st),
+                       'xrd_gs_tile_ranges')
+        else:
+            plist = torch.zeros(1, **i)
+        color = torch.empty(3, H, W, **f)
+        depth = torch.empty(1, H, W, **f)
+        final_T = torch.empty(H, W, **f)
+        n_contrib = torch.empty(H, W, **i)
+        _lib.check(lib.xrd_gs_render_fwd(
+            C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+            _lib.ptr(cl), _lib.ptr(conic_o), _lib.ptr(depths),
+            _lib.ptr(color), _lib.ptr(depth), _lib.ptr(final_T),
+            _lib.ptr(n_contrib), st), 'xrd_gs_render_fwd')
+        ctx.rs, ctx.n = rs, n
+        ctx.save_for_backward(m3, sc, rt, cl, xy, conic_o, radii, ranges,
+                              plist, final_T, n_contrib)
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth):
+        lib = _lib.lib()
+        (m3, sc, rt, cl, xy, conic_o, radii, ranges, plist, final_T,
+         n_contrib) = ctx.saved_tensors
+        dev = m3.device
+        st = _lib.stream_ptr(dev)
+        cam = _camera(ctx.rs)
+        n = ctx.n
+        f = dict(dtype=torch.float32, device=dev)
+        d_mean2D = torch.zeros(n, 2, **f)
+        d_conic = torch.zeros(n, 3, **f)
+        d_op = torch.zeros(n, 1, **f)
+        d_col = torch.zeros(n, 3, **f)
+        gc = g_color.float().contiguous()
+        _lib.check(lib.xrd_gs_render_bwd(
+            C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+            _lib.ptr(conic_o), _lib.ptr(cl), _lib.ptr(final_T),
+            _lib.ptr(n_contrib), _lib.ptr(gc), _lib.ptr(d_mean2D),
+            _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_col), st),
+            'xrd_gs_render_bwd')
+        d_means = torch.empty(n, 3, **f)
+        d_scales = torch.empty(n, 3, **f)
+        d_rots = torch.empty(n, 4, **f)
+        _lib.check(lib.xrd_gs_preprocess_bwd(
+            C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
+            _lib.ptr(radii), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
+            _lib.ptr(d_means), _lib.ptr(d_scales), _lib.ptr(d_rots), st),
+            'xrd_gs_preprocess_bwd')
+        d_means2D = torch.cat([d_mean2D, torch.zeros(n, 1, **f)], 1)
+        return d_means, d_means2D, d_op, d_col, d_scales, d_rots, None
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None,
+                colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if shs is not None or colors_precomp is None:
+            raise NotImplementedError('only colors_precomp is built (the '
+                                      'reference uses sh_degree=0)')
+        if cov3D_precomp is not None or scales is None or rotations is None:
+            raise NotImplementedError('only the scales/rotations path is '
+                                      'built')
+        if not means3D.is_cuda:
+            raise _lib.XrdError('GaussianRasterizer needs CUDA tensors')
+        return _RasterizeFn.apply(means3D, means2D, opacities, colors_precomp,
+                                  scales, rotations, self.raster_settings)
