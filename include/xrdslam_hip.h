@@ -291,6 +291,32 @@ int xrd_gs_preprocess_bwd(const xrd_gs_camera* cam, int n,
                           float* dL_dmeans3D, float* dL_dscales,
                           float* dL_drotations, xrd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Point-SLAM neighbour search — replaces the FAISS index the reference builds
+ * in slam/model_components/neural_point_cloud.py:46-52 and queries at :255
+ * (`index.search(x, 8)` -> squared L2 distances + ids).  Exact kNN within
+ * max_radius on a uniform grid (FAISS-IVF is approximate),
+ * ties by smaller id, (FLT_MAX, -1) for missing neighbours.  Build = cell ids
+ * -> caller sorts points by cell id (torch.sort) -> cell ranges.
+ * ---------------------------------------------------------------------- */
+/* origin[3], dims[3] are HOST arrays; cell_ids[n] i64 = linear cell index
+ * (z major) of every point, coordinates clamped into the grid */
+int xrd_knn_cell_ids(int64_t n, const float* points, const float* origin,
+                     float cell, const int32_t* dims, int64_t* cell_ids,
+                     xrd_stream_t stream);
+/* cell_start/cell_end [n_cells] i32, pre-zeroed; from the SORTED cell ids */
+int xrd_knn_cell_ranges(int64_t n, const int64_t* sorted_cell_ids,
+                        int32_t* cell_start, int32_t* cell_end,
+                        xrd_stream_t stream);
+/* queries [m,3]; sorted_points [n,3] + sorted_ids [n] (original ids) in cell
+ * order; k must be 8 (Point-SLAM nn_num); out_d2 [m,8] f32 ascending,
+ * out_idx [m,8] i64 */
+int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
+                   const int32_t* sorted_ids, const float* origin, float cell,
+                   const int32_t* dims, const int32_t* cell_start,
+                   const int32_t* cell_end, int k, float max_radius,
+                   float* out_d2, int64_t* out_idx, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

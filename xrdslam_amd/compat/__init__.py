@@ -9,6 +9,7 @@ import sys
 _NAMES = {
     'tinycudann': 'xrdslam_amd.compat.tinycudann',
     'grid': 'xrdslam_amd.compat.grid',
+    'faiss': 'xrdslam_amd.compat.faiss',
     'diff_gaussian_rasterization':
     'xrdslam_amd.compat.diff_gaussian_rasterization',
 }

@@ -1,0 +1,81 @@
+"""Device-resident exact kNN index over a 3-D point cloud (uniform grid),
+the engine behind the ``faiss`` shim (xrdslam_amd/compat/faiss.py)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class GridKNN:
+    """exact k=8 nearest neighbours within ``max_radius``"""
+
+    def __init__(self, max_radius: float = 0.16, device='cuda:0'):
+        self.max_radius = float(max_radius)
+        self.device = torch.device(device)
+        self.points = torch.zeros(0, 3, device=self.device)
+        self._dirty = True
+
+    @property
+    def ntotal(self):
+        return int(self.points.shape[0])
+
+    def add(self, pts: torch.Tensor):
+        pts = pts.detach().to(self.device, torch.float32).reshape(-1, 3)
+        self.points = torch.cat([self.points, pts], 0)
+        self._dirty = True
+
+    def reset(self):
+        self.points = torch.zeros(0, 3, device=self.device)
+        self._dirty = True
+
+    def _build(self):
+        lib = _lib.lib()
+        n = self.ntotal
+        cell = self.max_radius
+        lo = self.points.min(0).values - 1e-3
+        hi = self.points.max(0).values + 1e-3
+        self._origin = np.ascontiguousarray(lo.cpu().numpy(), np.float32)
+        ext = (hi - lo).cpu().numpy()
+        self._dims = np.ascontiguousarray(
+            np.maximum(np.ceil(ext / cell), 1).astype(np.int32))
+        ncell = int(np.prod(self._dims.astype(np.int64)))
+        st = _lib.stream_ptr(self.device)
+        cid = torch.empty(n, dtype=torch.int64, device=self.device)
+        _lib.check(lib.xrd_knn_cell_ids(
+            n, _lib.ptr(self.points), self._origin.ctypes.data, cell,
+            self._dims.ctypes.data, _lib.ptr(cid), st), 'xrd_knn_cell_ids')
+        cid_s, order = torch.sort(cid, stable=True)
+        self._sorted_pts = self.points[order].contiguous()
+        self._sorted_ids = order.int().contiguous()
+        self._start = torch.zeros(ncell, dtype=torch.int32, device=self.device)
+        self._end = torch.zeros(ncell, dtype=torch.int32, device=self.device)
+        _lib.check(lib.xrd_knn_cell_ranges(
+            n, _lib.ptr(cid_s), _lib.ptr(self._start), _lib.ptr(self._end),
+            st), 'xrd_knn_cell_ranges')
+        self._dirty = False
+
+    def search(self, queries: torch.Tensor, k: int = 8):
+        """-> (squared distances [m,k] f32 ascending, ids [m,k] i64; FLT_MAX/-1
+        where fewer than k points lie within max_radius)"""
+        lib = _lib.lib()
+        q = queries.detach().to(self.device, torch.float32).reshape(
+            -1, 3).contiguous()
+        m = q.shape[0]
+        D = torch.full((m, k), torch.finfo(torch.float32).max,
+                       device=self.device)
+        I = torch.full((m, k), -1, dtype=torch.int64, device=self.device)
+        if self.ntotal == 0 or m == 0:
+            return D, I
+        if self._dirty:
+            self._build()
+        _lib.check(lib.xrd_knn_search(
+            m, _lib.ptr(q), _lib.ptr(self._sorted_pts),
+            _lib.ptr(self._sorted_ids), self._origin.ctypes.data,
+            self.max_radius, self._dims.ctypes.data, _lib.ptr(self._start),
+            _lib.ptr(self._end), k, self.max_radius, _lib.ptr(D), _lib.ptr(I),
+            _lib.stream_ptr(self.device)), 'xrd_knn_search')
+        return D, I
