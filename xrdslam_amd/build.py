@@ -18,7 +18,8 @@ OBJ = os.path.join(HERE, 'csrc', '_obj')
 
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-munsafe-fp-atomics', '-fno-gpu-rdc',
-         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + \
+    os.environ.get('XRD_HIPCC_EXTRA', '').split()
 
 
 def sources():

@@ -25,7 +25,13 @@ namespace {
 constexpr int PTS = 17;
 // scheduling fence: keeps hipcc from hoisting a whole phase's weight-fragment
 // loads (and their VGPRs) across phases
-#define XRD_SB() __builtin_amdgcn_sched_barrier(0)  // padded point stride of transposed LDS tiles
+#define XRD_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef XRD_BWD_WAVES
+#define XRD_BWD_WAVES 2
+#endif
+#ifndef XRD_EXP
+#define XRD_EXP 0
+#endif  // padded point stride of transposed LDS tiles
 
 // ---------------------------------------------------------------------------
 // host: packed <- flat index tables
@@ -583,7 +589,7 @@ __device__ __forceinline__ void mlp_bwd(
         if (q == 0) W.mk[(int64_t)i * W.P + pt[t]] = word;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
-          *reinterpret_cast<f32x4*>(W.gh + ((int64_t)i * W.P + pt[t]) * 32 +
+          if (XRD_EXP != 3) *reinterpret_cast<f32x4*>(W.gh + ((int64_t)i * W.P + pt[t]) * 32 +
                                     16 * jt + 4 * q) = gh[t][jt];
       }
     }
@@ -650,9 +656,9 @@ __device__ __forceinline__ void mlp_bwd(
 #pragma unroll
             for (int a = 0; a < 3; ++a) gp[t][a] += garg * bk[a];
           }
-          if (NEED_DW) W.ge[pt[t] * 96 + k] = garg;
+          if (NEED_DW && XRD_EXP != 2) W.ge[pt[t] * 96 + k] = garg;
         }
-        XRD_SB();  // keep the inlined cos bodies from being interleaved
+        if (XRD_EXP != 1) XRD_SB();  // keep the inlined cos bodies from being interleaved
       }
   }
 }
@@ -1156,15 +1162,21 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
   }
 }
 
-template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
-__global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
+// One launch back-propagates ONE decoder (DEC = XRD_DEC_*): the stages that
+// evaluate several decoders launch this kernel once per decoder (the
+// composite backward from the saved raw is recomputed, it is cheap).  Keeping
+// a single decoder per kernel keeps the register footprint below the spill
+// threshold (a fused three-decoder backward needed > 512 VGPRs).
+template <int DEC, int NT, bool NEED_DP, bool NEED_DW>
+__global__ __launch_bounds__(RPBB* NT * 64, XRD_BWD_WAVES) void nice_bwd_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const float* __restrict__ dmax_p, const float* __restrict__ raw,
     const double* __restrict__ g_depth, const double* __restrict__ g_var,
     const float* __restrict__ g_rgb, float* __restrict__ g_rays_o,
     float* __restrict__ g_rays_d, float* gg_coarse, float* gg_middle,
-    float* gg_fine, float* gg_color, float* __restrict__ ws) {
+    float* gg_fine, float* gg_color, float* __restrict__ ws,
+    int accumulate_rays) {
   constexpr int S = NT * 16;
   constexpr int NW = RPBB * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1193,7 +1205,7 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
     W.pp = W.go + Pn * 4;
     W.ge = W.pp + Pn * 4;
   }
-  const bool use_depth = (gt_depth != nullptr) && STAGE != XRD_STAGE_COARSE;
+  const bool use_depth = (gt_depth != nullptr) && DEC != XRD_DEC_COARSE;
   const int ngroups = (n + RPBB - 1) / RPBB;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int ray = __builtin_amdgcn_readfirstlane(grp * RPBB + slot);
@@ -1260,7 +1272,7 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
       float gp32[1][3] = {{0.f, 0.f, 0.f}};
       uint64_t mask[1];
       Tri tr;
-      if (STAGE == XRD_STAGE_COARSE) {
+      if (DEC == XRD_DEC_COARSE) {
         f32x4 c_a[1][2], gc[1][2];
         float o1[1];
         const float go[1] = {gocc};
@@ -1271,11 +1283,12 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
         tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[0], tr, q, gc[0], gp64);
         grid_scatter(gg_coarse, sc.gmask[0], tr, lane, gc[0], SL);
-      } else {
+      }
+      if (DEC == XRD_DEC_MIDDLE || DEC == XRD_DEC_FINE) {
         f32x4 c_m[1][2];
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
         tri_gather(sc.grid[1], tr, q, c_m[0]);
-        {
+        if (DEC == XRD_DEC_MIDDLE) {
           float om[1][1];
           const float go[1][1] = {{gocc}};
           f32x4 gc[1][2];
@@ -1287,7 +1300,7 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
           if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
           grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
         }
-        if (STAGE >= XRD_STAGE_FINE) {
+        if (DEC == XRD_DEC_FINE) {
           f32x4 c_f[1][4], gc[1][4], cf[2];
           float of[1][1];
           const float go[1][1] = {{gocc}};
@@ -1306,7 +1319,9 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
           if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
           grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
         }
-        if (STAGE == XRD_STAGE_COLOR) {
+      }
+      if (DEC == XRD_DEC_COLOR) {
+        {
           f32x4 c_c[1][2], gc[1][2];
           float oc[1][4];
           // channel 3 is overwritten by fine+middle occupancy -> no gradient
@@ -1342,10 +1357,9 @@ __global__ __launch_bounds__(RPBB* NT * 64) void nice_bwd_kernel(
         double s = 0.0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) s += gpart[(wave + t) * 8 + lane];
-        if (lane < 3)
-          g_rays_o[ray * 3 + lane] = (float)s;
-        else
-          g_rays_d[ray * 3 + lane - 3] = (float)s;
+        float* dst = lane < 3 ? g_rays_o + ray * 3 + lane
+                              : g_rays_d + ray * 3 + lane - 3;
+        *dst = (accumulate_rays ? *dst : 0.f) + (float)s;
       }
       __syncthreads();
     }
@@ -1485,7 +1499,7 @@ static int launch_bwd(const xrd_nice_scene* scene, int n, const float* rays_o,
                       const double* g_depth, const double* g_var,
                       const float* g_rgb, float* g_rays_o, float* g_rays_d,
                       float* const g_grid[4], float* ws, int nb,
-                      hipStream_t st) {
+                      hipStream_t st, int accumulate_rays) {
   auto kern = nice_bwd_kernel<ST, NTV, DP, DW>;
   const size_t lds = bwd_lds_bytes(NTV, DW);
   static bool attr_set = false;
@@ -1500,14 +1514,55 @@ static int launch_bwd(const xrd_nice_scene* scene, int n, const float* rays_o,
   hipLaunchKernelGGL(kern, dim3(nb), dim3(RPBB * NTV * 64), lds, st, *scene, n, rays_o,
                      rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb,
                      g_rays_o, g_rays_d, g_grid[0], g_grid[1], g_grid[2],
-                     g_grid[3], ws);
+                     g_grid[3], ws, accumulate_rays);
   return check_launch("xrd_nice_render_bwd");
 }
 
 #define BWD_CASE(ST, NTV, DP, DW)                                             \
   return launch_bwd<ST, NTV, DP, DW>(scene, n_rays, rays_o, rays_d, gt_depth, \
                                      dmax, raw, g_depth, g_var, g_rgb,        \
-                                     g_rays_o, g_rays_d, gg, ws, nb, st)
+                                     g_rays_o, g_rays_d, gg, ws, nb, st, acc)
+
+// one decoder per launch (see nice_bwd_kernel)
+static int bwd_dispatch_dec(const xrd_nice_scene* scene, int dec, int nt,
+                            bool dp, bool dw, int n_rays, const float* rays_o,
+                            const float* rays_d, const float* gt_depth,
+                            const float* dmax, const float* raw,
+                            const double* g_depth, const double* g_var,
+                            const float* g_rgb, float* g_rays_o,
+                            float* g_rays_d, float* const gg[4], float* ws,
+                            int nb, hipStream_t st, int acc) {
+  if (dec == XRD_DEC_COARSE) {
+    if (nt != 2 || dp || dw) return XRD_ERR_UNSUPPORTED;
+    BWD_CASE(XRD_DEC_COARSE, 2, false, false);
+  }
+  if (dec == XRD_DEC_MIDDLE) {
+    if (nt == 3) {
+      if (dp) BWD_CASE(XRD_DEC_MIDDLE, 3, true, false);
+      BWD_CASE(XRD_DEC_MIDDLE, 3, false, false);
+    }
+    if (dp) BWD_CASE(XRD_DEC_MIDDLE, 2, true, false);
+    BWD_CASE(XRD_DEC_MIDDLE, 2, false, false);
+  }
+  if (dec == XRD_DEC_FINE) {
+    if (nt == 3) {
+      if (dp) BWD_CASE(XRD_DEC_FINE, 3, true, false);
+      BWD_CASE(XRD_DEC_FINE, 3, false, false);
+    }
+    if (dp) BWD_CASE(XRD_DEC_FINE, 2, true, false);
+    BWD_CASE(XRD_DEC_FINE, 2, false, false);
+  }
+  if (nt == 3) {
+    if (dp && dw) BWD_CASE(XRD_DEC_COLOR, 3, true, true);
+    if (dp) BWD_CASE(XRD_DEC_COLOR, 3, true, false);
+    if (dw) BWD_CASE(XRD_DEC_COLOR, 3, false, true);
+    BWD_CASE(XRD_DEC_COLOR, 3, false, false);
+  }
+  if (dp && dw) BWD_CASE(XRD_DEC_COLOR, 2, true, true);
+  if (dp) BWD_CASE(XRD_DEC_COLOR, 2, true, false);
+  if (dw) BWD_CASE(XRD_DEC_COLOR, 2, false, true);
+  BWD_CASE(XRD_DEC_COLOR, 2, false, false);
+}
 
 static int bwd_dispatch(const xrd_nice_scene* scene, int stage, int nt,
                         bool dp, bool dw, int n_rays, const float* rays_o,
@@ -1516,36 +1571,19 @@ static int bwd_dispatch(const xrd_nice_scene* scene, int stage, int nt,
                         const double* g_depth, const double* g_var,
                         const float* g_rgb, float* g_rays_o, float* g_rays_d,
                         float* const gg[4], float* ws, int nb, hipStream_t st) {
-  if (stage == XRD_STAGE_COARSE) {
-    if (nt != 2) return XRD_ERR_UNSUPPORTED;
-    BWD_CASE(XRD_STAGE_COARSE, 2, false, false);
+  static const int decs[4][3] = {{XRD_DEC_COARSE, -1, -1},
+                                 {XRD_DEC_MIDDLE, -1, -1},
+                                 {XRD_DEC_MIDDLE, XRD_DEC_FINE, -1},
+                                 {XRD_DEC_MIDDLE, XRD_DEC_FINE, XRD_DEC_COLOR}};
+  for (int k = 0; k < 3 && decs[stage][k] >= 0; ++k) {
+    const int dec = decs[stage][k];
+    const int rc = bwd_dispatch_dec(
+        scene, dec, nt, dp, dw && dec == XRD_DEC_COLOR, n_rays, rays_o, rays_d,
+        gt_depth, dmax, raw, g_depth, g_var, g_rgb, g_rays_o, g_rays_d, gg, ws,
+        nb, st, k > 0);
+    if (rc != XRD_OK) return rc;
   }
-  if (stage == XRD_STAGE_MIDDLE) {
-    if (nt == 3) {
-      if (dp) BWD_CASE(XRD_STAGE_MIDDLE, 3, true, false);
-      BWD_CASE(XRD_STAGE_MIDDLE, 3, false, false);
-    }
-    if (dp) BWD_CASE(XRD_STAGE_MIDDLE, 2, true, false);
-    BWD_CASE(XRD_STAGE_MIDDLE, 2, false, false);
-  }
-  if (stage == XRD_STAGE_FINE) {
-    if (nt == 3) {
-      if (dp) BWD_CASE(XRD_STAGE_FINE, 3, true, false);
-      BWD_CASE(XRD_STAGE_FINE, 3, false, false);
-    }
-    if (dp) BWD_CASE(XRD_STAGE_FINE, 2, true, false);
-    BWD_CASE(XRD_STAGE_FINE, 2, false, false);
-  }
-  if (nt == 3) {
-    if (dp && dw) BWD_CASE(XRD_STAGE_COLOR, 3, true, true);
-    if (dp) BWD_CASE(XRD_STAGE_COLOR, 3, true, false);
-    if (dw) BWD_CASE(XRD_STAGE_COLOR, 3, false, true);
-    BWD_CASE(XRD_STAGE_COLOR, 3, false, false);
-  }
-  if (dp && dw) BWD_CASE(XRD_STAGE_COLOR, 2, true, true);
-  if (dp) BWD_CASE(XRD_STAGE_COLOR, 2, true, false);
-  if (dw) BWD_CASE(XRD_STAGE_COLOR, 2, false, true);
-  BWD_CASE(XRD_STAGE_COLOR, 2, false, false);
+  return XRD_OK;
 }
 
 extern "C" {
