@@ -317,6 +317,55 @@ int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
                    const int32_t* cell_end, int k, float max_radius,
                    float* out_d2, int64_t* out_idx, xrd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * One-launch replacements for the small-op chains around the render call of a
+ * NICE-SLAM iteration (each is ~20-60 tiny torch kernels in the reference).
+ * ---------------------------------------------------------------------- */
+/* get_samples + bbox filter (slam/common/common.py:39-122,188-227,
+ * slam/algorithms/nice_slam.py:181-194): crop_idx[n] i64 are the indices drawn
+ * in the cropped row-major pixel grid (rows [h0,..), cols [w0, w0+crop_width));
+ * depth_img [H*W], rgb_img [H*W,3], c2w [16] device row-major.  keep[i]=1 when
+ * the bbox exit distance >= sensor depth; dmax (optional device float, caller
+ * zeroes) receives max(depth) over kept rays (conv_onet.py:418,455). */
+int xrd_sample_rays(int n, int image_width, int h0, int w0, int crop_width,
+                    float fx, float fy, float cx, float cy,
+                    const double* bound6, const int64_t* crop_idx,
+                    const float* depth_img, const float* rgb_img,
+                    const float* c2w, float* rays_o, float* rays_d,
+                    float* tgt_d, float* tgt_rgb, uint8_t* keep, float* dmax,
+                    xrd_stream_t stream);
+/* g_c2w[16] = d loss / d c2w from the ray gradients (rotation via rays_d,
+ * translation via rays_o) */
+int xrd_sample_rays_bwd(int n, int image_width, int h0, int w0, int crop_width,
+                        float fx, float fy, float cx, float cy,
+                        const int64_t* crop_idx, const float* g_rays_o,
+                        const float* g_rays_d, float* g_c2w,
+                        xrd_stream_t stream);
+/* ConvOnet.get_loss_dict (slam/models/conv_onet.py:145-185) and its gradient
+ * in one launch: loss (f64 scalar) + g_depth[n] f64 + g_rgb[n,3] f32.
+ * tracking: sum |d-d^|/sqrt(var+1e-10) over (res < 10*median(res)) & d>0 &
+ * keep, + w_color*L1 colour on the same rays; mapping: L1 depth over d>0 &
+ * keep, + w_color*L1 colour over keep when use_color.  n <= 8192. */
+int xrd_nice_loss(int n, int is_mapping, int use_color, int handle_dynamic,
+                  float w_color, const double* depth, const double* var,
+                  const float* rgb, const float* tgt_d, const float* tgt_rgb,
+                  const uint8_t* keep, double* loss, double* g_depth,
+                  float* g_rgb, xrd_stream_t stream);
+/* OptimizablePose.matrix() for rot_rep='quat' (slam/utils/opt_pose.py:51-76):
+ * c2w = [R(q) | t], q = (r,i,j,k) not necessarily unit */
+int xrd_pose_quat_fwd(const float* t3, const float* q4, float* c2w16,
+                      xrd_stream_t stream);
+int xrd_pose_quat_bwd(const float* q4, const float* g_c2w16, float* g_t3,
+                      float* g_q4, xrd_stream_t stream);
+/* torch.optim.Adam step on a small dense tensor, step count on the device */
+int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
+                   int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, const int32_t* step_dev,
+                   xrd_stream_t stream);
+/* keep the pose with the lowest loss (base_algorithm.py:262-265) on device */
+int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
+                   float* best_c2w16, uint8_t* valid, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

@@ -82,6 +82,14 @@ _SIGS = {
     'xrd_knn_cell_ranges': (C.c_int, [i64, vp, vp, vp, vp]),
     'xrd_knn_search': (C.c_int, [i64, vp, vp, vp, vp, f32, vp, vp, vp,
                                  C.c_int, f32, vp, vp, vp]),
+    'xrd_sample_rays': (C.c_int, [C.c_int] * 5 + [f32] * 4 + [vp] * 12),
+    'xrd_sample_rays_bwd': (C.c_int, [C.c_int] * 5 + [f32] * 4 + [vp] * 5),
+    'xrd_nice_loss': (C.c_int, [C.c_int] * 4 + [f32] + [vp] * 10),
+    'xrd_pose_quat_fwd': (C.c_int, [vp] * 4),
+    'xrd_pose_quat_bwd': (C.c_int, [vp] * 5),
+    'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
+                                 vp, vp]),
+    'xrd_track_best': (C.c_int, [vp] * 6),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

@@ -1,0 +1,404 @@
+// Small fused kernels around the render call of one NICE-SLAM iteration.  The
+// reference expresses these steps as ~200 tiny PyTorch kernels per iteration
+// (pixel meshgrid + gather + ray rotation + bbox filter, the L1 losses with the
+// robust median mask, the pose quaternion -> matrix chain, Adam on a handful
+// of pose parameters); at ~1 ms of real work per iteration the launches ARE
+// the cost, so each step becomes one launch (forward) + one launch (backward).
+//   xrd_sample_rays / _bwd   slam/common/common.py:39-122,188-227 (get_samples)
+//                            + slam/algorithms/nice_slam.py:181-194 (bbox filter)
+//   xrd_nice_loss            slam/models/conv_onet.py:145-185 (get_loss_dict)
+//   xrd_pose_quat_fwd/_bwd   slam/utils/opt_pose.py:51-76 (matrix(), quat)
+//   xrd_adam_dense           torch.optim.Adam on small dense tensors
+//   xrd_track_best           slam/algorithms/base_algorithm.py:262-265
+#include "common.h"
+
+namespace xrd {
+namespace {
+
+// ---------------------------------------------------------------- sampling
+struct SampleArgs {
+  int n, W, H0, W0, wcrop;
+  float fx, fy, cx, cy;
+  double bound[6];
+};
+
+__global__ __launch_bounds__(256) void sample_rays_kernel(
+    SampleArgs a, const int64_t* __restrict__ idx,
+    const float* __restrict__ depth_img, const float* __restrict__ rgb_img,
+    const float* __restrict__ c2w, float* __restrict__ rays_o,
+    float* __restrict__ rays_d, float* __restrict__ tgt_d,
+    float* __restrict__ tgt_rgb, uint8_t* __restrict__ keep,
+    float* __restrict__ dmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t k = idx[i];
+  const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
+  const int64_t pix = (int64_t)row * a.W + col;
+  const float d = depth_img[pix];
+  const float dir[3] = {((float)col - a.cx) / a.fx, -((float)row - a.cy) / a.fy,
+                        -1.f};
+  float o[3], rd[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rd[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] +
+            dir[2] * c2w[r * 4 + 2];
+    o[r] = c2w[r * 4 + 3];
+    rays_o[i * 3 + r] = o[r];
+    rays_d[i * 3 + r] = rd[r];
+    tgt_rgb[i * 3 + r] = rgb_img[pix * 3 + r];
+  }
+  tgt_d[i] = d;
+  // rays whose sensor depth lies beyond the bound are dropped
+  double t_exit = 1e300;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double t0 = (a.bound[2 * r] - (double)o[r]) / (double)rd[r];
+    const double t1 = (a.bound[2 * r + 1] - (double)o[r]) / (double)rd[r];
+    t_exit = fmin(t_exit, fmax(t0, t1));
+  }
+  const bool kp = t_exit >= (double)d;
+  keep[i] = kp ? 1 : 0;
+  if (kp && d > 0.f && dmax)
+    atomicMax(reinterpret_cast<int*>(dmax), __float_as_int(d));
+}
+
+// g_c2w[r][k] = sum_i g_rays_d[i][r] * dir_i[k];  g_c2w[r][3] = sum_i g_rays_o[i][r]
+__global__ __launch_bounds__(256) void sample_rays_bwd_kernel(
+    SampleArgs a, const int64_t* __restrict__ idx,
+    const float* __restrict__ g_o, const float* __restrict__ g_d,
+    float* __restrict__ g_c2w) {
+  __shared__ float red[4][12];
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (int i = threadIdx.x; i < a.n; i += 256) {
+    const int64_t k = idx[i];
+    const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
+    const float dir[3] = {((float)col - a.cx) / a.fx,
+                          -((float)row - a.cy) / a.fy, -1.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float gd = g_d[i * 3 + r];
+      acc[r * 4 + 0] += gd * dir[0];
+      acc[r * 4 + 1] += gd * dir[1];
+      acc[r * 4 + 2] += gd * dir[2];
+      acc[r * 4 + 3] += g_o[i * 3 + r];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int k = threadIdx.x;
+    g_c2w[k] = k < 12 ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
+  }
+}
+
+// -------------------------------------------------------------------- loss
+constexpr int kLossMax = 8192;  // rays per call handled by the one-block loss
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void nice_loss_kernel(
+    int n, int is_mapping, int use_color, int handle_dynamic, float w_color,
+    const double* __restrict__ depth, const double* __restrict__ var,
+    const float* __restrict__ rgb, const float* __restrict__ tgt_d,
+    const float* __restrict__ tgt_rgb, const uint8_t* __restrict__ keep,
+    double* __restrict__ loss, double* __restrict__ g_depth,
+    float* __restrict__ g_rgb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* sorted = reinterpret_cast<double*>(smem);  // [npow2]
+  __shared__ double sh[16];
+  __shared__ int s_cnt;
+  const int tid = threadIdx.x, T = blockDim.x;
+  double thr = 1e300;
+  if (!is_mapping && handle_dynamic) {
+    // lower median of the residuals of the kept rays (torch.median)
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < np2; i += T) {
+      double v = 1e300;
+      if (i < n && (!keep || keep[i])) {
+        v = fabs((double)tgt_d[i] - depth[i]) / sqrt(var[i] + 1e-10);
+        ++local;
+      }
+      sorted[i] = v;
+    }
+    atomicAdd(&s_cnt, local);
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < np2; i += T) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const bool up = (i & k) == 0;
+            const double a = sorted[i], b = sorted[ixj];
+            if ((a > b) == up) {
+              sorted[i] = b;
+              sorted[ixj] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    const int cnt = s_cnt;
+    thr = cnt > 0 ? 10.0 * sorted[(cnt - 1) / 2] : 1e300;
+    __syncthreads();
+  }
+  double ld = 0.0, lc = 0.0;
+  for (int i = tid; i < n; i += T) {
+    const bool kp = !keep || keep[i];
+    const double diff = (double)tgt_d[i] - depth[i];
+    double gd = 0.0;
+    bool use_c;
+    if (!is_mapping) {
+      const double inv = 1.0 / sqrt(var[i] + 1e-10);
+      const double res = fabs(diff) * inv;
+      const bool m = kp && tgt_d[i] > 0.f && (!handle_dynamic || res < thr);
+      if (m) {
+        ld += res;
+        gd = (diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0)) * inv;
+      }
+      use_c = m && use_color;
+    } else {
+      const bool m = kp && tgt_d[i] > 0.f;
+      if (m) {
+        ld += fabs(diff);
+        gd = diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0);
+      }
+      use_c = kp && use_color;
+    }
+    g_depth[i] = gd;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float g = 0.f;
+      if (use_c) {
+        const float dc = tgt_rgb[i * 3 + c] - rgb[i * 3 + c];
+        lc += (double)fabsf(dc);
+        g = w_color * (dc > 0.f ? -1.f : (dc < 0.f ? 1.f : 0.f));
+      }
+      g_rgb[i * 3 + c] = g;
+    }
+  }
+  const double sd = block_sum(ld, sh);
+  const double sc = block_sum(lc, sh);
+  if (tid == 0) loss[0] = sd + (double)((float)w_color * (float)sc);
+}
+
+// -------------------------------------------------------------------- pose
+// c2w[16] (row-major 4x4) from translation t[3] and quaternion q=(r,i,j,k),
+// R = I + s*B(q), s = 2/|q|^2 (opt_pose.py:69 via pytorch3d quaternion_to_matrix)
+__global__ void pose_quat_fwd_kernel(const float* __restrict__ t,
+                                     const float* __restrict__ q,
+                                     float* __restrict__ c2w) {
+  if (threadIdx.x != 0) return;
+  const float r = q[0], i = q[1], j = q[2], k = q[3];
+  const float s = 2.f / (r * r + i * i + j * j + k * k);
+  const float R[9] = {1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r),
+                      s * (i * j + k * r), 1 - s * (i * i + k * k), s * (j * k - i * r),
+                      s * (i * k - j * r), s * (j * k + i * r), 1 - s * (i * i + j * j)};
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) c2w[a * 4 + b] = R[a * 3 + b];
+    c2w[a * 4 + 3] = t[a];
+  }
+  c2w[12] = c2w[13] = c2w[14] = 0.f;
+  c2w[15] = 1.f;
+}
+
+__global__ void pose_quat_bwd_kernel(const float* __restrict__ q,
+                                     const float* __restrict__ g_c2w,
+                                     float* __restrict__ g_t,
+                                     float* __restrict__ g_q) {
+  if (threadIdx.x != 0) return;
+  const float r = q[0], i = q[1], j = q[2], k = q[3];
+  const float N = r * r + i * i + j * j + k * k, s = 2.f / N;
+  float G[3][3];
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) G[a][b] = g_c2w[a * 4 + b];
+    g_t[a] = g_c2w[a * 4 + 3];
+  }
+  const float B[3][3] = {{-(j * j + k * k), i * j - k * r, i * k + j * r},
+                         {i * j + k * r, -(i * i + k * k), j * k - i * r},
+                         {i * k - j * r, j * k + i * r, -(i * i + j * j)}};
+  float GB = 0.f;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) GB += G[a][b] * B[a][b];
+  // d(sum G:B)/dq
+  const float dr = -k * G[0][1] + j * G[0][2] + k * G[1][0] - i * G[1][2] - j * G[2][0] + i * G[2][1];
+  const float di = j * G[0][1] + k * G[0][2] + j * G[1][0] - 2 * i * G[1][1] - r * G[1][2] +
+                   k * G[2][0] + r * G[2][1] - 2 * i * G[2][2];
+  const float dj = -2 * j * G[0][0] + i * G[0][1] + r * G[0][2] + i * G[1][0] + k * G[1][2] -
+                   r * G[2][0] + k * G[2][1] - 2 * j * G[2][2];
+  const float dk = -2 * k * G[0][0] - r * G[0][1] + i * G[0][2] + r * G[1][0] - 2 * k * G[1][1] +
+                   j * G[1][2] + i * G[2][0] + j * G[2][1];
+  const float ds = -s * s;  // ds/dq_x = -s^2 * q_x
+  g_q[0] = s * dr + GB * ds * r;
+  g_q[1] = s * di + GB * ds * i;
+  g_q[2] = s * dj + GB * ds * j;
+  g_q[3] = s * dk + GB * ds * k;
+}
+
+// -------------------------------------------------------------------- adam
+__global__ __launch_bounds__(256) void adam_dense_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+    float wd, const int32_t* __restrict__ step_dev) {
+  __shared__ float coef[2];
+  if (threadIdx.x == 0) {
+    const int t = step_dev[0];
+    coef[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+    coef[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - coef[0] * (mi / (sqrtf(vi) * coef[1] + eps));
+  }
+}
+
+__global__ void track_best_kernel(const double* __restrict__ loss,
+                                  const float* __restrict__ c2w,
+                                  double* __restrict__ best_loss,
+                                  float* __restrict__ best_c2w,
+                                  uint8_t* __restrict__ valid) {
+  const bool better = loss[0] < best_loss[0];
+  __syncthreads();
+  if (better) {
+    if (threadIdx.x < 16) best_c2w[threadIdx.x] = c2w[threadIdx.x];
+    if (threadIdx.x == 0) {
+      best_loss[0] = loss[0];
+      valid[0] = 1;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
+using namespace xrd;
+
+extern "C" {
+
+int xrd_sample_rays(int n, int image_width, int h0, int w0, int crop_width,
+                    float fx, float fy, float cx, float cy,
+                    const double* bound6, const int64_t* crop_idx,
+                    const float* depth_img, const float* rgb_img,
+                    const float* c2w, float* rays_o, float* rays_d,
+                    float* tgt_d, float* tgt_rgb, uint8_t* keep, float* dmax,
+                    xrd_stream_t stream) {
+  if (n < 0 || image_width < 1 || crop_width < 1 || !bound6) return XRD_ERR_ARG;
+  if (n == 0) return XRD_OK;
+  if (!crop_idx || !depth_img || !rgb_img || !c2w || !rays_o || !rays_d ||
+      !tgt_d || !tgt_rgb || !keep)
+    return XRD_ERR_ARG;
+  SampleArgs a{n, image_width, h0, w0, crop_width, fx, fy, cx, cy, {}};
+  for (int k = 0; k < 6; ++k) a.bound[k] = bound6[k];
+  hipLaunchKernelGGL(sample_rays_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, a, crop_idx, depth_img, rgb_img, c2w,
+                     rays_o, rays_d, tgt_d, tgt_rgb, keep, dmax);
+  return check_launch("xrd_sample_rays");
+}
+
+int xrd_sample_rays_bwd(int n, int image_width, int h0, int w0, int crop_width,
+                        float fx, float fy, float cx, float cy,
+                        const int64_t* crop_idx, const float* g_rays_o,
+                        const float* g_rays_d, float* g_c2w,
+                        xrd_stream_t stream) {
+  if (n < 0 || crop_width < 1 || !g_c2w) return XRD_ERR_ARG;
+  if (n > 0 && (!crop_idx || !g_rays_o || !g_rays_d)) return XRD_ERR_ARG;
+  SampleArgs a{n, image_width, h0, w0, crop_width, fx, fy, cx, cy, {}};
+  hipLaunchKernelGGL(sample_rays_bwd_kernel, dim3(1), dim3(256), 0,
+                     (hipStream_t)stream, a, crop_idx, g_rays_o, g_rays_d,
+                     g_c2w);
+  return check_launch("xrd_sample_rays_bwd");
+}
+
+int xrd_nice_loss(int n, int is_mapping, int use_color, int handle_dynamic,
+                  float w_color, const double* depth, const double* var,
+                  const float* rgb, const float* tgt_d, const float* tgt_rgb,
+                  const uint8_t* keep, double* loss, double* g_depth,
+                  float* g_rgb, xrd_stream_t stream) {
+  if (n < 1 || !depth || !var || !rgb || !tgt_d || !tgt_rgb || !loss ||
+      !g_depth || !g_rgb)
+    return XRD_ERR_ARG;
+  if (n > kLossMax) return XRD_ERR_UNSUPPORTED;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const size_t lds = (size_t)np2 * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nice_loss_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                        kLossMax * (int)sizeof(double));
+    attr = true;
+  }
+  hipLaunchKernelGGL(nice_loss_kernel, dim3(1), dim3(1024), lds,
+                     (hipStream_t)stream, n, is_mapping, use_color,
+                     handle_dynamic, w_color, depth, var, rgb, tgt_d, tgt_rgb,
+                     keep, loss, g_depth, g_rgb);
+  return check_launch("xrd_nice_loss");
+}
+
+int xrd_pose_quat_fwd(const float* t3, const float* q4, float* c2w16,
+                      xrd_stream_t stream) {
+  if (!t3 || !q4 || !c2w16) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_quat_fwd_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, t3, q4, c2w16);
+  return check_launch("xrd_pose_quat_fwd");
+}
+
+int xrd_pose_quat_bwd(const float* q4, const float* g_c2w16, float* g_t3,
+                      float* g_q4, xrd_stream_t stream) {
+  if (!q4 || !g_c2w16 || !g_t3 || !g_q4) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_quat_bwd_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, q4, g_c2w16, g_t3, g_q4);
+  return check_launch("xrd_pose_quat_bwd");
+}
+
+int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
+                   int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, const int32_t* step_dev,
+                   xrd_stream_t stream) {
+  if (n < 0 || !step_dev) return XRD_ERR_ARG;
+  if (n == 0) return XRD_OK;
+  if (!param || !grad || !m || !v) return XRD_ERR_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, step_dev);
+  return check_launch("xrd_adam_dense");
+}
+
+int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
+                   float* best_c2w16, uint8_t* valid, xrd_stream_t stream) {
+  if (!loss || !c2w16 || !best_loss || !best_c2w16 || !valid) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(track_best_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, loss, c2w16, best_loss, best_c2w16,
+                     valid);
+  return check_launch("xrd_track_best");
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""autograd wrappers of the small fused kernels (csrc/slam_ops.hip) that
+replace the tiny-op chains around the render call of one NICE-SLAM iteration:
+pose -> matrix, pixel sampling + bbox filter, the losses, small-tensor Adam."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _off(t: torch.Tensor, n_elems: int):
+    """pointer n_elems floats into a float32 tensor"""
+    return C.c_void_p(t.data_ptr() + 4 * n_elems)
+
+
+class PoseQuat7Fn(torch.autograd.Function):
+    """c2w[4,4] = matrix(data[7] = [t, q])  (non-separate pose parameter)"""
+
+    @staticmethod
+    def forward(ctx, data):
+        c2w = torch.empty(4, 4, dtype=torch.float32, device=data.device)
+        _lib.check(_lib.lib().xrd_pose_quat_fwd(
+            _lib.ptr(data), _off(data, 3), _lib.ptr(c2w),
+            _lib.stream_ptr(data.device)), 'xrd_pose_quat_fwd')
+        ctx.save_for_backward(data)
+        return c2w
+
+    @staticmethod
+    def backward(ctx, g):
+        data, = ctx.saved_tensors
+        out = torch.empty(7, dtype=torch.float32, device=data.device)
+        _lib.check(_lib.lib().xrd_pose_quat_bwd(
+            _off(data, 3), _lib.ptr(g.float().contiguous()), _lib.ptr(out),
+            _off(out, 3), _lib.stream_ptr(data.device)), 'xrd_pose_quat_bwd')
+        return out
+
+
+class PoseQuatSplitFn(torch.autograd.Function):
+    """c2w = matrix(t[3], q[4])  (separate_LR parameters)"""
+
+    @staticmethod
+    def forward(ctx, t, q):
+        c2w = torch.empty(4, 4, dtype=torch.float32, device=t.device)
+        _lib.check(_lib.lib().xrd_pose_quat_fwd(
+            _lib.ptr(t), _lib.ptr(q), _lib.ptr(c2w),
+            _lib.stream_ptr(t.device)), 'xrd_pose_quat_fwd')
+        ctx.save_for_backward(q)
+        return c2w
+
+    @staticmethod
+    def backward(ctx, g):
+        q, = ctx.saved_tensors
+        gt = torch.empty(3, dtype=torch.float32, device=q.device)
+        gq = torch.empty(4, dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().xrd_pose_quat_bwd(
+            _lib.ptr(q), _lib.ptr(g.float().contiguous()), _lib.ptr(gt),
+            _lib.ptr(gq), _lib.stream_ptr(q.device)), 'xrd_pose_quat_bwd')
+        return gt, gq
+
+
+class SampleRaysFn(torch.autograd.Function):
+    """rays of F frames in one batch: returns rays_o, rays_d (differentiable
+    w.r.t. the stacked c2w), target depth/colour, keep mask, dmax"""
+
+    @staticmethod
+    def forward(ctx, c2ws, idx, depth_imgs: Sequence[torch.Tensor],
+                rgb_imgs: Sequence[torch.Tensor], cam, crop, bound6):
+        lib = _lib.lib()
+        F, n = idx.shape
+        dev = idx.device
+        N = F * n
+        ro = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        rd = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        td = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        tc = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        keep = torch.empty(N, dtype=torch.uint8, device=dev)
+        dmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        c2ws = c2ws.detach().float().contiguous()
+        H0, W0, wcrop = crop
+        st = _lib.stream_ptr(dev)
+        b6 = (C.c_double * 6)(*bound6)
+        for f in range(F):
+            _lib.check(lib.xrd_sample_rays(
+                n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
+                b6, C.c_void_p(idx.data_ptr() + 8 * f * n),
+                _lib.ptr(depth_imgs[f]), _lib.ptr(rgb_imgs[f]),
+                _off(c2ws, 16 * f), _off(ro, 3 * f * n), _off(rd, 3 * f * n),
+                _off(td, f * n), _off(tc, 3 * f * n),
+                C.c_void_p(keep.data_ptr() + f * n), _lib.ptr(dmax), st),
+                'xrd_sample_rays')
+        ctx.args = (cam, crop, F, n)
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(td, tc, keep, dmax)
+        return ro, rd, td, tc, keep, dmax
+
+    @staticmethod
+    def backward(ctx, g_ro, g_rd, *unused):
+        lib = _lib.lib()
+        idx, = ctx.saved_tensors
+        cam, (H0, W0, wcrop), F, n = ctx.args
+        dev = idx.device
+        g_ro = g_ro.float().contiguous()
+        g_rd = g_rd.float().contiguous()
+        g_c2w = torch.empty(F, 4, 4, dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr(dev)
+        for f in range(F):
+            _lib.check(lib.xrd_sample_rays_bwd(
+                n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
+                C.c_void_p(idx.data_ptr() + 8 * f * n), _off(g_ro, 3 * f * n),
+                _off(g_rd, 3 * f * n), _off(g_c2w, 16 * f), st),
+                'xrd_sample_rays_bwd')
+        return g_c2w, None, None, None, None, None, None
+
+
+class NiceLossFn(torch.autograd.Function):
+    """scalar loss of ConvOnet.get_loss_dict (sum of its terms), f64"""
+
+    @staticmethod
+    def forward(ctx, depth, var, rgb, tgt_d, tgt_rgb, keep, is_mapping,
+                use_color, handle_dynamic, w_color):
+        n = depth.shape[0]
+        dev = depth.device
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        g_d = torch.empty(n, dtype=torch.float64, device=dev)
+        g_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().xrd_nice_loss(
+            n, int(is_mapping), int(use_color), int(handle_dynamic),
+            float(w_color), _lib.ptr(depth.detach().double().contiguous()),
+            _lib.ptr(var.detach().double().contiguous()),
+            _lib.ptr(rgb.detach().float().contiguous()),
+            _lib.ptr(tgt_d.reshape(-1).float().contiguous()),
+            _lib.ptr(tgt_rgb.float().contiguous()), _lib.ptr(keep),
+            _lib.ptr(loss), _lib.ptr(g_d), _lib.ptr(g_c),
+            _lib.stream_ptr(dev)), 'xrd_nice_loss')
+        ctx.save_for_backward(g_d, g_c)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        g_d, g_c = ctx.saved_tensors
+        return (g_d * go, None, g_c * go.float(), None, None, None, None, None,
+                None, None)
+
+
+class FusedDenseAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (no amsgrad) for small dense CUDA tensors,
+    one launch per parameter, step count on the device (graph-replayable).
+    Parameters whose grad is None are skipped, like torch does."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, **_ignored):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps,
+                                      weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = _lib.lib()
+        for grp in self.param_groups:
+            b1, b2 = grp['betas']
+            for p in grp['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['exp_avg'] = torch.zeros_like(p, dtype=torch.float32)
+                    st['exp_avg_sq'] = torch.zeros_like(p, dtype=torch.float32)
+                    st['step'] = torch.zeros(1, dtype=torch.int32,
+                                             device=p.device)
+                st['step'] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                _lib.check(lib.xrd_adam_dense(
+                    _lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']),
+                    _lib.ptr(st['exp_avg_sq']), p.numel(), float(grp['lr']),
+                    float(b1), float(b2), float(grp['eps']),
+                    float(grp['weight_decay']), _lib.ptr(st['step']),
+                    _lib.stream_ptr(p.device)), 'xrd_adam_dense')
+
+
+def track_best(loss, c2w, track):
+    """track: dict(loss f64 [], c2w [4,4] f32, valid uint8 [])"""
+    _lib.check(_lib.lib().xrd_track_best(
+        _lib.ptr(loss.detach()), _lib.ptr(c2w.detach().contiguous()),
+        _lib.ptr(track['loss']), _lib.ptr(track['c2w']),
+        _lib.ptr(track['valid']), _lib.stream_ptr(c2w.device)),
+        'xrd_track_best')

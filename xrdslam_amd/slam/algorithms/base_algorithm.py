@@ -247,11 +247,15 @@ class Algorithm:
             # keep the pose that produced the lowest loss (evaluated before
             # its Adam step, base_algorithm.py:262-265), on the device
             cur = optimize_frames[-1].get_pose().detach()
-            lval = loss.detach().to(cur.device, torch.float64)
-            better = lval < track['loss']
-            track['c2w'].copy_(torch.where(better, cur, track['c2w']))
-            track['loss'].copy_(torch.where(better, lval, track['loss']))
-            track['valid'].logical_or_(better)
+            if cur.is_cuda and loss.dtype == torch.float64 and loss.is_cuda:
+                from ...engine import slam_ops
+                slam_ops.track_best(loss, cur, track)
+            else:
+                lval = loss.detach().to(cur.device, torch.float64)
+                better = lval < track['loss']
+                track['c2w'].copy_(torch.where(better, cur, track['c2w']))
+                track['loss'].copy_(torch.where(better, lval, track['loss']))
+                track['valid'].logical_or_(better)
         loss.backward(retain_graph=(self.config.retain_graph and is_mapping))
         self.post_processing(step, is_mapping, optimizers.optimizers,
                              coarse=coarse)

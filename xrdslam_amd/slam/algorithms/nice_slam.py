@@ -175,11 +175,64 @@ class NiceSLAM(Algorithm):
         key, self.stage = self.stage, saved
         return key
 
+    def _fused_loss(self, optimize_frames, is_mapping):
+        """get_model_input + model + get_loss_dict as five launches (sampling,
+        render, loss and their backwards) instead of ~150 small kernels; same
+        arithmetic as the generic hooks (tests/test_nice_loop_hip.py)."""
+        from ...engine import nice as _en
+        from ...engine import slam_ops
+        cfg, cam, dev = self.config, self.camera, self.model.device
+        mcfg = self.model.config
+        n_pix, Hedge, Wedge = cfg.tracking_sample, cfg.tracking_Hedge, \
+            cfg.tracking_Wedge
+        gen = None
+        if is_mapping:
+            n_pix = max(cfg.mapping_sample // len(optimize_frames),
+                        cfg.min_sample_pixels)
+            Hedge = Wedge = 0
+            n_pix = _dist.state.shard_count(n_pix)
+            gen = _dist.state.shard_generator
+        wcrop = cam.width - 2 * Wedge
+        cnt = (cam.height - 2 * Hedge) * wcrop
+        idx = torch.stack([torch.randint(cnt, (n_pix, ), device=dev,
+                                         generator=gen)
+                           for _ in optimize_frames])
+        poses = []
+        for f in optimize_frames:
+            c2w = f.get_pose()
+            if is_mapping and not self.bundle_adjust:
+                c2w = c2w.detach()
+            poses.append(c2w.to(dev))
+        c2ws = torch.stack(poses) if len(poses) > 1 else poses[0].unsqueeze(0)
+        imgs = [f.device_images(dev) for f in optimize_frames]
+        bound6 = self.bounding_box.reshape(-1).tolist()
+        ro, rd, td, tc, keep, dmax = slam_ops.SampleRaysFn.apply(
+            c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
+            (Hedge, Wedge, wcrop), bound6)
+        stage = self.stage
+        depth, var, rgb = _en.nice_render(
+            self.model.scene(), stage, ro, rd,
+            None if stage == 'coarse' else td, dmax=dmax)
+        if is_mapping:
+            use_color, w = stage == 'color', mcfg.mapping_w_color_loss
+        else:
+            use_color, w = mcfg.tracking_use_color_in_tracking, \
+                mcfg.tracking_w_color_loss
+        return slam_ops.NiceLossFn.apply(depth, var, rgb, td, tc, keep,
+                                         is_mapping, use_color,
+                                         mcfg.tracking_handle_dynamic, w)
+
+    fused_iteration = True  # use the fused launches when the batch shape is fixed
+
     def get_loss(self, optimize_frames, is_mapping, step, n_iters,
                  coarse=False):
         self.set_stage(is_mapping, step, n_iters, coarse=coarse)
         if is_mapping:
             self.model.grid_processing(coarse=coarse)
+        if self.fused_iteration and getattr(self, 'fixed_shape_batches',
+                                            False) and \
+                torch.device(self.model.device).type == 'cuda':
+            return self._fused_loss(optimize_frames, is_mapping)
         model_input = self.get_model_input(optimize_frames, is_mapping)
         outputs = self.model(model_input)
         losses = self.model.get_loss_dict(outputs, model_input, is_mapping,

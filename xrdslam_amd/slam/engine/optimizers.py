@@ -38,9 +38,11 @@ class OptimizerConfig(PrintableConfig):
             return FusedCellAdam(params, lr=self.lr, betas=self.betas,
                                  eps=self.eps)
         if self._target is torch.optim.Adam and len(params) > 0 and \
-                all(p.is_cuda for p in params):
-            # device-side step counter: the step can be replayed from a graph
-            kwargs['capturable'] = True
+                all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            # one launch per parameter, device-side step counter (replayable
+            # from a hipGraph); same arithmetic as torch.optim.Adam
+            from ...engine.slam_ops import FusedDenseAdam
+            return FusedDenseAdam(params, **kwargs)
         return self._target(params, **kwargs)
 
 
