@@ -61,6 +61,7 @@ class SequentialSLAM:
                       rot_rep=alg.get_rot_rep(), device=self.pose_device)
         t0 = time.perf_counter()
         cand = alg.do_tracking(frame)
+        cand = self._sync_pose(cand)
         if alg.is_initialized() and cand is not None:
             frame.set_pose(cand, separate_LR=alg.is_separate_LR(),
                            rot_rep=alg.get_rot_rep())
@@ -81,6 +82,19 @@ class SequentialSLAM:
         self.t_track += t1 - t0
         self.t_map += t2 - t1
         return frame
+
+    def _sync_pose(self, cand):
+        """multi-GPU: tracking is replicated; rank 0's result is broadcast so
+        that every rank continues from bit-identical poses (frustum masks and
+        therefore all-reduce bucket sizes must agree across ranks)"""
+        from ..engine import dist as _dist
+        if not _dist.state.enabled or cand is None:
+            return cand
+        import torch.distributed as dist
+        dev = self.algorithm.device
+        t = torch.as_tensor(cand, dtype=torch.float32).to(dev).contiguous()
+        dist.broadcast(t, src=0)
+        return t.cpu().numpy()
 
     def ate_rmse(self):
         """translation RMSE between estimated and GT poses (no alignment: the
