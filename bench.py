@@ -42,6 +42,16 @@ CAM = dict(fx=320.0, fy=320.0, cx=319.5, cy=239.5, width=640, height=480)
 # per distinct grid lookup; backward read-modify-writes the same cells.
 GRIDS_PER_STAGE = {'coarse': 1, 'middle': 1, 'fine': 2, 'color': 3}
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
+MFMA_F32_PEAK = 157.3e12  # FLOP/s, v_mfma_f32_16x16x4_f32 (= fp32 vector peak)
+# algorithmic forward FLOPs per ray sample (2 x MACs
+# of the decoders a stage evaluates); backward ~ 2x forward (§8d)
+FWD_FLOPS = {'coarse': 12.4e3, 'middle': 31.0e3, 'fine': 72.0e3,
+             'color': 103.0e3}
+
+
+def algorithmic_flops(kernel, stage, n_rays):
+    S = 32 if stage == 'coarse' else 48
+    return n_rays * S * FWD_FLOPS[stage] * (2.0 if kernel == 'nice_bwd' else 1.0)
 
 
 def algorithmic_bytes(kernel, stage, n_rays, grid_grads):
@@ -192,11 +202,27 @@ def main():
         total_ms, key, calls, avg_ms = stats[0]
         kernel, stage, n_rays, need_pose, need_dec, grid_grads = key
         abytes = algorithmic_bytes(kernel, stage, n_rays, grid_grads)
-        achieved = abytes / (avg_ms * 1e-3) / 1e9
+        aflops = algorithmic_flops(kernel, stage, n_rays)
+        hbm = abytes / (avg_ms * 1e-3)
+        mfma = aflops / (avg_ms * 1e-3)
+        # the bound is the one the kernel's arithmetic intensity puts it under
+        # (ridge = 157.3 TF / 8 TB/s = 19.7 FLOP/B); the other is reported too
+        compute_bound = aflops / abytes > MFMA_F32_PEAK / HBM_PEAK
         roofline = {
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9,
-            'unit': 'GB/s', 'frac': achieved * 1e9 / HBM_PEAK,
+            'bound': 'mfma' if compute_bound else 'hbm',
+            'achieved': mfma / 1e12 if compute_bound else hbm / 1e9,
+            'peak': MFMA_F32_PEAK / 1e12 if compute_bound else HBM_PEAK / 1e9,
+            'unit': 'TFLOP/s' if compute_bound else 'GB/s',
+            'frac': mfma / MFMA_F32_PEAK if compute_bound else hbm / HBM_PEAK,
             'traffic': None,
+            'intensity_flop_per_byte': aflops / abytes,
+            'other_bound': {
+                'bound': 'hbm' if compute_bound else 'mfma',
+                'achieved': hbm / 1e9 if compute_bound else mfma / 1e12,
+                'unit': 'GB/s' if compute_bound else 'TFLOP/s',
+                'frac': hbm / HBM_PEAK if compute_bound else
+                mfma / MFMA_F32_PEAK},
+            'algorithmic_flops_per_launch': aflops,
             'kernel': f'{kernel}[stage={stage},rays={n_rays},pose_grad='
                       f'{int(need_pose)},decoder_grad={int(need_dec)},'
                       f'grid_grad={int(grid_grads)}]',

@@ -562,13 +562,10 @@ __device__ __forceinline__ void mlp_bwd(
         *reinterpret_cast<f32x4*>(W.c + pt[t] * 32 + 16 * kt + 4 * q) =
             c[t][kt];
   }
-  f32x4 ge[NT][NEED_E ? 6 : 1];
-  if (NEED_E) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kt = 0; kt < 6; ++kt) ge[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  // masked gradients entering layers 3 and 0: the Fourier features feed both
+  // (kept until the embedding backward after the loop; 16 registers instead
+  // of 24 accumulators live across the whole layer loop)
+  f32x4 ga3[NT][2], ga0[NT][2];
 #pragma unroll 1
   for (int i = 4; i >= 0; --i) {
     f32x4 ga[NT][2];
@@ -589,7 +586,7 @@ __device__ __forceinline__ void mlp_bwd(
         if (q == 0) W.mk[(int64_t)i * W.P + pt[t]] = word;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
-          if (XRD_EXP != 3) *reinterpret_cast<f32x4*>(W.gh + ((int64_t)i * W.P + pt[t]) * 32 +
+          *reinterpret_cast<f32x4*>(W.gh + ((int64_t)i * W.P + pt[t]) * 32 +
                                     16 * jt + 4 * q) = gh[t][jt];
       }
     }
@@ -604,17 +601,13 @@ __device__ __forceinline__ void mlp_bwd(
           gc[t][kt] = XRD_MFMA4(a, gh[t][s >> 2][s & 3], gc[t][kt]);
         if (s == 7) XRD_SB();
       }
-    if (NEED_E && (i == 3 || i == 0)) {
-      const int base = (i == 3) ? P::W3ET : P::W0T;
+    if (NEED_E) {
 #pragma unroll
-      for (int kt = 0; kt < 6; ++kt)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const float a = pk[base + (kt * 8 + s) * 64 + lane];
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            ge[t][kt] = XRD_MFMA4(a, ga[t][s >> 2][s & 3], ge[t][kt]);
-          if (s == 7) XRD_SB();
+        for (int jt = 0; jt < 2; ++jt) {
+          if (i == 3) ga3[t][jt] = ga[t][jt];
+          if (i == 0) ga0[t][jt] = ga[t][jt];
         }
     }
     if (i >= 1) {
@@ -642,24 +635,38 @@ __device__ __forceinline__ void mlp_bwd(
     }
   }
   if (NEED_E) {
-    // through sin(p.B): lane group q owns feature k = emap(4kt+r, q)
+    // d loss / d sin(p.B) = W0^T ga0 + W3e^T ga3, one 16-feature tile at a
+    // time; then through sin: lane group q owns feature k = emap(4kt+r, q)
+#pragma unroll 1
+    for (int kt = 0; kt < 6; ++kt) {
+      f32x4 ge[NT];
 #pragma unroll
-    for (int kt = 0; kt < 6; ++kt)
+      for (int t = 0; t < NT; ++t) ge[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float a3 = pk[P::W3ET + (kt * 8 + s) * 64 + lane];
+        const float a0 = pk[P::W0T + (kt * 8 + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          ge[t] = XRD_MFMA4(a3, ga3[t][s >> 2][s & 3], ge[t]);
+          ge[t] = XRD_MFMA4(a0, ga0[t][s >> 2][s & 3], ge[t]);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = emap(4 * kt + r, q);
         const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float garg = ge[t][kt][r] * cos_cw(embed_arg(p[t], bk));
+          const float garg = ge[t][r] * cos_cw(embed_arg(p[t], bk));
           if (NEED_DP) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) gp[t][a] += garg * bk[a];
           }
-          if (NEED_DW && XRD_EXP != 2) W.ge[pt[t] * 96 + k] = garg;
+          if (NEED_DW) W.ge[pt[t] * 96 + k] = garg;
         }
-        if (XRD_EXP != 1) XRD_SB();  // keep the inlined cos bodies from being interleaved
       }
+    }
   }
 }
 
