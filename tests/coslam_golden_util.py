@@ -1,0 +1,77 @@
+"""Drives the host mirror of Co-SLAM's JointEncoding on the inputs of
+tests/golden/coslam_render.npz (made by oracle/make_golden_coslam.py from the
+reference's own model) and compares outputs, loss terms and gradients."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden',
+                      'coslam_render.npz')
+TAGS = (('track', False, False), ('map', True, False),
+        ('map_first', True, True))
+
+
+def build_model(g, device):
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.joint_encoding import (JointEncoding,
+                                                        JointEncodingConfig)
+    cfg = JointEncodingConfig(cam_depth_trunc=100.0, tcnn_encoding=True,
+                              hashsize=int(g['hash_cfg'][1]),
+                              trainging_smooth_pts=8)
+    model = JointEncoding(cfg, Camera(40., 40., 31.5, 23.5, 64, 48),
+                          torch.from_numpy(g['bound']))
+    assert model.resolution_sdf == int(g['hash_cfg'][0])
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files
+          if k.startswith('dec/')}
+    model.decoder.load_state_dict(sd)
+    model = model.to(device)
+    with torch.no_grad():
+        assert model.embed_fn.params.numel() == g['hash_params'].size
+        model.embed_fn.params.copy_(torch.from_numpy(g['hash_params']))
+    return model
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def run_case(model, g, tag, is_mapping, first, device):
+    draws = [torch.from_numpy(g[f'{tag}/rand{i}'])
+             for i in range(int(g[f'{tag}/n_rand']))]
+    it = iter(draws)
+
+    def fed(shape, like):
+        t = next(it)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.to(like)
+
+    model._rand = fed
+    for p in model.parameters():
+        p.grad = None
+    ro = torch.from_numpy(g['rays_o']).to(device).requires_grad_(True)
+    rd = torch.from_numpy(g['rays_d']).to(device).requires_grad_(True)
+    inp = {'rays_o': ro, 'rays_d': rd, 'first': first,
+           'target_s': torch.from_numpy(g['target_s']).to(device),
+           'target_d': torch.from_numpy(g['target_d']).to(device)}
+    res = model.get_outputs(inp)
+    ld = model.get_loss_dict(res, inp, is_mapping, 0)
+    sum(ld.values()).backward()
+    errs = {}
+    for k in ('rgb', 'depth', 'depth_var', 'acc_map', 'z_vals', 'raw'):
+        errs[k] = rel_err(res[k].detach().cpu().numpy(), g[f'{tag}/{k}'])
+    gold_losses = [k for k in g.files if k.startswith(f'{tag}/loss_')]
+    assert len(gold_losses) == len(ld)
+    for k, v in ld.items():
+        errs[f'loss_{k}'] = rel_err(v.detach().cpu().numpy(),
+                                    g[f'{tag}/loss_{k}'])
+    errs['g_rays_o'] = rel_err(ro.grad.cpu().numpy(), g[f'{tag}/g_rays_o'])
+    errs['g_rays_d'] = rel_err(rd.grad.cpu().numpy(), g[f'{tag}/g_rays_d'])
+    errs['g_hash'] = rel_err(model.embed_fn.params.grad.cpu().numpy(),
+                             g[f'{tag}/g_hash'])
+    for k, p in model.decoder.named_parameters():
+        errs[f'g_dec/{k}'] = rel_err(p.grad.cpu().numpy(),
+                                     g[f'{tag}/g_dec/{k}'])
+    return errs

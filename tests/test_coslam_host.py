@@ -1,0 +1,55 @@
+"""CPU: the Co-SLAM host mirror (JointEncoding: sampling, SDF weights,
+rendering, losses, smoothness) against the reference-generated golden, with
+the oracle encodings standing in for the HIP encodings (the same stand-in the
+reference itself ran on when the golden was made), so that everything above
+the encodings is checked without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+sys.path.insert(0, os.path.dirname(__file__))
+import coslam_golden_util as cg  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture()
+def oracle_encodings(monkeypatch):
+    import tcnn_standin
+    import xrdslam_amd.slam.model_components.encodings_coslam as enc
+    monkeypatch.setattr(enc, 'tcnn', tcnn_standin.module())
+
+
+@pytest.mark.parametrize('tag,is_mapping,first', cg.TAGS)
+def test_joint_encoding_vs_reference(oracle_encodings, tag, is_mapping, first):
+    g = np.load(cg.GOLDEN)
+    model = cg.build_model(g, 'cpu')
+    errs = cg.run_case(model, g, tag, is_mapping, first, 'cpu')
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_fixed_shape_depth_loss_equals_compacted(oracle_encodings):
+    g = np.load(cg.GOLDEN)
+    model = cg.build_model(g, 'cpu')
+    model.fixed_shape_losses = True
+    errs = cg.run_case(model, g, 'track', False, False, 'cpu')
+    assert errs['loss_depth_loss'] < TOL and errs['g_hash'] < TOL
+
+
+def test_param_groups_and_config(oracle_encodings):
+    from xrdslam_amd.slam.configs.input_config import (algorithm_configs,
+                                                       cadence)
+    cfg = algorithm_configs['co-slam']()
+    assert cfg.model.tcnn_encoding and cfg.model.enc == 'HashGrid'
+    assert cfg.tracking_n_iters == 10 and cfg.mapping_sample == 2048
+    assert cadence['co-slam'].map_every == 5
+    g = np.load(cg.GOLDEN)
+    model = cg.build_model(g, 'cpu')
+    groups = model.get_param_groups()
+    assert set(groups) == {'decoder', 'embed_fn'}      # oneGrid default
+    assert set(groups) <= set(cfg.optimizers)

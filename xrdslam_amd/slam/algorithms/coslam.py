@@ -1,0 +1,212 @@
+"""``CoSLAM`` algorithm plugin (reference: slam/algorithms/coslam.py): a global
+bank of keyframe rays (5 % of the pixels of every keyframe as [dir_cam(3),
+rgb(3), depth(1)] rows), mapping batches = bank rays + current-frame rays
+rotated by their (optimisable) keyframe poses, ONE persistent model optimiser
+across all mapping calls, bundle adjustment of every keyframe pose but the
+first with 5-step gradient accumulation.
+
+MI355X-side: the ray bank and the per-frame ray table live in HBM and are
+sampled there (the reference keeps the bank on the host, draws indices with
+python's ``random.sample`` and uploads the batch every iteration,
+coslam.py:139-150,188-191); sampling stays WITHOUT replacement like
+``random.sample``."""
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass, field
+from typing import List, Type
+
+import numpy as np
+import torch
+
+from ..common.common import get_rays, get_samples
+from ..engine.optimizers import Optimizers
+from ..models.joint_encoding import JointEncodingConfig
+from .base_algorithm import Algorithm, AlgorithmConfig
+
+
+@dataclass
+class CoSLAMConfig(AlgorithmConfig):
+    _target: Type = field(default_factory=lambda: CoSLAM)
+    model: JointEncodingConfig = field(default_factory=JointEncodingConfig)
+    rays_to_save_ratio: float = 0.05
+    tracking_Wedge: int = 20
+    tracking_Hedge: int = 20
+    mapping_sample: int = 2048
+    min_sample_pixels: int = 100
+    tracking_sample: int = 1024
+    ray_batch_size: int = 3000
+    marching_cubes_bound: List[List[float]] = field(
+        default_factory=lambda: [[-3.5, 3], [-3, 3], [-3, 3]])
+    mapping_bound: List[List[float]] = field(
+        default_factory=lambda: [[-3.5, 3], [-3, 3], [-3, 3]])
+
+
+def camera_ray_table(camera, device):
+    """[H*W, 3] camera-frame ray directions, row-major pixels, OpenGL
+    (slam/utils/utils.py:28-65 get_camera_rays)"""
+    j, i = torch.meshgrid(
+        torch.arange(camera.height, dtype=torch.float32, device=device),
+        torch.arange(camera.width, dtype=torch.float32, device=device),
+        indexing='ij')
+    dirs = torch.stack([(i - camera.cx) / camera.fx,
+                        -(j - camera.cy) / camera.fy, -torch.ones_like(i)],
+                       -1)
+    return dirs.reshape(-1, 3)
+
+
+class CoSLAM(Algorithm):
+    config: CoSLAMConfig
+
+    def __init__(self, config: CoSLAMConfig, camera, device: str) -> None:
+        super().__init__(config, camera, device)
+        self.marching_cube_bound = torch.from_numpy(
+            np.array(config.marching_cubes_bound))
+        self.bounding_box = torch.from_numpy(np.array(config.mapping_bound))
+        self.model = config.model.setup(camera=camera,
+                                        bounding_box=self.bounding_box)
+        self.model.to(device)
+        self.cur_mesh = None
+        self.bundle_adjust = True
+        self.num_rays_to_save = int(camera.width * camera.height *
+                                    config.rays_to_save_ratio)
+        self.rays = None           # [n_kf * num_rays_to_save, 7] on the device
+        self.model_optimizers = None
+        self._dirs = None
+
+    # -- hooks that are no-ops for Co-SLAM --------------------------------------
+    def pre_precessing(self, cur_frame, is_mapping):
+        pass
+
+    def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
+        pass
+
+    def optimizer_config_update(self, max_iters, coarse=False):
+        pass
+
+    # -- optimisers (coslam.py:66-112) -----------------------------------------
+    def setup_optimizers(self, n_iters, optimize_frames, is_mapping=True,
+                         coarse=False) -> Optimizers:
+        cfg = dict(self.config.optimizers)
+        if not is_mapping:
+            return Optimizers(cfg, self._pose_groups(optimize_frames[:1],
+                                                     'tracking_pose'))
+        if self.model_optimizers is None:
+            self.model_optimizers = Optimizers(
+                cfg, {**self.model.get_param_groups()})
+        if not self.bundle_adjust or len(optimize_frames) == 1:
+            return self.model_optimizers
+        # the first keyframe's pose stays fixed
+        pose_opt = Optimizers(cfg, self._pose_groups(optimize_frames[1:],
+                                                     'mapping_pose'))
+        merged = pose_opt + self.model_optimizers
+        merged.parameters = {**pose_opt.parameters,
+                             **self.model_optimizers.parameters}
+        return merged
+
+    # -- ray bank ---------------------------------------------------------------
+    def _ray_dirs(self):
+        dev = self.model.device
+        if self._dirs is None or self._dirs.device != torch.device(dev):
+            self._dirs = camera_ray_table(self.camera, dev)
+        return self._dirs
+
+    def sample_single_keyframe_rays(self, keyframe, bs):
+        """bs rows [dir_cam, rgb, depth] of one frame, without replacement"""
+        dev = self.model.device
+        depth, rgb = keyframe.device_images(dev)
+        n = self.camera.height * self.camera.width
+        idx = torch.randperm(n, device=dev)[:bs]
+        return torch.cat([self._ray_dirs()[idx], rgb[idx], depth[idx]], -1)
+
+    def add_keyframe(self, keyframe):
+        with self.lock:
+            rays = self.sample_single_keyframe_rays(keyframe,
+                                                    self.num_rays_to_save)
+            self.rays = rays if self.rays is None else torch.cat(
+                [self.rays, rays], 0)
+            # only pose and rays are kept (coslam.py:135-137)
+            keyframe.rgb = None
+            keyframe.depth = None
+            keyframe._dev_cache = None
+            self.keyframe_graph.append(keyframe)
+
+    def sample_global_rays(self, bs):
+        total = len(self.keyframe_graph) * self.num_rays_to_save
+        idx = torch.randperm(total, device=self.rays.device)[:bs]
+        return self.rays[idx], torch.div(idx, self.num_rays_to_save,
+                                         rounding_mode='floor')
+
+    def get_model_input(self, optimize_frames, is_mapping):
+        cfg, dev = self.config, self.model.device
+        cur = optimize_frames[-1]
+        if not is_mapping:
+            o, d, dep, col = get_samples(self.camera, cfg.tracking_sample,
+                                         cur.get_pose(), cur.depth, cur.rgb,
+                                         device=dev,
+                                         Hedge=cfg.tracking_Hedge,
+                                         Wedge=cfg.tracking_Wedge, frame=cur)
+            return {'rays_o': o.float(), 'rays_d': d.float(),
+                    'target_s': col.float(), 'target_d': dep.float(),
+                    'first': False}
+        ids, rays, poses = [], [], []
+        n_cur = cfg.mapping_sample
+        have_kf = len(self.keyframe_graph) > 0
+        if have_kf:
+            bank, fid = self.sample_global_rays(cfg.mapping_sample)
+            ids.append(fid)
+            rays.append(bank)
+            for f in optimize_frames[:-1]:
+                pose = f.get_pose().unsqueeze(0).to(dev)
+                poses.append(pose.detach() if f.fid == 0 else pose)
+            n_cur = max(cfg.mapping_sample // len(self.keyframe_graph),
+                        cfg.min_sample_pixels)
+        cur_rays = self.sample_single_keyframe_rays(cur, n_cur)
+        poses.append(cur.get_pose().unsqueeze(0).to(dev))
+        # index -1 = the current frame = last pose
+        ids.append(torch.full((cur_rays.shape[0], ), len(poses) - 1,
+                              dtype=torch.int64, device=dev))
+        rays.append(cur_rays)
+        poses = torch.cat(poses, 0)
+        ids = torch.cat(ids, 0)
+        rays = torch.cat(rays, 0)
+        R = poses[ids, :3, :3]
+        rays_d = (rays[:, None, :3] * R).sum(-1)
+        rays_o = poses[ids, :3, 3]
+        return {'rays_o': rays_o.float(), 'rays_d': rays_d.float(),
+                'target_s': rays[:, 3:6].float(),
+                'target_d': rays[:, 6:7].float(), 'first': not have_kf}
+
+    def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
+                 coarse=False):
+        self.model.fixed_shape_losses = getattr(self, 'fixed_shape_batches',
+                                                False)
+        inp = self.get_model_input(optimize_frames, is_mapping)
+        out = self.model(inp)
+        losses = self.model.get_loss_dict(out, inp, is_mapping, step)
+        return functools.reduce(torch.add, losses.values())
+
+    def render_img(self, c2w, gt_depth=None, idx=None):
+        with torch.no_grad():
+            dev = self.model.device
+            rays_o, rays_d = get_rays(self.camera, c2w, device=dev)
+            rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+            if gt_depth is not None:
+                gt_depth = torch.as_tensor(gt_depth).to(dev).reshape(-1, 1)
+            depths, colors = [], []
+            bs = self.config.ray_batch_size
+            for i in range(0, rays_d.shape[0], bs):
+                out = self.model({
+                    'rays_o': rays_o[i:i + bs], 'rays_d': rays_d[i:i + bs],
+                    'target_s': None,
+                    'target_d': None if gt_depth is None
+                    else gt_depth[i:i + bs]})
+                depths.append(out['depth'].double())
+                colors.append(out['rgb'])
+            H, W = self.camera.height, self.camera.width
+            return torch.cat(colors).reshape(H, W, 3).cpu().numpy(), \
+                torch.cat(depths).reshape(H, W).cpu().numpy()
+
+    def get_mesh(self):
+        raise NotImplementedError('mesh extraction is out of the hot-path '
+                                  'scope (SURVEY.md §8f #3)')

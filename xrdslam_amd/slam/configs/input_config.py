@@ -7,10 +7,12 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict
 
+from ..algorithms.coslam import CoSLAMConfig
 from ..algorithms.nice_slam import NiceSLAMConfig
 from ..engine.optimizers import AdamOptimizerConfig
 from ..engine.schedulers import LRconfig, NiceSLAMSchedulerConfig
 from ..models.conv_onet import ConvOnetConfig
+from ..models.joint_encoding import JointEncodingConfig
 
 
 @dataclass
@@ -61,5 +63,40 @@ def nice_slam_config(bound=None) -> NiceSLAMConfig:
         })
 
 
-algorithm_configs: Dict[str, object] = {'nice-slam': nice_slam_config}
-cadence: Dict[str, PipelineCadence] = {'nice-slam': PipelineCadence()}
+def coslam_config(bound=None) -> CoSLAMConfig:
+    """algorithm_configs['co-slam'] (input_config.py:203-295), office0"""
+    bound = bound or [[-3, 3], [-4, 2.5], [-2, 2.5]]
+    adam = AdamOptimizerConfig
+    return CoSLAMConfig(
+        separate_LR=True, retain_graph=True, rot_rep='axis_angle',
+        tracking_n_iters=10, mapping_n_iters=10, mapping_first_n_iters=200,
+        keyframe_selection_method='all', mapping_sample=2048,
+        tracking_sample=1024, min_sample_pixels=100, ray_batch_size=30000,
+        tracking_Wedge=20, tracking_Hedge=20,
+        mapping_bound=[list(b) for b in bound],
+        marching_cubes_bound=[list(b) for b in bound],
+        model=JointEncodingConfig(cam_depth_trunc=100.0, tcnn_encoding=True),
+        optimizers={
+            'decoder': {'optimizer': adam(lr=1e-2, weight_decay=1e-6,
+                                          betas=(0.9, 0.99)),
+                        'scheduler': None},
+            'embed_fn': {'optimizer': adam(lr=1e-2, eps=1e-15,
+                                           betas=(0.9, 0.99)),
+                         'scheduler': None},
+            'embed_fn_color': {'optimizer': adam(lr=1e-2, eps=1e-15,
+                                                 betas=(0.9, 0.99)),
+                               'scheduler': None},
+            'tracking_pose_r': {'optimizer': adam(lr=1e-3), 'scheduler': None},
+            'tracking_pose_t': {'optimizer': adam(lr=1e-3), 'scheduler': None},
+            'mapping_pose_r': {'optimizer': adam(lr=1e-3, accum_step=5),
+                               'scheduler': None},
+            'mapping_pose_t': {'optimizer': adam(lr=1e-3, accum_step=5),
+                               'scheduler': None},
+        })
+
+
+algorithm_configs: Dict[str, object] = {'nice-slam': nice_slam_config,
+                                        'co-slam': coslam_config}
+cadence: Dict[str, PipelineCadence] = {
+    'nice-slam': PipelineCadence(),
+    'co-slam': PipelineCadence(map_every=5, keyframe_every=5)}

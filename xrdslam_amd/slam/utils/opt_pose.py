@@ -113,17 +113,21 @@ class OptimizablePose(nn.Module):
     @staticmethod
     def axis_angle_to_rotation_matrix(angle_axis):
         """Rodrigues; exactly I when the angle is (all)close to 0
-        (opt_pose.py:78-95)."""
-        angle = torch.norm(angle_axis, dim=-1, keepdim=True)
+        (opt_pose.py:78-95).  Written without the reference's host-side
+        ``torch.allclose`` branch so that it can be captured in a hipGraph:
+        the small-angle case is selected with ``torch.where`` (same values,
+        zero gradient there, like the constant I of the reference)."""
         eye = torch.eye(3, device=angle_axis.device, dtype=angle_axis.dtype)
-        if torch.allclose(angle, torch.zeros_like(angle)):
-            return eye
-        w = angle_axis / angle
+        small = torch.norm(angle_axis.detach(), dim=-1, keepdim=True) <= 1e-8
+        safe = torch.where(small, torch.ones_like(angle_axis), angle_axis)
+        angle = torch.norm(safe, dim=-1, keepdim=True)
+        w = safe / angle
         z = torch.zeros_like(w[0])
         K = torch.stack([torch.stack([z, -w[2], w[1]]),
                          torch.stack([w[2], z, -w[0]]),
                          torch.stack([-w[1], w[0], z])])
-        return eye + K * torch.sin(angle) + (1. - torch.cos(angle)) * (K @ K)
+        R = eye + K * torch.sin(angle) + (1. - torch.cos(angle)) * (K @ K)
+        return torch.where(small, eye, R)
 
     @classmethod
     def from_matrix(cls, Rt, separate_LR=True, rot_rep='axis_angle'):
