@@ -366,6 +366,69 @@ int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
 int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
                    float* best_c2w16, uint8_t* valid, xrd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Co-SLAM fused ray renderer — replaces, for the reference's default model
+ * (oneGrid, HashGrid 16x2 + OneBlob 16 bins, 2x32 bias-free MLPs, depth-guided
+ * sampling), JointEncoding.render_rays / run_network / query_color_sdf /
+ * sdf2weights / raw2outputs (slam/models/joint_encoding.py:250-344, 483-507,
+ * 463-481, 346-374, 376-407) and ColorSDFNet_v2.forward
+ * (slam/model_components/decoder_coslam.py), forward and backward.
+ * One ray = n_range_d + n_sample_d <= 48 samples.
+ * ---------------------------------------------------------------------- */
+#define XRD_COSLAM_LEVELS 16
+typedef struct xrd_coslam_scene {
+  double bound[6];            /* xmin,xmax, ymin,ymax, zmin,zmax (float64 as
+                                 in run_network's normalisation) */
+  float lv_scale[XRD_COSLAM_LEVELS];   /* xrd_hashgrid_levels() table */
+  uint32_t lv_res[XRD_COSLAM_LEVELS];
+  uint32_t lv_size[XRD_COSLAM_LEVELS];
+  uint32_t lv_offset[XRD_COSLAM_LEVELS];
+  const float* table;         /* hash-grid parameters [entries][2] (device) */
+  const float* pack;          /* packed decoder weights, xrd_coslam_pack_len()
+                                 floats (device) */
+  const float* t_near;        /* [n_range_d] linspace(-range_d, range_d) */
+  const float* t_far;         /* [n_range_d] linspace(near, far) (depth<=0) */
+  const float* t_uniform;     /* [n_sample_d] linspace(near, far) */
+  int32_t n_range_d, n_sample_d;
+  int32_t perturb, white_bkgd;
+  float trunc;                /* training_trunc */
+  float sc_factor;            /* data_sc_factor */
+} xrd_coslam_scene;
+
+/* HOST: length of the flat decoder vector (state_dict order: color_net.model.0
+ * [32,63], color_net.model.2 [3,32], sdf_net.model.0 [32,80], sdf_net.model.2
+ * [16,32]), of the packed MFMA-fragment buffer, and of the slot-space
+ * weight-gradient buffer the backward pass produces */
+int xrd_coslam_flat_len(void);
+int xrd_coslam_pack_len(void);
+int xrd_coslam_dw_len(void);
+/* HOST: pack_idx[pack_len]: flat index feeding each packed float (-1 = 0);
+ * dw_idx[flat_len]: position of each flat parameter's gradient in the
+ * slot-space buffer.  Either pointer may be NULL. */
+int xrd_coslam_index(int32_t* pack_idx, int32_t* dw_idx);
+
+/* forward.  target_d[n] (>0 valid), rnd[n,S] uniform draws (NULL iff
+ * perturb == 0).  out: z_vals[n,S], raw[n,S,4] (rgb logits, sdf),
+ * maps[n,8] = rgb(3), depth, depth_var, acc, disp, 0 */
+int xrd_coslam_render_fwd(const xrd_coslam_scene* scene, int n_rays,
+                          const float* rays_o, const float* rays_d,
+                          const float* target_d, const float* rnd,
+                          float* z_vals, float* raw, float* maps,
+                          xrd_stream_t stream);
+/* floats of workspace for the backward pass */
+int64_t xrd_coslam_bwd_ws_floats(void);
+/* backward from g_maps[n,8] (rgb, depth, depth_var, acc; disp ignored) and
+ * g_raw[n,S,4] (may be NULL), with z_vals/raw as produced by the forward.
+ * g_rays_o/g_rays_d [n,3] overwritten (both NULL: no ray gradients);
+ * g_table ACCUMULATED (atomics) and g_dw[dw_len] overwritten (both NULL: map
+ * and decoder frozen, the tracking case). */
+int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
+                          const float* rays_o, const float* rays_d,
+                          const float* z_vals, const float* raw,
+                          const float* g_maps, const float* g_raw,
+                          float* g_rays_o, float* g_rays_d, float* g_table,
+                          float* g_dw, float* workspace, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

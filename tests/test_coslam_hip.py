@@ -16,10 +16,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('tag,is_mapping,first', cg.TAGS)
-def test_joint_encoding_vs_reference(tag, is_mapping, first):
+def test_joint_encoding_vs_reference(tag, is_mapping, first, fused):
+    """fused=True: one render kernel forward, one backward (xrd_coslam_*);
+    fused=False: modular HIP encodings + torch MLPs"""
     g = np.load(cg.GOLDEN)
     model = cg.build_model(g, 'cuda:0')
+    model.use_fused = fused
+    assert (model._fused_tables('cuda:0') is not None) == fused
     errs = cg.run_case(model, g, tag, is_mapping, first, 'cuda:0')
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, bad

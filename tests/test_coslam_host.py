@@ -53,3 +53,23 @@ def test_param_groups_and_config(oracle_encodings):
     groups = model.get_param_groups()
     assert set(groups) == {'decoder', 'embed_fn'}      # oneGrid default
     assert set(groups) <= set(cfg.optimizers)
+
+
+def test_fused_pack_and_gradient_index_tables():
+    """slot-space layout of the fused renderer (csrc/coslam_layout.h): every
+    decoder weight feeds exactly one lane of the forward fragments and one
+    lane of the transposed (backward) fragments, and has exactly one slot in
+    the weight-gradient buffer"""
+    from xrdslam_amd import _lib
+    lib = _lib.lib()
+    flat_len, pack_len = lib.xrd_coslam_flat_len(), lib.xrd_coslam_pack_len()
+    assert flat_len == 32 * 63 + 3 * 32 + 32 * 80 + 16 * 32
+    pack = np.zeros(pack_len, np.int32)
+    dw = np.zeros(flat_len, np.int32)
+    assert lib.xrd_coslam_index(pack.ctypes.data, dw.ctypes.data) == 0
+    half = pack_len // 2
+    for part in (pack[:half], pack[half:]):
+        used = part[part >= 0]
+        assert np.array_equal(np.sort(used), np.arange(flat_len))
+    assert len(np.unique(dw)) == flat_len
+    assert dw.min() >= 0 and dw.max() < lib.xrd_coslam_dw_len()

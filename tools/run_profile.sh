@@ -5,7 +5,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python $GRAFT_REPO_ROOT/bench.py "$@" > $out/bench_stdout.txt 2> $out/bench_stderr.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python $GRAFT_REPO_ROOT/${XRD_PROF_SCRIPT:-bench.py} "$@" > $out/bench_stdout.txt 2> $out/bench_stderr.txt
 cp /tmp/prof_$tag/bench_kernel_stats.csv $out/ 2>/dev/null
 python $GRAFT_REPO_ROOT/tools/prof_summary.py $out/bench_kernel_stats.csv 40 > $out/kernel_summary.txt
 tail -1 $out/bench_stdout.txt

@@ -28,6 +28,16 @@ class NiceScene(C.Structure):
                 ('coarse_enlarge', f64)]
 
 
+class CoslamScene(C.Structure):
+    """mirror of ``xrd_coslam_scene``"""
+    _fields_ = [('bound', f64 * 6), ('lv_scale', f32 * 16),
+                ('lv_res', C.c_uint32 * 16), ('lv_size', C.c_uint32 * 16),
+                ('lv_offset', C.c_uint32 * 16), ('table', vp), ('pack', vp),
+                ('t_near', vp), ('t_far', vp), ('t_uniform', vp),
+                ('n_range_d', i32), ('n_sample_d', i32), ('perturb', i32),
+                ('white_bkgd', i32), ('trunc', f32), ('sc_factor', f32)]
+
+
 _SIGS = {
     'xrd_abi_version': (C.c_int, []),
     'xrd_last_error': (C.c_char_p, []),
@@ -90,6 +100,15 @@ _SIGS = {
     'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
                                  vp, vp]),
     'xrd_track_best': (C.c_int, [vp] * 6),
+    'xrd_coslam_flat_len': (C.c_int, []),
+    'xrd_coslam_pack_len': (C.c_int, []),
+    'xrd_coslam_dw_len': (C.c_int, []),
+    'xrd_coslam_index': (C.c_int, [vp, vp]),
+    'xrd_coslam_render_fwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
+                              [vp] * 8),
+    'xrd_coslam_bwd_ws_floats': (i64, []),
+    'xrd_coslam_render_bwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
+                              [vp] * 12),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

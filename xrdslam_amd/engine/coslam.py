@@ -1,0 +1,176 @@
+"""Host side of the fused Co-SLAM ray renderer (csrc/coslam_render.hip,
+include/xrdslam_hip.h ``xrd_coslam_*``): one launch renders a batch of rays
+(depth-guided sampling, hash grid + OneBlob, both MLPs, SDF compositing), one
+launch back-propagates to rays, hash table and decoder weights.
+
+It covers the reference's default Co-SLAM model only (oneGrid, HashGrid 16x2,
+OneBlob 16 bins, hidden 32, geo feature 15, two layers per MLP, depth-guided
+samples <= 48 per ray); ``supported()`` says whether a model qualifies — the
+caller (slam/models/joint_encoding.py) otherwise uses the modular HIP
+encodings with torch MLPs.  No CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+_INDEX = {}
+
+
+def _index(device):
+    """(pack gather index into [flat, 0], dW gather index) on ``device``"""
+    key = str(device)
+    if key not in _INDEX:
+        lib = _lib.lib()
+        pack = np.zeros(lib.xrd_coslam_pack_len(), np.int32)
+        dw = np.zeros(lib.xrd_coslam_flat_len(), np.int32)
+        _lib.check(lib.xrd_coslam_index(pack.ctypes.data, dw.ctypes.data),
+                   'xrd_coslam_index')
+        pack = np.where(pack < 0, lib.xrd_coslam_flat_len(), pack)
+        _INDEX[key] = (torch.from_numpy(pack.astype(np.int64)).to(device),
+                       torch.from_numpy(dw.astype(np.int64)).to(device))
+    return _INDEX[key]
+
+
+def flat_decoder(decoder) -> torch.Tensor:
+    """state_dict order: color_net.model.0, color_net.model.2,
+    sdf_net.model.0, sdf_net.model.2 (differentiable concatenation)"""
+    ws = [decoder.color_net.model[0].weight, decoder.color_net.model[2].weight,
+          decoder.sdf_net.model[0].weight, decoder.sdf_net.model[2].weight]
+    return torch.cat([w.reshape(-1) for w in ws])
+
+
+def supported(model) -> bool:
+    cfg = model.config
+    enc = getattr(model.embed_fn, 'encoding_config', None)
+    pos = getattr(model.embedpos_fn, 'encoding_config', None)
+    if enc is None or pos is None or not cfg.oneGrid or cfg.tcnn_network:
+        return False
+    if not cfg.tcnn_encoding or cfg.training_n_importance > 0:
+        return False
+    if enc.get('otype') != 'HashGrid' or model.embed_fn.n_levels != 16 or \
+            pos.get('otype') != 'OneBlob' or model.embedpos_fn.n_bins != 16:
+        return False
+    if (cfg.hidden_dim, cfg.hidden_dim_color, cfg.geo_feat_dim,
+            cfg.num_layers, cfg.num_layers_color) != (32, 32, 15, 2, 2):
+        return False
+    return cfg.training_n_range_d + cfg.training_n_sample_d <= 48 and \
+        cfg.training_n_range_d >= 1
+
+
+class SceneTables:
+    """per-model constant tables on the device (linspaces exactly as the
+    reference builds them: torch.linspace on the CPU, then moved)"""
+
+    def __init__(self, model, device):
+        cfg = model.config
+        self.t_near = torch.linspace(-cfg.training_range_d,
+                                     cfg.training_range_d,
+                                     steps=cfg.training_n_range_d).to(device)
+        self.t_far = torch.linspace(cfg.cam_near, cfg.cam_far,
+                                    steps=cfg.training_n_range_d).to(device)
+        self.t_uniform = torch.linspace(
+            cfg.cam_near, cfg.cam_far,
+            max(cfg.training_n_sample_d, 1)).to(device)
+        self.ws = torch.empty(_lib.lib().xrd_coslam_bwd_ws_floats(),
+                              dtype=torch.float32, device=device)
+        self.device = torch.device(device)
+
+
+def make_scene(model, tables, table_params, pack):
+    cfg = model.config
+    enc = model.embed_fn
+    sc = _lib.CoslamScene()
+    bb = model.bounding_box.detach().cpu().double().numpy()
+    for d in range(3):
+        sc.bound[2 * d], sc.bound[2 * d + 1] = bb[d, 0], bb[d, 1]
+    for l in range(16):
+        sc.lv_scale[l] = float(enc._scales[l])
+        sc.lv_res[l] = int(enc._res[l])
+        sc.lv_size[l] = int(enc._sizes[l])
+        sc.lv_offset[l] = int(enc._offsets[l])
+    sc.table = table_params.data_ptr()
+    sc.pack = pack.data_ptr()
+    sc.t_near = tables.t_near.data_ptr()
+    sc.t_far = tables.t_far.data_ptr()
+    sc.t_uniform = tables.t_uniform.data_ptr()
+    sc.n_range_d = cfg.training_n_range_d
+    sc.n_sample_d = cfg.training_n_sample_d
+    sc.perturb = 1 if cfg.training_perturb > 0. else 0
+    sc.white_bkgd = 1 if cfg.training_white_bkgd else 0
+    sc.trunc = float(cfg.training_trunc)
+    sc.sc_factor = float(cfg.data_sc_factor)
+    return sc
+
+
+class _CoslamRenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, target_d, rnd, table, flat, model,
+                tables):
+        lib = _lib.lib()
+        dev = rays_o.device
+        pack_idx, _ = _index(dev)
+        with torch.no_grad():
+            pack = torch.cat([flat.detach().float(),
+                              flat.new_zeros(1)])[pack_idx].contiguous()
+        ro = rays_o.detach().float().contiguous()
+        rd = rays_d.detach().float().contiguous()
+        td = target_d.detach().float().reshape(-1).contiguous()
+        rn = None if rnd is None else rnd.detach().float().contiguous()
+        n = ro.shape[0]
+        sc = make_scene(model, tables, table.detach(), pack)
+        S = sc.n_range_d + sc.n_sample_d
+        z_vals = torch.empty(n, S, dtype=torch.float32, device=dev)
+        raw = torch.empty(n, S, 4, dtype=torch.float32, device=dev)
+        maps = torch.empty(n, 8, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_coslam_render_fwd(
+            C.byref(sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(td),
+            _lib.ptr(rn), _lib.ptr(z_vals), _lib.ptr(raw), _lib.ptr(maps),
+            _lib.stream_ptr(dev)), 'xrd_coslam_render_fwd')
+        ctx.sc, ctx.tables = sc, tables
+        ctx.save_for_backward(ro, rd, z_vals, raw, table, pack)
+        ctx.mark_non_differentiable(z_vals)
+        return maps, z_vals, raw
+
+    @staticmethod
+    def backward(ctx, g_maps, _gz, g_raw):
+        lib = _lib.lib()
+        ro, rd, z_vals, raw, table, pack = ctx.saved_tensors
+        dev = ro.device
+        n = ro.shape[0]
+        need_rays = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_map = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        g_o = torch.empty_like(ro) if need_rays else None
+        g_d = torch.empty_like(rd) if need_rays else None
+        g_table = g_dw = None
+        if need_map:
+            g_table = torch.zeros_like(table)
+            g_dw = torch.empty(lib.xrd_coslam_dw_len(), dtype=torch.float32,
+                               device=dev)
+        g_maps = torch.zeros(n, 8, dtype=torch.float32, device=dev) \
+            if g_maps is None else g_maps.float().contiguous()
+        if g_raw is not None:
+            g_raw = g_raw.float().contiguous()
+        _lib.check(lib.xrd_coslam_render_bwd(
+            C.byref(ctx.sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(z_vals),
+            _lib.ptr(raw), _lib.ptr(g_maps), _lib.ptr(g_raw), _lib.ptr(g_o),
+            _lib.ptr(g_d), _lib.ptr(g_table), _lib.ptr(g_dw),
+            _lib.ptr(ctx.tables.ws) if need_map else None,
+            _lib.stream_ptr(dev)), 'xrd_coslam_render_bwd')
+        g_flat = None
+        if need_map:
+            g_flat = g_dw[_index(dev)[1]]
+        return g_o, g_d, None, None, g_table, g_flat, None, None
+
+
+def render(model, tables, rays_o, rays_d, target_d, rnd):
+    """-> dict like JointEncoding.render_rays (joint_encoding.py:250-344)"""
+    maps, z_vals, raw = _CoslamRenderFn.apply(
+        rays_o, rays_d, target_d, rnd, model.embed_fn.params,
+        flat_decoder(model.decoder), model, tables)
+    return {'rgb': maps[:, 0:3], 'depth': maps[:, 3], 'disp_map': maps[:, 6],
+            'acc_map': maps[:, 5], 'depth_var': maps[:, 4], 'z_vals': z_vals,
+            'raw': raw}

@@ -167,9 +167,31 @@ class JointEncoding(Model):
         return tv / (sample_points**3)
 
     # -- rendering ----------------------------------------------------------
+    def _fused_tables(self, device):
+        """device tables of the fused renderer, or None when this model /
+        device is outside what the fused kernels cover"""
+        from ...engine import coslam as ec
+        if getattr(self, '_fused_ok', None) is None:
+            self._fused_ok = ec.supported(self)
+        if not self._fused_ok or not getattr(self, 'use_fused', True) or \
+                torch.device(device).type != 'cuda':
+            return None
+        t = getattr(self, '_fused_tab', None)
+        if t is None or t.device != torch.device(device):
+            t = self._fused_tab = ec.SceneTables(self, device)
+        return t
+
     def render_rays(self, rays_o, rays_d, target_d=None):
         cfg = self.config
         n_rays = rays_o.shape[0]
+        if target_d is not None:
+            tab = self._fused_tables(rays_o.device)
+            if tab is not None:
+                from ...engine import coslam as ec
+                S = cfg.training_n_range_d + cfg.training_n_sample_d
+                rnd = self._rand((n_rays, S), rays_o) \
+                    if cfg.training_perturb > 0. else None
+                return ec.render(self, tab, rays_o, rays_d, target_d, rnd)
         if target_d is not None:
             lin = torch.linspace(-cfg.training_range_d, cfg.training_range_d,
                                  steps=cfg.training_n_range_d).to(target_d)
