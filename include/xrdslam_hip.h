@@ -160,7 +160,8 @@ int xrd_hashgrid_fwd(int n_levels, const float* scales, const uint32_t* res,
                      const uint32_t* sizes, const uint32_t* offsets,
                      int64_t n_points, const float* x, const float* params,
                      float* y, xrd_stream_t stream);
-/* dparams (ACCUMULATED, atomics; may be NULL), dx[n,3] (overwritten; may be
+/* dparams (ACCUMULATED: LDS-privatised per 8192-entry chunk, then coalesced
+ * atomic adds of the non-zero entries; may be NULL), dx[n,3] (overwritten; may be
  * NULL) from dy[n,2*L] */
 int xrd_hashgrid_bwd(int n_levels, const float* scales, const uint32_t* res,
                      const uint32_t* sizes, const uint32_t* offsets,
@@ -415,13 +416,14 @@ int xrd_coslam_render_fwd(const xrd_coslam_scene* scene, int n_rays,
                           const float* target_d, const float* rnd,
                           float* z_vals, float* raw, float* maps,
                           xrd_stream_t stream);
-/* floats of workspace for the backward pass */
-int64_t xrd_coslam_bwd_ws_floats(void);
+/* floats of workspace the backward pass needs for n_rays rays */
+int64_t xrd_coslam_bwd_ws_floats(int n_rays);
 /* backward from g_maps[n,8] (rgb, depth, depth_var, acc; disp ignored) and
  * g_raw[n,S,4] (may be NULL), with z_vals/raw as produced by the forward.
  * g_rays_o/g_rays_d [n,3] overwritten (both NULL: no ray gradients);
- * g_table ACCUMULATED (atomics) and g_dw[dw_len] overwritten (both NULL: map
- * and decoder frozen, the tracking case). */
+ * g_table (whole table) and g_dw[dw_len] OVERWRITTEN (both NULL: map and
+ * decoder frozen, the tracking case).  The table gradient is scattered through
+ * LDS-privatised 8192-entry chunks (no random global atomics). */
 int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                           const float* rays_o, const float* rays_d,
                           const float* z_vals, const float* raw,

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libxrdslam_hip.so')
+# XRD_LIB: kernel-experiment builds (tools/build_variant.sh) only
+LIB_PATH = os.environ.get('XRD_LIB') or os.path.join(_HERE,
+                                                   'libxrdslam_hip.so')
 
 _lib = None
 
@@ -106,7 +108,7 @@ _SIGS = {
     'xrd_coslam_index': (C.c_int, [vp, vp]),
     'xrd_coslam_render_fwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
                               [vp] * 8),
-    'xrd_coslam_bwd_ws_floats': (i64, []),
+    'xrd_coslam_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_coslam_render_bwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
                               [vp] * 12),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),

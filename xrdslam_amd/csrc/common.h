@@ -17,6 +17,18 @@ namespace xrd {
 extern thread_local const char* g_last_error;
 int check_launch(const char* what);
 
+// Hash-table gradient scatter (encodings.hip): a block takes one 8192-entry
+// chunk of one level and a slice of the points, accumulates the contributions
+// that fall into its chunk in LDS and adds the chunk to dparams with coalesced
+// atomics (accumulate == false: dparams is zeroed first).  dy: per point and level one float2 at
+// dy[p * point_stride + l * level_stride].
+int launch_hash_chunk_scatter(int n_levels, const float* scales,
+                              const uint32_t* res, const uint32_t* sizes,
+                              const uint32_t* offsets, int64_t n_points,
+                              const float* x, const float* dy,
+                              int64_t point_stride, int64_t level_stride,
+                              float* dparams, bool accumulate, void* stream);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

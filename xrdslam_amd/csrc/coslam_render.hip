@@ -487,8 +487,8 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
     const float* __restrict__ rays_d, const float* __restrict__ z_vals,
     const float* __restrict__ raw, const float* __restrict__ g_maps,
     const float* __restrict__ g_raw, float* __restrict__ g_o,
-    float* __restrict__ g_d, float* __restrict__ g_table,
-    float* __restrict__ partials) {
+    float* __restrict__ g_d, float* __restrict__ partials,
+    float* __restrict__ xs, float* __restrict__ dfeat) {
   __shared__ __attribute__((aligned(16))) float lds[kBwdWaves * kStage];
   __shared__ LevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -498,6 +498,12 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
   const int S = sc.n_range_d + sc.n_sample_d;
   const int NT = (S + 15) >> 4;
   const int tiles = n_rays * NT;
+  const size_t n_samples = (size_t)n_rays * S;
+#ifdef XRD_CS_NO_DW  // experiment switch
+  constexpr bool DW = false;
+#else
+  constexpr bool DW = DG;
+#endif
   float* T = lds + wave * kStage;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 dw0[2][5], dw1[1][2], dw2[2][4], dw3[1][2];
@@ -532,6 +538,18 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
       const float g = __shfl(dr[c], src);
       gc[c] = live ? g : 0.f;
     }
+    // tiles whose samples all lie behind the truncation band of their ray
+    // carry exactly zero gradient: nothing to do
+    if (!__any(gc[0] != 0.f || gc[1] != 0.f || gc[2] != 0.f || gc[3] != 0.f)) {
+      if (DG && live) {
+        const size_t smp_g = (size_t)ray * S + smp;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          *reinterpret_cast<float2*>(dfeat + ((size_t)(q + 4 * a) * n_samples +
+                                              smp_g) * 2) = make_float2(0.f, 0.f);
+      }
+      continue;
+    }
     float xn[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
     f32x4 g3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) g3[r] = (q == 0 && r < 3) ? gc[r] : 0.f;
-    if (DG) {  // G = g3 (1 tile), X = hc (2 tiles)
+    if (DW) {  // G = g3 (1 tile), X = hc (2 tiles)
       stage4(T, 0, j, q, g3[0], g3[1], g3[2], g3[3]);
       stage4(T, 1, j, q, A.hc[0][0], A.hc[0][1], A.hc[0][2], A.hc[0][3]);
       stage4(T, 2, j, q, A.hc[1][0], A.hc[1][1], A.hc[1][2], A.hc[1][3]);
@@ -569,7 +587,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
       dhc[m] = acc;
     }
     CS_SB;
-    if (DG) {  // colour layer 1: G = dhc (2), X = OneBlob (3) + h2 (1)
+    if (DW) {  // colour layer 1: G = dhc (2), X = OneBlob (3) + h2 (1)
       stage4(T, 0, j, q, dhc[0][0], dhc[0][1], dhc[0][2], dhc[0][3]);
       stage4(T, 1, j, q, dhc[1][0], dhc[1][1], dhc[1][2], dhc[1][3]);
 #pragma unroll
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
     }
     f32x4 gh2 = dxc[3];
     if (q == 0) gh2[0] += gc[3];  // slot 0 = sdf
-    if (DG) {  // sdf layer 2: G = gh2 (1), X = h1 (2)
+    if (DW) {  // sdf layer 2: G = gh2 (1), X = h1 (2)
       stage4(T, 0, j, q, gh2[0], gh2[1], gh2[2], gh2[3]);
       stage4(T, 1, j, q, A.h1[0][0], A.h1[0][1], A.h1[0][2], A.h1[0][3]);
       stage4(T, 2, j, q, A.h1[1][0], A.h1[1][1], A.h1[1][2], A.h1[1][3]);
@@ -614,7 +632,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
       dh1[m] = acc;
     }
     CS_SB;
-    if (DG) {  // sdf layer 1: G = dh1 (2 tiles), X = X0 (5 tiles)
+    if (DW) {  // sdf layer 1: G = dh1 (2 tiles), X = X0 (5 tiles)
       stage4(T, 0, j, q, dh1[0][0], dh1[0][1], dh1[0][2], dh1[0][3]);
       stage4(T, 1, j, q, dh1[1][0], dh1[1][1], dh1[1][2], dh1[1][3]);
 #pragma unroll
@@ -638,12 +656,30 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
     }
     // ---- encodings backward
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+    if (DP) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float g0v = dx0[a >> 1][2 * (a & 1)], g1v = dx0[a >> 1][2 * (a & 1) + 1];
-      hash_level_bwd<DP, DG>(lt, sc.table, q + 4 * a, xn[0], xn[1], xn[2], g0v, g1v, live,
-                             g_table, dpx, dpy, dpz);
-      CS_SB;
+      for (int a = 0; a < 4; ++a) {
+        hash_level_bwd<true, false>(lt, sc.table, q + 4 * a, xn[0], xn[1],
+                                    xn[2], dx0[a >> 1][2 * (a & 1)],
+                                    dx0[a >> 1][2 * (a & 1) + 1], live, nullptr,
+                                    dpx, dpy, dpz);
+        CS_SB;
+      }
+    }
+    if (DG && live) {
+      // hash-feature gradients, level-major [level][sample] float2, for the
+      // chunked LDS scatter that follows this kernel (no global atomics)
+      const size_t smp_g = (size_t)ray * S + smp;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<float2*>(dfeat + ((size_t)(q + 4 * a) * n_samples +
+                                            smp_g) * 2) =
+            make_float2(dx0[a >> 1][2 * (a & 1)], dx0[a >> 1][2 * (a & 1) + 1]);
+      if (q == 0) {
+        xs[smp_g * 3 + 0] = xn[0];
+        xs[smp_g * 3 + 1] = xn[1];
+        xs[smp_g * 3 + 2] = xn[2];
+      }
     }
     if (DP) {
       float gb[4];
@@ -785,8 +821,12 @@ int xrd_coslam_render_fwd(const xrd_coslam_scene* scene, int n_rays,
   return check_launch("coslam_fwd_kernel");
 }
 
-int64_t xrd_coslam_bwd_ws_floats(void) {
-  return (int64_t)kBwdMaxBlocks * cs::kDwLen;
+// workspace: [block partials of dW][normalised sample positions N*3]
+// [hash-feature gradients 16*N*2], N = n_rays * kMaxS
+int64_t xrd_coslam_bwd_ws_floats(int n_rays) {
+  if (n_rays < 0) return -1;
+  return (int64_t)kBwdMaxBlocks * cs::kDwLen +
+         (int64_t)n_rays * kMaxS * (3 + 2 * XRD_COSLAM_LEVELS);
 }
 
 int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
@@ -816,11 +856,14 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
   const int tiles = n_rays * ((S + 15) / 16);
   int blocks = (tiles + kBwdWaves - 1) / kBwdWaves;
   if (dg && blocks > kBwdMaxBlocks) blocks = kBwdMaxBlocks;
+  const int64_t n_samples = (int64_t)n_rays * S;
+  float* xs = dg ? workspace + (size_t)kBwdMaxBlocks * cs::kDwLen : nullptr;
+  float* dfeat = dg ? xs + n_samples * 3 : nullptr;
 #define BWD_CASE(DPV, DGV)                                                    \
   hipLaunchKernelGGL((coslam_bwd_kernel<DPV, DGV>), dim3(blocks),             \
                      dim3(kBwdWaves * 64), 0, st, *scene, n_rays, rays_o,     \
                      rays_d, z_vals, raw, g_maps, g_raw, g_rays_o, g_rays_d,  \
-                     g_table, workspace)
+                     workspace, xs, dfeat)
   if (dp && dg) BWD_CASE(true, true);
   else if (dg) BWD_CASE(false, true);
   else BWD_CASE(true, false);
@@ -833,6 +876,12 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                        dim3((cs::kDwLen + 255) / 256, (blocks + chunk - 1) / chunk),
                        dim3(256), 0, st, workspace, blocks, chunk, g_dw);
     rc = check_launch("coslam_reduce_kernel");
+    if (rc != XRD_OK) return rc;
+    rc = launch_hash_chunk_scatter(XRD_COSLAM_LEVELS, scene->lv_scale,
+                                   scene->lv_res, scene->lv_size,
+                                   scene->lv_offset, n_samples, xs, dfeat, 2,
+                                   2 * n_samples, g_table,
+                                   /*accumulate=*/false, stream);
   }
   return rc;
 }

@@ -75,9 +75,15 @@ class SceneTables:
         self.t_uniform = torch.linspace(
             cfg.cam_near, cfg.cam_far,
             max(cfg.training_n_sample_d, 1)).to(device)
-        self.ws = torch.empty(_lib.lib().xrd_coslam_bwd_ws_floats(),
-                              dtype=torch.float32, device=device)
         self.device = torch.device(device)
+        self._ws = None
+
+    def workspace(self, n_rays):
+        need = _lib.lib().xrd_coslam_bwd_ws_floats(n_rays)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.float32,
+                                   device=self.device)
+        return self._ws
 
 
 def make_scene(model, tables, table_params, pack):
@@ -147,7 +153,7 @@ class _CoslamRenderFn(torch.autograd.Function):
         g_d = torch.empty_like(rd) if need_rays else None
         g_table = g_dw = None
         if need_map:
-            g_table = torch.zeros_like(table)
+            g_table = torch.empty_like(table)  # fully overwritten
             g_dw = torch.empty(lib.xrd_coslam_dw_len(), dtype=torch.float32,
                                device=dev)
         g_maps = torch.zeros(n, 8, dtype=torch.float32, device=dev) \
@@ -158,7 +164,7 @@ class _CoslamRenderFn(torch.autograd.Function):
             C.byref(ctx.sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(z_vals),
             _lib.ptr(raw), _lib.ptr(g_maps), _lib.ptr(g_raw), _lib.ptr(g_o),
             _lib.ptr(g_d), _lib.ptr(g_table), _lib.ptr(g_dw),
-            _lib.ptr(ctx.tables.ws) if need_map else None,
+            _lib.ptr(ctx.tables.workspace(n)) if need_map else None,
             _lib.stream_ptr(dev)), 'xrd_coslam_render_bwd')
         g_flat = None
         if need_map:
@@ -166,11 +172,15 @@ class _CoslamRenderFn(torch.autograd.Function):
         return g_o, g_d, None, None, g_table, g_flat, None, None
 
 
-def render(model, tables, rays_o, rays_d, target_d, rnd):
-    """-> dict like JointEncoding.render_rays (joint_encoding.py:250-344)"""
+def render(model, tables, rays_o, rays_d, target_d, rnd, train_map=True):
+    """-> dict like JointEncoding.render_rays (joint_encoding.py:250-344).
+    ``train_map=False`` (tracking: only the pose is stepped) skips the hash
+    table / decoder gradients, which nobody consumes."""
+    table, flat = model.embed_fn.params, flat_decoder(model.decoder)
+    if not train_map:
+        table, flat = table.detach(), flat.detach()
     maps, z_vals, raw = _CoslamRenderFn.apply(
-        rays_o, rays_d, target_d, rnd, model.embed_fn.params,
-        flat_decoder(model.decoder), model, tables)
+        rays_o, rays_d, target_d, rnd, table, flat, model, tables)
     return {'rgb': maps[:, 0:3], 'depth': maps[:, 3], 'disp_map': maps[:, 6],
             'acc_map': maps[:, 5], 'depth_var': maps[:, 4], 'z_vals': z_vals,
             'raw': raw}

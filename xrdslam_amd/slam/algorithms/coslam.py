@@ -181,6 +181,8 @@ class CoSLAM(Algorithm):
                  coarse=False):
         self.model.fixed_shape_losses = getattr(self, 'fixed_shape_batches',
                                                 False)
+        # tracking steps the pose only: no map gradients are computed
+        self.model.map_trainable = bool(is_mapping)
         inp = self.get_model_input(optimize_frames, is_mapping)
         out = self.model(inp)
         losses = self.model.get_loss_dict(out, inp, is_mapping, step)

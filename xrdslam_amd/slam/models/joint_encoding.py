@@ -191,7 +191,8 @@ class JointEncoding(Model):
                 S = cfg.training_n_range_d + cfg.training_n_sample_d
                 rnd = self._rand((n_rays, S), rays_o) \
                     if cfg.training_perturb > 0. else None
-                return ec.render(self, tab, rays_o, rays_d, target_d, rnd)
+                return ec.render(self, tab, rays_o, rays_d, target_d, rnd,
+                                 getattr(self, 'map_trainable', True))
         if target_d is not None:
             lin = torch.linspace(-cfg.training_range_d, cfg.training_range_d,
                                  steps=cfg.training_n_range_d).to(target_d)
