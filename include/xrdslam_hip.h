@@ -431,6 +431,40 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                           float* g_rays_o, float* g_rays_d, float* g_table,
                           float* g_dw, float* workspace, xrd_stream_t stream);
 
+/* Co-SLAM mapping batch (slam/algorithms/coslam.py:139-150 sample_global_rays,
+ * :152-210 get_model_input).
+ * xrd_sample_distinct: n_out DISTINCT indices in [0, n_total) — the device
+ * counterpart of python's random.sample(range(n_total), n_out): a keyed
+ * pseudo-random permutation (4-round Feistel, cycle-walking) evaluated at
+ * 0..n_out-1; keys4 = 4 int64 round keys in DEVICE memory (drawn by the
+ * caller's RNG).
+ * xrd_pose_rays_*: rays_d[i] = R[id_i] dirs[i], rays_o[i] = t[id_i] for per-ray
+ * pose ids into c2w[n_pose,4,4] (the reference's poses[ids] gather, multiply
+ * and sum); backward accumulates d/dc2w per pose (g_c2w overwritten, rows 0..2
+ * of every 4x4 used). dirs rows are dir_stride floats apart (bank rows: 7). */
+int xrd_sample_distinct(int64_t n_total, int n_out, const int64_t* keys4,
+                        int64_t* out_idx, xrd_stream_t stream);
+int xrd_pose_rays_fwd(int n, const float* dirs, int dir_stride,
+                      const int64_t* pose_ids, const float* c2w, float* rays_o,
+                      float* rays_d, xrd_stream_t stream);
+int xrd_pose_rays_bwd(int n, int n_pose, const float* dirs, int dir_stride,
+                      const int64_t* pose_ids, const float* g_rays_o,
+                      const float* g_rays_d, float* g_c2w, xrd_stream_t stream);
+
+/* JointEncoding.get_loss_dict without the smoothness term
+ * (slam/models/joint_encoding.py:94-147; get_sdf_loss / get_masks of
+ * slam/model_components/utils.py:100-186) on the renderer's outputs:
+ * loss5 = {total, rgb, depth, sdf, fs} (weighted terms), g_maps[n,8] and
+ * g_raw[n,S,4] = d total / d (maps, raw).  trunc = training_trunc *
+ * data_sc_factor.  The depth term averages over valid-depth rays (0 when there
+ * is none).  workspace: n*8 floats. */
+int xrd_coslam_loss(int n_rays, int n_samples, float w_rgb, float w_depth,
+                    float w_sdf, float w_fs, float trunc, float depth_trunc,
+                    float rgb_missing, const float* maps, const float* z_vals,
+                    const float* raw, const float* target_d,
+                    const float* target_rgb, float* loss5, float* g_maps,
+                    float* g_raw, float* workspace, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

@@ -63,10 +63,15 @@ def run_case(model, g, tag, is_mapping, first, device):
     for k in ('rgb', 'depth', 'depth_var', 'acc_map', 'z_vals', 'raw'):
         errs[k] = rel_err(res[k].detach().cpu().numpy(), g[f'{tag}/{k}'])
     gold_losses = [k for k in g.files if k.startswith(f'{tag}/loss_')]
-    assert len(gold_losses) == len(ld)
-    for k, v in ld.items():
-        errs[f'loss_{k}'] = rel_err(v.detach().cpu().numpy(),
-                                    g[f'{tag}/loss_{k}'])
+    if 'data_loss' in ld:  # fused: one total for the four data terms
+        gold = sum(float(g[k]) for k in gold_losses)
+        errs['loss_total'] = rel_err(
+            sum(v.detach().cpu().numpy() for v in ld.values()), gold)
+    else:
+        assert len(gold_losses) == len(ld)
+        for k, v in ld.items():
+            errs[f'loss_{k}'] = rel_err(v.detach().cpu().numpy(),
+                                        g[f'{tag}/loss_{k}'])
     errs['g_rays_o'] = rel_err(ro.grad.cpu().numpy(), g[f'{tag}/g_rays_o'])
     errs['g_rays_d'] = rel_err(rd.grad.cpu().numpy(), g[f'{tag}/g_rays_d'])
     errs['g_hash'] = rel_err(model.embed_fn.params.grad.cpu().numpy(),

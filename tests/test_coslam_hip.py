@@ -30,6 +30,97 @@ def test_joint_encoding_vs_reference(tag, is_mapping, first, fused):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('tag,is_mapping,first', cg.TAGS)
+def test_fused_loss_vs_reference(tag, is_mapping, first):
+    """xrd_coslam_loss (loss terms + their gradients through the fused
+    renderer) against the reference's get_loss_dict"""
+    g = np.load(cg.GOLDEN)
+    model = cg.build_model(g, 'cuda:0')
+    model.fused_losses = True
+    errs = cg.run_case(model, g, tag, is_mapping, first, 'cuda:0')
+    l5 = model.last_loss_terms.cpu().numpy()
+    for k, name in enumerate(('rgb', 'depth', 'sdf', 'fs')):
+        errs[f'term_{name}'] = cg.rel_err(l5[k + 1],
+                                          g[f'{tag}/loss_{name}_loss'])
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_fused_tracking_iteration_matches_generic_hooks():
+    """CoSLAM.get_loss through the fused launches (sampling, render, loss)
+    equals the generic get_model_input -> model -> get_loss_dict path on the
+    same random draws: loss value and pose gradient"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.common.frame import Frame
+    from xrdslam_amd.slam.configs.input_config import coslam_config
+    bound = [[-3, 3], [-4, 2.5], [-2, 2.5]]
+    cam = Camera(fx=150., fy=150., cx=79.5, cy=59.5, width=160, height=120)
+    cfg = coslam_config(bound)
+    cfg.tracking_Wedge = cfg.tracking_Hedge = 5
+    torch.manual_seed(0)
+    algo = cfg.setup(camera=cam, device='cuda:0')
+    with torch.no_grad():
+        algo.model.embed_fn.params.normal_(0, 0.05)
+    data = SyntheticRoom(bound, H=120, W=160, fx=150., fy=150., cx=79.5,
+                         cy=59.5, n_frames=4, device='cuda:0')
+    d = data[1]
+    res = {}
+    for fused in (True, False):
+        algo.fused_iteration = fused
+        f = Frame(fid=1, rgb=d['rgb'], depth=d['depth'],
+                  gt_pose=d['c2w'].astype(np.float32),
+                  init_pose=data[0]['c2w'].astype(np.float32),
+                  separate_LR=True, rot_rep='axis_angle', device='cuda:0')
+        torch.manual_seed(5)
+        loss = algo.get_loss([f], False, 0, 10)
+        loss.backward()
+        res[fused] = (float(loss.detach()),
+                      [p.grad.clone() for p in f.get_params()])
+    assert abs(res[True][0] - res[False][0]) < 1e-4 * abs(res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a - b).abs().max() < 2e-4 * b.abs().max()
+
+
+def test_sample_distinct_is_a_random_subset():
+    from xrdslam_amd.engine import slam_ops
+    torch.manual_seed(1)
+    for total, n in ((307200, 2048), (15360 * 7, 2048), (5000, 5000), (3, 1)):
+        idx = slam_ops.sample_distinct(total, n, 'cuda:0').cpu().numpy()
+        assert idx.min() >= 0 and idx.max() < total
+        assert len(np.unique(idx)) == n          # without replacement
+    a = slam_ops.sample_distinct(307200, 4096, 'cuda:0').cpu().numpy()
+    b = slam_ops.sample_distinct(307200, 4096, 'cuda:0').cpu().numpy()
+    assert len(np.intersect1d(a, b)) < 200       # fresh keys per call
+    # spread: each decile of the range gets its share
+    hist = np.histogram(a, bins=10, range=(0, 307200))[0]
+    assert hist.min() > 300 and hist.max() < 520
+
+
+def test_pose_rays_matches_reference_gather():
+    """rays_d = sum(dir * R[ids]), rays_o = t[ids] (coslam.py:196-204) and
+    the gradient w.r.t. the poses"""
+    from xrdslam_amd.engine import slam_ops
+    g = torch.Generator().manual_seed(0)
+    n_pose, n = 7, 3000
+    c2w = torch.randn(n_pose, 4, 4, generator=g).cuda()
+    rows = torch.randn(n, 7, generator=g).cuda()
+    ids = torch.randint(0, n_pose, (n, ), generator=g).cuda()
+    ids[-500:] = n_pose - 1
+    wo = torch.randn(n, 3, generator=g).cuda()
+    wd = torch.randn(n, 3, generator=g).cuda()
+    a = c2w.clone().requires_grad_(True)
+    ro, rd = slam_ops.PoseRaysFn.apply(a, rows, ids)
+    ((ro * wo).sum() + (rd * wd).sum()).backward()
+    b = c2w.clone().requires_grad_(True)
+    rd_ref = (rows[:, None, :3] * b[ids, :3, :3]).sum(-1)
+    ro_ref = b[ids, :3, 3]
+    ((ro_ref * wo).sum() + (rd_ref * wd).sum()).backward()
+    assert torch.allclose(ro, ro_ref) and torch.allclose(rd, rd_ref,
+                                                         atol=1e-5)
+    assert (a.grad - b.grad).abs().max() < 1e-4 * b.grad.abs().max()
+
+
 def test_coslam_loop_tracks_synthetic_room():
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera
@@ -42,6 +133,9 @@ def test_coslam_loop_tracks_synthetic_room():
     cfg = coslam_config(bound)
     cfg.mapping_first_n_iters = 100
     cfg.tracking_Wedge = cfg.tracking_Hedge = 5
+    # the bank holds 5 % of 160x120 = 960 rays per keyframe: like python's
+    # random.sample, a batch larger than the bank is an error
+    cfg.mapping_sample = 768
     algo = cfg.setup(camera=cam, device='cuda:0')
     data = SyntheticRoom(bound, H=120, W=160, fx=150., fy=150., cx=79.5,
                          cy=59.5, n_frames=200, device='cuda:0')

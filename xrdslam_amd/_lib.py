@@ -111,6 +111,11 @@ _SIGS = {
     'xrd_coslam_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_coslam_render_bwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
                               [vp] * 12),
+    'xrd_sample_distinct': (C.c_int, [i64, C.c_int, vp, vp, vp]),
+    'xrd_pose_rays_fwd': (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
+    'xrd_pose_rays_bwd': (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp,
+                                    vp, vp]),
+    'xrd_coslam_loss': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 + [vp] * 10),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

@@ -22,6 +22,10 @@ int check_launch(const char* what);
 // that fall into its chunk in LDS and adds the chunk to dparams with coalesced
 // atomics (accumulate == false: dparams is zeroed first).  dy: per point and level one float2 at
 // dy[p * point_stride + l * level_stride].
+// zero-fill as a kernel node: hipMemsetAsync nodes inside a captured hipGraph
+// were observed to race with neighbouring kernel nodes on replay (ROCm 7.2)
+int zero_floats(float* p, size_t n, void* stream);
+
 int launch_hash_chunk_scatter(int n_levels, const float* scales,
                               const uint32_t* res, const uint32_t* sizes,
                               const uint32_t* offsets, int64_t n_points,

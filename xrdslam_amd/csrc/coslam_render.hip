@@ -734,6 +734,136 @@ __global__ __launch_bounds__(256) void coslam_reduce_kernel(
   if (b1 > b0) atomicAdd(g_dw + i, s);
 }
 
+// ---------------------------------------------------------------------------
+// loss of JointEncoding.get_loss_dict without the smoothness term
+// (joint_encoding.py:94-147, model_components/utils.py get_sdf_loss/get_masks)
+// ---------------------------------------------------------------------------
+struct LossCfg {
+  float w_rgb, w_depth, w_sdf, w_fs;
+  float trunc;        // training_trunc * data_sc_factor
+  float depth_trunc;  // cam_depth_trunc
+  float rgb_missing;  // weight of colour on invalid-depth pixels
+  int S;
+};
+// per-ray statistics: n_fs, n_sdf, S_fs, S_sdf, valid, depth err^2, rgb err^2
+__global__ __launch_bounds__(256) void coslam_loss_stats_kernel(
+    LossCfg L, int n, const float* __restrict__ maps,
+    const float* __restrict__ z_vals, const float* __restrict__ raw,
+    const float* __restrict__ tgt_d, const float* __restrict__ tgt_rgb,
+    float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n) return;
+  const float d = tgt_d[ray];
+  float nfs = 0.f, nsdf = 0.f, sfs = 0.f, ssdf = 0.f;
+  if (lane < L.S) {
+    const float z = z_vals[(size_t)ray * L.S + lane];
+    const float sdf = raw[((size_t)ray * L.S + lane) * 4 + 3];
+    const bool front = z < d - L.trunc, back = z > d + L.trunc;
+    const bool m = !front && !back && d > 0.f;
+    nfs = front ? 1.f : 0.f;
+    nsdf = m ? 1.f : 0.f;
+    const float e0 = sdf - 1.f, e1 = z + sdf * L.trunc - d;
+    sfs = front ? e0 * e0 : 0.f;
+    ssdf = m ? e1 * e1 : 0.f;
+  }
+  nfs = wave_sum(nfs);
+  nsdf = wave_sum(nsdf);
+  sfs = wave_sum(sfs);
+  ssdf = wave_sum(ssdf);
+  if (lane == 0) {
+    const float* m = maps + (size_t)ray * 8;
+    const bool valid = d > 0.f && d < L.depth_trunc;
+    // reference quirk (joint_encoding.py:106-107): the colour weight tensor
+    // is boolean, so rgb_missing != 0 stores True
+    const float w = valid ? 1.f : (L.rgb_missing != 0.f ? 1.f : 0.f);
+    float sr = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float e = m[c] * w - tgt_rgb[ray * 3 + c] * w;
+      sr += e * e;
+    }
+    const float ed = m[3] - d;
+    float* o = stats + (size_t)ray * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(nfs, nsdf, sfs, ssdf);
+    *reinterpret_cast<float4*>(o + 4) =
+        make_float4(valid ? 1.f : 0.f, valid ? ed * ed : 0.f, sr, w);
+  }
+}
+
+// every block reduces the per-ray statistics (n x 8 floats, L2 resident), then
+// writes the gradients of its 16 rays; block 0 writes the loss terms
+__global__ __launch_bounds__(1024) void coslam_loss_grad_kernel(
+    LossCfg L, int n, const float* __restrict__ maps,
+    const float* __restrict__ z_vals, const float* __restrict__ raw,
+    const float* __restrict__ tgt_d, const float* __restrict__ tgt_rgb,
+    const float* __restrict__ stats, float* __restrict__ loss_out,
+    float* __restrict__ g_maps, float* __restrict__ g_raw) {
+  __shared__ double red[16][7];
+  __shared__ double tot[7];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int r = tid; r < n; r += 1024) {
+    const float4 a = *reinterpret_cast<const float4*>(stats + (size_t)r * 8);
+    const float4 b = *reinterpret_cast<const float4*>(stats + (size_t)r * 8 + 4);
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (tid < 7) {
+    double v = 0;
+    for (int w = 0; w < 16; ++w) v += red[w][tid];
+    tot[tid] = v;
+  }
+  __syncthreads();
+  const float n_fs = (float)tot[0], n_sdf = (float)tot[1];
+  const float n_all = n_fs + n_sdf;
+  const float fs_w = 1.f - n_fs / n_all, sdf_w = 1.f - n_sdf / n_all;
+  const float nS = (float)n * (float)L.S;
+  const float nv = fmaxf((float)tot[4], 1.f);
+  if (blockIdx.x == 0 && tid == 0) {
+    const float l_rgb = (float)(tot[6] / (3.0 * n)) * L.w_rgb;
+    const float l_d = (float)(tot[5] / nv) * L.w_depth;
+    const float l_sdf = (float)(tot[3] / nS) * sdf_w * L.w_sdf;
+    const float l_fs = (float)(tot[2] / nS) * fs_w * L.w_fs;
+    loss_out[0] = l_rgb + l_d + l_sdf + l_fs;
+    loss_out[1] = l_rgb;
+    loss_out[2] = l_d;
+    loss_out[3] = l_sdf;
+    loss_out[4] = l_fs;
+  }
+  const int ray = blockIdx.x * 16 + wave;
+  if (ray >= n) return;
+  const float d = tgt_d[ray];
+  if (lane < L.S) {
+    const size_t o = (size_t)ray * L.S + lane;
+    const float z = z_vals[o], sdf = raw[o * 4 + 3];
+    const bool front = z < d - L.trunc, back = z > d + L.trunc;
+    const bool m = !front && !back && d > 0.f;
+    float g = 0.f;
+    if (front) g += L.w_fs * fs_w * 2.f * (sdf - 1.f) / nS;
+    if (m) g += L.w_sdf * sdf_w * 2.f * (z + sdf * L.trunc - d) * L.trunc / nS;
+    *reinterpret_cast<float4*>(g_raw + o * 4) = make_float4(0.f, 0.f, 0.f, g);
+  }
+  if (lane == 0) {
+    const float* mp = maps + (size_t)ray * 8;
+    const bool valid = d > 0.f && d < L.depth_trunc;
+    const float w = valid ? 1.f : (L.rgb_missing != 0.f ? 1.f : 0.f);
+    const float k = L.w_rgb * 2.f * w * w / (3.f * (float)n);
+    float* gm = g_maps + (size_t)ray * 8;
+    *reinterpret_cast<float4*>(gm) = make_float4(
+        k * (mp[0] - tgt_rgb[ray * 3]), k * (mp[1] - tgt_rgb[ray * 3 + 1]),
+        k * (mp[2] - tgt_rgb[ray * 3 + 2]),
+        valid ? L.w_depth * 2.f * (mp[3] - d) / nv : 0.f);
+    *reinterpret_cast<float4*>(gm + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 int check_scene(const Scene* sc, int n_rays) {
   if (sc == nullptr || n_rays < 0) return XRD_ERR_ARG;
   if (sc->table == nullptr || sc->pack == nullptr || sc->t_near == nullptr ||
@@ -845,12 +975,11 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
   if (!dp && !dg) return XRD_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dp) {
-    if (hipMemsetAsync(g_rays_o, 0, sizeof(float) * 3 * n_rays, st) != hipSuccess ||
-        hipMemsetAsync(g_rays_d, 0, sizeof(float) * 3 * n_rays, st) != hipSuccess)
-      return check_launch("memset g_rays");
+    if ((rc = zero_floats(g_rays_o, (size_t)3 * n_rays, stream)) != XRD_OK ||
+        (rc = zero_floats(g_rays_d, (size_t)3 * n_rays, stream)) != XRD_OK)
+      return rc;
   }
-  if (dg && hipMemsetAsync(g_dw, 0, sizeof(float) * cs::kDwLen, st) != hipSuccess)
-    return check_launch("memset g_dw");
+  if (dg && (rc = zero_floats(g_dw, cs::kDwLen, stream)) != XRD_OK) return rc;
   if (n_rays == 0) return XRD_OK;
   const int S = scene->n_range_d + scene->n_sample_d;
   const int tiles = n_rays * ((S + 15) / 16);
@@ -884,6 +1013,28 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                                    /*accumulate=*/false, stream);
   }
   return rc;
+}
+
+int xrd_coslam_loss(int n_rays, int n_samples, float w_rgb, float w_depth,
+                    float w_sdf, float w_fs, float trunc, float depth_trunc,
+                    float rgb_missing, const float* maps, const float* z_vals,
+                    const float* raw, const float* target_d,
+                    const float* target_rgb, float* loss5, float* g_maps,
+                    float* g_raw, float* workspace, xrd_stream_t stream) {
+  if (n_rays < 1 || n_samples < 1 || n_samples > 64 || !maps || !z_vals ||
+      !raw || !target_d || !target_rgb || !loss5 || !g_maps || !g_raw ||
+      !workspace)
+    return XRD_ERR_ARG;
+  const LossCfg L{w_rgb, w_depth, w_sdf, w_fs, trunc, depth_trunc, rgb_missing,
+                  n_samples};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(coslam_loss_stats_kernel, dim3((n_rays + 3) / 4), dim3(256),
+                     0, st, L, n_rays, maps, z_vals, raw, target_d, target_rgb,
+                     workspace);
+  hipLaunchKernelGGL(coslam_loss_grad_kernel, dim3((n_rays + 15) / 16),
+                     dim3(1024), 0, st, L, n_rays, maps, z_vals, raw, target_d,
+                     target_rgb, workspace, loss5, g_maps, g_raw);
+  return check_launch("xrd_coslam_loss");
 }
 
 }  // extern "C"

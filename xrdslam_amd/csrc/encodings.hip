@@ -286,8 +286,8 @@ int launch_hash_chunk_scatter(int n_levels, const float* scales,
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) {
     const uint64_t total = (uint64_t)offsets[n_levels - 1] + sizes[n_levels - 1];
-    if (hipMemsetAsync(dparams, 0, total * 2 * sizeof(float), st) != hipSuccess)
-      return check_launch("memset dparams");
+    rc = zero_floats(dparams, (size_t)total * 2, stream);
+    if (rc != XRD_OK) return rc;
   }
   if (n_points == 0) return XRD_OK;
   ChunkMeta M;

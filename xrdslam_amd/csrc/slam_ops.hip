@@ -299,6 +299,124 @@ __global__ void track_best_kernel(const double* __restrict__ loss,
 
 using namespace xrd;
 
+
+// ---------------------------------------------------------------------------
+// Co-SLAM mapping batch (slam/algorithms/coslam.py:139-150, 152-210)
+// ---------------------------------------------------------------------------
+namespace xrd {
+namespace {
+
+// Keyed pseudo-random permutation of [0, 2^bits) (4-round balanced Feistel),
+// walked until the value falls below n: perm(0..n_out-1) are n_out DISTINCT
+// uniform-looking indices in [0, n) in O(1) each — random.sample() without the
+// O(n) shuffle/sort, with n free to grow between launches.
+__device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint64_t key) {
+  uint32_t x = r * 0x9E3779B1u + (uint32_t)key;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x ^ (uint32_t)(key >> 32);
+}
+__global__ __launch_bounds__(256) void sample_distinct_kernel(
+    int64_t n, int n_out, int half_bits, const int64_t* __restrict__ keys,
+    int64_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint64_t k[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) k[r] = (uint64_t)keys[r];
+  uint64_t y = (uint64_t)i;
+  do {
+    uint32_t L = (uint32_t)(y >> half_bits) & mask, R = (uint32_t)y & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t t = L ^ (feistel_round(R, k[r]) & mask);
+      L = R;
+      R = t;
+    }
+    y = ((uint64_t)L << half_bits) | R;
+  } while (y >= (uint64_t)n);
+  out[i] = (int64_t)y;
+}
+
+// rays_d = R[id] dir, rays_o = t[id] for per-ray pose ids
+__global__ __launch_bounds__(256) void pose_rays_fwd_kernel(
+    int n, const float* __restrict__ dirs, int dir_stride,
+    const int64_t* __restrict__ ids, const float* __restrict__ c2w,
+    float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* M = c2w + ids[i] * 16;
+  const float dx = dirs[(size_t)i * dir_stride], dy = dirs[(size_t)i * dir_stride + 1],
+              dz = dirs[(size_t)i * dir_stride + 2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    rays_d[i * 3 + a] = dx * M[4 * a] + dy * M[4 * a + 1] + dz * M[4 * a + 2];
+    rays_o[i * 3 + a] = M[4 * a + 3];
+  }
+}
+
+constexpr int kPoseLds = 1024;  // poses accumulated in LDS per block
+__global__ __launch_bounds__(256) void pose_rays_bwd_kernel(
+    int n, int n_pose, const float* __restrict__ dirs, int dir_stride,
+    const int64_t* __restrict__ ids, const float* __restrict__ g_o,
+    const float* __restrict__ g_d, float* __restrict__ g_c2w) {
+  __shared__ float acc[kPoseLds * 12];
+  const bool use_lds = n_pose <= kPoseLds;
+  if (use_lds) {
+    for (int k = threadIdx.x; k < n_pose * 12; k += 256) acc[k] = 0.f;
+    __syncthreads();
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  const int id = live ? (int)ids[i] : -1;
+  float g[12];
+  if (live) {
+    const float d[3] = {dirs[(size_t)i * dir_stride], dirs[(size_t)i * dir_stride + 1],
+                        dirs[(size_t)i * dir_stride + 2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[4 * a + b] = g_d[i * 3 + a] * d[b];
+      g[4 * a + 3] = g_o[i * 3 + a];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) g[k] = 0.f;
+  }
+  // rays of one frame are contiguous: usually the whole wave shares the pose
+  const int id0 = __shfl(id, 0);
+  if (__all(id == id0 || !live) && id0 >= 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float v = wave_sum(g[k]);
+      if ((threadIdx.x & 63) == 0) {
+        if (use_lds) atomicAdd(&acc[id0 * 12 + k], v);
+        else atomicAdd(g_c2w + (size_t)id0 * 16 + k, v);
+      }
+    }
+  } else if (live) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      if (use_lds) atomicAdd(&acc[id * 12 + k], g[k]);
+      else atomicAdd(g_c2w + (size_t)id * 16 + k, g[k]);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_pose * 12; k += 256) {
+      const float v = acc[k];
+      if (v != 0.f) atomicAdd(g_c2w + (size_t)(k / 12) * 16 + (k % 12), v);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
 extern "C" {
 
 int xrd_sample_rays(int n, int image_width, int h0, int w0, int crop_width,
@@ -399,6 +517,47 @@ int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
                      (hipStream_t)stream, loss, c2w16, best_loss, best_c2w16,
                      valid);
   return check_launch("xrd_track_best");
+}
+
+int xrd_sample_distinct(int64_t n_total, int n_out, const int64_t* keys4,
+                        int64_t* out_idx, xrd_stream_t stream) {
+  if (n_total < 1 || n_out < 0 || n_out > n_total || !keys4 || (n_out && !out_idx))
+    return XRD_ERR_ARG;
+  if (n_total > (1ll << 40)) return XRD_ERR_UNSUPPORTED;
+  if (n_out == 0) return XRD_OK;
+  int bits = 1;
+  while ((1ll << bits) < n_total) ++bits;
+  const int half = (bits + 1) / 2;
+  hipLaunchKernelGGL(sample_distinct_kernel, dim3((n_out + 255) / 256), dim3(256),
+                     0, (hipStream_t)stream, n_total, n_out, half, keys4, out_idx);
+  return check_launch("xrd_sample_distinct");
+}
+
+int xrd_pose_rays_fwd(int n, const float* dirs, int dir_stride,
+                      const int64_t* pose_ids, const float* c2w, float* rays_o,
+                      float* rays_d, xrd_stream_t stream) {
+  if (n < 0 || dir_stride < 3 || (n && (!dirs || !pose_ids || !c2w || !rays_o ||
+                                        !rays_d)))
+    return XRD_ERR_ARG;
+  if (n == 0) return XRD_OK;
+  hipLaunchKernelGGL(pose_rays_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, n, dirs, dir_stride, pose_ids, c2w,
+                     rays_o, rays_d);
+  return check_launch("xrd_pose_rays_fwd");
+}
+
+int xrd_pose_rays_bwd(int n, int n_pose, const float* dirs, int dir_stride,
+                      const int64_t* pose_ids, const float* g_rays_o,
+                      const float* g_rays_d, float* g_c2w, xrd_stream_t stream) {
+  if (n < 0 || n_pose < 1 || dir_stride < 3 || !g_c2w ||
+      (n && (!dirs || !pose_ids || !g_rays_o || !g_rays_d)))
+    return XRD_ERR_ARG;
+  int rc = zero_floats(g_c2w, (size_t)n_pose * 16, stream);
+  if (rc != XRD_OK || n == 0) return rc;
+  hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, n, n_pose, dirs, dir_stride, pose_ids,
+                     g_rays_o, g_rays_d, g_c2w);
+  return check_launch("xrd_pose_rays_bwd");
 }
 
 }  // extern "C"

@@ -183,4 +183,48 @@ def render(model, tables, rays_o, rays_d, target_d, rnd, train_map=True):
         rays_o, rays_d, target_d, rnd, table, flat, model, tables)
     return {'rgb': maps[:, 0:3], 'depth': maps[:, 3], 'disp_map': maps[:, 6],
             'acc_map': maps[:, 5], 'depth_var': maps[:, 4], 'z_vals': z_vals,
-            'raw': raw}
+            'raw': raw, '_maps': maps}
+
+
+class _CoslamLossFn(torch.autograd.Function):
+    """total of the rgb / depth / sdf / free-space terms of
+    JointEncoding.get_loss_dict, two launches, gradients produced with it"""
+
+    @staticmethod
+    def forward(ctx, maps, z_vals, raw, target_d, target_rgb, cfgv):
+        lib = _lib.lib()
+        dev = maps.device
+        n, S = z_vals.shape
+        m = maps.detach().float().contiguous()
+        r = raw.detach().float().contiguous()
+        z = z_vals.detach().float().contiguous()
+        td = target_d.detach().float().reshape(-1).contiguous()
+        tc = target_rgb.detach().float().contiguous()
+        loss5 = torch.empty(5, dtype=torch.float32, device=dev)
+        g_maps = torch.empty(n, 8, dtype=torch.float32, device=dev)
+        g_raw = torch.empty(n, S, 4, dtype=torch.float32, device=dev)
+        ws = torch.empty(n * 8, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_coslam_loss(
+            n, S, *[float(v) for v in cfgv], _lib.ptr(m), _lib.ptr(z),
+            _lib.ptr(r), _lib.ptr(td), _lib.ptr(tc), _lib.ptr(loss5),
+            _lib.ptr(g_maps), _lib.ptr(g_raw), _lib.ptr(ws),
+            _lib.stream_ptr(dev)), 'xrd_coslam_loss')
+        ctx.save_for_backward(g_maps, g_raw)
+        ctx.mark_non_differentiable(loss5)
+        return loss5[0], loss5
+
+    @staticmethod
+    def backward(ctx, g, _g5):
+        g_maps, g_raw = ctx.saved_tensors
+        return g * g_maps, None, g * g_raw, None, None, None
+
+
+def loss(model, outputs, target_d, target_rgb):
+    """-> (total with autograd, loss5 = [total, rgb, depth, sdf, fs])"""
+    cfg = model.config
+    cfgv = (cfg.trainging_rgb_weight, cfg.trainging_depth_weight,
+            cfg.trainging_sdf_weight, cfg.trainging_fs_weight,
+            cfg.training_trunc * cfg.data_sc_factor, cfg.cam_depth_trunc,
+            cfg.training_rgb_missing)
+    return _CoslamLossFn.apply(outputs['_maps'], outputs['z_vals'],
+                               outputs['raw'], target_d, target_rgb, cfgv)

@@ -187,3 +187,52 @@ def track_best(loss, c2w, track):
         _lib.ptr(track['loss']), _lib.ptr(track['c2w']),
         _lib.ptr(track['valid']), _lib.stream_ptr(c2w.device)),
         'xrd_track_best')
+
+
+def sample_distinct(n_total: int, n_out: int, device, generator=None):
+    """n_out distinct indices in [0, n_total) (python's random.sample on the
+    device): keyed permutation evaluated at 0..n_out-1, keys from torch's RNG"""
+    keys = torch.randint(-2**62, 2**62, (4, ), device=device,
+                         dtype=torch.int64, generator=generator)
+    out = torch.empty(n_out, dtype=torch.int64, device=device)
+    _lib.check(_lib.lib().xrd_sample_distinct(
+        int(n_total), int(n_out), _lib.ptr(keys), _lib.ptr(out),
+        _lib.stream_ptr(torch.device(device))), 'xrd_sample_distinct')
+    return out
+
+
+class PoseRaysFn(torch.autograd.Function):
+    """rays_o, rays_d of rays with per-ray pose ids: rays_d = R[id] dir,
+    rays_o = t[id]; differentiable w.r.t. c2w [n_pose,4,4].  ``rows`` [n,>=3]
+    holds the camera-frame directions in its first three columns."""
+
+    @staticmethod
+    def forward(ctx, c2w, rows, ids):
+        lib = _lib.lib()
+        dev = rows.device
+        n = rows.shape[0]
+        assert rows.dtype == torch.float32 and rows.stride(1) == 1
+        c = c2w.detach().float().contiguous()
+        ids = ids.contiguous()
+        ro = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        rd = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_pose_rays_fwd(
+            n, _lib.ptr(rows), rows.stride(0), _lib.ptr(ids), _lib.ptr(c),
+            _lib.ptr(ro), _lib.ptr(rd), _lib.stream_ptr(dev)),
+            'xrd_pose_rays_fwd')
+        ctx.n_pose = c.shape[0]
+        ctx.save_for_backward(rows, ids)
+        return ro, rd
+
+    @staticmethod
+    def backward(ctx, g_ro, g_rd):
+        lib = _lib.lib()
+        rows, ids = ctx.saved_tensors
+        dev = rows.device
+        g = torch.empty(ctx.n_pose, 4, 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_pose_rays_bwd(
+            rows.shape[0], ctx.n_pose, _lib.ptr(rows), rows.stride(0),
+            _lib.ptr(ids), _lib.ptr(g_ro.float().contiguous()),
+            _lib.ptr(g_rd.float().contiguous()), _lib.ptr(g),
+            _lib.stream_ptr(dev)), 'xrd_pose_rays_bwd')
+        return g, None, None

@@ -94,15 +94,64 @@ class CoSLAM(Algorithm):
         if self.model_optimizers is None:
             self.model_optimizers = Optimizers(
                 cfg, {**self.model.get_param_groups()})
+        self._ba = None
         if not self.bundle_adjust or len(optimize_frames) == 1:
             return self.model_optimizers
         # the first keyframe's pose stays fixed
-        pose_opt = Optimizers(cfg, self._pose_groups(optimize_frames[1:],
-                                                     'mapping_pose'))
+        if self._stack_ba(optimize_frames):
+            pose_opt = Optimizers(cfg, {'mapping_pose_r': [self._ba['r']],
+                                        'mapping_pose_t': [self._ba['t']]})
+        else:
+            pose_opt = Optimizers(cfg, self._pose_groups(optimize_frames[1:],
+                                                         'mapping_pose'))
         merged = pose_opt + self.model_optimizers
         merged.parameters = {**pose_opt.parameters,
                              **self.model_optimizers.parameters}
         return merged
+
+    # -- bundle adjustment on stacked pose parameters ----------------------------
+    def _stack_ba(self, frames):
+        """MI355X: the poses of one mapping call are optimised as TWO stacked
+        parameters ([n,3] rotations, [n,3] translations) instead of 2n small
+        ones — Adam is element-wise, so the arithmetic is that of the
+        reference's per-frame parameters (coslam.py:66-112), but pose
+        matrices, their gradients and the optimiser step cost a constant
+        number of launches however many keyframes there are.  Row 0 (the first
+        keyframe) receives no gradient.  ``_unstack_ba`` writes the result
+        back into the frames."""
+        dev = torch.device(self.model.device)
+        if not (self.fused_iteration and dev.type == 'cuda' and
+                self.config.separate_LR and
+                self.config.rot_rep == 'axis_angle' and
+                len(frames) == len(self.keyframe_graph) + 1 and
+                self.model._fused_tables(dev) is not None):
+            return False
+        with torch.no_grad():
+            r = torch.stack([f.pose.data_r.detach().to(dev) for f in frames])
+            t = torch.stack([f.pose.data_t.detach().to(dev) for f in frames])
+        fixed = torch.zeros(len(frames), 1, 1, dtype=torch.bool, device=dev)
+        fixed[0] = True
+        self._ba = {'frames': list(frames), 'r': torch.nn.Parameter(r),
+                    't': torch.nn.Parameter(t), 'fixed': fixed}
+        return True
+
+    def _unstack_ba(self):
+        ba, self._ba = getattr(self, '_ba', None), None
+        if ba is None:
+            return
+        with torch.no_grad():
+            dst = [f.pose.data_r for f in ba['frames']] + \
+                  [f.pose.data_t for f in ba['frames']]
+            src = [x.to(d.device) for x, d in zip(
+                list(ba['r'].detach().unbind(0)) +
+                list(ba['t'].detach().unbind(0)), dst)]
+            torch._foreach_copy_(dst, src)
+
+    def do_mapping(self, cur_frame):
+        try:
+            super().do_mapping(cur_frame)
+        finally:
+            self._unstack_ba()
 
     # -- ray bank ---------------------------------------------------------------
     def _ray_dirs(self):
@@ -116,8 +165,16 @@ class CoSLAM(Algorithm):
         dev = self.model.device
         depth, rgb = keyframe.device_images(dev)
         n = self.camera.height * self.camera.width
-        idx = torch.randperm(n, device=dev)[:bs]
+        idx = self._distinct(n, bs, dev)
         return torch.cat([self._ray_dirs()[idx], rgb[idx], depth[idx]], -1)
+
+    def _distinct(self, total, bs, dev):
+        """bs distinct indices in [0,total) — random.sample of the reference
+        (coslam.py:122,147); O(bs) on the GPU, a randperm elsewhere"""
+        if torch.device(dev).type == 'cuda':
+            from ...engine import slam_ops
+            return slam_ops.sample_distinct(total, bs, dev)
+        return torch.randperm(total, device=dev)[:bs]
 
     def add_keyframe(self, keyframe):
         with self.lock:
@@ -133,7 +190,7 @@ class CoSLAM(Algorithm):
 
     def sample_global_rays(self, bs):
         total = len(self.keyframe_graph) * self.num_rays_to_save
-        idx = torch.randperm(total, device=self.rays.device)[:bs]
+        idx = self._distinct(total, bs, self.rays.device)
         return self.rays[idx], torch.div(idx, self.num_rays_to_save,
                                          rounding_mode='floor')
 
@@ -177,13 +234,73 @@ class CoSLAM(Algorithm):
                 'target_s': rays[:, 3:6].float(),
                 'target_d': rays[:, 6:7].float(), 'first': not have_kf}
 
+    fused_iteration = True  # fused sampling / loss launches on the GPU
+
+    def _fused_track_input(self, cur):
+        """tracking batch in ONE launch (pixel sampling, colour/depth gather,
+        rays from the pose; backward to the pose in one more): the same
+        arithmetic as get_samples (slam/common/common.py:188-227)"""
+        from ...engine import slam_ops
+        cfg, cam, dev = self.config, self.camera, self.model.device
+        wcrop = cam.width - 2 * cfg.tracking_Wedge
+        cnt = (cam.height - 2 * cfg.tracking_Hedge) * wcrop
+        idx = torch.randint(cnt, (1, cfg.tracking_sample), device=dev)
+        d_img, c_img = cur.device_images(dev)
+        ro, rd, td, tc, _keep, _dmax = slam_ops.SampleRaysFn.apply(
+            cur.get_pose().to(dev).unsqueeze(0), idx, [d_img], [c_img], cam,
+            (cfg.tracking_Hedge, cfg.tracking_Wedge, wcrop),
+            self.bounding_box.reshape(-1).tolist())
+        return {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
+                'first': False}
+
+    def _fused_map_input(self, optimize_frames):
+        """mapping batch with the pose gather / rotation (and its backward)
+        in one launch each and all poses evaluated as one batch"""
+        from ...engine import slam_ops
+        from ..utils.opt_pose import axis_angle_translation_to_matrix
+        cfg, dev = self.config, self.model.device
+        cur = optimize_frames[-1]
+        K = len(self.keyframe_graph)
+        ba = getattr(self, '_ba', None)
+        if ba is not None:
+            assert len(ba['frames']) == len(optimize_frames) == K + 1
+            c2w = axis_angle_translation_to_matrix(ba['r'], ba['t'])
+            c2w = torch.where(ba['fixed'], c2w.detach(), c2w)
+        else:  # no pose is stepped in this call
+            with torch.no_grad():
+                c2w = torch.stack([f.get_pose().to(dev)
+                                   for f in optimize_frames])
+        rows, ids = [], []
+        n_cur = cfg.mapping_sample
+        if K > 0:
+            bank, fid = self.sample_global_rays(cfg.mapping_sample)
+            rows.append(bank)
+            ids.append(fid)
+            n_cur = max(cfg.mapping_sample // K, cfg.min_sample_pixels)
+        rows.append(self.sample_single_keyframe_rays(cur, n_cur))
+        ids.append(torch.full((n_cur, ), c2w.shape[0] - 1, dtype=torch.int64,
+                              device=dev))
+        rows, ids = torch.cat(rows, 0), torch.cat(ids, 0)
+        rays_o, rays_d = slam_ops.PoseRaysFn.apply(c2w, rows, ids)
+        return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': rows[:, 3:6],
+                'target_d': rows[:, 6:7], 'first': K == 0}
+
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):
         self.model.fixed_shape_losses = getattr(self, 'fixed_shape_batches',
                                                 False)
         # tracking steps the pose only: no map gradients are computed
         self.model.map_trainable = bool(is_mapping)
-        inp = self.get_model_input(optimize_frames, is_mapping)
+        on_gpu = torch.device(self.model.device).type == 'cuda'
+        fused = self.fused_iteration and on_gpu and \
+            self.model._fused_tables(self.model.device) is not None
+        self.model.fused_losses = fused
+        if fused and not is_mapping:
+            inp = self._fused_track_input(optimize_frames[-1])
+        elif fused and len(optimize_frames) == len(self.keyframe_graph) + 1:
+            inp = self._fused_map_input(optimize_frames)
+        else:
+            inp = self.get_model_input(optimize_frames, is_mapping)
         out = self.model(inp)
         losses = self.model.get_loss_dict(out, inp, is_mapping, step)
         return functools.reduce(torch.add, losses.values())

@@ -116,6 +116,19 @@ class JointEncoding(Model):
                       stage=None) -> Dict[str, torch.Tensor]:
         cfg = self.config
         target_d, target_rgb = inputs['target_d'], inputs['target_s']
+        if '_maps' in outputs and getattr(self, 'fused_losses', False):
+            # fused renderer output + fused loss: the four data terms come
+            # as ONE differentiable total ('data_loss'); the individual terms
+            # are kept (detached) in self.last_loss_terms
+            from ...engine import coslam as ec
+            total, l5 = ec.loss(self, outputs, target_d, target_rgb)
+            self.last_loss_terms = l5
+            losses = {'data_loss': total}
+            if is_mapping and not inputs['first']:
+                losses['smooth_loss'] = self.smoothness(
+                    cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
+                    cfg.trainging_smooth_margin) * cfg.trainging_smooth_weight
+            return losses
         td = target_d.squeeze()
         valid = (td > 0.) * (td < cfg.cam_depth_trunc)
         # reference quirk kept on purpose (joint_encoding.py:106-107): the

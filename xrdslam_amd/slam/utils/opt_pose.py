@@ -63,6 +63,29 @@ def quaternion_to_axis_angle(q: torch.Tensor) -> torch.Tensor:
     return v * scale
 
 
+def axis_angle_translation_to_matrix(rot: torch.Tensor,
+                                     trans: torch.Tensor) -> torch.Tensor:
+    """batched OptimizablePose.matrix() for rot_rep='axis_angle': rot [n,3],
+    trans [n,3] -> c2w [n,4,4]; same formula (Rodrigues, exact identity below
+    1e-8 rad) evaluated for all poses at once"""
+    n = rot.shape[0]
+    small = torch.norm(rot.detach(), dim=-1, keepdim=True) <= 1e-8
+    safe = torch.where(small, torch.ones_like(rot), rot)
+    angle = torch.norm(safe, dim=-1, keepdim=True)
+    w = safe / angle
+    z = torch.zeros_like(w[:, 0])
+    K = torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1],
+                     w[:, 0], z], -1).reshape(n, 3, 3)
+    eye = torch.eye(3, device=rot.device, dtype=rot.dtype).expand(n, 3, 3)
+    s, c = torch.sin(angle)[..., None], torch.cos(angle)[..., None]
+    R = eye + K * s + (1. - c) * (K @ K)
+    R = torch.where(small[..., None], eye, R)
+    top = torch.cat([R, trans[..., None]], -1)
+    bottom = torch.tensor([0., 0., 0., 1.], device=rot.device,
+                          dtype=rot.dtype).expand(n, 1, 4)
+    return torch.cat([top, bottom], 1)
+
+
 class OptimizablePose(nn.Module):
     def __init__(self, init_pose, separate_LR=True, rot_rep='axis_angle'):
         super().__init__()
