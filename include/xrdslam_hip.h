@@ -358,6 +358,13 @@ int xrd_pose_quat_fwd(const float* t3, const float* q4, float* c2w16,
                       xrd_stream_t stream);
 int xrd_pose_quat_bwd(const float* q4, const float* g_c2w16, float* g_t3,
                       float* g_q4, xrd_stream_t stream);
+/* OptimizablePose.matrix() for rot_rep='axis_angle' (slam/utils/opt_pose.py:
+ * 51-95, Rodrigues; exactly I when |r| <= 1e-8), n poses per launch:
+ * r3[n,3], t3[n,3] -> c2w16[n,16]; backward to g_r3, g_t3 */
+int xrd_pose_aa_fwd(int n, const float* r3, const float* t3, float* c2w16,
+                    xrd_stream_t stream);
+int xrd_pose_aa_bwd(int n, const float* r3, const float* g_c2w16, float* g_r3,
+                    float* g_t3, xrd_stream_t stream);
 /* torch.optim.Adam step on a small dense tensor, step count on the device */
 int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
                    int64_t n, float lr, float beta1, float beta2, float eps,

@@ -82,6 +82,30 @@ def test_fused_tracking_iteration_matches_generic_hooks():
         assert (a - b).abs().max() < 2e-4 * b.abs().max()
 
 
+def test_axis_angle_pose_kernel_matches_torch_formula():
+    """xrd_pose_aa_fwd/bwd against the torch restatement of
+    OptimizablePose.matrix (checked on the CPU against the per-frame module
+    in tests/test_coslam_host.py)"""
+    from xrdslam_amd.slam.utils.opt_pose import (
+        axis_angle_translation_to_matrix)
+    g = torch.Generator().manual_seed(0)
+    rot = torch.randn(70, 3, generator=g) * 0.9
+    rot[3] = 0.0
+    rot[5] *= 1e-3
+    trans = torch.randn(70, 3, generator=g)
+    w = torch.randn(70, 4, 4, generator=g)
+    ra, ta = rot.clone().requires_grad_(True), trans.clone().requires_grad_(True)
+    Ma = axis_angle_translation_to_matrix(ra, ta)         # torch ops, CPU
+    (Ma * w).sum().backward()
+    rb = rot.cuda().requires_grad_(True)
+    tb = trans.cuda().requires_grad_(True)
+    Mb = axis_angle_translation_to_matrix(rb, tb)         # fused kernels
+    (Mb * w.cuda()).sum().backward()
+    assert torch.allclose(Ma, Mb.cpu(), atol=2e-6)
+    assert torch.allclose(ra.grad, rb.grad.cpu(), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(ta.grad, tb.grad.cpu(), atol=1e-6)
+
+
 def test_sample_distinct_is_a_random_subset():
     from xrdslam_amd.engine import slam_ops
     torch.manual_seed(1)

@@ -99,6 +99,8 @@ _SIGS = {
     'xrd_nice_loss': (C.c_int, [C.c_int] * 4 + [f32] + [vp] * 10),
     'xrd_pose_quat_fwd': (C.c_int, [vp] * 4),
     'xrd_pose_quat_bwd': (C.c_int, [vp] * 5),
+    'xrd_pose_aa_fwd': (C.c_int, [C.c_int, vp, vp, vp, vp]),
+    'xrd_pose_aa_bwd': (C.c_int, [C.c_int, vp, vp, vp, vp, vp]),
     'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
                                  vp, vp]),
     'xrd_track_best': (C.c_int, [vp] * 6),

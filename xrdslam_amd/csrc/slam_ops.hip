@@ -306,6 +306,83 @@ using namespace xrd;
 namespace xrd {
 namespace {
 
+// c2w [n,16] from axis-angle r[n,3] and translation t[n,3]
+// (OptimizablePose.matrix(), rot_rep='axis_angle', slam/utils/opt_pose.py:51-95:
+// Rodrigues R = I + sin(a) K + (1 - cos(a)) K^2, K = skew(r/a), exactly I when
+// |r| <= 1e-8), one thread per pose
+__global__ __launch_bounds__(64) void pose_aa_fwd_kernel(
+    int n, const float* __restrict__ r3, const float* __restrict__ t3,
+    float* __restrict__ c2w) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  const float x = r3[p * 3], y = r3[p * 3 + 1], z = r3[p * 3 + 2];
+  const float a = sqrtf(x * x + y * y + z * z);
+  float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (a > 1e-8f) {
+    const float w0 = x / a, w1 = y / a, w2 = z / a;
+    const float s = sinf(a), c1 = 1.f - cosf(a);
+    const float K[9] = {0.f, -w2, w1, w2, 0.f, -w0, -w1, w0, 0.f};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float kk = 0.f;
+        for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+        R[i * 3 + j] += K[i * 3 + j] * s + c1 * kk;
+      }
+  }
+  float* M = c2w + (size_t)p * 16;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) M[i * 4 + j] = R[i * 3 + j];
+    M[i * 4 + 3] = t3[p * 3 + i];
+  }
+  M[12] = M[13] = M[14] = 0.f;
+  M[15] = 1.f;
+}
+
+__global__ __launch_bounds__(64) void pose_aa_bwd_kernel(
+    int n, const float* __restrict__ r3, const float* __restrict__ g_c2w,
+    float* __restrict__ g_r, float* __restrict__ g_t) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  const float* Gm = g_c2w + (size_t)p * 16;
+  float G[9];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) G[i * 3 + j] = Gm[i * 4 + j];
+    g_t[p * 3 + i] = Gm[i * 4 + 3];
+  }
+  const float x = r3[p * 3], y = r3[p * 3 + 1], z = r3[p * 3 + 2];
+  const float a = sqrtf(x * x + y * y + z * z);
+  float gr[3] = {0.f, 0.f, 0.f};
+  if (a > 1e-8f) {
+    const float w[3] = {x / a, y / a, z / a};
+    const float s = sinf(a), c = cosf(a);
+    const float K[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+    float K2[9], sGK = 0.f, sGK2 = 0.f;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float kk = 0.f;
+        for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+        K2[i * 3 + j] = kk;
+        sGK += G[i * 3 + j] * K[i * 3 + j];
+        sGK2 += G[i * 3 + j] * kk;
+      }
+    // dL/dK = s G + (1-c) (G K^T + K^T G)
+    float dK[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float v = 0.f;
+        for (int k = 0; k < 3; ++k)
+          v += G[i * 3 + k] * K[j * 3 + k] + K[k * 3 + i] * G[k * 3 + j];
+        dK[i * 3 + j] = s * G[i * 3 + j] + (1.f - c) * v;
+      }
+    const float dw[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    const float da = c * sGK + s * sGK2;
+    const float wd = w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2];
+    for (int i = 0; i < 3; ++i) gr[i] = (dw[i] - w[i] * wd) / a + da * w[i];
+    (void)K2;
+  }
+  for (int i = 0; i < 3; ++i) g_r[p * 3 + i] = gr[i];
+}
+
 // Keyed pseudo-random permutation of [0, 2^bits) (4-round balanced Feistel),
 // walked until the value falls below n: perm(0..n_out-1) are n_out DISTINCT
 // uniform-looking indices in [0, n) in O(1) each — random.sample() without the
@@ -517,6 +594,22 @@ int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
                      (hipStream_t)stream, loss, c2w16, best_loss, best_c2w16,
                      valid);
   return check_launch("xrd_track_best");
+}
+
+int xrd_pose_aa_fwd(int n, const float* r3, const float* t3, float* c2w16,
+                    xrd_stream_t stream) {
+  if (n < 1 || !r3 || !t3 || !c2w16) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_aa_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0,
+                     (hipStream_t)stream, n, r3, t3, c2w16);
+  return check_launch("xrd_pose_aa_fwd");
+}
+
+int xrd_pose_aa_bwd(int n, const float* r3, const float* g_c2w16, float* g_r3,
+                    float* g_t3, xrd_stream_t stream) {
+  if (n < 1 || !r3 || !g_c2w16 || !g_r3 || !g_t3) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_aa_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0,
+                     (hipStream_t)stream, n, r3, g_c2w16, g_r3, g_t3);
+  return check_launch("xrd_pose_aa_bwd");
 }
 
 int xrd_sample_distinct(int64_t n_total, int n_out, const int64_t* keys4,

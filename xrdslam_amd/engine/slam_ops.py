@@ -62,6 +62,33 @@ class PoseQuatSplitFn(torch.autograd.Function):
         return gt, gq
 
 
+class PoseAxisAngleFn(torch.autograd.Function):
+    """c2w [n,4,4] = matrix(r[n,3] axis-angle, t[n,3]) — OptimizablePose.matrix
+    for any number of poses in one launch (and one for the backward)"""
+
+    @staticmethod
+    def forward(ctx, r, t):
+        n = r.shape[0]
+        c2w = torch.empty(n, 4, 4, dtype=torch.float32, device=r.device)
+        rc, tc = r.detach().contiguous(), t.detach().contiguous()
+        _lib.check(_lib.lib().xrd_pose_aa_fwd(
+            n, _lib.ptr(rc), _lib.ptr(tc), _lib.ptr(c2w),
+            _lib.stream_ptr(r.device)), 'xrd_pose_aa_fwd')
+        ctx.save_for_backward(rc)
+        return c2w
+
+    @staticmethod
+    def backward(ctx, g):
+        rc, = ctx.saved_tensors
+        n = rc.shape[0]
+        gr = torch.empty(n, 3, dtype=torch.float32, device=rc.device)
+        gt = torch.empty(n, 3, dtype=torch.float32, device=rc.device)
+        _lib.check(_lib.lib().xrd_pose_aa_bwd(
+            n, _lib.ptr(rc), _lib.ptr(g.float().contiguous()), _lib.ptr(gr),
+            _lib.ptr(gt), _lib.stream_ptr(rc.device)), 'xrd_pose_aa_bwd')
+        return gr, gt
+
+
 class SampleRaysFn(torch.autograd.Function):
     """rays of F frames in one batch: returns rays_o, rays_d (differentiable
     w.r.t. the stacked c2w), target depth/colour, keep mask, dmax"""

@@ -247,9 +247,10 @@ class Algorithm:
             # keep the pose that produced the lowest loss (evaluated before
             # its Adam step, base_algorithm.py:262-265), on the device
             cur = optimize_frames[-1].get_pose().detach()
-            if cur.is_cuda and loss.dtype == torch.float64 and loss.is_cuda:
+            if cur.is_cuda and loss.is_cuda and \
+                    track['loss'].device == loss.device:
                 from ...engine import slam_ops
-                slam_ops.track_best(loss, cur, track)
+                slam_ops.track_best(loss.detach().double(), cur, track)
             else:
                 lval = loss.detach().to(cur.device, torch.float64)
                 better = lval < track['loss']

@@ -68,6 +68,9 @@ def axis_angle_translation_to_matrix(rot: torch.Tensor,
     """batched OptimizablePose.matrix() for rot_rep='axis_angle': rot [n,3],
     trans [n,3] -> c2w [n,4,4]; same formula (Rodrigues, exact identity below
     1e-8 rad) evaluated for all poses at once"""
+    if rot.is_cuda and rot.dtype == torch.float32:
+        from ...engine import slam_ops
+        return slam_ops.PoseAxisAngleFn.apply(rot, trans)
     n = rot.shape[0]
     small = torch.norm(rot.detach(), dim=-1, keepdim=True) <= 1e-8
     safe = torch.where(small, torch.ones_like(rot), rot)
@@ -119,6 +122,11 @@ class OptimizablePose(nn.Module):
                     return slam_ops.PoseQuatSplitFn.apply(self.data_t,
                                                           self.data_q)
                 return slam_ops.PoseQuat7Fn.apply(self.data)
+        if self.rot_rep == 'axis_angle' and self.separate_LR and \
+                self.data_r.is_cuda and self.data_r.dtype == torch.float32:
+            from ...engine import slam_ops
+            return slam_ops.PoseAxisAngleFn.apply(
+                self.data_r.unsqueeze(0), self.data_t.unsqueeze(0))[0]
         rot, t = self.rotation(), self.translation()
         Rt = torch.eye(4, device=t.device, dtype=t.dtype)
         Rt[:3, :3] = rot
