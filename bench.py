@@ -1,6 +1,7 @@
-"""bench.py — tracking+mapping FPS of the MI355X-native NICE-SLAM hot path.
+"""bench.py — tracking+mapping FPS of the MI355X-native NICE-SLAM / Co-SLAM
+hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--algo nice-slam|co-slam]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -17,6 +18,12 @@ N > 1: one process per GPU; tracking is replicated, the mapping rays are
 sharded over ranks and the selected-cell/decoder gradients are summed with one
 RCCL all-reduce per iteration (engine/dist.py) -> "strong" scaling of one
 frame stream.
+
+--algo co-slam (single GPU) runs the same frame loop with Co-SLAM (hash grid +
+OneBlob + 2x32 MLPs, 10 tracking it x 1024 rays per frame, every 5th frame 10
+mapping it x (2048 bank rays + current-frame rays) with bundle adjustment,
+43 samples per ray, office0 bound).  The default (nice-slam, N=1) line carries
+that run as the extra object "co_slam".
 
 The JSON line also carries
   roofline     for the dominant kernel of the timed region (per-launch HIP-event
@@ -114,12 +121,171 @@ def cpu_baseline(threads):
                    f'coarse={t_coarse:.3f}')}
 
 
+# ---- Co-SLAM (BASELINE.json north_star names it next to NICE-SLAM) ----------
+CO_BOUND = [[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]]  # office0, co-slam config
+CO_S = 43                  # 11 depth-guided + 32 uniform samples per ray
+CO_FLOPS = 2 * 5184        # decoders, forward, per sample
+CO_GATHER = 16 * 8 * 8     # hash-grid corner reads per sample (bytes)
+
+
+def co_algorithmic(kernel, n_rays, ray_grads, map_grads):
+    """(bytes, flops) one launch of the fused Co-SLAM renderer moves/computes:
+    forward = corner gathers + raw/z outputs; backward recomputes the forward,
+    reads the corners again for d/dx, and (mapping) writes the hash-feature
+    gradients + read-modify-writes the touched table entries, plus the
+    weight-gradient GEMMs"""
+    n = n_rays * CO_S
+    if kernel == 'coslam_fwd':
+        return n * (CO_GATHER + 20), n * CO_FLOPS
+    by = CO_GATHER + 20 + 16
+    fl = 2 * CO_FLOPS
+    if ray_grads:
+        by += CO_GATHER
+    if map_grads:
+        by += 2 * 128 + 12 + 2 * CO_GATHER
+        fl += CO_FLOPS
+    return n * by, n * fl
+
+
+def co_cpu_baseline(threads):
+    """the host mirror of the reference's Co-SLAM model on the CPU with the
+    oracle encodings (the configuration tests/test_coslam_host.py pins against
+    the reference-generated golden): 1 tracking iteration (1024 rays) and 1
+    mapping iteration (2048 + 341 rays, smoothness term), fwd+bwd; converted
+    with the reference iteration counts (10 tracking it/frame, 10 mapping
+    it / 5 frames)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import tcnn_standin
+    import xrdslam_amd.slam.model_components.encodings_coslam as enc
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.joint_encoding import (JointEncoding,
+                                                        JointEncodingConfig)
+    torch.set_num_threads(threads)
+    real = enc.tcnn
+    enc.tcnn = tcnn_standin.module()
+    try:
+        model = JointEncoding(
+            JointEncodingConfig(cam_depth_trunc=100.0, tcnn_encoding=True),
+            Camera(**CAM), torch.from_numpy(np.array(CO_BOUND)))
+    finally:
+        enc.tcnn = real
+    g = torch.Generator().manual_seed(0)
+
+    def one(n, is_mapping):
+        o = ((torch.rand(n, 3, generator=g) - 0.5) * 2).requires_grad_()
+        d = torch.randn(n, 3, generator=g)
+        d = (d / d.norm(dim=1, keepdim=True)).requires_grad_()
+        inp = {'rays_o': o, 'rays_d': d, 'first': False,
+               'target_d': 1.0 + 2.0 * torch.rand(n, 1, generator=g),
+               'target_s': torch.rand(n, 3, generator=g)}
+        t0 = time.perf_counter()
+        out = model.get_outputs(inp)
+        loss = sum(model.get_loss_dict(out, inp, is_mapping, 0).values())
+        loss.backward()
+        return time.perf_counter() - t0
+
+    one(64, False)
+    t_track, t_map = one(1024, False), one(2048 + 341, True)
+    per_frame = 10 * t_track + 10 * t_map / 5.0
+    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': threads,
+            'kind': 'port',
+            'sample': ('1 tracking iter (1024 rays) + 1 mapping iter (2389 '
+                       'rays + smoothness), fwd+bwd, 43 samples/ray; scaled '
+                       'by the reference iteration counts; iter seconds '
+                       f'track={t_track:.3f} map={t_map:.3f}')}
+
+
+def run_coslam(args, dev, with_cpu):
+    """Co-SLAM frame loop on one GPU -> result object"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.engine import coslam as ec
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import cadence, coslam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = coslam_config(CO_BOUND)
+    if args.first_iters is not None:
+        cfg.mapping_first_n_iters = args.first_iters
+    cam = Camera(**CAM)
+    algo = cfg.setup(camera=cam, device=str(dev))
+    algo.use_graphs = not args.no_graphs
+    data = SyntheticRoom(CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx,
+                         fy=cam.fy, cx=cam.cx, cy=cam.cy,
+                         n_frames=max(args.warmup + args.steps + 1, 200),
+                         device=dev)
+    cad = cadence['co-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device=str(dev))
+    for k in range(1 + args.warmup):
+        slam.step(k)
+    ec.PROFILE = {}
+    slam.t_track = slam.t_map = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
+        slam.step(k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, ec.PROFILE = ec.PROFILE, None
+    stats = []
+    for key, evs in prof.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        stats.append((sum(ms), key, len(ms), sum(ms) / len(ms)))
+    stats.sort(reverse=True)
+    total_ms, key, calls, avg_ms = stats[0]
+    kernel, n_rays, ray_grads, map_grads = key
+    abytes, aflops = co_algorithmic(kernel, n_rays, ray_grads, map_grads)
+    hbm, mfma = abytes / (avg_ms * 1e-3), aflops / (avg_ms * 1e-3)
+    compute_bound = aflops / abytes > MFMA_F32_PEAK / HBM_PEAK
+    roofline = {
+        'bound': 'mfma' if compute_bound else 'hbm',
+        'achieved': mfma / 1e12 if compute_bound else hbm / 1e9,
+        'peak': MFMA_F32_PEAK / 1e12 if compute_bound else HBM_PEAK / 1e9,
+        'unit': 'TFLOP/s' if compute_bound else 'GB/s',
+        'frac': mfma / MFMA_F32_PEAK if compute_bound else hbm / HBM_PEAK,
+        'traffic': None,
+        'intensity_flop_per_byte': aflops / abytes,
+        'kernel': f'{kernel}[rays={n_rays},ray_grad={int(ray_grads)},'
+                  f'map_grad={int(map_grads)}] (launch group: zero-fill, '
+                  'render backward, dW reduce, chunked table scatter)'
+                  if kernel == 'coslam_bwd' else f'{kernel}[rays={n_rays}]',
+        'avg_launch_us': avg_ms * 1e3, 'launches': calls,
+        'algorithmic_bytes_per_launch': abytes,
+        'algorithmic_flops_per_launch': aflops,
+        'share_of_timed_kernel_time': total_ms / sum(s[0] for s in stats),
+        'note': 'launches inside replayed hipGraphs (tracking) are not '
+                'event-timed; eager launches (mapping, first tracking '
+                'iteration of a frame) are'}
+    return {
+        'metric': 'tracking+mapping FPS @640x480',
+        'value': args.steps / elapsed, 'unit': 'frames/s',
+        'ms_per_step': elapsed / args.steps * 1e3, 'dtype': 'f32',
+        'config': {
+            'workload': 'Co-SLAM Replica/office0-shaped 640x480 RGB-D: 10 '
+                        'tracking it x 1024 rays/frame + every 5th frame 10 '
+                        'mapping it x (2048 bank rays + current-frame rays) '
+                        'with bundle adjustment, 43 samples/ray, hash grid '
+                        '16x2 (2^16) + OneBlob + 2x32 MLPs',
+            'track_ms_per_frame': slam.t_track / args.steps * 1e3,
+            'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+            'ate_rmse_m': slam.ate_rmse()},
+        'roofline': roofline,
+        'cpu_baseline': co_cpu_baseline(min(16, os.cpu_count() or 1))
+        if with_cpu else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--algo', default='nice-slam',
+                    choices=['nice-slam', 'co-slam'])
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-coslam', action='store_true',
+                    help='skip the Co-SLAM leg of the default run')
     ap.add_argument('--no-graphs', action='store_true',
                     help='run every iteration eagerly (no hipGraph capture)')
     ap.add_argument('--first-iters', type=int, default=None,
@@ -141,6 +307,16 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=dev)
+
+    if args.algo == 'co-slam':
+        if world > 1:
+            raise SystemExit('--algo co-slam runs on one GPU this round')
+        res = run_coslam(args, dev, not args.no_cpu_baseline)
+        res.update({'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                    'higher_is_better': True, 'scaling': 'weak',
+                    'vs_baseline': None, 'data': 'synthetic'})
+        print(json.dumps(res), flush=True)
+        return
 
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.engine import dist as xdist
@@ -257,6 +433,12 @@ def main():
                 'ate_rmse_m': slam.ate_rmse()},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if world == 1 and not args.no_coslam:
+            # the second algorithm the north star names, same frame loop
+            co_args = argparse.Namespace(**vars(args))
+            co_args.first_iters = None
+            co = run_coslam(co_args, dev, not args.no_cpu_baseline)
+            out['co_slam'] = co
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

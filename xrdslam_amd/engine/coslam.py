@@ -19,6 +19,27 @@ from .. import _lib
 
 _INDEX = {}
 
+# bench.py: per-launch HIP-event timing on the launch stream, keyed
+# (kernel, n_rays, ray_grads, map_grads); None = off
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, key):
+        self.key = key if PROFILE is not None and \
+            not torch.cuda.is_current_stream_capturing() else None
+
+    def __enter__(self):
+        if self.key is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.key is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1))
+
 
 def _index(device):
     """(pack gather index into [flat, 0], dW gather index) on ``device``"""
@@ -132,10 +153,11 @@ class _CoslamRenderFn(torch.autograd.Function):
         z_vals = torch.empty(n, S, dtype=torch.float32, device=dev)
         raw = torch.empty(n, S, 4, dtype=torch.float32, device=dev)
         maps = torch.empty(n, 8, dtype=torch.float32, device=dev)
-        _lib.check(lib.xrd_coslam_render_fwd(
-            C.byref(sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(td),
-            _lib.ptr(rn), _lib.ptr(z_vals), _lib.ptr(raw), _lib.ptr(maps),
-            _lib.stream_ptr(dev)), 'xrd_coslam_render_fwd')
+        with _Timed(('coslam_fwd', n, False, False)):
+            _lib.check(lib.xrd_coslam_render_fwd(
+                C.byref(sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(td),
+                _lib.ptr(rn), _lib.ptr(z_vals), _lib.ptr(raw), _lib.ptr(maps),
+                _lib.stream_ptr(dev)), 'xrd_coslam_render_fwd')
         ctx.sc, ctx.tables = sc, tables
         ctx.save_for_backward(ro, rd, z_vals, raw, table, pack)
         ctx.mark_non_differentiable(z_vals)
@@ -160,12 +182,14 @@ class _CoslamRenderFn(torch.autograd.Function):
             if g_maps is None else g_maps.float().contiguous()
         if g_raw is not None:
             g_raw = g_raw.float().contiguous()
-        _lib.check(lib.xrd_coslam_render_bwd(
-            C.byref(ctx.sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(z_vals),
-            _lib.ptr(raw), _lib.ptr(g_maps), _lib.ptr(g_raw), _lib.ptr(g_o),
-            _lib.ptr(g_d), _lib.ptr(g_table), _lib.ptr(g_dw),
-            _lib.ptr(ctx.tables.workspace(n)) if need_map else None,
-            _lib.stream_ptr(dev)), 'xrd_coslam_render_bwd')
+        ws = _lib.ptr(ctx.tables.workspace(n)) if need_map else None
+        with _Timed(('coslam_bwd', n, bool(need_rays), bool(need_map))):
+            _lib.check(lib.xrd_coslam_render_bwd(
+                C.byref(ctx.sc), n, _lib.ptr(ro), _lib.ptr(rd),
+                _lib.ptr(z_vals), _lib.ptr(raw), _lib.ptr(g_maps),
+                _lib.ptr(g_raw), _lib.ptr(g_o), _lib.ptr(g_d),
+                _lib.ptr(g_table), _lib.ptr(g_dw), ws,
+                _lib.stream_ptr(dev)), 'xrd_coslam_render_bwd')
         g_flat = None
         if need_map:
             g_flat = g_dw[_index(dev)[1]]
