@@ -56,6 +56,42 @@ FWD_FLOPS = {'coarse': 12.4e3, 'middle': 31.0e3, 'fine': 72.0e3,
              'color': 103.0e3}
 
 
+def pmc_traffic(kernels):
+    """bytes per launch of a launch group from the committed PMC pass
+    (profiles/r01_pmc.json, made by tools/run_pmc.sh on this same workload):
+    sum over the group's kernels of 2 x FETCH_SIZE (gfx950 correction) +
+    WRITE_SIZE; None when the file or a kernel is missing"""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
+    if not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    total = 0.0
+    for k in kernels:
+        try:
+            total += 2.0 * pmc['FETCH_SIZE'][k]['mean'] + \
+                pmc['WRITE_SIZE'][k]['mean']
+        except KeyError:
+            return None
+    return total * 1024.0
+
+
+def nice_group_kernels(kernel, stage, need_pose, need_dec):
+    """rocprof kernel names behind one xrd_nice_render_fwd/bwd call"""
+    if kernel != 'nice_bwd':
+        return None
+    dp = 'true' if need_pose else 'false'
+    decs = {'coarse': [0], 'middle': [1], 'fine': [1, 2],
+            'color': [1, 2, 3]}[stage]
+    out = []
+    for d in decs:
+        nt = 2 if d == 0 else 3
+        dw = 'true' if (d == 3 and need_dec) else 'false'
+        out.append(f'nice_bwd<dec/stage={d},NT={nt},dp={dp},dw={dw}>')
+    if need_dec and stage == 'color':
+        out.append('nice_dw_kernel')
+    return out
+
+
 def algorithmic_flops(kernel, stage, n_rays):
     S = 32 if stage == 'coarse' else 48
     return n_rays * S * FWD_FLOPS[stage] * (2.0 if kernel == 'nice_bwd' else 1.0)
@@ -245,7 +281,13 @@ def run_coslam(args, dev, with_cpu):
         'peak': MFMA_F32_PEAK / 1e12 if compute_bound else HBM_PEAK / 1e9,
         'unit': 'TFLOP/s' if compute_bound else 'GB/s',
         'frac': mfma / MFMA_F32_PEAK if compute_bound else hbm / HBM_PEAK,
-        'traffic': None,
+        'traffic': pmc_traffic(
+            [f'coslam_bwd<dp={str(bool(ray_grads)).lower()},'
+             f'dg={str(bool(map_grads)).lower()}>'] +
+            (['coslam_reduce_kernel', 'hash_chunk_scatter_kernel']
+             if map_grads else [])) if kernel == 'coslam_bwd'
+        else pmc_traffic(['coslam_fwd_kernel']),
+        'traffic_source': 'profiles/r01_pmc.json (see NICE line)',
         'intensity_flop_per_byte': aflops / abytes,
         'kernel': f'{kernel}[rays={n_rays},ray_grad={int(ray_grads)},'
                   f'map_grad={int(map_grads)}] (launch group: zero-fill, '
@@ -390,7 +432,13 @@ def main():
             'peak': MFMA_F32_PEAK / 1e12 if compute_bound else HBM_PEAK / 1e9,
             'unit': 'TFLOP/s' if compute_bound else 'GB/s',
             'frac': mfma / MFMA_F32_PEAK if compute_bound else hbm / HBM_PEAK,
-            'traffic': None,
+            'traffic': (pmc_traffic(nice_group_kernels(kernel, stage,
+                                                       need_pose, need_dec))
+                        if nice_group_kernels(kernel, stage, need_pose,
+                                              need_dec) else None),
+            'traffic_source': 'profiles/r01_pmc.json (rocprofv3 --pmc '
+                              'FETCH_SIZE, WRITE_SIZE passes of this workload;'
+                              ' bytes per launch group, FETCH x2 on gfx950)',
             'intensity_flop_per_byte': aflops / abytes,
             'other_bound': {
                 'bound': 'hbm' if compute_bound else 'mfma',

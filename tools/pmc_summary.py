@@ -1,21 +1,43 @@
-"""summarise rocprofv3 --pmc counter_collection.csv: per kernel mean counter"""
-import csv, re, sys, collections
+"""summarise rocprofv3 --pmc counter_collection.csv: mean counter value per
+kernel (our kernels only).  usage: pmc_summary.py <csv> <COUNTER> [json_out]"""
+import collections
+import csv
+import json
+import re
+import sys
+
 path, counter = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list)
+
+
+def short_name(name):
+    m = re.search(r'nice_(fwd|bwd)_kernel<(\d+), (\d+)(?:, (\w+), (\w+))?>',
+                  name)
+    if m:
+        return (f'nice_{m.group(1)}<dec/stage={m.group(2)},NT={m.group(3)},'
+                f'dp={m.group(4)},dw={m.group(5)}>')
+    m = re.search(r'coslam_bwd_kernel<(\w+), (\w+)>', name)
+    if m:
+        return f'coslam_bwd<dp={m.group(1)},dg={m.group(2)}>'
+    for k in ('nice_dw_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
+              'hash_chunk_scatter_kernel', 'coslam_reduce_kernel',
+              'coslam_loss_grad_kernel', 'adam_dense_kernel',
+              'reduce_partials_kernel', 'hashgrid_kernel'):
+        if k in name:
+            return k
+    return None
+
+
 for r in csv.DictReader(open(path)):
     if r.get('Counter_Name') != counter:
         continue
-    name = r['Kernel_Name']
-    m = re.search(r'nice_(fwd|bwd)_kernel<(\d+), (\d+)(?:, (\w+), (\w+))?>', name)
-    short = name[:50]
-    if m:
-        short = f"nice_{m.group(1)}<dec/stage={m.group(2)},NT={m.group(3)},dp={m.group(4)},dw={m.group(5)}>"
-    elif 'nice_dw_kernel' in name:
-        short = 'nice_dw_kernel'
-    elif 'adam_cells' in name:
-        short = 'adam_cells_kernel'
-    else:
-        continue
-    acc[short].append(float(r['Counter_Value']))
+    s = short_name(r['Kernel_Name'])
+    if s is not None:
+        acc[s].append(float(r['Counter_Value']))
+out = {}
 for k, v in sorted(acc.items()):
-    print(f'{k:55s} launches={len(v):4d} mean_{counter}={sum(v)/len(v):14.1f}')
+    out[k] = {'launches': len(v), 'mean': sum(v) / len(v), 'max': max(v)}
+    print(f'{k:48s} launches={len(v):5d} mean_{counter}={sum(v)/len(v):14.1f} '
+          f'max={max(v):14.1f}')
+if len(sys.argv) > 3:
+    json.dump({counter: out}, open(sys.argv[3], 'w'), indent=1)
