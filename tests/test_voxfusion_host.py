@@ -1,0 +1,46 @@
+"""CPU: the Vox-Fusion host mirror (SparseVoxel: octree bookkeeping, hit
+sorting/trimming, sampling wrapper, trilinear features, decoder, SDF
+compositing, losses) against the golden made from the reference's own model.
+The two native ray/voxel operators are stood in for by the C oracle
+(oracle/grid_standin.py) — the same stand-in the reference ran on when the
+golden was made; the octree is the product's host C++ (ids must match the
+compiled reference bit for bit)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+sys.path.insert(0, os.path.dirname(__file__))
+import voxfusion_golden_util as vg  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture()
+def oracle_grid(monkeypatch):
+    import grid_standin
+    import xrdslam_amd.slam.model_components.voxel_helpers_voxfusion as vh
+    monkeypatch.setattr(vh, '_ext', grid_standin.module())
+
+
+def test_sparse_voxel_vs_reference(oracle_grid):
+    g = np.load(vg.GOLDEN)
+    model = vg.build_model(g, 'cpu')
+    exact, errs = vg.run(model, g, 'cpu', dedup=False)
+    assert all(exact.values()), exact
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_voxfusion_config_and_relative_pose():
+    from xrdslam_amd.slam.configs.input_config import (algorithm_configs,
+                                                       cadence)
+    cfg = algorithm_configs['vox-fusion']()
+    assert cfg.tracking_n_iters == 30 and cfg.mapping_n_iters == 15
+    assert cfg.model.voxel_size == 0.2 and cfg.model.embed_dim == 16
+    cad = cadence['vox-fusion']
+    assert cad.map_every == 1 and cad.use_relative_pose and \
+        cad.init_pose_offset == 10

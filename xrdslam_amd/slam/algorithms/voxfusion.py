@@ -1,0 +1,130 @@
+"""``VoxFusion`` algorithm plugin (reference: slam/algorithms/voxfusion.py):
+every frame is a map frame; mapping first allocates voxels for the new depth
+image (back-projected with the current pose), then optimises embeddings,
+decoder and the poses of a random keyframe window + the current frame."""
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass, field
+from typing import Type
+
+import numpy as np
+import torch
+
+from ..common.common import get_rays, get_samples
+from ..models.sparse_voxel import SparseVoxelConfig
+from .base_algorithm import Algorithm, AlgorithmConfig
+
+
+@dataclass
+class VoxFusionConfig(AlgorithmConfig):
+    _target: Type = field(default_factory=lambda: VoxFusion)
+    model: SparseVoxelConfig = field(default_factory=SparseVoxelConfig)
+    mapping_sample: int = 2048
+    min_sample_pixels: int = 100
+    tracking_sample: int = 1024
+    ray_batch_size: int = 3000
+
+
+class VoxFusion(Algorithm):
+    config: VoxFusionConfig
+
+    def __init__(self, config: VoxFusionConfig, camera, device: str) -> None:
+        super().__init__(config, camera, device)
+        self.model = config.model.setup(camera=camera, bounding_box=None)
+        self.model.to(device)
+        self.bundle_adjust = True
+        self._rays_cam = None
+
+    def _camera_rays(self, device):
+        """[H*W,3] camera-frame directions, OpenGL (precompute(), :37-52)"""
+        if self._rays_cam is None or self._rays_cam.device != \
+                torch.device(device):
+            cam = self.camera
+            ix, iy = torch.meshgrid(
+                torch.arange(cam.width, device=device),
+                torch.arange(cam.height, device=device), indexing='xy')
+            self._rays_cam = torch.stack(
+                [(ix - cam.cx) / cam.fx, -(iy - cam.cy) / cam.fy,
+                 -torch.ones_like(ix)], -1).float().reshape(-1, 3)
+        return self._rays_cam
+
+    # -- hooks ---------------------------------------------------------------------
+    def get_model_input(self, optimize_frames, is_mapping):
+        cfg, dev = self.config, self.model.device
+        n = cfg.mapping_sample if is_mapping else cfg.tracking_sample
+        ro, rd, gd, gc = [], [], [], []
+        for f in optimize_frames:
+            o, d, dep, col = get_samples(self.camera, n, f.get_pose(), f.depth,
+                                         f.rgb, device=dev, frame=f)
+            ro.append(o.float())
+            rd.append(d.float())
+            gd.append(dep.float())
+            gc.append(col.float())
+        return {'rays_o': torch.cat(ro), 'rays_d': torch.cat(rd),
+                'target_s': torch.cat(gc), 'target_d': torch.cat(gd)}
+
+    def create_voxels(self, frame):
+        """allocate the voxels seen by this frame (:96-107); the back
+        projection runs on the device-resident depth image"""
+        dev = self.model.device
+        depth, _ = frame.device_images(dev)
+        pts = self._camera_rays(dev) * depth
+        pts = pts[depth.reshape(-1) > 0]
+        pose = frame.get_pose().detach().to(dev)
+        pts = pts @ pose[:3, :3].transpose(-1, -2) + pose[:3, 3]
+        self.model.insert_points(pts)
+
+    def pre_precessing(self, cur_frame, is_mapping):
+        if is_mapping:
+            self.create_voxels(cur_frame)
+
+    def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
+        pass
+
+    def optimizer_config_update(self, max_iters, coarse=False):
+        pass
+
+    def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
+                 coarse=False):
+        inp = self.get_model_input(optimize_frames, is_mapping)
+        out = self.model(inp)
+        losses = self.model.get_loss_dict(out, inp, is_mapping, step)
+        return functools.reduce(torch.add, losses.values())
+
+    def render_img(self, c2w, gt_depth=None, idx=None):
+        with torch.no_grad():
+            dev = self.model.device
+            rays_o, rays_d = get_rays(self.camera, c2w, device=dev)
+            rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+            if gt_depth is not None:
+                gt_depth = torch.as_tensor(gt_depth).to(dev).reshape(-1, 1)
+            H, W = self.camera.height, self.camera.width
+            depths, colors = [], []
+            bs = self.config.ray_batch_size
+            for i in range(0, rays_d.shape[0], bs):
+                td = None if gt_depth is None else gt_depth[i:i + bs]
+                n = rays_d[i:i + bs].shape[0]
+                out = self.model.render_rays(
+                    rays_o[None, i:i + bs], rays_d[None, i:i + bs],
+                    target_d=td)
+                if out is None:  # no voxel hit in this chunk
+                    depths.append(torch.zeros(n, dtype=torch.float64,
+                                              device=dev))
+                    colors.append(torch.zeros(n, 3, device=dev))
+                    continue
+                depths.append(out['depth'].double())
+                colors.append(out['rgb'])
+            return torch.cat(colors).reshape(H, W, 3).cpu().numpy(), \
+                torch.cat(depths).reshape(H, W).cpu().numpy()
+
+    def update_mesh(self):
+        pass
+
+    def get_cloud(self, c2w_np, gt_depth_np):
+        return None
+
+    def get_mesh(self):
+        raise NotImplementedError('mesh extraction (marching cubes per voxel) '
+                                  'is out of the hot-path scope '
+                                  '(SURVEY.md §8f)')

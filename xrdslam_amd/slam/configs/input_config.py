@@ -9,10 +9,12 @@ from typing import Dict
 
 from ..algorithms.coslam import CoSLAMConfig
 from ..algorithms.nice_slam import NiceSLAMConfig
+from ..algorithms.voxfusion import VoxFusionConfig
 from ..engine.optimizers import AdamOptimizerConfig
 from ..engine.schedulers import LRconfig, NiceSLAMSchedulerConfig
 from ..models.conv_onet import ConvOnetConfig
 from ..models.joint_encoding import JointEncodingConfig
+from ..models.sparse_voxel import SparseVoxelConfig
 
 
 @dataclass
@@ -22,6 +24,7 @@ class PipelineCadence:
     keyframe_every: int = 50
     render_freq: int = 50
     use_relative_pose: bool = False
+    init_pose_offset: int = 0
 
 
 def _sched(**lr):
@@ -95,8 +98,28 @@ def coslam_config(bound=None) -> CoSLAMConfig:
         })
 
 
+def voxfusion_config() -> VoxFusionConfig:
+    """algorithm_configs['vox-fusion'] (input_config.py:159-201)"""
+    adam = AdamOptimizerConfig
+    return VoxFusionConfig(
+        keyframe_selection_method='random', tracking_n_iters=30,
+        mapping_n_iters=15, mapping_first_n_iters=30, mapping_window_size=5,
+        mapping_sample=1024, tracking_sample=1024, ray_batch_size=3000,
+        model=SparseVoxelConfig(),
+        optimizers={
+            'decoder': {'optimizer': adam(lr=5e-3), 'scheduler': None},
+            'embeddings': {'optimizer': adam(lr=5e-3), 'scheduler': None},
+            'tracking_pose': {'optimizer': adam(lr=1e-2), 'scheduler': None},
+            'mapping_pose': {'optimizer': adam(lr=1e-3), 'scheduler': None},
+        })
+
+
 algorithm_configs: Dict[str, object] = {'nice-slam': nice_slam_config,
-                                        'co-slam': coslam_config}
+                                        'co-slam': coslam_config,
+                                        'vox-fusion': voxfusion_config}
 cadence: Dict[str, PipelineCadence] = {
     'nice-slam': PipelineCadence(),
-    'co-slam': PipelineCadence(map_every=5, keyframe_every=5)}
+    'co-slam': PipelineCadence(map_every=5, keyframe_every=5),
+    'vox-fusion': PipelineCadence(map_every=1, keyframe_every=50,
+                                  use_relative_pose=True,
+                                  init_pose_offset=10)}

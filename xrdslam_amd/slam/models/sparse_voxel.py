@@ -1,0 +1,226 @@
+"""``SparseVoxel`` — the Vox-Fusion model (reference:
+slam/models/sparse_voxel.py:39-357): a sparse voxel octree whose leaf-voxel
+vertices index rows of one embedding table; rays are intersected with the
+octree, sampled inside the hit voxels, decoded by a small MLP and composited
+with SDF bell weights.
+
+Native operators: the octree (``compat.svo.Octree``, host C++, node ids
+bit-exact with the reference's pybind class) and the two ray/voxel kernels
+(``compat.grid``, HIP).  The rest — feature gather, decoder, compositing,
+losses — is torch on the device for now (fusion of this chain is a next row,
+DESIGN.md §1)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Type, Union
+
+import torch
+from torch.nn import Parameter
+
+from ...compat import svo as _svo
+from ..model_components import voxel_helpers_voxfusion as vh
+from ..model_components.decoder_voxfusion import Decoder
+from ..model_components.utils import compute_loss, get_sdf_loss
+from .base_model import Model, ModelConfig
+
+
+@dataclass
+class SparseVoxelConfig(ModelConfig):
+    _target: Type = field(default_factory=lambda: SparseVoxel)
+    # octree
+    voxels_each_dim: int = 256
+    voxel_size: float = 0.2
+    num_embeddings: int = 20000
+    embed_dim: int = 16
+    max_distance: int = 10
+    max_dpeth: float = 10
+    # loss weights
+    training_trunc: float = 0.05
+    trainging_rgb_weight: float = .5
+    trainging_depth_weight: float = 1.0
+    trainging_sdf_weight: float = 5000
+    trainging_fs_weight: float = 10.0
+    # decoder
+    depth: int = 2
+    width: int = 128
+    in_dim: int = 16
+    embedder: str = 'none'
+    # tracking / mapping
+    step_size: float = 0.05
+    max_voxel_hit: int = 20
+    num_iterations: int = 30
+    overlap_th: float = 0.7
+    keyframe_th: int = 30
+    keyframe_selection: str = 'random'
+    data_sc_factor: int = 1
+
+
+class SparseVoxel(Model):
+    config: SparseVoxelConfig
+
+    def __init__(self, config, camera, bounding_box=None, **kwargs) -> None:
+        super().__init__(config=config, camera=camera,
+                         bounding_box=bounding_box, **kwargs)
+        self.map_lock = torch.multiprocessing.RLock()
+        # like the reference (:89-92) the step is stored in metres on the
+        # config object itself
+        self.config.step_size = self.config.voxel_size * self.config.step_size
+        self.pose_offset = int(self.config.voxels_each_dim / 2.0 *
+                               self.config.voxel_size)
+        self.map_states = None
+        self.noise_fn = vh._uniform_noise  # replaceable for parity tests
+
+    def populate_modules(self):
+        super().populate_modules()
+        cfg = self.config
+        # node ids come from a process-global counter (the reference's static
+        # Octant::next_index_) and double as row indices of the exported
+        # arrays: one live octree per process, like the reference — a new
+        # model starts the counter again
+        _svo.reset_id_counter()
+        self.svo = _svo.Octree()
+        self.svo.init(256, cfg.embed_dim, cfg.voxel_size)
+        self.embeddings = torch.nn.Parameter(
+            torch.zeros(cfg.num_embeddings, cfg.embed_dim))
+        torch.nn.init.normal_(self.embeddings, std=0.01)
+        self.decoder = Decoder(depth=cfg.depth, width=cfg.width,
+                               in_dim=cfg.embed_dim, embedder=cfg.embedder)
+
+    # -- plugin surface -------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        return {'decoder': list(self.decoder.parameters()),
+                'embeddings': [self.embeddings]}
+
+    def get_outputs(self, input) -> Dict[str, Union[torch.Tensor, List]]:
+        return self.render_rays(input['rays_o'].unsqueeze(0),
+                                input['rays_d'].unsqueeze(0),
+                                target_d=input['target_d'].unsqueeze(0))
+
+    def get_loss_dict(self, outputs, inputs, is_mapping,
+                      stage=None) -> Dict[str, torch.Tensor]:
+        """L1 colour/depth on the rays that hit the octree, SDF + free-space
+        terms on their samples (:103-143)"""
+        cfg = self.config
+        ray_mask = outputs['ray_mask']
+        target_d = inputs['target_d'][ray_mask]
+        target_rgb = inputs['target_s'][ray_mask]
+        td = target_d.squeeze()
+        valid = (td > 0.01) * (td < cfg.max_dpeth)
+        w = valid.clone().unsqueeze(-1)
+        rgb_loss = compute_loss(outputs['rgb'][ray_mask] * w, target_rgb * w,
+                                loss_type='l1')
+        depth_loss = compute_loss(outputs['depth'][ray_mask].squeeze()[valid],
+                                  td[valid], loss_type='l1')
+        fs_loss, sdf_loss = get_sdf_loss(
+            outputs['z_vals'], target_d, outputs['sdf'],
+            cfg.training_trunc * cfg.data_sc_factor, 'l2')
+        return {'rgb_loss': rgb_loss * cfg.trainging_rgb_weight,
+                'depth_loss': depth_loss * cfg.trainging_depth_weight,
+                'sdf_loss': sdf_loss * cfg.trainging_sdf_weight,
+                'fs_loss': fs_loss * cfg.trainging_fs_weight}
+
+    # -- rendering --------------------------------------------------------------
+    def render_rays(self, rays_o, rays_d, target_d=None, chunk_size=-1):
+        """rays [1,N,3] -> dict (None when nothing is hit), :160-275"""
+        cfg = self.config
+        ms = self.map_states
+        intersections, hits = vh.ray_intersect(
+            rays_o, rays_d, ms['voxel_center_xyz'], ms['voxel_structure'],
+            cfg.voxel_size, cfg.max_voxel_hit, cfg.max_distance)
+        if hits.sum() == 0:
+            print('\n\n', '!' * 20, 'render_rays. no hit', '!' * 20, '\n\n')
+            return None
+        ray_mask = hits.view(1, -1)
+        intersections = {k: v[ray_mask].reshape(-1, v.size(-1))
+                         for k, v in intersections.items()}
+        rays_o = rays_o[ray_mask].reshape(-1, 3)
+        rays_d = rays_d[ray_mask].reshape(-1, 3)
+        samples = vh.ray_sample(intersections, step_size=cfg.step_size,
+                                noise_fn=self.noise_fn)
+        z_vals = samples['sampled_point_depth']
+        sample_mask = samples['sampled_point_voxel_idx'].long().ne(-1)
+        if sample_mask.sum() == 0:
+            return None
+        xyz = vh.ray(rays_o.unsqueeze(1), rays_d.unsqueeze(1),
+                     z_vals.unsqueeze(2))
+        dirs = rays_d.unsqueeze(1).expand(*z_vals.size(), rays_d.size(-1))
+        dirs = dirs / (torch.norm(dirs, 2, -1, keepdim=True) + 1e-8)
+        samples['sampled_point_xyz'] = xyz
+        samples['sampled_point_ray_direction'] = dirs
+        valid = {k: v[sample_mask] for k, v in samples.items()}
+        n_pts = valid['sampled_point_depth'].shape[0]
+        step = n_pts if chunk_size < 0 else chunk_size
+        outs = []
+        for i in range(0, n_pts, step):
+            chunk = {k: v[i:i + step] for k, v in valid.items()}
+            outs.append(self.decoder(vh.get_features(chunk, ms,
+                                                     cfg.voxel_size)))
+        field_out = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+        # padded samples read sdf = 1 (free space) and colour 0
+        sdf = vh.masked_scatter_ones(sample_mask, field_out['sdf']).squeeze(-1)
+        colour = vh.masked_scatter(sample_mask, field_out['color'])
+        valid_mask = torch.where(sample_mask, torch.ones_like(sample_mask),
+                                 torch.zeros_like(sample_mask))
+        weights, z_min = self.sdf2weights(sdf, z_vals, valid_mask)
+        rgb = torch.sum(weights[..., None] * colour, dim=-2)
+        depth = torch.sum(weights * z_vals, dim=-1)
+        ray_mask = ray_mask.squeeze()
+        n = ray_mask.shape[0]
+        depth = depth.new_zeros(n).masked_scatter(ray_mask, depth)
+        rgb = rgb.new_zeros(n, 3).masked_scatter(
+            ray_mask.unsqueeze(-1).expand(n, 3), rgb)
+        return {'depth': depth, 'rgb': rgb, 'sdf': sdf, 'z_vals': z_vals,
+                'ray_mask': ray_mask, 'weights': weights, 'z_min': z_min}
+
+    def sdf2weights(self, sdf, z_vals, valid_mask):
+        """sigma(s/tr) sigma(-s/tr), cut ``tr`` behind the first sign change,
+        padded samples removed, normalised (:277-304)"""
+        tr = self.config.training_trunc
+        w = torch.sigmoid(sdf / tr) * torch.sigmoid(-sdf / tr)
+        signs = sdf[:, 1:] * sdf[:, :-1]
+        crossing = torch.where(signs < 0.0, torch.ones_like(signs),
+                               torch.zeros_like(signs))
+        inds = torch.argmax(crossing, axis=1)[..., None]
+        z_min = torch.gather(z_vals, 1, inds)
+        mask = torch.where(z_vals < z_min + self.config.data_sc_factor * tr,
+                           torch.ones_like(z_vals), torch.zeros_like(z_vals))
+        w = w * mask * valid_mask
+        return w / (torch.sum(w, axis=-1, keepdims=True) + 1e-8), z_min
+
+    # -- map maintenance ----------------------------------------------------------
+    def insert_points(self, points, dedup=True):
+        """world points -> voxel coordinates -> octree (:333-340).  With
+        ``dedup`` the distinct voxels are extracted on the device in
+        first-occurrence order before the (host-side) insertion: the octree
+        only ever creates a node for the first occurrence, so node and vertex
+        ids are identical while the device->host copy shrinks from one row per
+        depth pixel to one per voxel."""
+        voxels = torch.div(points, self.config.voxel_size,
+                           rounding_mode='floor').int()
+        if dedup and voxels.is_cuda and voxels.shape[0] > 0:
+            uniq, inv = torch.unique(voxels, dim=0, return_inverse=True)
+            first = torch.full((uniq.shape[0], ), voxels.shape[0],
+                               dtype=torch.int64, device=voxels.device)
+            first.scatter_reduce_(0, inv, torch.arange(
+                voxels.shape[0], device=voxels.device), reduce='amin')
+            voxels = voxels[torch.sort(first).values]
+        self.svo.insert(voxels.cpu().int())
+        self.update_map_states()
+
+    @torch.enable_grad()
+    def update_map_states(self):
+        """flat octree arrays on the device (:342-357)"""
+        dev = self.embeddings.device
+        voxels, children, features = self.svo.get_centres_and_children()
+        centres = (voxels[:, :3] + voxels[:, -1:] / 2) * self.config.voxel_size
+        children = torch.cat([children, voxels[:, -1:]], -1)
+        state = {'voxel_vertex_idx': features.to(dev),
+                 'voxel_center_xyz': centres.to(dev).float(),
+                 'voxel_structure': children.to(dev).int(),
+                 'voxel_vertex_emb': self.embeddings}
+        with self.map_lock:
+            self.map_states = state
+
+    def get_map_states(self):
+        with self.map_lock:
+            return self.map_states.copy()

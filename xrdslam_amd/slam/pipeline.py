@@ -36,11 +36,18 @@ def predict_current_pose(frame_id, gt_c2w_np, estimate_c2w_list):
 
 class SequentialSLAM:
     def __init__(self, algorithm, dataset, map_every=5, keyframe_every=50,
-                 lazy_start=-1, pose_device='cpu'):
+                 lazy_start=-1, pose_device='cpu', use_relative_pose=False,
+                 init_pose_offset=0):
         self.algorithm, self.dataset = algorithm, dataset
         self.map_every, self.keyframe_every = map_every, keyframe_every
         self.lazy_start = lazy_start
         self.pose_device = pose_device
+        # tracker.py:76-89: poses relative to the first frame, which is placed
+        # at identity + init_pose_offset (Vox-Fusion: keeps octree coordinates
+        # positive)
+        self.use_relative_pose = use_relative_pose
+        self.init_pose_offset = init_pose_offset
+        self._first_old = self._first_new = None
         self.t_track = 0.0
         self.t_map = 0.0
 
@@ -53,7 +60,17 @@ class SequentialSLAM:
         """process frame ``idx``: track, then (if it is a map frame) map"""
         alg = self.algorithm
         data = self.dataset[idx]
-        gt_c2w = data['c2w'].astype(np.float32)
+        gt_c2w = data['c2w'].astype(np.float64)
+        if self.use_relative_pose:
+            if idx == 0 or self._first_old is None:
+                self._first_old = gt_c2w
+                self._first_new = np.eye(4)
+                self._first_new[:3, 3] += self.init_pose_offset
+                gt_c2w = self._first_new
+            else:
+                gt_c2w = self._first_new @ (np.linalg.inv(self._first_old) @
+                                            gt_c2w)
+        gt_c2w = gt_c2w.astype(np.float32)
         init = predict_current_pose(idx, gt_c2w, alg.get_estimate_c2w_list())
         frame = Frame(fid=idx, rgb=data['rgb'], depth=data['depth'],
                       gt_pose=gt_c2w, init_pose=init,
