@@ -318,10 +318,60 @@ def run_coslam(args, dev, with_cpu):
         if with_cpu else None}
 
 
+def run_voxfusion(args, dev):
+    """Vox-Fusion frame loop (every frame tracked with 30 it x 1024 rays and
+    mapped with 15 it x 1024 rays x <=6 frames; relative poses + 10 m offset).
+    Functional end-to-end path on the HIP ray/voxel operators; the feature /
+    decoder / compositing chain is still torch ops (no fused kernel yet), so
+    no roofline object is reported for it."""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import (cadence,
+                                                       voxfusion_config)
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cam = Camera(**CAM)
+    algo = voxfusion_config().setup(camera=cam, device=str(dev))
+    data = SyntheticRoom(CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx,
+                         fy=cam.fy, cx=cam.cx, cy=cam.cy,
+                         n_frames=max(args.warmup + args.steps + 1, 200),
+                         device=dev)
+    cad = cadence['vox-fusion']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device=str(dev),
+                          use_relative_pose=cad.use_relative_pose,
+                          init_pose_offset=cad.init_pose_offset)
+    for k in range(1 + args.warmup):
+        slam.step(k)
+    slam.t_track = slam.t_map = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
+        slam.step(k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return {
+        'metric': 'tracking+mapping FPS @640x480',
+        'value': args.steps / elapsed, 'unit': 'frames/s',
+        'ms_per_step': elapsed / args.steps * 1e3, 'dtype': 'f32',
+        'config': {
+            'workload': 'Vox-Fusion 640x480 synthetic RGB-D: 30 tracking it x '
+                        '1024 rays + 15 mapping it x 1024 rays x <=6 frames '
+                        'every frame, 0.2 m voxels, 16-d embeddings, 2x128 '
+                        'MLP',
+            'track_ms_per_frame': slam.t_track / args.steps * 1e3,
+            'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+            'ate_rmse_m': slam.ate_rmse(),
+            'leaf_voxels': int(algo.model.svo.count_leaf_nodes())},
+        'roofline': None, 'cpu_baseline': None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--algo', default='nice-slam',
-                    choices=['nice-slam', 'co-slam'])
+                    choices=['nice-slam', 'co-slam', 'vox-fusion'])
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
@@ -350,10 +400,11 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=dev)
 
-    if args.algo == 'co-slam':
+    if args.algo in ('co-slam', 'vox-fusion'):
         if world > 1:
-            raise SystemExit('--algo co-slam runs on one GPU this round')
-        res = run_coslam(args, dev, not args.no_cpu_baseline)
+            raise SystemExit(f'--algo {args.algo} runs on one GPU this round')
+        res = run_coslam(args, dev, not args.no_cpu_baseline) \
+            if args.algo == 'co-slam' else run_voxfusion(args, dev)
         res.update({'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
                     'higher_is_better': True, 'scaling': 'weak',
                     'vs_baseline': None, 'data': 'synthetic'})
