@@ -91,6 +91,48 @@ def get_rays(camera, c2w, device):
     return rays_o, rays_d
 
 
+def get_pointcloud(depth, camera, c2w, sampled_indices):
+    """world points of the pixels ``sampled_indices`` [n,2] = (row, col),
+    camera looking down +z; points that coincide with the camera origin
+    (rounded to 1e-4) are dropped (common.py:313-339)"""
+    xx = (sampled_indices[:, 1] - camera.cx) / camera.fx
+    yy = (sampled_indices[:, 0] - camera.cy) / camera.fy
+    z = depth[sampled_indices[:, 0], sampled_indices[:, 1]]
+    pts_cam = torch.stack((xx * z, yy * z, z), -1)
+    pts4 = torch.cat([pts_cam, torch.ones_like(pts_cam[:, :1])], 1)
+    pts = (c2w.to(pts4) @ pts4.T).T[:, :3]
+    rounded = torch.abs(torch.round(pts, decimals=4))
+    origin = torch.zeros(1, 3, device=pts.device, dtype=pts.dtype)
+    _, idx, counts = torch.cat([rounded, origin], 0).unique(
+        dim=0, return_inverse=True, return_counts=True)
+    dup = torch.isin(idx, torch.where(counts.gt(1))[0])[:len(rounded)]
+    return pts[~dup]
+
+
+def setup_camera(camera, w2c, near=0.01, far=100, device='cuda'):
+    """rasteriser settings of SplaTAM for the FIRST frame's w2c
+    (common.py:592-619): transposed view matrix and full projection"""
+    from ...compat.diff_gaussian_rasterization import \
+        GaussianRasterizationSettings
+    w, h = camera.width, camera.height
+    fx, fy, cx, cy = camera.fx, camera.fy, camera.cx, camera.cy
+    w2c = torch.as_tensor(np.asarray(w2c), dtype=torch.float32).to(device)
+    cam_center = torch.inverse(w2c)[:3, 3]
+    w2c_t = w2c.unsqueeze(0).transpose(1, 2)
+    proj = torch.tensor(
+        [[2 * fx / w, 0.0, -(w - 2 * cx) / w, 0.0],
+         [0.0, 2 * fy / h, -(h - 2 * cy) / h, 0.0],
+         [0.0, 0.0, far / (far - near), -(far * near) / (far - near)],
+         [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32,
+        device=device).unsqueeze(0).transpose(1, 2)
+    return GaussianRasterizationSettings(
+        image_height=h, image_width=w, tanfovx=w / (2 * fx),
+        tanfovy=h / (2 * fy),
+        bg=torch.zeros(3, dtype=torch.float32, device=device),
+        scale_modifier=1.0, viewmatrix=w2c_t, projmatrix=w2c_t.bmm(proj),
+        sh_degree=0, campos=cam_center, prefiltered=False)
+
+
 @torch.no_grad()
 def keyframe_selection_overlap(camera, cur_frame, keyframes_graph, k,
                                N_samples=16, pixs_per_image=100,
@@ -99,33 +141,43 @@ def keyframe_selection_overlap(camera, cur_frame, keyframes_graph, k,
     k of them (common.py:342-426, ray-sample branch).  Points: 16 samples in
     [0.8 d, d+0.5] along 100 valid-depth rays; a keyframe counts a point when
     it projects >20 px inside the image and lies in front of the camera."""
-    if not use_ray_sample:
-        raise NotImplementedError('only the ray-sample overlap test is built')
     if len(keyframes_graph) == 0:
         return []
     H, W = camera.height, camera.width
-    rays_o, rays_d, gd, _ = get_samples(camera, pixs_per_image,
-                                        cur_frame.get_pose(), cur_frame.depth,
-                                        cur_frame.rgb, device,
-                                        depth_filter=True, frame=cur_frame)
-    gd = gd.reshape(-1, 1).repeat(1, N_samples)
-    t = torch.linspace(0., 1., steps=N_samples, device=device)
-    z = gd * 0.8 * (1. - t) + (gd + 0.5) * t
-    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]).reshape(
-        -1, 3)
+    if use_ray_sample:
+        rays_o, rays_d, gd, _ = get_samples(camera, pixs_per_image,
+                                            cur_frame.get_pose(),
+                                            cur_frame.depth, cur_frame.rgb,
+                                            device, depth_filter=True,
+                                            frame=cur_frame)
+        gd = gd.reshape(-1, 1).repeat(1, N_samples)
+        t = torch.linspace(0., 1., steps=N_samples, device=device)
+        z = gd * 0.8 * (1. - t) + (gd + 0.5) * t
+        pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]) \
+            .reshape(-1, 3)
+    else:
+        # SplaTAM branch (:373-387): back-projected valid-depth pixels, camera
+        # looking down +z, no x flip
+        depth = torch.as_tensor(cur_frame.depth).to(device)
+        valid = torch.stack(torch.where(depth > 0), 1)
+        pick = valid[torch.randint(valid.shape[0],
+                                   (pixs_per_image * N_samples, )).to(device)]
+        pts = get_pointcloud(depth, camera, cur_frame.get_pose().to(device),
+                             pick)
     c2ws = torch.stack([kf.get_pose().detach().to(device)
                         for kf in keyframes_graph])
     w2c = torch.linalg.inv(c2ws.double())
     homo = torch.cat([pts.double(), torch.ones_like(pts[:, :1]).double()], 1)
     cam = torch.einsum('kij,nj->kni', w2c, homo)[..., :3]
-    cam[..., 0] *= -1  # x flip: pixel u grows to the right
+    if use_ray_sample:
+        cam[..., 0] *= -1  # x flip: pixel u grows to the right
     u = camera.fx * cam[..., 0] + camera.cx * cam[..., 2]
     v = camera.fy * cam[..., 1] + camera.cy * cam[..., 2]
     zc = cam[..., 2] + 1e-5
     u, v = (u / zc).float(), (v / zc).float()
     edge = 20
     inside = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge) & \
-        (zc < 0)
+        ((zc < 0) if use_ray_sample else (zc > 0))
     percent = inside.float().mean(1).cpu().numpy()
     order = np.argsort(-percent, kind='stable')
     selected = [keyframes_graph[a] for a in order if percent[a] > 0.0]

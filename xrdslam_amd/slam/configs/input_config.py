@@ -9,10 +9,12 @@ from typing import Dict
 
 from ..algorithms.coslam import CoSLAMConfig
 from ..algorithms.nice_slam import NiceSLAMConfig
+from ..algorithms.splatam import SplaTAMConfig
 from ..algorithms.voxfusion import VoxFusionConfig
 from ..engine.optimizers import AdamOptimizerConfig
 from ..engine.schedulers import LRconfig, NiceSLAMSchedulerConfig
 from ..models.conv_onet import ConvOnetConfig
+from ..models.gaussian_splatting import GaussianSplattingConfig
 from ..models.joint_encoding import JointEncodingConfig
 from ..models.sparse_voxel import SparseVoxelConfig
 
@@ -114,12 +116,33 @@ def voxfusion_config() -> VoxFusionConfig:
         })
 
 
+def splatam_config() -> SplaTAMConfig:
+    """algorithm_configs['splaTAM'] (input_config.py:377-431)"""
+    def adam(lr, eps=1e-8):
+        return {'optimizer': AdamOptimizerConfig(lr=lr, eps=eps),
+                'scheduler': None}
+    return SplaTAMConfig(
+        retain_graph=False, separate_LR=True, keyframe_use_ray_sample=False,
+        tracking_n_iters=40, mapping_n_iters=60, mapping_first_n_iters=60,
+        mapping_window_size=24, model=GaussianSplattingConfig(),
+        optimizers={'means3D': adam(0.0001, 1e-15),
+                    'rgb_colors': adam(0.0025, 1e-15),
+                    'unnorm_rotations': adam(0.001, 1e-15),
+                    'logit_opacities': adam(0.05, 1e-15),
+                    'log_scales': adam(0.001, 1e-15),
+                    'tracking_pose_r': adam(0.0004),
+                    'tracking_pose_t': adam(0.002)})
+
+
 algorithm_configs: Dict[str, object] = {'nice-slam': nice_slam_config,
                                         'co-slam': coslam_config,
-                                        'vox-fusion': voxfusion_config}
+                                        'vox-fusion': voxfusion_config,
+                                        'splaTAM': splatam_config}
 cadence: Dict[str, PipelineCadence] = {
     'nice-slam': PipelineCadence(),
     'co-slam': PipelineCadence(map_every=5, keyframe_every=5),
     'vox-fusion': PipelineCadence(map_every=1, keyframe_every=50,
                                   use_relative_pose=True,
-                                  init_pose_offset=10)}
+                                  init_pose_offset=10),
+    'splaTAM': PipelineCadence(map_every=1, keyframe_every=5,
+                               use_relative_pose=True)}
