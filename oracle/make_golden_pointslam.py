@@ -1,0 +1,146 @@
+"""TEST INFRASTRUCTURE ONLY.  Point-SLAM golden vectors: executes the
+REFERENCE's own ``ConvOnet2`` / ``NeuralPointCloud`` / ``POINT`` decoders
+(imported from /root/reference) on the CPU with oracle/faiss_standin.py (exact
+brute-force kNN) and stores: point-cloud growth over two frames, renders in
+the geometry and colour stages, tracking and mapping losses, all gradients,
+and every random draw (feature initialisation, empty-neighbour features) in
+tests/golden/pointslam_render.npz.
+
+    python oracle/make_golden_pointslam.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import faiss_standin  # noqa: E402
+import ref_harness  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def frame_rays(k, n, g):
+    """rays of a camera in front of a wall at z = -2 (OpenGL: looks down -z)"""
+    o = torch.tensor([0.1 * k, 0.0, 0.05 * k]).repeat(n, 1)
+    d = torch.stack([(torch.rand(n, generator=g) - 0.5) * 1.0,
+                     (torch.rand(n, generator=g) - 0.5) * 0.8,
+                     -torch.ones(n)], -1)
+    depth = (2.0 + 0.3 * d[:, 0] + 0.05 * k) * (1 + 0.01 * torch.randn(
+        n, generator=g))
+    color = torch.rand(n, 3, generator=g)
+    r_add = 0.02 + 0.06 * torch.rand(n, generator=g).double()
+    return o.float(), d.float(), depth.float(), color.float(), r_add
+
+
+def main():
+    ref_harness.install()
+    sys.modules['faiss'] = faiss_standin.module()
+    import slam.model_components.neural_point_cloud as npc_mod
+    npc_mod.faiss = sys.modules['faiss']
+    from slam.common.camera import Camera
+    from slam.models.conv_onet_pointslam import ConvOnet2, ConvOnet2Config
+    ConvOnet2.load_pretrain = lambda self: None  # LFS pointer only
+    torch.manual_seed(0)
+    model = ConvOnet2(ConvOnet2Config(mapping_pixels_based_on_color_grad=40),
+                      Camera(40., 40., 31.5, 23.5, 64, 48))
+    out = {}
+    for k, v in model.decoder.state_dict().items():
+        out[f'dec/{k}'] = v.numpy().copy()
+    # non-learnable Fourier matrix of the colour decoder is a plain attribute
+    out['dec_attr/color_decoder.embedder._B'] = \
+        model.decoder.color_decoder.embedder._B.numpy().copy()
+
+    draws = []
+    gen = torch.Generator().manual_seed(21)
+    real_normal = torch.Tensor.normal_
+
+    def rec_normal(self, mean=0, std=1, **k):
+        real_normal(self, mean=mean, std=std, generator=gen)
+        draws.append(self.clone())
+        return self
+
+    g = torch.Generator().manual_seed(4)
+    torch.Tensor.normal_ = rec_normal
+    try:
+        for k in range(2):
+            o, d, depth, color, r_add = frame_rays(k, 150, g)
+            o2, d2, depth2, color2, r_add2 = frame_rays(k, 40, g)
+            for name, v in (('o', o), ('d', d), ('depth', depth),
+                            ('color', color), ('r', r_add), ('o2', o2),
+                            ('d2', d2), ('depth2', depth2),
+                            ('color2', color2), ('r2', r_add2)):
+                out[f'add{k}/{name}'] = v.numpy()
+            model.model_update({
+                'batch_rays_o': o, 'batch_rays_d': d, 'batch_gt_depth': depth,
+                'batch_gt_color': color, 'batch_dynamic_r': r_add,
+                'batch_rays_o_grad': o2, 'batch_rays_d_grad': d2,
+                'batch_gt_depth_grad': depth2, 'batch_gt_color_grad': color2,
+                'batch_dynamic_r_grad': r_add2})
+            npc = model.neural_point_cloud
+            out[f'add{k}/cloud'] = np.array(npc._cloud_pos, np.float32)
+            out[f'add{k}/n_input'] = np.int64(len(npc._input_pos))
+        out['geo_feats'] = npc.geo_feats.detach().numpy().copy()
+        out['col_feats'] = npc.col_feats.detach().numpy().copy()
+        # frustum mask: a third of the points frozen
+        fm = torch.ones(npc.pts_num(), dtype=torch.bool)
+        fm[::3] = False
+        model.masked_indices = fm
+        out['frustum_mask'] = fm.numpy()
+        model.get_param_groups()  # applies the mask like the mapper does
+
+        o, d, depth, color, r_add = frame_rays(1, 90, g)
+        depth[5:12] = 0.0       # pixels without sensor depth
+        d[80:, 2] = 1.0         # rays that look away from every point
+        rq = 2 * r_add
+        out.update({'q/o': o.numpy(), 'q/d': d.numpy(),
+                    'q/depth': depth.numpy(), 'q/color': color.numpy(),
+                    'q/r': rq.numpy()})
+        for tag, stage, is_mapping in (('map_geo', 'geometry', True),
+                                       ('map_col', 'color', True),
+                                       ('track', 'color', False)):
+            for p in model.parameters():
+                p.grad = None
+            npc.geo_feats.grad = npc.col_feats.grad = None
+            ro = o.clone().requires_grad_(True)
+            rd = d.clone().requires_grad_(True)
+            n0 = len(draws)
+            inp = {'rays_o': ro, 'rays_d': rd, 'target_s': color,
+                   'target_d': depth.reshape(-1, 1), 'stage': stage,
+                   'batch_dynamic_r': rq}
+            res = model.get_outputs(inp)
+            ld = model.get_loss_dict(res, inp, is_mapping, stage)
+            sum(ld.values()).backward()
+            out[f'{tag}/n_draws'] = np.int64(len(draws) - n0)
+            for k2 in ('rgb', 'depth', 'uncertainty', 'valid_ray_mask'):
+                out[f'{tag}/{k2}'] = res[k2].detach().numpy()
+            for k2, v in ld.items():
+                out[f'{tag}/loss_{k2}'] = v.detach().numpy()
+            out[f'{tag}/g_rays_o'] = ro.grad.numpy()
+            out[f'{tag}/g_rays_d'] = rd.grad.numpy()
+            out[f'{tag}/g_geo'] = npc.geo_feats.grad.numpy().copy()
+            if npc.col_feats.grad is not None:
+                out[f'{tag}/g_col'] = npc.col_feats.grad.numpy().copy()
+            for k2, p in model.decoder.named_parameters():
+                if p.grad is not None:
+                    out[f'{tag}/g_dec/{k2}'] = p.grad.numpy().copy()
+    finally:
+        torch.Tensor.normal_ = real_normal
+    for i, dr in enumerate(draws):
+        out[f'draw{i}'] = dr.numpy()
+    out['n_draws'] = np.int64(len(draws))
+    path = os.path.join(GOLD, 'pointslam_render.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB; points',
+          out['add0/cloud'].shape[0], '->', out['add1/cloud'].shape[0],
+          'draws', len(draws), 'valid rays',
+          int(out['map_col/valid_ray_mask'].sum()),
+          {k2: float(v.detach()) for k2, v in ld.items()})
+
+
+if __name__ == '__main__':
+    main()

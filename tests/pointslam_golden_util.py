@@ -1,0 +1,122 @@
+"""Drives the host mirror of Point-SLAM's ConvOnet2 / NeuralPointCloud / POINT
+through the stages of tests/golden/pointslam_render.npz (made by
+oracle/make_golden_pointslam.py from the reference's own model)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden',
+                      'pointslam_render.npz')
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def run(g, device, knn_factory=None):
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.conv_onet_pointslam import (ConvOnet2,
+                                                             ConvOnet2Config)
+    T = lambda k: torch.from_numpy(g[k]).to(device)  # noqa: E731
+    model = ConvOnet2(ConvOnet2Config(mapping_pixels_based_on_color_grad=40),
+                      Camera(40., 40., 31.5, 23.5, 64, 48))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files
+          if k.startswith('dec/')}
+    model.decoder.load_state_dict(sd)
+    model.decoder.color_decoder.embedder._B = torch.from_numpy(
+        g['dec_attr/color_decoder.embedder._B'])
+    model = model.to(device)
+    model.knn_factory = knn_factory
+    draws = [torch.from_numpy(g[f'draw{i}'])
+             for i in range(int(g['n_draws']))]
+    it = iter(draws)
+
+    def feat_init(n, c):
+        t = next(it)
+        assert tuple(t.shape) == (n, c), (t.shape, n, c)
+        return t.clone()
+
+    def empty_feat(c, dev):
+        t = next(it)
+        assert tuple(t.shape) == (c, )
+        return t.to(dev)
+
+    model.decoder.geo_decoder.empty_feature_fn = empty_feat
+    model.decoder.color_decoder.empty_feature_fn = empty_feat
+    errs = {}
+    for k in range(2):
+        inp = {'batch_rays_o': T(f'add{k}/o'), 'batch_rays_d': T(f'add{k}/d'),
+               'batch_gt_depth': T(f'add{k}/depth'),
+               'batch_gt_color': T(f'add{k}/color'),
+               'batch_dynamic_r': T(f'add{k}/r'),
+               'batch_rays_o_grad': T(f'add{k}/o2'),
+               'batch_rays_d_grad': T(f'add{k}/d2'),
+               'batch_gt_depth_grad': T(f'add{k}/depth2'),
+               'batch_gt_color_grad': T(f'add{k}/color2'),
+               'batch_dynamic_r_grad': T(f'add{k}/r2')}
+        if model.neural_point_cloud is None:
+            # the cloud is created inside model_update: hook its initialiser
+            orig = model.model_update
+
+            def first(i, _orig=orig):
+                from xrdslam_amd.slam.model_components import \
+                    neural_point_cloud as npm
+                real = npm._feature_init
+                npm._feature_init = feat_init
+                try:
+                    _orig(i)
+                finally:
+                    npm._feature_init = real
+                model.neural_point_cloud.feature_init_fn = feat_init
+            first(inp)
+        else:
+            model.model_update(inp)
+        npc = model.neural_point_cloud
+        cloud = npc.cloud_tensor().cpu().numpy()
+        errs[f'add{k}/count'] = abs(cloud.shape[0] -
+                                    g[f'add{k}/cloud'].shape[0])
+        if errs[f'add{k}/count'] == 0:
+            errs[f'add{k}/cloud'] = rel_err(cloud, g[f'add{k}/cloud'])
+        errs[f'add{k}/n_input'] = abs(npc._input_pos.shape[0] -
+                                      int(g[f'add{k}/n_input']))
+    errs['geo_feats'] = rel_err(npc.geo_feats.detach().cpu(), g['geo_feats'])
+    errs['col_feats'] = rel_err(npc.col_feats.detach().cpu(), g['col_feats'])
+    model.masked_indices = T('frustum_mask')
+    model.get_param_groups()
+    for tag, stage, is_mapping in (('map_geo', 'geometry', True),
+                                   ('map_col', 'color', True),
+                                   ('track', 'color', False)):
+        for p in model.parameters():
+            p.grad = None
+        npc.geo_feats.grad = npc.col_feats.grad = None
+        ro = T('q/o').requires_grad_(True)
+        rd = T('q/d').requires_grad_(True)
+        inp = {'rays_o': ro, 'rays_d': rd, 'target_s': T('q/color'),
+               'target_d': T('q/depth').reshape(-1, 1), 'stage': stage,
+               'batch_dynamic_r': T('q/r')}
+        res = model.get_outputs(inp)
+        ld = model.get_loss_dict(res, inp, is_mapping, stage)
+        sum(ld.values()).backward()
+        errs[f'{tag}/valid_ray_mask'] = float(np.any(
+            res['valid_ray_mask'].cpu().numpy() != g[f'{tag}/valid_ray_mask']))
+        for k2 in ('rgb', 'depth', 'uncertainty'):
+            errs[f'{tag}/{k2}'] = rel_err(res[k2].detach().cpu(),
+                                          g[f'{tag}/{k2}'])
+        for k2, v in ld.items():
+            errs[f'{tag}/loss_{k2}'] = rel_err(v.detach().cpu(),
+                                               g[f'{tag}/loss_{k2}'])
+        errs[f'{tag}/g_rays_o'] = rel_err(ro.grad.cpu(), g[f'{tag}/g_rays_o'])
+        errs[f'{tag}/g_rays_d'] = rel_err(rd.grad.cpu(), g[f'{tag}/g_rays_d'])
+        errs[f'{tag}/g_geo'] = rel_err(npc.geo_feats.grad.cpu(),
+                                       g[f'{tag}/g_geo'])
+        if f'{tag}/g_col' in g.files:
+            errs[f'{tag}/g_col'] = rel_err(npc.col_feats.grad.cpu(),
+                                           g[f'{tag}/g_col'])
+        for k2, p in model.decoder.named_parameters():
+            key = f'{tag}/g_dec/{k2}'
+            if key in g.files:
+                errs[key] = rel_err(p.grad.cpu(), g[key])
+    return errs

@@ -1,0 +1,252 @@
+"""``PointSLAM`` algorithm plugin (reference: slam/algorithms/point_slam.py):
+before each mapping call neural points are added along sampled rays of the new
+frame (uniform pixels + strongest-colour-gradient pixels) with a per-pixel
+radius that shrinks where the image has texture; mapping optimises the
+features of the points inside the current frustum (geometry stage, then
+colour), tracking optimises the pose with uncertainty-normalised losses."""
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass, field
+from typing import Type
+
+import numpy as np
+import torch
+
+from ..common.common import (color_gradient_magnitude, get_rays, get_samples,
+                             get_samples_with_pixel_grad)
+from ..models.conv_onet_pointslam import ConvOnet2Config
+from .base_algorithm import Algorithm, AlgorithmConfig
+
+
+@dataclass
+class PointSLAMConfig(AlgorithmConfig):
+    _target: Type = field(default_factory=lambda: PointSLAM)
+    model: ConvOnet2Config = field(default_factory=ConvOnet2Config)
+    use_dynamic_radius: bool = True
+    pixels_adding: int = 6000
+    mapping_sample: int = 2048
+    min_sample_pixels: int = 100
+    tracking_sample: int = 1024
+    ray_batch_size: int = 3000
+    tracking_sample_with_color_grad: bool = False
+    tracking_Wedge: int = 100
+    tracking_Hedge: int = 100
+    mapping_geo_iter_ratio: float = 0.4
+    mapping_pixels_based_on_color_grad: int = 0
+    mapping_frustum_feature_selection: bool = True
+    mapping_frustum_edge: int = -4
+    mapping_BA: bool = False
+    model_encode_exposure: bool = False
+    pointcloud_radius_add_max: float = 0.08
+    pointcloud_radius_add_min: float = 0.02
+    pointcloud_radius_add: float = 0.04
+    pointcloud_radius_query: float = 0.08
+    pointcloud_radius_query_ratio: int = 2
+    pointcloud_color_grad_threshold: float = 0.15
+    clean_mesh: bool = True
+
+
+class PointSLAM(Algorithm):
+    config: PointSLAMConfig
+
+    def __init__(self, config: PointSLAMConfig, camera, device: str) -> None:
+        super().__init__(config, camera, device)
+        self.stage = 'color'
+        mc = config.model
+        mc.model_encode_exposure = config.model_encode_exposure
+        mc.use_dynamic_radius = config.use_dynamic_radius
+        mc.mapping_pixels_based_on_color_grad = \
+            config.mapping_pixels_based_on_color_grad
+        self.model = mc.setup(camera=camera)
+        self.model.to(device)
+        self.dynamic_r_query_allkeyframe = {}
+
+    @property
+    def _dev(self):
+        return self.model.device
+
+    # -- per-frame preparation ------------------------------------------------------
+    def pre_precessing(self, cur_frame, is_mapping):
+        cfg = self.config
+        depth_np, color_np = cur_frame.depth, cur_frame.rgb
+        c2w, idx = cur_frame.get_pose(), cur_frame.fid
+        r_add = None
+        if cfg.use_dynamic_radius:
+            r_add, r_query = self.cal_dynamic_radius(color_np)
+            self.dynamic_r_query_allkeyframe[np.array2string(
+                np.asarray(idx))] = r_query
+        if not is_mapping:
+            return
+        dev = self._dev
+        depth = torch.as_tensor(depth_np).to(dev)
+        n_add = cfg.pixels_adding
+        if idx == 0:
+            n_add = torch.clamp(
+                cfg.pixels_adding * ((depth.median() / 2.5)**2),
+                min=cfg.pixels_adding, max=cfg.pixels_adding * 3).int().item()
+        ro, rd, gd, gc, i, j = get_samples(
+            self.camera, n_add, c2w, depth_np, color_np, device=dev,
+            depth_filter=True, return_index=True, frame=cur_frame)
+        inp = {'batch_rays_o': ro, 'batch_rays_d': rd, 'batch_gt_depth': gd,
+               'batch_gt_color': gc,
+               'batch_dynamic_r': r_add[j, i] if r_add is not None else None}
+        if cfg.mapping_pixels_based_on_color_grad > 0:
+            ro2, rd2, gd2, gc2, i2, j2 = get_samples_with_pixel_grad(
+                self.camera, cfg.mapping_pixels_based_on_color_grad, c2w,
+                depth_np, color_np, device=dev, depth_filter=True,
+                return_index=True)
+            inp.update({'batch_rays_o_grad': ro2, 'batch_rays_d_grad': rd2,
+                        'batch_gt_depth_grad': gd2,
+                        'batch_gt_color_grad': gc2,
+                        'batch_dynamic_r_grad': r_add[j2, i2]
+                        if r_add is not None else None})
+        self.model.model_update(inp)
+        if cfg.mapping_frustum_feature_selection:
+            self.model.masked_indices = self.get_mask_from_c2w(c2w, depth)
+
+    def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
+        pass
+
+    def optimizer_config_update(self, max_iters, coarse=False):
+        cfg = self.config
+        self.bundle_adjust = len(self.keyframe_graph) > 4 and cfg.mapping_BA
+        for params in cfg.optimizers.values():
+            if params.get('scheduler') is not None:
+                params['optimizer'].lr = 1.0
+                params['scheduler'].max_steps = max_iters
+                params['scheduler'].geo_iter_ratio = cfg.mapping_geo_iter_ratio
+
+    # -- batches --------------------------------------------------------------------
+    def get_model_input(self, optimize_frames, is_mapping):
+        cfg, dev = self.config, self._dev
+        n, Hedge, Wedge = cfg.tracking_sample, cfg.tracking_Hedge, \
+            cfg.tracking_Wedge
+        if is_mapping:
+            n = int(np.maximum(cfg.mapping_sample // len(optimize_frames),
+                               cfg.min_sample_pixels))
+            Hedge = Wedge = 0
+        ro, rd, gd, gc, rq = [], [], [], [], []
+        for f in optimize_frames:
+            sampler = get_samples_with_pixel_grad \
+                if (not is_mapping and cfg.tracking_sample_with_color_grad) \
+                else functools.partial(get_samples, frame=f)
+            o, d, dep, col, i, j = sampler(
+                self.camera, n, f.get_pose(), f.depth, f.rgb, device=dev,
+                Hedge=Hedge, Wedge=Wedge, depth_filter=True,
+                return_index=True)
+            ro.append(o.float())
+            rd.append(d.float())
+            gd.append(dep.float())
+            gc.append(col.float())
+            if cfg.use_dynamic_radius:
+                rq.append(self.dynamic_r_query_allkeyframe[np.array2string(
+                    np.asarray(f.fid))][j, i])
+        ro, rd, gd, gc = (torch.cat(x) for x in (ro, rd, gd, gc))
+        rq = torch.cat(rq) if cfg.use_dynamic_radius else None
+        with torch.no_grad():
+            inside = gd <= torch.minimum(10 * gd.median(), 1.2 * torch.max(gd))
+        return {'rays_o': ro[inside], 'rays_d': rd[inside],
+                'target_s': gc[inside], 'target_d': gd[inside],
+                'batch_dynamic_r': rq[inside] if rq is not None else None,
+                'stage': self.stage}
+
+    def set_stage(self, is_mapping, step, n_iters):
+        if not is_mapping:
+            self.stage = 'color'
+        elif step <= int(n_iters * self.config.mapping_geo_iter_ratio):
+            self.stage = 'geometry'
+        else:
+            self.stage = 'color'
+
+    def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
+                 coarse=False):
+        self.set_stage(is_mapping, step, n_iters)
+        inp = self.get_model_input(optimize_frames, is_mapping)
+        out = self.model(inp)
+        losses = self.model.get_loss_dict(out, inp, is_mapping, self.stage)
+        return functools.reduce(torch.add, losses.values())
+
+    def render_img(self, c2w, gt_depth=None, idx=None):
+        with torch.no_grad():
+            dev, cfg = self._dev, self.config
+            rays_o, rays_d = get_rays(self.camera, c2w, device=dev)
+            rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+            rq = None
+            if cfg.use_dynamic_radius:
+                rq = self.dynamic_r_query_allkeyframe[np.array2string(
+                    np.asarray(idx))].reshape(-1, 1)
+            if gt_depth is not None:
+                gt_depth = torch.as_tensor(gt_depth).to(dev).reshape(-1)
+            depths, colors = [], []
+            bs = cfg.ray_batch_size
+            for s in range(0, rays_d.shape[0], bs):
+                out = self.model({
+                    'rays_o': rays_o[s:s + bs], 'rays_d': rays_d[s:s + bs],
+                    'target_s': None, 'stage': 'color',
+                    'target_d': None if gt_depth is None
+                    else gt_depth[s:s + bs],
+                    'batch_dynamic_r': None if rq is None else rq[s:s + bs]})
+                depths.append(out['depth'].double())
+                colors.append(out['rgb'])
+            H, W = self.camera.height, self.camera.width
+            return torch.cat(colors).reshape(H, W, 3).cpu().numpy(), \
+                torch.cat(depths).reshape(H, W).cpu().numpy()
+
+    # -- helpers ------------------------------------------------------------------
+    def cal_dynamic_radius(self, gt_color_np):
+        """per-pixel add / query radius from the colour-gradient magnitude:
+        flat regions get the largest radius, textured ones the smallest
+        (piece-wise linear in the clipped gradient, :326-354)"""
+        cfg = self.config
+        color = gt_color_np.cpu().numpy() if torch.is_tensor(gt_color_np) \
+            else np.asarray(gt_color_np)
+        mag = np.clip(color_gradient_magnitude(color), 0.0,
+                      cfg.pointcloud_color_grad_threshold)
+        xs = [0, 0.01, cfg.pointcloud_color_grad_threshold]
+        ys = [cfg.pointcloud_radius_add_max, cfg.pointcloud_radius_add_max,
+              cfg.pointcloud_radius_add_min]
+        r_add = np.interp(mag, xs, ys)
+        r_query = np.interp(mag, xs, [cfg.pointcloud_radius_query_ratio * y
+                                      for y in ys])
+        return torch.from_numpy(r_add).to(self._dev), \
+            torch.from_numpy(r_query).to(self._dev)
+
+    def get_mask_from_c2w(self, c2w, depth):
+        """bool per neural point: projects inside the image (+4 px) and not
+        behind the measured depth + 0.5 m (:356-420; bilinear depth lookup with
+        zero border in place of cv2.remap, evaluated on the device)"""
+        cam, dev = self.camera, self._dev
+        H, W, edge = cam.height, cam.width, self.config.mapping_frustum_edge
+        pts = self.model.neural_point_cloud.cloud_tensor(dev).double()
+        w2c = torch.linalg.inv(c2w.detach().to(dev).double())
+        pc = pts @ w2c[:3, :3].T + w2c[:3, 3]
+        u = cam.fx * (-pc[:, 0]) + cam.cx * pc[:, 2]
+        v = cam.fy * pc[:, 1] + cam.cy * pc[:, 2]
+        z = pc[:, 2] + 1e-5
+        u, v = (u / z).float(), (v / z).float()
+        img = depth.reshape(H, W).float()
+        u0, v0 = torch.floor(u), torch.floor(v)
+        fu, fv = u - u0, v - v0
+
+        def tap(uu, vv):
+            ok = (uu >= 0) & (uu <= W - 1) & (vv >= 0) & (vv <= H - 1)
+            val = img[vv.clamp(0, H - 1).long(), uu.clamp(0, W - 1).long()]
+            return torch.where(ok, val, torch.zeros_like(val))
+
+        d = tap(u0, v0) * (1 - fu) * (1 - fv) + tap(u0 + 1, v0) * fu * \
+            (1 - fv) + tap(u0, v0 + 1) * (1 - fu) * fv + \
+            tap(u0 + 1, v0 + 1) * fu * fv
+        mask = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge)
+        d = torch.where(d == 0, d.max(), d)
+        return mask & (-z >= 0) & (-z.float() <= d + 0.5)
+
+    def update_mesh(self):
+        pass
+
+    def get_cloud(self, c2w_np, gt_depth_np):
+        npc = self.model.neural_point_cloud
+        return np.array(npc.input_pos()), np.array(npc.input_rgb()) / 255.0
+
+    def get_mesh(self):
+        raise NotImplementedError('mesh output is out of the hot-path scope')

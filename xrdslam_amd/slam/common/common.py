@@ -76,6 +76,76 @@ def get_samples(camera, n, c2w, depth, color, device, Hedge=0, Wedge=0,
     return rays_o, rays_d, sd, sc
 
 
+def rgb2gray(image):
+    """luma of an RGB image (skimage.color.rgb2gray weights)"""
+    return image[..., 0] * 0.2125 + image[..., 1] * 0.7154 + \
+        image[..., 2] * 0.0721
+
+
+def _sobel(intensity, axis):
+    """skimage.filters.sobel_h (axis 0) / sobel_v (axis 1): difference
+    [1,0,-1] along ``axis``, smoothing [1,2,1]/4 across it, reflected borders.
+    Restated from the published definition (skimage is not installed here:
+    parity unpinned; it only steers WHICH pixels are sampled and the per-pixel
+    radii, not the render arithmetic)."""
+    a = np.asarray(intensity, dtype=np.float64)
+    p = np.pad(a, 1, mode='symmetric')
+    if axis == 0:
+        d = p[:-2, :] - p[2:, :]
+        return (d[:, :-2] + 2 * d[:, 1:-1] + d[:, 2:]) / 4.0
+    d = p[:, :-2] - p[:, 2:]
+    return (d[:-2, :] + 2 * d[1:-1, :] + d[2:, :]) / 4.0
+
+
+def color_gradient_magnitude(image):
+    gray = rgb2gray(np.asarray(image))
+    return np.sqrt(_sobel(gray, 1)**2 + _sobel(gray, 0)**2)
+
+
+def get_sample_uv_with_grad(H0, H1, W0, W1, n, image, ratio=15):
+    """n flat pixel indices drawn (without replacement) from the ratio*n
+    pixels with the largest colour gradient that fall inside the crop
+    (common.py:74-106)"""
+    image = np.asarray(image.cpu() if torch.is_tensor(image) else image)
+    grad_mag = color_gradient_magnitude(image)
+    size = (image.shape[0], image.shape[1])
+    top = np.argpartition(grad_mag, -ratio * n, axis=None)[-ratio * n:]
+    h, w = np.unravel_index(top, size)
+    m = (h >= H0) & (h < H1) & (w >= W0) & (w < W1)
+    h, w = h[m], w[m]
+    flat = np.ravel_multi_index(np.array((h, w)), size)
+    return flat[np.random.choice(range(0, h.shape[0]), size=n, replace=False)]
+
+
+def get_samples_with_pixel_grad(camera, n_color, c2w, depth, color, device,
+                                Hedge=0, Wedge=0, depth_filter=True,
+                                return_index=True, depth_limit=None):
+    """rays through the pixels with the strongest colour gradients
+    (common.py:230-285)"""
+    assert n_color > 0, 'invalid number of rays to sample.'
+    H, W = camera.height, camera.width
+    idx = np.union1d(get_sample_uv_with_grad(Hedge, H - Hedge, Wedge,
+                                             W - Wedge, n_color, color), [])
+    rows, cols = np.unravel_index(idx.astype(int), (H, W))
+    i = torch.from_numpy(cols).to(device).float()
+    j = torch.from_numpy(rows).to(device).float()
+    rays_o, rays_d = get_rays_from_uv(i, j, c2w.to(device), camera.fx,
+                                      camera.fy, camera.cx, camera.cy, device)
+    i, j = i.long(), j.long()
+    depth = torch.as_tensor(depth).to(device)
+    color = torch.as_tensor(color).to(device)
+    sd, sc = depth[j, i].reshape(-1), color[j, i].reshape(-1, 3)
+    if depth_filter:
+        m = sd > 0
+        if depth_limit is not None:
+            m = m & (sd < depth_limit)
+        rays_o, rays_d, sd, sc, i, j = rays_o[m], rays_d[m], sd[m], sc[m], \
+            i[m], j[m]
+    if return_index:
+        return rays_o, rays_d, sd, sc, i.to(torch.int64), j.to(torch.int64)
+    return rays_o, rays_d, sd, sc
+
+
 def get_rays(camera, c2w, device):
     """rays of the full image, [H,W,3] each (common.py:288-310)"""
     if isinstance(c2w, np.ndarray):

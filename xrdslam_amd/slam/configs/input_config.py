@@ -9,11 +9,14 @@ from typing import Dict
 
 from ..algorithms.coslam import CoSLAMConfig
 from ..algorithms.nice_slam import NiceSLAMConfig
+from ..algorithms.point_slam import PointSLAMConfig
 from ..algorithms.splatam import SplaTAMConfig
 from ..algorithms.voxfusion import VoxFusionConfig
 from ..engine.optimizers import AdamOptimizerConfig
-from ..engine.schedulers import LRconfig, NiceSLAMSchedulerConfig
+from ..engine.schedulers import (LRconfig, NiceSLAMSchedulerConfig,
+                                 PointSLAMSchedulerConfig)
 from ..models.conv_onet import ConvOnetConfig
+from ..models.conv_onet_pointslam import ConvOnet2Config
 from ..models.gaussian_splatting import GaussianSplattingConfig
 from ..models.joint_encoding import JointEncodingConfig
 from ..models.sparse_voxel import SparseVoxelConfig
@@ -27,6 +30,7 @@ class PipelineCadence:
     render_freq: int = 50
     use_relative_pose: bool = False
     init_pose_offset: int = 0
+    lazy_start: int = -1
 
 
 def _sched(**lr):
@@ -116,6 +120,34 @@ def voxfusion_config() -> VoxFusionConfig:
         })
 
 
+def pointslam_config() -> PointSLAMConfig:
+    """algorithm_configs['point-slam'] (input_config.py:298-375)"""
+    adam = AdamOptimizerConfig
+
+    def sched(a, b):
+        return {'optimizer': adam(),
+                'scheduler': PointSLAMSchedulerConfig(start_lr=a, end_lr=b)}
+    return PointSLAMConfig(
+        separate_LR=True, tracking_n_iters=40, mapping_n_iters=300,
+        mapping_first_n_iters=1500, mapping_window_size=12,
+        tracking_sample=1500, mapping_sample=5000, min_sample_pixels=40,
+        ray_batch_size=3000, tracking_Wedge=100, tracking_Hedge=100,
+        mapping_BA=False, mapping_frustum_feature_selection=True,
+        mapping_pixels_based_on_color_grad=1000,
+        model=ConvOnet2Config(cuda_id=0, points_batch_size=500000),
+        optimizers={
+            'decoder': sched(0.001, 0.005), 'geometry': sched(0.03, 0.005),
+            'color': sched(0.0, 0.005),
+            'tracking_pose_r': {'optimizer': adam(lr=0.002 * 0.2),
+                                'scheduler': None},
+            'tracking_pose_t': {'optimizer': adam(lr=0.002),
+                                'scheduler': None},
+            'mapping_pose_r': {'optimizer': adam(lr=0.0002),
+                               'scheduler': None},
+            'mapping_pose_t': {'optimizer': adam(lr=0.0002),
+                               'scheduler': None}})
+
+
 def splatam_config() -> SplaTAMConfig:
     """algorithm_configs['splaTAM'] (input_config.py:377-431)"""
     def adam(lr, eps=1e-8):
@@ -137,7 +169,8 @@ def splatam_config() -> SplaTAMConfig:
 algorithm_configs: Dict[str, object] = {'nice-slam': nice_slam_config,
                                         'co-slam': coslam_config,
                                         'vox-fusion': voxfusion_config,
-                                        'splaTAM': splatam_config}
+                                        'splaTAM': splatam_config,
+                                        'point-slam': pointslam_config}
 cadence: Dict[str, PipelineCadence] = {
     'nice-slam': PipelineCadence(),
     'co-slam': PipelineCadence(map_every=5, keyframe_every=5),
@@ -145,4 +178,6 @@ cadence: Dict[str, PipelineCadence] = {
                                   use_relative_pose=True,
                                   init_pose_offset=10),
     'splaTAM': PipelineCadence(map_every=1, keyframe_every=5,
-                               use_relative_pose=True)}
+                               use_relative_pose=True),
+    'point-slam': PipelineCadence(map_every=5, keyframe_every=20,
+                                  lazy_start=20)}

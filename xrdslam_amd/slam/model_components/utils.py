@@ -51,3 +51,23 @@ def get_sdf_loss(z_vals, target_d, predicted_sdf, truncation, loss_type=None,
                sdf_mask.sum()).sum()
         return fs_loss, sdf_loss, eik
     return fs_loss, sdf_loss
+
+
+def raw2outputs_nerf_color2(raw, z_vals, rays_d, device='cuda:0', coef=0.1):
+    """Point-SLAM compositing (reference: slam/model_components/utils.py:
+    247-294): occupancy alpha = sigmoid(coef * logit) (written back into
+    ``raw`` like the reference does), transmittance weights, colour and depth
+    NORMALISED by the weight sum, depth variance around the rendered depth."""
+    rgb = raw[..., :-1]
+    raw[..., -1] = torch.sigmoid(coef * raw[..., -1])
+    alpha = raw[..., -1]
+    ones = torch.ones((alpha.shape[0], 1), device=alpha.device).float()
+    weights = alpha.float() * torch.cumprod(
+        torch.cat([ones, (1. - alpha + 1e-10).float()], -1).float(),
+        dim=-1)[:, :-1]
+    wsum = torch.sum(weights, dim=-1).unsqueeze(-1) + 1e-10
+    rgb_map = torch.sum(weights[..., None] * rgb, -2) / wsum
+    depth_map = torch.sum(weights * z_vals, -1) / wsum.squeeze(-1)
+    tmp = z_vals - depth_map.unsqueeze(-1)
+    depth_var = torch.sum(weights * tmp * tmp, dim=1)
+    return depth_map, depth_var, rgb_map, weights
