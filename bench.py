@@ -436,10 +436,79 @@ def run_splatam(args, dev):
         'roofline': None, 'cpu_baseline': None}
 
 
+class _NumpyImages:
+    """synthetic sequence handing out numpy images (Point-SLAM derives its
+    per-pixel radii from a Sobel filter on the host, like the reference)"""
+
+    def __init__(self, data):
+        self.data = data
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, i):
+        d = dict(self.data[i])
+        for k in ('rgb', 'depth'):
+            if torch.is_tensor(d[k]):
+                d[k] = d[k].cpu().numpy()
+        return d
+
+
+def run_pointslam(args, dev):
+    """Point-SLAM frame loop: 40 tracking it x 1500 rays per frame, every 5th
+    frame (every frame for the first 20) 300 mapping it x 5000 rays, 5 samples
+    per ray, 8-NN feature interpolation from the neural point cloud.  Random-
+    initialised decoders (the pretrained checkpoint is not available offline).
+    Functional end-to-end path on the HIP grid kNN; no roofline object yet."""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import (cadence,
+                                                       pointslam_config)
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cam = Camera(**CAM)
+    cfg = pointslam_config()
+    if args.first_iters is not None:
+        cfg.mapping_first_n_iters = args.first_iters
+    algo = cfg.setup(camera=cam, device=str(dev))
+    data = _NumpyImages(SyntheticRoom(
+        CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,
+        cy=cam.cy, n_frames=max(args.warmup + args.steps + 1, 200),
+        device=dev))
+    cad = cadence['point-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          lazy_start=cad.lazy_start, pose_device=str(dev))
+    for k in range(1 + args.warmup):
+        slam.step(k)
+    slam.t_track = slam.t_map = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
+        slam.step(k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return {
+        'metric': 'tracking+mapping FPS @640x480',
+        'value': args.steps / elapsed, 'unit': 'frames/s',
+        'ms_per_step': elapsed / args.steps * 1e3, 'dtype': 'f32',
+        'config': {
+            'workload': 'Point-SLAM 640x480 synthetic RGB-D: 40 tracking it x '
+                        '1500 rays + 300 mapping it x 5000 rays (every frame '
+                        'during the first 20, then every 5th), 5 samples/ray',
+            'track_ms_per_frame': slam.t_track / args.steps * 1e3,
+            'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+            'ate_rmse_m': slam.ate_rmse(),
+            'neural_points': int(algo.model.neural_point_cloud.pts_num())},
+        'roofline': None, 'cpu_baseline': None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--algo', default='nice-slam',
-                    choices=['nice-slam', 'co-slam', 'vox-fusion', 'splaTAM'])
+                    choices=['nice-slam', 'co-slam', 'vox-fusion', 'splaTAM',
+                             'point-slam'])
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
@@ -468,12 +537,13 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=dev)
 
-    if args.algo in ('co-slam', 'vox-fusion', 'splaTAM'):
+    if args.algo in ('co-slam', 'vox-fusion', 'splaTAM', 'point-slam'):
         if world > 1:
             raise SystemExit(f'--algo {args.algo} runs on one GPU this round')
         res = run_coslam(args, dev, not args.no_cpu_baseline) \
             if args.algo == 'co-slam' else run_voxfusion(args, dev) \
-            if args.algo == 'vox-fusion' else run_splatam(args, dev)
+            if args.algo == 'vox-fusion' else run_splatam(args, dev) \
+            if args.algo == 'splaTAM' else run_pointslam(args, dev)
         res.update({'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
                     'higher_is_better': True, 'scaling': 'weak',
                     'vs_baseline': None, 'data': 'synthetic'})
