@@ -93,6 +93,12 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
                         double* depth, double* var, float* rgb, float* raw_out,
                         xrd_stream_t stream);
 
+/* stage COARSE with a grid gradient: optional workspace of private replicas of
+ * the coarse-grid gradient (the coarse grid has ~1e3 cells and every ray starts
+ * in the camera's cell: blocks scatter into 32 replicas that are summed into
+ * g_grid[0] afterwards).  The buffer must be ZERO on entry and is left zero.
+ * Pass it as `workspace`; NULL = scatter straight into g_grid[0]. */
+int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):
  *   g_rays_o, g_rays_d [n,3] f32 (overwritten);

@@ -49,6 +49,7 @@ _SIGS = {
     'xrd_nice_render_fwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
+    'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                       C.POINTER(vp * 4), C.POINTER(vp * 4), vp,

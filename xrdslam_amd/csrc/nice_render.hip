@@ -1174,6 +1174,25 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
 // composite backward from the saved raw is recomputed, it is cheap).  Keeping
 // a single decoder per kernel keeps the register footprint below the spill
 // threshold (a fused three-decoder backward needed > 512 VGPRs).
+constexpr int kCoarseRep = 32;  // replicas of the coarse-grid gradient
+
+// grad += sum of the replicas; the replicas are left zeroed for the next call
+__global__ __launch_bounds__(256) void coarse_rep_reduce_kernel(
+    float* __restrict__ rep, int64_t n, float* __restrict__ grad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < kCoarseRep; ++r) {
+    const float v = rep[(size_t)r * n + i];
+    if (v != 0.f) {
+      s += v;
+      rep[(size_t)r * n + i] = 0.f;
+    }
+  }
+  if (s != 0.f) grad[i] += s;
+}
+
 template <int DEC, int NT, bool NEED_DP, bool NEED_DW>
 __global__ __launch_bounds__(RPBB* NT * 64, XRD_BWD_WAVES) void nice_bwd_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
@@ -1289,7 +1308,14 @@ __global__ __launch_bounds__(RPBB* NT * 64, XRD_BWD_WAVES) void nice_bwd_kernel(
         noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
         tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[0], tr, q, gc[0], gp64);
-        grid_scatter(gg_coarse, sc.gmask[0], tr, lane, gc[0], SL);
+        // coarse grid: ~1.3e3 cells and every ray starts in the camera's
+        // cell, so the atomics of 1000 rays serialise on a few lines; blocks
+        // spread over kCoarseRep private replicas (ws), summed afterwards
+        float* ggc = gg_coarse;
+        if (ws != nullptr && gg_coarse != nullptr)
+          ggc = ws + (size_t)(blockIdx.x & (kCoarseRep - 1)) *
+                         ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
+        grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
       }
       if (DEC == XRD_DEC_MIDDLE || DEC == XRD_DEC_FINE) {
         f32x4 c_m[1][2];
@@ -1491,6 +1517,12 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
   return check_launch("xrd_nice_render_fwd");
 }
 
+int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene) {
+  if (scene == nullptr) return -1;
+  return (int64_t)kCoarseRep * scene->gdim[0] * scene->gdim[1] *
+         scene->gdim[2] * 32;
+}
+
 int64_t xrd_nice_bwd_ws_floats(int n_rays) {
   // staging arrays for n_rays * 48 points + the per-block partial gradients
   return (int64_t)n_rays * 48 * kDwFloatsPerPoint +
@@ -1631,6 +1663,13 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
                     dmax, raw, g_depth, g_var, g_rgb, g_rays_o, g_rays_d, gg,
                     ws, nb, st);
   if (rc != XRD_OK) return rc;
+  if (stage == XRD_STAGE_COARSE && ws != nullptr && gg[0] != nullptr) {
+    const int64_t ne = (int64_t)scene->gdim[0] * scene->gdim[1] *
+                       scene->gdim[2] * 32;
+    hipLaunchKernelGGL(coarse_rep_reduce_kernel, dim3((unsigned)((ne + 255) / 256)),
+                       dim3(256), 0, st, ws, ne, gg[0]);
+    return check_launch("coarse_rep_reduce_kernel");
+  }
   if (dw) {
     DwSave W = {};
     const int64_t Pn = (int64_t)n_rays * (nt * 16);

@@ -281,10 +281,18 @@ class _NiceRenderFn(torch.autograd.Function):
             ws = torch.empty(lib.xrd_nice_bwd_ws_floats(n),
                              dtype=torch.float32, device=dev)
             gdec[3] = g_flat.data_ptr()
+        cs = scene.c_struct()
+        if stage == 'coarse' and ctx.grid_grads and gg[0]:
+            # zero-initialised once, kept zero by the call (static pointer:
+            # replayable from a hipGraph)
+            ws = getattr(scene, '_coarse_ws', None)
+            need = lib.xrd_nice_coarse_ws_floats(C.byref(cs))
+            if ws is None or ws.numel() != need or ws.device != dev:
+                ws = scene._coarse_ws = torch.zeros(
+                    need, dtype=torch.float32, device=dev)
         gdp = g_depth.double().contiguous() if g_depth is not None else None
         gvr = g_var.double().contiguous() if g_var is not None else None
         grg = g_rgb.float().contiguous() if g_rgb is not None else None
-        cs = scene.c_struct()
         with _Timed(('nice_bwd', stage, n, bool(need_rays), bool(need_dec),
                      bool(ctx.grid_grads))):
             _lib.check(lib.xrd_nice_render_bwd(
