@@ -1,10 +1,15 @@
-"""``Model`` base class — the plugin contract of slam/models/base_model.py:23-70:
-``populate_modules``, ``forward = get_outputs(input: dict) -> dict``,
-``get_loss_dict(outputs, inputs, is_mapping, stage)``,
-``get_param_groups() -> Dict[str, List[Parameter]]``."""
+"""Plugin contract of a SLAM model (what slam/models/base_model.py:23-70 asks
+of its subclasses):
+
+* ``populate_modules()``  build sub-modules (called once from ``__init__``)
+* ``get_outputs(input: dict) -> dict``  the forward pass (``forward`` calls it)
+* ``get_loss_dict(outputs, inputs, is_mapping, stage) -> dict of tensors``
+* ``get_param_groups() -> {group name: [Parameter, ...]}`` for ``Optimizers``
+
+``device`` is wherever the (empty) indicator parameter lives, so
+``model.to(dev)`` moves it."""
 from __future__ import annotations
 
-from abc import abstractmethod
 from dataclasses import dataclass, field
 from typing import Dict, List, Type, Union
 
@@ -13,6 +18,8 @@ from torch import nn
 from torch.nn import Parameter
 
 from ..configs.base_config import InstantiateConfig
+
+TensorDict = Dict[str, Union[torch.Tensor, List]]
 
 
 @dataclass
@@ -24,31 +31,30 @@ class Model(nn.Module):
     config: ModelConfig
 
     def __init__(self, config, camera, bounding_box=None, **kwargs) -> None:
-        super().__init__()
-        self.config, self.camera = config, camera
-        self.bounding_box, self.kwargs = bounding_box, kwargs
+        nn.Module.__init__(self)
+        self.kwargs = kwargs
+        self.camera, self.bounding_box = camera, bounding_box
+        self.config = config
         self.populate_modules()
+
+    def populate_modules(self):
+        # subclasses extend this; the indicator parameter tracks the device
+        self.device_indicator_param = nn.Parameter(torch.empty(0))
 
     @property
     def device(self):
         return self.device_indicator_param.device
 
-    @abstractmethod
-    def populate_modules(self):
-        self.device_indicator_param = nn.Parameter(torch.empty(0))
-
-    def forward(self, input) -> Dict[str, Union[torch.Tensor, List]]:
+    def forward(self, input) -> TensorDict:
         return self.get_outputs(input)
 
-    @abstractmethod
+    # -- to be provided by the algorithm's model --------------------------------
+    def get_outputs(self, input) -> TensorDict:
+        raise NotImplementedError
+
     def get_loss_dict(self, outputs, inputs, is_mapping,
                       stage=None) -> Dict[str, torch.Tensor]:
-        pass
+        raise NotImplementedError
 
-    @abstractmethod
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
-        pass
-
-    @abstractmethod
-    def get_outputs(self, input) -> Dict[str, Union[torch.Tensor, List]]:
-        pass
+        raise NotImplementedError
