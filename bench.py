@@ -231,8 +231,11 @@ def co_cpu_baseline(threads):
                        f'track={t_track:.3f} map={t_map:.3f}')}
 
 
-def run_coslam(args, dev, with_cpu):
-    """Co-SLAM frame loop on one GPU -> result object"""
+def run_coslam(args, dev, with_cpu, world=1):
+    """Co-SLAM frame loop -> result object.  world > 1: tracking replicated
+    (shared RNG stream, pose broadcast), the mapping batch sliced over ranks,
+    loss normalisers made batch-global by an all-reduce of seven sums, one
+    all-reduce (SUM) of hash-table / decoder / pose gradients per step"""
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.engine import coslam as ec
     from xrdslam_amd.slam.common.camera import Camera
@@ -246,6 +249,9 @@ def run_coslam(args, dev, with_cpu):
     cam = Camera(**CAM)
     algo = cfg.setup(camera=cam, device=str(dev))
     algo.use_graphs = not args.no_graphs
+    if world > 1:
+        from xrdslam_amd.engine import dist as xdist
+        xdist.state.setup(dev, seed=0)
     data = SyntheticRoom(CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx,
                          fy=cam.fy, cx=cam.cx, cy=cam.cy,
                          n_frames=max(args.warmup + args.steps + 1, 200),
@@ -258,12 +264,21 @@ def run_coslam(args, dev, with_cpu):
         slam.step(k)
     ec.PROFILE = {}
     slam.t_track = slam.t_map = 0.0
+    import torch.distributed as tdist
+    if world > 1:
+        tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
         slam.step(k)
+    if world > 1:
+        tdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
     prof, ec.PROFILE = ec.PROFILE, None
     stats = []
     for key, evs in prof.items():
@@ -538,16 +553,22 @@ def main():
                                 device_id=dev)
 
     if args.algo in ('co-slam', 'vox-fusion', 'splaTAM', 'point-slam'):
-        if world > 1:
+        if world > 1 and args.algo != 'co-slam':
             raise SystemExit(f'--algo {args.algo} runs on one GPU this round')
-        res = run_coslam(args, dev, not args.no_cpu_baseline) \
+        res = run_coslam(args, dev, not args.no_cpu_baseline and rank == 0,
+                         world) \
             if args.algo == 'co-slam' else run_voxfusion(args, dev) \
             if args.algo == 'vox-fusion' else run_splatam(args, dev) \
             if args.algo == 'splaTAM' else run_pointslam(args, dev)
-        res.update({'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-                    'higher_is_better': True, 'scaling': 'weak',
+        res.update({'n_gpus': world, 'steps': args.steps,
+                    'warmup': args.warmup, 'higher_is_better': True,
+                    'scaling': 'strong' if world > 1 else 'weak',
                     'vs_baseline': None, 'data': 'synthetic'})
-        print(json.dumps(res), flush=True)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     from xrdslam_amd.data.synthetic import SyntheticRoom

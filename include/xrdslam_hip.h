@@ -477,6 +477,28 @@ int xrd_coslam_loss(int n_rays, int n_samples, float w_rgb, float w_depth,
                     const float* raw, const float* target_d,
                     const float* target_rgb, float* loss5, float* g_maps,
                     float* g_raw, float* workspace, xrd_stream_t stream);
+/* The same in two steps, for a batch SHARDED over ranks (multi-GPU mapping):
+ * stats[n,8] per ray = {n_fs, n_sdf, S_fs, S_sdf, valid, depth err^2, rgb
+ * err^2, w}; the caller sums columns 0..6 over its rays, all-reduces the seven
+ * sums over ranks and hands them in as totals7 (device, float64) with the
+ * global ray count: every normaliser and the batch-global balancing weights
+ * are then those of the whole batch, so the all-reduced gradient equals the
+ * single-GPU one.  totals7 == NULL: this rank's rays are the whole batch. */
+int xrd_coslam_loss_stats(int n_rays, int n_samples, float trunc,
+                          float depth_trunc, float rgb_missing,
+                          const float* maps, const float* z_vals,
+                          const float* raw, const float* target_d,
+                          const float* target_rgb, float* stats,
+                          xrd_stream_t stream);
+int xrd_coslam_loss_grads(int n_rays, int n_samples, float w_rgb, float w_depth,
+                          float w_sdf, float w_fs, float trunc,
+                          float depth_trunc, float rgb_missing,
+                          const float* maps, const float* z_vals,
+                          const float* raw, const float* target_d,
+                          const float* target_rgb, const float* stats,
+                          const double* totals7, int64_t n_rays_total,
+                          float* loss5, float* g_maps, float* g_raw,
+                          xrd_stream_t stream);
 
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */

@@ -82,6 +82,62 @@ def test_fused_tracking_iteration_matches_generic_hooks():
         assert (a - b).abs().max() < 2e-4 * b.abs().max()
 
 
+def test_sharded_loss_kernels_equal_the_unsharded_call():
+    """xrd_coslam_loss_stats + xrd_coslam_loss_grads with all-reduced totals
+    (multi-GPU mapping) on two halves of a batch = xrd_coslam_loss on the whole
+    batch: same loss terms, same gradients for every ray"""
+    from xrdslam_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    n, S = 301, 43
+    dev = 'cuda:0'
+    maps = torch.rand(n, 8, generator=g).to(dev)
+    z = torch.sort(torch.rand(n, S, generator=g) * 4, dim=1).values.to(dev)
+    raw = torch.randn(n, S, 4, generator=g).to(dev)
+    td = (1.0 + 2 * torch.rand(n, generator=g))
+    td[::9] = 0.0
+    td = td.to(dev)
+    tc = torch.rand(n, 3, generator=g).to(dev)
+    cfg = (5.0, 0.1, 1000.0, 10.0, 0.1, 100.0, 0.05)
+    st = _lib.stream_ptr(torch.device(dev))
+    P = _lib.ptr
+
+    def full():
+        l5 = torch.empty(5, device=dev)
+        gm, gr = torch.empty(n, 8, device=dev), torch.empty(n, S, 4, device=dev)
+        ws = torch.empty(n * 8, device=dev)
+        _lib.check(lib.xrd_coslam_loss(n, S, *cfg, P(maps), P(z), P(raw),
+                                       P(td), P(tc), P(l5), P(gm), P(gr),
+                                       P(ws), st), 'loss')
+        return l5, gm, gr
+
+    l5, gm, gr = full()
+    cut = 140
+    parts = [(0, cut), (cut, n)]
+    stats = []
+    for lo, hi in parts:
+        s_ = torch.empty(hi - lo, 8, device=dev)
+        _lib.check(lib.xrd_coslam_loss_stats(
+            hi - lo, S, *cfg[4:], P(maps[lo:hi].contiguous()),
+            P(z[lo:hi].contiguous()), P(raw[lo:hi].contiguous()),
+            P(td[lo:hi].contiguous()), P(tc[lo:hi].contiguous()), P(s_), st),
+            'stats')
+        stats.append(s_)
+    totals = sum(s_[:, :7].double().sum(0) for s_ in stats).contiguous()
+    for (lo, hi), s_ in zip(parts, stats):
+        l5s = torch.empty(5, device=dev)
+        gms = torch.empty(hi - lo, 8, device=dev)
+        grs = torch.empty(hi - lo, S, 4, device=dev)
+        _lib.check(lib.xrd_coslam_loss_grads(
+            hi - lo, S, *cfg, P(maps[lo:hi].contiguous()),
+            P(z[lo:hi].contiguous()), P(raw[lo:hi].contiguous()),
+            P(td[lo:hi].contiguous()), P(tc[lo:hi].contiguous()), P(s_),
+            P(totals), n, P(l5s), P(gms), P(grs), st), 'grads')
+        assert torch.allclose(l5s, l5, rtol=1e-5)
+        assert torch.allclose(gms, gm[lo:hi], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(grs, gr[lo:hi], rtol=1e-5, atol=1e-9)
+
+
 def test_axis_angle_pose_kernel_matches_torch_formula():
     """xrd_pose_aa_fwd/bwd against the torch restatement of
     OptimizablePose.matrix (checked on the CPU against the per-frame module

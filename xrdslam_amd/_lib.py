@@ -119,6 +119,10 @@ _SIGS = {
     'xrd_pose_rays_bwd': (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp,
                                     vp, vp]),
     'xrd_coslam_loss': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 + [vp] * 10),
+    'xrd_coslam_loss_stats': (C.c_int, [C.c_int, C.c_int] + [f32] * 3 +
+                              [vp] * 7),
+    'xrd_coslam_loss_grads': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 +
+                              [vp] * 7 + [i64] + [vp] * 4),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

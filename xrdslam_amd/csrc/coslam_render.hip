@@ -797,13 +797,16 @@ __global__ __launch_bounds__(1024) void coslam_loss_grad_kernel(
     LossCfg L, int n, const float* __restrict__ maps,
     const float* __restrict__ z_vals, const float* __restrict__ raw,
     const float* __restrict__ tgt_d, const float* __restrict__ tgt_rgb,
-    const float* __restrict__ stats, float* __restrict__ loss_out,
+    const float* __restrict__ stats, const double* __restrict__ totals,
+    int64_t n_total, float* __restrict__ loss_out,
     float* __restrict__ g_maps, float* __restrict__ g_raw) {
   __shared__ double red[16][7];
   __shared__ double tot[7];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int r = tid; r < n; r += 1024) {
+  // totals != NULL: the batch is sharded over ranks and the caller has
+  // all-reduced the seven sums; normalisers use the GLOBAL ray count
+  for (int r = tid; totals == nullptr && r < n; r += 1024) {
     const float4 a = *reinterpret_cast<const float4*>(stats + (size_t)r * 8);
     const float4 b = *reinterpret_cast<const float4*>(stats + (size_t)r * 8 + 4);
     acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
@@ -818,16 +821,17 @@ __global__ __launch_bounds__(1024) void coslam_loss_grad_kernel(
   if (tid < 7) {
     double v = 0;
     for (int w = 0; w < 16; ++w) v += red[w][tid];
-    tot[tid] = v;
+    tot[tid] = totals != nullptr ? totals[tid] : v;
   }
   __syncthreads();
   const float n_fs = (float)tot[0], n_sdf = (float)tot[1];
   const float n_all = n_fs + n_sdf;
   const float fs_w = 1.f - n_fs / n_all, sdf_w = 1.f - n_sdf / n_all;
-  const float nS = (float)n * (float)L.S;
+  const float n_glob = (float)n_total;
+  const float nS = n_glob * (float)L.S;
   const float nv = fmaxf((float)tot[4], 1.f);
   if (blockIdx.x == 0 && tid == 0) {
-    const float l_rgb = (float)(tot[6] / (3.0 * n)) * L.w_rgb;
+    const float l_rgb = (float)(tot[6] / (3.0 * n_total)) * L.w_rgb;
     const float l_d = (float)(tot[5] / nv) * L.w_depth;
     const float l_sdf = (float)(tot[3] / nS) * sdf_w * L.w_sdf;
     const float l_fs = (float)(tot[2] / nS) * fs_w * L.w_fs;
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(1024) void coslam_loss_grad_kernel(
     const float* mp = maps + (size_t)ray * 8;
     const bool valid = d > 0.f && d < L.depth_trunc;
     const float w = valid ? 1.f : (L.rgb_missing != 0.f ? 1.f : 0.f);
-    const float k = L.w_rgb * 2.f * w * w / (3.f * (float)n);
+    const float k = L.w_rgb * 2.f * w * w / (3.f * n_glob);
     float* gm = g_maps + (size_t)ray * 8;
     *reinterpret_cast<float4*>(gm) = make_float4(
         k * (mp[0] - tgt_rgb[ray * 3]), k * (mp[1] - tgt_rgb[ray * 3 + 1]),
@@ -1015,26 +1019,70 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
   return rc;
 }
 
+static int coslam_loss_check(int n_rays, int n_samples, const void* a,
+                             const void* b, const void* c, const void* d,
+                             const void* e, const void* ws) {
+  if (n_rays < 1 || n_samples < 1 || n_samples > 64 || !a || !b || !c || !d ||
+      !e || !ws)
+    return XRD_ERR_ARG;
+  return XRD_OK;
+}
+
+int xrd_coslam_loss_stats(int n_rays, int n_samples, float trunc,
+                          float depth_trunc, float rgb_missing,
+                          const float* maps, const float* z_vals,
+                          const float* raw, const float* target_d,
+                          const float* target_rgb, float* stats,
+                          xrd_stream_t stream) {
+  int rc = coslam_loss_check(n_rays, n_samples, maps, z_vals, raw, target_d,
+                             target_rgb, stats);
+  if (rc != XRD_OK) return rc;
+  const LossCfg L{0.f, 0.f, 0.f, 0.f, trunc, depth_trunc, rgb_missing,
+                  n_samples};
+  hipLaunchKernelGGL(coslam_loss_stats_kernel, dim3((n_rays + 3) / 4), dim3(256),
+                     0, (hipStream_t)stream, L, n_rays, maps, z_vals, raw,
+                     target_d, target_rgb, stats);
+  return check_launch("xrd_coslam_loss_stats");
+}
+
+int xrd_coslam_loss_grads(int n_rays, int n_samples, float w_rgb, float w_depth,
+                          float w_sdf, float w_fs, float trunc,
+                          float depth_trunc, float rgb_missing,
+                          const float* maps, const float* z_vals,
+                          const float* raw, const float* target_d,
+                          const float* target_rgb, const float* stats,
+                          const double* totals7, int64_t n_rays_total,
+                          float* loss5, float* g_maps, float* g_raw,
+                          xrd_stream_t stream) {
+  int rc = coslam_loss_check(n_rays, n_samples, maps, z_vals, raw, target_d,
+                             target_rgb, stats);
+  if (rc != XRD_OK) return rc;
+  if (!loss5 || !g_maps || !g_raw) return XRD_ERR_ARG;
+  if (totals7 == nullptr) n_rays_total = n_rays;
+  if (n_rays_total < n_rays) return XRD_ERR_ARG;
+  const LossCfg L{w_rgb, w_depth, w_sdf, w_fs, trunc, depth_trunc, rgb_missing,
+                  n_samples};
+  hipLaunchKernelGGL(coslam_loss_grad_kernel, dim3((n_rays + 15) / 16),
+                     dim3(1024), 0, (hipStream_t)stream, L, n_rays, maps, z_vals,
+                     raw, target_d, target_rgb, stats, totals7, n_rays_total,
+                     loss5, g_maps, g_raw);
+  return check_launch("xrd_coslam_loss_grads");
+}
+
 int xrd_coslam_loss(int n_rays, int n_samples, float w_rgb, float w_depth,
                     float w_sdf, float w_fs, float trunc, float depth_trunc,
                     float rgb_missing, const float* maps, const float* z_vals,
                     const float* raw, const float* target_d,
                     const float* target_rgb, float* loss5, float* g_maps,
                     float* g_raw, float* workspace, xrd_stream_t stream) {
-  if (n_rays < 1 || n_samples < 1 || n_samples > 64 || !maps || !z_vals ||
-      !raw || !target_d || !target_rgb || !loss5 || !g_maps || !g_raw ||
-      !workspace)
-    return XRD_ERR_ARG;
-  const LossCfg L{w_rgb, w_depth, w_sdf, w_fs, trunc, depth_trunc, rgb_missing,
-                  n_samples};
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(coslam_loss_stats_kernel, dim3((n_rays + 3) / 4), dim3(256),
-                     0, st, L, n_rays, maps, z_vals, raw, target_d, target_rgb,
-                     workspace);
-  hipLaunchKernelGGL(coslam_loss_grad_kernel, dim3((n_rays + 15) / 16),
-                     dim3(1024), 0, st, L, n_rays, maps, z_vals, raw, target_d,
-                     target_rgb, workspace, loss5, g_maps, g_raw);
-  return check_launch("xrd_coslam_loss");
+  int rc = xrd_coslam_loss_stats(n_rays, n_samples, trunc, depth_trunc,
+                                 rgb_missing, maps, z_vals, raw, target_d,
+                                 target_rgb, workspace, stream);
+  if (rc != XRD_OK) return rc;
+  return xrd_coslam_loss_grads(n_rays, n_samples, w_rgb, w_depth, w_sdf, w_fs,
+                               trunc, depth_trunc, rgb_missing, maps, z_vals,
+                               raw, target_d, target_rgb, workspace, nullptr,
+                               n_rays, loss5, g_maps, g_raw, stream);
 }
 
 }  // extern "C"

@@ -212,10 +212,13 @@ def render(model, tables, rays_o, rays_d, target_d, rnd, train_map=True):
 
 class _CoslamLossFn(torch.autograd.Function):
     """total of the rgb / depth / sdf / free-space terms of
-    JointEncoding.get_loss_dict, two launches, gradients produced with it"""
+    JointEncoding.get_loss_dict, two launches, gradients produced with it.
+    ``sharded``: this rank holds a shard of the mapping batch — the seven
+    batch sums are all-reduced between the two launches so that normalisers
+    and the batch-global balancing weights are those of the whole batch."""
 
     @staticmethod
-    def forward(ctx, maps, z_vals, raw, target_d, target_rgb, cfgv):
+    def forward(ctx, maps, z_vals, raw, target_d, target_rgb, cfgv, sharded):
         lib = _lib.lib()
         dev = maps.device
         n, S = z_vals.shape
@@ -227,12 +230,26 @@ class _CoslamLossFn(torch.autograd.Function):
         loss5 = torch.empty(5, dtype=torch.float32, device=dev)
         g_maps = torch.empty(n, 8, dtype=torch.float32, device=dev)
         g_raw = torch.empty(n, S, 4, dtype=torch.float32, device=dev)
-        ws = torch.empty(n * 8, dtype=torch.float32, device=dev)
-        _lib.check(lib.xrd_coslam_loss(
-            n, S, *[float(v) for v in cfgv], _lib.ptr(m), _lib.ptr(z),
-            _lib.ptr(r), _lib.ptr(td), _lib.ptr(tc), _lib.ptr(loss5),
-            _lib.ptr(g_maps), _lib.ptr(g_raw), _lib.ptr(ws),
-            _lib.stream_ptr(dev)), 'xrd_coslam_loss')
+        stats = torch.empty(n, 8, dtype=torch.float32, device=dev)
+        w_rgb, w_d, w_sdf, w_fs, trunc, dtrunc, miss = [float(v) for v in cfgv]
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.xrd_coslam_loss_stats(
+            n, S, trunc, dtrunc, miss, _lib.ptr(m), _lib.ptr(z), _lib.ptr(r),
+            _lib.ptr(td), _lib.ptr(tc), _lib.ptr(stats), st),
+            'xrd_coslam_loss_stats')
+        totals, n_total = None, n
+        if sharded:
+            import torch.distributed as dist
+            t = torch.cat([stats[:, :7].double().sum(0),
+                           torch.tensor([float(n)], dtype=torch.float64,
+                                        device=dev)])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            totals, n_total = t[:7].contiguous(), int(round(float(t[7])))
+        _lib.check(lib.xrd_coslam_loss_grads(
+            n, S, w_rgb, w_d, w_sdf, w_fs, trunc, dtrunc, miss, _lib.ptr(m),
+            _lib.ptr(z), _lib.ptr(r), _lib.ptr(td), _lib.ptr(tc),
+            _lib.ptr(stats), _lib.ptr(totals), n_total, _lib.ptr(loss5),
+            _lib.ptr(g_maps), _lib.ptr(g_raw), st), 'xrd_coslam_loss_grads')
         ctx.save_for_backward(g_maps, g_raw)
         ctx.mark_non_differentiable(loss5)
         return loss5[0], loss5
@@ -240,15 +257,18 @@ class _CoslamLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g5):
         g_maps, g_raw = ctx.saved_tensors
-        return g * g_maps, None, g * g_raw, None, None, None
+        return g * g_maps, None, g * g_raw, None, None, None, None
 
 
-def loss(model, outputs, target_d, target_rgb):
-    """-> (total with autograd, loss5 = [total, rgb, depth, sdf, fs])"""
+def loss(model, outputs, target_d, target_rgb, sharded=False):
+    """-> (total with autograd, loss5 = [total, rgb, depth, sdf, fs]).  With
+    ``sharded`` every rank gets the GLOBAL loss value and the gradient of its
+    own rays; summing the gradients over ranks gives the single-GPU one."""
     cfg = model.config
     cfgv = (cfg.trainging_rgb_weight, cfg.trainging_depth_weight,
             cfg.trainging_sdf_weight, cfg.trainging_fs_weight,
             cfg.training_trunc * cfg.data_sc_factor, cfg.cam_depth_trunc,
             cfg.training_rgb_missing)
     return _CoslamLossFn.apply(outputs['_maps'], outputs['z_vals'],
-                               outputs['raw'], target_d, target_rgb, cfgv)
+                               outputs['raw'], target_d, target_rgb, cfgv,
+                               bool(sharded))

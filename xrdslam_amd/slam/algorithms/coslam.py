@@ -19,6 +19,7 @@ from typing import List, Type
 import numpy as np
 import torch
 
+from ...engine import dist as _dist
 from ..common.common import get_rays, get_samples
 from ..engine.optimizers import Optimizers
 from ..models.joint_encoding import JointEncodingConfig
@@ -281,9 +282,19 @@ class CoSLAM(Algorithm):
         ids.append(torch.full((n_cur, ), c2w.shape[0] - 1, dtype=torch.int64,
                               device=dev))
         rows, ids = torch.cat(rows, 0), torch.cat(ids, 0)
+        sharded = _dist.state.enabled
+        if sharded:
+            # every rank drew the SAME batch (shared RNG stream); it renders a
+            # contiguous 1/world slice of it.  Loss normalisers are made
+            # global in the loss (engine/coslam.py), gradients are summed in
+            # Optimizers.optimizer_step_all
+            n, W, r = rows.shape[0], _dist.state.world, _dist.state.rank
+            lo, hi = (n * r) // W, (n * (r + 1)) // W
+            rows, ids = rows[lo:hi].contiguous(), ids[lo:hi].contiguous()
         rays_o, rays_d = slam_ops.PoseRaysFn.apply(c2w, rows, ids)
         return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': rows[:, 3:6],
-                'target_d': rows[:, 6:7], 'first': K == 0}
+                'target_d': rows[:, 6:7], 'first': K == 0,
+                'sharded': sharded}
 
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):
@@ -295,6 +306,15 @@ class CoSLAM(Algorithm):
         fused = self.fused_iteration and on_gpu and \
             self.model._fused_tables(self.model.device) is not None
         self.model.fused_losses = fused
+        # multi-GPU mapping: per-rank jitter comes from the rank's own RNG
+        # stream so that the shared default stream (batch indices, tracking)
+        # stays in lock-step although shard sizes may differ by one ray
+        if is_mapping and _dist.state.enabled:
+            gen = _dist.state.shard_generator
+            self.model._rand = lambda shape, like: torch.rand(
+                shape, device=like.device, dtype=like.dtype, generator=gen)
+        elif '_rand' in self.model.__dict__:
+            del self.model._rand
         if fused and not is_mapping:
             inp = self._fused_track_input(optimize_frames[-1])
         elif fused and len(optimize_frames) == len(self.keyframe_graph) + 1:

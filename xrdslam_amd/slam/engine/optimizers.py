@@ -149,7 +149,15 @@ class Optimizers:
         from ...engine import dist as _dist
         if _dist.state.enabled and getattr(self, 'parameters', None) and \
                 getattr(self, 'allreduce', False):
-            _dist.allreduce_param_grads(self.parameters)
+            # only the groups that step now: gradients of an accumulating
+            # group (accum_step) stay local until its step, then their SUM is
+            # exchanged once (the all-reduce is linear)
+            stepping = {
+                n: p for n, p in self.parameters.items()
+                if n in self.optimizers and (
+                    self.config[n]['optimizer'].accum_step is None or
+                    (step + 1) % self.config[n]['optimizer'].accum_step == 0)}
+            _dist.allreduce_param_grads(stepping)
         for name, opt in self.optimizers.items():
             ocfg = self.config[name]['optimizer']
             if ocfg.max_norm is not None:

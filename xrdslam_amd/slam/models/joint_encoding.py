@@ -116,18 +116,33 @@ class JointEncoding(Model):
                       stage=None) -> Dict[str, torch.Tensor]:
         cfg = self.config
         target_d, target_rgb = inputs['target_d'], inputs['target_s']
+        from ...engine import dist as _dist
+        sharded = bool(inputs.get('sharded', False)) and _dist.state.enabled
+        # the smoothness term is evaluated identically on every rank (shared
+        # RNG stream): 1/world of it per rank sums to one copy
+        smooth_scale = 1.0 / _dist.state.world if sharded else 1.0
         if '_maps' in outputs and getattr(self, 'fused_losses', False):
             # fused renderer output + fused loss: the four data terms come
             # as ONE differentiable total ('data_loss'); the individual terms
             # are kept (detached) in self.last_loss_terms
             from ...engine import coslam as ec
-            total, l5 = ec.loss(self, outputs, target_d, target_rgb)
+            total, l5 = ec.loss(self, outputs, target_d, target_rgb,
+                                sharded=sharded)
             self.last_loss_terms = l5
             losses = {'data_loss': total}
             if is_mapping and not inputs['first']:
                 losses['smooth_loss'] = self.smoothness(
                     cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
-                    cfg.trainging_smooth_margin) * cfg.trainging_smooth_weight
+                    cfg.trainging_smooth_margin) * \
+                    (cfg.trainging_smooth_weight * smooth_scale)
+            return losses
+        if sharded:
+            losses = self._sharded_data_losses(outputs, inputs)
+            if is_mapping and not inputs['first']:
+                losses['smooth_loss'] = self.smoothness(
+                    cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
+                    cfg.trainging_smooth_margin) * \
+                    (cfg.trainging_smooth_weight * smooth_scale)
             return losses
         td = target_d.squeeze()
         valid = (td > 0.) * (td < cfg.cam_depth_trunc)
@@ -159,6 +174,43 @@ class JointEncoding(Model):
                 cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
                 cfg.trainging_smooth_margin) * cfg.trainging_smooth_weight
         return losses
+
+    def _sharded_data_losses(self, outputs, inputs):
+        """the four data terms for a SHARD of the mapping batch (multi-GPU):
+        local sums over this rank's rays divided by the batch-global
+        normalisers (ray / valid-depth / mask counts all-reduced first), so
+        that the per-rank losses add up to the single-GPU loss and the
+        all-reduced gradient equals the single-GPU gradient"""
+        import torch.distributed as dist
+        cfg = self.config
+        target_d, target_rgb = inputs['target_d'], inputs['target_s']
+        td = target_d.squeeze(-1)
+        valid = (td > 0.) & (td < cfg.cam_depth_trunc)
+        w = (valid | bool(cfg.training_rgb_missing)).to(target_rgb.dtype)[:, None]
+        rgb_sum = ((outputs['rgb'] * w - target_rgb * w)**2).sum()
+        depth_sum = torch.where(valid, (outputs['depth'] - td)**2,
+                                torch.zeros_like(td)).sum()
+        z, sdf = outputs['z_vals'], outputs['raw'][..., -1]
+        trunc = cfg.training_trunc * cfg.data_sc_factor
+        front = (z < (target_d - trunc)).to(z.dtype)
+        back = (z > (target_d + trunc)).to(z.dtype)
+        m = (1.0 - front) * (1.0 - back) * (target_d > 0.0).to(z.dtype)
+        fs_sum = ((sdf * front - front)**2).sum()
+        sdf_sum = (((z + sdf * trunc) * m - target_d * m)**2).sum()
+        counts = torch.stack([front.sum(), m.sum(), valid.sum().to(z.dtype),
+                              torch.tensor(float(td.shape[0]), device=z.device,
+                                           dtype=z.dtype)]).double()
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        n_fs, n_sdf, n_valid, n = [float(c) for c in counts]
+        fs_w = 1.0 - n_fs / (n_fs + n_sdf)
+        sdf_w = 1.0 - n_sdf / (n_fs + n_sdf)
+        S = z.shape[1]
+        return {
+            'rgb_loss': rgb_sum / (3.0 * n) * cfg.trainging_rgb_weight,
+            'depth_loss': depth_sum / max(n_valid, 1.0) *
+            cfg.trainging_depth_weight,
+            'sdf_loss': sdf_sum / (n * S) * sdf_w * cfg.trainging_sdf_weight,
+            'fs_loss': fs_sum / (n * S) * fs_w * cfg.trainging_fs_weight}
 
     def smoothness(self, sample_points=256, voxel_size=0.1, margin=0.05):
         """total variation of the hash features on a random lattice"""
