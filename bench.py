@@ -544,13 +544,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP engine has no CPU '
                          'fallback')
-    dev = torch.device(f'cuda:{local_rank}')
+    # functional test of the multi-process path on a box with ONE GPU:
+    # XRD_DIST_SAME_GPU=1 XRD_DIST_BACKEND=gloo puts every rank on cuda:0
+    same_gpu = os.environ.get('XRD_DIST_SAME_GPU') == '1'
+    backend = os.environ.get('XRD_DIST_BACKEND', 'nccl')
+    dev = torch.device('cuda:0' if same_gpu else f'cuda:{local_rank}')
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.algo in ('co-slam', 'vox-fusion', 'splaTAM', 'point-slam'):
         if world > 1 and args.algo != 'co-slam':
