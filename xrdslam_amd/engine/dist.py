@@ -57,11 +57,12 @@ def allreduce_bucket(tensors: List[torch.Tensor]) -> None:
         off += n
 
 
-def allreduce_param_grads(param_groups) -> None:
-    """gather the gradients the optimisers are about to consume: for grid
-    parameters only the selected cells (``_xrd_cells``), dense otherwise."""
-    if not state.enabled:
-        return
+def collect_grad_jobs(param_groups):
+    """what an exchange touches: (dense gradient tensors, [(cell-major view of
+    a grid gradient, selected cell ids)]).  For grid parameters only the
+    selected cells (``_xrd_cells``) travel.  The returned tensors alias the
+    gradients, so a job list collected in the iteration that a hipGraph is
+    captured from stays valid for its replays (static addresses)."""
     dense, cell_jobs = [], []
     for params in param_groups.values():
         for p in params:
@@ -72,12 +73,26 @@ def allreduce_param_grads(param_groups) -> None:
                     continue
                 g = p.grad.permute(0, 2, 3, 4, 1).reshape(-1, p.shape[1])
                 cells = p._xrd_cells
-                sel = g if cells is None else g[cells.long()]
-                cell_jobs.append((g, cells, sel))
-                dense.append(sel)
+                cell_jobs.append((g, None if cells is None else cells.long()))
             else:
                 dense.append(p.grad)
-    allreduce_bucket(dense)
-    for g, cells, sel in cell_jobs:
+    return dense, cell_jobs
+
+
+def run_grad_jobs(jobs) -> None:
+    """SUM all-reduce of one flat bucket holding every job's gradients"""
+    if not state.enabled:
+        return
+    dense, cell_jobs = jobs
+    sels = [g if cells is None else g[cells] for g, cells in cell_jobs]
+    allreduce_bucket(list(dense) + sels)
+    for (g, cells), sel in zip(cell_jobs, sels):
         if cells is not None:
-            g[cells.long()] = sel
+            g[cells] = sel
+
+
+def allreduce_param_grads(param_groups) -> None:
+    """exchange the gradients the optimisers are about to consume"""
+    if not state.enabled:
+        return
+    run_grad_jobs(collect_grad_jobs(param_groups))

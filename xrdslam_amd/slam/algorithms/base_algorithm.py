@@ -28,6 +28,7 @@ from typing import Any, Dict, Type
 
 import torch
 
+from ...engine import dist as _dist
 from ..common.common import keyframe_selection_overlap
 from ..configs.base_config import InstantiateConfig
 from ..engine.optimizers import OptimizerConfig, Optimizers
@@ -221,13 +222,12 @@ class Algorithm:
         return 0
 
     def _graphs_ok(self, optimizers, is_mapping):
-        from ...engine import dist as _dist
         if not self.use_graphs or not torch.cuda.is_available():
             return False
         if torch.device(self.device).type != 'cuda':
             return False
-        if is_mapping and _dist.state.enabled:
-            return False  # sharded mapping issues collectives: stay eager
+        # sharded mapping issues a collective per iteration: it is kept OUT of
+        # the graphs (two graphs around an eager all-reduce, optimize_update)
         for name in optimizers.optimizers:
             if self.config.optimizers[name]['optimizer'].accum_step is not None \
                     or self.config.optimizers[name]['optimizer'].max_norm \
@@ -239,7 +239,13 @@ class Algorithm:
         return not (self.config.retain_graph and is_mapping)
 
     def _iteration(self, optimizers, optimize_frames, is_mapping, step,
-                   n_iters, coarse, track):
+                   n_iters, coarse, track, part=None):
+        """one optimisation iteration.  ``part``: None = all of it; 'grad' =
+        up to and including backward / post_processing; 'step' = the optimiser
+        steps without the gradient exchange (multi-GPU split-graph mode)"""
+        if part == 'step':
+            optimizers.optimizer_step_all(step=step, exchange=False)
+            return
         optimizers.zero_grad_all()
         loss = self.get_loss(optimize_frames, is_mapping, step, n_iters,
                              coarse=coarse)
@@ -260,6 +266,8 @@ class Algorithm:
         loss.backward(retain_graph=(self.config.retain_graph and is_mapping))
         self.post_processing(step, is_mapping, optimizers.optimizers,
                              coarse=coarse)
+        if part == 'grad':
+            return
         optimizers.optimizer_step_all(step=step)
 
     # ---- persistent tracking graph ---------------------------------------
@@ -362,9 +370,46 @@ class Algorithm:
                     'valid': torch.zeros((), dtype=torch.bool, device=pdev)}
             graphed = self._graphs_ok(optimizers, is_mapping)
             self.fixed_shape_batches = graphed
+            # multi-GPU mapping: the per-iteration all-reduce stays eager
+            # between a "gradient" graph and a "step" graph
+            split = graphed and is_mapping and _dist.state.enabled
             seg_key, seg_iter, graph = None, 0, None
+            graph_b, jobs = None, None
+            args = (optimizers, optimize_frames, is_mapping)
             for step in range(n_iters):
-                if graphed:
+                if graphed and split:
+                    key = self.graph_segment_key(is_mapping, step, n_iters,
+                                                 coarse)
+                    if key != seg_key:
+                        seg_key, seg_iter, graph, graph_b = key, 0, None, None
+                    if seg_iter == 0:
+                        self._iteration(*args, step, n_iters, coarse, track)
+                    elif graph is None:
+                        graph = torch.cuda.CUDAGraph()
+                        # the per-rank ray sampling draws from the rank's own
+                        # generator: it has to be known to the graph
+                        gen = _dist.state.shard_generator
+                        if gen is not None and hasattr(
+                                graph, 'register_generator_state'):
+                            graph.register_generator_state(gen)
+                        with torch.cuda.graph(graph):
+                            self._iteration(*args, step, n_iters, coarse,
+                                            track, part='grad')
+                        graph.replay()
+                        jobs = _dist.collect_grad_jobs(
+                            optimizers.stepping_parameters(step))
+                        _dist.run_grad_jobs(jobs)
+                        graph_b = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph_b):
+                            self._iteration(*args, step, n_iters, coarse,
+                                            track, part='step')
+                        graph_b.replay()
+                    else:
+                        graph.replay()
+                        _dist.run_grad_jobs(jobs)
+                        graph_b.replay()
+                    seg_iter += 1
+                elif graphed:
                     key = self.graph_segment_key(is_mapping, step, n_iters,
                                                  coarse)
                     if key != seg_key:

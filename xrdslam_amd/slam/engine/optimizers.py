@@ -145,19 +145,22 @@ class Optimizers:
             if self.config[name]['optimizer'].accum_step is None:
                 opt.zero_grad(set_to_none=True)
 
-    def optimizer_step_all(self, step: int) -> None:
+    def stepping_parameters(self, step: int):
+        """parameter groups whose optimiser steps at ``step``: gradients of
+        an accumulating group (accum_step) stay local until its step, then
+        their SUM is exchanged once (the all-reduce is linear)"""
+        return {
+            n: p for n, p in getattr(self, 'parameters', {}).items()
+            if n in self.optimizers and (
+                self.config[n]['optimizer'].accum_step is None or
+                (step + 1) % self.config[n]['optimizer'].accum_step == 0)}
+
+    def optimizer_step_all(self, step: int, exchange: bool = True) -> None:
         from ...engine import dist as _dist
-        if _dist.state.enabled and getattr(self, 'parameters', None) and \
+        if exchange and _dist.state.enabled and \
+                getattr(self, 'parameters', None) and \
                 getattr(self, 'allreduce', False):
-            # only the groups that step now: gradients of an accumulating
-            # group (accum_step) stay local until its step, then their SUM is
-            # exchanged once (the all-reduce is linear)
-            stepping = {
-                n: p for n, p in self.parameters.items()
-                if n in self.optimizers and (
-                    self.config[n]['optimizer'].accum_step is None or
-                    (step + 1) % self.config[n]['optimizer'].accum_step == 0)}
-            _dist.allreduce_param_grads(stepping)
+            _dist.allreduce_param_grads(self.stepping_parameters(step))
         for name, opt in self.optimizers.items():
             ocfg = self.config[name]['optimizer']
             if ocfg.max_norm is not None:
