@@ -333,7 +333,37 @@ def run_coslam(args, dev, with_cpu, world=1):
         if with_cpu else None}
 
 
-def run_voxfusion(args, dev):
+def _timed_frames(slam, args, dev, world):
+    """untimed frame 0 + warm-up, then args.steps frames between barriers;
+    -> seconds (max over ranks)"""
+    import torch.distributed as tdist
+    for k in range(1 + args.warmup):
+        slam.step(k)
+    slam.t_track = slam.t_map = 0.0
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
+        slam.step(k)
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def _setup_dist(dev, world):
+    if world > 1:
+        from xrdslam_amd.engine import dist as xdist
+        xdist.state.setup(dev, seed=0)
+
+
+def run_voxfusion(args, dev, world=1):
     """Vox-Fusion frame loop (every frame tracked with 30 it x 1024 rays and
     mapped with 15 it x 1024 rays x <=6 frames; relative poses + 10 m offset).
     Functional end-to-end path on the HIP ray/voxel operators; the feature /
@@ -348,6 +378,7 @@ def run_voxfusion(args, dev):
     np.random.seed(0)
     cam = Camera(**CAM)
     algo = voxfusion_config().setup(camera=cam, device=str(dev))
+    _setup_dist(dev, world)
     data = SyntheticRoom(CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx,
                          fy=cam.fy, cx=cam.cx, cy=cam.cy,
                          n_frames=max(args.warmup + args.steps + 1, 200),
@@ -358,15 +389,7 @@ def run_voxfusion(args, dev):
                           pose_device=str(dev),
                           use_relative_pose=cad.use_relative_pose,
                           init_pose_offset=cad.init_pose_offset)
-    for k in range(1 + args.warmup):
-        slam.step(k)
-    slam.t_track = slam.t_map = 0.0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
-        slam.step(k)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = _timed_frames(slam, args, dev, world)
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -469,7 +492,7 @@ class _NumpyImages:
         return d
 
 
-def run_pointslam(args, dev):
+def run_pointslam(args, dev, world=1):
     """Point-SLAM frame loop: 40 tracking it x 1500 rays per frame, every 5th
     frame (every frame for the first 20) 300 mapping it x 5000 rays, 5 samples
     per ray, 8-NN feature interpolation from the neural point cloud.  Random-
@@ -487,6 +510,7 @@ def run_pointslam(args, dev):
     if args.first_iters is not None:
         cfg.mapping_first_n_iters = args.first_iters
     algo = cfg.setup(camera=cam, device=str(dev))
+    _setup_dist(dev, world)
     data = _NumpyImages(SyntheticRoom(
         CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,
         cy=cam.cy, n_frames=max(args.warmup + args.steps + 1, 200),
@@ -495,15 +519,7 @@ def run_pointslam(args, dev):
     slam = SequentialSLAM(algo, data, map_every=cad.map_every,
                           keyframe_every=cad.keyframe_every,
                           lazy_start=cad.lazy_start, pose_device=str(dev))
-    for k in range(1 + args.warmup):
-        slam.step(k)
-    slam.t_track = slam.t_map = 0.0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
-        slam.step(k)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = _timed_frames(slam, args, dev, world)
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -560,13 +576,13 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.algo in ('co-slam', 'vox-fusion', 'splaTAM', 'point-slam'):
-        if world > 1 and args.algo != 'co-slam':
-            raise SystemExit(f'--algo {args.algo} runs on one GPU this round')
+        if world > 1 and args.algo == 'splaTAM':
+            raise SystemExit('--algo splaTAM runs on one GPU this round')
         res = run_coslam(args, dev, not args.no_cpu_baseline and rank == 0,
                          world) \
-            if args.algo == 'co-slam' else run_voxfusion(args, dev) \
+            if args.algo == 'co-slam' else run_voxfusion(args, dev, world) \
             if args.algo == 'vox-fusion' else run_splatam(args, dev) \
-            if args.algo == 'splaTAM' else run_pointslam(args, dev)
+            if args.algo == 'splaTAM' else run_pointslam(args, dev, world)
         res.update({'n_gpus': world, 'steps': args.steps,
                     'warmup': args.warmup, 'higher_is_better': True,
                     'scaling': 'strong' if world > 1 else 'weak',

@@ -1,0 +1,99 @@
+"""world_size-2 gloo test of the sharded Vox-Fusion mapping loss on the CPU.
+The reference's inverse-CDF sampler is batch dependent (a ray can gain or lose
+its last sample with the batch's maximum hit count), so "same rays, different
+batch split" is not bit-comparable at the render level; what sharding must
+guarantee is the LOSS algebra: every rank takes half of the rays of one
+rendered batch (SparseVoxel mirror, C-oracle operators), evaluates the sharded
+loss (batch-global normalisers incl. the padded sample length) and all-reduces
+gradients — sum of losses and exchanged gradients must equal the unsharded
+ones."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
+sys.path.insert(0, HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup():
+    import grid_standin
+    import voxfusion_golden_util as vg
+    import xrdslam_amd.slam.model_components.voxel_helpers_voxfusion as vh
+    vh._ext = grid_standin.module()
+    g = np.load(vg.GOLDEN)
+    model = vg.build_model(g, 'cpu')
+    model.insert_points(torch.from_numpy(g['points']), dedup=False)
+    model.noise_fn = lambda shape, like: like.new_full(shape, 0.5)
+    batch = {k: torch.from_numpy(g[k]) for k in
+             ('rays_o', 'rays_d', 'target_s', 'target_d')}
+    return model, batch
+
+
+def _run(model, batch, idx, sharded):
+    for p in model.parameters():
+        p.grad = None
+    full = model.get_outputs(dict(batch))
+    rm = full['ray_mask']
+    hit_row = torch.cumsum(rm.long(), 0) - 1
+    rows = hit_row[idx][rm[idx]]
+    out = {'depth': full['depth'][idx], 'rgb': full['rgb'][idx],
+           'sdf': full['sdf'][rows], 'z_vals': full['z_vals'][rows],
+           'ray_mask': rm[idx]}
+    inp = {k: v[idx] for k, v in batch.items()}
+    inp['sharded'] = sharded
+    losses = model.get_loss_dict(out, inp, True, 0)
+    sum(losses.values()).backward()
+    grads = {'emb': model.embeddings.grad.clone(),
+             **{k: p.grad.clone() for k, p in model.decoder.named_parameters()}}
+    return {k: float(v.detach()) for k, v in losses.items()}, grads
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xrdslam_amd.engine import dist as xd
+    xd.state.setup('cpu', seed=1)
+    model, batch = _setup()
+    n = batch['rays_o'].shape[0]
+    idx = torch.arange(n)[rank::world]   # interleaved shards
+    losses, _ = _run(model, batch, idx, sharded=True)
+    xd.allreduce_param_grads({'embeddings': [model.embeddings],
+                              'decoder': list(model.decoder.parameters())})
+    grads = {'emb': model.embeddings.grad.clone(),
+             **{k: p.grad.clone() for k, p in model.decoder.named_parameters()}}
+    out[rank] = (grads, losses)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_voxfusion_mapping_equals_single_process():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    model, batch = _setup()
+    n = batch['rays_o'].shape[0]
+    full_losses, full = _run(model, batch, torch.arange(n), sharded=False)
+    for k, v in full_losses.items():
+        s = sum(out[r][1][k] for r in range(world))
+        assert abs(s - v) < 1e-5 * max(abs(v), 1e-6), (k, s, v)
+    for r in range(world):
+        for k, gfull in full.items():
+            g = out[r][0][k]
+            err = (g - gfull).abs().max() / gfull.abs().max().clamp(min=1e-30)
+            assert err < 1e-4, (r, k, float(err))

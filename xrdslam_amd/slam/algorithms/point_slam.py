@@ -13,6 +13,7 @@ from typing import Type
 import numpy as np
 import torch
 
+from ...engine import dist as _dist
 from ..common.common import (color_gradient_magnitude, get_rays, get_samples,
                              get_samples_with_pixel_grad)
 from ..models.conv_onet_pointslam import ConvOnet2Config
@@ -122,15 +123,23 @@ class PointSLAM(Algorithm):
         cfg, dev = self.config, self._dev
         n, Hedge, Wedge = cfg.tracking_sample, cfg.tracking_Hedge, \
             cfg.tracking_Wedge
+        gen = None
         if is_mapping:
             n = int(np.maximum(cfg.mapping_sample // len(optimize_frames),
                                cfg.min_sample_pixels))
             Hedge = Wedge = 0
+            if _dist.state.enabled:
+                # multi-GPU: the mapping losses are plain sums over rays
+                # (conv_onet_pointslam.py:190-204), so each rank renders
+                # 1/world of the rays from its own RNG stream and the
+                # gradients are summed (Optimizers.optimizer_step_all)
+                n = _dist.state.shard_count(n)
+                gen = _dist.state.shard_generator
         ro, rd, gd, gc, rq = [], [], [], [], []
         for f in optimize_frames:
             sampler = get_samples_with_pixel_grad \
                 if (not is_mapping and cfg.tracking_sample_with_color_grad) \
-                else functools.partial(get_samples, frame=f)
+                else functools.partial(get_samples, frame=f, generator=gen)
             o, d, dep, col, i, j = sampler(
                 self.camera, n, f.get_pose(), f.depth, f.rgb, device=dev,
                 Hedge=Hedge, Wedge=Wedge, depth_filter=True,

@@ -11,6 +11,7 @@ from typing import Type
 import numpy as np
 import torch
 
+from ...engine import dist as _dist
 from ..common.common import get_rays, get_samples
 from ..models.sparse_voxel import SparseVoxelConfig
 from .base_algorithm import Algorithm, AlgorithmConfig
@@ -53,16 +54,25 @@ class VoxFusion(Algorithm):
     def get_model_input(self, optimize_frames, is_mapping):
         cfg, dev = self.config, self.model.device
         n = cfg.mapping_sample if is_mapping else cfg.tracking_sample
+        # multi-GPU mapping: every rank draws 1/world of the rays from its own
+        # RNG stream; losses use batch-global normalisers, gradients are
+        # summed in Optimizers.optimizer_step_all
+        sharded = is_mapping and _dist.state.enabled
+        gen = _dist.state.shard_generator if sharded else None
+        if sharded:
+            n = _dist.state.shard_count(n)
         ro, rd, gd, gc = [], [], [], []
         for f in optimize_frames:
             o, d, dep, col = get_samples(self.camera, n, f.get_pose(), f.depth,
-                                         f.rgb, device=dev, frame=f)
+                                         f.rgb, device=dev, frame=f,
+                                         generator=gen)
             ro.append(o.float())
             rd.append(d.float())
             gd.append(dep.float())
             gc.append(col.float())
         return {'rays_o': torch.cat(ro), 'rays_d': torch.cat(rd),
-                'target_s': torch.cat(gc), 'target_d': torch.cat(gd)}
+                'target_s': torch.cat(gc), 'target_d': torch.cat(gd),
+                'sharded': sharded}
 
     def create_voxels(self, frame):
         """allocate the voxels seen by this frame (:96-107); the back

@@ -101,6 +101,9 @@ class SparseVoxel(Model):
         """L1 colour/depth on the rays that hit the octree, SDF + free-space
         terms on their samples (:103-143)"""
         cfg = self.config
+        from ...engine import dist as _dist
+        if inputs.get('sharded', False) and _dist.state.enabled:
+            return self._sharded_losses(outputs, inputs)
         ray_mask = outputs['ray_mask']
         target_d = inputs['target_d'][ray_mask]
         target_rgb = inputs['target_s'][ray_mask]
@@ -118,6 +121,50 @@ class SparseVoxel(Model):
                 'depth_loss': depth_loss * cfg.trainging_depth_weight,
                 'sdf_loss': sdf_loss * cfg.trainging_sdf_weight,
                 'fs_loss': fs_loss * cfg.trainging_fs_weight}
+
+    def _sharded_losses(self, outputs, inputs):
+        """the same four terms for a SHARD of the mapping rays (multi-GPU):
+        local sums divided by batch-global normalisers.  The reference's
+        SDF / free-space terms are means over the PADDED [rays, samples] array,
+        so the global denominator is (hit rays over all ranks) x (longest
+        sample row over all ranks); the balancing weights use global counts."""
+        import torch.distributed as dist
+        cfg = self.config
+        ray_mask = outputs['ray_mask']
+        target_d = inputs['target_d'][ray_mask]
+        target_rgb = inputs['target_s'][ray_mask]
+        td = target_d.squeeze(-1)
+        valid = (td > 0.01) & (td < cfg.max_dpeth)
+        w = valid.unsqueeze(-1).to(target_rgb.dtype)
+        rgb_sum = torch.abs(outputs['rgb'][ray_mask] * w - target_rgb * w).sum()
+        depth_sum = torch.where(
+            valid, torch.abs(outputs['depth'][ray_mask] - td),
+            torch.zeros_like(td)).sum()
+        z, sdf = outputs['z_vals'], outputs['sdf']
+        trunc = cfg.training_trunc * cfg.data_sc_factor
+        front = (z < (target_d - trunc)).to(z.dtype)
+        back = (z > (target_d + trunc)).to(z.dtype)
+        m = (1.0 - front) * (1.0 - back) * (target_d > 0.0).to(z.dtype)
+        fs_sum = ((sdf * front - front)**2).sum()
+        sdf_sum = (((z + sdf * trunc) * m - target_d * m)**2).sum()
+        counts = torch.stack([
+            front.sum(), m.sum(), valid.sum().to(z.dtype),
+            torch.tensor(float(td.shape[0]), device=z.device, dtype=z.dtype)
+        ]).double()
+        s_max = torch.tensor(float(z.shape[1]), device=z.device,
+                             dtype=torch.float64)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(s_max, op=dist.ReduceOp.MAX)
+        n_fs, n_sdf, n_valid, n_hit = [float(c) for c in counts]
+        fs_w = 1.0 - n_fs / (n_fs + n_sdf)
+        sdf_w = 1.0 - n_sdf / (n_fs + n_sdf)
+        denom = n_hit * float(s_max)
+        return {
+            'rgb_loss': rgb_sum / (3.0 * n_hit) * cfg.trainging_rgb_weight,
+            'depth_loss': depth_sum / max(n_valid, 1.0) *
+            cfg.trainging_depth_weight,
+            'sdf_loss': sdf_sum / denom * sdf_w * cfg.trainging_sdf_weight,
+            'fs_loss': fs_sum / denom * fs_w * cfg.trainging_fs_weight}
 
     # -- rendering --------------------------------------------------------------
     def render_rays(self, rays_o, rays_d, target_d=None, chunk_size=-1):
