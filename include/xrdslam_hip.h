@@ -500,6 +500,20 @@ int xrd_coslam_loss_grads(int n_rays, int n_samples, float w_rgb, float w_depth,
                           float* loss5, float* g_maps, float* g_raw,
                           xrd_stream_t stream);
 
+/* SSIM map of SplaTAM's mapping colour loss (calc_ssim / _ssim,
+ * slam/model_components/slam_external_splatam.py:59-96): 11x11 Gaussian window
+ * (sigma 1.5), zero padding, per channel; img*, ssim_map [C,H,W] f32.  The
+ * three d_* maps (may all be NULL) keep d ssim / d (mu1, E[x^2], E[xy]) for
+ * xrd_ssim_bwd, which returns d loss / d img1 from g_map = d loss / d ssim_map
+ * (img2, the target image, gets no gradient). */
+int xrd_ssim_fwd(int channels, int height, int width, const float* img1,
+                 const float* img2, float* ssim_map, float* d_mu1, float* d_e11,
+                 float* d_e12, xrd_stream_t stream);
+int xrd_ssim_bwd(int channels, int height, int width, const float* img1,
+                 const float* img2, const float* g_map, const float* d_mu1,
+                 const float* d_e11, const float* d_e12, float* g_img1,
+                 xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

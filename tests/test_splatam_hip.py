@@ -29,6 +29,27 @@ def test_gaussian_splatting_vs_reference():
     assert not bad, bad
 
 
+@pytest.mark.parametrize('shape', [(3, 50, 70), (3, 480, 640)])
+def test_fused_ssim_matches_convolution_path(shape):
+    """xrd_ssim_fwd/bwd against the depth-wise-convolution restatement of the
+    reference's calc_ssim (evaluated by torch on the CPU)"""
+    from xrdslam_amd.slam.model_components.slam_helpers_splatam import \
+        calc_ssim
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(*shape, generator=g)
+    b = (a + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    a_ref = a.clone().requires_grad_(True)
+    v_ref = calc_ssim(a_ref, b)                      # CPU: convolutions
+    v_ref.backward()
+    a_gpu = a.cuda().requires_grad_(True)
+    v = calc_ssim(a_gpu, b.cuda())                   # GPU: fused kernels
+    v.backward()
+    assert abs(float(v) - float(v_ref)) < 1e-5
+    err = (a_gpu.grad.cpu() - a_ref.grad).abs().max() / \
+        a_ref.grad.abs().max()
+    assert err < 1e-4, float(err)
+
+
 class _CvPoses:
     """the synthetic sequence with OpenCV-convention poses (camera looks down
     +z), the convention SplaTAM's back-projection assumes"""

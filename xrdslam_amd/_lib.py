@@ -123,6 +123,8 @@ _SIGS = {
                               [vp] * 7),
     'xrd_coslam_loss_grads': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 +
                               [vp] * 7 + [i64] + [vp] * 4),
+    'xrd_ssim_fwd': (C.c_int, [C.c_int] * 3 + [vp] * 7),
+    'xrd_ssim_bwd': (C.c_int, [C.c_int] * 3 + [vp] * 8),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
 }
 

@@ -263,3 +263,36 @@ class PoseRaysFn(torch.autograd.Function):
             _lib.ptr(g_rd.float().contiguous()), _lib.ptr(g),
             _lib.stream_ptr(dev)), 'xrd_pose_rays_bwd')
         return g, None, None
+
+
+class SsimMapFn(torch.autograd.Function):
+    """per-pixel SSIM of img1 [C,H,W] against img2 (no gradient to img2)"""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        lib = _lib.lib()
+        a = img1.detach().float().contiguous()
+        b = img2.detach().float().contiguous()
+        Cn, H, W = a.shape
+        out = torch.empty_like(a)
+        need = ctx.needs_input_grad[0]
+        d = [torch.empty_like(a) for _ in range(3)] if need else [None] * 3
+        _lib.check(lib.xrd_ssim_fwd(Cn, H, W, _lib.ptr(a), _lib.ptr(b),
+                                    _lib.ptr(out), _lib.ptr(d[0]),
+                                    _lib.ptr(d[1]), _lib.ptr(d[2]),
+                                    _lib.stream_ptr(a.device)), 'xrd_ssim_fwd')
+        if need:
+            ctx.save_for_backward(a, b, *d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, d0, d1, d2 = ctx.saved_tensors
+        Cn, H, W = a.shape
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().xrd_ssim_bwd(
+            Cn, H, W, _lib.ptr(a), _lib.ptr(b),
+            _lib.ptr(g.float().contiguous()), _lib.ptr(d0), _lib.ptr(d1),
+            _lib.ptr(d2), _lib.ptr(out), _lib.stream_ptr(a.device)),
+            'xrd_ssim_bwd')
+        return out, None

@@ -34,6 +34,12 @@ def _gaussian_window(size, channel, sigma=1.5):
 def calc_ssim(img1, img2, window_size=11, size_average=True):
     """structural similarity with an 11x11 Gaussian window (sigma 1.5),
     zero-padded depth-wise convolutions (slam_external_splatam.py:59-96)"""
+    if img1.is_cuda and img1.dim() == 3 and window_size == 11 and \
+            size_average and img1.dtype == torch.float32:
+        # MI355X: one fused launch (and one for the backward) instead of five
+        # depth-wise convolutions and their autograd graph
+        from ...engine import slam_ops
+        return slam_ops.SsimMapFn.apply(img1, img2).mean()
     ch = img1.size(-3)
     win = _gaussian_window(window_size, ch).to(img1)
     pad = window_size // 2
