@@ -43,6 +43,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Wave reduction on DPP (full-rate VALU, no LDS crossbar): quad swaps, row
+// half-mirror / mirror, then row broadcasts; the TOTAL is returned to every
+// lane through a scalar read of lane 63.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define XRD_DPP_ADD(CTRL, ROWMASK)                                            \
+  v += __builtin_bit_cast(                                                    \
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, \
+                                         ROWMASK, 0xf, false))
+  XRD_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  XRD_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  XRD_DPP_ADD(0x141, 0xf);  // row_half_mirror
+  XRD_DPP_ADD(0x140, 0xf);  // row_mirror: every lane holds its row's sum
+  XRD_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+  XRD_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+#undef XRD_DPP_ADD
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // sum over the 4 lane groups (l>>4) that hold the same point (l&15)
 __device__ __forceinline__ float group4_sum(float v) {
   v += __shfl_xor(v, 16);

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void gs_render_bwd_kernel(
         float v[9] = {g_col[0], g_col[1], g_col[2], g_m[0], g_m[1],
                       g_con[0], g_con[1], g_con[2], g_op};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = wave_sum(v[k]);
+        for (int k = 0; k < 9; ++k) v[k] = wave_sum_dpp(v[k]);
         if (lane == 0) {
           const int g = s_id[j];
           atomicAdd(dL_dcolors + g * 3 + 0, v[0]);
