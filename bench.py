@@ -296,9 +296,10 @@ def run_coslam(args, dev, with_cpu, world=1):
         'peak': MFMA_F32_PEAK / 1e12 if compute_bound else HBM_PEAK / 1e9,
         'unit': 'TFLOP/s' if compute_bound else 'GB/s',
         'frac': mfma / MFMA_F32_PEAK if compute_bound else hbm / HBM_PEAK,
+        # map + pose gradients run as two launches (map-only, pose-only)
         'traffic': pmc_traffic(
-            [f'coslam_bwd<dp={str(bool(ray_grads)).lower()},'
-             f'dg={str(bool(map_grads)).lower()}>'] +
+            (['coslam_bwd<dp=false,dg=true>'] if map_grads else []) +
+            (['coslam_bwd<dp=true,dg=false>'] if ray_grads else []) +
             (['coslam_reduce_kernel', 'hash_chunk_scatter_kernel']
              if map_grads else [])) if kernel == 'coslam_bwd'
         else pmc_traffic(['coslam_fwd_kernel']),

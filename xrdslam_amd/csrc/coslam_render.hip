@@ -997,9 +997,18 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                      dim3(kBwdWaves * 64), 0, st, *scene, n_rays, rays_o,     \
                      rays_d, z_vals, raw, g_maps, g_raw, g_rays_o, g_rays_d,  \
                      workspace, xs, dfeat)
-  if (dp && dg) BWD_CASE(true, true);
-  else if (dg) BWD_CASE(false, true);
-  else BWD_CASE(true, false);
+  // map + pose gradients: two launches (each recomputes the tile's forward)
+  // beat the combined variant, which needs all 512 registers and runs at one
+  // wave per SIMD: 2.8 + 3.3 ms vs 9.1 ms at 1e5 rays, 0.23 vs 0.36 ms at
+  // 2560 rays (profiles/r01_large_batch.txt)
+  if (dg) BWD_CASE(false, true);
+  if (dp) {
+    const int all = (tiles + kBwdWaves - 1) / kBwdWaves;
+    const int saved = blocks;
+    blocks = all;
+    BWD_CASE(true, false);
+    blocks = saved;
+  }
 #undef BWD_CASE
   rc = check_launch("coslam_bwd_kernel");
   if (rc != XRD_OK) return rc;
