@@ -123,14 +123,13 @@ __device__ __forceinline__ void hash_level_fwd(const LevelTab& lt,
   f1 = a1;
 }
 
-template <bool DP, bool DG>
-__device__ __forceinline__ void hash_level_bwd(const LevelTab& lt,
-                                               const float* table, int lvl,
-                                               float x, float y, float z,
-                                               float g0, float g1, bool live,
-                                               float* __restrict__ g_table,
-                                               float& dx, float& dy,
-                                               float& dz) {
+// d(loss)/d(position) through one level: sum over corners of the trilinear
+// weight derivatives times <entry, feature gradient>
+__device__ __forceinline__ void hash_level_dx(const LevelTab& lt,
+                                              const float* table, int lvl,
+                                              float x, float y, float z,
+                                              float g0, float g1, float& dx,
+                                              float& dy, float& dz) {
   const uint32_t res = lt.res[lvl], szf = lt.size[lvl];
   const uint32_t size = szf & 0x7fffffffu;
   const bool dense = (szf >> 31) != 0;
@@ -146,26 +145,15 @@ __device__ __forceinline__ void hash_level_bwd(const LevelTab& lt,
     const float ax = (c & 1) ? p.wx : 1.f - p.wx,
                 ay = (c & 2) ? p.wy : 1.f - p.wy,
                 az = (c & 4) ? p.wz : 1.f - p.wz;
-    if (DG) {
-      const float w = ax * ay * az;
-      if (live) {
-        atomicAdd(g_table + 2 * (size_t)idx, w * g0);
-        atomicAdd(g_table + 2 * (size_t)idx + 1, w * g1);
-      }
-    }
-    if (DP) {
-      const float2 v = reinterpret_cast<const float2*>(table)[idx];
-      const float dv = v.x * g0 + v.y * g1;
-      sx += ((c & 1) ? 1.f : -1.f) * ay * az * dv;
-      sy += ((c & 2) ? 1.f : -1.f) * ax * az * dv;
-      sz += ((c & 4) ? 1.f : -1.f) * ax * ay * dv;
-    }
+    const float2 v = reinterpret_cast<const float2*>(table)[idx];
+    const float dv = v.x * g0 + v.y * g1;
+    sx += ((c & 1) ? 1.f : -1.f) * ay * az * dv;
+    sy += ((c & 2) ? 1.f : -1.f) * ax * az * dv;
+    sz += ((c & 4) ? 1.f : -1.f) * ax * ay * dv;
   }
-  if (DP) {
-    dx = fmaf(scale, sx, dx);
-    dy = fmaf(scale, sy, dy);
-    dz = fmaf(scale, sz, dz);
-  }
+  dx = fmaf(scale, sx, dx);
+  dy = fmaf(scale, sy, dy);
+  dz = fmaf(scale, sz, dz);
 }
 
 // ---- OneBlob (quartic kernel, 16 bins) ------------------------------------
@@ -659,10 +647,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
     if (DP) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        hash_level_bwd<true, false>(lt, sc.table, q + 4 * a, xn[0], xn[1],
-                                    xn[2], dx0[a >> 1][2 * (a & 1)],
-                                    dx0[a >> 1][2 * (a & 1) + 1], live, nullptr,
-                                    dpx, dpy, dpz);
+        hash_level_dx(lt, sc.table, q + 4 * a, xn[0], xn[1], xn[2],
+                      dx0[a >> 1][2 * (a & 1)], dx0[a >> 1][2 * (a & 1) + 1],
+                      dpx, dpy, dpz);
         CS_SB;
       }
     }

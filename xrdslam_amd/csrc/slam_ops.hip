@@ -356,12 +356,11 @@ __global__ __launch_bounds__(64) void pose_aa_bwd_kernel(
     const float w[3] = {x / a, y / a, z / a};
     const float s = sinf(a), c = cosf(a);
     const float K[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
-    float K2[9], sGK = 0.f, sGK2 = 0.f;
+    float sGK = 0.f, sGK2 = 0.f;  // <G, K> and <G, K^2>
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
         float kk = 0.f;
         for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
-        K2[i * 3 + j] = kk;
         sGK += G[i * 3 + j] * K[i * 3 + j];
         sGK2 += G[i * 3 + j] * kk;
       }
@@ -378,7 +377,6 @@ __global__ __launch_bounds__(64) void pose_aa_bwd_kernel(
     const float da = c * sGK + s * sGK2;
     const float wd = w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2];
     for (int i = 0; i < 3; ++i) gr[i] = (dw[i] - w[i] * wd) / a + da * w[i];
-    (void)K2;
   }
   for (int i = 0; i < 3; ++i) g_r[p * 3 + i] = gr[i];
 }
