@@ -85,9 +85,11 @@ def rgb2gray(image):
 def _sobel(intensity, axis):
     """skimage.filters.sobel_h (axis 0) / sobel_v (axis 1): difference
     [1,0,-1] along ``axis``, smoothing [1,2,1]/4 across it, reflected borders.
-    Restated from the published definition (skimage is not installed here:
-    parity unpinned; it only steers WHICH pixels are sampled and the per-pixel
-    radii, not the render arithmetic)."""
+    Restated from the published definition (skimage is not installed here, so
+    parity with skimage itself is unpinned; the magnitude is checked against
+    scipy.ndimage.convolve with the published kernel in
+    tests/test_reference_host_parity.py).  It only steers WHICH pixels are
+    sampled and the per-pixel radii, not the render arithmetic."""
     a = np.asarray(intensity, dtype=np.float64)
     p = np.pad(a, 1, mode='symmetric')
     if axis == 0:
