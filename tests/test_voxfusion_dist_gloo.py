@@ -12,6 +12,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -81,8 +82,8 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_voxfusion_mapping_equals_single_process():
-    world = 2
+@pytest.mark.parametrize('world', [2, 3])   # 3: uneven shards
+def test_sharded_voxfusion_mapping_equals_single_process(world):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
