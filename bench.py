@@ -30,6 +30,10 @@ The JSON line also carries
                timing on the launch stream; algorithmic bytes from SURVEY §8d)
   cpu_baseline the CPU oracle (oracle/nice_oracle.py, a port of the reference's
                PyTorch path) timed on this host's cores on a bounded sample.
+  torch_gpu_baseline  the same oracle ops run unfused by torch ON the MI355X
+               (SURVEY 8d "reference PyTorch on ROCm" row), N=1 only
+  config.render_img_ms  full 640x480 render_img (307 200 rays), outside the
+               timed region
 """
 import argparse
 import json
@@ -105,56 +109,75 @@ def algorithmic_bytes(kernel, stage, n_rays, grid_grads):
     return n_rays * S * per_sample
 
 
-def cpu_baseline(threads):
+def cpu_baseline(threads, device='cpu'):
     """oracle timed on the host: 1 tracking iteration (200 rays, colour stage,
     fwd+bwd) and 1 mapping iteration per stage (1000 rays) + 1 coarse, with
     office0-sized grids; converted to frames/s with the reference's iteration
     counts (10 tracking it/frame; (24 middle + 12 fine + 24 color + 60 coarse)
-    mapping it / 5 frames)."""
+    mapping it / 5 frames).  With device='cuda:0' the same unfused torch ops
+    run on the GPU (the "reference PyTorch on this GPU" row of SURVEY 8d)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import nice_oracle as no
     from xrdslam_amd.engine import nice as en
     torch.set_num_threads(threads)
+    on_gpu = str(device) != 'cpu'
     g = torch.Generator().manual_seed(0)
     bound = torch.tensor([[-5.5, 6.0199995], [-6.7, 5.4599998],
-                          [-4.7, 5.5399998]], dtype=torch.float64)
+                          [-4.7, 5.5399998]], dtype=torch.float64,
+                         device=device)
     shapes = {'grid_coarse': (10, 12, 11), 'grid_middle': (31, 37, 35),
               'grid_fine': (63, 75, 71), 'grid_color': (63, 75, 71)}
-    grids = {k: (torch.randn(1, 32, *s, generator=g) * 0.01).requires_grad_()
-             for k, s in shapes.items()}
+    grids = {k: (torch.randn(1, 32, *s, generator=g) * 0.01).to(device)
+             .requires_grad_() for k, s in shapes.items()}
     decs = {kind: {n: (torch.randn(*s, generator=g) *
-                       (25. if n == 'embedder._B' else 0.2)).requires_grad_()
+                       (25. if n == 'embedder._B' else 0.2)).to(device)
+                   .requires_grad_()
                    for n, s in en.param_shapes(kind)}
             for kind in ('coarse', 'middle', 'fine', 'color')}
 
     def one(n, stage, is_mapping):
-        o = ((torch.rand(n, 3, generator=g) - 0.5) * 2).requires_grad_()
+        o = ((torch.rand(n, 3, generator=g) - 0.5) * 2).to(device) \
+            .requires_grad_()
         d = torch.randn(n, 3, generator=g)
-        d = (d / d.norm(dim=1, keepdim=True)).requires_grad_()
-        dep = 1.0 + 2.0 * torch.rand(n, 1, generator=g)
-        col = torch.rand(n, 3, generator=g)
+        d = (d / d.norm(dim=1, keepdim=True)).to(device).requires_grad_()
+        dep = (1.0 + 2.0 * torch.rand(n, 1, generator=g)).to(device)
+        col = torch.rand(n, 3, generator=g).to(device)
+        if on_gpu:
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = no.render_batch_ray(o, d, dep, grids, decs, bound, stage)
         loss = sum(no.loss_dict(out, dep, col, is_mapping, stage).values())
         loss.backward()
+        if on_gpu:
+            torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    def best(n, stage, is_mapping):
+        # the GPU leg is cheap: warm up each shape, keep the best of three
+        if not on_gpu:
+            return one(n, stage, is_mapping)
+        one(n, stage, is_mapping)
+        return min(one(n, stage, is_mapping) for _ in range(3))
+
     one(50, 'color', True)  # warm up the allocator / threads
-    t_track = one(200, 'color', False)
-    t_mid, t_fine, t_col = (one(1000, s, True)
+    t_track = best(200, 'color', False)
+    t_mid, t_fine, t_col = (best(1000, s, True)
                             for s in ('middle', 'fine', 'color'))
-    t_coarse = one(1000, 'coarse', True)
+    t_coarse = best(1000, 'coarse', True)
     per_frame = 10 * t_track + (24 * t_mid + 12 * t_fine + 24 * t_col +
                                 60 * t_coarse) / 5.0
     return {
-        'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': threads,
+        'value': 1.0 / per_frame, 'unit': 'frames/s',
+        'cores': 0 if on_gpu else threads,
         'kind': 'port',
         'sample': ('1 tracking iter (200 rays) + 1 mapping iter per stage '
                    '(1000 rays: middle/fine/color/coarse), fwd+bwd, office0 '
                    'grids; scaled by the reference iteration counts; '
-                   f'iter seconds track={t_track:.3f} middle={t_mid:.3f} '
-                   f'fine={t_fine:.3f} color={t_col:.3f} '
-                   f'coarse={t_coarse:.3f}')}
+                   f'iter seconds track={t_track:.4f} middle={t_mid:.4f} '
+                   f'fine={t_fine:.4f} color={t_col:.4f} '
+                   f'coarse={t_coarse:.4f}' +
+                   ('; unfused torch autograd ops on the MI355X (eager, no '
+                    'optimizer step)' if on_gpu else ''))}
 
 
 # ---- Co-SLAM (BASELINE.json north_star names it next to NICE-SLAM) ----------
@@ -328,10 +351,30 @@ def run_coslam(args, dev, with_cpu, world=1):
                         '16x2 (2^16) + OneBlob + 2x32 MLPs',
             'track_ms_per_frame': slam.t_track / args.steps * 1e3,
             'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+            'render_img_ms': render_img_ms(algo, data,
+                                           args.warmup + args.steps, dev),
             'ate_rmse_m': slam.ate_rmse()},
         'roofline': roofline,
         'cpu_baseline': co_cpu_baseline(min(16, os.cpu_count() or 1))
         if with_cpu else None}
+
+
+def render_img_ms(algo, data, k, dev, reps=3):
+    """full-image render (307 200 rays at 640x480, in the algorithm's
+    ray_batch_size chunks) of frame k at its estimated pose, device to device
+    + the copy of colour/depth to the host that render_img returns; best of
+    ``reps`` after one warm-up.  Outside the timed FPS region."""
+    c2w = algo.get_estimate_c2w_list()[k].to(dev)
+    depth = data[k]['depth']
+    algo.render_img(c2w, gt_depth=depth)
+    best = float('inf')
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        algo.render_img(c2w, gt_depth=depth)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
 
 
 def _timed_frames(slam, args, dev, world):
@@ -542,8 +585,13 @@ def main():
                     choices=['nice-slam', 'co-slam', 'vox-fusion', 'splaTAM',
                              'point-slam'])
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='timed frames (default 100 for nice-slam/co-slam: '
+                         'a 20-frame region is 0.3 s and one sporadic ~75 ms '
+                         'runtime stall moves it by 25 %%; 20 for vox-fusion/'
+                         'splaTAM, 5 for point-slam)')
+    ap.add_argument('--warmup', type=int, default=None,
+                    help='untimed frames after frame 0 (default 10 / 5 / 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-coslam', action='store_true',
                     help='skip the Co-SLAM leg of the default run')
@@ -552,6 +600,12 @@ def main():
     ap.add_argument('--first-iters', type=int, default=None,
                     help='override mapping_first_n_iters (untimed set-up)')
     args = ap.parse_args()
+    d_steps, d_warm = {'nice-slam': (100, 10), 'co-slam': (100, 10),
+                       'point-slam': (5, 2)}.get(args.algo, (20, 5))
+    if args.steps is None:
+        args.steps = d_steps
+    if args.warmup is None:
+        args.warmup = d_warm
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -579,7 +633,7 @@ def main():
     if args.algo in ('co-slam', 'vox-fusion', 'splaTAM', 'point-slam'):
         if world > 1 and args.algo == 'splaTAM':
             raise SystemExit('--algo splaTAM runs on one GPU this round')
-        res = run_coslam(args, dev, not args.no_cpu_baseline and rank == 0,
+        res = run_coslam(args, dev, not args.no_cpu_baseline and world == 1,
                          world) \
             if args.algo == 'co-slam' else run_voxfusion(args, dev, world) \
             if args.algo == 'vox-fusion' else run_splatam(args, dev) \
@@ -635,10 +689,16 @@ def main():
     slam.t_track = slam.t_map = 0.0
     barrier()
     t0 = time.perf_counter()
+    stamps = []
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
         slam.step(k)
+        stamps.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get('XRD_BENCH_TRACE'):   # host-side time per frame
+        print('frame ms:', ' '.join(
+            f'{k + 1 + args.warmup}:{(b - a) * 1e3:.1f}' for k, (a, b) in
+            enumerate(zip([t0] + stamps[:-1], stamps))), file=sys.stderr)
     prof, en.PROFILE = en.PROFILE, None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -690,11 +750,12 @@ def main():
             'share_of_kernel_time': total_ms / sum(s[0] for s in stats),
             'kernel_time_ms_per_step': sum(s[0] for s in stats) / args.steps,
         }
-        cpu = None
-        if not args.no_cpu_baseline:
+        cpu = torch_gpu = None
+        if not args.no_cpu_baseline and world == 1:
             # torch CPU ops on these small tensors stop scaling (and collapse)
             # beyond a few tens of threads: use at most 16 host cores
             cpu = cpu_baseline(min(16, os.cpu_count() or 1))
+            torch_gpu = cpu_baseline(1, device=str(dev))
         fps = args.steps / elapsed
         out = {
             'metric': 'tracking+mapping FPS @640x480', 'value': fps,
@@ -713,8 +774,13 @@ def main():
                                if world > 1 else 'single GPU',
                 'track_ms_per_frame': slam.t_track / args.steps * 1e3,
                 'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+                'render_img_ms': render_img_ms(algo, data,
+                                               args.warmup + args.steps, dev),
                 'ate_rmse_m': slam.ate_rmse()},
             'roofline': roofline, 'cpu_baseline': cpu,
+            # the oracle's unfused torch ops on this GPU (a second baseline,
+            # not a product path)
+            'torch_gpu_baseline': torch_gpu,
         }
         if world == 1 and not args.no_coslam:
             # the second algorithm the north star names, same frame loop

@@ -94,7 +94,7 @@ def nice_forward(p, grids, decoders, bound, stage, coarse_enlarge=2):
     ``grids``: dict grid_{coarse,middle,fine,color} -> [1,32,Z,Y,X];
     ``decoders``: dict {coarse,middle,fine,color} -> state dict."""
     P = p.shape[0]
-    raw = torch.zeros(P, 4, dtype=torch.float32)
+    raw = torch.zeros(P, 4, dtype=torch.float32, device=p.device)
     if stage == 'coarse':
         c = sample_grid(p, grids['grid_coarse'], bound * coarse_enlarge)
         raw[:, 3] = mlp_no_xyz_forward(decoders['coarse'], c).squeeze(-1)
@@ -163,14 +163,16 @@ def sample_z(rays_o, rays_d, bound, gt_depth: Optional[torch.Tensor],
         far = far_bb
     if n_surface > 0:
         nz = (gt_depth > 0).squeeze(-1)
-        ts = torch.linspace(0., 1., steps=n_surface).double()
+        ts = torch.linspace(0., 1., steps=n_surface,
+                            device=gt_depth.device).double()
         dnz = gt_depth[nz].reshape(-1, 1).repeat(1, n_surface)
         z_nz = 0.95 * dnz * (1. - ts) + 1.05 * dnz * ts
-        z_surf = torch.zeros(gt_depth.shape[0], n_surface).double()
+        z_surf = torch.zeros(gt_depth.shape[0], n_surface,
+                             device=gt_depth.device).double()
         z_surf[nz, :] = z_nz
         z_zero = 0.001 * (1. - ts) + torch.max(gt_depth) * ts
         z_surf[~nz, :] = z_zero
-    t_vals = torch.linspace(0., 1., steps=n_samples)
+    t_vals = torch.linspace(0., 1., steps=n_samples, device=rays_o.device)
     z_vals = near * (1. - t_vals) + far * t_vals
     if n_surface > 0:
         z_vals, _ = torch.sort(torch.cat([z_vals, z_surf.double()], -1), -1)
@@ -184,7 +186,8 @@ def composite(raw, z_vals, coef=10.0):
     z_vals is float64."""
     rgb = raw[..., :3]
     alpha = torch.sigmoid(coef * raw[..., 3]).float()
-    ones = torch.ones((alpha.shape[0], 1), dtype=torch.float32)
+    ones = torch.ones((alpha.shape[0], 1), dtype=torch.float32,
+                      device=alpha.device)
     weights = alpha * torch.cumprod(
         torch.cat([ones, (1. - alpha + 1e-10).float()], -1), -1)[:, :-1]
     rgb_map = torch.sum(weights[..., None] * rgb, -2)
