@@ -140,6 +140,16 @@ int xrd_adam_cells_devstep(float* param, float* g, float* m, float* v,
                            float eps, const int32_t* step_dev, int zero_grad,
                            xrd_stream_t stream);
 
+/* same, for a launch that is replayed across mapping calls: cell_idx has room
+ * for `capacity` entries (m, v: capacity x cell_floats), the number of valid
+ * entries is read from *n_cells_dev at execution time */
+int xrd_adam_cells_devcount(float* param, float* g, float* m, float* v,
+                            const int32_t* cell_idx, int64_t capacity,
+                            int cell_floats, float lr, float beta1,
+                            float beta2, float eps, const int32_t* step_dev,
+                            const int32_t* n_cells_dev, int zero_grad,
+                            xrd_stream_t stream);
+
 /* one-time set-up of kernel attributes (dynamic LDS sizes); call once per
  * process before capturing launches into a hipGraph */
 int xrd_nice_warmup(void);

@@ -141,3 +141,23 @@ def test_convonet_bound_and_grid_shapes_cpu():
     assert tuple(m.grid_c['grid_middle'].shape) == (1, 32, 31, 37, 35)
     assert tuple(m.grid_c['grid_coarse'].shape) == (1, 32, 10, 12, 11)
     assert m.decoder.color_decoder.flat.numel() == 15899
+
+
+def test_synthetic_room_preload_is_transparent():
+    """preloaded frames are the frames generated on demand; items are copies
+    (callers may edit the dict), and on the CPU no device images are added"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    bound = [[-2.0, 2.0], [-2.4, 1.8], [-1.6, 2.0]]
+    a = SyntheticRoom(bound, H=24, W=32, fx=16., fy=16., cx=15.5, cy=11.5,
+                      n_frames=8)
+    b = SyntheticRoom(bound, H=24, W=32, fx=16., fy=16., cx=15.5, cy=11.5,
+                      n_frames=8).preload(range(-1, 20))
+    assert sorted(b._cache) == list(range(8))
+    for k in (0, 5):
+        x, y = a[k], b[k]
+        assert set(x) == set(y) == {'index', 'rgb', 'depth', 'c2w'}
+        for key in ('rgb', 'depth', 'c2w'):
+            assert np.array_equal(x[key], y[key])
+    item = b[3]
+    item['c2w'] = None
+    assert b[3]['c2w'] is not None

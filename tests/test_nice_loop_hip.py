@@ -109,3 +109,104 @@ def test_graph_replay_matches_eager_tracking():
     # statistically: both stay close to the initial pose and to each other
     assert np.abs(ca - cb).max() < 5e-2
     assert np.allclose(ca[3], [0, 0, 0, 1])
+
+
+# ---- the whole loop: persistent mapping graphs ------------------------------
+def _run_slam(persistent, n_frames, seed=0):
+    import random
+
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import nice_slam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    cam = Camera(80., 80., 79.5, 59.5, 160, 120)
+    cfg = nice_slam_config(BOUND)
+    cfg.tracking_Hedge = cfg.tracking_Wedge = 10
+    cfg.mapping_first_n_iters = 300
+    algo = cfg.setup(camera=cam, device='cuda:0')
+    algo.use_graphs = True
+    algo.persistent_map_graph = persistent
+    data = SyntheticRoom(BOUND, H=120, W=160, fx=80., fy=80., cx=79.5, cy=59.5,
+                         n_frames=200, shrink=0.3, device='cuda:0')
+    slam = SequentialSLAM(algo, data, map_every=5, keyframe_every=5,
+                          pose_device='cuda:0')
+    for k in range(n_frames):
+        slam.step(k)
+    return algo, slam
+
+
+def test_persistent_mapping_graphs_match_per_call_graphs():
+    """mapping through graphs kept across calls (static frame slots, static
+    cell selection, Adam state zeroed per call) against the per-call capture:
+    same trajectory quality, and the invariants of one replay-only call"""
+    from xrdslam_amd.engine import nice as en
+    a, sa = _run_slam(True, 41)
+    b, sb = _run_slam(False, 41)
+    assert not getattr(b, '_map_slots', None)
+    slots = a._map_slots
+    assert slots and max(s.get('calls', 0) for s in slots.values()) >= 2
+    assert not any(s.get('unusable') for s in slots.values())
+    ate_a, ate_b = sa.ate_rmse(), sb.ate_rmse()
+    assert ate_a < max(1.5 * ate_b, ate_b + 0.01), (ate_a, ate_b)
+    # packed decoder weights follow the trained flat parameter, in place
+    for algo in (a, b):
+        flat = algo.model.decoder.color_decoder.flat
+        sc = algo.model.scene()
+        assert torch.equal(sc.packed['color'],
+                           en.pack_decoder(flat, 'color'))
+    # one more (replay-only) mapping call, watched
+    for k in range(41, 45):
+        sa.step(k)
+    grids = {k: g.detach().clone() for k, g in a.model.grid_c.items()}
+    flat0 = a.model.decoder.color_decoder.flat.detach().clone()
+    kf_poses = [f.get_pose().detach().clone() for f in a.keyframe_graph]
+    calls = {k: s.get('calls', 0) for k, s in slots.items()}
+    seen, select = [], a.model.select_cells
+
+    def recording_select():
+        seen.append({k: m.clone() for k, m in a.model.grid_opti_mask.items()
+                     if m is not None})
+        select()
+
+    a.model.select_cells = recording_select
+    sa.step(45)                                   # a map frame (45 % 5 == 0)
+    del a.model.select_cells
+    assert len(seen) == 2                         # main pass, coarse pass
+    key = a._last_map_slot_key
+    main = [k for k in slots if not k[3] and slots[k].get('calls', 0) >
+            calls.get(k, 0)]
+    assert len(main) == 1 and calls.get(main[0], 0) >= 1, 'not a replay call'
+    slot = slots[main[0]]
+    assert main[0][1], 'bundle adjustment expected with > 4 keyframes'
+    n_it = main[0][2]
+    segs = [a.graph_segment_key(True, s, n_it) for s in range(n_it)]
+    want = {'grid_middle': n_it, 'grid_fine': n_it - segs.count('middle'),
+            'grid_color': segs.count('color'), 'decoder': segs.count('color')}
+    for name, n in want.items():
+        opt = slot['opt'].optimizers[name]
+        got = int(opt._step_dev) if hasattr(opt, '_step_dev') else \
+            int(next(iter(opt.state.values()))['step'])
+        assert got == n, (name, got, n)
+    for k in ('grid_middle', 'grid_fine', 'grid_color'):
+        st = a.model._sel_static[k]
+        mask = a.model.grid_opti_mask[k].reshape(-1)
+        assert int(st['count']) == int(mask.sum())
+        assert torch.equal(st['cells'][:int(st['count'])].long(),
+                           mask.nonzero().reshape(-1))
+        g_new = a.model.grid_c[k].detach()
+        changed = (g_new != grids[k]).permute(0, 2, 3, 4, 1).reshape(
+            -1, 32).any(1)                       # per cell, [Z][Y][X] order
+        assert changed.any()
+        # only cells the MAIN pass selected moved (the coarse pass re-selects
+        # for the bundle-adjusted pose but only steps grid_coarse)
+        assert not (changed & ~seen[0][k].reshape(-1)).any(), k
+    assert not torch.equal(a.model.decoder.color_decoder.flat.detach(), flat0)
+    # bundle adjustment wrote poses back to the real keyframes (all but the
+    # oldest of the window) and left the others alone
+    moved = [not torch.equal(f.get_pose().detach(), p0)
+             for f, p0 in zip(a.keyframe_graph, kf_poses)]
+    assert 1 <= sum(moved) <= 4, moved
+    assert key in slots

@@ -43,10 +43,11 @@ for k in range(max(which) + 1):
         pr.disable()
         dt = (time.perf_counter() - t0) * 1e3
         s = io.StringIO()
-        pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(22)
+        key = os.environ.get('XRD_CP_SORT', 'cumulative')
+        pstats.Stats(pr, stream=s).sort_stats(key).print_stats(28)
         lines = [ln for ln in s.getvalue().splitlines() if '/' in ln or
                  '{' in ln]
         print(f'--- frame {k}: {dt:.1f} ms')
-        print('\n'.join(ln[:150] for ln in lines[:22]))
+        print('\n'.join(ln[:150] for ln in lines[:28]))
     else:
         slam.step(k)

@@ -58,6 +58,9 @@ _SIGS = {
                                  f32, f32, C.c_int, C.c_int, vp]),
     'xrd_adam_cells_devstep': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32,
                                          f32, f32, f32, vp, C.c_int, vp]),
+    'xrd_adam_cells_devcount': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int,
+                                          f32, f32, f32, f32, vp, vp, C.c_int,
+                                          vp]),
     'xrd_nice_warmup': (C.c_int, []),
     'xrd_hashgrid_levels': (C.c_int, [C.c_int, C.c_int, f32, C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp]),

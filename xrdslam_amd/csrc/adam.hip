@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
     float* __restrict__ v, const int32_t* __restrict__ cell_idx,
     int64_t n_cells, int vec_per_cell, float lr, float beta1, float beta2,
     float eps, int step_host, const int32_t* __restrict__ step_dev,
-    int zero_grad) {
+    const int32_t* __restrict__ n_cells_dev, int zero_grad) {
   __shared__ float s_coef[2];
   if (threadIdx.x == 0) {
     const int t = step_dev ? step_dev[0] : step_host;
@@ -32,6 +32,9 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
   }
   __syncthreads();
   const float step_size = s_coef[0], inv_bc2_sqrt = s_coef[1];
+  // persistent hipGraphs: the launch covers the list's capacity, the number of
+  // valid entries is read at execution time
+  if (n_cells_dev) n_cells = min(n_cells, (int64_t)n_cells_dev[0]);
   const int64_t total = n_cells * vec_per_cell;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -67,7 +70,8 @@ static int adam_launch(float* param, float* g, float* m, float* v,
                        const int32_t* cell_idx, int64_t n_cells,
                        int cell_floats, float lr, float beta1, float beta2,
                        float eps, int step, const int32_t* step_dev,
-                       int zero_grad, xrd_stream_t stream) {
+                       const int32_t* n_cells_dev, int zero_grad,
+                       xrd_stream_t stream) {
   if (!param || !g || !m || !v || n_cells < 0 || cell_floats <= 0 ||
       (cell_floats & 3) || (step < 1 && !step_dev))
     return XRD_ERR_ARG;
@@ -78,7 +82,8 @@ static int adam_launch(float* param, float* g, float* m, float* v,
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(xrd::adam_cells_kernel, dim3((unsigned)blocks), dim3(256),
                      0, (hipStream_t)stream, param, g, m, v, cell_idx, n_cells,
-                     vec, lr, beta1, beta2, eps, step, step_dev, zero_grad);
+                     vec, lr, beta1, beta2, eps, step, step_dev, n_cells_dev,
+                     zero_grad);
   return xrd::check_launch("xrd_adam_cells");
 }
 
@@ -88,7 +93,7 @@ extern "C" int xrd_adam_cells(float* param, float* g, float* m, float* v,
                               float beta2, float eps, int step, int zero_grad,
                               xrd_stream_t stream) {
   return adam_launch(param, g, m, v, cell_idx, n_cells, cell_floats, lr, beta1,
-                     beta2, eps, step, nullptr, zero_grad, stream);
+                     beta2, eps, step, nullptr, nullptr, zero_grad, stream);
 }
 
 extern "C" int xrd_adam_cells_devstep(float* param, float* g, float* m,
@@ -99,5 +104,18 @@ extern "C" int xrd_adam_cells_devstep(float* param, float* g, float* m,
                                       int zero_grad, xrd_stream_t stream) {
   if (!step_dev) return XRD_ERR_ARG;
   return adam_launch(param, g, m, v, cell_idx, n_cells, cell_floats, lr, beta1,
-                     beta2, eps, 0, step_dev, zero_grad, stream);
+                     beta2, eps, 0, step_dev, nullptr, zero_grad, stream);
+}
+
+extern "C" int xrd_adam_cells_devcount(float* param, float* g, float* m,
+                                       float* v, const int32_t* cell_idx,
+                                       int64_t capacity, int cell_floats,
+                                       float lr, float beta1, float beta2,
+                                       float eps, const int32_t* step_dev,
+                                       const int32_t* n_cells_dev,
+                                       int zero_grad, xrd_stream_t stream) {
+  if (!step_dev || !n_cells_dev || !cell_idx) return XRD_ERR_ARG;
+  return adam_launch(param, g, m, v, cell_idx, capacity, cell_floats, lr,
+                     beta1, beta2, eps, 0, step_dev, n_cells_dev, zero_grad,
+                     stream);
 }

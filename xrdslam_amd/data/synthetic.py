@@ -42,6 +42,7 @@ class SyntheticRoom:
                         (c + ext * np.array([-0.3, 0.1, -0.25]), 0.10 * ext.min()),
                         (c + ext * np.array([0.1, -0.3, -0.35]), 0.08 * ext.min())]
         self.poses = [self._pose(k) for k in range(n_frames)]
+        self._cache = {}
 
     def _pose(self, k):
         """<= ~2 cm / ~1 deg per frame at 200 frames"""
@@ -87,7 +88,28 @@ class SyntheticRoom:
         pts = o + d * t[..., None]
         return t, pts
 
+    def preload(self, indices, device_images=True):
+        """generate frames ahead of time (what a prefetching dataset loader
+        does) and, on a GPU, keep their float32 images resident in HBM: items
+        then also carry 'depth_dev' [H*W,1] / 'rgb_dev' [H*W,3], which
+        SequentialSLAM hands to the Frame as its device image cache"""
+        for k in indices:
+            if k in self._cache or not 0 <= k < self.n_frames:
+                continue
+            item = self._make(k)
+            if device_images and self.device.type == 'cuda':
+                item['depth_dev'] = torch.from_numpy(item['depth']).to(
+                    self.device).reshape(-1, 1)
+                item['rgb_dev'] = torch.from_numpy(item['rgb']).to(
+                    self.device).reshape(-1, 3)
+            self._cache[k] = item
+        return self
+
     def __getitem__(self, k):
+        hit = self._cache.get(k)
+        return dict(hit) if hit is not None else self._make(k)
+
+    def _make(self, k):
         c2w = self.poses[k]
         depth, pts = self._raycast(c2w)
         x, y, z = pts[..., 0], pts[..., 1], pts[..., 2]

@@ -112,13 +112,19 @@ def pack_index(kind: str, device) -> torch.Tensor:
     return _pack_index_cache[key]
 
 
-def pack_decoder(flat: torch.Tensor, kind: str) -> torch.Tensor:
+def pack_decoder(flat: torch.Tensor, kind: str,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.lib()
     assert flat.numel() == lib.xrd_nice_flat_len(DEC_KINDS[kind]), \
         (kind, flat.numel())
     ext = torch.cat([flat.detach().float().reshape(-1),
                      flat.new_zeros(1, dtype=torch.float32)])
-    return ext[pack_index(kind, flat.device)].contiguous()
+    idx = pack_index(kind, flat.device)
+    if out is not None:
+        # in place: launches captured in a hipGraph (and graphs captured
+        # earlier, e.g. the tracking graph) keep reading the same buffer
+        return torch.index_select(ext, 0, idx, out=out)
+    return ext[idx].contiguous()
 
 
 def to_channels_last_grid(val: torch.Tensor) -> torch.Tensor:
@@ -167,7 +173,10 @@ class NiceScene:
     def set_decoder(self, kind: str, flat: torch.Tensor):
         """flat: state_dict-ordered parameter vector (may require grad)"""
         self.dec_flat[kind] = flat
-        self.packed[kind] = pack_decoder(flat, kind)
+        old = self.packed.get(kind)
+        if old is not None and old.device != flat.device:
+            old = None
+        self.packed[kind] = pack_decoder(flat, kind, out=old)
 
     def c_struct(self) -> _lib.NiceScene:
         s = _lib.NiceScene()

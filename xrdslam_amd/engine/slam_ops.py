@@ -205,6 +205,10 @@ class FusedDenseAdam(torch.optim.Optimizer):
                     float(b1), float(b2), float(grp['eps']),
                     float(grp['weight_decay']), _lib.ptr(st['step']),
                     _lib.stream_ptr(p.device)), 'xrd_adam_dense')
+                # the kernel writes through the raw pointer: torch's version
+                # counter does not see it; consumers that cache a derived
+                # layout (packed decoder weights) watch this counter instead
+                p._xrd_steps = getattr(p, '_xrd_steps', 0) + 1
 
 
 def track_best(loss, c2w, track):

@@ -215,6 +215,17 @@ class Algorithm:
     # ---- the optimiser loop ------------------------------------------------
     use_graphs = False  # capture each stage segment into a hipGraph (MI355X)
     persistent_track_graph = True  # one tracking graph reused across frames
+    # mapping graphs kept from one mapping call to the next (algorithms whose
+    # mapping work has call-independent shapes opt in, see _map_slot_run)
+    persistent_map_graph = False
+
+    def map_slot_key(self, n_iters, optimize_frames, coarse):
+        """everything a captured mapping iteration depends on besides the
+        data that _map_slot_run copies into the slot; None = do not persist"""
+        return None
+
+    def after_mapping_update(self):
+        """end of a mapping optimize_update (replayed graphs included)"""
 
     def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
         """iterations with equal keys run identical device work (same stage,
@@ -298,10 +309,11 @@ class Algorithm:
             self._track_slot = slot
         sf = slot['frame']
         d_dev, c_dev = sf.device_images(dev)
-        d_dev.copy_(torch.as_tensor(frame.depth, dtype=torch.float32)
-                    .reshape(-1, 1), non_blocking=True)
-        c_dev.copy_(torch.as_tensor(frame.rgb, dtype=torch.float32)
-                    .reshape(-1, 3), non_blocking=True)
+        # through the frame's own device cache: uploaded once per frame (or
+        # already resident), reused when the frame becomes a mapping frame
+        f_d, f_c = frame.device_images(dev)
+        d_dev.copy_(f_d, non_blocking=True)
+        c_dev.copy_(f_c, non_blocking=True)
         with torch.no_grad():
             for ps, pf in zip(sf.get_params(), frame.get_params()):
                 ps.copy_(pf.detach().to(ps.device))
@@ -344,6 +356,125 @@ class Algorithm:
             return None
         return track['c2w'].cpu().numpy()
 
+    # ---- persistent mapping graphs -----------------------------------------
+    def _map_slot_run(self, key, n_iters, frames, coarse):
+        """One mapping call through hipGraphs that outlive it.  A slot (per
+        ``map_slot_key``) owns stand-in frames with static image buffers and
+        pose parameters, ONE Optimizers object and one captured graph per stage
+        segment.  A call copies the window's images and poses into the slot,
+        lets the model refresh its cell selection in place, zeroes the Adam
+        state (the reference builds fresh optimisers per call,
+        base_algorithm.py:160-181) and replays; bundle-adjusted poses are
+        copied back.  The first call of a slot runs the ordinary segment loop
+        (first iteration eager, second captured) and keeps the graphs.
+        Returns False when the slot cannot be used (caller falls back)."""
+        slots = self.__dict__.setdefault('_map_slots', {})
+        slot = slots.get(key)
+        if slot is not None and slot.get('unusable'):
+            return False
+        static_before = getattr(self.model, 'static_selection', None)
+        if static_before is not None:
+            self.model.static_selection = True
+        try:
+            return self._map_slot_body(slots, slot, key, n_iters, frames,
+                                       coarse)
+        finally:
+            if static_before is not None:
+                self.model.static_selection = static_before
+
+    def _map_slot_body(self, slots, slot, key, n_iters, frames, coarse):
+        from ..common.frame import Frame
+        from ..engine.optimizers import reset_optimizer_state
+        dev = self.device
+        self.optimizer_config_update(n_iters, coarse)
+        if self.bundle_adjust and len(frames) > 1:
+            # bundle adjustment keeps the oldest frame fixed
+            # (setup_optimizers): it always takes slot 0
+            j = min(range(len(frames)), key=lambda i: frames[i].fid)
+            if j != len(frames) - 1:
+                frames = [frames[j]] + frames[:j] + frames[j + 1:]
+        if slot is None:
+            sfs = []
+            for i, f in enumerate(frames):
+                sf = Frame(i - len(frames), f.rgb, f.depth,
+                           init_pose=f.get_pose().detach().cpu().numpy(),
+                           gt_pose=None, separate_LR=f.separate_LR,
+                           rot_rep=f.rot_rep, device=str(dev))
+                fd, fc = f.device_images(dev)
+                sf._dev_cache = (torch.empty_like(fd), torch.empty_like(fc))
+                sfs.append(sf)
+            slot = slots[key] = {'frames': sfs, 'opt': None, 'graphs': {}}
+        slot['calls'] = slot.get('calls', 0) + 1
+        self._last_map_slot_key = key
+        sfs = slot['frames']
+        with torch.no_grad():
+            for sf, f in zip(sfs, frames):
+                fd, fc = f.device_images(dev)
+                sd, sc = sf._dev_cache
+                sd.copy_(fd, non_blocking=True)
+                sc.copy_(fc, non_blocking=True)
+                for ps, pf in zip(sf.get_params(), f.get_params()):
+                    ps.copy_(pf.detach().to(ps.device))
+        self.pre_precessing(sfs[-1], True)
+        first = slot['opt'] is None
+        if first:
+            slot['opt'] = self.setup_optimizers(n_iters, sfs, True,
+                                                coarse=coarse)
+            slot['opt'].allreduce = False
+            if not self._graphs_ok(slot['opt'], True):
+                slot['unusable'] = True
+                return False
+        else:
+            self.refresh_map_selection()
+            for opt in slot['opt'].optimizers.values():
+                reset_optimizer_state(opt)
+        opt, graphs = slot['opt'], slot['graphs']
+        self.fixed_shape_batches = True
+        if first:
+            seg_key, seg_iter = None, 0
+            for step in range(n_iters):
+                k = self.graph_segment_key(True, step, n_iters, coarse)
+                if k != seg_key:
+                    seg_key, seg_iter = k, 0
+                if seg_iter == 0:
+                    self._iteration(opt, sfs, True, step, n_iters, coarse,
+                                    None)
+                elif k not in graphs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._iteration(opt, sfs, True, step, n_iters, coarse,
+                                        None)
+                    graphs[k] = g
+                    g.replay()
+                else:
+                    graphs[k].replay()
+                seg_iter += 1
+                opt.scheduler_step_all()
+            segs = {self.graph_segment_key(True, s, n_iters, coarse)
+                    for s in range(n_iters)}
+            if segs - set(graphs):
+                # a one-iteration segment was never captured: replay-only
+                # calls are impossible, use the ordinary path from now on
+                slot['unusable'] = True
+        else:
+            for step in range(n_iters):
+                graphs[self.graph_segment_key(True, step, n_iters,
+                                              coarse)].replay()
+        self.fixed_shape_batches = False
+        if self.bundle_adjust:
+            with torch.no_grad():
+                for sf, f in zip(sfs, frames):
+                    for ps, pf in zip(sf.get_params(), f.get_params()):
+                        pf.copy_(ps.detach().to(pf.device))
+        return True
+
+    def refresh_map_selection(self):
+        """replay-only mapping call: re-select what get_param_groups selected
+        when the slot's optimisers were built (model hook)"""
+        sel = getattr(self.model, 'select_cells', None)
+        if sel is not None:
+            sel()
+
     def optimize_update(self, n_iters, optimize_frames, is_mapping,
                         coarse=False):
         with self.lock:
@@ -355,6 +486,14 @@ class Algorithm:
                         for k in self.config.optimizers if
                         k.startswith('tracking_pose')):
                 return self._track_slot_run(n_iters, optimize_frames[0])
+            if is_mapping and self.use_graphs and self.persistent_map_graph \
+                    and not _dist.state.enabled and self.is_initialized() \
+                    and torch.device(self.device).type == 'cuda':
+                key = self.map_slot_key(n_iters, optimize_frames, coarse)
+                if key is not None and self._map_slot_run(
+                        key, n_iters, optimize_frames, coarse):
+                    self.after_mapping_update()
+                    return None
             self.pre_precessing(optimize_frames[-1], is_mapping)
             optimizers = self.setup_optimizers(n_iters, optimize_frames,
                                                is_mapping, coarse=coarse)
@@ -435,7 +574,10 @@ class Algorithm:
                                     step, n_iters, coarse, track)
                 optimizers.scheduler_step_all()
             self.fixed_shape_batches = False
-            if is_mapping or not bool(track['valid'].item()):
+            if is_mapping:
+                self.after_mapping_update()
+                return None
+            if not bool(track['valid'].item()):
                 return None
             return track['c2w'].cpu().numpy()
 

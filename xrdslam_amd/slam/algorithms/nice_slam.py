@@ -79,6 +79,24 @@ class NiceSLAM(Algorithm):
         if not self.is_initialized():
             self.set_initialized()
 
+    # the mapping work of a call depends on the window only through data that
+    # fits static buffers (images, poses, cell selection): keep its graphs
+    persistent_map_graph = True
+
+    def map_slot_key(self, n_iters, optimize_frames, coarse):
+        cfg, m, f = self.config, self.model.config, optimize_frames[-1]
+        ba = len(self.keyframe_graph) > 4 and not coarse and \
+            len(optimize_frames) > 1
+        return (len(optimize_frames), ba, n_iters, bool(coarse), f.h, f.w,
+                f.separate_LR, f.rot_rep, cfg.mapping_middle_iter_ratio,
+                cfg.mapping_fine_iter_ratio, cfg.mapping_sample,
+                cfg.min_sample_pixels, cfg.mapping_lr_factor,
+                m.mapping_fix_color, m.mapping_frustum_feature_selection)
+
+    def after_mapping_update(self):
+        # the tracking graph reads the packed decoder weights in place
+        self.model.sync_decoders(force=True)
+
     def optimizer_config_update(self, max_iters, coarse=False):
         """nice_slam.py:114-132: BA once >4 keyframes (never in the coarse
         pass); base LR = lr factor (x5 before initialisation, except poses);

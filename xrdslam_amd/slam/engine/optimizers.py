@@ -85,6 +85,10 @@ class FusedCellAdam(torch.optim.Optimizer):
         if not getattr(p, '_xrd_grad_fresh', False) or p.grad is None:
             return
         cells = p._xrd_cells
+        # static selection (persistent mapping graphs): ``cells`` is a buffer
+        # with room for every cell, the valid count lives on the device
+        count = getattr(p, '_xrd_cells_count', None) if cells is not None \
+            else None
         cf = p.shape[1]
         n = int(cells.numel()) if cells is not None else p.numel() // cf
         if self._m is None:
@@ -94,6 +98,16 @@ class FusedCellAdam(torch.optim.Optimizer):
                                          device=p.device)
         self._step_dev += 1  # on the stream: replayable from a hipGraph
         b1, b2 = grp['betas']
+        if count is not None:
+            _lib.check(_lib.lib().xrd_adam_cells_devcount(
+                _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
+                _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
+                float(b1), float(b2), float(grp['eps']),
+                _lib.ptr(self._step_dev), _lib.ptr(count), 1,
+                _lib.stream_ptr(p.device)), 'xrd_adam_cells_devcount')
+            if not torch.cuda.is_current_stream_capturing():
+                p._xrd_grad_fresh = False
+            return
         _lib.check(_lib.lib().xrd_adam_cells_devstep(
             _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
             _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
@@ -101,6 +115,20 @@ class FusedCellAdam(torch.optim.Optimizer):
             1, _lib.stream_ptr(p.device)), 'xrd_adam_cells_devstep')
         if not torch.cuda.is_current_stream_capturing():
             p._xrd_grad_fresh = False
+
+
+def reset_optimizer_state(opt: torch.optim.Optimizer) -> None:
+    """back to the state of a freshly built optimiser, keeping every tensor
+    (and its address: the launches may live in a captured hipGraph)"""
+    if isinstance(opt, FusedCellAdam):
+        for t in (opt._m, opt._v, opt._step_dev):
+            if t is not None:
+                t.zero_()
+        return
+    for st in opt.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
 
 
 class Optimizers:

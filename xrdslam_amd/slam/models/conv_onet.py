@@ -184,12 +184,23 @@ class ConvOnet(Model):
                 sc.set_grid(key, g)
             self._scene = sc
             self._packed_version = {}
+        self.sync_decoders()
+        return self._scene
+
+    def sync_decoders(self, force: bool = False):
+        """re-pack (in place) the MFMA weight layout of every decoder whose
+        flat parameter changed: torch's version counter for torch ops, the
+        ``_xrd_steps`` counter for the fused Adam kernel (raw-pointer writes).
+        Inside a captured iteration this records the re-pack at the start of
+        the iteration; ``force`` is for the end of a mapping call, where the
+        last step (or a replayed graph) is invisible to both counters."""
+        if self._scene is None:
+            return
         for kind, dec in self.decoder.decoders().items():
-            ver = dec.flat._version
-            if self._packed_version.get(kind) != ver:
+            ver = (dec.flat._version, getattr(dec.flat, '_xrd_steps', 0))
+            if force or self._packed_version.get(kind) != ver:
                 self._scene.set_decoder(kind, dec.flat)
                 self._packed_version[kind] = ver
-        return self._scene
 
     # -- frustum feature selection ----------------------------------------
     def pre_precessing(self, cur_frame):
@@ -235,18 +246,50 @@ class ConvOnet(Model):
             dec_params.append(self.decoder.color_decoder.flat)
         if dec_params:
             groups['decoder'] = dec_params
+        self.select_cells()
+        for key, g in self.grid_c.items():
+            groups[key] = [g]
+        return groups
+
+    static_selection = False
+
+    def select_cells(self):
+        """hand the frustum selection (pre_precessing) to the kernels: the
+        list of selected cells for the fused Adam, the byte mask for the
+        render backward.  With ``static_selection`` both live in buffers that
+        keep their address from one mapping call to the next (capacity = all
+        cells, valid count on the device), so that launches captured in a
+        hipGraph can be replayed for a new selection."""
+        sc = self.scene()
         sel = self.config.mapping_frustum_feature_selection
         for key, g in self.grid_c.items():
             mask = self.grid_opti_mask.get(key) if sel else None
             if mask is None:
-                g._xrd_cells = None
+                g._xrd_cells = g._xrd_cells_count = None
                 sc.gmask[key] = None
-            else:
-                flat = mask.reshape(-1)
-                g._xrd_cells = flat.nonzero().reshape(-1).int()
+                continue
+            flat = mask.reshape(-1)
+            idx = flat.nonzero().reshape(-1).int()
+            if not self.static_selection:
+                g._xrd_cells, g._xrd_cells_count = idx, None
                 sc.gmask[key] = flat.to(torch.uint8).contiguous()
-            groups[key] = [g]
-        return groups
+                continue
+            if not hasattr(self, '_sel_static'):
+                self._sel_static = {}
+            st = self._sel_static.get(key)
+            if st is None:
+                st = self._sel_static[key] = {
+                    'cells': torch.zeros(flat.numel(), dtype=torch.int32,
+                                         device=flat.device),
+                    'count': torch.zeros(1, dtype=torch.int32,
+                                         device=flat.device),
+                    'mask': torch.zeros(flat.numel(), dtype=torch.uint8,
+                                        device=flat.device)}
+            st['cells'][:idx.numel()].copy_(idx)
+            st['count'].fill_(idx.numel())
+            st['mask'].copy_(flat)
+            g._xrd_cells, g._xrd_cells_count = st['cells'], st['count']
+            sc.gmask[key] = st['mask']
 
     # -- forward / loss ----------------------------------------------------
     def get_outputs(self, input) -> Dict[str, Union[torch.Tensor, List]]:

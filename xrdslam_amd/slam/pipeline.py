@@ -76,6 +76,9 @@ class SequentialSLAM:
                       gt_pose=gt_c2w, init_pose=init,
                       separate_LR=alg.is_separate_LR(),
                       rot_rep=alg.get_rot_rep(), device=self.pose_device)
+        if 'depth_dev' in data:
+            # images already resident in HBM (device-resident frame store)
+            frame._dev_cache = (data['depth_dev'], data['rgb_dev'])
         t0 = time.perf_counter()
         cand = alg.do_tracking(frame)
         cand = self._sync_pose(cand)
