@@ -701,11 +701,25 @@ def main():
     barrier()
     t0 = time.perf_counter()
     stamps = []
+    frame = None
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
-        slam.step(k)
+        frame = slam.step(k)
         stamps.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    ate = slam.ate_rmse()
+    if world == 1 and frame is not None:
+        # launches inside replayed hipGraphs cannot be event-timed one by one,
+        # and with mapping graphs kept across calls the timed region holds
+        # few eager launches: right after it, five mapping calls with
+        # per-call capture (same shapes, first iteration of every stage
+        # segment eager) feed the per-launch statistics
+        keep = algo.persistent_map_graph
+        algo.persistent_map_graph = False
+        for _ in range(5):
+            algo.do_mapping(frame)
+        torch.cuda.synchronize()
+        algo.persistent_map_graph = keep
     if os.environ.get('XRD_BENCH_TRACE'):   # host-side time per frame
         print('frame ms:', ' '.join(
             f'{k + 1 + args.warmup}:{(b - a) * 1e3:.1f}' for k, (a, b) in
@@ -758,8 +772,13 @@ def main():
                       f'grid_grad={int(grid_grads)}]',
             'avg_launch_us': avg_ms * 1e3, 'launches': calls,
             'algorithmic_bytes_per_launch': abytes,
-            'share_of_kernel_time': total_ms / sum(s[0] for s in stats),
-            'kernel_time_ms_per_step': sum(s[0] for s in stats) / args.steps,
+            'share_of_event_timed_time': total_ms / sum(s[0] for s in stats),
+            'timing_source': 'HIP events around eager launches on the launch '
+                             'stream: first iteration of each stage segment '
+                             'of mapping graphs captured in the timed region '
+                             '+ 5 per-call-capture mapping calls right after '
+                             'it (same shapes); replayed graph nodes are not '
+                             'event-timed',
         }
         cpu = torch_gpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -787,7 +806,7 @@ def main():
                 'map_ms_per_frame': slam.t_map / args.steps * 1e3,
                 'render_img_ms': render_img_ms(algo, data,
                                                args.warmup + args.steps, dev),
-                'ate_rmse_m': slam.ate_rmse()},
+                'ate_rmse_m': ate},
             'roofline': roofline, 'cpu_baseline': cpu,
             # the oracle's unfused torch ops on this GPU (a second baseline,
             # not a product path)
