@@ -351,6 +351,33 @@ int xrd_sample_rays(int n, int image_width, int h0, int w0, int crop_width,
                     const float* c2w, float* rays_o, float* rays_d,
                     float* tgt_d, float* tgt_rgb, uint8_t* keep, float* dmax,
                     xrd_stream_t stream);
+/* the same for the n_frames (<= 16) frames of a mapping window in ONE launch,
+ * poses given as parameters: pose_t[f] -> t[3], pose_q[f] -> quaternion
+ * (r,i,j,k) of frame f (host arrays of device pointers; OptimizablePose with
+ * rot_rep 'quat', slam/utils/opt_pose.py:51-69).  crop_idx [n_frames*n], all
+ * outputs frame-major [n_frames*n, ...]; c2w_out [n_frames*16] receives the
+ * matrices.  Equals n_frames x (xrd_pose_quat_fwd + xrd_sample_rays) up to
+ * the last ulp of rays_d (the matrix stays in registers). */
+int xrd_sample_rays_multi(int n_frames, int n, int image_width, int h0, int w0,
+                          int crop_width, float fx, float fy, float cx,
+                          float cy, const double* bound6,
+                          const int64_t* crop_idx,
+                          const float* const* depth_imgs,
+                          const float* const* rgb_imgs,
+                          const float* const* pose_t,
+                          const float* const* pose_q, float* c2w_out,
+                          float* rays_o, float* rays_d, float* tgt_d,
+                          float* tgt_rgb, uint8_t* keep, float* dmax,
+                          xrd_stream_t stream);
+/* g_pose [n_frames*7] = per frame [d/dt (3), d/dq (4)]: pose-parameter
+ * gradients (= xrd_sample_rays_bwd followed by xrd_pose_quat_bwd, per frame) */
+int xrd_sample_rays_multi_bwd(int n_frames, int n, int image_width, int h0,
+                              int w0, int crop_width, float fx, float fy,
+                              float cx, float cy, const int64_t* crop_idx,
+                              const float* const* pose_t,
+                              const float* const* pose_q,
+                              const float* g_rays_o, const float* g_rays_d,
+                              float* g_pose, xrd_stream_t stream);
 /* g_c2w[16] = d loss / d c2w from the ray gradients (rotation via rays_d,
  * translation via rays_o) */
 int xrd_sample_rays_bwd(int n, int image_width, int h0, int w0, int crop_width,

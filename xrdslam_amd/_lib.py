@@ -100,6 +100,10 @@ _SIGS = {
                                  C.c_int, f32, vp, vp, vp]),
     'xrd_sample_rays': (C.c_int, [C.c_int] * 5 + [f32] * 4 + [vp] * 12),
     'xrd_sample_rays_bwd': (C.c_int, [C.c_int] * 5 + [f32] * 4 + [vp] * 5),
+    'xrd_sample_rays_multi': (C.c_int,
+                              [C.c_int] * 6 + [f32] * 4 + [vp] * 14),
+    'xrd_sample_rays_multi_bwd': (C.c_int,
+                                  [C.c_int] * 6 + [f32] * 4 + [vp] * 7),
     'xrd_nice_loss': (C.c_int, [C.c_int] * 4 + [f32] + [vp] * 10),
     'xrd_pose_quat_fwd': (C.c_int, [vp] * 4),
     'xrd_pose_quat_bwd': (C.c_int, [vp] * 5),

@@ -204,10 +204,9 @@ __global__ __launch_bounds__(1024) void nice_loss_kernel(
 // -------------------------------------------------------------------- pose
 // c2w[16] (row-major 4x4) from translation t[3] and quaternion q=(r,i,j,k),
 // R = I + s*B(q), s = 2/|q|^2 (opt_pose.py:69 via pytorch3d quaternion_to_matrix)
-__global__ void pose_quat_fwd_kernel(const float* __restrict__ t,
-                                     const float* __restrict__ q,
-                                     float* __restrict__ c2w) {
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void quat_to_c2w(const float* __restrict__ t,
+                                            const float* __restrict__ q,
+                                            float* __restrict__ c2w) {
   const float r = q[0], i = q[1], j = q[2], k = q[3];
   const float s = 2.f / (r * r + i * i + j * j + k * k);
   const float R[9] = {1 - s * (j * j + k * k), s * (i * j - k * r), s * (i * k + j * r),
@@ -221,11 +220,17 @@ __global__ void pose_quat_fwd_kernel(const float* __restrict__ t,
   c2w[15] = 1.f;
 }
 
-__global__ void pose_quat_bwd_kernel(const float* __restrict__ q,
-                                     const float* __restrict__ g_c2w,
-                                     float* __restrict__ g_t,
-                                     float* __restrict__ g_q) {
+__global__ void pose_quat_fwd_kernel(const float* __restrict__ t,
+                                     const float* __restrict__ q,
+                                     float* __restrict__ c2w) {
   if (threadIdx.x != 0) return;
+  quat_to_c2w(t, q, c2w);
+}
+
+__device__ __forceinline__ void quat_c2w_bwd(const float* __restrict__ q,
+                                             const float* __restrict__ g_c2w,
+                                             float* __restrict__ g_t,
+                                             float* __restrict__ g_q) {
   const float r = q[0], i = q[1], j = q[2], k = q[3];
   const float N = r * r + i * i + j * j + k * k, s = 2.f / N;
   float G[3][3];
@@ -252,6 +257,117 @@ __global__ void pose_quat_bwd_kernel(const float* __restrict__ q,
   g_q[1] = s * di + GB * ds * i;
   g_q[2] = s * dj + GB * ds * j;
   g_q[3] = s * dk + GB * ds * k;
+}
+
+__global__ void pose_quat_bwd_kernel(const float* __restrict__ q,
+                                     const float* __restrict__ g_c2w,
+                                     float* __restrict__ g_t,
+                                     float* __restrict__ g_q) {
+  if (threadIdx.x != 0) return;
+  quat_c2w_bwd(q, g_c2w, g_t, g_q);
+}
+
+// ------------------------------------------------- sampling, F frames at once
+// One launch for the F frames of a mapping window: blockIdx.y = frame.  Every
+// thread rebuilds its frame's c2w from the pose parameters (7 broadcast loads,
+// ~40 flops) with the arithmetic of pose_quat_fwd_kernel; the result equals
+// F x (pose_quat_fwd + sample_rays) up to the last ulp of rays_d.
+constexpr int kMaxFrames = 16;
+struct FramePtrs {
+  const float* depth[kMaxFrames];
+  const float* rgb[kMaxFrames];
+  const float* t[kMaxFrames];
+  const float* q[kMaxFrames];
+};
+
+__global__ __launch_bounds__(256) void sample_rays_multi_kernel(
+    SampleArgs a, FramePtrs fr, const int64_t* __restrict__ idx,
+    float* __restrict__ c2w_out, float* __restrict__ rays_o,
+    float* __restrict__ rays_d, float* __restrict__ tgt_d,
+    float* __restrict__ tgt_rgb, uint8_t* __restrict__ keep,
+    float* __restrict__ dmax) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float c2w[16];
+  quat_to_c2w(fr.t[f], fr.q[f], c2w);
+  if (i == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c2w_out[f * 16 + k] = c2w[k];
+  }
+  if (i >= a.n) return;
+  const int64_t g = (int64_t)f * a.n + i;
+  const int64_t k = idx[g];
+  const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
+  const int64_t pix = (int64_t)row * a.W + col;
+  const float d = fr.depth[f][pix];
+  const float dir[3] = {((float)col - a.cx) / a.fx, -((float)row - a.cy) / a.fy,
+                        -1.f};
+  float o[3], rd[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rd[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] +
+            dir[2] * c2w[r * 4 + 2];
+    o[r] = c2w[r * 4 + 3];
+    rays_o[g * 3 + r] = o[r];
+    rays_d[g * 3 + r] = rd[r];
+    tgt_rgb[g * 3 + r] = fr.rgb[f][pix * 3 + r];
+  }
+  tgt_d[g] = d;
+  double t_exit = 1e300;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double t0 = (a.bound[2 * r] - (double)o[r]) / (double)rd[r];
+    const double t1 = (a.bound[2 * r + 1] - (double)o[r]) / (double)rd[r];
+    t_exit = fmin(t_exit, fmax(t0, t1));
+  }
+  const bool kp = t_exit >= (double)d;
+  keep[g] = kp ? 1 : 0;
+  if (kp && d > 0.f && dmax)
+    atomicMax(reinterpret_cast<int*>(dmax), __float_as_int(d));
+}
+
+// block f: g_c2w of frame f (like sample_rays_bwd_kernel), then its pose
+// parameter gradients g_pose[f] = [g_t(3), g_q(4)]
+__global__ __launch_bounds__(256) void sample_rays_multi_bwd_kernel(
+    SampleArgs a, FramePtrs fr, const int64_t* __restrict__ idx,
+    const float* __restrict__ g_o, const float* __restrict__ g_d,
+    float* __restrict__ g_pose) {
+  __shared__ float red[4][12];
+  __shared__ float gc[16];
+  const int f = blockIdx.x;
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (int i = threadIdx.x; i < a.n; i += 256) {
+    const int64_t g = (int64_t)f * a.n + i;
+    const int64_t k = idx[g];
+    const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
+    const float dir[3] = {((float)col - a.cx) / a.fx,
+                          -((float)row - a.cy) / a.fy, -1.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float gd = g_d[g * 3 + r];
+      acc[r * 4 + 0] += gd * dir[0];
+      acc[r * 4 + 1] += gd * dir[1];
+      acc[r * 4 + 2] += gd * dir[2];
+      acc[r * 4 + 3] += g_o[g * 3 + r];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int k = threadIdx.x;
+    gc[k] = k < 12 ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    quat_c2w_bwd(fr.q[f], gc, g_pose + f * 7, g_pose + f * 7 + 3);
 }
 
 // -------------------------------------------------------------------- adam
@@ -526,6 +642,69 @@ int xrd_sample_rays_bwd(int n, int image_width, int h0, int w0, int crop_width,
                      (hipStream_t)stream, a, crop_idx, g_rays_o, g_rays_d,
                      g_c2w);
   return check_launch("xrd_sample_rays_bwd");
+}
+
+static bool fill_frames(FramePtrs& fr, int F, const float* const* depth,
+                        const float* const* rgb, const float* const* t,
+                        const float* const* q, bool need_images) {
+  for (int f = 0; f < F; ++f) {
+    if (!t[f] || !q[f]) return false;
+    if (need_images && (!depth[f] || !rgb[f])) return false;
+    fr.depth[f] = need_images ? depth[f] : nullptr;
+    fr.rgb[f] = need_images ? rgb[f] : nullptr;
+    fr.t[f] = t[f];
+    fr.q[f] = q[f];
+  }
+  return true;
+}
+
+int xrd_sample_rays_multi(int n_frames, int n, int image_width, int h0, int w0,
+                          int crop_width, float fx, float fy, float cx,
+                          float cy, const double* bound6,
+                          const int64_t* crop_idx,
+                          const float* const* depth_imgs,
+                          const float* const* rgb_imgs,
+                          const float* const* pose_t,
+                          const float* const* pose_q, float* c2w_out,
+                          float* rays_o, float* rays_d, float* tgt_d,
+                          float* tgt_rgb, uint8_t* keep, float* dmax,
+                          xrd_stream_t stream) {
+  if (n_frames < 1 || n < 1 || image_width < 1 || crop_width < 1 || !bound6 ||
+      !crop_idx || !depth_imgs || !rgb_imgs || !pose_t || !pose_q ||
+      !c2w_out || !rays_o || !rays_d || !tgt_d || !tgt_rgb || !keep)
+    return XRD_ERR_ARG;
+  if (n_frames > kMaxFrames) return XRD_ERR_UNSUPPORTED;
+  FramePtrs fr{};
+  if (!fill_frames(fr, n_frames, depth_imgs, rgb_imgs, pose_t, pose_q, true))
+    return XRD_ERR_ARG;
+  SampleArgs a{n, image_width, h0, w0, crop_width, fx, fy, cx, cy, {}};
+  for (int k = 0; k < 6; ++k) a.bound[k] = bound6[k];
+  hipLaunchKernelGGL(sample_rays_multi_kernel,
+                     dim3((n + 255) / 256, n_frames), dim3(256), 0,
+                     (hipStream_t)stream, a, fr, crop_idx, c2w_out, rays_o,
+                     rays_d, tgt_d, tgt_rgb, keep, dmax);
+  return check_launch("xrd_sample_rays_multi");
+}
+
+int xrd_sample_rays_multi_bwd(int n_frames, int n, int image_width, int h0,
+                              int w0, int crop_width, float fx, float fy,
+                              float cx, float cy, const int64_t* crop_idx,
+                              const float* const* pose_t,
+                              const float* const* pose_q,
+                              const float* g_rays_o, const float* g_rays_d,
+                              float* g_pose, xrd_stream_t stream) {
+  if (n_frames < 1 || n < 1 || crop_width < 1 || !crop_idx || !pose_t ||
+      !pose_q || !g_rays_o || !g_rays_d || !g_pose)
+    return XRD_ERR_ARG;
+  if (n_frames > kMaxFrames) return XRD_ERR_UNSUPPORTED;
+  FramePtrs fr{};
+  if (!fill_frames(fr, n_frames, nullptr, nullptr, pose_t, pose_q, false))
+    return XRD_ERR_ARG;
+  SampleArgs a{n, image_width, h0, w0, crop_width, fx, fy, cx, cy, {}};
+  hipLaunchKernelGGL(sample_rays_multi_bwd_kernel, dim3(n_frames), dim3(256),
+                     0, (hipStream_t)stream, a, fr, crop_idx, g_rays_o,
+                     g_rays_d, g_pose);
+  return check_launch("xrd_sample_rays_multi_bwd");
 }
 
 int xrd_nice_loss(int n, int is_mapping, int use_color, int handle_dynamic,

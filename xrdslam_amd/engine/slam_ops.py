@@ -143,6 +143,75 @@ class SampleRaysFn(torch.autograd.Function):
         return g_c2w, None, None, None, None, None, None
 
 
+class SampleRaysPosesFn(torch.autograd.Function):
+    """SampleRaysFn with the poses given as PARAMETERS (quaternion poses): one
+    launch builds the F camera matrices and samples the F frames, one launch
+    returns the pose-parameter gradients.  ``pose_params``: per frame either
+    one tensor data[7] = [t, q] or two tensors (t[3], q[4]), flattened in
+    frame order; ``layout`` says which ('7' or 'tq') per frame."""
+
+    @staticmethod
+    def forward(ctx, idx, depth_imgs, rgb_imgs, cam, crop, bound6, layout,
+                *pose_params):
+        lib = _lib.lib()
+        F, n = idx.shape
+        dev = idx.device
+        N = F * n
+        tp, qp, k = [], [], 0
+        for lay in layout:
+            if lay == '7':
+                d = pose_params[k]
+                tp.append(d.data_ptr())
+                qp.append(d.data_ptr() + 12)
+                k += 1
+            else:
+                tp.append(pose_params[k].data_ptr())
+                qp.append(pose_params[k + 1].data_ptr())
+                k += 2
+        arr = C.c_void_p * F
+        tp, qp = arr(*tp), arr(*qp)
+        dp = arr(*[t.data_ptr() for t in depth_imgs])
+        cp = arr(*[t.data_ptr() for t in rgb_imgs])
+        ro = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        rd = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        td = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        tc = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        keep = torch.empty(N, dtype=torch.uint8, device=dev)
+        dmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        c2ws = torch.empty(F, 4, 4, dtype=torch.float32, device=dev)
+        H0, W0, wcrop = crop
+        b6 = (C.c_double * 6)(*bound6)
+        _lib.check(lib.xrd_sample_rays_multi(
+            F, n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
+            b6, _lib.ptr(idx), dp, cp, tp, qp, _lib.ptr(c2ws), _lib.ptr(ro),
+            _lib.ptr(rd), _lib.ptr(td), _lib.ptr(tc), _lib.ptr(keep),
+            _lib.ptr(dmax), _lib.stream_ptr(dev)), 'xrd_sample_rays_multi')
+        ctx.args = (cam, crop, F, n, layout, tp, qp)
+        ctx.save_for_backward(idx, *pose_params)
+        ctx.mark_non_differentiable(td, tc, keep, dmax)
+        return ro, rd, td, tc, keep, dmax
+
+    @staticmethod
+    def backward(ctx, g_ro, g_rd, *unused):
+        lib = _lib.lib()
+        idx = ctx.saved_tensors[0]
+        cam, (H0, W0, wcrop), F, n, layout, tp, qp = ctx.args
+        dev = idx.device
+        g7 = torch.empty(F, 7, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_sample_rays_multi_bwd(
+            F, n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
+            _lib.ptr(idx), tp, qp, _lib.ptr(g_ro.float().contiguous()),
+            _lib.ptr(g_rd.float().contiguous()), _lib.ptr(g7),
+            _lib.stream_ptr(dev)), 'xrd_sample_rays_multi_bwd')
+        grads = []
+        for f, lay in enumerate(layout):   # views of g7: no launches
+            if lay == '7':
+                grads.append(g7[f])
+            else:
+                grads.extend([g7[f, :3], g7[f, 3:]])
+        return (None, None, None, None, None, None, None, *grads)
+
+
 class NiceLossFn(torch.autograd.Function):
     """scalar loss of ConvOnet.get_loss_dict (sum of its terms), f64"""
 

@@ -212,21 +212,36 @@ class NiceSLAM(Algorithm):
             gen = _dist.state.shard_generator
         wcrop = cam.width - 2 * Wedge
         cnt = (cam.height - 2 * Hedge) * wcrop
-        idx = torch.stack([torch.randint(cnt, (n_pix, ), device=dev,
-                                         generator=gen)
-                           for _ in optimize_frames])
-        poses = []
-        for f in optimize_frames:
-            c2w = f.get_pose()
-            if is_mapping and not self.bundle_adjust:
-                c2w = c2w.detach()
-            poses.append(c2w.to(dev))
-        c2ws = torch.stack(poses) if len(poses) > 1 else poses[0].unsqueeze(0)
+        F = len(optimize_frames)
+        if self.batched_draws:
+            idx = torch.randint(cnt, (F, n_pix), device=dev, generator=gen)
+        else:
+            # one draw per frame, like get_model_input (the parity tests
+            # compare both paths on equal draws)
+            idx = torch.stack([torch.randint(cnt, (n_pix, ), device=dev,
+                                             generator=gen)
+                               for _ in optimize_frames])
         imgs = [f.device_images(dev) for f in optimize_frames]
         bound6 = self.bounding_box.reshape(-1).tolist()
-        ro, rd, td, tc, keep, dmax = slam_ops.SampleRaysFn.apply(
-            c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
-            (Hedge, Wedge, wcrop), bound6)
+        detach = is_mapping and not self.bundle_adjust
+        quat = self._quat_pose_params(optimize_frames, dev, detach)
+        if quat is not None:
+            # poses as parameters: matrices + sampling of all frames in ONE
+            # launch (and one for the pose gradients)
+            ro, rd, td, tc, keep, dmax = slam_ops.SampleRaysPosesFn.apply(
+                idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
+                (Hedge, Wedge, wcrop), bound6, quat[0], *quat[1])
+        else:
+            poses = []
+            for f in optimize_frames:
+                c2w = f.get_pose()
+                if detach:
+                    c2w = c2w.detach()
+                poses.append(c2w.to(dev))
+            c2ws = torch.stack(poses) if F > 1 else poses[0].unsqueeze(0)
+            ro, rd, td, tc, keep, dmax = slam_ops.SampleRaysFn.apply(
+                c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
+                (Hedge, Wedge, wcrop), bound6)
         stage = self.stage
         depth, var, rgb = _en.nice_render(
             self.model.scene(), stage, ro, rd,
@@ -241,6 +256,27 @@ class NiceSLAM(Algorithm):
                                          mcfg.tracking_handle_dynamic, w)
 
     fused_iteration = True  # use the fused launches when the batch shape is fixed
+    batched_draws = True    # one randint launch for the whole window
+
+    @staticmethod
+    def _quat_pose_params(frames, dev, detach):
+        """(layout, parameter tensors) for SampleRaysPosesFn, or None when a
+        frame's pose is not a float32 quaternion pose on ``dev``"""
+        if len(frames) > 16:
+            return None
+        layout, params = [], []
+        for f in frames:
+            pose = f.pose
+            if pose is None or pose.rot_rep != 'quat':
+                return None
+            ps = [pose.data_t, pose.data_q] if pose.separate_LR \
+                else [pose.data]
+            if any(p.device != torch.device(dev) or p.dtype != torch.float32
+                   or not p.is_contiguous() for p in ps):
+                return None
+            layout.append('tq' if pose.separate_LR else '7')
+            params += [p.detach() for p in ps] if detach else ps
+        return tuple(layout), params
 
     def get_loss(self, optimize_frames, is_mapping, step, n_iters,
                  coarse=False):
