@@ -673,6 +673,8 @@ def main():
     cam = Camera(**CAM)
     algo = cfg.setup(camera=cam, device=str(dev))
     algo.use_graphs = not args.no_graphs
+    if os.environ.get('XRD_PERSISTENT_SHARDED') == '0':   # A/B switch
+        algo.persistent_map_graph_sharded = False
     xdist.state.setup(dev, seed=0)
     n_frames = args.warmup + args.steps + 1
     data = SyntheticRoom(BOUND, H=cam.height, W=cam.width, fx=cam.fx,
@@ -708,12 +710,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ate = slam.ate_rmse()
-    if world == 1 and frame is not None:
+    if frame is not None:
         # launches inside replayed hipGraphs cannot be event-timed one by one,
         # and with mapping graphs kept across calls the timed region holds
         # few eager launches: right after it, five mapping calls with
         # per-call capture (same shapes, first iteration of every stage
-        # segment eager) feed the per-launch statistics
+        # segment eager) feed the per-launch statistics (every rank takes
+        # part: the sharded mapping calls all-reduce)
         keep = algo.persistent_map_graph
         algo.persistent_map_graph = False
         for _ in range(5):
@@ -737,6 +740,9 @@ def main():
             ms = [a.elapsed_time(b) for a, b in evs]
             stats.append((sum(ms), key, len(ms), sum(ms) / len(ms)))
         stats.sort(reverse=True)
+        if not stats:
+            raise SystemExit('bench.py: no event-timed launches (PROFILE '
+                             'hooks not reached)')
         total_ms, key, calls, avg_ms = stats[0]
         kernel, stage, n_rays, need_pose, need_dec, grid_grads = key
         abytes = algorithmic_bytes(kernel, stage, n_rays, grid_grads)

@@ -72,11 +72,28 @@ def collect_grad_jobs(param_groups):
                 if not getattr(p, '_xrd_grad_fresh', False):
                     continue
                 g = p.grad.permute(0, 2, 3, 4, 1).reshape(-1, p.shape[1])
-                cells = p._xrd_cells
-                cell_jobs.append((g, None if cells is None else cells.long()))
+                cell_jobs.append((g, _selected_cells(p), p))
             else:
                 dense.append(p.grad)
     return dense, cell_jobs
+
+
+def _selected_cells(p):
+    cells = p._xrd_cells
+    if cells is None:
+        return None
+    if getattr(p, '_xrd_cells_count', None) is not None:
+        # static selection buffer (capacity = all cells): the host knows how
+        # many entries the current mapping call selected
+        cells = cells[:p._xrd_cells_n]
+    return cells.long()
+
+
+def refresh_grad_jobs(jobs):
+    """a job list kept with a persistent mapping graph, for a new mapping
+    call: same gradient tensors, the call's own cell selection"""
+    dense, cell_jobs = jobs
+    return dense, [(g, _selected_cells(p), p) for g, _, p in cell_jobs]
 
 
 def run_grad_jobs(jobs) -> None:
@@ -84,9 +101,9 @@ def run_grad_jobs(jobs) -> None:
     if not state.enabled:
         return
     dense, cell_jobs = jobs
-    sels = [g if cells is None else g[cells] for g, cells in cell_jobs]
+    sels = [g if cells is None else g[cells] for g, cells, _ in cell_jobs]
     allreduce_bucket(list(dense) + sels)
-    for (g, cells), sel in zip(cell_jobs, sels):
+    for (g, cells, _), sel in zip(cell_jobs, sels):
         if cells is not None:
             g[cells] = sel
 

@@ -218,6 +218,9 @@ class Algorithm:
     # mapping graphs kept from one mapping call to the next (algorithms whose
     # mapping work has call-independent shapes opt in, see _map_slot_run)
     persistent_map_graph = False
+    # ... also when the mapping rays are sharded over ranks (two graphs around
+    # the eager gradient all-reduce, job list refreshed per call)
+    persistent_map_graph_sharded = True
 
     def map_slot_key(self, n_iters, optimize_frames, coarse):
         """everything a captured mapping iteration depends on besides the
@@ -420,7 +423,7 @@ class Algorithm:
         if first:
             slot['opt'] = self.setup_optimizers(n_iters, sfs, True,
                                                 coarse=coarse)
-            slot['opt'].allreduce = False
+            slot['opt'].allreduce = bool(_dist.state.enabled)
             if not self._graphs_ok(slot['opt'], True):
                 slot['unusable'] = True
                 return False
@@ -430,7 +433,57 @@ class Algorithm:
                 reset_optimizer_state(opt)
         opt, graphs = slot['opt'], slot['graphs']
         self.fixed_shape_batches = True
-        if first:
+        split = _dist.state.enabled
+        if first and split:
+            # sharded mapping: [gradient graph] eager all-reduce [step graph]
+            seg_key, seg_iter = None, 0
+            for step in range(n_iters):
+                k = self.graph_segment_key(True, step, n_iters, coarse)
+                if k != seg_key:
+                    seg_key, seg_iter = k, 0
+                if seg_iter == 0:
+                    self._iteration(opt, sfs, True, step, n_iters, coarse,
+                                    None)
+                elif k not in graphs:
+                    ga = torch.cuda.CUDAGraph()
+                    gen = _dist.state.shard_generator
+                    if gen is not None and hasattr(
+                            ga, 'register_generator_state'):
+                        ga.register_generator_state(gen)
+                    with torch.cuda.graph(ga):
+                        self._iteration(opt, sfs, True, step, n_iters, coarse,
+                                        None, part='grad')
+                    ga.replay()
+                    jobs = _dist.collect_grad_jobs(
+                        opt.stepping_parameters(step))
+                    _dist.run_grad_jobs(jobs)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        self._iteration(opt, sfs, True, step, n_iters, coarse,
+                                        None, part='step')
+                    gb.replay()
+                    graphs[k] = [ga, jobs, gb]
+                else:
+                    ga, jobs, gb = graphs[k]
+                    ga.replay()
+                    _dist.run_grad_jobs(jobs)
+                    gb.replay()
+                seg_iter += 1
+                opt.scheduler_step_all()
+            segs = {self.graph_segment_key(True, s, n_iters, coarse)
+                    for s in range(n_iters)}
+            if segs - set(graphs):
+                slot['unusable'] = True
+        elif split:
+            for g3 in graphs.values():     # this call's cell selection
+                g3[1] = _dist.refresh_grad_jobs(g3[1])
+            for step in range(n_iters):
+                ga, jobs, gb = graphs[self.graph_segment_key(
+                    True, step, n_iters, coarse)]
+                ga.replay()
+                _dist.run_grad_jobs(jobs)
+                gb.replay()
+        elif first:
             seg_key, seg_iter = None, 0
             for step in range(n_iters):
                 k = self.graph_segment_key(True, step, n_iters, coarse)
@@ -487,7 +540,9 @@ class Algorithm:
                         k.startswith('tracking_pose')):
                 return self._track_slot_run(n_iters, optimize_frames[0])
             if is_mapping and self.use_graphs and self.persistent_map_graph \
-                    and not _dist.state.enabled and self.is_initialized() \
+                    and (not _dist.state.enabled or
+                         self.persistent_map_graph_sharded) \
+                    and self.is_initialized() \
                     and torch.device(self.device).type == 'cuda':
                 key = self.map_slot_key(n_iters, optimize_frames, coarse)
                 if key is not None and self._map_slot_run(

@@ -287,6 +287,7 @@ class ConvOnet(Model):
                                         device=flat.device)}
             st['cells'][:idx.numel()].copy_(idx)
             st['count'].fill_(idx.numel())
+            g._xrd_cells_n = int(idx.numel())
             st['mask'].copy_(flat)
             g._xrd_cells, g._xrd_cells_count = st['cells'], st['count']
             sc.gmask[key] = st['mask']
