@@ -64,3 +64,49 @@ def test_allreduce_param_grads_world2():
         assert torch.equal(cells[~sel], torch.full((9, 32), float(r + 1)))
         assert torch.equal(stale, torch.full_like(stale, 5.0))
     assert not torch.equal(out[0][3], out[1][3])
+
+
+def _worker_static(rank, world, port, out):
+    """a job list kept with a persistent mapping graph: the static selection
+    buffer (capacity = all cells, host-known count) changes between calls"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xrdslam_amd.engine import dist as xd
+    xd.state.setup('cpu', seed=3)
+    grid = torch.zeros(1, 32, 2, 2, 3).contiguous(
+        memory_format=torch.channels_last_3d).requires_grad_(True)
+    grid.grad = torch.zeros_like(grid, memory_format=torch.preserve_format)
+    cells_buf = torch.zeros(12, dtype=torch.int32)
+    grid._xrd_cells = cells_buf
+    grid._xrd_cells_count = torch.zeros(1, dtype=torch.int32)
+    grid._xrd_grad_fresh = True
+    res = []
+    jobs = None
+    for sel in ([1, 7, 8], [0, 2, 3, 4, 11]):
+        grid.grad.fill_(float(rank + 1))
+        cells_buf.zero_()
+        cells_buf[:len(sel)] = torch.tensor(sel, dtype=torch.int32)
+        grid._xrd_cells_n = len(sel)
+        jobs = xd.collect_grad_jobs({'g': [grid]}) if jobs is None \
+            else xd.refresh_grad_jobs(jobs)
+        xd.run_grad_jobs(jobs)
+        res.append(grid.grad.permute(0, 2, 3, 4, 1).reshape(-1, 32).clone())
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_refreshed_grad_jobs_follow_the_static_selection():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_static, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    for r in range(world):
+        for cells, sel in zip(out[r], ([1, 7, 8], [0, 2, 3, 4, 11])):
+            m = torch.zeros(12, dtype=torch.bool)
+            m[sel] = True
+            assert torch.equal(cells[m], torch.full((len(sel), 32), 3.0))
+            assert torch.equal(cells[~m],
+                               torch.full((12 - len(sel), 32), float(r + 1)))
