@@ -161,3 +161,53 @@ def test_synthetic_room_preload_is_transparent():
     item = b[3]
     item['c2w'] = None
     assert b[3]['c2w'] is not None
+
+
+def test_trajectory_evaluation_recovers_a_similarity_transform(tmp_path):
+    """eval.tar round trip and the closed-form alignment (utils/eval_traj.py;
+    pinned against the reference's evaluate_ate in
+    tests/test_reference_host_parity.py)"""
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    from xrdslam_amd.slam.utils import eval_traj as et
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(4, generator=g)
+    q = q / q.norm()
+    w, x, y, z = q.tolist()
+    R = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w),
+                       2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                       2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w),
+                       1 - 2 * (x * x + y * y)]])
+    gt, est = [], []
+    for k in range(25):
+        p = torch.eye(4)
+        p[:3, 3] = torch.tensor([0.1 * k, np.sin(0.3 * k), 0.02 * k * k])
+        gt.append(p)
+        e = torch.eye(4)
+        e[:3, 3] = (R.T @ (p[:3, 3] - torch.tensor([1., 2., 3.]))) / 0.8
+        est.append(e)
+
+    class Algo:
+        def get_gt_c2w_list_ori(self): return gt
+        def get_gt_c2w_list(self): return gt
+        def get_estimate_c2w_list(self): return est
+
+    slam = SequentialSLAM.__new__(SequentialSLAM)
+    slam.algorithm = Algo()
+    st = slam.trajectory_stats(align=True, correct_scale=True)
+    assert st['compared_pose_pairs'] == 25
+    assert st['absolute_translational_error.rmse'] < 1e-6
+    assert abs(st['scale'] - 0.8) < 1e-6
+    assert np.allclose(st['rot'], R.numpy(), atol=1e-6)
+    assert np.allclose(st['trans'], [1., 2., 3.], atol=1e-5)
+    rigid = slam.trajectory_stats(align=True)
+    assert rigid['scale'] == 1.0
+    assert rigid['absolute_translational_error.rmse'] > 1e-3
+    raw = slam.trajectory_stats(align=False)
+    assert abs(raw['absolute_translational_error.rmse'] -
+               slam.ate_rmse()) < 1e-6
+    path = str(tmp_path / 'eval.tar')
+    slam.save_eval_tar(path)
+    again = et.evaluate_eval_tar(path, correct_scale=True)
+    assert abs(again['scale'] - 0.8) < 1e-6

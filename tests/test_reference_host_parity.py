@@ -254,3 +254,59 @@ def test_point_cloud_and_camera_frame_helpers_match_reference():
     assert torch.allclose(a, b, atol=1e-6)
     assert torch.allclose(rh.l1_loss_v1(pts, pts * 0.5),
                           mh.l1_loss_v1(pts, pts * 0.5))
+
+
+def test_trajectory_evaluation_matches_reference(tmp_path):
+    """eval.tar round trip + aligned ATE statistics against the reference's
+    evaluate_ate (its pose->quaternion conversion needs mathutils; the ATE only
+    reads the translations, which are handed over directly)"""
+    import importlib.util
+    import os
+    from xrdslam_amd.slam.utils import eval_traj as et
+    spec = importlib.util.spec_from_file_location(
+        'ref_eval_ate', os.path.join(ref_harness.REF_ROOT, 'scripts', 'utils',
+                                     'eval_ate.py'))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    g = torch.Generator().manual_seed(9)
+    n = 40
+    gt, est = [], []
+    R = _pose(7)[:3, :3]
+    for k in range(n):
+        p = torch.eye(4)
+        p[:3, 3] = torch.tensor([0.05 * k, 0.3 * np.sin(0.2 * k),
+                                 0.1 * np.cos(0.1 * k)])
+        gt.append(p)
+        q = torch.eye(4)
+        q[:3, 3] = 1.07 * (R @ p[:3, 3]) + torch.tensor([0.4, -0.2, 0.1]) + \
+            0.01 * torch.randn(3, generator=g)
+        est.append(q)
+    gt[5] = gt[5].clone()
+    gt[5][0, 0] = float('nan')           # dropped, like convert_poses does
+
+    class Algo:
+        def get_gt_c2w_list_ori(self): return gt
+        def get_gt_c2w_list(self): return gt
+        def get_estimate_c2w_list(self): return est
+
+    path = str(tmp_path / 'eval.tar')
+    et.save_eval_tar(Algo(), n, path)
+    ck = et.load_eval_tar(path)
+    assert int(ck['idx']) == n and len(ck['estimate_c2w_list']) == n
+    keep = [k for k in range(n) if k != 5]
+    for scale in (False, True):
+        mine = et.evaluate_eval_tar(path, correct_scale=scale)
+        first = {i: gt[k][:3, 3].double().numpy() for i, k in enumerate(keep)}
+        second = {i: est[k][:3, 3].double().numpy()
+                  for i, k in enumerate(keep)}
+        want = ref.evaluate_ate(first, second, plot='', correct_scale=scale,
+                                _args=[])
+        assert mine['compared_pose_pairs'] == want['compared_pose_pairs'] == 39
+        for key in ('rmse', 'mean', 'median', 'std', 'min', 'max'):
+            k = 'absolute_translational_error.' + key
+            assert abs(mine[k] - want[k]) < 1e-9, (scale, key)
+        assert np.allclose(mine['rot'], np.asarray(want['rot']), atol=1e-9)
+        assert np.allclose(mine['trans'],
+                           np.asarray(want['trans']).reshape(-1), atol=1e-9)
+        assert abs(mine['scale'] - want['scale']) < 1e-9
+    assert abs(et.evaluate_eval_tar(path, True)['scale'] - 1 / 1.07) < 2e-2

@@ -116,6 +116,23 @@ class SequentialSLAM:
         dist.broadcast(t, src=0)
         return t.cpu().numpy()
 
+    def trajectory_stats(self, align=True, correct_scale=False):
+        """ATE statistics of the frames processed so far, like ds-eval prints
+        them (utils/eval_traj.py); ``align=False`` = ate_rmse()"""
+        from .utils.eval_traj import evaluate_trajectory
+        alg = self.algorithm
+        n = len(alg.get_estimate_c2w_list())
+        return evaluate_trajectory(alg.get_gt_c2w_list(),
+                                   alg.get_estimate_c2w_list(), n,
+                                   correct_scale=correct_scale, align=align)
+
+    def save_eval_tar(self, path):
+        """the trajectory file the reference's tracker leaves in its output
+        directory (tracker.py:411-420)"""
+        from .utils.eval_traj import save_eval_tar
+        save_eval_tar(self.algorithm,
+                      len(self.algorithm.get_estimate_c2w_list()), path)
+
     def ate_rmse(self):
         """translation RMSE between estimated and GT poses (no alignment: the
         synthetic runs start from the GT pose of frame 0)"""
