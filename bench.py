@@ -12,12 +12,17 @@ x 200 rays per frame; every 5th frame a mapping call of 60 iterations x 1000
 rays (stages middle/fine/color) + 60 coarse iterations; 48 samples per ray.
 A STEP = one frame (tracking, plus the mapping call when the frame is a map
 frame).  The first-frame initialisation (mapping_first_n_iters=1500) runs in
-the untimed set-up.  value = frames / second of the whole job.
+the untimed set-up, and so does the generation of the synthetic frames: they
+are resident in HBM before the timed region starts (SyntheticRoom.preload).
+value = frames / second of the whole job.  Defaults: 100 timed frames after 10
+warm-up frames (20 / 5 for vox-fusion and splaTAM, 5 / 2 for point-slam).
 
 N > 1: one process per GPU; tracking is replicated, the mapping rays are
 sharded over ranks and the selected-cell/decoder gradients are summed with one
 RCCL all-reduce per iteration (engine/dist.py) -> "strong" scaling of one
-frame stream.
+frame stream (the reference's 1000-ray mapping batch split N ways: at these
+sizes every launch is latency-bound, so expect the all-reduce to cost about
+what the smaller shards save).
 
 --algo co-slam (single GPU) runs the same frame loop with Co-SLAM (hash grid +
 OneBlob + 2x32 MLPs, 10 tracking it x 1024 rays per frame, every 5th frame 10
