@@ -153,7 +153,8 @@ def test_persistent_mapping_graphs_match_per_call_graphs():
     # random-init decoders and different RNG consumption (replayed vs eager
     # first iterations): the two trajectories agree only statistically
     ate_a, ate_b = sa.ate_rmse(), sb.ate_rmse()
-    assert ate_a < 0.06 and ate_b < 0.06, (ate_a, ate_b)
+    # (seen: 1-4 cm for either; a broken map shows up as decimetres)
+    assert ate_a < 0.10 and ate_b < 0.10, (ate_a, ate_b)
     # packed decoder weights follow the trained flat parameter, in place
     for algo in (a, b):
         flat = algo.model.decoder.color_decoder.flat
