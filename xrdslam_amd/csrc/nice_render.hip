@@ -672,7 +672,7 @@ __device__ __forceinline__ void mlp_bwd(
 
 // Weight-gradient contraction of the colour decoder: dW = sum over points of
 // (gradient) x (layer input), as v_mfma_f32_16x16x4_f32 with the POINTS on the
-// K dimension.  256 persistent blocks x 4 waves; each wave owns a slice of the
+// K dimension.  kDwBlocks (512) persistent blocks x 4 waves; each wave owns a slice of the
 // flat gradient (accumulated in registers over all of the block's 16-point
 // chunks) and writes it once to the block's partial vector.
 //   wave 0: fc_c.{0..4} weight+bias      wave 1: pts_linears hidden parts+bias
@@ -1429,7 +1429,14 @@ size_t bwd_lds_bytes(int nt, bool dw) {
          nw * kScatterFloats * sizeof(float);
 }
 
-constexpr int kDwBlocks = 256;
+#ifndef XRD_DW_BLOCKS
+#define XRD_DW_BLOCKS 512
+#endif
+// persistent blocks of nice_dw_kernel.  Measured on MI355X (colour-stage
+// backward group, 1000 rays): 256 blocks 642 us, 512 blocks 594 us, 1024 blocks
+// 629 us — two blocks per CU hide the dependent mask -> gradient loads, more
+// only grows the partial-sum traffic.
+constexpr int kDwBlocks = XRD_DW_BLOCKS;
 
 }  // namespace
 }  // namespace xrd
