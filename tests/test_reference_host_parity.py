@@ -310,3 +310,32 @@ def test_trajectory_evaluation_matches_reference(tmp_path):
                            np.asarray(want['trans']).reshape(-1), atol=1e-9)
         assert abs(mine['scale'] - want['scale']) < 1e-9
     assert abs(et.evaluate_eval_tar(path, True)['scale'] - 1 / 1.07) < 2e-2
+
+
+def test_render_metrics_match_reference(tmp_path):
+    """PSNR / depth L1 against save_render_imgs; the plotting, MS-SSIM and
+    LPIPS calls of that function run on stand-ins"""
+    from unittest import mock
+    from slam.common import common as rc
+    from xrdslam_amd.slam.utils.eval_2d import render_metrics
+    g = torch.Generator().manual_seed(12)
+    gt_c = (torch.rand(24, 32, 3, generator=g) * 1.2 - 0.1).numpy()
+    c = (torch.rand(24, 32, 3, generator=g) * 1.2 - 0.1).numpy()
+    gt_d = (1 + torch.rand(24, 32, generator=g)).numpy()
+    gt_d[:4, :9] = 0
+    d = gt_d + 0.05 * torch.randn(24, 32, generator=g).numpy()
+    plt = mock.MagicMock()
+    plt.subplots.side_effect = lambda *a, **k: (mock.MagicMock(),
+                                                mock.MagicMock())
+    with mock.patch.object(rc, 'plt', plt), \
+            mock.patch.object(rc, 'ms_ssim',
+                              lambda *a, **k: torch.tensor(0.5)), \
+            mock.patch.object(rc, 'LearnedPerceptualImagePatchSimilarity',
+                              lambda **k: (lambda a, b: torch.tensor(0.1))):
+        for depth in (d, None):
+            ref = rc.save_render_imgs(3, gt_c.copy(), gt_d.copy(), c.copy(),
+                                      None if depth is None else depth.copy(),
+                                      str(tmp_path))
+            psnr, l1 = render_metrics(gt_c, gt_d, c, depth)
+            assert abs(psnr - float(ref[0])) < 1e-4
+            assert abs(l1 - float(ref[3])) < 1e-4
