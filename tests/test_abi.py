@@ -40,3 +40,67 @@ def test_bad_arguments_are_reported_not_fatal():
     assert lib.xrd_nice_pack_index(0, None) == 1  # XRD_ERR_ARG
     assert lib.xrd_adam_cells(None, None, None, None, None, 0, 32, 0.1, 0.9,
                               0.999, 1e-8, 1, 0, None) == 1
+
+
+def test_argument_checks_of_the_iteration_kernels():
+    """the error behaviour the header promises, on entry points whose argument
+    validation runs before any HIP call (safe on a CPU-only box): XRD_ERR_ARG
+    = 1 for null pointers / bad sizes, XRD_ERR_UNSUPPORTED = 3 outside the
+    built range, XRD_OK = 0 for empty work"""
+    lib = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    b6 = (ctypes.c_double * 6)(-1, 1, -1, 1, -1, 1)
+    # fused Adam variants
+    assert lib.xrd_adam_cells_devstep(p, p, p, p, None, 4, 32, 0.1, 0.9, 0.999,
+                                      1e-8, None, 0, None) == 1
+    assert lib.xrd_adam_cells_devcount(p, p, p, p, p, 4, 32, 0.1, 0.9, 0.999,
+                                       1e-8, p, None, 0, None) == 1
+    assert lib.xrd_adam_cells_devcount(p, p, p, p, None, 4, 32, 0.1, 0.9,
+                                       0.999, 1e-8, p, p, 0, None) == 1
+    assert lib.xrd_adam_cells(p, p, p, p, None, 4, 30, 0.1, 0.9, 0.999, 1e-8,
+                              1, 0, None) == 1        # cell_floats % 4 != 0
+    assert lib.xrd_adam_cells(p, p, p, p, None, 0, 32, 0.1, 0.9, 0.999, 1e-8,
+                              1, 0, None) == 0        # nothing to do
+    assert lib.xrd_adam_dense(p, p, p, p, -1, 0.1, 0.9, 0.999, 1e-8, 0.0, p,
+                              None) == 1
+    assert lib.xrd_adam_dense(None, None, None, None, 0, 0.1, 0.9, 0.999,
+                              1e-8, 0.0, p, None) == 0
+    # sampling
+    args = (160, 0, 0, 160, 80.0, 80.0, 79.5, 59.5)
+    assert lib.xrd_sample_rays(-1, *args, b6, p, p, p, p, p, p, p, p, p, p,
+                               None) == 1
+    assert lib.xrd_sample_rays(0, *args, b6, None, None, None, None, None,
+                               None, None, None, None, None, None) == 0
+    assert lib.xrd_sample_rays(8, *args, b6, None, p, p, p, p, p, p, p, p, p,
+                               None) == 1
+    arr = (ctypes.c_void_p * 17)(*([p.value] * 17))
+    multi = (b6, p, arr, arr, arr, arr, p, p, p, p, p, p, p, None)
+    assert lib.xrd_sample_rays_multi(0, 8, *args, *multi) == 1
+    assert lib.xrd_sample_rays_multi(17, 8, *args, *multi) == 3   # > 16 frames
+    hole = (ctypes.c_void_p * 2)(p.value, None)
+    assert lib.xrd_sample_rays_multi(2, 8, *args, b6, p, arr, arr, hole, arr,
+                                     p, p, p, p, p, p, p, None) == 1
+    assert lib.xrd_sample_rays_multi_bwd(17, 8, *args, p, arr, arr, p, p, p,
+                                         None) == 3
+    assert lib.xrd_sample_rays_multi_bwd(2, 8, *args, p, arr, arr, p, p, None,
+                                         None) == 1
+    # loss / pose
+    assert lib.xrd_nice_loss(0, 1, 1, 0, 0.2, p, p, p, p, p, p, p, p, p,
+                             None) == 1
+    assert lib.xrd_nice_loss(8193, 1, 1, 0, 0.2, p, p, p, p, p, p, p, p, p,
+                             None) == 3               # one-block loss: <= 8192
+    assert lib.xrd_pose_quat_fwd(None, p, p, None) == 1
+    assert lib.xrd_pose_quat_bwd(p, None, p, p, None) == 1
+
+
+def test_backward_workspace_contract():
+    """xrd_nice_bwd_ws_floats(n): staging of n*48 points + one partial weight
+    gradient per persistent block of the dW kernel + 64 floats"""
+    lib = _lib.lib()
+    color_flat = lib.xrd_nice_flat_len(3)
+    per_point = 5 * 32 + 5 * 32 + 5 + 32 + 4 + 4 + 96
+    a, b = lib.xrd_nice_bwd_ws_floats(1000), lib.xrd_nice_bwd_ws_floats(200)
+    assert a - b == 800 * 48 * per_point
+    blocks, rem = divmod(b - 200 * 48 * per_point - 64, color_flat)
+    assert rem == 0 and blocks == 512
