@@ -104,3 +104,29 @@ def test_backward_workspace_contract():
     assert a - b == 800 * 48 * per_point
     blocks, rem = divmod(b - 200 * 48 * per_point - 64, color_flat)
     assert rem == 0 and blocks == 512
+
+
+def test_every_entry_point_survives_null_arguments():
+    """null pointers and zero sizes into EVERY declared entry point: a defined
+    status (or a length / a null handle), never a fault — the checks sit in
+    front of the first HIP call, so this runs without a GPU.  Status-returning
+    compute entry points must not report success for all-null work unless they
+    have nothing to do by contract."""
+    lib = _lib.lib()
+    ok_when_empty = {'xrd_gs_tile_ranges', 'xrd_knn_cell_ranges',
+                     'xrd_coslam_index'}          # n == 0: nothing to do
+    for name, (ret, args) in _lib._SIGS.items():
+        vals = [0.0 if a in (ctypes.c_float, ctypes.c_double) else
+                0 if a in (ctypes.c_int, ctypes.c_int64, ctypes.c_longlong)
+                else None for a in args]        # pointers of any kind: null
+        r = getattr(lib, name)(*vals)
+        if ret is not ctypes.c_int or name.endswith('_len') or \
+                name in ('xrd_abi_version', 'xrd_octree_has_voxel') or \
+                'count' in name or 'get_' in name:
+            continue
+        if name == 'xrd_nice_warmup':
+            assert r in (0, 2), (name, r)         # 2: no HIP device here
+        elif name in ok_when_empty:
+            assert r == 0, (name, r)
+        else:
+            assert r in (1, 3), (name, r)
