@@ -43,6 +43,7 @@ The JSON line also carries
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
@@ -271,6 +272,7 @@ def run_coslam(args, dev, with_cpu, world=1):
     from xrdslam_amd.slam.pipeline import SequentialSLAM
     torch.manual_seed(0)
     np.random.seed(0)
+    random.seed(0)   # keyframe window sampling: same on every rank
     cfg = coslam_config(CO_BOUND)
     if args.first_iters is not None:
         cfg.mapping_first_n_iters = args.first_iters
@@ -429,6 +431,7 @@ def run_voxfusion(args, dev, world=1):
     from xrdslam_amd.slam.pipeline import SequentialSLAM
     torch.manual_seed(0)
     np.random.seed(0)
+    random.seed(0)   # keyframe window sampling: same on every rank
     cam = Camera(**CAM)
     algo = voxfusion_config().setup(camera=cam, device=str(dev))
     _setup_dist(dev, world)
@@ -494,6 +497,7 @@ def run_splatam(args, dev):
     from xrdslam_amd.slam.pipeline import SequentialSLAM
     torch.manual_seed(0)
     np.random.seed(0)
+    random.seed(0)   # keyframe window sampling: same on every rank
     cam = Camera(**CAM)
     algo = splatam_config().setup(camera=cam, device=str(dev))
     data = _CvPoses(SyntheticRoom(
@@ -562,6 +566,7 @@ def run_pointslam(args, dev, world=1):
     from xrdslam_amd.slam.pipeline import SequentialSLAM
     torch.manual_seed(0)
     np.random.seed(0)
+    random.seed(0)   # keyframe window sampling: same on every rank
     cam = Camera(**CAM)
     cfg = pointslam_config()
     if args.first_iters is not None:
@@ -674,6 +679,7 @@ def main():
 
     torch.manual_seed(0)  # identical on all ranks: tracking stays in lock-step
     np.random.seed(0)
+    random.seed(0)   # keyframe window sampling: same on every rank
     cfg = nice_slam_config(BOUND)
     if args.first_iters is not None:
         cfg.mapping_first_n_iters = args.first_iters
