@@ -34,6 +34,13 @@ class DistState:
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
             self.shard_generator = torch.Generator(device=device)
             self.shard_generator.manual_seed(seed * 1000 + 17 + self.rank)
+            # replicated decisions (keyframe window: random.sample, overlap
+            # selection: numpy) must come out the same on every rank
+            import random
+
+            import numpy as np
+            random.seed(seed * 7919 + 13)
+            np.random.seed(seed * 7919 + 13)
 
     def shard_count(self, n: int) -> int:
         """rays this rank draws out of n (ceil split, every rank the same)"""
