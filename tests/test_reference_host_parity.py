@@ -339,3 +339,58 @@ def test_render_metrics_match_reference(tmp_path):
             psnr, l1 = render_metrics(gt_c, gt_d, c, depth)
             assert abs(psnr - float(ref[0])) < 1e-4
             assert abs(l1 - float(ref[3])) < 1e-4
+
+
+def _remap_bilinear(img, map_x, map_y, interpolation=None):
+    """cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) in exact float arithmetic
+    (cv2 is not installed; its 1/32 fixed-point coefficients are the one
+    detail this stand-in does not reproduce)"""
+    H, W = img.shape
+    x = np.asarray(map_x, np.float32)
+    y = np.asarray(map_y, np.float32)
+    x0, y0 = np.floor(x), np.floor(y)
+    fx, fy = x - x0, y - y0
+
+    def tap(xx, yy):
+        ok = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+        v = img[np.clip(yy, 0, H - 1).astype(np.int64),
+                np.clip(xx, 0, W - 1).astype(np.int64)]
+        return np.where(ok, v, 0).astype(np.float32)
+
+    return (tap(x0, y0) * (1 - fx) * (1 - fy) + tap(x0 + 1, y0) * fx *
+            (1 - fy) + tap(x0, y0 + 1) * (1 - fx) * fy +
+            tap(x0 + 1, y0 + 1) * fx * fy).astype(np.float32)
+
+
+def test_frustum_cell_mask_matches_reference():
+    """the device frustum mask against get_mask_from_c2w (utils.py:298-375)
+    with the exact-bilinear remap stand-in: projection conventions, the depth
+    test, zero-depth fill, cells near the camera, output layout"""
+    from unittest import mock
+    from slam.model_components import utils as ru
+    from xrdslam_amd.slam.models.conv_onet import frustum_cell_mask
+    rcam, cam = _cams()
+    g = torch.Generator().manual_seed(21)
+    bound = torch.tensor([[-2.0, 2.2], [-2.4, 1.9], [-1.6, 2.1]])
+    depth = (1.0 + 1.5 * torch.rand(48, 64, generator=g)).numpy() \
+        .astype(np.float32)
+    depth[20:26, 30:40] = 0
+    cv2 = mock.MagicMock()
+    cv2.remap.side_effect = _remap_bilinear
+    worst = 0.0
+    with mock.patch.object(ru, 'cv2', cv2):
+        for seed, shape in ((1, (9, 11, 10)), (2, (17, 21, 20)),
+                            (3, (31, 37, 35))):
+            c2w = _pose(seed)
+            c2w[:3, 3] = torch.tensor([0.2, -0.3, 0.1]) * seed
+            ref = ru.get_mask_from_c2w(rcam, bound, c2w.clone(), 'grid_fine',
+                                       shape, depth)
+            ref = torch.from_numpy(np.asarray(ref)).permute(2, 1, 0)
+            mine = frustum_cell_mask(cam, bound, c2w, shape,
+                                     torch.from_numpy(depth).reshape(-1, 1))
+            assert mine.shape == ref.shape == tuple(shape)
+            assert 0.02 < mine.float().mean() < 0.98
+            worst = max(worst, float((mine != ref).float().mean()))
+        assert ru.get_mask_from_c2w(rcam, bound, c2w, 'grid_coarse',
+                                    (3, 4, 5), depth).all()
+    assert worst == 0.0, worst

@@ -63,9 +63,11 @@ class ConvOnetConfig(ModelConfig):
 def frustum_cell_mask(camera, bound, c2w, val_shape, depth_dev):
     """bool [Z,Y,X]: lattice points of a grid that project into the current
     depth image within depth+0.5 m, or lie within 0.5 m of the camera
-    (restates get_mask_from_c2w, utils.py:298-375, on the device; the depth
-    lookup is a plain bilinear sample with zero border in place of cv2.remap —
-    cv2 is not available to pin that detail)."""
+    (restates get_mask_from_c2w, utils.py:298-375, on the device; equal cell for
+    cell to the reference function when its cv2.remap is an exact bilinear
+    sample with zero border, tests/test_reference_host_parity.py — cv2 itself
+    is not installed, so its 1/32 fixed-point interpolation weights are the one
+    detail left unpinned)."""
     dev = depth_dev.device
     H, W = camera.height, camera.width
     Z, Y, X = val_shape
