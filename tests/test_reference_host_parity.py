@@ -394,3 +394,43 @@ def test_frustum_cell_mask_matches_reference():
         assert ru.get_mask_from_c2w(rcam, bound, c2w, 'grid_coarse',
                                     (3, 4, 5), depth).all()
     assert worst == 0.0, worst
+
+
+def test_pose_conversions_against_the_vendored_pytorch3d_code():
+    """the reference tree carries pytorch3d's matrix_to_quaternion
+    (slam_helpers_splatam.py, used by SplaTAM) and a normalising
+    quaternion->matrix (slam_external_splatam.build_rotation): they pin two of
+    the three conversions utils/opt_pose.py restates"""
+    import slam.model_components.slam_external_splatam as re
+    import slam.model_components.slam_helpers_splatam as rh
+    from xrdslam_amd.slam.utils import opt_pose as mp
+    g = torch.Generator().manual_seed(31)
+    q = torch.randn(200, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    # cover every branch of the largest-component selection
+    q = torch.cat([q, torch.eye(4), -torch.eye(4),
+                   torch.tensor([[0.5, 0.5, 0.5, 0.5], [1e-4, 1., 0., 0.]])])
+    q = q / q.norm(dim=1, keepdim=True)
+    R = mp.quaternion_to_matrix(q)
+    real_zeros = torch.zeros
+    torch.zeros = lambda *x, **k: real_zeros(
+        *x, **{kk: ('cpu' if kk == 'device' else vv) for kk, vv in k.items()})
+    try:
+        R_ref = re.build_rotation(q)
+    finally:
+        torch.zeros = real_zeros
+    assert torch.allclose(R, R_ref, atol=1e-6)
+    # un-normalised input: pytorch3d's formula scales by 2/|q|^2
+    assert torch.allclose(mp.quaternion_to_matrix(3.0 * q), R, atol=1e-6)
+    back = torch.stack([mp.matrix_to_quaternion(r) for r in R])  # one pose
+    back_ref = rh.matrix_to_quaternion(R)
+    # the vendored copy predates pytorch3d's standardize_quaternion (real part
+    # >= 0), which the reference's `git+.../pytorch3d.git` install applies and
+    # opt_pose.py mirrors: equal up to that sign
+    assert (back[:, 0] >= 0).all()
+    flip = torch.where(back_ref[:, :1] < 0, -back_ref, back_ref)
+    tie = back_ref[:, 0].abs() < 1e-6           # w == 0: either sign is valid
+    assert torch.allclose(back[~tie], flip[~tie], atol=1e-6)
+    same = torch.minimum((back - q).abs().max(1).values,
+                         (back + q).abs().max(1).values)
+    assert float(same.max()) < 1e-5
