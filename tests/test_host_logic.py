@@ -211,3 +211,38 @@ def test_trajectory_evaluation_recovers_a_similarity_transform(tmp_path):
     slam.save_eval_tar(path)
     again = et.evaluate_eval_tar(path, correct_scale=True)
     assert abs(again['scale'] - 0.8) < 1e-6
+
+
+def test_pose_conversion_round_trips():
+    """quaternion -> axis-angle -> Rodrigues matrix == quaternion -> matrix, and
+    matrix -> quaternion -> matrix is the identity (the property pytorch3d's
+    conversions are defined by; sign-standardised quaternion: angle <= pi)"""
+    from xrdslam_amd.slam.utils import opt_pose as mp
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(300, 4, generator=g, dtype=torch.float64)
+    q = torch.cat([q, torch.tensor([[1., 0, 0, 0], [1., 1e-12, 0, 0],
+                                    [0., 1, 0, 0], [-0.3, 0.2, 0.1, 0.9]],
+                                   dtype=torch.float64)])
+    q = q / q.norm(dim=1, keepdim=True)
+    R = mp.quaternion_to_matrix(q)
+    assert torch.allclose(R @ R.transpose(-1, -2),
+                          torch.eye(3, dtype=torch.float64).expand_as(R),
+                          atol=1e-12)
+    aa = mp.quaternion_to_axis_angle(q)
+    for k in range(q.shape[0]):
+        Rk = mp.OptimizablePose.axis_angle_to_rotation_matrix(aa[k])
+        assert torch.allclose(Rk, R[k], atol=1e-9), k
+        qk = mp.matrix_to_quaternion(R[k])
+        assert qk[0] >= 0
+        assert torch.allclose(mp.quaternion_to_matrix(qk), R[k], atol=1e-9)
+        # from_matrix (what Frame.set_pose uses) reproduces the matrix
+        Rt = torch.eye(4, dtype=torch.float64)
+        Rt[:3, :3] = R[k]
+        Rt[:3, 3] = torch.tensor([0.1, -0.2, 0.3], dtype=torch.float64)
+        for rep in ('axis_angle', 'quat'):
+            pose = mp.OptimizablePose.from_matrix(Rt, separate_LR=True,
+                                                  rot_rep=rep)
+            assert torch.allclose(pose.matrix().double(), Rt, atol=1e-6), \
+                (k, rep)
+            if rep == 'axis_angle':
+                assert float(pose.data_r.detach().norm()) <= np.pi + 1e-6
