@@ -434,3 +434,76 @@ def test_pose_conversions_against_the_vendored_pytorch3d_code():
     same = torch.minimum((back - q).abs().max(1).values,
                          (back + q).abs().max(1).values)
     assert float(same.max()) < 1e-5
+
+
+def test_optimisation_window_selection_matches_reference():
+    """Algorithm.select_optimize_frames (base_algorithm.py:277-302) as an
+    unbound function on a stand-in self, equal python RNG"""
+    import random
+    import types
+    from slam.algorithms.base_algorithm import Algorithm as RAlgo
+    from xrdslam_amd.slam.algorithms.base_algorithm import Algorithm
+
+    class F:
+        def __init__(self, fid):
+            self.fid = fid
+
+    for n_kf in (1, 4, 5, 6, 12):
+        kfs = [F(5 * k) for k in range(n_kf)]
+        cur = F(5 * n_kf + 2)
+        for method in ('random', 'all', 'none'):
+            me = types.SimpleNamespace(
+                keyframe_graph=kfs, camera=None, device='cpu',
+                config=types.SimpleNamespace(mapping_window_size=5,
+                                             keyframe_use_ray_sample=True))
+            random.seed(4)
+            ref = RAlgo.select_optimize_frames(me, cur, method)
+            random.seed(4)
+            mine = Algorithm.select_optimize_frames(me, cur, method)
+            assert [f.fid for f in ref] == [f.fid for f in mine], \
+                (n_kf, method)
+            assert mine[-1] is cur
+
+
+def test_nice_model_input_matches_reference():
+    """NiceSLAM.get_model_input (nice_slam.py:141-199: per-frame sampling,
+    bounding-box depth filter) as an unbound function on a stand-in self, for
+    tracking and mapping, equal torch RNG"""
+    import types
+    from slam.algorithms.nice_slam import NiceSLAM as RNice
+    from xrdslam_amd.slam.algorithms.nice_slam import NiceSLAM
+    from xrdslam_amd.slam.common.frame import Frame
+    rcam, cam = _cams()
+    g = torch.Generator().manual_seed(41)
+    frames = []
+    for k in range(3):
+        depth = (0.5 + 3.5 * torch.rand(48, 64, generator=g)).numpy() \
+            .astype(np.float32)          # some depths beyond the small bound
+        color = torch.rand(48, 64, 3, generator=g).numpy().astype(np.float32)
+        c2w = _pose(10 + k)
+        c2w[:3, 3] *= 0.2
+        frames.append(Frame(fid=k, rgb=color, depth=depth,
+                            init_pose=c2w.numpy(), gt_pose=c2w.numpy(),
+                            separate_LR=False, rot_rep='quat'))
+    bound = torch.tensor([[-2.0, 2.0], [-2.0, 2.0], [-2.0, 2.0]])
+    cfg = types.SimpleNamespace(tracking_sample=150, tracking_Hedge=4,
+                                tracking_Wedge=6, mapping_sample=400,
+                                min_sample_pixels=50)
+
+    def me(camera):
+        return types.SimpleNamespace(
+            config=cfg, camera=camera, device='cpu', bounding_box=bound,
+            stage='color', bundle_adjust=True, fixed_shape_batches=False,
+            model=types.SimpleNamespace(device='cpu'))
+
+    for is_mapping, use in ((False, frames[-1:]), (True, frames)):
+        torch.manual_seed(2)
+        ref = RNice.get_model_input(me(rcam), use, is_mapping)
+        torch.manual_seed(2)
+        mine = NiceSLAM.get_model_input(me(cam), use, is_mapping)
+        assert ref['stage'] == mine['stage'] == 'color'
+        n = ref['rays_o'].shape[0]
+        assert 0 < n < (400 // 3 * 3 if is_mapping else 150)   # filter bites
+        for key in ('rays_o', 'rays_d', 'target_s', 'target_d'):
+            assert ref[key].shape == mine[key].shape, key
+            assert torch.allclose(ref[key], mine[key], atol=1e-6), key
