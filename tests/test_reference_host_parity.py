@@ -507,3 +507,91 @@ def test_nice_model_input_matches_reference():
         for key in ('rays_o', 'rays_d', 'target_s', 'target_d'):
             assert ref[key].shape == mine[key].shape, key
             assert torch.allclose(ref[key], mine[key], atol=1e-6), key
+
+
+def test_coslam_ray_bank_and_mapping_input_match_reference():
+    """CoSLAM.add_keyframe / sample_global_rays / get_model_input
+    (coslam.py:114-230) on instances built without __init__, the index draws of
+    both sides (random.sample there, a device permutation here) replaced by the
+    same deterministic choice"""
+    import random
+    import threading
+    import types
+    from unittest import mock
+    from slam.algorithms.coslam import CoSLAM as RCo
+    from xrdslam_amd.slam.algorithms.coslam import CoSLAM
+    from xrdslam_amd.slam.common.frame import Frame
+    rcam, cam = _cams()
+
+    def pick(total, k):
+        rs = np.random.RandomState(total * 131 + k)
+        return rs.permutation(total)[:k]
+
+    def frames():
+        g = torch.Generator().manual_seed(51)
+        out = []
+        for k in range(4):
+            depth = (1 + torch.rand(48, 64, generator=g)).numpy() \
+                .astype(np.float32)
+            color = torch.rand(48, 64, 3, generator=g).numpy() \
+                .astype(np.float32)
+            c2w = _pose(20 + k)
+            out.append(Frame(fid=5 * k, rgb=color, depth=depth,
+                             init_pose=c2w.numpy(), gt_pose=c2w.numpy(),
+                             separate_LR=True, rot_rep='axis_angle'))
+        return out
+
+    cfg = types.SimpleNamespace(mapping_sample=300, min_sample_pixels=40,
+                                tracking_sample=100, tracking_Hedge=2,
+                                tracking_Wedge=3)
+
+    def make(cls, camera):
+        a = cls.__new__(cls)
+        a.config, a.camera = cfg, camera
+        a.model = types.SimpleNamespace(device='cpu')   # .device follows it
+        a.lock = threading.RLock()
+        a.keyframe_graph, a.rays = [], None
+        a.num_rays_to_save = 200
+        a._dirs = None
+        return a
+
+    ref, mine = make(RCo, rcam), make(CoSLAM, cam)
+    fr, fm = frames(), frames()
+    with mock.patch.object(random, 'sample',
+                           lambda pop, k: pick(len(pop), k).tolist()), \
+            mock.patch.object(
+                CoSLAM, '_distinct',
+                lambda self, total, bs, dev: torch.from_numpy(
+                    pick(total, bs))):
+        # mapping before any keyframe exists ('first' batch)
+        a = ref.get_model_input([fr[0]], True)
+        b = mine.get_model_input([fm[0]], True)
+        assert a['first'] is True and b['first'] is True
+        for key in ('rays_o', 'rays_d', 'target_s', 'target_d'):
+            assert torch.allclose(a[key], b[key], atol=1e-6), key
+        for k in range(3):
+            ref.add_keyframe(fr[k])
+            mine.add_keyframe(fm[k])
+        assert torch.allclose(ref.rays, mine.rays, atol=1e-6)
+        assert fr[0].rgb is None and fm[0].rgb is None
+        r_rays, r_ids = ref.sample_global_rays(64)
+        m_rays, m_ids = mine.sample_global_rays(64)
+        assert torch.equal(r_ids, m_ids)
+        assert torch.allclose(r_rays, m_rays, atol=1e-6)
+        a = ref.get_model_input(fr[:3] + [fr[3]], True)
+        b = mine.get_model_input(fm[:3] + [fm[3]], True)
+    assert a['first'] is False and b['first'] is False
+    assert a['rays_o'].shape == (300 + 100, 3)
+    for key in ('rays_o', 'rays_d', 'target_s', 'target_d'):
+        assert a[key].shape == b[key].shape, key
+        assert torch.allclose(a[key], b[key], atol=1e-6), key
+    # gradients reach the same poses: frame 0 fixed, the others and the
+    # current frame free
+    (a['rays_d'].sum() + a['rays_o'].sum()).backward()
+    (b['rays_d'].sum() + b['rays_o'].sum()).backward()
+    for x, y in zip(fr, fm):
+        for p, q in zip(x.get_params(), y.get_params()):
+            assert (p.grad is None) == (q.grad is None), x.fid
+            if p.grad is not None:
+                assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-5)
+    assert all(p.grad is None for p in fm[0].get_params())
