@@ -134,6 +134,17 @@ def test_keyframe_overlap_selection_matches_reference():
     mine = mc.keyframe_selection_overlap(cam, fr[-1], fr[:-1], 3,
                                          use_ray_sample=True, device='cpu')
     assert [f.fid for f in ref] == [f.fid for f in mine]
+    # SplaTAM's branch: back-projected pixels instead of ray samples, camera
+    # looking down +z (no x flip, z > 0 test)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    ref = rc.keyframe_selection_overlap(rcam, fr[-1], fr[:-1], 3,
+                                        use_ray_sample=False, device='cpu')
+    torch.manual_seed(1)
+    np.random.seed(1)
+    mine = mc.keyframe_selection_overlap(cam, fr[-1], fr[:-1], 3,
+                                         use_ray_sample=False, device='cpu')
+    assert len(ref) > 0 and [f.fid for f in ref] == [f.fid for f in mine]
 
 
 def test_axis_angle_matrix_matches_reference():
