@@ -606,3 +606,125 @@ def test_coslam_ray_bank_and_mapping_input_match_reference():
             if p.grad is not None:
                 assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-5)
     assert all(p.grad is None for p in fm[0].get_params())
+
+
+def test_voxfusion_voxel_creation_points_match_reference():
+    """VoxFusion.precompute + create_voxels (voxfusion.py:37-52,96-107): the
+    world points handed to the octree insert, valid-depth pixels only"""
+    import types
+    from slam.algorithms.voxfusion import VoxFusion as RVox
+    from xrdslam_amd.slam.algorithms.voxfusion import VoxFusion
+    from xrdslam_amd.slam.common.frame import Frame
+    rcam, cam = _cams()
+    g = torch.Generator().manual_seed(61)
+    depth = (1 + 2 * torch.rand(48, 64, generator=g)).numpy() \
+        .astype(np.float32)
+    depth[::5, ::3] = 0
+    color = torch.rand(48, 64, 3, generator=g).numpy().astype(np.float32)
+    c2w = _pose(33)
+    c2w[:3, 3] += 10.0                   # Vox-Fusion's 10 m pose offset
+    frame = Frame(fid=0, rgb=color, depth=depth, init_pose=c2w.numpy(),
+                  gt_pose=c2w.numpy(), separate_LR=False, rot_rep='quat')
+    got = {}
+
+    def side(cls, camera, tag):
+        me = cls.__new__(cls)
+        me.camera, me.config = camera, None
+        me.model = types.SimpleNamespace(
+            device='cpu',
+            insert_points=lambda p, tag=tag: got.__setitem__(tag, p.clone()))
+        me._rays_cam = None
+        if hasattr(cls, 'precompute'):
+            cls.precompute(me)
+        cls.create_voxels(me, frame)
+
+    side(RVox, rcam, 'ref')
+    side(VoxFusion, cam, 'mine')
+    assert got['ref'].shape == got['mine'].shape == \
+        (int((depth > 0).sum()), 3)
+    assert torch.allclose(got['ref'], got['mine'], atol=1e-5)
+
+
+def test_point_slam_algorithm_helpers_match_reference():
+    """PointSLAM.cal_dynamic_radius, get_mask_from_c2w and get_model_input
+    (point_slam.py:167-249,339-424) as unbound functions on stand-in selves;
+    skimage / cv2 calls of the reference run on the published-definition
+    stand-ins used above"""
+    import types
+    from unittest import mock
+    import slam.algorithms.point_slam as rmod
+    from slam.algorithms.point_slam import PointSLAM as RPs
+    from xrdslam_amd.slam.algorithms.point_slam import PointSLAM
+    from xrdslam_amd.slam.common.frame import Frame
+    from slam.common import common as rc
+    rcam, cam = _cams()
+    _skimage_standins(rc)
+    _skimage_standins(rmod)
+    g = torch.Generator().manual_seed(71)
+    cfg = types.SimpleNamespace(
+        pointcloud_radius_query_ratio=2.0,
+        pointcloud_color_grad_threshold=0.15, pointcloud_radius_add_max=0.08,
+        pointcloud_radius_add_min=0.02, mapping_frustum_edge=-4,
+        tracking_sample=60, tracking_Hedge=3, tracking_Wedge=4,
+        mapping_sample=240, min_sample_pixels=30, use_dynamic_radius=True,
+        tracking_sample_with_color_grad=True)
+    frames = []
+    for k in range(3):
+        depth = (1 + 2 * torch.rand(48, 64, generator=g)).numpy() \
+            .astype(np.float32)
+        depth[k:6 + k, 10:20] = 0
+        depth[40, 50] = 60.0                 # an outlier the median rule drops
+        color = torch.rand(48, 64, 3, generator=g).numpy().astype(np.float32)
+        c2w = _pose(40 + k)
+        frames.append(Frame(fid=np.array(5 * k), rgb=color, depth=depth,
+                            init_pose=c2w.numpy(), gt_pose=c2w.numpy(),
+                            separate_LR=False, rot_rep='quat'))
+    pts = (torch.randn(500, 3, generator=g) * 2).numpy()
+    ref = RPs.__new__(RPs)
+    mine = PointSLAM.__new__(PointSLAM)
+    ref.model = types.SimpleNamespace(
+        device='cpu', neural_point_cloud=types.SimpleNamespace(
+            _cloud_pos=pts.tolist()))
+    mine.model = types.SimpleNamespace(
+        device='cpu', neural_point_cloud=types.SimpleNamespace(
+            cloud_tensor=lambda dev: torch.from_numpy(pts).float()))
+    # (PointSLAM._dev is a property of model.device)
+    for a, camera in ((ref, rcam), (mine, cam)):
+        a.config, a.camera, a.stage = cfg, camera, 'geometry'
+        a.dynamic_r_query_allkeyframe = {}
+    # per-pixel radii
+    ra, rq = RPs.cal_dynamic_radius(ref, frames[0].rgb)
+    ma, mq = PointSLAM.cal_dynamic_radius(mine, frames[0].rgb)
+    assert torch.allclose(ra, ma, atol=1e-12) and \
+        torch.allclose(rq, mq, atol=1e-12)
+    assert ra.min() >= 0.02 - 1e-9 and ra.max() <= 0.08 + 1e-9
+    # frustum mask over the neural points
+    cv2 = mock.MagicMock()
+    cv2.remap.side_effect = _remap_bilinear
+    c2w = frames[1].get_pose().detach()
+    with mock.patch.object(rmod, 'cv2', cv2):
+        rmask = RPs.get_mask_from_c2w(ref, c2w, frames[1].depth)
+    mmask = PointSLAM.get_mask_from_c2w(mine, c2w,
+                                        torch.from_numpy(frames[1].depth))
+    assert 0 < int(rmask.sum()) < 500
+    assert np.array_equal(np.asarray(rmask), mmask.numpy())
+    # batches: mapping over three frames, tracking with colour-gradient pixels
+    for f in frames:
+        key = np.array2string(np.asarray(f.fid))
+        q = PointSLAM.cal_dynamic_radius(mine, f.rgb)[1]
+        ref.dynamic_r_query_allkeyframe[key] = q
+        mine.dynamic_r_query_allkeyframe[key] = q
+    for is_mapping, use in ((True, frames), (False, frames[-1:])):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        a = RPs.get_model_input(ref, use, is_mapping)
+        torch.manual_seed(3)
+        np.random.seed(3)
+        b = PointSLAM.get_model_input(mine, use, is_mapping)
+        assert a['stage'] == b['stage']
+        for key in ('rays_o', 'rays_d', 'target_s', 'target_d',
+                    'batch_dynamic_r'):
+            assert a[key].shape == b[key].shape, (is_mapping, key)
+            assert torch.allclose(a[key].double(), b[key].double(),
+                                  atol=1e-6), (is_mapping, key)
+        assert float(a['target_d'].max()) < 60.0
