@@ -180,19 +180,25 @@ def test_optimizers_accumulation_and_schedules_match_reference():
         cfg = {'a': {'optimizer': mod.AdamOptimizerConfig(lr=1e-2,
                                                           accum_step=3),
                      'scheduler': None},
+               'c': {'optimizer': mod.AdamOptimizerConfig(lr=2e-2,
+                                                          max_norm=0.5),
+                     'scheduler': None},
                'b': {'optimizer': mod.AdamOptimizerConfig(lr=1.0),
                      'scheduler': sched_mod.PointSLAMSchedulerConfig(
                          start_lr=0.03, end_lr=0.005, max_steps=10,
                          geo_iter_ratio=0.4)}}
-        opt = mod.Optimizers(cfg, {'a': [p1], 'b': [p2]})
+        p3 = torch.nn.Parameter(torch.full((5, ), 2.0))
+        opt = mod.Optimizers(cfg, {'a': [p1], 'b': [p2], 'c': [p3]})
         hist = []
         for step in range(10):
             opt.zero_grad_all()
-            loss = (p1 * (step + 1)).sum() + (p2**2).sum()
+            loss = (p1 * (step + 1)).sum() + (p2**2).sum() + \
+                (p3**3).sum() * (step % 3)         # clipped when large
             loss.backward()
             opt.optimizer_step_all(step=step)
             opt.scheduler_step_all()
-            hist.append(torch.cat([p1.detach(), p2.detach()]).clone())
+            hist.append(torch.cat([p1.detach(), p2.detach(),
+                                   p3.detach()]).clone())
         return torch.stack(hist)
 
     assert torch.allclose(run(ro, rs), run(mo, ms), atol=1e-7)
