@@ -23,6 +23,9 @@ def build_c():
 if __name__ == '__main__':
     print(build_c())
     sys.path.insert(0, HERE)
+    import build_ref_grid
     import build_ref_octree
+    if build_ref_grid.available():
+        print(build_ref_grid.build())
     if build_ref_octree.available() and '--with-ref' in sys.argv:
         build_ref_octree.load()

@@ -7,9 +7,12 @@
  *
  * including their quirks (DFS push order child 0..7 / LIFO pop, n_max cut-off,
  * the -1 miss sentinel, `(~done)` always true, `pts_idx[curr_bin]` without the
- * ray offset, the `num_rays > H + curr_bin` guard).  The CUDA source cannot be
- * built here (no CUDA); `__fdividef(1,x)` is restated as the exact 1.0f/x
- * (depths are compared at 1e-6, ids exactly).  Outputs must be pre-filled like
+ * ray offset, the `num_rays > H + curr_bin` guard).  PINNED: the reference's
+ * own two kernels are compiled for the host by oracle/build_ref_grid.py
+ * (oracle/_ref/sparse_voxels/grid_ref.so); tests/test_svo_oracle.py checks
+ * this restatement bit for bit against them and against the vectors generated
+ * from them (tests/golden/svo_grid.npz).  `__fdividef(1,x)` is the exact
+ * 1.0f/x in both; the one expression nvcc contracts is an explicit fmaf.  Outputs must be pre-filled like
  * the host wrappers do (intersect.cpp:98-106, sample.cpp:77-86): idx -1 is
  * written by the kernel itself; sampled_idx = -1, depths/dists = 0.
  *
@@ -125,7 +128,8 @@ void inverse_cdf_sampling_ref(int b, int num_rays, int max_hits, int max_steps,
         }
         if (done) break;
         const float u = (curr_cdf - curr_min_cdf) / (curr_max_cdf - curr_min_cdf);
-        const float z = curr_min_depth + u * (curr_max_depth - curr_min_depth);
+        /* nvcc's default --fmad=true contracts this expression */
+        const float z = fmaf(u, curr_max_depth - curr_min_depth, curr_min_depth);
         SI[K + s] = PI[H + curr_bin];
         SS[K + s] = (z - z_low);
         SD[K + s] = (z + z_low) * .5;

@@ -21,6 +21,56 @@ def P(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def ref_lib():
+    """the REFERENCE's own two kernels compiled for the host
+    (oracle/build_ref_grid.py -> oracle/_ref/sparse_voxels/grid_ref.so).
+    Built on demand where /root/reference exists; the built .so travels to the
+    GPU box.  None when neither is there."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import build_ref_grid
+    if build_ref_grid.available():
+        return C.CDLL(build_ref_grid.build())
+    if os.path.exists(build_ref_grid.LIB):
+        return C.CDLL(build_ref_grid.LIB)
+    return None
+
+
+def svo_intersect_ref(ray_start, ray_dir, points, children, voxelsize, n_max):
+    """compiled reference kernel; points/children must be replicated per
+    batch like the reference wrapper does (voxel_helpers_voxfusion.py:246-247)"""
+    lib = ref_lib()
+    B, M = ray_start.shape[:2]
+    N = points.shape[1]
+    assert points.shape[0] == B and children.shape[0] == B
+    idx = np.zeros((B, M, n_max), np.int32)
+    mn = np.zeros((B, M, n_max), np.float32)
+    mx = np.zeros((B, M, n_max), np.float32)
+    lib.ref_svo_intersect(
+        C.c_int(B), C.c_int(N), C.c_int(M), C.c_float(voxelsize),
+        C.c_int(n_max), P(ray_start), P(ray_dir), P(points), P(children),
+        P(idx), P(mn), P(mx))
+    return idx, mn, mx
+
+
+def inverse_cdf_ref(pts_idx, mn, mx, noise, probs, steps, fixed):
+    """compiled reference kernel with the host wrapper's pre-fill
+    (sample.cpp:77-86)"""
+    lib = ref_lib()
+    G, R, Pn = mn.shape
+    S = noise.shape[-1]
+    sidx = -np.ones((G, R, S), np.int32)
+    sdep = np.zeros((G, R, S), np.float32)
+    sdis = np.zeros((G, R, S), np.float32)
+    # the reference reads pts_idx[H + max_hits] of the LAST ray (one past the
+    # buffer) when that ray runs out of bins; give it a defined -1 there
+    pi = np.concatenate([pts_idx.reshape(-1), -np.ones(Pn + 1, np.int32)])
+    lib.ref_inverse_cdf_sampling(
+        C.c_int(G), C.c_int(R), C.c_int(Pn), C.c_int(S), C.c_float(fixed),
+        P(pi), P(mn), P(mx), P(noise), P(probs), P(steps), P(sidx),
+        P(sdep), P(sdis))
+    return sidx, sdep, sdis
+
+
 def svo_intersect_oracle(ray_start, ray_dir, points, children, voxelsize,
                          n_max):
     lib = oracle_lib()
@@ -44,9 +94,11 @@ def inverse_cdf_oracle(pts_idx, mn, mx, noise, probs, steps, fixed):
     sidx = -np.ones((G, R, S), np.int32)
     sdep = np.zeros((G, R, S), np.float32)
     sdis = np.zeros((G, R, S), np.float32)
+    # one-past-the-buffer read of the last ray (see inverse_cdf_ref)
+    pi = np.concatenate([pts_idx.reshape(-1), -np.ones(Pn + 1, np.int32)])
     lib.inverse_cdf_sampling_ref(
         C.c_int(G), C.c_int(R), C.c_int(Pn), C.c_int(S), C.c_float(fixed),
-        P(pts_idx), P(mn), P(mx), P(noise), P(probs), P(steps), P(sidx),
+        P(pi), P(mn), P(mx), P(noise), P(probs), P(steps), P(sidx),
         P(sdep), P(sdis))
     return sidx, sdep, sdis
 
@@ -67,3 +119,54 @@ def make_tree(seed=0, n_vox=1500):
     centres = (voxels[:, :3] + voxels[:, -1:] / 2) * voxel_size
     childs = torch.cat([children, voxels[:, -1:]], -1).int()
     return centres.numpy().astype(np.float32), childs.numpy().astype(np.int32)
+
+
+def sampler_case(seed, G, n_rays=None, deterministic=False, n_vox=1500):
+    """inputs of inverse_cdf_sampling built like the reference builds them
+    (voxel_helpers_voxfusion.py:647-714 and :396-437): hits sorted by entry
+    depth and trimmed, probs = chord / sum, steps = sum / 0.01, rays padded
+    with copies of ray 0 to a multiple of G and reshaped to [G, R, P], noise
+    in (0.001, 0.999) or 0.5.  Returns (pts_idx, min, max, noise, probs,
+    steps) as contiguous arrays."""
+    centres, childs = make_tree(seed, n_vox)
+    rng = np.random.default_rng(100 + seed)
+    M = n_rays or (G * 3 - (G // 2 if G > 1 else 0))
+    o = (np.array([[13.0, 13.0, 9.0]]) + rng.uniform(-1, 1, (M, 3))).astype(
+        np.float32)
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d[:, 2] = np.abs(d[:, 2]) + 0.1
+    idx, mn, mx, _ = svo_intersect_oracle(o[None], d[None], centres[None],
+                                          childs[None], 0.2, 50)
+    idx, mn, mx = idx[0], mn[0], mx[0]
+    keep = (idx >= 0).any(1)
+    idx, mn, mx = idx[keep], mn[keep], mx[keep]
+    mn_s = np.where(idx >= 0, mn, 10.0).astype(np.float32)
+    mx = np.where(idx >= 0, mx, 10.0).astype(np.float32)
+    order = np.argsort(mn_s, 1, kind='stable')
+    idx = np.take_along_axis(idx, order, 1)
+    mn = np.take_along_axis(mn_s, order, 1)
+    mx = np.take_along_axis(mx, order, 1)
+    nh = int((idx >= 0).sum(1).max())
+    idx, mn, mx = idx[:, :nh].copy(), mn[:, :nh].copy(), mx[:, :nh].copy()
+    length = np.where(idx >= 0, mx - mn, 0).astype(np.float32)
+    tot = length.sum(1, keepdims=True, dtype=np.float32)
+    probs = (length / tot).astype(np.float32)
+    steps = (tot[:, 0] / np.float32(0.01)).astype(np.float32)
+    N = idx.shape[0]
+    Hh = int(np.ceil(N / G)) * G
+
+    def pad(t):
+        return np.concatenate([t, np.repeat(t[:1], Hh - N, 0)], 0)
+    idx, mn, mx, probs, steps = (pad(t) for t in (idx, mn, mx, probs, steps))
+    S = int(np.ceil(steps.max())) + nh
+    R = Hh // G
+    if deterministic:
+        noise = np.full((G, R, S), 0.5, np.float32)
+    else:
+        noise = rng.uniform(0, 1, (G, R, S)).astype(np.float32).clip(
+            0.001, 0.999)
+    return (np.ascontiguousarray(idx.reshape(G, R, nh).astype(np.int32)),
+            np.ascontiguousarray(mn.reshape(G, R, nh)),
+            np.ascontiguousarray(mx.reshape(G, R, nh)), noise,
+            np.ascontiguousarray(probs.reshape(G, R, nh)),
+            np.ascontiguousarray(steps.reshape(G, R)))

@@ -38,7 +38,11 @@ def test_abi_version_and_lengths():
 def test_bad_arguments_are_reported_not_fatal():
     lib = _lib.lib()
     assert lib.xrd_nice_pack_index(0, None) == 1  # XRD_ERR_ARG
+    # an empty cell selection is a no-op whatever the pointers (torch's Adam
+    # over an empty val[mask]); a non-empty one needs them
     assert lib.xrd_adam_cells(None, None, None, None, None, 0, 32, 0.1, 0.9,
+                              0.999, 1e-8, 1, 0, None) == 0
+    assert lib.xrd_adam_cells(None, None, None, None, None, 4, 32, 0.1, 0.9,
                               0.999, 1e-8, 1, 0, None) == 1
 
 

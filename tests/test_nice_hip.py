@@ -179,3 +179,23 @@ def test_adam_cells_matches_torch():
     mask = torch.ones(ncell, dtype=torch.bool, device=dev)
     mask[idx.long()] = False
     assert torch.equal(p[mask], p0[mask])
+
+
+def test_fused_cell_adam_empty_selection_is_noop():
+    """a frustum mask that selects no cell of a grid: the reference's Adam over
+    an empty ``val[mask]`` does nothing; so must the fused one (zero-sized
+    moments have NULL data pointers)"""
+    from xrdslam_amd.engine import nice as en
+    from xrdslam_amd.slam.engine.optimizers import FusedCellAdam
+    dev = _cuda()
+    p = en.to_channels_last_grid(torch.randn(1, 32, 4, 5, 6, device=dev))
+    p.requires_grad_(True)
+    before = p.detach().clone()
+    p.grad = torch.zeros_like(p)
+    p._xrd_cells = torch.zeros(0, dtype=torch.int32, device=dev)
+    p._xrd_grad_fresh = True
+    opt = FusedCellAdam([p], lr=0.1, betas=(0.9, 0.999), eps=1e-8)
+    opt.step()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(p.detach(), before)

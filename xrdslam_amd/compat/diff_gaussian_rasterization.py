@@ -42,7 +42,27 @@ class GaussianRasterizationSettings(NamedTuple):
     prefiltered: bool
 
 
+# The settings are constant for the life of a GaussianCloud (one object per
+# cloud, gaussian_cloud_splatam.py:37), so the device->host copies of
+# bg / viewmatrix / projmatrix are paid once per settings object, not on every
+# forward and backward.  The cache keeps the settings object alive next to its
+# camera so that an id() is never reused while its entry exists.
+_CAM_CACHE: "dict[int, tuple]" = {}
+_CAM_CACHE_MAX = 32
+
+
 def _camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
+    hit = _CAM_CACHE.get(id(rs))
+    if hit is not None and hit[0] is rs:
+        return hit[1]
+    cam = _build_camera(rs)
+    if len(_CAM_CACHE) >= _CAM_CACHE_MAX:
+        _CAM_CACHE.pop(next(iter(_CAM_CACHE)))
+    _CAM_CACHE[id(rs)] = (rs, cam)
+    return cam
+
+
+def _build_camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
     cam = _lib.GsCamera()
     cam.image_height, cam.image_width = int(rs.image_height), \
         int(rs.image_width)

@@ -72,10 +72,13 @@ static int adam_launch(float* param, float* g, float* m, float* v,
                        float eps, int step, const int32_t* step_dev,
                        const int32_t* n_cells_dev, int zero_grad,
                        xrd_stream_t stream) {
-  if (!param || !g || !m || !v || n_cells < 0 || cell_floats <= 0 ||
-      (cell_floats & 3) || (step < 1 && !step_dev))
+  if (n_cells < 0 || cell_floats <= 0 || (cell_floats & 3) ||
+      (step < 1 && !step_dev))
     return XRD_ERR_ARG;
+  // an empty selection is a no-op like torch's Adam over an empty val[mask]
+  // (the compact moments are then zero-sized: NULL data pointers are fine)
   if (n_cells == 0) return XRD_OK;
+  if (!param || !g || !m || !v) return XRD_ERR_ARG;
   const int vec = cell_floats / 4;
   const int64_t total = n_cells * vec;
   int64_t blocks = (total + 255) / 256;

@@ -104,73 +104,156 @@ __global__ __launch_bounds__(kRaysPerBlock) void svo_intersect_kernel(
   (void)n;
 }
 
-__global__ __launch_bounds__(64) void inverse_cdf_kernel(
+// Inverse-CDF sampling, one WAVE per ray (sample_gpu.cu:133-239 walks a ray's
+// steps serially on one thread, carrying (bin, z_low); tests/
+// svo_parallel_model.py states and checks the re-formulation used here):
+//   * cum[b] = serial float prefix sum of the ray's probs (same addition
+//     order as the reference), kept in LDS;
+//   * lane c owns step c: cdf(c), bin(c) = first b with !(cdf > cum[b])
+//     (running max over the lanes by a wave scan), its in-bin sample goes to
+//     slot c + bin(c); the bin boundaries crossed since step c-1 go to slots
+//     c + b; z_low comes from lane c-1 by shuffle when it lies in the same
+//     bin, else it is the bin's entry depth;
+//   * the first lane whose bin reaches the number of valid bins ends the ray
+//     ("done" in the reference);
+//   * the reference's trailing loop over the remaining bins, with its quirks
+//     (`~done` always true, `pts_idx[curr_bin]` read without the ray offset,
+//     the `num_rays > H + curr_bin` guard), runs on lane 0.
+// Writes beyond max_steps are dropped and pts_idx reads one past the buffer
+// (the reference performs both) return -1.
+constexpr int kCdfWaves = 4;
+
+__global__ __launch_bounds__(kCdfWaves * 64) void inverse_cdf_kernel(
     int num_rays, int max_hits, int max_steps, float fixed_step_size,
-    const int* __restrict__ pts_idx, const float* __restrict__ min_depth,
-    const float* __restrict__ max_depth,
+    int64_t pi_total, const int* __restrict__ pts_idx,
+    const float* __restrict__ min_depth, const float* __restrict__ max_depth,
     const float* __restrict__ uniform_noise, const float* __restrict__ probs,
     const float* __restrict__ steps, int* __restrict__ sampled_idx,
     float* __restrict__ sampled_depth, float* __restrict__ sampled_dists) {
+  extern __shared__ float cdf_lds[];  // [kCdfWaves][max_hits]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.y;
-  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.x * kCdfWaves + wave;
   if (j >= num_rays) return;
-  const int* PI = pts_idx + (int64_t)bi * num_rays * max_hits;
-  const float* MN = min_depth + (int64_t)bi * num_rays * max_hits;
-  const float* MX = max_depth + (int64_t)bi * num_rays * max_hits;
-  const float* PR = probs + (int64_t)bi * num_rays * max_hits;
-  const float* ST = steps + (int64_t)bi * num_rays;
+  float* cum = cdf_lds + wave * max_hits;
+  const int64_t boff = (int64_t)bi * num_rays * max_hits;
+  const int* PI = pts_idx + boff;
+  const float* MN = min_depth + boff;
+  const float* MX = max_depth + boff;
+  const float* PR = probs + boff;
   const float* UN = uniform_noise + (int64_t)bi * num_rays * max_steps;
   int* SI = sampled_idx + (int64_t)bi * num_rays * max_steps;
   float* SD = sampled_depth + (int64_t)bi * num_rays * max_steps;
   float* SS = sampled_dists + (int64_t)bi * num_rays * max_steps;
   const int H = j * max_hits, K = j * max_steps;
-  int curr_bin = 0, s = 0;
-  float curr_min_depth = MN[H], curr_max_depth = MX[H];
-  float curr_min_cdf = 0, curr_max_cdf = PR[H];
-  float step_size = 1.0 / ST[j];
-  float z_low = curr_min_depth;
-  const int total_steps = (int)ceil((double)ST[j]);
-  bool done = false;
-  if (fixed_step_size > 0.0) step_size = fixed_step_size;
-  for (int curr_step = 0; curr_step < total_steps; curr_step++) {
-    const float curr_cdf = ((float)curr_step + UN[K + curr_step]) * step_size;
-    while (curr_cdf > curr_max_cdf) {
-      SI[K + s] = PI[H + curr_bin];
-      SS[K + s] = (curr_max_depth - z_low);
-      SD[K + s] = (curr_max_depth + z_low) * .5;
-      curr_bin++;
-      s++;
-      if ((curr_bin >= max_hits) || (PI[H + curr_bin] == -1)) {
-        done = true;
-        break;
-      }
-      curr_min_depth = MN[H + curr_bin];
-      curr_max_depth = MX[H + curr_bin];
-      curr_min_cdf = curr_max_cdf;
-      curr_max_cdf = curr_max_cdf + PR[H + curr_bin];
-      z_low = curr_min_depth;
+  auto pi = [&](int i) -> int {
+    return (boff + i < pi_total) ? PI[i] : -1;
+  };
+  auto emit = [&](int slot, int id, float zhi, float zlo) {
+    if (slot < max_steps) {
+      SI[K + slot] = id;
+      SS[K + slot] = zhi - zlo;
+      SD[K + slot] = (zhi + zlo) * 0.5f;
     }
-    if (done) break;
-    const float u = (curr_cdf - curr_min_cdf) / (curr_max_cdf - curr_min_cdf);
-    const float z = curr_min_depth + u * (curr_max_depth - curr_min_depth);
-    SI[K + s] = PI[H + curr_bin];
-    SS[K + s] = (z - z_low);
-    SD[K + s] = (z + z_low) * .5;
-    z_low = z;
-    s++;
+  };
+  // valid bins: bin 0 always, then up to the first -1
+  int nbv = max_hits;
+  for (int b0 = 0; b0 < max_hits; b0 += 64) {
+    const int b = b0 + lane;
+    const bool stop = b >= 1 && b < max_hits && pi(H + b) == -1;
+    const uint64_t m = __ballot(stop);
+    if (m) {
+      nbv = b0 + __builtin_ctzll(m);
+      break;
+    }
   }
-  // remaining bins; the reference's "(~done)" is always true and its
-  // termination test reads pts_idx WITHOUT the ray offset (sample_gpu.cu:224,231)
-  while ((z_low < curr_max_depth) && (num_rays > (H + curr_bin))) {
-    SI[K + s] = PI[H + curr_bin];
-    SS[K + s] = (curr_max_depth - z_low);
-    SD[K + s] = (curr_max_depth + z_low) * .5;
-    curr_bin++;
-    s++;
-    if ((curr_bin >= max_hits) || (PI[curr_bin] == -1)) break;
-    curr_min_depth = MN[H + curr_bin];
-    curr_max_depth = MX[H + curr_bin];
-    z_low = curr_min_depth;
+  {  // serial prefix sum, one writer
+    float acc = 0.f;
+    for (int b = 0; b < nbv; ++b) {
+      acc = acc + PR[H + b];
+      if (lane == 0) cum[b] = acc;
+    }
+  }
+  wave_lds_sync();
+  const float st = steps[(int64_t)bi * num_rays + j];
+  float step_size = (float)(1.0 / (double)st);
+  if (fixed_step_size > 0.0) step_size = fixed_step_size;
+  const int total = (int)ceil((double)st);
+  int carry_bin = 0;         // bin of the last step of the previous round
+  float carry_z = MN[H];     // its z
+  int run_bin = 0;
+  bool done = false;
+  int tail_bin = 0, tail_s = 0;
+  float tail_zlow = carry_z, tail_max = MX[H];
+  for (int base = 0; base < total; base += 64) {
+    const int c = base + lane;
+    const bool act = c < total;
+    int f = 0;
+    float cdf = 0.f;
+    if (act) {
+      cdf = ((float)c + UN[K + c]) * step_size;
+      while (f < nbv && cdf > cum[f]) ++f;
+    }
+    int bn = f;  // inclusive running max over the lanes, then the carry
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(bn, o);
+      if (lane >= o) bn = bn > u ? bn : u;
+    }
+    bn = bn > run_bin ? bn : run_bin;
+    const uint64_t dmask = __ballot(act && bn >= nbv);
+    const int first_done = dmask ? __builtin_ctzll(dmask) : 64;
+    const bool mine = act && lane <= first_done;
+    const bool is_done = lane == first_done;
+    float z = 0.f;
+    if (mine && !is_done) {
+      const float cmin = bn > 0 ? cum[bn - 1] : 0.f;
+      const float u = (cdf - cmin) / (cum[bn] - cmin);
+      const float lo = MN[H + bn];
+      z = fmaf(u, MX[H + bn] - lo, lo);  // nvcc contracts this expression
+    }
+    int pb = __shfl_up(bn, 1);
+    float pz = __shfl_up(z, 1);
+    if (lane == 0) {
+      pb = carry_bin;
+      pz = carry_z;
+    }
+    if (mine) {
+      const int hi = bn < nbv ? bn : nbv;
+      for (int b = pb; b < hi; ++b)  // boundaries crossed since step c-1
+        emit(c + b, pi(H + b), MX[H + b], b == pb ? pz : MN[H + b]);
+      if (!is_done)
+        emit(c + bn, pi(H + bn), z, bn == pb ? pz : MN[H + bn]);
+    }
+    if (first_done < 64) {
+      // state after the reference's `done` break, from the done lane
+      const float zl = (nbv - 1 == pb) ? pz : MN[H + nbv - 1];
+      tail_zlow = __shfl(zl, first_done);
+      tail_bin = nbv;
+      tail_s = base + first_done + nbv;
+      tail_max = MX[H + nbv - 1];
+      done = true;
+      break;
+    }
+    const int last = (total - base < 64 ? total - base : 64) - 1;
+    carry_bin = __shfl(bn, last);
+    carry_z = __shfl(z, last);
+    run_bin = carry_bin;
+  }
+  if (!done) {
+    tail_bin = carry_bin;
+    tail_s = total + carry_bin;
+    tail_zlow = carry_z;
+    tail_max = MX[H + carry_bin];
+  }
+  if (lane != 0) return;
+  while (tail_zlow < tail_max && num_rays > H + tail_bin) {
+    emit(tail_s, pi(H + tail_bin), tail_max, tail_zlow);
+    ++tail_bin;
+    ++tail_s;
+    if (tail_bin >= max_hits || pi(tail_bin) == -1) break;
+    tail_max = MX[H + tail_bin];
+    tail_zlow = MN[H + tail_bin];
   }
 }
 
@@ -215,12 +298,14 @@ int xrd_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
       !steps || !sampled_idx || !sampled_depth || !sampled_dists)
     return XRD_ERR_ARG;
   if (b > 65535) return XRD_ERR_UNSUPPORTED;
-  const dim3 grid((num_rays + 63) / 64, b);
-  hipLaunchKernelGGL(inverse_cdf_kernel, grid, dim3(64), 0,
+  const dim3 grid((num_rays + kCdfWaves - 1) / kCdfWaves, b);
+  const size_t lds = (size_t)kCdfWaves * max_hits * sizeof(float);
+  if (lds > 60 * 1024) return XRD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(inverse_cdf_kernel, grid, dim3(kCdfWaves * 64), lds,
                      (hipStream_t)stream, num_rays, max_hits, max_steps,
-                     fixed_step_size, pts_idx, min_depth, max_depth,
-                     uniform_noise, probs, steps, sampled_idx, sampled_depth,
-                     sampled_dists);
+                     fixed_step_size, (int64_t)b * num_rays * max_hits, pts_idx,
+                     min_depth, max_depth, uniform_noise, probs, steps,
+                     sampled_idx, sampled_depth, sampled_dists);
   return check_launch("xrd_inverse_cdf_sampling");
 }
 

@@ -91,6 +91,11 @@ class FusedCellAdam(torch.optim.Optimizer):
             else None
         cf = p.shape[1]
         n = int(cells.numel()) if cells is not None else p.numel() // cf
+        if n == 0 and count is None:
+            # empty frustum selection: torch's Adam over an empty val[mask]
+            # does nothing (and does not advance this parameter's step)
+            p._xrd_grad_fresh = False
+            return
         if self._m is None:
             self._m = torch.zeros(n * cf, dtype=torch.float32, device=p.device)
             self._v = torch.zeros_like(self._m)
