@@ -80,3 +80,128 @@ def run_case(model, g, tag, is_mapping, first, device):
         errs[f'g_dec/{k}'] = rel_err(p.grad.cpu().numpy(),
                                      g[f'{tag}/g_dec/{k}'])
     return errs
+
+
+# ---------------------------------------------------------------------------
+# BASELINE-config case: default JointEncodingConfig (2^16-entry table, 16
+# levels of which 5..15 are hashed), office0 mapping bound, the ray counts of
+# the reference loop (1024 tracking rays; 2048 + 341 mapping rays).  The
+# fixture (tests/golden/coslam_office0.npz, oracle/make_golden_coslam_office0.py)
+# stores only what cannot be regenerated: the reference's outputs.  Inputs,
+# the hash table and the random draws come from seeded generators, the same
+# code on both sides.
+# ---------------------------------------------------------------------------
+OFFICE0 = os.path.join(os.path.dirname(__file__), 'golden',
+                       'coslam_office0.npz')
+OFFICE0_BOUND = [[-3, 3], [-4, 2.5], [-2, 2.5]]  # input_config.py:224
+OFFICE0_CASES = (('track', False, False, 1024), ('map', True, False, 2389))
+HASH_SAMPLE = 65536   # table-gradient entries stored in the fixture
+RAY_STRIDE = 16       # z_vals / raw are stored for every 16th ray
+
+
+def office0_inputs(n, seed):
+    """rays from inside the office0 bound with sensor depths (some invalid)"""
+    g = torch.Generator().manual_seed(seed)
+    rays_o = torch.tensor([0.3, -0.6, 0.2]) + \
+        (torch.rand(n, 3, generator=g) - 0.5) * 0.8
+    rays_d = torch.randn(n, 3, generator=g)
+    rays_d = rays_d / rays_d.norm(dim=1, keepdim=True)
+    depth = 0.5 + 2.5 * torch.rand(n, 1, generator=g)
+    depth[torch.rand(n, 1, generator=g) < 0.1] = 0.0
+    color = torch.rand(n, 3, generator=g)
+    return rays_o, rays_d, depth, color
+
+
+def office0_table(n_params, seed=21):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n_params, dtype=np.float32) *
+            np.float32(0.05))
+
+
+def office0_decoder_state(model, seed=22):
+    """deterministic non-trivial decoder weights (the module's own init
+    depends on the global RNG state at construction)"""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in model.decoder.state_dict().items():
+        fan = v.shape[-1] if v.dim() > 1 else v.shape[0]
+        sd[k] = (torch.rand(v.shape, generator=g) * 2 - 1) / float(fan)**0.5
+    return sd
+
+
+def hash_sample_index(n_params, seed=23):
+    return np.random.default_rng(seed).integers(0, n_params, HASH_SAMPLE)
+
+
+def office0_summary(res, ld, ro, rd, hash_grad, dec_named_grads, n_params):
+    """what the fixture stores of one case"""
+    out = {}
+    for k in ('rgb', 'depth', 'depth_var', 'acc_map'):
+        out[k] = res[k].detach().cpu().numpy()
+    out['z_vals'] = res['z_vals'].detach().cpu().numpy()[::RAY_STRIDE]
+    out['raw'] = res['raw'].detach().cpu().numpy()[::RAY_STRIDE]
+    for k, v in ld.items():
+        out[f'loss_{k}'] = v.detach().cpu().numpy()
+    out['g_rays_o'] = ro.grad.cpu().numpy()
+    out['g_rays_d'] = rd.grad.cpu().numpy()
+    gh = hash_grad.detach().cpu().numpy().astype(np.float64)
+    out['g_hash_sample'] = gh[hash_sample_index(n_params)].astype(np.float32)
+    out['g_hash_sum'] = np.array([gh.sum(), np.abs(gh).sum(),
+                                  np.sqrt((gh * gh).sum())])
+    out['g_hash_nnz'] = np.int64((gh != 0).sum())
+    for k, gr in dec_named_grads:
+        out[f'g_dec/{k}'] = gr.cpu().numpy().copy()
+    return out
+
+
+def build_office0_model(device):
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.joint_encoding import (JointEncoding,
+                                                        JointEncodingConfig)
+    cfg = JointEncodingConfig(cam_depth_trunc=100.0, tcnn_encoding=True)
+    model = JointEncoding(cfg, Camera(600., 600., 599.5, 339.5, 1200, 680),
+                          torch.tensor(OFFICE0_BOUND, dtype=torch.float64))
+    model.decoder.load_state_dict(office0_decoder_state(model))
+    model = model.to(device)
+    with torch.no_grad():
+        n = model.embed_fn.params.numel()
+        model.embed_fn.params.copy_(torch.from_numpy(office0_table(n)))
+    return model
+
+
+def run_office0_case(model, tag, is_mapping, first, n, device):
+    """-> summary dict of the same layout as the fixture's"""
+    gen = torch.Generator().manual_seed(11)
+
+    def fed(shape, like):
+        return torch.rand(tuple(shape), generator=gen).to(like)
+
+    model._rand = fed
+    for p in model.parameters():
+        p.grad = None
+    rays_o, rays_d, depth, color = office0_inputs(n, 3 if not is_mapping
+                                                  else 4)
+    ro = rays_o.to(device).requires_grad_(True)
+    rd = rays_d.to(device).requires_grad_(True)
+    inp = {'rays_o': ro, 'rays_d': rd, 'first': first,
+           'target_s': color.to(device), 'target_d': depth.to(device)}
+    res = model.get_outputs(inp)
+    ld = model.get_loss_dict(res, inp, is_mapping, 0)
+    sum(ld.values()).backward()
+    return office0_summary(
+        res, ld, ro, rd, model.embed_fn.params.grad,
+        [(k, p.grad) for k, p in model.decoder.named_parameters()],
+        model.embed_fn.params.numel())
+
+
+def office0_pairs(got, gold, tag):
+    """(name, got, want) for every stored quantity of one case"""
+    pairs = []
+    for k, v in got.items():
+        key = f'{tag}/{k}'
+        if k == 'g_hash_nnz':
+            continue
+        if k.startswith('loss_') and key not in gold.files:
+            continue  # fused loss path reports one data term (see run_case)
+        pairs.append((f'coslam_office0/{key}', v, gold[key]))
+    return pairs

@@ -30,6 +30,33 @@ def test_joint_encoding_vs_reference(tag, is_mapping, first, fused):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('mode', ['fused', 'fused_loss', 'modular'])
+@pytest.mark.parametrize('tag,is_mapping,first,n', cg.OFFICE0_CASES)
+def test_baseline_config_vs_reference(tag, is_mapping, first, n, mode):
+    """BASELINE configuration: the reference's DEFAULT JointEncodingConfig
+    (2^16-entry table: levels 5..15 hashed), office0 bound, 1024 tracking /
+    2389 mapping rays, against tests/golden/coslam_office0.npz (made from the
+    reference's own model).  1e-4 in the max norm AND element-wise
+    (tests/parity.py) for outputs, losses, ray / table / decoder gradients."""
+    import parity
+    gold = np.load(cg.OFFICE0)
+    model = cg.build_office0_model('cuda:0')
+    model.use_fused = mode != 'modular'
+    model.fused_losses = mode == 'fused_loss'
+    assert (model._fused_tables('cuda:0') is not None) == model.use_fused
+    got = cg.run_office0_case(model, tag, is_mapping, first, n, 'cuda:0')
+    pairs = cg.office0_pairs(got, gold, tag)
+    if mode == 'fused_loss':
+        # the fused loss reports the four data terms as one value
+        data = [k for k in gold.files if k.startswith(f'{tag}/loss_')
+                and not k.endswith('smooth_loss')]
+        total = sum(float(v) for k, v in got.items() if k.startswith('loss_')
+                    and not k.endswith('smooth_loss'))
+        pairs.append((f'coslam_office0/{tag}/loss_data_total', total,
+                      sum(float(gold[k]) for k in data)))
+    parity.assert_all([(f'{mode}:{n_}', a, b) for n_, a, b in pairs])
+
+
 @pytest.mark.parametrize('tag,is_mapping,first', cg.TAGS)
 def test_fused_loss_vs_reference(tag, is_mapping, first):
     """xrd_coslam_loss (loss terms + their gradients through the fused

@@ -33,6 +33,20 @@ def test_joint_encoding_vs_reference(oracle_encodings, tag, is_mapping, first):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('tag,is_mapping,first,n', cg.OFFICE0_CASES)
+def test_joint_encoding_at_baseline_config(oracle_encodings, tag, is_mapping,
+                                           first, n):
+    """host mirror == the reference's JointEncoding at its DEFAULT config
+    (2^16 table, office0 bound, 1024 / 2389 rays), max-norm and element-wise"""
+    import parity
+    gold = np.load(cg.OFFICE0)
+    model = cg.build_office0_model('cpu')
+    assert model.embed_fn.params.numel() == int(gold['n_params'])
+    assert model.resolution_sdf == int(gold['resolution_sdf'])
+    got = cg.run_office0_case(model, tag, is_mapping, first, n, 'cpu')
+    parity.assert_all(cg.office0_pairs(got, gold, tag))
+
+
 def test_fixed_shape_depth_loss_equals_compacted(oracle_encodings):
     g = np.load(cg.GOLDEN)
     model = cg.build_model(g, 'cpu')

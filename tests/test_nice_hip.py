@@ -152,6 +152,121 @@ def test_render_vs_oracle_fresh_inputs(n_rays):
             assert rel_err(rgb.cpu(), ref['rgb']) < TOL, stage
 
 
+OFFICE0_BOUND = [[-5.5, 6.0199995], [-6.7, 5.4599998], [-4.7, 5.5399998]]
+OFFICE0_GRIDS = {'grid_coarse': (10, 12, 11), 'grid_middle': (31, 37, 35),
+                 'grid_fine': (63, 75, 71), 'grid_color': (63, 75, 71)}
+
+
+def _office0_case(seed):
+    """NICE-SLAM at BASELINE configs[1]: office0 bound (input_config.py:66,
+    rounded up to whole cells like conv_onet.py:67-75 does) with the grid
+    sizes that follow from it: fine / colour 63x75x71 cells"""
+    from xrdslam_amd.engine import nice as en
+    g = torch.Generator().manual_seed(seed)
+    bound = torch.tensor(OFFICE0_BOUND, dtype=torch.float64)
+    grids = {k: torch.randn(1, 32, *s, generator=g) * 0.05
+             for k, s in OFFICE0_GRIDS.items()}
+    # hidden layers O(1); a small output layer keeps the occupancy logits
+    # around +-0.1 so that 10*occ does not saturate the sigmoid and every
+    # sample of a ray carries weight and gradient
+    def scale(kind, n):
+        if n == 'embedder._B':
+            return 25.
+        if n.startswith('output_linear') and kind != 'color':
+            return 0.01
+        return 0.2
+    decs = {kind: {n: torch.randn(*s, generator=g) * scale(kind, n)
+                   for n, s in en.param_shapes(kind)}
+            for kind in ('coarse', 'middle', 'fine', 'color')}
+    for kind in ('coarse', 'middle', 'fine'):
+        # mostly free space along a ray: weights spread over many samples
+        decs[kind]['output_linear.bias'] -= 0.12
+    return bound, grids, decs
+
+
+def _office0_rays(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    rays_o = torch.tensor([0.2, -0.5, 0.3]) + \
+        (torch.rand(n, 3, generator=g) - 0.5) * 1.5
+    rays_d = torch.randn(n, 3, generator=g)
+    rays_d = rays_d / rays_d.norm(dim=1, keepdim=True)
+    depth = 0.8 + 3.5 * torch.rand(n, 1, generator=g)
+    depth[torch.rand(n, 1, generator=g) < 0.08] = 0.0
+    color = torch.rand(n, 3, generator=g)
+    return rays_o, rays_d, depth, color
+
+
+@pytest.mark.parametrize('tag,n_rays', [('color_track', 200),
+                                        ('middle_map', 1000),
+                                        ('fine_map', 1000),
+                                        ('color_map', 1000),
+                                        ('coarse_map', 1000)])
+def test_render_at_baseline_config_vs_oracle(tag, n_rays):
+    """the batch sizes of the reference loop (200 tracking rays, 1000 mapping
+    rays) on office0-sized grids, forward and backward, against the CPU oracle
+    (pinned to the reference by tests/test_oracle_nice.py): rendered
+    depth / uncertainty / colour, loss, ray gradients, all four grid
+    gradients and the colour-decoder gradient, 1e-4 in the max norm and
+    element-wise (tests/parity.py)."""
+    import parity
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    stage, mode = tag.split('_')
+    is_mapping = mode == 'map'
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n_rays, 2 + n_rays)
+    # oracle
+    og = {k: v.clone().requires_grad_(is_mapping) for k, v in grids.items()}
+    od = {kind: {n: v.clone().requires_grad_(is_mapping and kind == 'color')
+                 for n, v in sd.items()} for kind, sd in decs.items()}
+    ro = rays_o.clone().requires_grad_(stage != 'coarse')
+    rd = rays_d.clone().requires_grad_(stage != 'coarse')
+    ref = no.render_batch_ray(ro, rd, depth, og, od, bound, stage)
+    ref_loss = sum(no.loss_dict(ref, depth, color, is_mapping,
+                                stage).values())
+    ref_loss.backward()
+    # HIP
+    scene, gl, flats = build_scene(bound, grids, decs, dev,
+                                   color_requires_grad=is_mapping,
+                                   grid_requires_grad=is_mapping)
+    go = rays_o.to(dev).requires_grad_(stage != 'coarse')
+    gd = rays_d.to(dev).requires_grad_(stage != 'coarse')
+    d, u, rgb = en.nice_render(scene, stage, go, gd, depth.to(dev))
+    out = {'depth': d, 'uncertainty': u, 'rgb': rgb}
+    loss = sum(no.loss_dict(out, depth.to(dev), color.to(dev), is_mapping,
+                            stage).values())
+    loss.backward()
+    torch.cuda.synchronize()
+    pairs = [('depth', d, ref['depth']), ('uncertainty', u,
+                                          ref['uncertainty']),
+             ('loss', loss, ref_loss)]
+    if stage == 'color':
+        pairs.append(('rgb', rgb, ref['rgb']))
+    if stage != 'coarse':
+        pairs += [('g_rays_o', go.grad, ro.grad), ('g_rays_d', gd.grad,
+                                                   rd.grad)]
+    if is_mapping:
+        for k, grid in gl.items():
+            want = og[k].grad
+            if want is None or float(want.abs().max()) == 0.0:
+                assert grid.grad is None or float(grid.grad.abs().max()) == 0
+                continue
+            pairs.append((f'g_{k}', grid.grad, want))
+        if stage == 'color':
+            gf = flats['color'].grad.cpu()
+            off = 0
+            for name, shape in en.param_shapes('color'):
+                n = int(np.prod(shape))
+                want = od['color'][name].grad
+                got = gf[off:off + n].reshape(shape)
+                off += n
+                if want is None:  # fc_c/.. entries the stage does not reach
+                    assert float(got.abs().max()) == 0.0, name
+                    continue
+                pairs.append((f'g_dec_color/{name}', got, want))
+    parity.assert_all([(f'nice_office0/{tag}/{n}', a, b) for n, a, b in pairs])
+
+
 def test_adam_cells_matches_torch():
     from xrdslam_amd import _lib
     dev = _cuda()
