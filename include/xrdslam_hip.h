@@ -101,15 +101,23 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):
- *   g_rays_o, g_rays_d [n,3] f32 (overwritten);
+ *   g_rays_o, g_rays_d [n,3] f32 (overwritten; per-tile f64 partial sums in
+ *     `ws`, added in a fixed order);
  *   g_grid[4] channel-last like the grids (ACCUMULATED with atomics: caller
  *     zeroes);
- *   g_dec[4]  flat state_dict-ordered decoder gradients (overwritten;
- *     deterministic two-stage reduction through `ws`).  Only XRD_DEC_COLOR is
- *     supported in this version (mapping_fix_fine=True default,
- *     conv_onet.py:62,190-195); others -> XRD_ERR_UNSUPPORTED.
- *   ws: float workspace of xrd_nice_bwd_ws_floats(n_rays) floats (needed only
- *     when a g_dec is requested). */
+ *   g_dec[4]  flat state_dict-ordered decoder gradients (overwritten).  The
+ *     weight gradients are contracted inside the render backward (MFMA
+ *     accumulators kept across tiles, operands exchanged through LDS) and
+ *     added to 8 replicas in `ws` that a finishing launch sums.  Only
+ *     XRD_DEC_COLOR is supported in this version (mapping_fix_fine=True
+ *     default, conv_onet.py:62,190-195); others -> XRD_ERR_UNSUPPORTED.
+ *   ws: float workspace of xrd_nice_bwd_ws_floats(n_rays) floats, 16-byte
+ *     aligned, contents arbitrary on entry (needed when ray or decoder
+ *     gradients are requested; the coarse stage takes its replica buffer
+ *     here instead, see above).
+ * Launches: the middle / fine / colour stages are ONE kernel over every decoder
+ * of the stage (+ one finishing launch when ray or decoder gradients are
+ * wanted, + one fill of the replicas for decoder gradients). */
 int64_t xrd_nice_bwd_ws_floats(int n_rays);
 int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
                         const float* rays_o, const float* rays_d,

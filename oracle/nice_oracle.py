@@ -18,8 +18,27 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
+
+# compute type of the "f32" casts of the reference.  float32 restates the
+# reference; ``with high_precision():`` evaluates the same formulas in float64
+# throughout — the yardstick for terms where two correct float32 evaluations
+# (torch on the CPU, torch on CUDA, the fused kernels) differ by more than 1e-4
+# because the term itself is ill-conditioned (tests/test_nice_hip.py).
+_FT = torch.float32
+
+
+@contextlib.contextmanager
+def high_precision():
+    global _FT
+    old, _FT = _FT, torch.float64
+    try:
+        yield
+    finally:
+        _FT = old
 
 
 # --------------------------------------------------------------------------
@@ -53,7 +72,7 @@ def sample_grid(p, grid, bound):
     f64 normalisation -> f32 -> F.grid_sample(bilinear, border,
     align_corners=True) on a [1,C,Z,Y,X] grid; returns [P,C]."""
     p_nor = normalize_3d(p, bound).unsqueeze(0)
-    vgrid = p_nor[:, :, None, None].float()
+    vgrid = p_nor[:, :, None, None].to(_FT)
     c = F.grid_sample(grid, vgrid, padding_mode='border', align_corners=True,
                       mode='bilinear').squeeze(-1).squeeze(-1)
     return c.transpose(1, 2).squeeze(0)
@@ -62,7 +81,7 @@ def sample_grid(p, grid, bound):
 def mlp_forward(sd: Dict[str, torch.Tensor], p, c, skips=(2, ), n_blocks=5):
     """slam/model_components/decoder_nice.py:207-234 (MLP.forward) with the
     Gaussian-Fourier embedding of :33-38 (sin(p @ B), p cast to f32)."""
-    p = p.float()
+    p = p.to(_FT)
     emb = torch.sin(p @ sd['embedder._B'])
     h = emb
     for i in range(n_blocks):
@@ -94,7 +113,7 @@ def nice_forward(p, grids, decoders, bound, stage, coarse_enlarge=2):
     ``grids``: dict grid_{coarse,middle,fine,color} -> [1,32,Z,Y,X];
     ``decoders``: dict {coarse,middle,fine,color} -> state dict."""
     P = p.shape[0]
-    raw = torch.zeros(P, 4, dtype=torch.float32, device=p.device)
+    raw = torch.zeros(P, 4, dtype=_FT, device=p.device)
     if stage == 'coarse':
         c = sample_grid(p, grids['grid_coarse'], bound * coarse_enlarge)
         raw[:, 3] = mlp_no_xyz_forward(decoders['coarse'], c).squeeze(-1)
@@ -185,11 +204,11 @@ def composite(raw, z_vals, coef=10.0):
     1-alpha+1e-10); rgb/depth/var sums. depth/var come out float64 because
     z_vals is float64."""
     rgb = raw[..., :3]
-    alpha = torch.sigmoid(coef * raw[..., 3]).float()
-    ones = torch.ones((alpha.shape[0], 1), dtype=torch.float32,
+    alpha = torch.sigmoid(coef * raw[..., 3]).to(_FT)
+    ones = torch.ones((alpha.shape[0], 1), dtype=_FT,
                       device=alpha.device)
     weights = alpha * torch.cumprod(
-        torch.cat([ones, (1. - alpha + 1e-10).float()], -1), -1)[:, :-1]
+        torch.cat([ones, (1. - alpha + 1e-10).to(_FT)], -1), -1)[:, :-1]
     rgb_map = torch.sum(weights[..., None] * rgb, -2)
     depth_map = torch.sum(weights * z_vals, -1)
     tmp = z_vals - depth_map.unsqueeze(-1)

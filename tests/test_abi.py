@@ -99,15 +99,16 @@ def test_argument_checks_of_the_iteration_kernels():
 
 
 def test_backward_workspace_contract():
-    """xrd_nice_bwd_ws_floats(n): staging of n*48 points + one partial weight
-    gradient per persistent block of the dW kernel + 64 floats"""
+    """xrd_nice_bwd_ws_floats(n): one row of 6 f64 ray-gradient partials per
+    tile (3 tiles a ray at most) + 8 replicas of the colour-decoder gradient +
+    64 floats.  No per-point staging any more: the dW operands stay in LDS."""
     lib = _lib.lib()
     color_flat = lib.xrd_nice_flat_len(3)
-    per_point = 5 * 32 + 5 * 32 + 5 + 32 + 4 + 4 + 96
     a, b = lib.xrd_nice_bwd_ws_floats(1000), lib.xrd_nice_bwd_ws_floats(200)
-    assert a - b == 800 * 48 * per_point
-    blocks, rem = divmod(b - 200 * 48 * per_point - 64, color_flat)
-    assert rem == 0 and blocks == 512
+    assert a - b == 800 * 3 * 6 * 2
+    reps, rem = divmod(b - 200 * 3 * 6 * 2 - 64, color_flat)
+    assert rem == 0 and reps == 8
+    assert a * 4 < 1 << 20  # round 1 staged 93 MB for 1000 rays
 
 
 def test_every_entry_point_survives_null_arguments():

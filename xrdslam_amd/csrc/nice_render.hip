@@ -26,12 +26,6 @@ constexpr int PTS = 17;
 // scheduling fence: keeps hipcc from hoisting a whole phase's weight-fragment
 // loads (and their VGPRs) across phases
 #define XRD_SB() __builtin_amdgcn_sched_barrier(0)
-#ifndef XRD_BWD_WAVES
-#define XRD_BWD_WAVES 2
-#endif
-#ifndef XRD_EXP
-#define XRD_EXP 0
-#endif  // padded point stride of transposed LDS tiles
 
 // ---------------------------------------------------------------------------
 // host: packed <- flat index tables
@@ -294,21 +288,27 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
       atomicAdd(ggrid + cur[k] + ch, acc[k]);
 }
 
-// Staging buffers for the colour-decoder weight gradients.  The backward
-// kernel stores, per sample point, what the dW contraction needs; a separate
-// split-K MFMA kernel (nice_dw_kernel) then contracts over all points.  This
-// keeps the per-tile backward free of LDS accumulators and atomics.
-struct DwSave {
-  float* gh;      // [5][P][32]  d loss / d h_i (before the ReLU mask)
-  float* hs;      // [5][P][32]  h_i (layer outputs)
-  uint32_t* mk;   // [5][P]      ReLU masks, bit f = feature f active
-  float* c;       // [P][32]     grid features
-  float* go;      // [P][4]      d loss / d decoder output
-  float* pp;      // [P][4]      f32 sample position
-  float* ge;      // [P][96]     d loss / d (p.B) per Fourier feature
-  int64_t P;      // number of points
+// Per-wave LDS region of the fused backward when the colour decoder's weight
+// gradients are wanted.  Every wave (= one 16-point tile) keeps what the dW
+// contractions need as point-major matrices [16 points][32 features] with a
+// row stride of 36 floats: the producer writes its accumulator-layout
+// registers as one b128 per (jt) and a consumer lane (m = l&15, q = l>>4)
+// reads feature 16jt+m of point 4q+s for K-step s — with stride 36 the four
+// lane groups q fall into four disjoint 16-bank ranges.  The matrices never
+// leave LDS (round 1 staged them through HBM: 90 MB per launch).
+struct DwLds {
+  static constexpr int RS = 36;
+  static constexpr int MAT = 16 * RS;    // 576 floats
+  static constexpr int TC = 0;           // grid features c
+  static constexpr int TH0 = MAT;        // h_0..h_3, then h_4 (= TX)
+  static constexpr int TX = 5 * MAT;     // h_4, later the masked ga_0
+  static constexpr int TA = 6 * MAT;     // gh_4, gh_2, gh_0
+  static constexpr int TB = 7 * MAT;     // gh_3, gh_1, later the masked ga_3
+  static constexpr int TM = 8 * MAT;     // ReLU masks [5][16] (bit f = feature f)
+  static constexpr int TP = TM + 80;     // sample positions [16][4]
+  static constexpr int TGO = TP + 64;    // d loss / d decoder output [16][4]
+  static constexpr int LEN = TGO + 64;   // 4816 floats = 19264 B per wave
 };
-constexpr int kDwFloatsPerPoint = 5 * 32 + 5 * 32 + 5 + 32 + 4 + 4 + 96;
 
 // ---------------------------------------------------------------------------
 // device: MLP decoder forward (decoder_nice.py:207-234)
@@ -325,9 +325,11 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
                                         const float (&p)[NT][3],
                                         const f32x4 (&c)[NT][CD / 16],
                                         float (&out)[NT][OD],
-                                        uint64_t (&mask)[NT], const DwSave& W,
-                                        const int64_t (&pt)[NT]) {
+                                        uint64_t (&mask)[NT],
+                                        float* __restrict__ hl) {
+  // SAVE_H: layer outputs h_0..h_4 go to the wave's LDS region hl (DwLds)
   using P = MlpPack<CD, OD>;
+  static_assert(!SAVE_H || NT == 1, "LDS save: one tile per wave");
   const int q = lane >> 4;
   f32x4 acc[NT][2], acc3[NT][2];
 #pragma unroll
@@ -400,8 +402,9 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
           h[t][jt][r] = fmaxf(a, 0.f) + cc[t][jt][r];
         }
         if (SAVE_H)
-          *reinterpret_cast<f32x4*>(W.hs + ((int64_t)i * W.P + pt[t]) * 32 +
-                                    16 * jt + 4 * q) = h[t][jt];
+          *reinterpret_cast<f32x4*>(hl + DwLds::TH0 + i * DwLds::MAT +
+                                    (lane & 15) * DwLds::RS + 16 * jt +
+                                    4 * q) = h[t][jt];
       }
     if (i < 4) {
 #pragma unroll
@@ -515,15 +518,13 @@ __device__ __forceinline__ void noxyz_fwd(const float* __restrict__ pk,
 // ---------------------------------------------------------------------------
 // device: MLP decoder backward
 // ---------------------------------------------------------------------------
-template <int NT, int CD, int OD, bool NEED_E, bool NEED_DP, bool NEED_DW>
+template <int NT, int CD, int OD, bool NEED_E, bool NEED_DP>
 __device__ __forceinline__ void mlp_bwd(
     const float* __restrict__ pk, int lane, const float (&p)[NT][3],
     const f32x4 (&c)[NT][CD / 16], const float (&gout)[NT][OD],
-    const uint64_t (&mask)[NT], f32x4 (&gc)[NT][CD / 16], float (&gp)[NT][3],
-    const DwSave& W, const int64_t (&pt)[NT]) {
+    const uint64_t (&mask)[NT], f32x4 (&gc)[NT][CD / 16],
+    float (&gp)[NT][3]) {
   using P = MlpPack<CD, OD>;
-  static_assert(!NEED_DW || (CD == 32 && OD == 4),
-                "weight grads: colour decoder only");
   const int q = lane >> 4;
   f32x4 gh[NT][2];
 #pragma unroll
@@ -545,23 +546,6 @@ __device__ __forceinline__ void mlp_bwd(
       gh[t][1] += w1 * gout[t][o];
     }
   }
-  if (NEED_DW && q == 0) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      *reinterpret_cast<f32x4*>(W.go + pt[t] * 4) =
-          f32x4{gout[t][0], gout[t][1], gout[t][2], gout[t][OD - 1]};
-      *reinterpret_cast<f32x4*>(W.pp + pt[t] * 4) =
-          f32x4{p[t][0], p[t][1], p[t][2], 0.f};
-    }
-  }
-  if (NEED_DW) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        *reinterpret_cast<f32x4*>(W.c + pt[t] * 32 + 16 * kt + 4 * q) =
-            c[t][kt];
-  }
   // masked gradients entering layers 3 and 0: the Fourier features feed both
   // (kept until the embedding backward after the loop; 16 registers instead
   // of 24 accumulators live across the whole layer loop)
@@ -571,24 +555,13 @@ __device__ __forceinline__ void mlp_bwd(
     f32x4 ga[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      uint32_t word = 0;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool on = (mask[t] >> (i * 8 + jt * 4 + r)) & 1;
           ga[t][jt][r] = on ? gh[t][jt][r] : 0.f;
-          if (NEED_DW && on) word |= 1u << (16 * jt + 4 * q + r);
         }
-      if (NEED_DW) {
-        word |= __shfl_xor((int)word, 16);
-        word |= __shfl_xor((int)word, 32);
-        if (q == 0) W.mk[(int64_t)i * W.P + pt[t]] = word;
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-          *reinterpret_cast<f32x4*>(W.gh + ((int64_t)i * W.P + pt[t]) * 32 +
-                                    16 * jt + 4 * q) = gh[t][jt];
-      }
     }
     // g_c += Wc_i^T gh
 #pragma unroll
@@ -663,223 +636,8 @@ __device__ __forceinline__ void mlp_bwd(
 #pragma unroll
             for (int a = 0; a < 3; ++a) gp[t][a] += garg * bk[a];
           }
-          if (NEED_DW) W.ge[pt[t] * 96 + k] = garg;
         }
       }
-    }
-  }
-}
-
-// Weight-gradient contraction of the colour decoder: dW = sum over points of
-// (gradient) x (layer input), as v_mfma_f32_16x16x4_f32 with the POINTS on the
-// K dimension.  kDwBlocks (512) persistent blocks x 4 waves; each wave owns a slice of the
-// flat gradient (accumulated in registers over all of the block's 16-point
-// chunks) and writes it once to the block's partial vector.
-//   wave 0: fc_c.{0..4} weight+bias      wave 1: pts_linears hidden parts+bias
-//   wave 2: pts_linears.0 (Fourier)      wave 3: pts_linears.3 Fourier part,
-//                                                output_linear, embedder._B
-__global__ __launch_bounds__(256) void nice_dw_kernel(
-    const float* __restrict__ pk, DwSave W, float* __restrict__ partial) {
-  using F = MlpFlat<32, 4>;
-  using P = MlpPack<32, 4>;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q = lane >> 4, m = lane & 15;
-  float* out = partial + (size_t)blockIdx.x * F::LEN;
-  const int64_t Pn = W.P;
-  const int64_t nchunks = (Pn + 15) / 16;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  if (wave == 0) {
-    f32x4 acc[5][2][2];
-    float bs[5][2];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        acc[i][jt][0] = z4;
-        acc[i][jt][1] = z4;
-        bs[i][jt] = 0.f;
-      }
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-      float cb[2][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int64_t pt = ch * 16 + 4 * s + q;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          cb[kt][s] = pt < Pn ? W.c[pt * 32 + 16 * kt + m] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int64_t pt = ch * 16 + 4 * s + q;
-#pragma unroll
-          for (int jt = 0; jt < 2; ++jt) {
-            const float a =
-                pt < Pn ? W.gh[((int64_t)i * Pn + pt) * 32 + 16 * jt + m] : 0.f;
-            bs[i][jt] += a;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-              acc[i][jt][kt] = XRD_MFMA4(a, cb[kt][s], acc[i][jt][kt]);
-          }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            out[F::fcw(i) + (16 * jt + 4 * q + r) * 32 + 16 * kt + m] =
-                acc[i][jt][kt][r];
-        const float b = group4_sum(bs[i][jt]);
-        if (q == 0) out[F::fcb(i) + 16 * jt + m] = b;
-      }
-  } else if (wave == 1) {
-    f32x4 acc[4][2][2];
-    float bs[5][2];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        if (i < 4) {
-          acc[i][jt][0] = z4;
-          acc[i][jt][1] = z4;
-        }
-        bs[i][jt] = 0.f;
-      }
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int64_t pt = ch * 16 + 4 * s + q;
-          const bool ok = pt < Pn;
-          const uint32_t word = ok ? W.mk[(int64_t)i * Pn + pt] : 0u;
-          float hb[2] = {0.f, 0.f};
-          if (i >= 1 && ok) {
-            hb[0] = W.hs[((int64_t)(i - 1) * Pn + pt) * 32 + m];
-            hb[1] = W.hs[((int64_t)(i - 1) * Pn + pt) * 32 + 16 + m];
-          }
-#pragma unroll
-          for (int jt = 0; jt < 2; ++jt) {
-            float a = 0.f;
-            if (ok && ((word >> (16 * jt + m)) & 1))
-              a = W.gh[((int64_t)i * Pn + pt) * 32 + 16 * jt + m];
-            bs[i][jt] += a;
-            if (i >= 1) {
-#pragma unroll
-              for (int kt = 0; kt < 2; ++kt)
-                acc[i - 1 < 0 ? 0 : i - 1][jt][kt] = XRD_MFMA4(
-                    a, hb[kt], acc[i - 1 < 0 ? 0 : i - 1][jt][kt]);
-            }
-          }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        if (i >= 1) {
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              out[F::pw(i) + (16 * jt + 4 * q + r) * F::pstride(i) +
-                  F::pcol(i) + 16 * kt + m] = acc[i - 1 < 0 ? 0 : i - 1][jt][kt][r];
-        }
-        const float b = group4_sum(bs[i][jt]);
-        if (q == 0) out[F::pb(i) + 16 * jt + m] = b;
-      }
-  } else {
-    // Fourier-feature weights: wave 2 -> layer 0, wave 3 -> layer 3
-    const int li = (wave == 2) ? 0 : 3;
-    const int wbase = (wave == 2) ? F::P0W : F::P3W;
-    const int wstride = (wave == 2) ? kEmbK : kEmbK + 32;
-    f32x4 acc[2][6], accO[2], accB[6];
-    float bo = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 6; ++kt) {
-      acc[0][kt] = z4;
-      acc[1][kt] = z4;
-      accB[kt] = z4;
-    }
-    accO[0] = z4;
-    accO[1] = z4;
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int64_t pt = ch * 16 + 4 * s + q;
-        const bool ok = pt < Pn;
-        const uint32_t word = ok ? W.mk[(int64_t)li * Pn + pt] : 0u;
-        float a[2];
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-          a[jt] = (ok && ((word >> (16 * jt + m)) & 1))
-                      ? W.gh[((int64_t)li * Pn + pt) * 32 + 16 * jt + m]
-                      : 0.f;
-        f32x4 pp = z4;
-        if (ok) pp = *reinterpret_cast<const f32x4*>(W.pp + pt * 4);
-        const float pv[3] = {pp[0], pp[1], pp[2]};
-#pragma unroll
-        for (int kt = 0; kt < 6; ++kt) {
-          const f32x4 bk =
-              *reinterpret_cast<const f32x4*>(pk + P::EMB + (16 * kt + m) * 4);
-          const float e = ok ? sin_cw(embed_arg(pv, bk)) : 0.f;
-          acc[0][kt] = XRD_MFMA4(a[0], e, acc[0][kt]);
-          acc[1][kt] = XRD_MFMA4(a[1], e, acc[1][kt]);
-        }
-        if (wave == 3) {
-          // output_linear: rows = output o (lane m < 4), cols = h4 features
-          const float ao = (ok && m < 4) ? W.go[pt * 4 + m] : 0.f;
-          bo += ao;
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            const float hb =
-                ok ? W.hs[((int64_t)4 * Pn + pt) * 32 + 16 * kt + m] : 0.f;
-            accO[kt] = XRD_MFMA4(ao, hb, accO[kt]);
-          }
-          // embedder._B: rows = axis a (lane m < 3), cols = Fourier feature
-          const float ap = (ok && m < 3) ? pv[m] : 0.f;
-#pragma unroll
-          for (int kt = 0; kt < 6; ++kt) {
-            const float gb = ok ? W.ge[pt * 96 + 16 * kt + m] : 0.f;
-            accB[kt] = XRD_MFMA4(ap, gb, accB[kt]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int kt = 0; kt < 6; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * kt + m;
-          if (k < kEmbK)
-            out[wbase + (16 * jt + 4 * q + r) * wstride + k] =
-                acc[jt][kt][r];
-        }
-    if (wave == 3) {
-      if (q == 0) {  // rows 0..3 of the accumulator live in lane group 0
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-            out[F::OW + r * 32 + 16 * kt + m] = accO[kt][r];
-          if (r < 3) {
-#pragma unroll
-            for (int kt = 0; kt < 6; ++kt) {
-              const int k = 16 * kt + m;
-              if (k < kEmbK) out[F::EB + r * kEmbK + k] = accB[kt][r];
-            }
-          }
-        }
-      }
-      const float b = group4_sum(bo);
-      if (q == 0 && m < 4) out[F::OB + m] = b;
     }
   }
 }
@@ -1086,8 +844,6 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
     const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
     float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
     uint64_t mdummy[1];
-    const DwSave wdummy = {};
-    const int64_t ptd[1] = {0};
     Tri tr;
     if (STAGE == XRD_STAGE_COARSE) {
       f32x4 c_a[1][2];
@@ -1103,7 +859,7 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
       {
         float om[1][1];
         mlp_fwd<1, 32, 1, false, false>(sc.dec[1], lane, p32, c_m, om, mdummy,
-                                        wdummy, ptd);
+                                        nullptr);
         occ = om[0][0];
       }
       if (STAGE >= XRD_STAGE_FINE) {
@@ -1116,7 +872,7 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
         c_f[0][2] = c_m[0][0];
         c_f[0][3] = c_m[0][1];
         mlp_fwd<1, 64, 1, false, false>(sc.dec[2], lane, p32, c_f, of, mdummy,
-                                        wdummy, ptd);
+                                        nullptr);
         occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
       }
       if (STAGE == XRD_STAGE_COLOR) {
@@ -1125,7 +881,7 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
         tri_gather(sc.grid[3], tr, q, c_c[0]);
         mlp_fwd<1, 32, 4, false, false>(sc.dec[3], lane, p32, c_c, oc, mdummy,
-                                        wdummy, ptd);
+                                        nullptr);
         col[0] = oc[0][0];
         col[1] = oc[0][1];
         col[2] = oc[0][2];
@@ -1169,11 +925,6 @@ __global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
   }
 }
 
-// One launch back-propagates ONE decoder (DEC = XRD_DEC_*): the stages that
-// evaluate several decoders launch this kernel once per decoder (the
-// composite backward from the saved raw is recomputed, it is cheap).  Keeping
-// a single decoder per kernel keeps the register footprint below the spill
-// threshold (a fused three-decoder backward needed > 512 VGPRs).
 constexpr int kCoarseRep = 32;  // replicas of the coarse-grid gradient
 
 // grad += sum of the replicas; the replicas are left zeroed for the next call
@@ -1193,224 +944,679 @@ __global__ __launch_bounds__(256) void coarse_rep_reduce_kernel(
   if (s != 0.f) grad[i] += s;
 }
 
-template <int DEC, int NT, bool NEED_DP, bool NEED_DW>
-__global__ __launch_bounds__(RPBB* NT * 64, XRD_BWD_WAVES) void nice_bwd_kernel(
+// Compositing backward (utils.py:189-244) of one ray from the saved raw: lane
+// l is sample l.  Returns d loss / d occupancy logit of the lane's sample, its
+// weight, and the ray's colour gradient.
+template <int S>
+__device__ __forceinline__ void composite_bwd(
+    const float* __restrict__ raw, int ray, int lane, double zl,
+    const double* __restrict__ g_depth, const double* __restrict__ g_var,
+    const float* __restrict__ g_rgb, float& gocc_s, float& w,
+    float (&grgb)[3]) {
+  const bool valid = lane < S;
+  f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+  if (valid)
+    rw = *reinterpret_cast<const f32x4*>(raw + ((size_t)ray * S + lane) * 4);
+  // alpha = sigmoid(10 occ) AND 1 - alpha = sigmoid(-10 occ), each to full
+  // relative precision: at a sharp surface alpha -> 1 and the reference's
+  // f32 "1 - alpha" (transmittance factor, sigmoid derivative) keeps only
+  // eps / (1 - alpha) relative accuracy — two f32 evaluations then disagree
+  // at 1e-4 on exactly the rays the tracking loss weights most
+  float alpha = 0.f, oma = 1.f;
+  if (valid) {
+    const float e = expf(-10.f * fabsf(rw[3]));  // <= 1
+    const float hi = 1.f / (1.f + e), lo = e / (1.f + e);
+    alpha = rw[3] >= 0.f ? hi : lo;
+    oma = rw[3] >= 0.f ? lo : hi;
+  }
+  const double f = (double)oma + 1e-10;
+  // transmittance, weights and the sums below in f64: the weight gradient
+  // subtracts nearly equal sums of gw*w, which turns the ~1e-6 rounding of an
+  // f32 product scan into 1e-4 of the result
+  double incl = valid ? f : 1.0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_up(incl, o);
+    if (lane >= o) incl *= u;
+  }
+  double T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.0;
+  const double wd = (double)alpha * T;
+  w = (float)wd;
+  const double dep = wave_sum(valid ? wd * zl : 0.0);
+  const double tmp = zl - dep;
+  const double gd_in = g_depth ? g_depth[ray] : 0.0;
+  const double gv_in = g_var ? g_var[ray] : 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) grgb[a] = g_rgb ? g_rgb[ray * 3 + a] : 0.f;
+  const double sw_tmp = wave_sum(valid ? wd * tmp : 0.0);
+  const double gdep = gd_in - 2.0 * gv_in * sw_tmp;
+  // d loss / d weight, and the suffix sums of the product-scan backward, in
+  // f64: galpha = gw*T - (sum_{j>i} gw_j w_j)/f subtracts two numbers that
+  // agree to ~2-3 digits when the depth term dominates (the tracking loss
+  // scales it by 1/sqrt(var)), so f32 sums lose the 1e-4 bar there — torch's
+  // own f32 evaluation does (tests/test_nice_hip.py compares both with an f64
+  // evaluation of the same formulas)
+  double gw = 0.0;
+  if (valid)
+    gw = gdep * zl + gv_in * tmp * tmp +
+         (double)(grgb[0] * rw[0] + grgb[1] * rw[1] + grgb[2] * rw[2]);
+  double suf = valid ? gw * wd : 0.0;  // inclusive suffix sum
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_down(suf, o);
+    if (lane + o < 64) suf += u;
+  }
+  double sexc = __shfl_down(suf, 1);
+  if (lane == 63) sexc = 0.0;
+  const float galpha =
+      valid ? (float)(gw * T - sexc / f) : 0.f;
+  gocc_s = galpha * 10.f * alpha * oma;
+}
+
+// Coarse stage backward (grid_coarse is its only parameter; no pose gradient,
+// conv_onet.py:187-195): one wave = one tile, a block = one ray.
+__global__ __launch_bounds__(2 * 64, 2) void nice_bwd_coarse_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ raw,
+    const double* __restrict__ g_depth, const double* __restrict__ g_var,
+    const float* __restrict__ g_rgb, float* gg_coarse,
+    float* __restrict__ ws) {
+  constexpr int NT = 2, S = 32;
+  __shared__ __attribute__((aligned(16))) float smem[NT * (256 + kScatterFloats)];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  float* R = smem + wave * (256 + kScatterFloats);
+  double* zbuf = reinterpret_cast<double*>(R);
+  ScatterLds SL;
+  SL.gt = R + 256;
+  SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
+  SL.w = SL.gt + 16 * 33 + 16 * 8;
+  for (int ray = blockIdx.x; ray < n; ray += gridDim.x) {
+    RayCtx rc;
+    load_ray(rays_o, rays_d, nullptr, ray, false, rc);
+    const double zl = sample_z<S>(sc, rc, 0.f, lane, zbuf, zbuf + 64);
+    float gocc_s, w, grgb[3];
+    composite_bwd<S>(raw, ray, lane, zl, g_depth, g_var, g_rgb, gocc_s, w,
+                     grgb);
+    const int src = 16 * wave + li;
+    TileGeom tg;
+    tile_geom(rc, zbuf[64 + src], sc.bound, tg);
+    float gocc = __shfl(gocc_s, src);
+    if (!tg.inb) gocc = 0.f;  // occupancy was overridden to 100
+    f32x4 c_a[1][2], gc[1][2];
+    float o1[1];
+    uint64_t mask[1];
+    const float go[1] = {gocc};
+    Tri tr;
+    tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+    tri_gather(sc.grid[0], tr, q, c_a[0]);
+    noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
+    noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
+    tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+    // coarse grid: ~1.3e3 cells and every ray starts in the camera's cell, so
+    // the atomics of 1000 rays serialise on a few lines; blocks spread over
+    // kCoarseRep private replicas (ws), summed afterwards
+    float* ggc = gg_coarse;
+    if (ws != nullptr && gg_coarse != nullptr)
+      ggc = ws + (size_t)(blockIdx.x & (kCoarseRep - 1)) *
+                     ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
+    grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused backward of the middle / fine / colour stages: ONE launch
+// back-propagates every decoder of the stage (round 1: one launch per decoder,
+// each re-running the ray set-up, + a staging pass through HBM and a separate
+// dW kernel for the colour decoder's weight gradients).
+//
+// A block = FW consecutive 16-sample tiles (tiles of a ray are consecutive, a
+// ray may straddle blocks); a wave owns one tile through all decoder phases:
+//   compositing backward of its ray -> middle -> fine -> colour, each phase
+//   = gather, forward recompute (ReLU masks), backward on transposed weight
+//   fragments, grid-gradient scatter.  Ray-gradient partial sums go to a
+//   workspace row per tile (f64) and are added up by nice_bwd_finish_kernel.
+//
+// Colour-decoder weight gradients (NEED_DW): dW = sum over points of
+// (gradient) x (layer input) as v_mfma_f32_16x16x4_f32 with the POINTS on the
+// K dimension.  The 68 16x16 blocks of the flat gradient are split over the FW
+// waves of the block; every wave keeps ITS blocks in MFMA accumulators across
+// all tiles the block ever processes (persistent blocks) and adds them to one
+// of kDwRep replicas once, at the end.  Operands are exchanged through LDS
+// (DwLds): layer by layer, each wave publishes its tile's gh_i (+ mask), the
+// block synchronises, and every wave contracts its blocks over the FW tiles.
+// ---------------------------------------------------------------------------
+// Per-iteration laundering of a uniform pointer: the persistent tile loop
+// re-reads the same weight fragments every iteration, which makes every
+// fully-unrolled fragment load loop-invariant; hipcc then hoists them out of
+// the loop and keeps them in registers (hundreds of VGPRs, spilled).  Behind
+// this no-op the compiler cannot prove the address unchanged.
+__device__ __forceinline__ const float* per_iteration(const float* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+constexpr int FW = 4;            // tiles (waves) per block
+constexpr int FWD = 8;           // ... when weight gradients are exchanged
+constexpr int kDwRep = 8;        // replicas the blocks add their dW into
+constexpr int kPlainLds = 256 + kScatterFloats;  // per wave without dW
+
+// The 68 blocks over the FWD = 8 waves of a block (w = wave, b = w & 3,
+// jt = b >> 1, kt = b & 1):
+//   layer i:  w < 4  fc_c.i.weight block (jt, kt)       [A = gh_i, B = c]
+//             w >= 4 pts_linears.i hidden block (jt, kt) [A = ga_i, B = h_{i-1}]
+//             (i = 0 has no hidden block); bias rows jt by the kt == 0 waves
+//   layer 4 also: output_linear.weight, cols 16(w&1).. by waves 6, 7
+//   Fourier parts: w < 4 of pts_linears.0, w >= 4 of pts_linears.3:
+//             rows jt, column tiles 3kt..3kt+2
+//   embedder._B: column tile w by waves 0..5
+struct DwAcc {
+  f32x4 lay[5];   // the wave's block of layer i
+  f32x4 emb[3];   // its three Fourier-part blocks
+  f32x4 x;        // output_linear (w = 6,7) / embedder._B (w < 6) block
+  float bias[5];  // kt == 0 waves: fc_c.i.bias (w < 4) / pts_linears.i.bias rows jt
+  float bout;     // wave 6: output_linear.bias
+};
+
+__device__ __forceinline__ void dw_acc_zero(DwAcc& A) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    A.lay[i] = z;
+    A.bias[i] = 0.f;
+    if (i < 3) A.emb[i] = z;
+  }
+  A.x = z;
+  A.bout = 0.f;
+}
+
+// layer I of the dW exchange: gh_I of every active tile is in slot `gslot`
+template <int I>
+__device__ __forceinline__ void dw_layer_step(const float* __restrict__ lds,
+                                              int nact, int wave, int lane,
+                                              int gslot, DwAcc& A) {
+  const int m = lane & 15, q = lane >> 4;
+  const int jt = (wave >> 1) & 1, kt = wave & 1;
+  const bool hid = wave >= 4;
+  if (!(I == 0 && hid && kt != 0)) {
+    for (int t = 0; t < nact; ++t) {
+      const float* R = lds + t * DwLds::LEN;
+      const uint32_t* M =
+          reinterpret_cast<const uint32_t*>(R + DwLds::TM) + I * 16;
+      const int bslot =
+          hid ? DwLds::TH0 + (I >= 1 ? I - 1 : 0) * DwLds::MAT : DwLds::TC;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int pt = 4 * q + s;
+        float a = R[gslot + pt * DwLds::RS + 16 * jt + m];
+        if (hid && !((M[pt] >> (16 * jt + m)) & 1u)) a = 0.f;  // ga = masked gh
+        if (I >= 1 || !hid) {
+          const float b = R[bslot + pt * DwLds::RS + 16 * kt + m];
+          A.lay[I] = XRD_MFMA4(a, b, A.lay[I]);
+        }
+        if (kt == 0) A.bias[I] += a;
+      }
+    }
+  }
+  if (I == 4 && wave >= 6) {  // output layer: rows = output o, cols = h_4
+    for (int t = 0; t < nact; ++t) {
+      const float* R = lds + t * DwLds::LEN;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int pt = 4 * q + s;
+        const float ao = (m < 4) ? R[DwLds::TGO + pt * 4 + (m & 3)] : 0.f;
+        const float bh = R[DwLds::TX + pt * DwLds::RS + 16 * kt + m];
+        A.x = XRD_MFMA4(ao, bh, A.x);
+        if (wave == 6) A.bout += ao;
+      }
+    }
+  }
+}
+
+// Fourier-feature weights of layers 0 and 3 against the recomputed sin(p.B):
+// masked ga_0 is in TX, masked ga_3 in TB
+__device__ __forceinline__ void dw_emb_step(const float* __restrict__ pk,
+                                            const float* __restrict__ lds,
+                                            int nact, int wave, int lane,
+                                            DwAcc& A) {
+  using P = MlpPack<32, 4>;
+  const int m = lane & 15, q = lane >> 4;
+  const int jt = (wave >> 1) & 1, kb = 3 * (wave & 1);
+  const int aslot = wave < 4 ? DwLds::TX : DwLds::TB;
+  f32x4 bk[3];
+#pragma unroll
+  for (int k3 = 0; k3 < 3; ++k3)
+    bk[k3] = *reinterpret_cast<const f32x4*>(pk + P::EMB +
+                                             (16 * (kb + k3) + m) * 4);
+  for (int t = 0; t < nact; ++t) {
+    const float* R = lds + t * DwLds::LEN;
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      const int pt = 4 * q + s;
+      const float a = R[aslot + pt * DwLds::RS + 16 * jt + m];
+      const f32x4 pp = *reinterpret_cast<const f32x4*>(R + DwLds::TP + pt * 4);
+      const float pv[3] = {pp[0], pp[1], pp[2]};
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3)
+        A.emb[k3] = XRD_MFMA4(a, sin_cw(embed_arg(pv, bk[k3])), A.emb[k3]);
+    }
+  }
+}
+
+// embedder._B: rows = axis a (lane m < 3), cols = Fourier feature; the
+// per-point d loss / d (p.B) sits in the h_0..h_2 slots (feature f -> matrix
+// f>>5, column f&31)
+__device__ __forceinline__ void dw_embB_step(const float* __restrict__ lds,
+                                             int nact, int wave, int lane,
+                                             DwAcc& A) {
+  const int m = lane & 15, q = lane >> 4;
+  if (wave >= 6) return;
+  const int f = 16 * wave + m;
+  for (int t = 0; t < nact; ++t) {
+    const float* R = lds + t * DwLds::LEN;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int pt = 4 * q + s;
+      const float ap = (m < 3) ? R[DwLds::TP + pt * 4 + (m & 3)] : 0.f;
+      const float gb =
+          R[DwLds::TH0 + (f >> 5) * DwLds::MAT + pt * DwLds::RS + (f & 31)];
+      A.x = XRD_MFMA4(ap, gb, A.x);
+    }
+  }
+}
+
+// add the wave's dW blocks to one replica of the flat gradient
+__device__ __forceinline__ void dw_flush(float* __restrict__ rep, int wave,
+                                         int lane, DwAcc& A) {
+  using F = MlpFlat<32, 4>;
+  const int n = lane & 15, q = lane >> 4;
+  const int jt = (wave >> 1) & 1, kt = wave & 1;
+  const bool hid = wave >= 4;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    if (!hid || i >= 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * q + r;
+        float* dst = hid ? rep + F::pw(i) + j * F::pstride(i) + F::pcol(i)
+                         : rep + F::fcw(i) + j * 32;
+        atomicAdd(dst + 16 * kt + n, A.lay[i][r]);
+      }
+    }
+    // bias rows: lane (m = n, q) holds the sum over points 4q..4q+3
+    const float b = group4_sum(A.bias[i]);
+    if (kt == 0 && q == 0)
+      atomicAdd(rep + (hid ? F::pb(i) : F::fcb(i)) + 16 * jt + n, b);
+  }
+#pragma unroll
+  for (int k3 = 0; k3 < 3; ++k3) {
+    const int k = 16 * (3 * kt + k3) + n;
+    if (k < kEmbK) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * q + r;
+        float* dst = hid ? rep + F::P3W + j * (kEmbK + 32)
+                         : rep + F::P0W + j * kEmbK;
+        atomicAdd(dst + k, A.emb[k3][r]);
+      }
+    }
+  }
+  if (wave >= 6) {
+    if (q == 0) {  // rows 0..3 of the accumulator = lane group 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(rep + F::OW + r * 32 + 16 * kt + n, A.x[r]);
+    }
+    if (wave == 6) {
+      const float b = group4_sum(A.bout);
+      if (q == 0 && n < 4) atomicAdd(rep + F::OB + n, b);
+    }
+  } else if (q == 0) {
+    const int k = 16 * wave + n;
+    if (k < kEmbK) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        atomicAdd(rep + F::EB + r * kEmbK + k, A.x[r]);
+    }
+  }
+}
+
+// write a D-layout register pair (features 16jt+4q+r of point li) to a slot
+__device__ __forceinline__ void lds_put(float* R, int slot, int lane,
+                                        const f32x4 (&v)[2]) {
+  const int q = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+    *reinterpret_cast<f32x4*>(R + slot + li * DwLds::RS + 16 * jt + 4 * q) =
+        v[jt];
+}
+
+// ReLU mask of layer i -> one word per point (bit f = feature f active)
+__device__ __forceinline__ void lds_put_mask(float* R, int i, int lane,
+                                             uint64_t mask) {
+  const int q = lane >> 4, li = lane & 15;
+  uint32_t word = 0;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if ((mask >> (i * 8 + jt * 4 + r)) & 1)
+        word |= 1u << (16 * jt + 4 * q + r);
+  word |= (uint32_t)__shfl_xor((int)word, 16);
+  word |= (uint32_t)__shfl_xor((int)word, 32);
+  if (q == 0) reinterpret_cast<uint32_t*>(R + DwLds::TM)[i * 16 + li] = word;
+}
+
+// Colour decoder backward with the weight-gradient exchange.  EVERY wave of
+// the block runs this (8 block barriers per group of tiles); `active` waves also back-propagate
+// their own tile: gc = d loss / d grid features, gp += d loss / d position.
+template <bool NEED_DP>
+__device__ __forceinline__ void color_bwd_dw(
+    const float* __restrict__ pk, float* __restrict__ lds, int wave, int lane,
+    bool active, int nact, const float (&p)[1][3], const f32x4 (&c)[1][2],
+    const float (&go)[1][4], f32x4 (&gc)[1][2], float (&gp)[1][3], DwAcc& A) {
+  using P = MlpPack<32, 4>;
+  const int q = lane >> 4, li = lane & 15;
+  float* R = lds + wave * DwLds::LEN;
+  uint64_t mask[1] = {0};
+  f32x4 gh[2], ga[2], ga3[2], ga0[2];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  gc[0][0] = z4;
+  gc[0][1] = z4;
+  gh[0] = gh[1] = ga3[0] = ga3[1] = ga0[0] = ga0[1] = z4;
+  if (active) {
+    lds_put(R, DwLds::TC, lane, c[0]);
+    if (q == 0) {
+      *reinterpret_cast<f32x4*>(R + DwLds::TP + li * 4) =
+          f32x4{p[0][0], p[0][1], p[0][2], 0.f};
+      *reinterpret_cast<f32x4*>(R + DwLds::TGO + li * 4) =
+          f32x4{go[0][0], go[0][1], go[0][2], go[0][3]};
+    }
+    float oc[1][4];
+#ifndef XRD_T5
+    mlp_fwd<1, 32, 4, true, true>(pk, lane, p, c, oc, mask, R);
+#endif
+    // gh_4 = Wout^T go
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const f32x4 w0 =
+          *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 4 * q);
+      const f32x4 w1 =
+          *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 16 + 4 * q);
+      gh[0] += w0 * go[0][o];
+      gh[1] += w1 * go[0][o];
+    }
+    lds_put(R, DwLds::TA, lane, gh);
+    lds_put_mask(R, 4, lane, mask[0]);
+  }
+  // one layer of the tile's own backward: gc += Wc_i^T gh, ga = masked gh,
+  // gh <- W_i^T ga (i >= 1)
+  auto layer = [&](int i) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ga[jt][r] =
+            ((mask[0] >> (i * 8 + jt * 4 + r)) & 1) ? gh[jt][r] : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float a = pk[P::wct(i) + (kt * 8 + s) * 64 + lane];
+        gc[0][kt] = XRD_MFMA4(a, gh[s >> 2][s & 3], gc[0][kt]);
+      }
+    XRD_SB();
+    if (i >= 1) {
+      f32x4 gprev[2] = {z4, z4};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float a = pk[P::wht(i) + (kt * 8 + s) * 64 + lane];
+          gprev[kt] = XRD_MFMA4(a, ga[s >> 2][s & 3], gprev[kt]);
+        }
+      gh[0] = gprev[0];
+      gh[1] = gprev[1];
+      XRD_SB();
+    }
+  };
+  // Layer loop, NOT unrolled: unrolled, every weight-fragment load becomes
+  // invariant of the persistent tile loop and hipcc hoists all ~250 of them
+  // out of it (1.5 KB of spills per lane).  gh_i sits in TA for even i, TB for
+  // odd i: a slot is rewritten two barriers after its last reader.
+#pragma unroll 1
+  for (int i = 4; i >= 0; --i) {
+    __syncthreads();  // B_i: gh_i, mask_i (and c, h_*, p, go) of every tile
+    const int gslot = (i & 1) ? DwLds::TB : DwLds::TA;
+    switch (i) {
+      case 4: dw_layer_step<4>(lds, nact, wave, lane, gslot, A); break;
+      case 3: dw_layer_step<3>(lds, nact, wave, lane, gslot, A); break;
+      case 2: dw_layer_step<2>(lds, nact, wave, lane, gslot, A); break;
+      case 1: dw_layer_step<1>(lds, nact, wave, lane, gslot, A); break;
+      default: dw_layer_step<0>(lds, nact, wave, lane, gslot, A); break;
+    }
+    if (active) {
+      layer(i);  // ga = masked gh_i; gh <- gh_{i-1}
+      if (i == 3) {
+        ga3[0] = ga[0];
+        ga3[1] = ga[1];
+      }
+      if (i >= 1) {
+        lds_put(R, ((i - 1) & 1) ? DwLds::TB : DwLds::TA, lane, gh);
+        lds_put_mask(R, i - 1, lane, mask[0]);
+      } else {
+        ga0[0] = ga[0];
+        ga0[1] = ga[1];
+        lds_put(R, DwLds::TX, lane, ga0);  // h_4 was consumed in step 4
+        lds_put(R, DwLds::TB, lane, ga3);  // gh_1 was consumed in step 1
+      }
+    }
+  }
+  __syncthreads();  // Be
+#ifndef XRD_T2
+  dw_emb_step(pk, lds, nact, wave, lane, A);
+#endif
+  if (active) {
+    // d loss / d sin(p.B) = W0^T ga0 + W3e^T ga3, through the sine; lane
+    // group q owns feature k = emap(4kt+r, q) (h_0..h_2 are consumed)
+#pragma unroll 1
+    for (int kt = 0; kt < 6; ++kt) {
+      f32x4 ge = z4;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float a3 = pk[P::W3ET + (kt * 8 + s) * 64 + lane];
+        const float a0 = pk[P::W0T + (kt * 8 + s) * 64 + lane];
+        ge = XRD_MFMA4(a3, ga3[s >> 2][s & 3], ge);
+        ge = XRD_MFMA4(a0, ga0[s >> 2][s & 3], ge);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = emap(4 * kt + r, q);
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
+        const float garg = ge[r] * cos_cw(embed_arg(p[0], bk));
+        if (NEED_DP) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) gp[0][a] += garg * bk[a];
+        }
+        R[DwLds::TH0 + (k >> 5) * DwLds::MAT + li * DwLds::RS + (k & 31)] =
+            garg;
+      }
+    }
+  }
+  __syncthreads();  // Bg
+#ifndef XRD_T3
+  dw_embB_step(lds, nact, wave, lane, A);
+#endif
+  __syncthreads();  // Bend: the regions may be reused
+}
+
+template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
+__global__ __launch_bounds__((NEED_DW ? FWD : FW) * 64, 2) void
+nice_bwd_fused_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const float* __restrict__ dmax_p, const float* __restrict__ raw,
     const double* __restrict__ g_depth, const double* __restrict__ g_var,
-    const float* __restrict__ g_rgb, float* __restrict__ g_rays_o,
-    float* __restrict__ g_rays_d, float* gg_coarse, float* gg_middle,
-    float* gg_fine, float* gg_color, float* __restrict__ ws,
-    int accumulate_rays) {
+    const float* __restrict__ g_rgb, float* gg_middle, float* gg_fine,
+    float* gg_color, double* __restrict__ part, float* __restrict__ dw_rep) {
+  static_assert(!NEED_DW || STAGE == XRD_STAGE_COLOR, "dW: colour stage");
   constexpr int S = NT * 16;
-  constexpr int NW = RPBB * NT;
+  constexpr int FWV = NEED_DW ? FWD : FW;
+  constexpr int RLEN = NEED_DW ? DwLds::LEN : kPlainLds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = lane >> 4, li = lane & 15;
-  const int slot = wave / NT, tile = wave % NT;
-  // LDS carve-up: [NW][128] f64 z | [NW][8] f64 ray-grad partials |
-  //   [NW][kScatterFloats] scatter tiles
-  double* zbuf = reinterpret_cast<double*>(smem_raw) + wave * 128;
-  double* gpart = reinterpret_cast<double*>(smem_raw) + NW * 128;
-  float* fbase = reinterpret_cast<float*>(gpart + NW * 8);
+  float* R = lds + wave * RLEN;
+  // the wave's region: z scratch (128 f64) first; the scatter tiles behind it
+  // (with dW: in the h_0/h_1 slots, free outside the colour phase)
+  double* zbuf = reinterpret_cast<double*>(R);
   ScatterLds SL;
-  SL.gt = fbase + wave * kScatterFloats;
+  SL.gt = R + (NEED_DW ? DwLds::TH0 : 256);
   SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
   SL.w = SL.gt + 16 * 33 + 16 * 8;
-  DwSave W = {};
-  if (NEED_DW) {
-    // staging arrays live in the caller's workspace
-    const int64_t Pn = (int64_t)n * S;
-    W.P = Pn;
-    W.gh = ws;
-    W.hs = W.gh + 5 * Pn * 32;
-    W.mk = reinterpret_cast<uint32_t*>(W.hs + 5 * Pn * 32);
-    W.c = reinterpret_cast<float*>(W.mk + 5 * Pn);
-    W.go = W.c + Pn * 32;
-    W.pp = W.go + Pn * 4;
-    W.ge = W.pp + Pn * 4;
-  }
-  const bool use_depth = (gt_depth != nullptr) && DEC != XRD_DEC_COARSE;
-  const int ngroups = (n + RPBB - 1) / RPBB;
+  static_assert(kScatterFloats <= 2 * DwLds::MAT, "scatter tiles fit h_0,h_1");
+  static_assert(256 <= DwLds::TH0, "z scratch fits the c slot");
+  DwAcc A;
+  if (NEED_DW) dw_acc_zero(A);
+  const bool use_depth = gt_depth != nullptr;
+  const int ntiles = n * NT;
+  const int ngroups = (ntiles + FWV - 1) / FWV;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int ray = __builtin_amdgcn_readfirstlane(grp * RPBB + slot);
-    const bool active = ray < n;
-    double gsum[6] = {0, 0, 0, 0, 0, 0};
+    const int tile_id = __builtin_amdgcn_readfirstlane(grp * FWV + wave);
+    const bool active = tile_id < ntiles;
+    const int nact = ntiles - grp * FWV < FWV ? ntiles - grp * FWV : FWV;
+    const int ray = active ? tile_id / NT : 0;
+    const int tile = active ? tile_id % NT : 0;
+    const float* dec_m = per_iteration(sc.dec[1]);
+    const float* dec_f = per_iteration(sc.dec[2]);
+    const float* dec_c = per_iteration(sc.dec[3]);
+    TileGeom tg = {};
+    float gocc = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+    double gp64[3] = {0.0, 0.0, 0.0};
+    float gp32[1][3] = {{0.f, 0.f, 0.f}};
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    f32x4 c_m[1][2];
+    uint64_t mask[1];
+    Tri tr;
     if (active) {
       RayCtx rc;
       load_ray(rays_o, rays_d, gt_depth, ray, use_depth, rc);
       const float dmax = use_depth ? dmax_p[0] : 0.f;
       const double zl = sample_z<S>(sc, rc, dmax, lane, zbuf, zbuf + 64);
-      const bool valid = lane < S;
-      // ---- compositing backward (utils.py:189-244) from the saved raw ----
-      f32x4 rw = {0.f, 0.f, 0.f, 0.f};
-      if (valid)
-        rw = *reinterpret_cast<const f32x4*>(raw +
-                                             ((size_t)ray * S + lane) * 4);
-      const float alpha = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
-      const float f = valid ? (1.f - alpha + 1e-10f) : 1.f;
-      float incl = f;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_up(incl, o);
-        if (lane >= o) incl *= u;
-      }
-      float T = __shfl_up(incl, 1);
-      if (lane == 0) T = 1.f;
-      const float w = alpha * T;
-      const double dep = wave_sum(valid ? (double)w * zl : 0.0);
-      const double tmp = zl - dep;
-      const double gd_in = g_depth ? g_depth[ray] : 0.0;
-      const double gv_in = g_var ? g_var[ray] : 0.0;
-      float grgb[3] = {0.f, 0.f, 0.f};
-      if (g_rgb) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) grgb[a] = g_rgb[ray * 3 + a];
-      }
-      const double sw_tmp = wave_sum(valid ? (double)w * tmp : 0.0);
-      const double gdep = gd_in - 2.0 * gv_in * sw_tmp;
-      float gw = 0.f;
-      if (valid)
-        gw = (float)(gdep * zl) + (float)(gv_in * tmp * tmp) +
-             (grgb[0] * rw[0] + grgb[1] * rw[1] + grgb[2] * rw[2]);
-      float suf = valid ? gw * w : 0.f;  // inclusive suffix sum of gw*w
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_down(suf, o);
-        if (lane + o < 64) suf += u;
-      }
-      float sexc = __shfl_down(suf, 1);
-      if (lane == 63) sexc = 0.f;
-      const float galpha = valid ? (gw * T - sexc / f) : 0.f;
-      const float gocc_s = galpha * 10.f * alpha * (1.f - alpha);
-      // ---- this wave's tile ---------------------------------------------
+      float gocc_s, w, grgb[3];
+      composite_bwd<S>(raw, ray, lane, zl, g_depth, g_var, g_rgb, gocc_s, w,
+                       grgb);
       const int src = 16 * tile + li;
-      TileGeom tg;
       tile_geom(rc, zbuf[64 + src], sc.bound, tg);
-      float gocc = __shfl(gocc_s, src);
+      gocc = __shfl(gocc_s, src);
       if (!tg.inb) gocc = 0.f;  // occupancy was overridden to 100
       const float wsrc = __shfl(w, src);
-      const float gcol[3] = {grgb[0] * wsrc, grgb[1] * wsrc, grgb[2] * wsrc};
-      const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
-      const int64_t ptg[1] = {(int64_t)ray * S + src};
-      double gp64[3] = {0.0, 0.0, 0.0};
-      float gp32[1][3] = {{0.f, 0.f, 0.f}};
-      uint64_t mask[1];
-      Tri tr;
-      if (DEC == XRD_DEC_COARSE) {
-        f32x4 c_a[1][2], gc[1][2];
-        float o1[1];
-        const float go[1] = {gocc};
-        tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
-        tri_gather(sc.grid[0], tr, q, c_a[0]);
-        noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
-        noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
-        tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
-        if (NEED_DP) tri_backward_dp(sc.grid[0], tr, q, gc[0], gp64);
-        // coarse grid: ~1.3e3 cells and every ray starts in the camera's
-        // cell, so the atomics of 1000 rays serialise on a few lines; blocks
-        // spread over kCoarseRep private replicas (ws), summed afterwards
-        float* ggc = gg_coarse;
-        if (ws != nullptr && gg_coarse != nullptr)
-          ggc = ws + (size_t)(blockIdx.x & (kCoarseRep - 1)) *
-                         ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
-        grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
-      }
-      if (DEC == XRD_DEC_MIDDLE || DEC == XRD_DEC_FINE) {
-        f32x4 c_m[1][2];
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
-        tri_gather(sc.grid[1], tr, q, c_m[0]);
-        if (DEC == XRD_DEC_MIDDLE) {
-          float om[1][1];
-          const float go[1][1] = {{gocc}};
-          f32x4 gc[1][2];
-          mlp_fwd<1, 32, 1, true, false>(sc.dec[1], lane, p32, c_m, om, mask,
-                                         W, ptg);
-          mlp_bwd<1, 32, 1, NEED_DP, NEED_DP, false>(
-              sc.dec[1], lane, p32, c_m, go, mask, gc, gp32, W, ptg);
-          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
-          if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
-          grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
-        }
-        if (DEC == XRD_DEC_FINE) {
-          f32x4 c_f[1][4], gc[1][4], cf[2];
-          float of[1][1];
-          const float go[1][1] = {{gocc}};
-          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
-          tri_gather(sc.grid[2], tr, q, cf);
-          c_f[0][0] = cf[0];
-          c_f[0][1] = cf[1];
-          c_f[0][2] = c_m[0][0];
-          c_f[0][3] = c_m[0][1];
-          mlp_fwd<1, 64, 1, true, false>(sc.dec[2], lane, p32, c_f, of, mask,
-                                         W, ptg);
-          mlp_bwd<1, 64, 1, NEED_DP, NEED_DP, false>(
-              sc.dec[2], lane, p32, c_f, go, mask, gc, gp32, W, ptg);
-          const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
-          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
-          if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
-          grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
-        }
-      }
-      if (DEC == XRD_DEC_COLOR) {
-        {
-          f32x4 c_c[1][2], gc[1][2];
-          float oc[1][4];
-          // channel 3 is overwritten by fine+middle occupancy -> no gradient
-          const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
-          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
-          tri_gather(sc.grid[3], tr, q, c_c[0]);
-          mlp_fwd<1, 32, 4, true, NEED_DW>(sc.dec[3], lane, p32, c_c, oc, mask,
-                                           W, ptg);
-          mlp_bwd<1, 32, 4, (NEED_DP || NEED_DW), NEED_DP, NEED_DW>(
-              sc.dec[3], lane, p32, c_c, go, mask, gc, gp32, W, ptg);
-          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
-          if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
-          grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
-        }
-      }
-      if (NEED_DP) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const double g = gp64[a] + (double)gp32[0][a];
-          gsum[a] = wave_sum(g);
-          gsum[3 + a] = wave_sum(g * tg.z);
-        }
+      for (int a = 0; a < 3; ++a) {
+        gcol[a] = grgb[a] * wsrc;
+        p32[0][a] = tg.p32[a];
+      }
+      // ---- middle decoder (every stage) -----------------------------------
+      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+      tri_gather(sc.grid[1], tr, q, c_m[0]);
+      {
+        float om[1][1];
+        const float go[1][1] = {{gocc}};
+        f32x4 gc[1][2];
+        mlp_fwd<1, 32, 1, true, false>(dec_m, lane, p32, c_m, om, mask,
+                                       nullptr);
+        mlp_bwd<1, 32, 1, NEED_DP, NEED_DP>(dec_m, lane, p32, c_m, go,
+                                            mask, gc, gp32);
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+        if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
+        grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
+      }
+      // ---- fine decoder -----------------------------------------------------
+      if (STAGE >= XRD_STAGE_FINE) {
+        f32x4 c_f[1][4], gc[1][4], cf[2];
+        float of[1][1];
+        const float go[1][1] = {{gocc}};
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        tri_gather(sc.grid[2], tr, q, cf);
+        c_f[0][0] = cf[0];
+        c_f[0][1] = cf[1];
+        c_f[0][2] = c_m[0][0];
+        c_f[0][3] = c_m[0][1];
+        mlp_fwd<1, 64, 1, true, false>(dec_f, lane, p32, c_f, of, mask,
+                                       nullptr);
+        mlp_bwd<1, 64, 1, NEED_DP, NEED_DP>(dec_f, lane, p32, c_f, go,
+                                            mask, gc, gp32);
+        const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
+        grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
       }
     }
-    if (NEED_DP) {
-      // deterministic sum over the NT waves of the ray
-      if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) gpart[wave * 8 + a] = gsum[a];
+    // ---- colour decoder -------------------------------------------------------
+    if (STAGE == XRD_STAGE_COLOR) {
+      f32x4 c_c[1][2], gc[1][2];
+      // channel 3 is overwritten by fine+middle occupancy -> no gradient
+      const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
+      if (active) {
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        tri_gather(sc.grid[3], tr, q, c_c[0]);
       }
-      __syncthreads();
-      if (active && tile == 0 && lane < 6) {
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) s += gpart[(wave + t) * 8 + lane];
-        float* dst = lane < 3 ? g_rays_o + ray * 3 + lane
-                              : g_rays_d + ray * 3 + lane - 3;
-        *dst = (accumulate_rays ? *dst : 0.f) + (float)s;
+      if (NEED_DW) {
+        color_bwd_dw<NEED_DP>(dec_c, lds, wave, lane, active, nact, p32,
+                              c_c, go, gc, gp32, A);
+      } else if (active) {
+        float oc[1][4];
+        mlp_fwd<1, 32, 4, true, false>(dec_c, lane, p32, c_c, oc, mask,
+                                       nullptr);
+        mlp_bwd<1, 32, 4, NEED_DP, NEED_DP>(dec_c, lane, p32, c_c, go,
+                                            mask, gc, gp32);
       }
-      __syncthreads();
+      if (active) {
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
+        grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
+      }
+    }
+    if (NEED_DP && active) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double g = gp64[a] + (double)gp32[0][a];
+        const double so = wave_sum(g), sd = wave_sum(g * tg.z);
+        if (lane == 0) {
+          part[(size_t)tile_id * 6 + a] = so;
+          part[(size_t)tile_id * 6 + 3 + a] = sd;
+        }
+      }
     }
   }
+  if (NEED_DW)
+    dw_flush(dw_rep + (size_t)(blockIdx.x % kDwRep) * kColorFlat, wave, lane,
+             A);
 }
 
-// out[i] = sum_b ws[b][i]; block = 64 elements x 4 partial stripes
-__global__ __launch_bounds__(256) void reduce_partials_kernel(
-    const float* __restrict__ ws, int nb, int len, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + x;
-  float s = 0.f;
-  if (i < len)
-    for (int b = y; b < nb; b += 4) s += ws[(size_t)b * len + i];
-  red[y][x] = s;
-  __syncthreads();
-  if (y == 0 && i < len) out[i] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+// g_dec = sum of the dW replicas; g_rays_{o,d}[ray] = sum of the ray's tile
+// partials (fixed order: deterministic)
+__global__ __launch_bounds__(256) void nice_bwd_finish_kernel(
+    const float* __restrict__ rep, int len, float* __restrict__ g_dec,
+    const double* __restrict__ part, int n, int nt,
+    float* __restrict__ g_rays_o, float* __restrict__ g_rays_d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < len) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < kDwRep; ++r) s += rep[(size_t)r * len + i];
+    g_dec[i] = s;
+    return;
+  }
+  const int j = i - len;
+  if (j >= n * 6) return;
+  const int ray = j / 6, a = j % 6;
+  double s = 0.0;
+  for (int t = 0; t < nt; ++t) s += part[((size_t)ray * nt + t) * 6 + a];
+  float* dst = a < 3 ? g_rays_o + ray * 3 + a : g_rays_d + ray * 3 + a - 3;
+  *dst = (float)s;
 }
 
 __global__ void mfma_selftest_kernel(const float* a, const float* b,
@@ -1422,21 +1628,9 @@ __global__ void mfma_selftest_kernel(const float* a, const float* b,
   for (int r = 0; r < 4; ++r) out[((l >> 4) * 4 + r) * 16 + (l & 15)] = d[r];
 }
 
-size_t bwd_lds_bytes(int nt, bool dw) {
-  (void)dw;
-  const size_t nw = (size_t)RPBB * nt;
-  return nw * 128 * sizeof(double) + nw * 8 * sizeof(double) +
-         nw * kScatterFloats * sizeof(float);
-}
-
-#ifndef XRD_DW_BLOCKS
-#define XRD_DW_BLOCKS 512
-#endif
-// persistent blocks of nice_dw_kernel.  Measured on MI355X (colour-stage
-// backward group, 1000 rays): 256 blocks 642 us, 512 blocks 594 us, 1024 blocks
-// 629 us — two blocks per CU hide the dependent mask -> gradient loads, more
-// only grows the partial-sum traffic.
-constexpr int kDwBlocks = XRD_DW_BLOCKS;
+// persistent blocks of the fused backward when weight gradients are
+// accumulated in registers: one 8-wave block (154 KB of LDS) per CU
+constexpr int kFusedBlocks = 256;
 
 }  // namespace
 }  // namespace xrd
@@ -1531,23 +1725,27 @@ int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene) {
 }
 
 int64_t xrd_nice_bwd_ws_floats(int n_rays) {
-  // staging arrays for n_rays * 48 points + the per-block partial gradients
-  return (int64_t)n_rays * 48 * kDwFloatsPerPoint +
-         (int64_t)kDwBlocks * kColorFlat + 64;
+  // per-tile ray-gradient partials (6 doubles each, at most 3 tiles a ray) +
+  // the replicas of the colour-decoder gradient
+  return (int64_t)n_rays * 3 * 6 * 2 + (int64_t)kDwRep * kColorFlat + 64;
 }
 
 }  // extern "C"
 
+static size_t fused_lds_bytes(bool dw) {
+  return (size_t)(dw ? FWD * DwLds::LEN : FW * kPlainLds) * sizeof(float);
+}
+
 template <int ST, int NTV, bool DP, bool DW>
-static int launch_bwd(const xrd_nice_scene* scene, int n, const float* rays_o,
-                      const float* rays_d, const float* gt_depth,
-                      const float* dmax, const float* raw,
-                      const double* g_depth, const double* g_var,
-                      const float* g_rgb, float* g_rays_o, float* g_rays_d,
-                      float* const g_grid[4], float* ws, int nb,
-                      hipStream_t st, int accumulate_rays) {
-  auto kern = nice_bwd_kernel<ST, NTV, DP, DW>;
-  const size_t lds = bwd_lds_bytes(NTV, DW);
+static int launch_fused(const xrd_nice_scene* scene, int n,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        const float* raw, const double* g_depth,
+                        const double* g_var, const float* g_rgb,
+                        float* const gg[4], double* part, float* dw_rep,
+                        hipStream_t st) {
+  auto kern = nice_bwd_fused_kernel<ST, NTV, DP, DW>;
+  const size_t lds = fused_lds_bytes(DW);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1557,79 +1755,58 @@ static int launch_bwd(const xrd_nice_scene* scene, int n, const float* rays_o,
     attr_set = true;
   }
   if (n == 0) return XRD_OK;  // warm-up call: attributes only
-  hipLaunchKernelGGL(kern, dim3(nb), dim3(RPBB * NTV * 64), lds, st, *scene, n, rays_o,
-                     rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb,
-                     g_rays_o, g_rays_d, g_grid[0], g_grid[1], g_grid[2],
-                     g_grid[3], ws, accumulate_rays);
+  constexpr int fw = DW ? FWD : FW;
+  int64_t ngroups = ((int64_t)n * NTV + fw - 1) / fw;
+  // with register-resident dW the blocks are persistent (one flush each)
+  const int64_t cap = DW ? kFusedBlocks : kMaxBwdBlocks;
+  const int nb = (int)(ngroups < cap ? ngroups : cap);
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(fw * 64), lds, st, *scene, n, rays_o,
+                     rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg[1],
+                     gg[2], gg[3], part, dw_rep);
   return check_launch("xrd_nice_render_bwd");
 }
 
-#define BWD_CASE(ST, NTV, DP, DW)                                             \
-  return launch_bwd<ST, NTV, DP, DW>(scene, n_rays, rays_o, rays_d, gt_depth, \
-                                     dmax, raw, g_depth, g_var, g_rgb,        \
-                                     g_rays_o, g_rays_d, gg, ws, nb, st, acc)
+#define FUSED_CASE(ST, NTV, DP, DW)                                          \
+  return launch_fused<ST, NTV, DP, DW>(scene, n_rays, rays_o, rays_d,        \
+                                       gt_depth, dmax, raw, g_depth, g_var,  \
+                                       g_rgb, gg, part, dw_rep, st)
 
-// one decoder per launch (see nice_bwd_kernel)
-static int bwd_dispatch_dec(const xrd_nice_scene* scene, int dec, int nt,
-                            bool dp, bool dw, int n_rays, const float* rays_o,
-                            const float* rays_d, const float* gt_depth,
-                            const float* dmax, const float* raw,
-                            const double* g_depth, const double* g_var,
-                            const float* g_rgb, float* g_rays_o,
-                            float* g_rays_d, float* const gg[4], float* ws,
-                            int nb, hipStream_t st, int acc) {
-  if (dec == XRD_DEC_COARSE) {
-    if (nt != 2 || dp || dw) return XRD_ERR_UNSUPPORTED;
-    BWD_CASE(XRD_DEC_COARSE, 2, false, false);
-  }
-  if (dec == XRD_DEC_MIDDLE) {
+static int fused_dispatch(const xrd_nice_scene* scene, int stage, int nt,
+                          bool dp, bool dw, int n_rays, const float* rays_o,
+                          const float* rays_d, const float* gt_depth,
+                          const float* dmax, const float* raw,
+                          const double* g_depth, const double* g_var,
+                          const float* g_rgb, float* const gg[4], double* part,
+                          float* dw_rep, hipStream_t st) {
+#ifdef XRD_RES_PROBE  // build-time probe of one variant's register use
+  FUSED_CASE(XRD_STAGE_COLOR, 3, XRD_RES_PROBE & 1, true);
+#endif
+  if (stage == XRD_STAGE_MIDDLE) {
     if (nt == 3) {
-      if (dp) BWD_CASE(XRD_DEC_MIDDLE, 3, true, false);
-      BWD_CASE(XRD_DEC_MIDDLE, 3, false, false);
+      if (dp) FUSED_CASE(XRD_STAGE_MIDDLE, 3, true, false);
+      FUSED_CASE(XRD_STAGE_MIDDLE, 3, false, false);
     }
-    if (dp) BWD_CASE(XRD_DEC_MIDDLE, 2, true, false);
-    BWD_CASE(XRD_DEC_MIDDLE, 2, false, false);
+    if (dp) FUSED_CASE(XRD_STAGE_MIDDLE, 2, true, false);
+    FUSED_CASE(XRD_STAGE_MIDDLE, 2, false, false);
   }
-  if (dec == XRD_DEC_FINE) {
+  if (stage == XRD_STAGE_FINE) {
     if (nt == 3) {
-      if (dp) BWD_CASE(XRD_DEC_FINE, 3, true, false);
-      BWD_CASE(XRD_DEC_FINE, 3, false, false);
+      if (dp) FUSED_CASE(XRD_STAGE_FINE, 3, true, false);
+      FUSED_CASE(XRD_STAGE_FINE, 3, false, false);
     }
-    if (dp) BWD_CASE(XRD_DEC_FINE, 2, true, false);
-    BWD_CASE(XRD_DEC_FINE, 2, false, false);
+    if (dp) FUSED_CASE(XRD_STAGE_FINE, 2, true, false);
+    FUSED_CASE(XRD_STAGE_FINE, 2, false, false);
   }
   if (nt == 3) {
-    if (dp && dw) BWD_CASE(XRD_DEC_COLOR, 3, true, true);
-    if (dp) BWD_CASE(XRD_DEC_COLOR, 3, true, false);
-    if (dw) BWD_CASE(XRD_DEC_COLOR, 3, false, true);
-    BWD_CASE(XRD_DEC_COLOR, 3, false, false);
+    if (dp && dw) FUSED_CASE(XRD_STAGE_COLOR, 3, true, true);
+    if (dp) FUSED_CASE(XRD_STAGE_COLOR, 3, true, false);
+    if (dw) FUSED_CASE(XRD_STAGE_COLOR, 3, false, true);
+    FUSED_CASE(XRD_STAGE_COLOR, 3, false, false);
   }
-  if (dp && dw) BWD_CASE(XRD_DEC_COLOR, 2, true, true);
-  if (dp) BWD_CASE(XRD_DEC_COLOR, 2, true, false);
-  if (dw) BWD_CASE(XRD_DEC_COLOR, 2, false, true);
-  BWD_CASE(XRD_DEC_COLOR, 2, false, false);
-}
-
-static int bwd_dispatch(const xrd_nice_scene* scene, int stage, int nt,
-                        bool dp, bool dw, int n_rays, const float* rays_o,
-                        const float* rays_d, const float* gt_depth,
-                        const float* dmax, const float* raw,
-                        const double* g_depth, const double* g_var,
-                        const float* g_rgb, float* g_rays_o, float* g_rays_d,
-                        float* const gg[4], float* ws, int nb, hipStream_t st) {
-  static const int decs[4][3] = {{XRD_DEC_COARSE, -1, -1},
-                                 {XRD_DEC_MIDDLE, -1, -1},
-                                 {XRD_DEC_MIDDLE, XRD_DEC_FINE, -1},
-                                 {XRD_DEC_MIDDLE, XRD_DEC_FINE, XRD_DEC_COLOR}};
-  for (int k = 0; k < 3 && decs[stage][k] >= 0; ++k) {
-    const int dec = decs[stage][k];
-    const int rc = bwd_dispatch_dec(
-        scene, dec, nt, dp, dw && dec == XRD_DEC_COLOR, n_rays, rays_o, rays_d,
-        gt_depth, dmax, raw, g_depth, g_var, g_rgb, g_rays_o, g_rays_d, gg, ws,
-        nb, st, k > 0);
-    if (rc != XRD_OK) return rc;
-  }
-  return XRD_OK;
+  if (dp && dw) FUSED_CASE(XRD_STAGE_COLOR, 2, true, true);
+  if (dp) FUSED_CASE(XRD_STAGE_COLOR, 2, true, false);
+  if (dw) FUSED_CASE(XRD_STAGE_COLOR, 2, false, true);
+  FUSED_CASE(XRD_STAGE_COLOR, 2, false, false);
 }
 
 extern "C" {
@@ -1657,44 +1834,49 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
       return XRD_ERR_UNSUPPORTED;
     dw = g_dec[XRD_DEC_COLOR] != nullptr;
   }
-  if (dw && (stage != XRD_STAGE_COLOR || ws == nullptr)) return XRD_ERR_ARG;
+  if (dw && stage != XRD_STAGE_COLOR) return XRD_ERR_ARG;
   const bool dp = g_rays_o != nullptr;
   if (stage == XRD_STAGE_COARSE && dp) return XRD_ERR_UNSUPPORTED;
+  if ((dw || dp) && ws == nullptr) return XRD_ERR_ARG;
   if (n_rays == 0) return XRD_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (stage == XRD_STAGE_COARSE) gt_depth = nullptr;
-  int nb = (n_rays + RPBB - 1) / RPBB;
-
-  if (nb > 65535 * 16) nb = 65535 * 16;
-  rc = bwd_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d, gt_depth,
-                    dmax, raw, g_depth, g_var, g_rgb, g_rays_o, g_rays_d, gg,
-                    ws, nb, st);
-  if (rc != XRD_OK) return rc;
-  if (stage == XRD_STAGE_COARSE && ws != nullptr && gg[0] != nullptr) {
-    const int64_t ne = (int64_t)scene->gdim[0] * scene->gdim[1] *
-                       scene->gdim[2] * 32;
-    hipLaunchKernelGGL(coarse_rep_reduce_kernel, dim3((unsigned)((ne + 255) / 256)),
-                       dim3(256), 0, st, ws, ne, gg[0]);
-    return check_launch("coarse_rep_reduce_kernel");
+  if (stage == XRD_STAGE_COARSE) {
+    if (nt != 2) return XRD_ERR_UNSUPPORTED;
+    int nb = n_rays < kMaxBwdBlocks ? n_rays : kMaxBwdBlocks;
+    hipLaunchKernelGGL(nice_bwd_coarse_kernel, dim3(nb), dim3(128), 0, st,
+                       *scene, n_rays, rays_o, rays_d, raw, g_depth, g_var,
+                       g_rgb, gg[0], ws);
+    rc = check_launch("xrd_nice_render_bwd/coarse");
+    if (rc != XRD_OK) return rc;
+    if (ws != nullptr && gg[0] != nullptr) {
+      const int64_t ne = (int64_t)scene->gdim[0] * scene->gdim[1] *
+                         scene->gdim[2] * 32;
+      hipLaunchKernelGGL(coarse_rep_reduce_kernel,
+                         dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
+                         ws, ne, gg[0]);
+      return check_launch("coarse_rep_reduce_kernel");
+    }
+    return XRD_OK;
   }
+  // workspace: [n_rays * nt][6] f64 tile partials | kDwRep gradient replicas
+  double* part = reinterpret_cast<double*>(ws);
+  float* dw_rep = ws ? ws + (size_t)n_rays * 3 * 6 * 2 : nullptr;
   if (dw) {
-    DwSave W = {};
-    const int64_t Pn = (int64_t)n_rays * (nt * 16);
-    W.P = Pn;
-    W.gh = ws;
-    W.hs = W.gh + 5 * Pn * 32;
-    W.mk = reinterpret_cast<uint32_t*>(W.hs + 5 * Pn * 32);
-    W.c = reinterpret_cast<float*>(W.mk + 5 * Pn);
-    W.go = W.c + Pn * 32;
-    W.pp = W.go + Pn * 4;
-    W.ge = W.pp + Pn * 4;
-    float* partial = W.ge + Pn * 96;
-    hipLaunchKernelGGL(nice_dw_kernel, dim3(kDwBlocks), dim3(256), 0, st,
-                       scene->dec[XRD_DEC_COLOR], W, partial);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((kColorFlat + 63) / 64),
-                       dim3(256), 0, st, partial, kDwBlocks, kColorFlat,
-                       g_dec[XRD_DEC_COLOR]);
-    return check_launch("xrd_nice_render_bwd/dw");
+    rc = zero_floats(dw_rep, (size_t)kDwRep * kColorFlat, stream);
+    if (rc != XRD_OK) return rc;
+  }
+  rc = fused_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d,
+                      gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg, part,
+                      dw_rep, st);
+  if (rc != XRD_OK) return rc;
+  if (dw || dp) {
+    const int len = dw ? kColorFlat : 0;
+    const int total = len + (dp ? n_rays * 6 : 0);
+    hipLaunchKernelGGL(nice_bwd_finish_kernel, dim3((total + 255) / 256),
+                       dim3(256), 0, st, dw_rep, len,
+                       dw ? g_dec[XRD_DEC_COLOR] : nullptr, part,
+                       dp ? n_rays : 0, nt, g_rays_o, g_rays_d);
+    return check_launch("xrd_nice_render_bwd/finish");
   }
   return XRD_OK;
 }
@@ -1702,16 +1884,14 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
 int xrd_nice_warmup(void) {
   float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
   xrd_nice_scene sc = {};
-  for (int stage = 0; stage < 4; ++stage)
+  for (int stage = XRD_STAGE_MIDDLE; stage <= XRD_STAGE_COLOR; ++stage)
     for (int nt = 2; nt <= 3; ++nt)
       for (int dp = 0; dp < 2; ++dp)
         for (int dw = 0; dw < 2; ++dw) {
-          if (stage == XRD_STAGE_COARSE && (nt != 2 || dp || dw)) continue;
           if (stage != XRD_STAGE_COLOR && dw) continue;
-          int rc = bwd_dispatch(&sc, stage, nt, dp, dw, 0, nullptr, nullptr,
-                                nullptr, nullptr, nullptr, nullptr, nullptr,
-                                nullptr, nullptr, nullptr, gg, nullptr, 1,
-                                nullptr);
+          int rc = fused_dispatch(&sc, stage, nt, dp, dw, 0, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, gg, nullptr, nullptr, nullptr);
           if (rc != XRD_OK) return rc;
         }
   return XRD_OK;

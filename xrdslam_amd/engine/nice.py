@@ -287,9 +287,12 @@ class _NiceRenderFn(torch.autograd.Function):
         if need_dec:
             g_flat = torch.empty(lib.xrd_nice_flat_len(3), dtype=torch.float32,
                                  device=dev)
+            gdec[3] = g_flat.data_ptr()
+        if need_dec or need_rays:
+            # tile partials of the ray gradients + replicas of the decoder
+            # gradient (contents arbitrary on entry)
             ws = torch.empty(lib.xrd_nice_bwd_ws_floats(n),
                              dtype=torch.float32, device=dev)
-            gdec[3] = g_flat.data_ptr()
         cs = scene.c_struct()
         if stage == 'coarse' and ctx.grid_grads and gg[0]:
             # zero-initialised once, kept zero by the call (static pointer:
