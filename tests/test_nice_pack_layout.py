@@ -47,14 +47,14 @@ def pack(kind, flat):
 def offsets(CD):
     KC, KTC = CD // 4, CD // 16
     o = {}
-    o['EMB'] = 0
-    o['W0'] = 384
+    o['W0'] = 0
     o['W3E'] = o['W0'] + 2 * 24 * 64
     o['WH'] = o['W3E'] + 2 * 24 * 64
     o['WC'] = o['WH'] + 4 * 1024
     o['B'] = o['WC'] + 5 * 2 * KC * 64
     o['BC'] = o['B'] + 160
-    o['WOUT'] = o['BC'] + 160
+    o['EMB'] = o['BC'] + 160
+    o['WOUT'] = o['EMB'] + 384
     o['BOUT'] = o['WOUT'] + 128
     o['WHT'] = o['BOUT'] + 4
     o['WCT'] = o['WHT'] + 4096

@@ -1,0 +1,96 @@
+"""HIP-event timing of xrd_nice_render_fwd / xrd_nice_render_bwd (the launch
+group of one call) per stage and gradient set at the office0 config.
+Run on the GPU box:  python tools/nice_bwd_timing.py [n_rays ...]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from xrdslam_amd import _lib
+from xrdslam_amd.engine import nice as en
+
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+bound = torch.tensor([[-5.5, 6.0199995], [-6.7, 5.4599998],
+                      [-4.7, 5.5399998]], dtype=torch.float64)
+shapes = {'grid_coarse': (10, 12, 11), 'grid_middle': (31, 37, 35),
+          'grid_fine': (63, 75, 71), 'grid_color': (63, 75, 71)}
+scene = en.NiceScene(bound, device=dev)
+grads = {}
+for k, s in shapes.items():
+    g = en.to_channels_last_grid(torch.randn(1, 32, *s, device=dev) * 0.01)
+    scene.set_grid(k, g)
+    grads[k] = torch.zeros_like(g, memory_format=torch.preserve_format)
+for kind in ('coarse', 'middle', 'fine', 'color'):
+    flat = torch.cat([torch.randn(int(np.prod(s))) *
+                      (25. if n == 'embedder._B' else 0.2)
+                      for n, s in en.param_shapes(kind)]).to(dev)
+    scene.set_decoder(kind, flat)
+lib = _lib.lib()
+st = _lib.stream_ptr(dev)
+P = _lib.ptr
+
+
+def timeit(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+for n in [int(a) for a in sys.argv[1:]] or [200, 1000]:
+    o = ((torch.rand(n, 3, device=dev) - 0.5) * 2.0).contiguous()
+    d = torch.randn(n, 3, device=dev)
+    d = (d / d.norm(dim=1, keepdim=True)).contiguous()
+    depth = (1.0 + 2.0 * torch.rand(n, device=dev)).contiguous()
+    dmax = depth.max().reshape(1)
+    for stage, si in (('middle', 1), ('fine', 2), ('color', 3)):
+        S = 48
+        dep = torch.empty(n, dtype=torch.float64, device=dev)
+        var = torch.empty_like(dep)
+        rgb = torch.empty(n, 3, device=dev)
+        raw = torch.empty(n, S, 4, device=dev)
+        cs = scene.c_struct()
+
+        def fwd():
+            _lib.check(lib.xrd_nice_render_fwd(
+                C.byref(cs), si, n, P(o), P(d), P(depth), P(dmax), P(dep),
+                P(var), P(rgb), P(raw), st))
+        t_f = timeit(fwd)
+        gd = torch.ones(n, dtype=torch.float64, device=dev)
+        gr = torch.full((n, 3), 0.2, device=dev)
+        ws = torch.empty(lib.xrd_nice_bwd_ws_floats(n), device=dev)
+        g_o = torch.empty(n, 3, device=dev)
+        g_d = torch.empty(n, 3, device=dev)
+        g_flat = torch.empty(lib.xrd_nice_flat_len(3), device=dev)
+        msg = f'n={n:5d} {stage:6s} fwd {t_f:7.1f} us |'
+        for grid in (1, 0):
+            for dp in (0, 1):
+                for dw in ((0, 1) if stage == 'color' else (0, )):
+                    gg = (C.c_void_p * 4)()
+                    if grid:
+                        for gi, k in enumerate(('grid_coarse', 'grid_middle',
+                                                'grid_fine', 'grid_color')):
+                            if 1 <= gi <= si:
+                                gg[gi] = grads[k].data_ptr()
+                    gdec = (C.c_void_p * 4)()
+                    if dw:
+                        gdec[3] = g_flat.data_ptr()
+
+                    def bwd():
+                        _lib.check(lib.xrd_nice_render_bwd(
+                            C.byref(cs), si, n, P(o), P(d), P(depth), P(dmax),
+                            P(raw), P(gd), None, P(gr),
+                            P(g_o) if dp else None, P(g_d) if dp else None,
+                            C.byref(gg), C.byref(gdec), P(ws), st))
+                    msg += f' grid{grid}dp{dp}dw{dw} {timeit(bwd):7.1f}'
+        print(msg, flush=True)

@@ -67,14 +67,17 @@ template <int CD, int OD>
 struct MlpPack {
   static constexpr int KC = CD / 4;    // K-steps of fc_c
   static constexpr int KTC = CD / 16;  // 16-feature tiles of c
-  static constexpr int EMB = 0;        // [96][4]: B[0][k],B[1][k],B[2][k],0
-  static constexpr int W0 = EMB + 96 * 4;          // frag (jt,s): 2*24
+  // forward-only fragments first, then what both passes read, then the
+  // transposed (backward) fragments: the forward needs [0, WHT), the backward
+  // [EMB, LEN) — each ONE contiguous range to stage into LDS
+  static constexpr int W0 = 0;                     // frag (jt,s): 2*24
   static constexpr int W3E = W0 + 2 * kEmbS * 64;  // frag (jt,s): 2*24
   static constexpr int WH = W3E + 2 * kEmbS * 64;  // i=1..4: frag (jt,s) 2*8
   static constexpr int WC = WH + 4 * 1024;         // i=0..4: frag (jt,s) 2*KC
   static constexpr int B = WC + 5 * 2 * KC * 64;   // [5][32]
   static constexpr int BC = B + 160;               // [5][32]
-  static constexpr int WOUT = BC + 160;            // [4][32] (rows >= OD zero)
+  static constexpr int EMB = BC + 160;  // [96][4]: B[0][k],B[1][k],B[2][k],0
+  static constexpr int WOUT = EMB + 96 * 4;        // [4][32] (rows >= OD zero)
   static constexpr int BOUT = WOUT + 128;          // [4]
   static constexpr int WHT = BOUT + 4;             // i=1..4: frag (kt,s) 2*8
   static constexpr int WCT = WHT + 4 * 1024;       // i=0..4: frag (kt,s) KTC*8

@@ -14,6 +14,7 @@
 // align_corners=True) semantics.  Parity oracle: oracle/nice_oracle.py.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -288,28 +289,6 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
       atomicAdd(ggrid + cur[k] + ch, acc[k]);
 }
 
-// Per-wave LDS region of the fused backward when the colour decoder's weight
-// gradients are wanted.  Every wave (= one 16-point tile) keeps what the dW
-// contractions need as point-major matrices [16 points][32 features] with a
-// row stride of 36 floats: the producer writes its accumulator-layout
-// registers as one b128 per (jt) and a consumer lane (m = l&15, q = l>>4)
-// reads feature 16jt+m of point 4q+s for K-step s — with stride 36 the four
-// lane groups q fall into four disjoint 16-bank ranges.  The matrices never
-// leave LDS (round 1 staged them through HBM: 90 MB per launch).
-struct DwLds {
-  static constexpr int RS = 36;
-  static constexpr int MAT = 16 * RS;    // 576 floats
-  static constexpr int TC = 0;           // grid features c
-  static constexpr int TH0 = MAT;        // h_0..h_3, then h_4 (= TX)
-  static constexpr int TX = 5 * MAT;     // h_4, later the masked ga_0
-  static constexpr int TA = 6 * MAT;     // gh_4, gh_2, gh_0
-  static constexpr int TB = 7 * MAT;     // gh_3, gh_1, later the masked ga_3
-  static constexpr int TM = 8 * MAT;     // ReLU masks [5][16] (bit f = feature f)
-  static constexpr int TP = TM + 80;     // sample positions [16][4]
-  static constexpr int TGO = TP + 64;    // d loss / d decoder output [16][4]
-  static constexpr int LEN = TGO + 64;   // 4816 floats = 19264 B per wave
-};
-
 // ---------------------------------------------------------------------------
 // device: MLP decoder forward (decoder_nice.py:207-234)
 // ---------------------------------------------------------------------------
@@ -326,10 +305,11 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
                                         const f32x4 (&c)[NT][CD / 16],
                                         float (&out)[NT][OD],
                                         uint64_t (&mask)[NT],
-                                        float* __restrict__ hl) {
-  // SAVE_H: layer outputs h_0..h_4 go to the wave's LDS region hl (DwLds)
+                                        f32x4 (*hs)[2]) {
+  // SAVE_H: the layer outputs h_0..h_4 are returned in hs[5][2] (registers:
+  // the layer loop is then unrolled so that the indices are static)
   using P = MlpPack<CD, OD>;
-  static_assert(!SAVE_H || NT == 1, "LDS save: one tile per wave");
+  static_assert(!SAVE_H || NT == 1, "h output: one tile per wave");
   const int q = lane >> 4;
   f32x4 acc[NT][2], acc3[NT][2];
 #pragma unroll
@@ -368,7 +348,8 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
   f32x4 h[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) mask[t] = 0;
-#pragma unroll 1
+  constexpr int kLayerUnroll = SAVE_H ? 5 : 1;
+#pragma unroll kLayerUnroll
   for (int i = 0; i < 5; ++i) {
     // cc = fc_c[i](c)
     f32x4 cc[NT][2];
@@ -401,10 +382,7 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
             mask[t] |= (uint64_t)1 << (i * 8 + jt * 4 + r);
           h[t][jt][r] = fmaxf(a, 0.f) + cc[t][jt][r];
         }
-        if (SAVE_H)
-          *reinterpret_cast<f32x4*>(hl + DwLds::TH0 + i * DwLds::MAT +
-                                    (lane & 15) * DwLds::RS + 16 * jt +
-                                    4 * q) = h[t][jt];
+        if (SAVE_H) hs[i][jt] = h[t][jt];
       }
     if (i < 4) {
 #pragma unroll
@@ -1071,43 +1049,102 @@ __global__ __launch_bounds__(2 * 64, 2) void nice_bwd_coarse_kernel(
 // each re-running the ray set-up, + a staging pass through HBM and a separate
 // dW kernel for the colour decoder's weight gradients).
 //
-// A block = FW consecutive 16-sample tiles (tiles of a ray are consecutive, a
+// A block = FWV consecutive 16-sample tiles (tiles of a ray are consecutive, a
 // ray may straddle blocks); a wave owns one tile through all decoder phases:
 //   compositing backward of its ray -> middle -> fine -> colour, each phase
 //   = gather, forward recompute (ReLU masks), backward on transposed weight
 //   fragments, grid-gradient scatter.  Ray-gradient partial sums go to a
 //   workspace row per tile (f64) and are added up by nice_bwd_finish_kernel.
 //
+// WEIGHTS IN LDS.  Measured on MI355X (profiles/r02_weight_fetch.txt): with
+// the fragments read from L2 the backward is bound by their fetch — the same
+// kernels with every fragment load folded onto 4 KB (L1 hits) run 1.7-2.4x
+// faster.  The packed parameters of a decoder do not fit a CU's L1 (32 KB),
+// but one PASS of one decoder fits LDS (forward <= 85 KB, backward <= 84 KB,
+// nice_layout.h keeps each one contiguous): the block stages the pass's
+// fragments once per group of tiles (block barrier, cooperative b128 copy,
+// barrier) and every wave reads them with ds_read — L2 traffic per tile drops
+// by the number of tiles per block, fragment latency to LDS latency, and the
+// registers the compiler spent on prefetching global fragments are free.
+//
 // Colour-decoder weight gradients (NEED_DW): dW = sum over points of
 // (gradient) x (layer input) as v_mfma_f32_16x16x4_f32 with the POINTS on the
-// K dimension.  The 68 16x16 blocks of the flat gradient are split over the FW
-// waves of the block; every wave keeps ITS blocks in MFMA accumulators across
-// all tiles the block ever processes (persistent blocks) and adds them to one
-// of kDwRep replicas once, at the end.  Operands are exchanged through LDS
-// (DwLds): layer by layer, each wave publishes its tile's gh_i (+ mask), the
-// block synchronises, and every wave contracts its blocks over the FW tiles.
+// K dimension.  The 68 16x16 blocks of the flat gradient are split over the
+// eight waves of a block; every wave keeps ITS blocks in MFMA accumulators
+// across all tiles the block ever processes (persistent blocks) and adds them
+// to one of kDwRep replicas once, at the end.  Operands are exchanged through
+// LDS (DwLds): layer by layer each wave publishes its tile's gh_i, ReLU mask
+// and h_{i-1} (kept in registers since the forward pass), the block
+// synchronises, and every wave contracts its block over the eight tiles.
+// Nothing is staged through HBM (round 1: 90 MB per launch).
 // ---------------------------------------------------------------------------
-// Per-iteration laundering of a uniform pointer: the persistent tile loop
-// re-reads the same weight fragments every iteration, which makes every
-// fully-unrolled fragment load loop-invariant; hipcc then hoists them out of
-// the loop and keeps them in registers (hundreds of VGPRs, spilled).  Behind
-// this no-op the compiler cannot prove the address unchanged.
-__device__ __forceinline__ const float* per_iteration(const float* p) {
-  asm volatile("" : "+s"(p));
-  return p;
+#ifndef XRD_FW
+#define XRD_FW 8
+#endif
+#ifndef XRD_OCC
+#define XRD_OCC 2
+#endif
+constexpr int FW = XRD_FW;       // tiles (waves) per block, 2 waves per SIMD
+constexpr int FWD = 8;           // ... with weight gradients (2 per SIMD too)
+constexpr int kDwRep = 8;        // replicas the blocks add their dW into
+constexpr int kRS = 36;          // row stride of a point-major LDS matrix
+constexpr int kMat = 16 * kRS;   // 576 floats
+// LDS map (floats).  [0, kWMax) the staged fragments of the current pass
+// (largest: fine decoder forward 21316); the waves' dW exchange regions start
+// behind the largest COLOUR pass (16196) and overlap the tail of the fragment
+// region, which only the fine decoder uses; the scratch of a wave (z values,
+// scatter tiles) aliases its exchange region, idle outside the colour
+// backward.
+constexpr int kWMax = 21696;
+constexpr int kDwBase = 16256;
+constexpr int kScratch = 256 + kScatterFloats;  // per wave
+// Exchange region of one wave = one tile: point-major matrices [16 points][32
+// features] with a row stride of 36 floats — the producer writes its
+// accumulator-layout registers as b128, a consumer lane (m = l&15, q = l>>4)
+// reads feature 16jt+m of point 4q+s for K-step s; with stride 36 the four
+// lane groups q fall into four disjoint 16-bank ranges.
+struct DwLds {
+  static constexpr int TC = 0;             // grid features c (later garg 0..31)
+  static constexpr int TH = kMat;          // h_{i-1} (later garg 32..63)
+  static constexpr int TG = 2 * kMat;      // gh_i; masked ga_0 (garg 64..95)
+  static constexpr int TX = 3 * kMat;      // h_4; masked ga_3
+  static constexpr int TM = 4 * kMat;      // ReLU masks [5][16] (bit f)
+  static constexpr int TP = TM + 80;       // sample positions [16][4]
+  static constexpr int TGO = TP + 64;      // d loss / d decoder output [16][4]
+  static constexpr int LEN = TGO + 64;     // 2512 floats
+};
+static_assert(kScratch <= DwLds::LEN, "scratch aliases the exchange region");
+static_assert(MlpPack<64, 1>::WHT <= kWMax, "fine forward fits");
+static_assert(MlpPack<64, 1>::LEN - MlpPack<64, 1>::EMB <= kWMax, "fine bwd");
+static_assert(MlpPack<32, 4>::WHT <= kDwBase, "colour forward below dW region");
+static_assert(MlpPack<32, 4>::LEN - MlpPack<32, 4>::EMB <= kDwBase, "");
+
+constexpr size_t fused_lds_floats(bool dw) {
+  return dw ? ((size_t)kDwBase + FWD * DwLds::LEN > (size_t)kWMax
+                   ? (size_t)kDwBase + FWD * DwLds::LEN
+                   : (size_t)kWMax)
+            : (size_t)kWMax + FW * kScratch;
+}
+static_assert(fused_lds_floats(true) * 4 <= 163840, "LDS per CU");
+static_assert(fused_lds_floats(false) * 4 <= 163840, "LDS per CU");
+
+// stage n floats (multiple of 4, 16-byte aligned) of packed parameters
+__device__ __forceinline__ void stage_weights(float* __restrict__ wl,
+                                              const float* __restrict__ src,
+                                              int n) {
+  __syncthreads();  // everybody is done with the previous pass's fragments
+  for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(wl + i) =
+        *reinterpret_cast<const f32x4*>(src + i);
+  __syncthreads();
 }
 
-constexpr int FW = 4;            // tiles (waves) per block
-constexpr int FWD = 8;           // ... when weight gradients are exchanged
-constexpr int kDwRep = 8;        // replicas the blocks add their dW into
-constexpr int kPlainLds = 256 + kScatterFloats;  // per wave without dW
-
-// The 68 blocks over the FWD = 8 waves of a block (w = wave, b = w & 3,
-// jt = b >> 1, kt = b & 1):
-//   layer i:  w < 4  fc_c.i.weight block (jt, kt)       [A = gh_i, B = c]
-//             w >= 4 pts_linears.i hidden block (jt, kt) [A = ga_i, B = h_{i-1}]
+// The 68 16x16 blocks of the colour decoder's flat gradient over the FWD = 8
+// waves of a block (w = wave, jt = (w >> 1) & 1, kt = w & 1):
+//   layer i:  w < 4  fc_c.i.weight block (jt, kt)        [A = gh_i, B = c]
+//             w >= 4 pts_linears.i hidden block (jt, kt)  [A = ga_i, B = h_{i-1}]
 //             (i = 0 has no hidden block); bias rows jt by the kt == 0 waves
-//   layer 4 also: output_linear.weight, cols 16(w&1).. by waves 6, 7
+//   layer 4 also: output_linear.weight, columns 16(w&1).. by waves 6, 7
 //   Fourier parts: w < 4 of pts_linears.0, w >= 4 of pts_linears.3:
 //             rows jt, column tiles 3kt..3kt+2
 //   embedder._B: column tile w by waves 0..5
@@ -1131,28 +1168,28 @@ __device__ __forceinline__ void dw_acc_zero(DwAcc& A) {
   A.bout = 0.f;
 }
 
-// layer I of the dW exchange: gh_I of every active tile is in slot `gslot`
+// layer I of the exchange: gh_I in TG, mask_I in TM, c in TC, h_{I-1} in TH
+// (and h_4 in TX for the output layer) of every active tile
 template <int I>
 __device__ __forceinline__ void dw_layer_step(const float* __restrict__ lds,
                                               int nact, int wave, int lane,
-                                              int gslot, DwAcc& A) {
+                                              DwAcc& A) {
   const int m = lane & 15, q = lane >> 4;
   const int jt = (wave >> 1) & 1, kt = wave & 1;
   const bool hid = wave >= 4;
   if (!(I == 0 && hid && kt != 0)) {
+    const int bslot = hid ? DwLds::TH : DwLds::TC;
     for (int t = 0; t < nact; ++t) {
       const float* R = lds + t * DwLds::LEN;
       const uint32_t* M =
           reinterpret_cast<const uint32_t*>(R + DwLds::TM) + I * 16;
-      const int bslot =
-          hid ? DwLds::TH0 + (I >= 1 ? I - 1 : 0) * DwLds::MAT : DwLds::TC;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int pt = 4 * q + s;
-        float a = R[gslot + pt * DwLds::RS + 16 * jt + m];
+        float a = R[DwLds::TG + pt * kRS + 16 * jt + m];
         if (hid && !((M[pt] >> (16 * jt + m)) & 1u)) a = 0.f;  // ga = masked gh
         if (I >= 1 || !hid) {
-          const float b = R[bslot + pt * DwLds::RS + 16 * kt + m];
+          const float b = R[bslot + pt * kRS + 16 * kt + m];
           A.lay[I] = XRD_MFMA4(a, b, A.lay[I]);
         }
         if (kt == 0) A.bias[I] += a;
@@ -1166,7 +1203,7 @@ __device__ __forceinline__ void dw_layer_step(const float* __restrict__ lds,
       for (int s = 0; s < 4; ++s) {
         const int pt = 4 * q + s;
         const float ao = (m < 4) ? R[DwLds::TGO + pt * 4 + (m & 3)] : 0.f;
-        const float bh = R[DwLds::TX + pt * DwLds::RS + 16 * kt + m];
+        const float bh = R[DwLds::TX + pt * kRS + 16 * kt + m];
         A.x = XRD_MFMA4(ao, bh, A.x);
         if (wave == 6) A.bout += ao;
       }
@@ -1175,38 +1212,36 @@ __device__ __forceinline__ void dw_layer_step(const float* __restrict__ lds,
 }
 
 // Fourier-feature weights of layers 0 and 3 against the recomputed sin(p.B):
-// masked ga_0 is in TX, masked ga_3 in TB
-__device__ __forceinline__ void dw_emb_step(const float* __restrict__ pk,
+// masked ga_0 is in TG, masked ga_3 in TX
+__device__ __forceinline__ void dw_emb_step(const float* __restrict__ w,
                                             const float* __restrict__ lds,
                                             int nact, int wave, int lane,
                                             DwAcc& A) {
   using P = MlpPack<32, 4>;
   const int m = lane & 15, q = lane >> 4;
   const int jt = (wave >> 1) & 1, kb = 3 * (wave & 1);
-  const int aslot = wave < 4 ? DwLds::TX : DwLds::TB;
-  f32x4 bk[3];
-#pragma unroll
-  for (int k3 = 0; k3 < 3; ++k3)
-    bk[k3] = *reinterpret_cast<const f32x4*>(pk + P::EMB +
-                                             (16 * (kb + k3) + m) * 4);
+  const int aslot = (wave < 4 ? DwLds::TG : DwLds::TX) + 16 * jt + m;
   for (int t = 0; t < nact; ++t) {
     const float* R = lds + t * DwLds::LEN;
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
       const int pt = 4 * q + s;
-      const float a = R[aslot + pt * DwLds::RS + 16 * jt + m];
+      const float a = R[aslot + pt * kRS];
       const f32x4 pp = *reinterpret_cast<const f32x4*>(R + DwLds::TP + pt * 4);
       const float pv[3] = {pp[0], pp[1], pp[2]};
 #pragma unroll
-      for (int k3 = 0; k3 < 3; ++k3)
-        A.emb[k3] = XRD_MFMA4(a, sin_cw(embed_arg(pv, bk[k3])), A.emb[k3]);
+      for (int k3 = 0; k3 < 3; ++k3) {
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(
+            w + P::EMB + (16 * (kb + k3) + m) * 4);
+        A.emb[k3] = XRD_MFMA4(a, sin_cw(embed_arg(pv, bk)), A.emb[k3]);
+      }
     }
   }
 }
 
 // embedder._B: rows = axis a (lane m < 3), cols = Fourier feature; the
-// per-point d loss / d (p.B) sits in the h_0..h_2 slots (feature f -> matrix
-// f>>5, column f&31)
+// per-point d loss / d (p.B) sits in TC / TH / TG (feature f -> matrix f>>5,
+// column f&31)
 __device__ __forceinline__ void dw_embB_step(const float* __restrict__ lds,
                                              int nact, int wave, int lane,
                                              DwAcc& A) {
@@ -1219,8 +1254,7 @@ __device__ __forceinline__ void dw_embB_step(const float* __restrict__ lds,
     for (int s = 0; s < 4; ++s) {
       const int pt = 4 * q + s;
       const float ap = (m < 3) ? R[DwLds::TP + pt * 4 + (m & 3)] : 0.f;
-      const float gb =
-          R[DwLds::TH0 + (f >> 5) * DwLds::MAT + pt * DwLds::RS + (f & 31)];
+      const float gb = R[(f >> 5) * kMat + pt * kRS + (f & 31)];
       A.x = XRD_MFMA4(ap, gb, A.x);
     }
   }
@@ -1282,14 +1316,13 @@ __device__ __forceinline__ void dw_flush(float* __restrict__ rep, int wave,
   }
 }
 
-// write a D-layout register pair (features 16jt+4q+r of point li) to a slot
-__device__ __forceinline__ void lds_put(float* R, int slot, int lane,
+// write a D-layout register pair (features 16jt+4q+r of point li) to a matrix
+__device__ __forceinline__ void lds_put(float* M, int lane,
                                         const f32x4 (&v)[2]) {
   const int q = lane >> 4, li = lane & 15;
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)
-    *reinterpret_cast<f32x4*>(R + slot + li * DwLds::RS + 16 * jt + 4 * q) =
-        v[jt];
+    *reinterpret_cast<f32x4*>(M + li * kRS + 16 * jt + 4 * q) = v[jt];
 }
 
 // ReLU mask of layer i -> one word per point (bit f = feature f active)
@@ -1309,150 +1342,132 @@ __device__ __forceinline__ void lds_put_mask(float* R, int i, int lane,
 }
 
 // Colour decoder backward with the weight-gradient exchange.  EVERY wave of
-// the block runs this (8 block barriers per group of tiles); `active` waves also back-propagate
+// the block runs this (block barriers); `active` waves also back-propagate
 // their own tile: gc = d loss / d grid features, gp += d loss / d position.
+// w: the staged backward fragments (MlpPack offsets), lds: exchange regions of
+// the block's waves, hs: the tile's layer outputs h_0..h_4 (registers).
 template <bool NEED_DP>
 __device__ __forceinline__ void color_bwd_dw(
-    const float* __restrict__ pk, float* __restrict__ lds, int wave, int lane,
+    const float* __restrict__ w, float* __restrict__ lds, int wave, int lane,
     bool active, int nact, const float (&p)[1][3], const f32x4 (&c)[1][2],
-    const float (&go)[1][4], f32x4 (&gc)[1][2], float (&gp)[1][3], DwAcc& A) {
+    const float (&go)[1][4], uint64_t mask, const f32x4 (&hs)[5][2],
+    f32x4 (&gc)[1][2], float (&gp)[1][3], DwAcc& A) {
   using P = MlpPack<32, 4>;
   const int q = lane >> 4, li = lane & 15;
   float* R = lds + wave * DwLds::LEN;
-  uint64_t mask[1] = {0};
-  f32x4 gh[2], ga[2], ga3[2], ga0[2];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gh[2] = {z4, z4}, ga[2] = {z4, z4}, ga3[2] = {z4, z4};
   gc[0][0] = z4;
   gc[0][1] = z4;
-  gh[0] = gh[1] = ga3[0] = ga3[1] = ga0[0] = ga0[1] = z4;
+  __syncthreads();  // the scratch aliases of every wave are idle
   if (active) {
-    lds_put(R, DwLds::TC, lane, c[0]);
+    lds_put(R + DwLds::TC, lane, c[0]);
+    lds_put(R + DwLds::TX, lane, hs[4]);
     if (q == 0) {
       *reinterpret_cast<f32x4*>(R + DwLds::TP + li * 4) =
           f32x4{p[0][0], p[0][1], p[0][2], 0.f};
       *reinterpret_cast<f32x4*>(R + DwLds::TGO + li * 4) =
           f32x4{go[0][0], go[0][1], go[0][2], go[0][3]};
     }
-    float oc[1][4];
-#ifndef XRD_T5
-    mlp_fwd<1, 32, 4, true, true>(pk, lane, p, c, oc, mask, R);
-#endif
     // gh_4 = Wout^T go
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const f32x4 w0 =
-          *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 4 * q);
+          *reinterpret_cast<const f32x4*>(w + P::WOUT + o * 32 + 4 * q);
       const f32x4 w1 =
-          *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 16 + 4 * q);
+          *reinterpret_cast<const f32x4*>(w + P::WOUT + o * 32 + 16 + 4 * q);
       gh[0] += w0 * go[0][o];
       gh[1] += w1 * go[0][o];
     }
-    lds_put(R, DwLds::TA, lane, gh);
-    lds_put_mask(R, 4, lane, mask[0]);
   }
-  // one layer of the tile's own backward: gc += Wc_i^T gh, ga = masked gh,
-  // gh <- W_i^T ga (i >= 1)
-  auto layer = [&](int i) {
+  // one layer: publish (gh_i, mask_i, h_{i-1}), contract the block's share,
+  // back-propagate the own tile
+  auto layer = [&](auto IC) {
+    constexpr int i = decltype(IC)::value;
+    if (active) {
+      lds_put(R + DwLds::TG, lane, gh);
+      lds_put_mask(R, i, lane, mask);
+      if (i >= 1) lds_put(R + DwLds::TH, lane, hs[i >= 1 ? i - 1 : 0]);
+    }
+    __syncthreads();
+    dw_layer_step<i>(lds, nact, wave, lane, A);
+    if (active) {
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+      for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        ga[jt][r] =
-            ((mask[0] >> (i * 8 + jt * 4 + r)) & 1) ? gh[jt][r] : 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const float a = pk[P::wct(i) + (kt * 8 + s) * 64 + lane];
-        gc[0][kt] = XRD_MFMA4(a, gh[s >> 2][s & 3], gc[0][kt]);
-      }
-    XRD_SB();
-    if (i >= 1) {
-      f32x4 gprev[2] = {z4, z4};
+        for (int r = 0; r < 4; ++r)
+          ga[jt][r] = ((mask >> (i * 8 + jt * 4 + r)) & 1) ? gh[jt][r] : 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          const float a = pk[P::wht(i) + (kt * 8 + s) * 64 + lane];
-          gprev[kt] = XRD_MFMA4(a, ga[s >> 2][s & 3], gprev[kt]);
+          const float a = w[P::wct(i) + (kt * 8 + s) * 64 + lane];
+          gc[0][kt] = XRD_MFMA4(a, gh[s >> 2][s & 3], gc[0][kt]);
         }
-      gh[0] = gprev[0];
-      gh[1] = gprev[1];
-      XRD_SB();
-    }
-  };
-  // Layer loop, NOT unrolled: unrolled, every weight-fragment load becomes
-  // invariant of the persistent tile loop and hipcc hoists all ~250 of them
-  // out of it (1.5 KB of spills per lane).  gh_i sits in TA for even i, TB for
-  // odd i: a slot is rewritten two barriers after its last reader.
-#pragma unroll 1
-  for (int i = 4; i >= 0; --i) {
-    __syncthreads();  // B_i: gh_i, mask_i (and c, h_*, p, go) of every tile
-    const int gslot = (i & 1) ? DwLds::TB : DwLds::TA;
-    switch (i) {
-      case 4: dw_layer_step<4>(lds, nact, wave, lane, gslot, A); break;
-      case 3: dw_layer_step<3>(lds, nact, wave, lane, gslot, A); break;
-      case 2: dw_layer_step<2>(lds, nact, wave, lane, gslot, A); break;
-      case 1: dw_layer_step<1>(lds, nact, wave, lane, gslot, A); break;
-      default: dw_layer_step<0>(lds, nact, wave, lane, gslot, A); break;
-    }
-    if (active) {
-      layer(i);  // ga = masked gh_i; gh <- gh_{i-1}
-      if (i == 3) {
-        ga3[0] = ga[0];
-        ga3[1] = ga[1];
-      }
       if (i >= 1) {
-        lds_put(R, ((i - 1) & 1) ? DwLds::TB : DwLds::TA, lane, gh);
-        lds_put_mask(R, i - 1, lane, mask[0]);
-      } else {
-        ga0[0] = ga[0];
-        ga0[1] = ga[1];
-        lds_put(R, DwLds::TX, lane, ga0);  // h_4 was consumed in step 4
-        lds_put(R, DwLds::TB, lane, ga3);  // gh_1 was consumed in step 1
+        f32x4 gprev[2] = {z4, z4};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const float a =
+                w[P::wht(i >= 1 ? i : 1) + (kt * 8 + s) * 64 + lane];
+            gprev[kt] = XRD_MFMA4(a, ga[s >> 2][s & 3], gprev[kt]);
+          }
+        gh[0] = gprev[0];
+        gh[1] = gprev[1];
       }
     }
+    __syncthreads();  // TG / TH may be rewritten
+  };
+  layer(std::integral_constant<int, 4>{});
+  layer(std::integral_constant<int, 3>{});
+  ga3[0] = ga[0];
+  ga3[1] = ga[1];
+  layer(std::integral_constant<int, 2>{});
+  layer(std::integral_constant<int, 1>{});
+  layer(std::integral_constant<int, 0>{});
+  // ga now holds the masked ga_0
+  if (active) {
+    lds_put(R + DwLds::TG, lane, ga);
+    lds_put(R + DwLds::TX, lane, ga3);
   }
-  __syncthreads();  // Be
-#ifndef XRD_T2
-  dw_emb_step(pk, lds, nact, wave, lane, A);
-#endif
+  __syncthreads();
+  dw_emb_step(w, lds, nact, wave, lane, A);
+  __syncthreads();  // TC / TH / TG may be rewritten
   if (active) {
     // d loss / d sin(p.B) = W0^T ga0 + W3e^T ga3, through the sine; lane
-    // group q owns feature k = emap(4kt+r, q) (h_0..h_2 are consumed)
+    // group q owns feature k = emap(4kt+r, q)
 #pragma unroll 1
     for (int kt = 0; kt < 6; ++kt) {
       f32x4 ge = z4;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const float a3 = pk[P::W3ET + (kt * 8 + s) * 64 + lane];
-        const float a0 = pk[P::W0T + (kt * 8 + s) * 64 + lane];
+        const float a3 = w[P::W3ET + (kt * 8 + s) * 64 + lane];
+        const float a0 = w[P::W0T + (kt * 8 + s) * 64 + lane];
         ge = XRD_MFMA4(a3, ga3[s >> 2][s & 3], ge);
-        ge = XRD_MFMA4(a0, ga0[s >> 2][s & 3], ge);
+        ge = XRD_MFMA4(a0, ga[s >> 2][s & 3], ge);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = emap(4 * kt + r, q);
-        const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(w + P::EMB + k * 4);
         const float garg = ge[r] * cos_cw(embed_arg(p[0], bk));
         if (NEED_DP) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) gp[0][a] += garg * bk[a];
         }
-        R[DwLds::TH0 + (k >> 5) * DwLds::MAT + li * DwLds::RS + (k & 31)] =
-            garg;
+        R[(k >> 5) * kMat + li * kRS + (k & 31)] = garg;
       }
     }
   }
-  __syncthreads();  // Bg
-#ifndef XRD_T3
+  __syncthreads();
   dw_embB_step(lds, nact, wave, lane, A);
-#endif
-  __syncthreads();  // Bend: the regions may be reused
+  __syncthreads();  // the regions (and their scratch aliases) may be reused
 }
 
 template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
-__global__ __launch_bounds__((NEED_DW ? FWD : FW) * 64, 2) void
+__global__ __launch_bounds__((NEED_DW ? FWD : FW) * 64, XRD_OCC) void
 nice_bwd_fused_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
@@ -1463,42 +1478,37 @@ nice_bwd_fused_kernel(
   static_assert(!NEED_DW || STAGE == XRD_STAGE_COLOR, "dW: colour stage");
   constexpr int S = NT * 16;
   constexpr int FWV = NEED_DW ? FWD : FW;
-  constexpr int RLEN = NEED_DW ? DwLds::LEN : kPlainLds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* lds = reinterpret_cast<float*>(smem_raw);
+  float* wl = reinterpret_cast<float*>(smem_raw);  // staged fragments
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = lane >> 4, li = lane & 15;
-  float* R = lds + wave * RLEN;
-  // the wave's region: z scratch (128 f64) first; the scatter tiles behind it
-  // (with dW: in the h_0/h_1 slots, free outside the colour phase)
-  double* zbuf = reinterpret_cast<double*>(R);
+  float* scratch = wl + (NEED_DW ? kDwBase + wave * DwLds::LEN
+                                 : kWMax + wave * kScratch);
+  double* zbuf = reinterpret_cast<double*>(scratch);
   ScatterLds SL;
-  SL.gt = R + (NEED_DW ? DwLds::TH0 : 256);
+  SL.gt = scratch + 256;
   SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
   SL.w = SL.gt + 16 * 33 + 16 * 8;
-  static_assert(kScatterFloats <= 2 * DwLds::MAT, "scatter tiles fit h_0,h_1");
-  static_assert(256 <= DwLds::TH0, "z scratch fits the c slot");
   DwAcc A;
   if (NEED_DW) dw_acc_zero(A);
   const bool use_depth = gt_depth != nullptr;
   const int ntiles = n * NT;
   const int ngroups = (ntiles + FWV - 1) / FWV;
+  using PM = MlpPack<32, 1>;
+  using PF = MlpPack<64, 1>;
+  using PC = MlpPack<32, 4>;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int tile_id = __builtin_amdgcn_readfirstlane(grp * FWV + wave);
     const bool active = tile_id < ntiles;
-    const int nact = ntiles - grp * FWV < FWV ? ntiles - grp * FWV : FWV;
     const int ray = active ? tile_id / NT : 0;
     const int tile = active ? tile_id % NT : 0;
-    const float* dec_m = per_iteration(sc.dec[1]);
-    const float* dec_f = per_iteration(sc.dec[2]);
-    const float* dec_c = per_iteration(sc.dec[3]);
     TileGeom tg = {};
     float gocc = 0.f, gcol[3] = {0.f, 0.f, 0.f};
     double gp64[3] = {0.0, 0.0, 0.0};
     float gp32[1][3] = {{0.f, 0.f, 0.f}};
     float p32[1][3] = {{0.f, 0.f, 0.f}};
     f32x4 c_m[1][2];
-    uint64_t mask[1];
+    uint64_t mask[1] = {0};
     Tri tr;
     if (active) {
       RayCtx rc;
@@ -1518,35 +1528,50 @@ nice_bwd_fused_kernel(
         gcol[a] = grgb[a] * wsrc;
         p32[0][a] = tg.p32[a];
       }
-      // ---- middle decoder (every stage) -----------------------------------
       tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
       tri_gather(sc.grid[1], tr, q, c_m[0]);
-      {
+    }
+    // ---- middle decoder (every stage) ---------------------------------------
+    {
+      const float go[1][1] = {{gocc}};
+      f32x4 gc[1][2];
+      stage_weights(wl, sc.dec[1], PM::WHT);
+      if (active) {
         float om[1][1];
-        const float go[1][1] = {{gocc}};
-        f32x4 gc[1][2];
-        mlp_fwd<1, 32, 1, true, false>(dec_m, lane, p32, c_m, om, mask,
-                                       nullptr);
-        mlp_bwd<1, 32, 1, NEED_DP, NEED_DP>(dec_m, lane, p32, c_m, go,
+        mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask, nullptr);
+      }
+      stage_weights(wl, sc.dec[1] + PM::EMB,
+                    (NEED_DP ? PM::LEN : PM::W0T) - PM::EMB);
+      if (active) {
+        mlp_bwd<1, 32, 1, NEED_DP, NEED_DP>(wl - PM::EMB, lane, p32, c_m, go,
                                             mask, gc, gp32);
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
         grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
       }
-      // ---- fine decoder -----------------------------------------------------
-      if (STAGE >= XRD_STAGE_FINE) {
-        f32x4 c_f[1][4], gc[1][4], cf[2];
-        float of[1][1];
-        const float go[1][1] = {{gocc}};
+    }
+    // ---- fine decoder ---------------------------------------------------------
+    if (STAGE >= XRD_STAGE_FINE) {
+      f32x4 c_f[1][4], gc[1][4];
+      const float go[1][1] = {{gocc}};
+      if (active) {
+        f32x4 cf[2];
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
         tri_gather(sc.grid[2], tr, q, cf);
         c_f[0][0] = cf[0];
         c_f[0][1] = cf[1];
         c_f[0][2] = c_m[0][0];
         c_f[0][3] = c_m[0][1];
-        mlp_fwd<1, 64, 1, true, false>(dec_f, lane, p32, c_f, of, mask,
-                                       nullptr);
-        mlp_bwd<1, 64, 1, NEED_DP, NEED_DP>(dec_f, lane, p32, c_f, go,
+      }
+      stage_weights(wl, sc.dec[2], PF::WHT);
+      if (active) {
+        float of[1][1];
+        mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_f, of, mask, nullptr);
+      }
+      stage_weights(wl, sc.dec[2] + PF::EMB,
+                    (NEED_DP ? PF::LEN : PF::W0T) - PF::EMB);
+      if (active) {
+        mlp_bwd<1, 64, 1, NEED_DP, NEED_DP>(wl - PF::EMB, lane, p32, c_f, go,
                                             mask, gc, gp32);
         const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
@@ -1563,14 +1588,20 @@ nice_bwd_fused_kernel(
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
         tri_gather(sc.grid[3], tr, q, c_c[0]);
       }
-      if (NEED_DW) {
-        color_bwd_dw<NEED_DP>(dec_c, lds, wave, lane, active, nact, p32,
-                              c_c, go, gc, gp32, A);
-      } else if (active) {
+      f32x4 hs[5][2];
+      stage_weights(wl, sc.dec[3], PC::WHT);
+      if (active) {
         float oc[1][4];
-        mlp_fwd<1, 32, 4, true, false>(dec_c, lane, p32, c_c, oc, mask,
-                                       nullptr);
-        mlp_bwd<1, 32, 4, NEED_DP, NEED_DP>(dec_c, lane, p32, c_c, go,
+        mlp_fwd<1, 32, 4, true, NEED_DW>(wl, lane, p32, c_c, oc, mask, hs);
+      }
+      stage_weights(wl, sc.dec[3] + PC::EMB,
+                    ((NEED_DP || NEED_DW) ? PC::LEN : PC::W0T) - PC::EMB);
+      if (NEED_DW) {
+        const int nact = ntiles - grp * FWV < FWV ? ntiles - grp * FWV : FWV;
+        color_bwd_dw<NEED_DP>(wl - PC::EMB, wl + kDwBase, wave, lane, active,
+                              nact, p32, c_c, go, mask[0], hs, gc, gp32, A);
+      } else if (active) {
+        mlp_bwd<1, 32, 4, NEED_DP, NEED_DP>(wl - PC::EMB, lane, p32, c_c, go,
                                             mask, gc, gp32);
       }
       if (active) {
@@ -1628,8 +1659,8 @@ __global__ void mfma_selftest_kernel(const float* a, const float* b,
   for (int r = 0; r < 4; ++r) out[((l >> 4) * 4 + r) * 16 + (l & 15)] = d[r];
 }
 
-// persistent blocks of the fused backward when weight gradients are
-// accumulated in registers: one 8-wave block (154 KB of LDS) per CU
+// persistent blocks of the fused backward: one per CU (the staged fragments
+// take most of its LDS)
 constexpr int kFusedBlocks = 256;
 
 }  // namespace
@@ -1733,7 +1764,7 @@ int64_t xrd_nice_bwd_ws_floats(int n_rays) {
 }  // extern "C"
 
 static size_t fused_lds_bytes(bool dw) {
-  return (size_t)(dw ? FWD * DwLds::LEN : FW * kPlainLds) * sizeof(float);
+  return fused_lds_floats(dw) * sizeof(float);
 }
 
 template <int ST, int NTV, bool DP, bool DW>
@@ -1757,9 +1788,7 @@ static int launch_fused(const xrd_nice_scene* scene, int n,
   if (n == 0) return XRD_OK;  // warm-up call: attributes only
   constexpr int fw = DW ? FWD : FW;
   int64_t ngroups = ((int64_t)n * NTV + fw - 1) / fw;
-  // with register-resident dW the blocks are persistent (one flush each)
-  const int64_t cap = DW ? kFusedBlocks : kMaxBwdBlocks;
-  const int nb = (int)(ngroups < cap ? ngroups : cap);
+  const int nb = (int)(ngroups < kFusedBlocks ? ngroups : kFusedBlocks);
   hipLaunchKernelGGL(kern, dim3(nb), dim3(fw * 64), lds, st, *scene, n, rays_o,
                      rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg[1],
                      gg[2], gg[3], part, dw_rep);
@@ -1778,9 +1807,6 @@ static int fused_dispatch(const xrd_nice_scene* scene, int stage, int nt,
                           const double* g_depth, const double* g_var,
                           const float* g_rgb, float* const gg[4], double* part,
                           float* dw_rep, hipStream_t st) {
-#ifdef XRD_RES_PROBE  // build-time probe of one variant's register use
-  FUSED_CASE(XRD_STAGE_COLOR, 3, XRD_RES_PROBE & 1, true);
-#endif
   if (stage == XRD_STAGE_MIDDLE) {
     if (nt == 3) {
       if (dp) FUSED_CASE(XRD_STAGE_MIDDLE, 3, true, false);
