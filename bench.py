@@ -68,10 +68,10 @@ FWD_FLOPS = {'coarse': 12.4e3, 'middle': 31.0e3, 'fine': 72.0e3,
 
 def pmc_traffic(kernels):
     """bytes per launch of a launch group from the committed PMC pass
-    (profiles/r01_pmc.json, made by tools/run_pmc.sh on this same workload):
+    (profiles/r02_pmc.json, made by tools/run_pmc.sh on this same workload):
     sum over the group's kernels of 2 x FETCH_SIZE (gfx950 correction) +
     WRITE_SIZE; None when the file or a kernel is missing"""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
     if not os.path.exists(path):
         return None
     pmc = json.load(open(path))
@@ -90,15 +90,13 @@ def nice_group_kernels(kernel, stage, need_pose, need_dec):
     if kernel != 'nice_bwd':
         return None
     dp = 'true' if need_pose else 'false'
-    decs = {'coarse': [0], 'middle': [1], 'fine': [1, 2],
-            'color': [1, 2, 3]}[stage]
-    out = []
-    for d in decs:
-        nt = 2 if d == 0 else 3
-        dw = 'true' if (d == 3 and need_dec) else 'false'
-        out.append(f'nice_bwd<dec/stage={d},NT={nt},dp={dp},dw={dw}>')
-    if need_dec and stage == 'color':
-        out.append('nice_dw_kernel')
+    dw = 'true' if (need_dec and stage == 'color') else 'false'
+    if stage == 'coarse':
+        return ['nice_bwd_coarse_kernel', 'coarse_rep_reduce_kernel']
+    st = {'middle': 1, 'fine': 2, 'color': 3}[stage]
+    out = [f'nice_bwd_fused<stage={st},NT=3,dp={dp},dw={dw}>']
+    if need_pose or dw == 'true':
+        out.append('nice_bwd_finish_kernel')
     return out
 
 
@@ -335,7 +333,7 @@ def run_coslam(args, dev, with_cpu, world=1):
             (['coslam_reduce_kernel', 'hash_chunk_scatter_kernel']
              if map_grads else [])) if kernel == 'coslam_bwd'
         else pmc_traffic(['coslam_fwd_kernel']),
-        'traffic_source': 'profiles/r01_pmc.json (see NICE line)',
+        'traffic_source': 'profiles/r02_pmc.json (see NICE line)',
         'intensity_flop_per_byte': aflops / abytes,
         'kernel': f'{kernel}[rays={n_rays},ray_grad={int(ray_grads)},'
                   f'map_grad={int(map_grads)}] (launch group: zero-fill, '
@@ -783,7 +781,7 @@ def main():
                                                        need_pose, need_dec))
                         if nice_group_kernels(kernel, stage, need_pose,
                                               need_dec) else None),
-            'traffic_source': 'profiles/r01_pmc.json (rocprofv3 --pmc '
+            'traffic_source': 'profiles/r02_pmc.json (rocprofv3 --pmc '
                               'FETCH_SIZE, WRITE_SIZE passes of this workload;'
                               ' bytes per launch group, FETCH x2 on gfx950)',
             'intensity_flop_per_byte': aflops / abytes,

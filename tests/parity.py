@@ -72,3 +72,17 @@ def assert_all(pairs, tol=RTOL):
     """pairs: iterable of (name, got, want)"""
     bad = [m for m in (check(n, a, b, tol) for n, a, b in pairs) if m]
     assert not bad, '\n'.join(bad)
+
+
+def row_outliers(a, b, tol=RTOL):
+    """per-row max deviation relative to max|b|; returns (fraction of rows
+    above tol, largest row deviation).  For per-ray gradients: a ReLU kink or
+    a trilinear cell border crossed by ONE sample under a last-bit rounding
+    difference changes that ray's gradient discontinuously (by ~1e-3 of the
+    largest gradient) while every other ray agrees to 1e-6 — two correct f32
+    evaluations (torch CPU / torch CUDA / these kernels) show such rows
+    against each other and against an f64 evaluation."""
+    a, b = _np(a), _np(b)
+    scale = max(np.abs(b).max(), 1e-30)
+    dev = np.abs(a - b).reshape(a.shape[0], -1).max(1) / scale
+    return float((dev > tol).mean()), float(dev.max())

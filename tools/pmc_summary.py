@@ -16,10 +16,15 @@ def short_name(name):
     if m:
         return (f'nice_{m.group(1)}<dec/stage={m.group(2)},NT={m.group(3)},'
                 f'dp={m.group(4)},dw={m.group(5)}>')
+    m = re.search(r'nice_bwd_fused_kernel<(\d+), (\d+), (\w+), (\w+)>', name)
+    if m:
+        return (f'nice_bwd_fused<stage={m.group(1)},NT={m.group(2)},'
+                f'dp={m.group(3)},dw={m.group(4)}>')
     m = re.search(r'coslam_bwd_kernel<(\w+), (\w+)>', name)
     if m:
         return f'coslam_bwd<dp={m.group(1)},dg={m.group(2)}>'
-    for k in ('nice_dw_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
+    for k in ('nice_bwd_coarse_kernel', 'nice_bwd_finish_kernel',
+              'coarse_rep_reduce_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
               'hash_chunk_scatter_kernel', 'coslam_reduce_kernel',
               'coslam_loss_grad_kernel', 'adam_dense_kernel',
               'reduce_partials_kernel', 'hashgrid_kernel'):

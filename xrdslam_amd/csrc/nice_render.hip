@@ -1078,13 +1078,16 @@ __global__ __launch_bounds__(2 * 64, 2) void nice_bwd_coarse_kernel(
 // synchronises, and every wave contracts its block over the eight tiles.
 // Nothing is staged through HBM (round 1: 90 MB per launch).
 // ---------------------------------------------------------------------------
-#ifndef XRD_FW
-#define XRD_FW 8
-#endif
-#ifndef XRD_OCC
-#define XRD_OCC 2
-#endif
-constexpr int FW = XRD_FW;       // tiles (waves) per block, 2 waves per SIMD
+// tiles (= waves) per block.  Measured at 1000 rays (colour stage, grid
+// gradients only): 4 waves 218 us, 8 waves 185 us, 16 waves 151 us — more
+// tiles share one staging of the fragments and more waves hide the gathers;
+// 16 waves leave 128 registers a lane, which the variants without pose
+// gradients fit and the others do not (they spill and lose: 263 vs 242 us).
+constexpr int FW = 8;
+constexpr int FW_WIDE = 16;
+__host__ __device__ constexpr int fused_waves(bool dp, bool dw) {
+  return (dp || dw) ? FW : FW_WIDE;
+}
 constexpr int FWD = 8;           // ... with weight gradients (2 per SIMD too)
 constexpr int kDwRep = 8;        // replicas the blocks add their dW into
 constexpr int kRS = 36;          // row stride of a point-major LDS matrix
@@ -1123,7 +1126,7 @@ constexpr size_t fused_lds_floats(bool dw) {
   return dw ? ((size_t)kDwBase + FWD * DwLds::LEN > (size_t)kWMax
                    ? (size_t)kDwBase + FWD * DwLds::LEN
                    : (size_t)kWMax)
-            : (size_t)kWMax + FW * kScratch;
+            : (size_t)kWMax + FW_WIDE * kScratch;
 }
 static_assert(fused_lds_floats(true) * 4 <= 163840, "LDS per CU");
 static_assert(fused_lds_floats(false) * 4 <= 163840, "LDS per CU");
@@ -1467,7 +1470,8 @@ __device__ __forceinline__ void color_bwd_dw(
 }
 
 template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
-__global__ __launch_bounds__((NEED_DW ? FWD : FW) * 64, XRD_OCC) void
+__global__ __launch_bounds__(fused_waves(NEED_DP, NEED_DW) * 64,
+                             fused_waves(NEED_DP, NEED_DW) / 4) void
 nice_bwd_fused_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
@@ -1477,7 +1481,8 @@ nice_bwd_fused_kernel(
     float* gg_color, double* __restrict__ part, float* __restrict__ dw_rep) {
   static_assert(!NEED_DW || STAGE == XRD_STAGE_COLOR, "dW: colour stage");
   constexpr int S = NT * 16;
-  constexpr int FWV = NEED_DW ? FWD : FW;
+  constexpr int FWV = fused_waves(NEED_DP, NEED_DW);
+  static_assert(FWD == FW, "exchange roles assume 8 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);  // staged fragments
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1786,7 +1791,7 @@ static int launch_fused(const xrd_nice_scene* scene, int n,
     attr_set = true;
   }
   if (n == 0) return XRD_OK;  // warm-up call: attributes only
-  constexpr int fw = DW ? FWD : FW;
+  constexpr int fw = fused_waves(DP, DW);
   int64_t ngroups = ((int64_t)n * NTV + fw - 1) / fw;
   const int nb = (int)(ngroups < kFusedBlocks ? ngroups : kFusedBlocks);
   hipLaunchKernelGGL(kern, dim3(nb), dim3(fw * 64), lds, st, *scene, n, rays_o,
