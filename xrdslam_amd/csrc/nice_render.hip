@@ -794,115 +794,6 @@ __device__ __forceinline__ void load_ray(const float* __restrict__ rays_o,
   rc.gd = use_depth ? gt_depth[ray] : 0.f;
 }
 
-template <int STAGE, int NT>
-__global__ __launch_bounds__(RPB* NT * 64) void nice_fwd_kernel(
-    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
-    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
-    const float* __restrict__ dmax_p, double* __restrict__ depth,
-    double* __restrict__ var, float* __restrict__ rgb,
-    float* __restrict__ raw_out) {
-  constexpr int S = NT * 16;
-  constexpr int NW = RPB * NT;
-  __shared__ double zbuf[NW][2][64];
-  __shared__ __attribute__((aligned(16))) float rawbuf[RPB][64][4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q = lane >> 4, li = lane & 15;
-  const int slot = wave / NT, tile = wave % NT;
-  const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * RPB + slot);
-  const bool active = ray < n;
-  const bool use_depth = (gt_depth != nullptr) && STAGE != XRD_STAGE_COARSE;
-  double zl = 0.0;
-  if (active) {
-    RayCtx rc;
-    load_ray(rays_o, rays_d, gt_depth, ray, use_depth, rc);
-    const float dmax = use_depth ? dmax_p[0] : 0.f;
-    zl = sample_z<S>(sc, rc, dmax, lane, zbuf[wave][0], zbuf[wave][1]);
-    TileGeom tg;
-    tile_geom(rc, zbuf[wave][1][16 * tile + li], sc.bound, tg);
-    const float p32[1][3] = {{tg.p32[0], tg.p32[1], tg.p32[2]}};
-    float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
-    uint64_t mdummy[1];
-    Tri tr;
-    if (STAGE == XRD_STAGE_COARSE) {
-      f32x4 c_a[1][2];
-      float o1[1];
-      tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
-      tri_gather(sc.grid[0], tr, q, c_a[0]);
-      noxyz_fwd<1, false>(sc.dec[0], lane, c_a, o1, mdummy);
-      occ = o1[0];
-    } else {
-      f32x4 c_m[1][2];
-      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
-      tri_gather(sc.grid[1], tr, q, c_m[0]);
-      {
-        float om[1][1];
-        mlp_fwd<1, 32, 1, false, false>(sc.dec[1], lane, p32, c_m, om, mdummy,
-                                        nullptr);
-        occ = om[0][0];
-      }
-      if (STAGE >= XRD_STAGE_FINE) {
-        f32x4 c_f[1][4], cf[2];
-        float of[1][1];
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
-        tri_gather(sc.grid[2], tr, q, cf);
-        c_f[0][0] = cf[0];
-        c_f[0][1] = cf[1];
-        c_f[0][2] = c_m[0][0];
-        c_f[0][3] = c_m[0][1];
-        mlp_fwd<1, 64, 1, false, false>(sc.dec[2], lane, p32, c_f, of, mdummy,
-                                        nullptr);
-        occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
-      }
-      if (STAGE == XRD_STAGE_COLOR) {
-        f32x4 c_c[1][2];
-        float oc[1][4];
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
-        tri_gather(sc.grid[3], tr, q, c_c[0]);
-        mlp_fwd<1, 32, 4, false, false>(sc.dec[3], lane, p32, c_c, oc, mdummy,
-                                        nullptr);
-        col[0] = oc[0][0];
-        col[1] = oc[0][1];
-        col[2] = oc[0][2];
-      }
-    }
-    if (!tg.inb) occ = 100.f;  // conv_onet.py:370
-    if (q == 0)
-      *reinterpret_cast<f32x4*>(&rawbuf[slot][16 * tile + li][0]) =
-          f32x4{col[0], col[1], col[2], occ};
-  }
-  __syncthreads();
-  if (!active || tile != 0) return;
-  // compositing: lane l (< S) is sample l of the ray
-  const bool valid = lane < S;
-  f32x4 rw = {0.f, 0.f, 0.f, 0.f};
-  if (valid) rw = *reinterpret_cast<const f32x4*>(&rawbuf[slot][lane][0]);
-  if (raw_out != nullptr && valid)
-    *reinterpret_cast<f32x4*>(raw_out + ((size_t)ray * S + lane) * 4) = rw;
-  const float alpha = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
-  const float f = valid ? (1.f - alpha + 1e-10f) : 1.f;
-  float incl = f;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float u = __shfl_up(incl, o);
-    if (lane >= o) incl *= u;
-  }
-  float T = __shfl_up(incl, 1);
-  if (lane == 0) T = 1.f;
-  const float w = alpha * T;
-  const float R = wave_sum(w * rw[0]), G = wave_sum(w * rw[1]),
-              B = wave_sum(w * rw[2]);
-  const double dep = wave_sum(valid ? (double)w * zl : 0.0);
-  const double tmp = zl - dep;
-  const double vr = wave_sum(valid ? (double)w * tmp * tmp : 0.0);
-  if (lane == 0) {
-    depth[ray] = dep;
-    var[ray] = vr;
-    rgb[ray * 3 + 0] = R;
-    rgb[ray * 3 + 1] = G;
-    rgb[ray * 3 + 2] = B;
-  }
-}
-
 constexpr int kCoarseRep = 32;  // replicas of the coarse-grid gradient
 
 // grad += sum of the replicas; the replicas are left zeroed for the next call
@@ -1083,11 +974,11 @@ __global__ __launch_bounds__(2 * 64, 2) void nice_bwd_coarse_kernel(
 // tiles share one staging of the fragments and more waves hide the gathers;
 // 16 waves leave 128 registers a lane, which the variants without pose
 // gradients fit and the others do not (they spill and lose: 263 vs 242 us).
+// Small batches (tracking: 200 rays = 600 tiles) fill more CUs with narrow
+// blocks — a block's staging costs only a few microseconds — so the width is
+// a launch-time choice: 4, 8 or 16 waves (fused_width()).
 constexpr int FW = 8;
 constexpr int FW_WIDE = 16;
-__host__ __device__ constexpr int fused_waves(bool dp, bool dw) {
-  return (dp || dw) ? FW : FW_WIDE;
-}
 constexpr int FWD = 8;           // ... with weight gradients (2 per SIMD too)
 constexpr int kDwRep = 8;        // replicas the blocks add their dW into
 constexpr int kRS = 36;          // row stride of a point-major LDS matrix
@@ -1126,7 +1017,7 @@ constexpr size_t fused_lds_floats(bool dw) {
   return dw ? ((size_t)kDwBase + FWD * DwLds::LEN > (size_t)kWMax
                    ? (size_t)kDwBase + FWD * DwLds::LEN
                    : (size_t)kWMax)
-            : (size_t)kWMax + FW_WIDE * kScratch;
+            : (size_t)kWMax + FW_WIDE * kScratch;  // widest variant
 }
 static_assert(fused_lds_floats(true) * 4 <= 163840, "LDS per CU");
 static_assert(fused_lds_floats(false) * 4 <= 163840, "LDS per CU");
@@ -1469,9 +1360,8 @@ __device__ __forceinline__ void color_bwd_dw(
   __syncthreads();  // the regions (and their scratch aliases) may be reused
 }
 
-template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
-__global__ __launch_bounds__(fused_waves(NEED_DP, NEED_DW) * 64,
-                             fused_waves(NEED_DP, NEED_DW) / 4) void
+template <int STAGE, int NT, bool NEED_DP, bool NEED_DW, int FWV>
+__global__ __launch_bounds__(FWV * 64, (FWV + 3) / 4) void
 nice_bwd_fused_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
@@ -1481,8 +1371,7 @@ nice_bwd_fused_kernel(
     float* gg_color, double* __restrict__ part, float* __restrict__ dw_rep) {
   static_assert(!NEED_DW || STAGE == XRD_STAGE_COLOR, "dW: colour stage");
   constexpr int S = NT * 16;
-  constexpr int FWV = fused_waves(NEED_DP, NEED_DW);
-  static_assert(FWD == FW, "exchange roles assume 8 waves");
+  static_assert(!NEED_DW || FWV == FWD, "exchange roles assume 8 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);  // staged fragments
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1632,6 +1521,154 @@ nice_bwd_fused_kernel(
              A);
 }
 
+// Forward render.  A block = RPB rays (15 / 16 waves, one 16-sample tile
+// each); like the backward it stages one decoder's forward fragments at a time
+// in LDS and loops over groups of rays (persistent blocks, one per CU).
+// (RPB = 5 / 8 rays = 15 / 16 waves for batches that still cover the chip,
+// one ray per block below that.)
+template <int NT>
+__host__ __device__ constexpr int fwd_rays_wide() { return NT == 3 ? 5 : 8; }
+template <int NT, int RPB>
+constexpr size_t fwd_lds_floats() {
+  return (size_t)kWMax + RPB * 256 + RPB * NT * 256;
+}
+
+template <int STAGE, int NT, int RPB>
+__global__ __launch_bounds__(RPB * NT * 64, (RPB * NT + 3) / 4) void
+nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+                const float* __restrict__ rays_d,
+                const float* __restrict__ gt_depth,
+                const float* __restrict__ dmax_p, double* __restrict__ depth,
+                double* __restrict__ var, float* __restrict__ rgb,
+                float* __restrict__ raw_out) {
+  constexpr int S = NT * 16;
+  constexpr int NW = RPB * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  float* rawbuf = wl + kWMax;                      // [RPB][64][4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* zbuf = reinterpret_cast<double*>(rawbuf + RPB * 256) + wave * 128;
+  const int q = lane >> 4, li = lane & 15;
+  const int slot = wave / NT, tile = wave % NT;
+  const bool use_depth = (gt_depth != nullptr) && STAGE != XRD_STAGE_COARSE;
+  const int ngroups = (n + RPB - 1) / RPB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * RPB + slot);
+    const bool active = ray < n;
+    double zl = 0.0;
+    TileGeom tg = {};
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
+    uint64_t mdummy[1];
+    Tri tr;
+    f32x4 c_m[1][2];
+    if (active) {
+      RayCtx rc;
+      load_ray(rays_o, rays_d, gt_depth, ray, use_depth, rc);
+      const float dmax = use_depth ? dmax_p[0] : 0.f;
+      zl = sample_z<S>(sc, rc, dmax, lane, zbuf, zbuf + 64);
+      tile_geom(rc, zbuf[64 + 16 * tile + li], sc.bound, tg);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) p32[0][a] = tg.p32[a];
+      if (STAGE == XRD_STAGE_COARSE)
+        tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+      else
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+      tri_gather(sc.grid[STAGE == XRD_STAGE_COARSE ? 0 : 1], tr, q, c_m[0]);
+    }
+    if (STAGE == XRD_STAGE_COARSE) {
+      stage_weights(wl, sc.dec[0], NoXyzPack::WT);
+      if (active) {
+        float o1[1];
+        noxyz_fwd<1, false>(wl, lane, c_m, o1, mdummy);
+        occ = o1[0];
+      }
+    } else {
+      stage_weights(wl, sc.dec[1], MlpPack<32, 1>::WHT);
+      if (active) {
+        float om[1][1];
+        mlp_fwd<1, 32, 1, false, false>(wl, lane, p32, c_m, om, mdummy,
+                                        nullptr);
+        occ = om[0][0];
+      }
+      if (STAGE >= XRD_STAGE_FINE) {
+        f32x4 c_f[1][4];
+        if (active) {
+          f32x4 cf[2];
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+          tri_gather(sc.grid[2], tr, q, cf);
+          c_f[0][0] = cf[0];
+          c_f[0][1] = cf[1];
+          c_f[0][2] = c_m[0][0];
+          c_f[0][3] = c_m[0][1];
+        }
+        stage_weights(wl, sc.dec[2], MlpPack<64, 1>::WHT);
+        if (active) {
+          float of[1][1];
+          mlp_fwd<1, 64, 1, false, false>(wl, lane, p32, c_f, of, mdummy,
+                                          nullptr);
+          occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
+        }
+      }
+      if (STAGE == XRD_STAGE_COLOR) {
+        f32x4 c_c[1][2];
+        if (active) {
+          tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+          tri_gather(sc.grid[3], tr, q, c_c[0]);
+        }
+        stage_weights(wl, sc.dec[3], MlpPack<32, 4>::WHT);
+        if (active) {
+          float oc[1][4];
+          mlp_fwd<1, 32, 4, false, false>(wl, lane, p32, c_c, oc, mdummy,
+                                          nullptr);
+          col[0] = oc[0][0];
+          col[1] = oc[0][1];
+          col[2] = oc[0][2];
+        }
+      }
+    }
+    if (active) {
+      if (!tg.inb) occ = 100.f;  // conv_onet.py:370
+      if (q == 0)
+        *reinterpret_cast<f32x4*>(rawbuf + (slot * 64 + 16 * tile + li) * 4) =
+            f32x4{col[0], col[1], col[2], occ};
+    }
+    __syncthreads();
+    // (rawbuf is rewritten only behind the next group's staging barriers)
+    if (!active || tile != 0) continue;
+    // compositing: lane l (< S) is sample l of the ray
+    const bool valid = lane < S;
+    f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+    if (valid)
+      rw = *reinterpret_cast<const f32x4*>(rawbuf + (slot * 64 + lane) * 4);
+    if (raw_out != nullptr && valid)
+      *reinterpret_cast<f32x4*>(raw_out + ((size_t)ray * S + lane) * 4) = rw;
+    const float alpha = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
+    const float f = valid ? (1.f - alpha + 1e-10f) : 1.f;
+    float incl = f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float u = __shfl_up(incl, o);
+      if (lane >= o) incl *= u;
+    }
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.f;
+    const float w = alpha * T;
+    const float R = wave_sum(w * rw[0]), G = wave_sum(w * rw[1]),
+                B = wave_sum(w * rw[2]);
+    const double dep = wave_sum(valid ? (double)w * zl : 0.0);
+    const double tmp = zl - dep;
+    const double vr = wave_sum(valid ? (double)w * tmp * tmp : 0.0);
+    if (lane == 0) {
+      depth[ray] = dep;
+      var[ray] = vr;
+      rgb[ray * 3 + 0] = R;
+      rgb[ray * 3 + 1] = G;
+      rgb[ray * 3 + 2] = B;
+    }
+  }
+}
+
 // g_dec = sum of the dW replicas; g_rays_{o,d}[ray] = sum of the ray's tile
 // partials (fixed order: deterministic)
 __global__ __launch_bounds__(256) void nice_bwd_finish_kernel(
@@ -1723,10 +1760,61 @@ static int nice_check(const xrd_nice_scene* sc, int stage, int n,
   return XRD_OK;
 }
 
-#define FWD_CASE(ST, NTV)                                                     \
-  hipLaunchKernelGGL((nice_fwd_kernel<ST, NTV>),                              \
-                     dim3((n_rays + RPB - 1) / RPB), dim3(RPB * NTV * 64), 0, st, *scene, n_rays, rays_o, rays_d,        \
-                     gt_depth, dmax, depth, var, rgb, raw_out)
+}  // extern "C"
+
+template <int ST, int NTV, int RPBV>
+static int launch_fwd(const xrd_nice_scene* scene, int n, const float* rays_o,
+                      const float* rays_d, const float* gt_depth,
+                      const float* dmax, double* depth, double* var,
+                      float* rgb, float* raw_out, hipStream_t st) {
+  auto kern = nice_fwd_kernel<ST, NTV, RPBV>;
+  const size_t lds = fwd_lds_floats<NTV, RPBV>() * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr_set = true;
+  }
+  if (n == 0) return XRD_OK;  // warm-up call: attributes only
+  constexpr int rpb = RPBV;
+  const int ngroups = (n + rpb - 1) / rpb;
+  const int nb = ngroups < kFusedBlocks ? ngroups : kFusedBlocks;
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(rpb * NTV * 64), lds, st, *scene, n,
+                     rays_o, rays_d, gt_depth, dmax, depth, var, rgb, raw_out);
+  return check_launch("xrd_nice_render_fwd");
+}
+
+#define FWD_CASE(ST, NTV)                                                    \
+  {                                                                          \
+    if (wide)                                                                \
+      return launch_fwd<ST, NTV, fwd_rays_wide<NTV>()>(                      \
+          scene, n_rays, rays_o, rays_d, gt_depth, dmax, depth, var, rgb,    \
+          raw_out, st);                                                      \
+    return launch_fwd<ST, NTV, 1>(scene, n_rays, rays_o, rays_d, gt_depth,   \
+                                  dmax, depth, var, rgb, raw_out, st);       \
+  }
+
+static int fwd_dispatch(const xrd_nice_scene* scene, int stage, int nt,
+                        int n_rays, const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        double* depth, double* var, float* rgb,
+                        float* raw_out, hipStream_t st, int wide = -1) {
+  if (wide < 0) wide = n_rays >= 512;  // else one ray per block
+  switch (stage * 4 + nt) {
+    case XRD_STAGE_COARSE * 4 + 2: FWD_CASE(XRD_STAGE_COARSE, 2);
+    case XRD_STAGE_MIDDLE * 4 + 2: FWD_CASE(XRD_STAGE_MIDDLE, 2);
+    case XRD_STAGE_MIDDLE * 4 + 3: FWD_CASE(XRD_STAGE_MIDDLE, 3);
+    case XRD_STAGE_FINE * 4 + 2: FWD_CASE(XRD_STAGE_FINE, 2);
+    case XRD_STAGE_FINE * 4 + 3: FWD_CASE(XRD_STAGE_FINE, 3);
+    case XRD_STAGE_COLOR * 4 + 2: FWD_CASE(XRD_STAGE_COLOR, 2);
+    case XRD_STAGE_COLOR * 4 + 3: FWD_CASE(XRD_STAGE_COLOR, 3);
+    default: return XRD_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" {
 
 int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
                         const float* rays_o, const float* rays_d,
@@ -1741,17 +1829,8 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
   if (n_rays == 0) return XRD_OK;
   hipStream_t st = (hipStream_t)stream;
   if (stage == XRD_STAGE_COARSE) gt_depth = nullptr;
-  switch (stage * 4 + nt) {
-    case XRD_STAGE_COARSE * 4 + 2: FWD_CASE(XRD_STAGE_COARSE, 2); break;
-    case XRD_STAGE_MIDDLE * 4 + 2: FWD_CASE(XRD_STAGE_MIDDLE, 2); break;
-    case XRD_STAGE_MIDDLE * 4 + 3: FWD_CASE(XRD_STAGE_MIDDLE, 3); break;
-    case XRD_STAGE_FINE * 4 + 2: FWD_CASE(XRD_STAGE_FINE, 2); break;
-    case XRD_STAGE_FINE * 4 + 3: FWD_CASE(XRD_STAGE_FINE, 3); break;
-    case XRD_STAGE_COLOR * 4 + 2: FWD_CASE(XRD_STAGE_COLOR, 2); break;
-    case XRD_STAGE_COLOR * 4 + 3: FWD_CASE(XRD_STAGE_COLOR, 3); break;
-    default: return XRD_ERR_UNSUPPORTED;
-  }
-  return check_launch("xrd_nice_render_fwd");
+  return fwd_dispatch(scene, stage, nt, n_rays, rays_o, rays_d, gt_depth,
+                      dmax, depth, var, rgb, raw_out, st);
 }
 
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene) {
@@ -1772,7 +1851,7 @@ static size_t fused_lds_bytes(bool dw) {
   return fused_lds_floats(dw) * sizeof(float);
 }
 
-template <int ST, int NTV, bool DP, bool DW>
+template <int ST, int NTV, bool DP, bool DW, int W>
 static int launch_fused(const xrd_nice_scene* scene, int n,
                         const float* rays_o, const float* rays_d,
                         const float* gt_depth, const float* dmax,
@@ -1780,8 +1859,10 @@ static int launch_fused(const xrd_nice_scene* scene, int n,
                         const double* g_var, const float* g_rgb,
                         float* const gg[4], double* part, float* dw_rep,
                         hipStream_t st) {
-  auto kern = nice_bwd_fused_kernel<ST, NTV, DP, DW>;
-  const size_t lds = fused_lds_bytes(DW);
+  auto kern = nice_bwd_fused_kernel<ST, NTV, DP, DW, W>;
+  const size_t lds =
+      (DW ? fused_lds_floats(true) : (size_t)kWMax + W * kScratch) *
+      sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1791,19 +1872,50 @@ static int launch_fused(const xrd_nice_scene* scene, int n,
     attr_set = true;
   }
   if (n == 0) return XRD_OK;  // warm-up call: attributes only
-  constexpr int fw = fused_waves(DP, DW);
-  int64_t ngroups = ((int64_t)n * NTV + fw - 1) / fw;
+  int64_t ngroups = ((int64_t)n * NTV + W - 1) / W;
   const int nb = (int)(ngroups < kFusedBlocks ? ngroups : kFusedBlocks);
-  hipLaunchKernelGGL(kern, dim3(nb), dim3(fw * 64), lds, st, *scene, n, rays_o,
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(W * 64), lds, st, *scene, n, rays_o,
                      rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg[1],
                      gg[2], gg[3], part, dw_rep);
   return check_launch("xrd_nice_render_bwd");
 }
 
-#define FUSED_CASE(ST, NTV, DP, DW)                                          \
-  return launch_fused<ST, NTV, DP, DW>(scene, n_rays, rays_o, rays_d,        \
-                                       gt_depth, dmax, raw, g_depth, g_var,  \
-                                       g_rgb, gg, part, dw_rep, st)
+// waves per block: as wide as the batch still spreads over >= ~half the CUs;
+// 16 only without pose gradients (128 registers a lane); weight gradients: 8
+static int fused_width(int64_t tiles, bool dp, bool dw) {
+  if (dw) return FWD;
+  if (!dp && tiles >= 16 * 128) return 16;
+  if (tiles >= 8 * 128) return 8;
+  return 4;
+}
+
+#define FUSED_ARGS                                                          \
+  scene, n_rays, rays_o, rays_d, gt_depth, dmax, raw, g_depth, g_var, g_rgb, \
+      gg, part, dw_rep, st
+
+template <int ST, int NTV>
+static int fused_dispatch_st(int width, bool dp, bool dw,
+                             const xrd_nice_scene* scene, int n_rays,
+                             const float* rays_o, const float* rays_d,
+                             const float* gt_depth, const float* dmax,
+                             const float* raw, const double* g_depth,
+                             const double* g_var, const float* g_rgb,
+                             float* const gg[4], double* part, float* dw_rep,
+                             hipStream_t st) {
+  if constexpr (ST == XRD_STAGE_COLOR) {
+    if (dw) {
+      if (dp) return launch_fused<ST, NTV, true, true, FWD>(FUSED_ARGS);
+      return launch_fused<ST, NTV, false, true, FWD>(FUSED_ARGS);
+    }
+  }
+  if (dp) {
+    if (width >= 8) return launch_fused<ST, NTV, true, false, 8>(FUSED_ARGS);
+    return launch_fused<ST, NTV, true, false, 4>(FUSED_ARGS);
+  }
+  if (width >= 16) return launch_fused<ST, NTV, false, false, 16>(FUSED_ARGS);
+  if (width >= 8) return launch_fused<ST, NTV, false, false, 8>(FUSED_ARGS);
+  return launch_fused<ST, NTV, false, false, 4>(FUSED_ARGS);
+}
 
 static int fused_dispatch(const xrd_nice_scene* scene, int stage, int nt,
                           bool dp, bool dw, int n_rays, const float* rays_o,
@@ -1811,33 +1923,21 @@ static int fused_dispatch(const xrd_nice_scene* scene, int stage, int nt,
                           const float* dmax, const float* raw,
                           const double* g_depth, const double* g_var,
                           const float* g_rgb, float* const gg[4], double* part,
-                          float* dw_rep, hipStream_t st) {
+                          float* dw_rep, hipStream_t st, int width = 0) {
+  if (width == 0) width = fused_width((int64_t)n_rays * nt, dp, dw);
+#define FUSED_ST(ST, NTV) \
+  return fused_dispatch_st<ST, NTV>(width, dp, dw, FUSED_ARGS)
   if (stage == XRD_STAGE_MIDDLE) {
-    if (nt == 3) {
-      if (dp) FUSED_CASE(XRD_STAGE_MIDDLE, 3, true, false);
-      FUSED_CASE(XRD_STAGE_MIDDLE, 3, false, false);
-    }
-    if (dp) FUSED_CASE(XRD_STAGE_MIDDLE, 2, true, false);
-    FUSED_CASE(XRD_STAGE_MIDDLE, 2, false, false);
+    if (nt == 3) FUSED_ST(XRD_STAGE_MIDDLE, 3);
+    FUSED_ST(XRD_STAGE_MIDDLE, 2);
   }
   if (stage == XRD_STAGE_FINE) {
-    if (nt == 3) {
-      if (dp) FUSED_CASE(XRD_STAGE_FINE, 3, true, false);
-      FUSED_CASE(XRD_STAGE_FINE, 3, false, false);
-    }
-    if (dp) FUSED_CASE(XRD_STAGE_FINE, 2, true, false);
-    FUSED_CASE(XRD_STAGE_FINE, 2, false, false);
+    if (nt == 3) FUSED_ST(XRD_STAGE_FINE, 3);
+    FUSED_ST(XRD_STAGE_FINE, 2);
   }
-  if (nt == 3) {
-    if (dp && dw) FUSED_CASE(XRD_STAGE_COLOR, 3, true, true);
-    if (dp) FUSED_CASE(XRD_STAGE_COLOR, 3, true, false);
-    if (dw) FUSED_CASE(XRD_STAGE_COLOR, 3, false, true);
-    FUSED_CASE(XRD_STAGE_COLOR, 3, false, false);
-  }
-  if (dp && dw) FUSED_CASE(XRD_STAGE_COLOR, 2, true, true);
-  if (dp) FUSED_CASE(XRD_STAGE_COLOR, 2, true, false);
-  if (dw) FUSED_CASE(XRD_STAGE_COLOR, 2, false, true);
-  FUSED_CASE(XRD_STAGE_COLOR, 2, false, false);
+  if (nt == 3) FUSED_ST(XRD_STAGE_COLOR, 3);
+  FUSED_ST(XRD_STAGE_COLOR, 2);
+#undef FUSED_ST
 }
 
 extern "C" {
@@ -1915,15 +2015,28 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
 int xrd_nice_warmup(void) {
   float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
   xrd_nice_scene sc = {};
+  for (int stage = XRD_STAGE_COARSE; stage <= XRD_STAGE_COLOR; ++stage)
+    for (int nt = 2; nt <= 3; ++nt) {
+      if (stage == XRD_STAGE_COARSE && nt != 2) continue;
+      for (int wide = 0; wide < 2; ++wide) {
+        int rc = fwd_dispatch(&sc, stage, nt, 0, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, wide);
+        if (rc != XRD_OK) return rc;
+      }
+    }
   for (int stage = XRD_STAGE_MIDDLE; stage <= XRD_STAGE_COLOR; ++stage)
     for (int nt = 2; nt <= 3; ++nt)
       for (int dp = 0; dp < 2; ++dp)
         for (int dw = 0; dw < 2; ++dw) {
           if (stage != XRD_STAGE_COLOR && dw) continue;
-          int rc = fused_dispatch(&sc, stage, nt, dp, dw, 0, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, gg, nullptr, nullptr, nullptr);
-          if (rc != XRD_OK) return rc;
+          for (int width = 4; width <= 16; width *= 2) {
+            int rc = fused_dispatch(&sc, stage, nt, dp, dw, 0, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, gg, nullptr,
+                                    nullptr, nullptr, width);
+            if (rc != XRD_OK) return rc;
+          }
         }
   return XRD_OK;
 }
