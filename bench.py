@@ -192,22 +192,18 @@ CO_GATHER = 16 * 8 * 8     # hash-grid corner reads per sample (bytes)
 
 
 def co_algorithmic(kernel, n_rays, ray_grads, map_grads):
-    """(bytes, flops) one launch of the fused Co-SLAM renderer moves/computes:
-    forward = corner gathers + raw/z outputs; backward recomputes the forward,
-    reads the corners again for d/dx, and (mapping) writes the hash-feature
-    gradients + read-modify-writes the touched table entries, plus the
-    weight-gradient GEMMs"""
+    """(bytes, flops) of one launch, SURVEY.md 8(d) per-sample figures:
+    forward 1024 B (16 levels x 8 corners x 2 features x 4 B) and 10.4 kFLOP;
+    backward 2048 B read-modify-write of the table (mapping) and/or 1024 B
+    re-read for the input gradient (tracking / bundle adjustment), 2 x the
+    forward FLOPs.  What the kernels move ON TOP of this (forward recompute
+    gather, level-major dy staging for the chunked scatter) is waste and shows
+    up in `traffic` (PMC counters) against these bytes."""
     n = n_rays * CO_S
     if kernel == 'coslam_fwd':
-        return n * (CO_GATHER + 20), n * CO_FLOPS
-    by = CO_GATHER + 20 + 16
-    fl = 2 * CO_FLOPS
-    if ray_grads:
-        by += CO_GATHER
-    if map_grads:
-        by += 2 * 128 + 12 + 2 * CO_GATHER
-        fl += CO_FLOPS
-    return n * by, n * fl
+        return n * CO_GATHER, n * CO_FLOPS
+    by = (2 * CO_GATHER if map_grads else 0) + (CO_GATHER if ray_grads else 0)
+    return n * max(by, CO_GATHER), n * 2 * CO_FLOPS
 
 
 def co_cpu_baseline(threads):
