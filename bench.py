@@ -593,6 +593,38 @@ def run_pointslam(args, dev, world=1):
         'roofline': None, 'cpu_baseline': None}
 
 
+def _files_ingest(room, n_frames, cam, dev):
+    """the synthetic sequence as a Replica-format folder, read back through
+    xrdslam_amd.data.datasets (file decode + prefetch + H2D in the loop)"""
+    import tempfile
+
+    from PIL import Image
+
+    from xrdslam_amd.data import datasets as fds
+    path = tempfile.mkdtemp(prefix='xrd_replica_')
+    os.makedirs(os.path.join(path, 'results'))
+    with open(os.path.join(path, 'devices.yaml'), 'w') as f:
+        f.write(f'cam:\n  H: {cam.height}\n  W: {cam.width}\n  fx: {cam.fx}\n'
+                f'  fy: {cam.fy}\n  cx: {cam.cx}\n  cy: {cam.cy}\n'
+                '  png_depth_scale: 6553.5\n')
+    lines = []
+    for k in range(n_frames):
+        it = room[k]
+        Image.fromarray(np.clip(np.rint(it['rgb'] * 255), 0, 255).astype(
+            np.uint8)).save(os.path.join(path, 'results', f'frame{k:06d}.jpg'),
+                            quality=95)
+        Image.fromarray(np.clip(np.rint(it['depth'] * 6553.5), 0, 65535)
+                        .astype(np.uint16)).save(
+            os.path.join(path, 'results', f'depth{k:06d}.png'))
+        cv = it['c2w'].copy()
+        cv[:3, 1] *= -1
+        cv[:3, 2] *= -1
+        lines.append(' '.join(f'{v:.9e}' for v in cv.reshape(-1)))
+    with open(os.path.join(path, 'traj.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return fds.Prefetcher(fds.Replica(path), dev, depth=3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--algo', default='nice-slam',
@@ -607,6 +639,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=None,
                     help='untimed frames after frame 0 (default 10 / 5 / 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ingest', default='resident',
+                    choices=['resident', 'files'],
+                    help='resident: frames in HBM before the timed region; '
+                         'files: the sequence is written once as a '
+                         'Replica-format folder (jpg/png/traj.txt) and read '
+                         'back INSIDE the timed region through the file '
+                         'dataset + prefetching loader (decode, pinned '
+                         'staging, one H2D per frame on a side stream)')
     ap.add_argument('--no-coslam', action='store_true',
                     help='skip the Co-SLAM leg of the default run')
     ap.add_argument('--no-graphs', action='store_true',
@@ -687,9 +727,11 @@ def main():
     data = SyntheticRoom(BOUND, H=cam.height, W=cam.width, fx=cam.fx,
                          fy=cam.fy, cx=cam.cx, cy=cam.cy,
                          n_frames=max(n_frames, 200), device=dev)
-    # inputs resident in HBM before the timed region (frame ingest = a
-    # prefetching loader)
-    data.preload(range(n_frames))
+    if args.ingest == 'files':
+        data = _files_ingest(data, n_frames, cam, dev)
+    else:
+        # inputs resident in HBM before the timed region
+        data.preload(range(n_frames))
     cad = cadence['nice-slam']
     slam = SequentialSLAM(algo, data, map_every=cad.map_every,
                           keyframe_every=cad.keyframe_every,
@@ -832,6 +874,12 @@ def main():
                 'fps_including_init_and_warmup':
                     (1 + args.warmup + args.steps) /
                     (t_init + t_warm + elapsed),
+                'ingest': ('frames resident in HBM before the timed region '
+                           '(the per-frame 4.9 MB upload is outside it)'
+                           if args.ingest == 'resident' else
+                           'Replica-format files decoded + uploaded inside '
+                           'the timed region (file dataset, prefetch depth 3, '
+                           'one H2D per frame on a side stream)'),
                 'ate_rmse_m': ate,
                 # after rigid alignment, the number ds-eval reports
                 'ate_rmse_aligned_m': ate_aligned},
