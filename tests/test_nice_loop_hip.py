@@ -3,6 +3,8 @@ iteration (sampling, render, loss kernels) gives the same loss and gradients as
 the generic plugin hooks (get_model_input / model / get_loss_dict) for the same
 random draws; (2) hipGraph replay reproduces eager execution; (3) the
 un-compacted (masked) batch equals the reference's compacted batch."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -272,3 +274,110 @@ def test_multi_frame_sampling_equals_per_frame_launches(separate):
         for x, y in zip(p.parameters(), q.parameters()):
             assert x.grad is not None and y.grad is not None
             assert close(y.grad, x.grad, 1e-5)
+
+
+# ---------------------------------------------------------------------------
+# ATE parity leg (BASELINE.md section 1 gate): the SAME short sequence through
+# (a) the engine (fused HIP render) and (b) the reference's arithmetic — the
+# oracle's torch ops with autograd (oracle/nice_oracle.py, pinned to the
+# reference's modules) under the same loop, the same random draws, the same
+# optimiser schedule.  Both start from seeded random-init decoders (the
+# pretrained ones are LFS pointers), which is why NICE-SLAM drifts on this
+# sequence: if the drift comes from the decoders' missing occupancy prior and
+# not from the kernels, the two trajectories have the same error.
+# ---------------------------------------------------------------------------
+def _run_sequence(render, n_frames, seed=0):
+    """render: 'engine' | 'oracle'; returns (ate, [n,3] estimated positions)"""
+    import nice_oracle as no
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import cadence, nice_slam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    import random
+    dev = 'cuda:0'
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    cam = Camera(80., 80., 79.5, 59.5, 160, 120)
+    cfg = nice_slam_config(BOUND)
+    cfg.tracking_Hedge = cfg.tracking_Wedge = 10
+    cfg.mapping_first_n_iters, cfg.mapping_n_iters = 150, 30
+    algo = cfg.setup(camera=cam, device=dev)
+    # identical call sequence on the torch RNG in both runs: generic plugin
+    # hooks (per-frame draws, compacted batches), eager launches
+    algo.use_graphs = False
+    algo.fused_iteration = False
+    algo.batched_draws = False
+    model = algo.model
+    if render == 'oracle':
+        def views(dec):
+            out, off = {}, 0
+            for name, shape in dec.shapes:
+                n = int(np.prod(shape))
+                out[name] = dec.flat[off:off + n].view(shape)
+                off += n
+            return out
+
+        def get_outputs(inp):
+            stage = inp['stage']
+            sel = model.config.mapping_frustum_feature_selection
+            grids = {}
+            for k, g in model.grid_c.items():
+                m = model.grid_opti_mask.get(k) if sel else None
+                if g.requires_grad and m is not None:
+                    # the reference optimises val[mask] only
+                    m = m[None, None].to(g.dtype)
+                    g = g * m + g.detach() * (1 - m)
+                grids[k] = g
+            for g in model.grid_c.values():
+                if g.requires_grad:
+                    g._xrd_grad_fresh = True
+            decs = {k: views(d) for k, d in model.decoder.decoders().items()}
+            td = None if stage == 'coarse' else inp['target_d']
+            out = no.render_batch_ray(inp['rays_o'], inp['rays_d'], td, grids,
+                                      decs, model.bounding_box.to(dev), stage)
+            return {'rgb': out['rgb'], 'depth': out['depth'],
+                    'uncertainty': out['uncertainty']}
+        model.get_outputs = get_outputs
+    data = SyntheticRoom(BOUND, H=120, W=160, fx=80., fy=80., cx=79.5, cy=59.5,
+                         n_frames=200, shrink=0.3, device=dev)
+    cad = cadence['nice-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every, pose_device=dev)
+    for k in range(n_frames):
+        slam.step(k)
+    est = torch.stack([p[:3, 3].cpu() for p in algo.get_estimate_c2w_list()
+                       [:n_frames]])
+    return slam.ate_rmse(), est.numpy()
+
+
+def test_ate_engine_equals_reference_arithmetic_loop():
+    n = int(os.environ.get('XRD_ATE_FRAMES', '11'))
+    ate_e, tr_e = _run_sequence('engine', n)
+    ate_o, tr_o = _run_sequence('oracle', n)
+    gaps = np.abs(tr_e - tr_o).max(1)
+    gap = float(gaps.max())
+    line = (f'NICE-SLAM 160x120, {n} frames, random-init decoders: ATE engine '
+            f'{ate_e * 100:.2f} cm, ATE oracle loop {ate_o * 100:.2f} cm, '
+            f'max position gap between the two trajectories '
+            f'{gap * 100:.3f} cm; per frame (mm): ' +
+            ' '.join(f'{g * 1e3:.2f}' for g in gaps))
+    rep = os.environ.get('XRD_PARITY_REPORT')
+    if rep:
+        with open(rep, 'a') as f:
+            f.write(line + '\n')
+    print(line)
+    # The two loops see the same draws and differ by f32 rounding of the
+    # render (and the order of the gradient atomics).  Adam normalises every
+    # pose component to a step of ~lr whatever the gradient's size, so a
+    # component whose gradient is near zero flips its direction under rounding
+    # noise: the trajectories separate by millimetres within the first tracked
+    # frame and wander apart like two runs of the SAME path do (run-to-run
+    # spread of the engine's ATE on this sequence: +-0.3 cm).  What must
+    # agree is the error against ground truth.
+    # (measured, profiles/r02_ate_parity.txt: 11 frames 2.9 / 2.1 cm, 26
+    # frames 3.9 / 9.6 cm, 51 frames 14.2 / 17.0 cm engine / oracle loop — the
+    # drift is that of random-init decoders under the reference arithmetic,
+    # with a large run-to-run spread; the engine must not be worse than it)
+    assert ate_e <= 2.0 * ate_o + 0.01, line
+    assert gap < 4 * max(ate_e, ate_o, 5e-3), line
