@@ -412,12 +412,76 @@ def _setup_dist(dev, world):
         xdist.state.setup(dev, seed=0)
 
 
+VOX_FLOPS = 2 * (16 * 128 + 128 * 128 + 129 * 128 + 144 * 128 + 3 * 128)
+VOX_BYTES = 8 * 4 + 12 + 8 * 16 * 4   # 556 B per point forward
+
+
+def vox_cpu_baseline(threads, leaf_voxels=800):
+    """the host mirror of the reference's SparseVoxel on the CPU with the C
+    oracle standing in for the two CUDA operators (the configuration
+    tests/test_voxfusion_host.py pins against the reference-made golden): one
+    tracking-sized iteration (1024 rays, pose gradient only) and one
+    mapping-sized one (1024 rays, map + decoder gradients), forward+backward;
+    converted with the reference iteration counts (30 + 15 per frame, the
+    mapping window of the first frames: 1 frame)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import grid_standin
+    import xrdslam_amd.slam.model_components.voxel_helpers_voxfusion as vh
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.sparse_voxel import SparseVoxelConfig
+    torch.set_num_threads(threads)
+    real = vh._ext
+    vh._ext = grid_standin.module()
+    try:
+        torch.manual_seed(0)
+        model = SparseVoxelConfig().setup(camera=Camera(**CAM),
+                                          bounding_box=None)
+        g = torch.Generator().manual_seed(0)
+        # a wall of surface points 2 m in front of the camera at the 10 m
+        # offset Vox-Fusion works at
+        n_pts = 40000
+        pts = torch.stack([10 + (torch.rand(n_pts, generator=g) - 0.5) * 4,
+                           10 + (torch.rand(n_pts, generator=g) - 0.5) * 3,
+                           torch.full((n_pts, ), 8.0)], 1)
+        model.insert_points(pts, dedup=False)
+
+        def one(n, is_mapping):
+            for p in model.parameters():
+                p.grad = None
+            o = torch.tensor([10.0, 10.0, 10.0]).expand(n, 3).clone() \
+                .requires_grad_()
+            d = torch.stack([(torch.rand(n, generator=g) - 0.5) * 1.2,
+                             (torch.rand(n, generator=g) - 0.5) * 0.9,
+                             -torch.ones(n)], 1).requires_grad_()
+            inp = {'rays_o': o, 'rays_d': d,
+                   'target_d': torch.full((n, 1), 2.0),
+                   'target_s': torch.rand(n, 3, generator=g)}
+            t0 = time.perf_counter()
+            out = model.get_outputs(inp)
+            loss = sum(model.get_loss_dict(out, inp, is_mapping, 0).values())
+            loss.backward()
+            return time.perf_counter() - t0
+
+        one(64, True)
+        t_track, t_map = one(1024, False), one(1024, True)
+    finally:
+        vh._ext = real
+    per_frame = 30 * t_track + 15 * t_map
+    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': threads,
+            'kind': 'port',
+            'sample': ('1 tracking iter + 1 mapping iter (1024 rays each, '
+                       'sampled inside the hit voxels at 1 cm), fwd+bwd, host '
+                       'mirror of SparseVoxel + C oracle of the two CUDA '
+                       'operators; scaled by the reference iteration counts '
+                       f'(30 + 15 per frame); iter seconds track='
+                       f'{t_track:.3f} map={t_map:.3f}')}
+
+
 def run_voxfusion(args, dev, world=1):
     """Vox-Fusion frame loop (every frame tracked with 30 it x 1024 rays and
-    mapped with 15 it x 1024 rays x <=6 frames; relative poses + 10 m offset).
-    Functional end-to-end path on the HIP ray/voxel operators; the feature /
-    decoder / compositing chain is still torch ops (no fused kernel yet), so
-    no roofline object is reported for it."""
+    mapped with 15 it x 1024 rays x <=6 frames; relative poses + 10 m offset)
+    on the HIP ray/voxel operators and the fused voxel-feature + decoder
+    kernels; compositing and losses are torch ops."""
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.configs.input_config import (cadence,
@@ -441,7 +505,44 @@ def run_voxfusion(args, dev, world=1):
                           pose_device=str(dev),
                           use_relative_pose=cad.use_relative_pose,
                           init_pose_offset=cad.init_pose_offset)
+    from xrdslam_amd.engine import vox as evox
+    evox.PROFILE = {}
     elapsed = _timed_frames(slam, args, dev, world)
+    prof, evox.PROFILE = evox.PROFILE, None
+    roofline = None
+    if prof:
+        groups = {}
+        for (kern, P, need_w), evs in prof.items():
+            g_ = groups.setdefault((kern, need_w), [0.0, 0, 0])
+            g_[0] += sum(a.elapsed_time(b) for a, b in evs)
+            g_[1] += len(evs)
+            g_[2] += P * len(evs)
+        (kern, need_w), (ms, calls, pts) = max(groups.items(),
+                                               key=lambda kv: kv[1][0])
+        bwd = kern.endswith('bwd')
+        flops = pts * VOX_FLOPS * (2 if bwd else 1)
+        byts = pts * (VOX_BYTES + (1024 if bwd and need_w else 0))
+        roofline = {
+            'bound': 'mfma', 'achieved': flops / (ms * 1e-3) / 1e12,
+            'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+            'frac': flops / (ms * 1e-3) / MFMA_F32_PEAK, 'traffic': None,
+            'kernel': f'{kern}[decoder_grad={int(need_w)}] (launch: gather, '
+                      'trilinear feature, 16-128-128-129 / 144-128-3 decoder'
+                      + (', embedding scatter, dW operands' if bwd else '')
+                      + ')',
+            'avg_launch_us': ms / calls * 1e3, 'launches': calls,
+            'avg_points_per_launch': pts / calls,
+            'algorithmic_flops_per_point': VOX_FLOPS * (2 if bwd else 1),
+            'other_bound': {'bound': 'hbm', 'unit': 'GB/s',
+                            'achieved': byts / (ms * 1e-3) / 1e9,
+                            'frac': byts / (ms * 1e-3) / HBM_PEAK},
+            'share_of_frame_time': ms * 1e-3 / elapsed,
+            'note': 'the frame rate is bound by ~100 small torch launches '
+                    'per iteration around these kernels (hit sorting, '
+                    'sample compaction, compositing, losses), not by them'}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = vox_cpu_baseline(min(os.cpu_count() or 1, 16))
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -455,7 +556,7 @@ def run_voxfusion(args, dev, world=1):
             'map_ms_per_frame': slam.t_map / args.steps * 1e3,
             'ate_rmse_m': slam.ate_rmse(),
             'leaf_voxels': int(algo.model.svo.count_leaf_nodes())},
-        'roofline': None, 'cpu_baseline': None}
+        'roofline': roofline, 'cpu_baseline': cpu}
 
 
 class _CvPoses:

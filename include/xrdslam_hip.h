@@ -259,6 +259,47 @@ int xrd_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
                              xrd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Vox-Fusion fused "voxel features + decoder" — replaces, per sample point,
+ * get_features (F.embedding x2 + trilinear_interp,
+ * slam/model_components/voxel_helpers_voxfusion.py:97-123) and
+ * Decoder.get_values (slam/model_components/decoder_voxfusion.py:123-149; the
+ * model's defaults sparse_voxel.py:59-62: in_dim 16, width 128, depth 2, no
+ * positional encoding) and their autograd backward.
+ *   xyz [P,3] f32 sample positions, voxel_idx [P] i32 leaf-voxel ids (>= 0),
+ *   centres [Nv,3] f32, vertex_idx [Nv,8] i32, embeddings [E,16] f32
+ *   (map_states of sparse_voxel.py:342-357), packed = the decoder's
+ *   state_dict, flattened in key order and gathered through
+ *   xrd_vox_pack_index (xrd_vox_pack_len floats).
+ * fwd: sdf [P], rgb [P,3] (after the sigmoid); optional saves for the
+ *   backward and the weight-gradient GEMMs: save_x [P,16], save_h1/h2/f/hc
+ *   [P,128] (post-ReLU layer outputs, f = sdf feature), masks [P,3,4] u32.
+ * bwd: g_sdf [P], g_rgb [P,3] (NULL = zero) -> g_xyz [P,3] (NULL = not
+ *   wanted), g_embeddings [E,16] (ACCUMULATED with atomics; NULL = not
+ *   wanted) and the per-point gradient operands g_c3 [P,4] (d/d rgb logits,
+ *   slot 3 = g_sdf), g_hc/g_f/g_h2/g_h1 [P,128] (pre-activation gradients;
+ *   NULL = not wanted).  The five weight gradients are then plain GEMMs over
+ *   the points: dW = G^T A (engine/vox.py runs them in rocBLAS).
+ * ---------------------------------------------------------------------- */
+int xrd_vox_flat_len(void);
+int xrd_vox_pack_len(void);
+int xrd_vox_pack_index(int32_t* packed_from_flat);
+int xrd_vox_points_fwd(int64_t n_points, const float* xyz,
+                       const int32_t* voxel_idx, const float* centres,
+                       const int32_t* vertex_idx, const float* embeddings,
+                       float voxel_size, const float* packed, float* sdf,
+                       float* rgb, float* save_x, float* save_h1,
+                       float* save_h2, float* save_f, float* save_hc,
+                       uint32_t* masks, xrd_stream_t stream);
+int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
+                       const int32_t* voxel_idx, const float* centres,
+                       const int32_t* vertex_idx, const float* embeddings,
+                       float voxel_size, const float* packed, const float* rgb,
+                       const uint32_t* masks, const float* g_sdf,
+                       const float* g_rgb, float* g_xyz, float* g_embeddings,
+                       float* g_c3, float* g_hc, float* g_f, float* g_h2,
+                       float* g_h1, xrd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * SplaTAM Gaussian rasteriser — replaces the unvendored CUDA module
  * diff_gaussian_rasterization (-w-depth @ cb65e4b): GaussianRasterizer(
  * raster_settings)(means3D, means2D, opacities, colors_precomp, scales,

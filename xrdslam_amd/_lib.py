@@ -87,6 +87,13 @@ _SIGS = {
     'xrd_inverse_cdf_sampling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int,
                                            f32, vp, vp, vp, vp, vp, vp, vp,
                                            vp, vp, vp]),
+    'xrd_vox_flat_len': (C.c_int, []),
+    'xrd_vox_pack_len': (C.c_int, []),
+    'xrd_vox_pack_index': (C.c_int, [vp]),
+    'xrd_vox_points_fwd': (C.c_int, [i64, vp, vp, vp, vp, vp, f32] +
+                           [vp] * 10),
+    'xrd_vox_points_bwd': (C.c_int, [i64, vp, vp, vp, vp, vp, f32] +
+                           [vp] * 13),
     'xrd_gs_preprocess': (C.c_int, [vp, C.c_int] + [vp] * 11),
     'xrd_gs_duplicate_keys': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         vp]),

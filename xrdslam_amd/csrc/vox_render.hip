@@ -1,0 +1,489 @@
+// Vox-Fusion: fused "voxel features + decoder" for gfx950 (MI355X).
+//
+//   sample point (xyz, leaf voxel id)
+//     -> 8 vertex ids of the voxel -> 8 embedding rows [16] -> trilinear
+//        feature x                       (voxel_helpers_voxfusion.py:97-123)
+//     -> decoder 16 -> 128 -> 128 -> (sdf, f[128]); [f, x] -> 128 -> rgb
+//                                        (decoder_voxfusion.py:123-149)
+// as one kernel forward and one backward.  One wave = 16 points; every layer
+// is an in-register chain of v_mfma_f32_16x16x4_f32 (exact f32): rows = output
+// features (8 tiles of 16), columns = the 16 points, the accumulators of a
+// layer are the B operand of the next (nice_layout.h).  A block = 8 waves; it
+// stages one layer's fragments (<= 74 KB) in LDS at a time and loops over
+// groups of 128 points (persistent blocks), so a fragment is fetched from L2
+// once per 128 points and read with ds_read afterwards.
+//
+// The backward returns d loss / d xyz (pose gradient), scatters the embedding
+// gradient with atomics and writes the per-point operands of the decoder's
+// weight gradients ([P,128] matrices): those five contractions over P ~ 1e5
+// points are plain GEMMs and run in rocBLAS (engine/vox.py) — the 54 276
+// weight gradients would need 848 accumulator registers a lane to stay in the
+// kernel.
+//
+// Reference behaviour restated, never copied; parity: tests/test_vox_hip.py
+// (torch fp32 modules) and the reference-made golden of the whole model
+// (tests/test_voxfusion_hip.py).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "vox_layout.h"
+
+namespace xrd {
+namespace {
+
+constexpr int VW = 8;            // waves (16-point tiles) per block
+constexpr int kVoxBlocks = 256;  // persistent blocks: one per CU
+
+__device__ __forceinline__ void stage(float* __restrict__ wl,
+                                      const float* __restrict__ src, int n) {
+  __syncthreads();
+  for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(wl + i) =
+        *reinterpret_cast<const f32x4*>(src + i);
+  __syncthreads();
+}
+
+// acc[jt] += W[16jt.., kin(s)] * in[kin(s)] for K-steps s0 .. s0+KS-1 of a
+// layer whose fragments are laid out (jt * KTOT + s); in: D-layout registers
+template <int JT, int KTOT, int KS>
+__device__ __forceinline__ void dense(const float* __restrict__ w, int lane,
+                                      int s0, const f32x4* in, f32x4* acc) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float b = in[s >> 2][s & 3];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+      acc[jt] = XRD_MFMA4(w[(jt * KTOT + s0 + s) * 64 + lane], b, acc[jt]);
+  }
+}
+
+struct Corner {
+  int row[8];    // embedding row of corner c (-1: no voxel)
+  float w[8];    // trilinear weights
+  float p[3];    // local coordinate
+};
+
+// voxel_helpers_voxfusion.py:97-107: p = (xyz - centre)/voxel_size + 0.5,
+// corner c = 4 ix + 2 iy + iz selects q_a in {0,1}, weight = prod over axes of
+// (p q + (1-p)(1-q)), evaluated in the reference's order ((x * y) * z)
+__device__ __forceinline__ void corners(const float* __restrict__ xyz,
+                                        const int* __restrict__ vox,
+                                        const float* __restrict__ centres,
+                                        const int* __restrict__ vertex_idx,
+                                        float voxel_size, int64_t pt,
+                                        bool valid, Corner& C) {
+  int v = valid ? vox[pt] : -1;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    C.row[c] = -1;
+    C.w[c] = 0.f;
+  }
+  C.p[0] = C.p[1] = C.p[2] = 0.f;
+  if (v < 0) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    C.p[a] = (xyz[pt * 3 + a] - centres[(int64_t)v * 3 + a]) / voxel_size +
+             0.5f;
+  const int4 lo = *reinterpret_cast<const int4*>(vertex_idx + (int64_t)v * 8);
+  const int4 hi =
+      *reinterpret_cast<const int4*>(vertex_idx + (int64_t)v * 8 + 4);
+  const int ids[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float wx = (c & 4) ? C.p[0] : 1.f - C.p[0];
+    const float wy = (c & 2) ? C.p[1] : 1.f - C.p[1];
+    const float wz = (c & 1) ? C.p[2] : 1.f - C.p[2];
+    C.row[c] = ids[c];
+    C.w[c] = (wx * wy) * wz;
+  }
+}
+
+__device__ __forceinline__ f32x4 relu4(const f32x4 a, uint32_t& bits,
+                                       int shift) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool on = a[k] > 0.f;
+    r[k] = on ? a[k] : 0.f;
+    if (on) bits |= 1u << (shift + k);
+  }
+  return r;
+}
+
+// store a D-layout activation (features 16jt+4q+r of point li) to [P][128]
+__device__ __forceinline__ void save128(float* __restrict__ dst, int64_t pt,
+                                        int q, const f32x4* v) {
+#pragma unroll
+  for (int jt = 0; jt < 8; ++jt)
+    *reinterpret_cast<f32x4*>(dst + pt * 128 + 16 * jt + 4 * q) = v[jt];
+}
+
+__global__ __launch_bounds__(VW * 64, 2) void vox_points_fwd_kernel(
+    int64_t P, const float* __restrict__ xyz, const int* __restrict__ vox,
+    const float* __restrict__ centres, const int* __restrict__ vertex_idx,
+    const float* __restrict__ emb, float voxel_size,
+    const float* __restrict__ pk, float* __restrict__ sdf,
+    float* __restrict__ rgb, float* __restrict__ sx, float* __restrict__ sh1,
+    float* __restrict__ sh2, float* __restrict__ sf, float* __restrict__ shc,
+    uint32_t* __restrict__ masks) {
+  using K = VoxPack;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  const int64_t ntiles = (P + 15) / 16;
+  const int64_t ngroups = (ntiles + VW - 1) / VW;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t pt = (grp * VW + wave) * 16 + li;
+    const bool valid = pt < P;
+    // ---- trilinear voxel feature: lane (q, li) gathers features 4q..4q+3 --
+    Corner C;
+    corners(xyz, vox, centres, vertex_idx, voxel_size, pt, valid, C);
+    f32x4 x[1] = {z4};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (C.row[c] >= 0)
+        x[0] += *reinterpret_cast<const f32x4*>(emb + (int64_t)C.row[c] * 16 +
+                                                4 * q) * C.w[c];
+    if (valid && sx)
+      *reinterpret_cast<f32x4*>(sx + pt * 16 + 4 * q) = x[0];
+    f32x4 h[8], a[8];
+    uint32_t m1 = 0, m2 = 0, mc = 0;
+    // ---- layer 0 -------------------------------------------------------------
+    stage(wl, pk + K::F0, K::F0_LEN);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+      a[jt] = *reinterpret_cast<const f32x4*>(wl + (K::B0 - K::F0) + 16 * jt +
+                                              4 * q);
+    dense<8, 4, 4>(wl + (K::W0 - K::F0), lane, 0, x, a);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) h[jt] = relu4(a[jt], m1, 4 * jt);
+    if (valid && sh1) save128(sh1, pt, q, h);
+    // ---- layer 1 -------------------------------------------------------------
+    stage(wl, pk + K::F1, K::F1_LEN);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+      a[jt] = *reinterpret_cast<const f32x4*>(wl + (K::B1 - K::F1) + 16 * jt +
+                                              4 * q);
+    dense<8, 32, 32>(wl + (K::W1 - K::F1), lane, 0, h, a);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) h[jt] = relu4(a[jt], m2, 4 * jt);
+    if (valid && sh2) save128(sh2, pt, q, h);
+    // ---- sdf_out: sdf (row 0, on the VALU) and the sdf feature f -----------
+    stage(wl, pk + K::FS, K::FS_LEN);
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 8; ++jt) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(
+            wl + (K::WS0 - K::FS) + 16 * jt + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = fmaf(w0[r], h[jt][r], s);
+        a[jt] = *reinterpret_cast<const f32x4*>(wl + (K::BS - K::FS) +
+                                                16 * jt + 4 * q);
+      }
+      s = group4_sum(s) + wl[K::BS0 - K::FS];
+      if (valid && q == 0) sdf[pt] = s;
+    }
+    dense<8, 32, 32>(wl + (K::WS - K::FS), lane, 0, h, a);
+    if (valid && sf) save128(sf, pt, q, a);  // f = a (no activation)
+    // ---- colour head ---------------------------------------------------------
+    stage(wl, pk + K::FC, K::FC_LEN);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+      h[jt] = *reinterpret_cast<const f32x4*>(wl + (K::BC - K::FC) + 16 * jt +
+                                              4 * q);
+    dense<8, 36, 32>(wl + (K::WC - K::FC), lane, 0, a, h);
+    dense<8, 36, 4>(wl + (K::WC - K::FC), lane, 32, x, h);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) h[jt] = relu4(h[jt], mc, 4 * jt);
+    if (valid && shc) save128(shc, pt, q, h);
+    float col[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float s = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 8; ++jt) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(
+            wl + (K::WO - K::FC) + o * 128 + 16 * jt + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = fmaf(w[r], h[jt][r], s);
+      }
+      s = group4_sum(s) + wl[(K::BO - K::FC) + o];
+      col[o] = 1.f / (1.f + expf(-s));
+    }
+    if (valid) {
+      if (q == 0) {
+        rgb[pt * 3 + 0] = col[0];
+        rgb[pt * 3 + 1] = col[1];
+        rgb[pt * 3 + 2] = col[2];
+      }
+      if (masks) {  // [P][3][4]: ReLU bits of the lane's 32 features
+        masks[(pt * 3 + 0) * 4 + q] = m1;
+        masks[(pt * 3 + 1) * 4 + q] = m2;
+        masks[(pt * 3 + 2) * 4 + q] = mc;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 mask4(const f32x4 g, uint32_t bits,
+                                       int shift) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = ((bits >> (shift + k)) & 1u) ? g[k] : 0.f;
+  return r;
+}
+
+__global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
+    int64_t P, const float* __restrict__ xyz, const int* __restrict__ vox,
+    const float* __restrict__ centres, const int* __restrict__ vertex_idx,
+    const float* __restrict__ emb, float voxel_size,
+    const float* __restrict__ pk, const float* __restrict__ rgb,
+    const uint32_t* __restrict__ masks, const float* __restrict__ g_sdf,
+    const float* __restrict__ g_rgb, float* __restrict__ g_xyz,
+    float* __restrict__ g_emb, float* __restrict__ gc3,
+    float* __restrict__ ghc, float* __restrict__ gf, float* __restrict__ gh2,
+    float* __restrict__ gh1) {
+  using K = VoxPack;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  const int64_t ntiles = (P + 15) / 16;
+  const int64_t ngroups = (ntiles + VW - 1) / VW;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t pt = (grp * VW + wave) * 16 + li;
+    const bool valid = pt < P;
+    uint32_t m1 = 0, m2 = 0, mc = 0;
+    float gs = 0.f, g3[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+      m1 = masks[(pt * 3 + 0) * 4 + q];
+      m2 = masks[(pt * 3 + 1) * 4 + q];
+      mc = masks[(pt * 3 + 2) * 4 + q];
+      gs = g_sdf ? g_sdf[pt] : 0.f;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        const float c = rgb[pt * 3 + o];
+        g3[o] = g_rgb ? g_rgb[pt * 3 + o] * (c * (1.f - c)) : 0.f;
+      }
+      if (gc3 && q == 0) {
+        gc3[pt * 4 + 0] = g3[0];
+        gc3[pt * 4 + 1] = g3[1];
+        gc3[pt * 4 + 2] = g3[2];
+        gc3[pt * 4 + 3] = gs;
+      }
+    }
+    f32x4 g[8], a[9];
+    // ---- colour head: ghc = mask(WO^T g3); [gf, gx] = WC^T ghc ----------------
+    stage(wl, pk + K::RC, K::RC_LEN);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+      f32x4 t = z4;
+#pragma unroll
+      for (int o = 0; o < 3; ++o)
+        t += *reinterpret_cast<const f32x4*>(wl + (K::WOB - K::RC) + o * 128 +
+                                             16 * jt + 4 * q) * g3[o];
+      g[jt] = mask4(t, mc, 4 * jt);
+    }
+    if (valid && ghc) save128(ghc, pt, q, g);
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) a[kt] = z4;
+    dense<9, 32, 32>(wl + (K::WCT - K::RC), lane, 0, g, a);
+    const f32x4 gx_c = a[8];  // colour head's share of d loss / d x
+    if (valid && gf) save128(gf, pt, q, a);
+    // ---- sdf_out: gh2 = mask(WS[1:]^T gf + WS[0] g_sdf) ------------------------
+    stage(wl, pk + K::RS, K::RS_LEN);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+      g[jt] = *reinterpret_cast<const f32x4*>(wl + (K::WS0B - K::RS) +
+                                              16 * jt + 4 * q) * gs;
+    dense<8, 32, 32>(wl + (K::WST - K::RS), lane, 0, a, g);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) g[jt] = mask4(g[jt], m2, 4 * jt);
+    if (valid && gh2) save128(gh2, pt, q, g);
+    // ---- layer 1: gh1 = mask(W1^T gh2) ----------------------------------------
+    stage(wl, pk + K::R1, K::R1_LEN);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) a[kt] = z4;
+    dense<8, 32, 32>(wl + (K::W1T - K::R1), lane, 0, g, a);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) a[jt] = mask4(a[jt], m1, 4 * jt);
+    if (valid && gh1) save128(gh1, pt, q, a);
+    // ---- layer 0: gx = W0^T gh1 (+ the colour head's share) --------------------
+    stage(wl, pk + K::R0, K::R0_LEN);
+    f32x4 gx[1] = {gx_c};
+    dense<1, 32, 32>(wl + (K::W0T - K::R0), lane, 0, a, gx);
+    // ---- trilinear backward -------------------------------------------------------
+    Corner C;
+    corners(xyz, vox, centres, vertex_idx, voxel_size, pt, valid, C);
+    float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (C.row[c] < 0) continue;
+      const int64_t base = (int64_t)C.row[c] * 16 + 4 * q;
+      if (g_emb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = C.w[c] * gx[0][r];
+          if (v != 0.f) atomicAdd(g_emb + base + r, v);
+        }
+      }
+      if (g_xyz) {
+        const f32x4 e = *reinterpret_cast<const f32x4*>(emb + base);
+        const float dot = e[0] * gx[0][0] + e[1] * gx[0][1] +
+                          e[2] * gx[0][2] + e[3] * gx[0][3];
+        const float wx = (c & 4) ? C.p[0] : 1.f - C.p[0];
+        const float wy = (c & 2) ? C.p[1] : 1.f - C.p[1];
+        const float wz = (c & 1) ? C.p[2] : 1.f - C.p[2];
+        gp[0] += ((c & 4) ? dot : -dot) * wy * wz;
+        gp[1] += ((c & 2) ? dot : -dot) * wx * wz;
+        gp[2] += ((c & 1) ? dot : -dot) * wx * wy;
+      }
+    }
+    if (g_xyz) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float s = group4_sum(gp[ax]) / voxel_size;
+        if (valid && q == 0) g_xyz[pt * 3 + ax] = s;
+      }
+    }
+  }
+}
+
+// host: packed <- flat index table
+void build_vox_index(int32_t* idx) {
+  using F = VoxFlat;
+  using K = VoxPack;
+  for (int i = 0; i < K::LEN; ++i) idx[i] = -1;
+  for (int jt = 0; jt < 8; ++jt)
+    for (int l = 0; l < 64; ++l) {
+      const int m = l & 15, q = l >> 4, row = 16 * jt + m;
+      for (int s = 0; s < 4; ++s)
+        idx[K::W0 + (jt * 4 + s) * 64 + l] = F::W0 + row * 16 + kmap(s, q);
+      for (int s = 0; s < 32; ++s) {
+        idx[K::W1 + (jt * 32 + s) * 64 + l] = F::W1 + row * 128 + kmap(s, q);
+        idx[K::WS + (jt * 32 + s) * 64 + l] =
+            F::WS + (1 + row) * 128 + kmap(s, q);
+        // transposed: rows = input feature 16kt + m, K-slot = output kmap(s,q)
+        idx[K::WST + (jt * 32 + s) * 64 + l] =
+            F::WS + (1 + kmap(s, q)) * 128 + row;
+        idx[K::W1T + (jt * 32 + s) * 64 + l] = F::W1 + kmap(s, q) * 128 + row;
+      }
+      for (int s = 0; s < 36; ++s)
+        idx[K::WC + (jt * 36 + s) * 64 + l] =
+            F::WC + row * 144 + vox_color_in(s, q);
+    }
+  for (int kt = 0; kt < 9; ++kt)
+    for (int s = 0; s < 32; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int m = l & 15, q = l >> 4;
+        // colour layer input 16kt + m (kt = 8: the 16 voxel features)
+        idx[K::WCT + (kt * 32 + s) * 64 + l] =
+            F::WC + kmap(s, q) * 144 + 16 * kt + m;
+      }
+  for (int s = 0; s < 32; ++s)
+    for (int l = 0; l < 64; ++l)
+      idx[K::W0T + s * 64 + l] = F::W0 + kmap(s, l >> 4) * 16 + (l & 15);
+  for (int j = 0; j < 128; ++j) {
+    idx[K::B0 + j] = F::B0 + j;
+    idx[K::B1 + j] = F::B1 + j;
+    idx[K::BS + j] = F::BS + 1 + j;
+    idx[K::WS0 + j] = F::WS + j;
+    idx[K::WS0B + j] = F::WS + j;
+    idx[K::BC + j] = F::BC + j;
+  }
+  idx[K::BS0] = F::BS;
+  for (int o = 0; o < 3; ++o) {
+    for (int j = 0; j < 128; ++j) {
+      idx[K::WO + o * 128 + j] = F::WO + o * 128 + j;
+      idx[K::WOB + o * 128 + j] = F::WO + o * 128 + j;
+    }
+    idx[K::BO + o] = F::BO + o;
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
+using namespace xrd;
+
+extern "C" {
+
+int xrd_vox_flat_len(void) { return VoxFlat::LEN; }
+int xrd_vox_pack_len(void) { return VoxPack::LEN; }
+
+int xrd_vox_pack_index(int32_t* idx) {
+  if (idx == nullptr) return XRD_ERR_ARG;
+  build_vox_index(idx);
+  return XRD_OK;
+}
+
+static int vox_setup(const void* kern) {
+  const int lds = VoxPack::STAGE_MAX * (int)sizeof(float);
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          lds) != hipSuccess)
+    return check_launch("hipFuncSetAttribute");
+  return XRD_OK;
+}
+
+int xrd_vox_points_fwd(int64_t n_points, const float* xyz,
+                       const int32_t* voxel_idx, const float* centres,
+                       const int32_t* vertex_idx, const float* embeddings,
+                       float voxel_size, const float* packed, float* sdf,
+                       float* rgb, float* save_x, float* save_h1,
+                       float* save_h2, float* save_f, float* save_hc,
+                       uint32_t* masks, xrd_stream_t stream) {
+  if (n_points < 0 || voxel_size <= 0.f) return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  if (!xyz || !voxel_idx || !centres || !vertex_idx || !embeddings ||
+      !packed || !sdf || !rgb)
+    return XRD_ERR_ARG;
+  static bool ready = false;
+  if (!ready) {
+    int rc = vox_setup(reinterpret_cast<const void*>(vox_points_fwd_kernel));
+    if (rc != XRD_OK) return rc;
+    ready = true;
+  }
+  const int64_t groups = ((n_points + 15) / 16 + VW - 1) / VW;
+  const int nb = (int)(groups < kVoxBlocks ? groups : kVoxBlocks);
+  hipLaunchKernelGGL(vox_points_fwd_kernel, dim3(nb), dim3(VW * 64),
+                     VoxPack::STAGE_MAX * sizeof(float), (hipStream_t)stream,
+                     n_points, xyz, voxel_idx, centres, vertex_idx, embeddings,
+                     voxel_size, packed, sdf, rgb, save_x, save_h1, save_h2,
+                     save_f, save_hc, masks);
+  return check_launch("xrd_vox_points_fwd");
+}
+
+int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
+                       const int32_t* voxel_idx, const float* centres,
+                       const int32_t* vertex_idx, const float* embeddings,
+                       float voxel_size, const float* packed, const float* rgb,
+                       const uint32_t* masks, const float* g_sdf,
+                       const float* g_rgb, float* g_xyz, float* g_embeddings,
+                       float* g_c3, float* g_hc, float* g_f, float* g_h2,
+                       float* g_h1, xrd_stream_t stream) {
+  if (n_points < 0 || voxel_size <= 0.f) return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  if (!xyz || !voxel_idx || !centres || !vertex_idx || !embeddings ||
+      !packed || !rgb || !masks)
+    return XRD_ERR_ARG;
+  static bool ready = false;
+  if (!ready) {
+    int rc = vox_setup(reinterpret_cast<const void*>(vox_points_bwd_kernel));
+    if (rc != XRD_OK) return rc;
+    ready = true;
+  }
+  const int64_t groups = ((n_points + 15) / 16 + VW - 1) / VW;
+  const int nb = (int)(groups < kVoxBlocks ? groups : kVoxBlocks);
+  hipLaunchKernelGGL(vox_points_bwd_kernel, dim3(nb), dim3(VW * 64),
+                     VoxPack::STAGE_MAX * sizeof(float), (hipStream_t)stream,
+                     n_points, xyz, voxel_idx, centres, vertex_idx, embeddings,
+                     voxel_size, packed, rgb, masks, g_sdf, g_rgb, g_xyz,
+                     g_embeddings, g_c3, g_hc, g_f, g_h2, g_h1);
+  return check_launch("xrd_vox_points_bwd");
+}
+
+}  // extern "C"

@@ -5,10 +5,11 @@ octree, sampled inside the hit voxels, decoded by a small MLP and composited
 with SDF bell weights.
 
 Native operators: the octree (``compat.svo.Octree``, host C++, node ids
-bit-exact with the reference's pybind class) and the two ray/voxel kernels
-(``compat.grid``, HIP).  The rest — feature gather, decoder, compositing,
-losses — is torch on the device for now (fusion of this chain is a next row,
-DESIGN.md §1)."""
+bit-exact with the reference's pybind class), the two ray/voxel kernels
+(``compat.grid``, HIP) and the fused voxel-feature + decoder kernels
+(``engine/vox.py``: vertex gather, trilinear feature, the 16-128-128-129 /
+144-128-3 decoder and their backward as one launch each way).  Compositing
+and losses are torch ops on the padded [rays, samples] arrays."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -200,8 +201,16 @@ class SparseVoxel(Model):
         outs = []
         for i in range(0, n_pts, step):
             chunk = {k: v[i:i + step] for k, v in valid.items()}
-            outs.append(self.decoder(vh.get_features(chunk, ms,
-                                                     cfg.voxel_size)))
+            fused = None
+            if getattr(self, 'use_fused', True):
+                # voxel features + decoder in one kernel each way
+                # (engine/vox.py: xrd_vox_points_fwd / _bwd)
+                from ...engine import vox as _vox
+                fused = _vox.points(self.decoder, chunk['sampled_point_xyz'],
+                                    chunk['sampled_point_voxel_idx'], ms,
+                                    cfg.voxel_size)
+            outs.append(fused if fused is not None else self.decoder(
+                vh.get_features(chunk, ms, cfg.voxel_size)))
         field_out = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         # padded samples read sdf = 1 (free space) and colour 0
         sdf = vh.masked_scatter_ones(sample_mask, field_out['sdf']).squeeze(-1)
