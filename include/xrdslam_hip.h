@@ -279,6 +279,11 @@ int xrd_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
  *   slot 3 = g_sdf), g_hc/g_f/g_h2/g_h1 [P,128] (pre-activation gradients;
  *   NULL = not wanted).  The five weight gradients are then plain GEMMs over
  *   the points: dW = G^T A (engine/vox.py runs them in rocBLAS).
+ * n_points_dev (NULL = unused): static-capacity launches (captured graphs) —
+ *   n_points is the CAPACITY of the arrays and the live count is read from
+ *   this device int (clamped to [0, n_points]); the backward zeroes the rows
+ *   [count, n_points) of g_c3 / g_hc / g_f / g_h2 / g_h1 so that the GEMMs may
+ *   run over the whole capacity.
  * ---------------------------------------------------------------------- */
 int xrd_vox_flat_len(void);
 int xrd_vox_pack_len(void);
@@ -289,7 +294,8 @@ int xrd_vox_points_fwd(int64_t n_points, const float* xyz,
                        float voxel_size, const float* packed, float* sdf,
                        float* rgb, float* save_x, float* save_h1,
                        float* save_h2, float* save_f, float* save_hc,
-                       uint32_t* masks, xrd_stream_t stream);
+                       uint32_t* masks, const int32_t* n_points_dev,
+                       xrd_stream_t stream);
 int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
                        const int32_t* voxel_idx, const float* centres,
                        const int32_t* vertex_idx, const float* embeddings,
@@ -297,7 +303,78 @@ int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
                        const uint32_t* masks, const float* g_sdf,
                        const float* g_rgb, float* g_xyz, float* g_embeddings,
                        float* g_c3, float* g_hc, float* g_f, float* g_h2,
-                       float* g_h1, xrd_stream_t stream);
+                       float* g_h1, const int32_t* n_points_dev,
+                       xrd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Vox-Fusion ray pipeline with STATIC capacities (csrc/vox_rays.hip) — what
+ * SparseVoxel.render_rays / get_loss_dict do around the decoder
+ * (slam/models/sparse_voxel.py:103-143,160-304) and ray_intersect /
+ * ray_sample do around the two `grid` kernels
+ * (slam/model_components/voxel_helpers_voxfusion.py:399-481,647-714), without
+ * a host sync: the data-dependent sizes the reference trims its tensors to
+ * (largest hit count, hit rays, sampler row length, longest sample row, valid
+ * samples, the loss's sample counts) are kept in meta [xrd_vox_meta_len()]
+ * i32 on the device.  meta[5] = overflow bits (1: a sample row needed more
+ * than s_cap slots, 2: more than p_cap points, 4: a sample row with a hole),
+ * meta[10] = traversal stack overflow; a caller checks them once per frame.
+ *
+ * xrd_vox_sample_rays: rays [n_rays,3] (+ target_d [n_rays]) -> hits (octree
+ *   traversal when centres != NULL, n_max <= 64 hits a ray; else hit_idx /
+ *   hit_min / hit_max [n_rays,n_max] are inputs), sorted by entry depth and cut
+ *   at max_distance IN PLACE; probs [n_rays,n_max], steps [n_rays], hit
+ *   [n_rays] (0/1), rank / hit_rays [n_rays] (hit-ray compaction both ways);
+ *   samples s_idx / s_depth [n_rays,s_cap] (-1 / 10.0 padded), cnt [n_rays],
+ *   offs [n_rays+1] (exclusive scan); points xyz [p_cap,3], vox [p_cap] in
+ *   ray-major order.  noise [n_rays,s_cap] uniform draws (NULL = 0.5, the
+ *   deterministic mode), clamped to [0.001, 0.999] like the reference.  Sample
+ *   ids and depths are those of xrd_inverse_cdf_sampling on the reference's
+ *   [200, R, P] regrouping of the hit rays.  loss_acc [4] f64 is zeroed.
+ * xrd_vox_render_fwd: per-point sdf_pt [p_cap] / rgb_pt [p_cap,3] -> depth
+ *   [n_rays], rgb [n_rays,3] (0 for rays without a hit), optional z_min
+ *   [n_rays] and weights [n_rays,s_cap]; with loss_acc != NULL also the four
+ *   loss terms: loss [5] = rgb, depth, sdf, fs (weighted) and their sum,
+ *   scale [4] = the normalisers the backward needs.
+ * xrd_vox_render_bwd: d loss[4] / d sdf_pt, d rgb_pt (g_sdf [p_cap], g_rgb
+ *   [p_cap,3]; rows >= the point count are not written), times *g_loss (device
+ *   float, NULL = 1).
+ * xrd_vox_ray_grads: g_xyz [p_cap,3] -> g_rays_o, g_rays_d [n_rays,3].
+ * ---------------------------------------------------------------------- */
+int xrd_vox_meta_len(void);
+int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
+                        int n_nodes, const float* centres,
+                        const int32_t* children, float voxel_size,
+                        float max_distance, float step_size, float trunc,
+                        float max_depth, const float* rays_o,
+                        const float* rays_d, const float* target_d,
+                        const float* noise, int32_t* hit_idx, float* hit_min,
+                        float* hit_max, float* probs, float* steps,
+                        int32_t* hit, int32_t* rank, int32_t* hit_rays,
+                        int32_t* s_idx, float* s_depth, int32_t* cnt,
+                        int32_t* offs, float* xyz, int32_t* vox, int32_t* meta,
+                        double* loss_acc, xrd_stream_t stream);
+int xrd_vox_render_fwd(int n_rays, int s_cap, int64_t p_cap, float trunc,
+                       float max_depth, const int32_t* hit,
+                       const int32_t* cnt, const int32_t* offs,
+                       const float* s_depth, const float* sdf_pt,
+                       const float* rgb_pt, const float* target_d,
+                       const float* target_rgb, const int32_t* meta,
+                       float* depth, float* rgb, float* z_min, float* weights,
+                       double* loss_acc, float w_rgb, float w_depth,
+                       float w_sdf, float w_fs, float* loss, float* scale,
+                       xrd_stream_t stream);
+int xrd_vox_render_bwd(int n_rays, int s_cap, int64_t p_cap, float trunc,
+                       float max_depth, const int32_t* hit,
+                       const int32_t* cnt, const int32_t* offs,
+                       const float* s_depth, const float* sdf_pt,
+                       const float* rgb_pt, const float* target_d,
+                       const float* target_rgb, const int32_t* meta,
+                       const float* scale, const float* g_loss, float* g_sdf,
+                       float* g_rgb, xrd_stream_t stream);
+int xrd_vox_ray_grads(int n_rays, int s_cap, int64_t p_cap, const int32_t* hit,
+                      const int32_t* cnt, const int32_t* offs,
+                      const float* s_depth, const float* g_xyz,
+                      float* g_rays_o, float* g_rays_d, xrd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * SplaTAM Gaussian rasteriser — replaces the unvendored CUDA module

@@ -1,0 +1,243 @@
+"""GPU parity of the fused Vox-Fusion ray pipeline (csrc/vox_rays.hip through
+engine/vox.py: octree traversal -> hit sort -> inverse-CDF sampling -> point
+compaction -> voxel features + decoder -> compositing + losses, and the
+backward of all of it, with static capacities and no host sync):
+
+(1) against the golden made from the REFERENCE's own SparseVoxel
+    (tests/golden/voxfusion_render.npz, oracle/make_golden_voxfusion.py): sample
+    depths, rendered depth/colour, the four loss terms and every gradient;
+(2) against the modular path (get_outputs + get_loss_dict on compat.grid, itself
+    pinned to the same golden) on a synthetic room view with 2048 rays and a
+    ragged, multi-chunk sample distribution;
+(3) capacity handling: a batch that does not fit is reported and the
+    capacities grow; (4) the VoxFusion loop through captured graphs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+import parity  # noqa: E402
+import voxfusion_golden_util as vg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _noise_by_ray(noise_rows, hit, s_cap):
+    """reference-layout noise (one row per HIT ray, in rank order) -> one row
+    per ray of the batch"""
+    n = hit.shape[0]
+    out = torch.full((n, s_cap), 0.5, device=hit.device)
+    rows = noise_rows[:int(hit.sum())]
+    w = min(rows.shape[1], s_cap)
+    out[hit.bool(), :w] = rows[:, :w].to(hit.device)
+    return out
+
+
+def test_fused_iteration_vs_reference_golden():
+    from xrdslam_amd.engine import vox as ev
+    g = np.load(vg.GOLDEN)
+    model = vg.build_model(g, DEV)
+    model.insert_points(torch.from_numpy(g['points']).to(DEV))
+    noise = torch.from_numpy(g['noise'])           # [G, R, max_steps]
+    hit = torch.from_numpy(g['out/ray_mask']).to(DEV)
+    rows = noise.reshape(-1, noise.shape[-1])
+    model.noise_fn = lambda shape, like: _noise_by_ray(rows, hit, shape[1])
+    ro = torch.from_numpy(g['rays_o']).to(DEV).requires_grad_(True)
+    rd = torch.from_numpy(g['rays_d']).to(DEV).requires_grad_(True)
+    inp = {'rays_o': ro, 'rays_d': rd,
+           'target_s': torch.from_numpy(g['target_s']).to(DEV),
+           'target_d': torch.from_numpy(g['target_d']).to(DEV)}
+    loss, terms = model.fused_loss(inp, True)
+    loss.backward()
+    ws = model._last_ws
+    sizes = model.check_capacity()
+    assert not sizes['grown'], sizes
+    # structure: hit rays, row length, sample depths
+    assert torch.equal(ws.hit.bool(), hit)
+    zg = g['out/z_vals']
+    assert sizes['s_max'] == zg.shape[1], (sizes, zg.shape)
+    z = ws.s_depth[hit][:, :zg.shape[1]].cpu().numpy()
+    assert np.abs(z - zg).max() < 1e-5
+    names = ['rgb_loss', 'depth_loss', 'sdf_loss', 'fs_loss']
+    pairs = [(f'loss/{k}', terms[i], torch.from_numpy(g[f'loss/{k}']))
+             for i, k in enumerate(names)]
+    pairs += [('depth', ws.depth, torch.from_numpy(g['out/depth'])),
+              ('rgb', ws.rgb, torch.from_numpy(g['out/rgb'])),
+              ('g_rays_o', ro.grad, torch.from_numpy(g['g_rays_o'])),
+              ('g_rays_d', rd.grad, torch.from_numpy(g['g_rays_d'])),
+              ('g_embeddings', model.embeddings.grad,
+               torch.from_numpy(g['g_embeddings']))]
+    for k, p in model.decoder.named_parameters():
+        pairs.append((f'g_dec/{k}', p.grad, torch.from_numpy(g[f'g_dec/{k}'])))
+    for name, a, b in pairs:
+        err = vg.rel_err(a.detach().cpu().numpy().reshape(-1),
+                         np.asarray(b).reshape(-1))
+        assert err < 1e-4, (name, err)
+    # inference entry: same depth / colour, plus the padded weights and z_min
+    zmin = torch.zeros(ws.n, device=DEV)
+    wts = torch.zeros(ws.n, ws.s_cap, device=DEV)
+    with torch.no_grad():
+        d2, c2 = ev.render(model.decoder, ws, model.map_states, model.config,
+                           ro.detach(), rd.detach(), model.draw_noise(ws),
+                           z_min=zmin, weights=wts)
+    assert vg.rel_err(d2.cpu().numpy(), g['out/depth']) < 1e-4
+    assert vg.rel_err(c2.cpu().numpy(), g['out/rgb']) < 1e-4
+    assert vg.rel_err(wts[hit][:, :zg.shape[1]].cpu().numpy(),
+                      g['out/weights']) < 1e-4
+    assert vg.rel_err(zmin[hit].cpu().numpy(),
+                      g['out/z_min'].reshape(-1)) < 1e-5
+
+
+def _room_model(n_rays, seed=0):
+    """a SparseVoxel that has seen one synthetic 160x120 room view"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import voxfusion_config
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    cam = Camera(fx=150., fy=150., cx=79.5, cy=59.5, width=160, height=120)
+    algo = voxfusion_config().setup(camera=cam, device=DEV)
+    data = SyntheticRoom([[-3, 3], [-4, 2.5], [-2, 2.5]], H=120, W=160,
+                         fx=150., fy=150., cx=79.5, cy=59.5, n_frames=40,
+                         device=DEV)
+    from xrdslam_amd.slam.common.frame import Frame
+    fr = data[3]
+    pose = np.array(fr['c2w'], dtype=np.float32).copy()
+    pose[:3, 3] += 10.0   # init_pose_offset: keeps voxel coordinates positive
+    depth = fr['depth'].cpu().numpy() if torch.is_tensor(fr['depth']) \
+        else np.asarray(fr['depth'])
+    rgb = fr['rgb'].cpu().numpy() if torch.is_tensor(fr['rgb']) \
+        else np.asarray(fr['rgb'])
+    f = Frame(0, rgb, depth, init_pose=pose, device=DEV)
+    algo.create_voxels(f)
+    algo.config.mapping_sample = n_rays
+    with torch.no_grad():
+        inp = algo.get_model_input([f], True)
+    # train the map a little so that the sdf has sign changes to composite
+    return algo, f, {k: (v.detach() if torch.is_tensor(v) else v)
+                     for k, v in inp.items()}
+
+
+def test_fused_iteration_vs_modular_path_room():
+    algo, f, inp = _room_model(2048)
+    model = algo.model
+    with torch.no_grad():
+        model.embeddings.mul_(30.0)   # sdf values of both signs
+    n = inp['rays_o'].shape[0]
+    base = torch.rand(n, 1024, generator=torch.Generator().manual_seed(5))
+    base = base.to(DEV)
+
+    def run_fused():
+        model.zero_grad(set_to_none=True)
+        ro = inp['rays_o'].clone().requires_grad_(True)
+        rd = inp['rays_d'].clone().requires_grad_(True)
+        model.noise_fn = lambda shape, like: base[:, :shape[1]].contiguous()
+        loss, terms = model.fused_loss({**inp, 'rays_o': ro, 'rays_d': rd},
+                                       True)
+        loss.backward()
+        res = {'loss': loss.detach().clone(), 'terms': terms[:4].clone(),
+               'g_o': ro.grad.clone(), 'g_d': rd.grad.clone(),
+               'g_emb': model.embeddings.grad.clone()}
+        for k, p in model.decoder.named_parameters():
+            res['g_' + k] = p.grad.clone()
+        return res
+
+    got = run_fused()
+    ws = model._last_ws
+    sizes = model.check_capacity()
+    assert not sizes['grown'], sizes
+    hit = ws.hit.bool().clone()
+    cnt = ws.cnt.clone()
+    depth, rgb = ws.depth.clone(), ws.rgb.clone()
+    assert int(hit.sum()) > 0.9 * n
+
+    def fed(shape, like):
+        G, R, S = shape
+        rows = base[hit][:, :S]
+        pad = rows[:1].expand(G * R - rows.shape[0], S)
+        return torch.cat([rows, pad]).reshape(G, R, S).contiguous()
+
+    model.zero_grad(set_to_none=True)
+    model.noise_fn = fed
+    ro = inp['rays_o'].clone().requires_grad_(True)
+    rd = inp['rays_d'].clone().requires_grad_(True)
+    inp2 = {**inp, 'rays_o': ro, 'rays_d': rd}
+    out = model.get_outputs(inp2)
+    ld = model.get_loss_dict(out, inp2, True, 0)
+    sum(ld.values()).backward()
+    assert torch.equal(out['ray_mask'], hit)
+    # identical sample structure (a row may differ when the float32 sum of
+    # its chord lengths, taken in a different order, crosses an integer)
+    ref_cnt = out['z_vals'].ne(10.0).sum(-1)   # MAX_DEPTH marks padding
+    same = ref_cnt == cnt[hit]
+    assert float(same.float().mean()) > 0.998, float(same.float().mean())
+    assert sizes['s_max'] == out['z_vals'].shape[1]
+    ref = {'loss': sum(ld.values()).detach(),
+           'terms': torch.stack([ld['rgb_loss'], ld['depth_loss'],
+                                 ld['sdf_loss'], ld['fs_loss']]).detach(),
+           'g_o': ro.grad, 'g_d': rd.grad, 'g_emb': model.embeddings.grad}
+    for k, p in model.decoder.named_parameters():
+        ref['g_' + k] = p.grad
+    errs = {k: vg.rel_err(got[k].cpu().numpy(), ref[k].cpu().numpy())
+            for k in ref}
+    errs['depth'] = vg.rel_err(depth.cpu().numpy(),
+                               out['depth'].detach().cpu().numpy())
+    errs['rgb'] = vg.rel_err(rgb.cpu().numpy(),
+                             out['rgb'].detach().cpu().numpy())
+    bad = {k: v for k, v in errs.items() if not v < 1e-4}
+    assert not bad, (bad, errs)
+
+
+def test_capacity_overflow_is_reported_and_grows():
+    algo, f, inp = _room_model(512)
+    model = algo.model
+    model.s_cap, model.pts_per_ray = 64, 8   # far too small
+    model.noise_fn = None
+    loss, _ = model.fused_loss(inp, False)
+    assert torch.isfinite(loss)
+    v0 = model.capacity_version
+    sizes = model.check_capacity()
+    assert sizes['grown'] and model.capacity_version == v0 + 1
+    assert model.s_cap >= sizes['row_len'] and model.s_cap % 64 == 0
+    loss2, _ = model.fused_loss(inp, False)
+    sizes2 = model.check_capacity()
+    assert not sizes2['grown'], sizes2
+    assert sizes2['n_pts'] <= 512 * model.pts_per_ray
+    assert torch.isfinite(loss2)
+
+
+def test_voxfusion_loop_through_graphs():
+    """tracking + mapping of the synthetic room with every iteration inside a
+    captured hipGraph (persistent tracking graph, mapping graphs kept across
+    calls, map arrays updated in place)"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import (cadence,
+                                                       voxfusion_config)
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cam = Camera(fx=150., fy=150., cx=79.5, cy=59.5, width=160, height=120)
+    algo = voxfusion_config().setup(camera=cam, device=DEV)
+    algo.use_graphs = True
+    data = SyntheticRoom([[-3, 3], [-4, 2.5], [-2, 2.5]], H=120, W=160,
+                         fx=150., fy=150., cx=79.5, cy=59.5, n_frames=200,
+                         device=DEV)
+    cad = cadence['vox-fusion']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device=DEV,
+                          use_relative_pose=cad.use_relative_pose,
+                          init_pose_offset=cad.init_pose_offset)
+    for k in range(12):
+        slam.step(k)
+    assert getattr(algo, '_track_slot', None) is not None
+    assert algo._track_slot['graph'] is not None
+    assert any(s.get('graphs') for s in algo._map_slots.values())
+    assert algo.last_batch_sizes['n_hit_rays'] > 0
+    ate = slam.ate_rmse()
+    assert ate < 0.03, ate

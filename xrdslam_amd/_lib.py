@@ -91,9 +91,18 @@ _SIGS = {
     'xrd_vox_pack_len': (C.c_int, []),
     'xrd_vox_pack_index': (C.c_int, [vp]),
     'xrd_vox_points_fwd': (C.c_int, [i64, vp, vp, vp, vp, vp, f32] +
-                           [vp] * 10),
+                           [vp] * 11),
     'xrd_vox_points_bwd': (C.c_int, [i64, vp, vp, vp, vp, vp, f32] +
-                           [vp] * 13),
+                           [vp] * 14),
+    'xrd_vox_meta_len': (C.c_int, []),
+    'xrd_vox_sample_rays': (C.c_int, [C.c_int, C.c_int, C.c_int, i64, C.c_int,
+                                      vp, vp, f32, f32, f32, f32, f32] +
+                            [vp] * 21),
+    'xrd_vox_render_fwd': (C.c_int, [C.c_int, C.c_int, i64, f32, f32] +
+                           [vp] * 14 + [f32] * 4 + [vp] * 3),
+    'xrd_vox_render_bwd': (C.c_int, [C.c_int, C.c_int, i64, f32, f32] +
+                           [vp] * 14),
+    'xrd_vox_ray_grads': (C.c_int, [C.c_int, C.c_int, i64] + [vp] * 8),
     'xrd_gs_preprocess': (C.c_int, [vp, C.c_int] + [vp] * 11),
     'xrd_gs_duplicate_keys': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         vp]),

@@ -13,6 +13,7 @@
 //   * the DFS stack (int[256] of scratch per thread in the reference) lives in
 //     LDS, transposed so that a wave's pushes hit 64 different banks.
 #include "common.h"
+#include "svo_sample.h"
 
 #pragma clang fp contract(off)  // keep the float expressions as written
 
@@ -104,23 +105,9 @@ __global__ __launch_bounds__(kRaysPerBlock) void svo_intersect_kernel(
   (void)n;
 }
 
-// Inverse-CDF sampling, one WAVE per ray (sample_gpu.cu:133-239 walks a ray's
-// steps serially on one thread, carrying (bin, z_low); tests/
-// svo_parallel_model.py states and checks the re-formulation used here):
-//   * cum[b] = serial float prefix sum of the ray's probs (same addition
-//     order as the reference), kept in LDS;
-//   * lane c owns step c: cdf(c), bin(c) = first b with !(cdf > cum[b])
-//     (running max over the lanes by a wave scan), its in-bin sample goes to
-//     slot c + bin(c); the bin boundaries crossed since step c-1 go to slots
-//     c + b; z_low comes from lane c-1 by shuffle when it lies in the same
-//     bin, else it is the bin's entry depth;
-//   * the first lane whose bin reaches the number of valid bins ends the ray
-//     ("done" in the reference);
-//   * the reference's trailing loop over the remaining bins, with its quirks
-//     (`~done` always true, `pts_idx[curr_bin]` read without the ray offset,
-//     the `num_rays > H + curr_bin` guard), runs on lane 0.
-// Writes beyond max_steps are dropped and pts_idx reads one past the buffer
-// (the reference performs both) return -1.
+// Inverse-CDF sampling, one WAVE per ray (body: svo_sample.h).  Writes beyond
+// max_steps are dropped and pts_idx reads one past the buffer (the reference
+// performs both) return -1.
 constexpr int kCdfWaves = 4;
 
 __global__ __launch_bounds__(kCdfWaves * 64) void inverse_cdf_kernel(
@@ -135,126 +122,26 @@ __global__ __launch_bounds__(kCdfWaves * 64) void inverse_cdf_kernel(
   const int bi = blockIdx.y;
   const int j = blockIdx.x * kCdfWaves + wave;
   if (j >= num_rays) return;
-  float* cum = cdf_lds + wave * max_hits;
   const int64_t boff = (int64_t)bi * num_rays * max_hits;
   const int* PI = pts_idx + boff;
-  const float* MN = min_depth + boff;
-  const float* MX = max_depth + boff;
-  const float* PR = probs + boff;
-  const float* UN = uniform_noise + (int64_t)bi * num_rays * max_steps;
-  int* SI = sampled_idx + (int64_t)bi * num_rays * max_steps;
-  float* SD = sampled_depth + (int64_t)bi * num_rays * max_steps;
-  float* SS = sampled_dists + (int64_t)bi * num_rays * max_steps;
   const int H = j * max_hits, K = j * max_steps;
-  auto pi = [&](int i) -> int {
-    return (boff + i < pi_total) ? PI[i] : -1;
-  };
-  auto emit = [&](int slot, int id, float zhi, float zlo) {
-    if (slot < max_steps) {
-      SI[K + slot] = id;
-      SS[K + slot] = zhi - zlo;
-      SD[K + slot] = (zhi + zlo) * 0.5f;
-    }
-  };
-  // valid bins: bin 0 always, then up to the first -1
-  int nbv = max_hits;
-  for (int b0 = 0; b0 < max_hits; b0 += 64) {
-    const int b = b0 + lane;
-    const bool stop = b >= 1 && b < max_hits && pi(H + b) == -1;
-    const uint64_t m = __ballot(stop);
-    if (m) {
-      nbv = b0 + __builtin_ctzll(m);
-      break;
-    }
-  }
-  {  // serial prefix sum, one writer
-    float acc = 0.f;
-    for (int b = 0; b < nbv; ++b) {
-      acc = acc + PR[H + b];
-      if (lane == 0) cum[b] = acc;
-    }
-  }
-  wave_lds_sync();
-  const float st = steps[(int64_t)bi * num_rays + j];
-  float step_size = (float)(1.0 / (double)st);
-  if (fixed_step_size > 0.0) step_size = fixed_step_size;
-  const int total = (int)ceil((double)st);
-  int carry_bin = 0;         // bin of the last step of the previous round
-  float carry_z = MN[H];     // its z
-  int run_bin = 0;
-  bool done = false;
-  int tail_bin = 0, tail_s = 0;
-  float tail_zlow = carry_z, tail_max = MX[H];
-  for (int base = 0; base < total; base += 64) {
-    const int c = base + lane;
-    const bool act = c < total;
-    int f = 0;
-    float cdf = 0.f;
-    if (act) {
-      cdf = ((float)c + UN[K + c]) * step_size;
-      while (f < nbv && cdf > cum[f]) ++f;
-    }
-    int bn = f;  // inclusive running max over the lanes, then the carry
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(bn, o);
-      if (lane >= o) bn = bn > u ? bn : u;
-    }
-    bn = bn > run_bin ? bn : run_bin;
-    const uint64_t dmask = __ballot(act && bn >= nbv);
-    const int first_done = dmask ? __builtin_ctzll(dmask) : 64;
-    const bool mine = act && lane <= first_done;
-    const bool is_done = lane == first_done;
-    float z = 0.f;
-    if (mine && !is_done) {
-      const float cmin = bn > 0 ? cum[bn - 1] : 0.f;
-      const float u = (cdf - cmin) / (cum[bn] - cmin);
-      const float lo = MN[H + bn];
-      z = fmaf(u, MX[H + bn] - lo, lo);  // nvcc contracts this expression
-    }
-    int pb = __shfl_up(bn, 1);
-    float pz = __shfl_up(z, 1);
-    if (lane == 0) {
-      pb = carry_bin;
-      pz = carry_z;
-    }
-    if (mine) {
-      const int hi = bn < nbv ? bn : nbv;
-      for (int b = pb; b < hi; ++b)  // boundaries crossed since step c-1
-        emit(c + b, pi(H + b), MX[H + b], b == pb ? pz : MN[H + b]);
-      if (!is_done)
-        emit(c + bn, pi(H + bn), z, bn == pb ? pz : MN[H + bn]);
-    }
-    if (first_done < 64) {
-      // state after the reference's `done` break, from the done lane
-      const float zl = (nbv - 1 == pb) ? pz : MN[H + nbv - 1];
-      tail_zlow = __shfl(zl, first_done);
-      tail_bin = nbv;
-      tail_s = base + first_done + nbv;
-      tail_max = MX[H + nbv - 1];
-      done = true;
-      break;
-    }
-    const int last = (total - base < 64 ? total - base : 64) - 1;
-    carry_bin = __shfl(bn, last);
-    carry_z = __shfl(z, last);
-    run_bin = carry_bin;
-  }
-  if (!done) {
-    tail_bin = carry_bin;
-    tail_s = total + carry_bin;
-    tail_zlow = carry_z;
-    tail_max = MX[H + carry_bin];
-  }
-  if (lane != 0) return;
-  while (tail_zlow < tail_max && num_rays > H + tail_bin) {
-    emit(tail_s, pi(H + tail_bin), tail_max, tail_zlow);
-    ++tail_bin;
-    ++tail_s;
-    if (tail_bin >= max_hits || pi(tail_bin) == -1) break;
-    tail_max = MX[H + tail_bin];
-    tail_zlow = MN[H + tail_bin];
-  }
+  const float* UN = uniform_noise + (int64_t)bi * num_rays * max_steps + K;
+  int* SI = sampled_idx + (int64_t)bi * num_rays * max_steps + K;
+  float* SD = sampled_depth + (int64_t)bi * num_rays * max_steps + K;
+  float* SS = sampled_dists + (int64_t)bi * num_rays * max_steps + K;
+  inverse_cdf_ray(
+      lane, cdf_lds + wave * max_hits, max_hits, num_rays, H,
+      min_depth + boff + H, max_depth + boff + H, probs + boff + H,
+      steps[(int64_t)bi * num_rays + j], fixed_step_size,
+      [&](int i) -> int { return (boff + i < pi_total) ? PI[i] : -1; },
+      [&](int c) -> float { return UN[c]; },
+      [&](int slot, int id, float zhi, float zlo) {
+        if (slot < max_steps) {
+          SI[slot] = id;
+          SS[slot] = zhi - zlo;
+          SD[slot] = (zhi + zlo) * 0.5f;
+        }
+      });
 }
 
 }  // namespace

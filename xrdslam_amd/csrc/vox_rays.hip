@@ -1,0 +1,740 @@
+// Vox-Fusion: the ray side of one optimisation iteration on gfx950 — what the
+// reference does between `svo_intersect` and the decoder, and between the
+// decoder and the loss, as ~100 small PyTorch launches and three host syncs
+// per iteration:
+//   ray_intersect      voxel_helpers_voxfusion.py:647-687  (mask, sort by entry
+//                      depth, max_distance cut, trim to the largest hit count)
+//   ray_sample         :690-714, InverseCDFRaySampling :399-481 (probs, steps,
+//                      [200, R, P] regrouping, sampler, trim to the longest row)
+//   render_rays        slam/models/sparse_voxel.py:160-275 (hit-ray compaction,
+//                      sample -> point compaction, padded sdf = 1 / colour = 0,
+//                      sdf2weights :277-304, colour / depth sums)
+//   get_loss_dict      :103-143 + get_sdf_loss / get_masks
+//                      (slam/model_components/utils.py:100-186)
+// Everything has STATIC capacity here (n_max hits, S_cap samples per ray, P_cap
+// points) and the data-dependent sizes the reference trims its tensors to —
+// which its results depend on: the [G,R,P] regrouping quirks of the sampler and
+// the means over the padded [hit rays, longest row] array — live in a small
+// device record (`meta`), so that an iteration is a fixed launch sequence
+// without a host sync and can be captured in a hipGraph.  One wave owns one
+// ray in every kernel; samples sit on lanes.
+//
+//   vox_hit_sort   rank sort of <= 64 hits on the lanes of a wave
+//   vox_ray_scan   hit-ray ranks (the sampler's [G,R] regrouping is over the
+//                  COMPACTED hit rays)
+//   vox_sample     svo_sample.h (bit-exact with the reference kernel)
+//   vox_point_scan / vox_compact   sample -> point offsets, xyz = o + d z,
+//                  free-space / band counts of the loss weights
+//   vox_render_fwd compositing + the four loss sums
+//   vox_loss_finalize
+//   vox_render_bwd analytic gradient of the loss w.r.t. per-point sdf / rgb
+//   vox_ray_grad   per-point position gradients -> rays_o / rays_d gradients
+// Reference behaviour restated, never copied.  Parity: tests/test_vox_rays_hip.py
+// (against the modular path, itself pinned to the reference-made golden).
+#include "common.h"
+#include "svo_sample.h"  // also switches fp contraction off for this file
+
+namespace xrd {
+namespace {
+
+enum Meta {
+  M_NHITCOL = 0,   // largest hit count of a ray   (reference: n_hit / P)
+  M_NHITRAYS = 1,  // rays with at least one hit   (N of the sampler)
+  M_MAXSTEPS = 2,  // ceil(max steps) + P          (row length of the sampler)
+  M_SMAX = 3,      // longest sample row           (max_len)
+  M_NPTS = 4,      // valid samples (clamped to the capacity)
+  M_OVERFLOW = 5,  // bit 0: S_cap, bit 1: P_cap, bit 2: non-contiguous row,
+                   // bit 3: traversal stack
+  M_NFRONT = 6,    // free-space samples
+  M_NMID = 7,      // samples inside the truncation band
+  M_NVALID = 8,    // hit rays with a usable sensor depth
+  M_MAXCEIL = 9,   // max over hit rays of ceil(steps)
+  M_STACKOVF = 10, // octree traversal stack overflow (xrd_svo_intersect)
+  M_LEN = 16
+};
+
+constexpr int kWaves = 4;          // rays per block
+constexpr float kPadDepth = 10.f;  // MAX_DEPTH of the padded samples
+constexpr int kGroups = 200;       // G of InverseCDFRaySampling.forward
+
+__global__ void vox_meta_reset_kernel(int* meta, double* acc) {
+  if (threadIdx.x < M_LEN) meta[threadIdx.x] = 0;
+  if (threadIdx.x < 4) acc[threadIdx.x] = 0.0;
+}
+
+// ---------------------------------------------------------------- hit sort
+// in place on idx / min_depth / max_depth [N, n_max]; probs [N, n_max],
+// steps [N], hit [N]
+__global__ __launch_bounds__(kWaves * 64) void vox_hit_sort_kernel(
+    int n_rays, int n_max, float max_distance, float inv_step,
+    int* __restrict__ idx, float* __restrict__ mn, float* __restrict__ mx,
+    float* __restrict__ probs, float* __restrict__ steps,
+    int* __restrict__ hit, int* __restrict__ meta) {
+  __shared__ int s_id[kWaves][64];
+  __shared__ float s_a[kWaves][64], s_b[kWaves][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * kWaves + wave;
+  if (ray >= n_rays) return;
+  const int64_t row = (int64_t)ray * n_max;
+  const bool in = lane < n_max;
+  int id = in ? idx[row + lane] : -1;
+  float a = in ? mn[row + lane] : 0.f, b = in ? mx[row + lane] : 0.f;
+  if (id == -1) a = b = max_distance;
+  // stable rank by entry depth
+  int rank = 0;
+  for (int j = 0; j < n_max; ++j) {
+    const float aj = __shfl(a, j);
+    rank += (aj < a || (aj == a && j < lane)) ? 1 : 0;
+  }
+  if (in) {
+    s_id[wave][rank] = id;
+    s_a[wave][rank] = a;
+    s_b[wave][rank] = b;
+  }
+  wave_lds_sync();
+  if (in) {
+    id = s_id[wave][lane];
+    a = s_a[wave][lane];
+    b = s_b[wave][lane];
+    if (a > max_distance) id = -1;
+    if (id == -1) a = b = max_distance;
+  }
+  wave_lds_sync();
+  const int count = __popcll(__ballot(in && id != -1));
+  const float len = (in && id != -1) ? b - a : 0.f;
+  if (in) s_a[wave][lane] = len;
+  wave_lds_sync();
+  float sum = 0.f;
+  for (int j = 0; j < n_max; ++j) sum = sum + s_a[wave][j];
+  if (in) {
+    idx[row + lane] = id;
+    mn[row + lane] = a;
+    mx[row + lane] = b;
+    probs[row + lane] = len / sum;
+  }
+  if (lane == 0) {
+    // torch divides by a python scalar as a multiplication with its reciprocal
+    const float st = sum * inv_step;
+    steps[ray] = st;
+    hit[ray] = count > 0 ? 1 : 0;
+    if (count > 0) {
+      atomicMax(meta + M_NHITCOL, count);
+      atomicMax(meta + M_MAXCEIL, (int)ceilf(st));
+    }
+  }
+}
+
+// exclusive scan of v[0..n) by ONE block of 1024 threads; out[n] = total
+template <class Load>
+__device__ __forceinline__ int block_scan_1024(int n, Load load,
+                                               int* __restrict__ out) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? load(i) : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int carry = carry_s;
+    if (i < n) out[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  return carry_s;
+}
+
+__global__ __launch_bounds__(1024) void vox_ray_scan_kernel(
+    int n_rays, const int* __restrict__ hit, int* __restrict__ rank,
+    int* __restrict__ hit_rays, int* __restrict__ meta) {
+  const int total = block_scan_1024(
+      n_rays, [&](int i) { return hit[i]; }, rank);
+  for (int i = threadIdx.x; i < n_rays; i += 1024)
+    if (hit[i]) hit_rays[rank[i]] = i;
+  if (threadIdx.x == 0) {
+    meta[M_NHITRAYS] = total;
+    meta[M_MAXSTEPS] = meta[M_MAXCEIL] + meta[M_NHITCOL];
+  }
+}
+
+// ---------------------------------------------------------------- sampling
+__global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
+    int n_rays, int n_max, int s_cap, const int* __restrict__ idx,
+    const float* __restrict__ mn, const float* __restrict__ mx,
+    const float* __restrict__ probs, const float* __restrict__ steps,
+    const float* __restrict__ noise, const int* __restrict__ hit,
+    const int* __restrict__ rank, const int* __restrict__ hit_rays,
+    int* __restrict__ meta, int* __restrict__ s_idx,
+    float* __restrict__ s_depth, int* __restrict__ cnt) {
+  __shared__ float cum_s[kWaves][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * kWaves + wave;
+  if (ray >= n_rays) return;
+  int* SI = s_idx + (int64_t)ray * s_cap;
+  float* SD = s_depth + (int64_t)ray * s_cap;
+  for (int s = lane; s < s_cap; s += 64) {
+    SI[s] = -1;
+    SD[s] = kPadDepth;
+  }
+  if (!hit[ray]) {
+    if (lane == 0) cnt[ray] = 0;
+    return;
+  }
+  __threadfence();  // the row initialisation lands before any sample
+  const int n_hit_rays = meta[M_NHITRAYS];
+  const int P = meta[M_NHITCOL];
+  const int R = (n_hit_rays + kGroups - 1) / kGroups;  // rays per group
+  const int r = rank[ray];
+  const int g = r / R, j = r - g * R;
+  const int H = j * P;
+  int max_steps = meta[M_MAXSTEPS];
+  if (max_steps > s_cap) {
+    if (lane == 0) atomicOr(meta + M_OVERFLOW, 1);
+    max_steps = s_cap;
+  }
+  const int* own = idx + (int64_t)ray * n_max;
+  const int64_t goff = (int64_t)g * R * P, total = (int64_t)kGroups * R * P;
+  const float* UN = noise ? noise + (int64_t)ray * s_cap : nullptr;
+  inverse_cdf_ray(
+      lane, cum_s[wave], P, R, H, mn + (int64_t)ray * n_max,
+      mx + (int64_t)ray * n_max, probs + (int64_t)ray * n_max, steps[ray],
+      -1.f,
+      [&](int i) -> int {
+        // flat index i of the group's [R, P] hit array
+        const int rr = i / P, col = i - rr * P;
+        if (rr == j) return own[col];
+        if (goff + i >= total) return -1;
+        // rows past the last hit ray are copies of the first one
+        const int q = g * R + rr;
+        const int src = hit_rays[q < n_hit_rays ? q : 0];
+        return idx[(int64_t)src * n_max + col];
+      },
+      [&](int c) -> float {
+        if (UN == nullptr || c >= s_cap) return 0.5f;
+        return fminf(fmaxf(UN[c], 0.001f), 0.999f);
+      },
+      [&](int slot, int id, float zhi, float zlo) {
+        if (slot < max_steps) {
+          SI[slot] = id;
+          SD[slot] = (zhi + zlo) * 0.5f;
+        }
+      });
+  __threadfence();
+  // valid samples of the row (they form a prefix; anything else is reported)
+  int count = 0, last = -1;
+  for (int s0 = 0; s0 < max_steps; s0 += 64) {
+    const int s = s0 + lane;
+    const uint64_t m = __ballot(s < max_steps && SI[s] != -1);
+    count += __popcll(m);
+    if (m) last = s0 + 63 - __builtin_clzll(m);
+  }
+  // padded samples: depth = MAX_DEPTH (ray_sample, :709-711)
+  for (int s = lane; s < max_steps; s += 64)
+    if (SI[s] == -1) SD[s] = kPadDepth;
+  if (lane == 0) {
+    cnt[ray] = count;
+    atomicMax(meta + M_SMAX, count);
+    if (last + 1 != count) atomicOr(meta + M_OVERFLOW, 4);
+  }
+}
+
+__global__ __launch_bounds__(1024) void vox_point_scan_kernel(
+    int n_rays, int64_t p_cap, const int* __restrict__ cnt,
+    int* __restrict__ offs, int* __restrict__ meta) {
+  const int total = block_scan_1024(
+      n_rays, [&](int i) { return cnt[i]; }, offs);
+  if (threadIdx.x == 0) {
+    offs[n_rays] = total;
+    if ((int64_t)total > p_cap) atomicOr(meta + M_OVERFLOW, 2);
+    meta[M_NPTS] = (int64_t)total > p_cap ? (int)p_cap : total;
+  }
+}
+
+// xyz / voxel id of every valid sample + the sample counts of the loss weights
+__global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
+    int n_rays, int s_cap, int64_t p_cap, float trunc, float max_depth,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ target_d, const int* __restrict__ hit,
+    const int* __restrict__ cnt, const int* __restrict__ offs,
+    const int* __restrict__ s_idx, const float* __restrict__ s_depth,
+    float* __restrict__ xyz, int* __restrict__ vox, int* __restrict__ meta) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * kWaves + wave;
+  if (ray >= n_rays || !hit[ray]) return;
+  const int s_max = meta[M_SMAX] < s_cap ? meta[M_SMAX] : s_cap;
+  const int n = cnt[ray];
+  const int64_t p0 = offs[ray];
+  const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1],
+                      rays_o[ray * 3 + 2]};
+  const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1],
+                      rays_d[ray * 3 + 2]};
+  const float td = target_d[ray];
+  const float lo = td - trunc, hi = td + trunc;
+  int n_front = 0, n_mid = 0;
+  for (int s0 = 0; s0 < s_max; s0 += 64) {
+    const int s = s0 + lane;
+    const bool in = s < s_max;
+    const bool valid = s < n;
+    const float z = valid ? s_depth[(int64_t)ray * s_cap + s] : kPadDepth;
+    if (valid && p0 + s < p_cap) {
+      const int64_t p = p0 + s;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xyz[p * 3 + k] = o[k] + d[k] * z;
+      vox[p] = s_idx[(int64_t)ray * s_cap + s];
+    }
+    const bool front = in && z < lo;
+    const bool back = in && z > hi;
+    n_front += __popcll(__ballot(front));
+    n_mid += __popcll(__ballot(in && !front && !back && td > 0.f));
+  }
+  if (lane == 0) {
+    if (n_front) atomicAdd(meta + M_NFRONT, n_front);
+    if (n_mid) atomicAdd(meta + M_NMID, n_mid);
+    if (td > 0.01f && td < max_depth) atomicAdd(meta + M_NVALID, 1);
+  }
+}
+
+// ---------------------------------------------------------------- compositing
+struct RayView {
+  int n, s_max;
+  int64_t p0, p_cap;
+  const float* z;     // the ray's sample depths
+  const float* sdf;   // per point
+  __device__ __forceinline__ bool live(int s) const {
+    return s < n && p0 + s < p_cap;
+  }
+  __device__ __forceinline__ float sdf_at(int s) const {
+    return live(s) ? sdf[p0 + s] : 1.f;   // padded samples: free space
+  }
+  __device__ __forceinline__ float z_at(int s) const {
+    return s < n ? z[s] : kPadDepth;
+  }
+};
+
+__device__ __forceinline__ float sigmoidf(float x) {
+  return 1.f / (1.f + expf(-x));
+}
+
+// depth of the first sign change of the (padded) sdf row, sdf2weights :284-291
+__device__ __forceinline__ float first_crossing_depth(const RayView& v,
+                                                      int lane) {
+  for (int s0 = 0; s0 + 1 < v.s_max; s0 += 64) {
+    const int s = s0 + lane;
+    const bool cross =
+        s + 1 < v.s_max && v.sdf_at(s + 1) * v.sdf_at(s) < 0.f;
+    const uint64_t m = __ballot(cross);
+    if (m) return v.z_at(s0 + __builtin_ctzll(m));
+  }
+  return v.z_at(0);
+}
+
+struct LossScale {  // written by vox_loss_finalize
+  float c_rgb, c_depth, c_fs, c_sdf;
+};
+
+// one wave: weights, colour, depth of one ray.  `u` of lane's samples are
+// recomputed by the callers from (sdf, z, z_min).
+__device__ __forceinline__ void composite_ray(const RayView& v, int lane,
+                                              const float* __restrict__ rgb_pt,
+                                              float inv_tr, float tr,
+                                              float& z_min, float& usum,
+                                              float (&rgb)[3], float& depth) {
+  z_min = first_crossing_depth(v, lane);
+  const float z_cut = z_min + tr;
+  float U = 0.f;
+  for (int s0 = 0; s0 < v.n; s0 += 64) {
+    const int s = s0 + lane;
+    if (v.live(s)) {
+      const float sd = v.sdf[v.p0 + s];
+      const float b = sigmoidf(sd * inv_tr) * sigmoidf(-sd * inv_tr);
+      U += v.z[s] < z_cut ? b : 0.f;
+    }
+  }
+  U = wave_sum(U);
+  usum = U;
+  const float den = U + 1e-8f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < v.n; s0 += 64) {
+    const int s = s0 + lane;
+    if (v.live(s)) {
+      const float sd = v.sdf[v.p0 + s];
+      const float b = sigmoidf(sd * inv_tr) * sigmoidf(-sd * inv_tr);
+      const float w = (v.z[s] < z_cut ? b : 0.f) / den;
+      const float* c = rgb_pt + (v.p0 + s) * 3;
+      acc[0] += w * c[0];
+      acc[1] += w * c[1];
+      acc[2] += w * c[2];
+      acc[3] += w * v.z[s];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rgb[k] = wave_sum(acc[k]);
+  depth = wave_sum(acc[3]);
+}
+
+struct RenderArgs {
+  int n_rays, s_cap;
+  int64_t p_cap;
+  float trunc, inv_trunc, max_depth;
+};
+
+__global__ __launch_bounds__(kWaves * 64) void vox_render_fwd_kernel(
+    RenderArgs a, const int* __restrict__ hit, const int* __restrict__ cnt,
+    const int* __restrict__ offs, const float* __restrict__ s_depth,
+    const float* __restrict__ sdf_pt, const float* __restrict__ rgb_pt,
+    const float* __restrict__ target_d, const float* __restrict__ target_rgb,
+    const int* __restrict__ meta, float* __restrict__ depth_out,
+    float* __restrict__ rgb_out, float* __restrict__ zmin_out,
+    float* __restrict__ weights_out, double* __restrict__ acc) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * kWaves + wave;
+  if (ray >= a.n_rays) return;
+  if (!hit[ray]) {
+    if (lane == 0) {
+      depth_out[ray] = 0.f;
+      rgb_out[ray * 3] = rgb_out[ray * 3 + 1] = rgb_out[ray * 3 + 2] = 0.f;
+      if (zmin_out) zmin_out[ray] = 0.f;
+    }
+    if (weights_out)
+      for (int s = lane; s < a.s_cap; s += 64)
+        weights_out[(int64_t)ray * a.s_cap + s] = 0.f;
+    return;
+  }
+  RayView v;
+  v.n = cnt[ray];
+  v.s_max = meta[M_SMAX] < a.s_cap ? meta[M_SMAX] : a.s_cap;
+  v.p0 = offs[ray];
+  v.p_cap = a.p_cap;
+  v.z = s_depth + (int64_t)ray * a.s_cap;
+  v.sdf = sdf_pt;
+  float z_min, U, rgb[3], depth;
+  composite_ray(v, lane, rgb_pt, a.inv_trunc, a.trunc, z_min, U, rgb, depth);
+  if (lane == 0) {
+    depth_out[ray] = depth;
+    rgb_out[ray * 3] = rgb[0];
+    rgb_out[ray * 3 + 1] = rgb[1];
+    rgb_out[ray * 3 + 2] = rgb[2];
+    if (zmin_out) zmin_out[ray] = z_min;
+  }
+  if (weights_out) {
+    const float den = U + 1e-8f, z_cut = z_min + a.trunc;
+    for (int s = lane; s < a.s_cap; s += 64) {
+      float w = 0.f;
+      if (v.live(s)) {
+        const float sd = v.sdf[v.p0 + s];
+        const float b =
+            sigmoidf(sd * a.inv_trunc) * sigmoidf(-sd * a.inv_trunc);
+        w = (v.z[s] < z_cut ? b : 0.f) / den;
+      }
+      weights_out[(int64_t)ray * a.s_cap + s] = w;
+    }
+  }
+  if (acc == nullptr) return;
+  // the four loss sums of this ray (get_loss_dict :103-143)
+  const float td = target_d[ray];
+  const float wv = (td > 0.01f && td < a.max_depth) ? 1.f : 0.f;
+  const float lo = td - a.trunc, hi = td + a.trunc;
+  float fs = 0.f, sd2 = 0.f;
+  for (int s0 = 0; s0 < v.s_max; s0 += 64) {
+    const int s = s0 + lane;
+    if (s >= v.s_max) continue;
+    const float z = v.z_at(s), sd = v.sdf_at(s);
+    const bool front = z < lo, back = z > hi;
+    if (front) fs += (sd - 1.f) * (sd - 1.f);
+    if (!front && !back && td > 0.f) {
+      const float e = (z + sd * a.trunc) - td;
+      sd2 += e * e;
+    }
+  }
+  fs = wave_sum(fs);
+  sd2 = wave_sum(sd2);
+  if (lane == 0) {
+    float l_rgb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      l_rgb += fabsf(rgb[k] * wv - target_rgb[ray * 3 + k] * wv);
+    atomicAdd(acc + 0, (double)l_rgb);
+    if (wv != 0.f) atomicAdd(acc + 1, (double)fabsf(depth - td));
+    if (fs != 0.f) atomicAdd(acc + 2, (double)fs);
+    if (sd2 != 0.f) atomicAdd(acc + 3, (double)sd2);
+  }
+}
+
+// loss[0..3] = rgb, depth, sdf, fs (weighted), loss[4] = their sum in the
+// order the algorithm adds them; scale = the factors of the backward
+__global__ void vox_loss_finalize_kernel(const int* __restrict__ meta,
+                                         int s_cap,
+                                         const double* __restrict__ acc,
+                                         float w_rgb, float w_depth,
+                                         float w_sdf, float w_fs,
+                                         float* __restrict__ loss,
+                                         LossScale* __restrict__ scale) {
+  if (threadIdx.x != 0) return;
+  const int n_hit = meta[M_NHITRAYS];
+  const int s_max = meta[M_SMAX] < s_cap ? meta[M_SMAX] : s_cap;
+  LossScale sc = {0.f, 0.f, 0.f, 0.f};
+  if (n_hit > 0 && s_max > 0) {
+    const float n_fs = (float)meta[M_NFRONT], n_sdf = (float)meta[M_NMID];
+    const float tot = n_fs + n_sdf;
+    const float fs_w = 1.f - n_fs / tot, sdf_w = 1.f - n_sdf / tot;
+    const float cells = (float)n_hit * (float)s_max;
+    sc.c_rgb = w_rgb / (3.f * (float)n_hit);
+    sc.c_depth = w_depth / (float)meta[M_NVALID];
+    sc.c_fs = w_fs * fs_w / cells;
+    sc.c_sdf = w_sdf * sdf_w / cells;
+  }
+  loss[0] = (float)acc[0] * sc.c_rgb;
+  loss[1] = meta[M_NVALID] > 0 ? (float)acc[1] * sc.c_depth : 0.f;
+  loss[2] = (float)acc[3] * sc.c_sdf;
+  loss[3] = (float)acc[2] * sc.c_fs;
+  loss[4] = ((loss[0] + loss[1]) + loss[2]) + loss[3];
+  if (!(meta[M_NVALID] > 0)) sc.c_depth = 0.f;
+  *scale = sc;
+}
+
+// d loss / d (per-point sdf, rgb), scaled by the upstream gradient *g_up
+__global__ __launch_bounds__(kWaves * 64) void vox_render_bwd_kernel(
+    RenderArgs a, const int* __restrict__ hit, const int* __restrict__ cnt,
+    const int* __restrict__ offs, const float* __restrict__ s_depth,
+    const float* __restrict__ sdf_pt, const float* __restrict__ rgb_pt,
+    const float* __restrict__ target_d, const float* __restrict__ target_rgb,
+    const int* __restrict__ meta, const LossScale* __restrict__ scale,
+    const float* __restrict__ g_up, float* __restrict__ g_sdf,
+    float* __restrict__ g_rgb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * kWaves + wave;
+  if (ray >= a.n_rays || !hit[ray]) return;
+  RayView v;
+  v.n = cnt[ray];
+  v.s_max = meta[M_SMAX] < a.s_cap ? meta[M_SMAX] : a.s_cap;
+  v.p0 = offs[ray];
+  v.p_cap = a.p_cap;
+  v.z = s_depth + (int64_t)ray * a.s_cap;
+  v.sdf = sdf_pt;
+  float z_min, U, rgb[3], depth;
+  composite_ray(v, lane, rgb_pt, a.inv_trunc, a.trunc, z_min, U, rgb, depth);
+  const LossScale sc = *scale;
+  const float up = g_up ? *g_up : 1.f;
+  const float td = target_d[ray];
+  const float wv = (td > 0.01f && td < a.max_depth) ? 1.f : 0.f;
+  auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
+  float gr[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    gr[k] = up * sc.c_rgb * wv *
+            sgn(rgb[k] * wv - target_rgb[ray * 3 + k] * wv);
+  const float gd = wv != 0.f ? up * sc.c_depth * sgn(depth - td) : 0.f;
+  const float den = U + 1e-8f, z_cut = z_min + a.trunc;
+  const float lo = td - a.trunc, hi = td + a.trunc;
+  // sum_k a_k w_k with a_k = d loss / d w_k
+  float aw = 0.f;
+  for (int s0 = 0; s0 < v.n; s0 += 64) {
+    const int s = s0 + lane;
+    if (v.live(s)) {
+      const float sd = v.sdf[v.p0 + s];
+      const float b = sigmoidf(sd * a.inv_trunc) * sigmoidf(-sd * a.inv_trunc);
+      const float w = (v.z[s] < z_cut ? b : 0.f) / den;
+      const float* c = rgb_pt + (v.p0 + s) * 3;
+      aw += w * (gr[0] * c[0] + gr[1] * c[1] + gr[2] * c[2] + gd * v.z[s]);
+    }
+  }
+  aw = wave_sum(aw);
+  for (int s0 = 0; s0 < v.n; s0 += 64) {
+    const int s = s0 + lane;
+    if (!v.live(s)) continue;
+    const int64_t p = v.p0 + s;
+    const float sd = v.sdf[p], z = v.z[s];
+    const float sp = sigmoidf(sd * a.inv_trunc),
+                sm = sigmoidf(-sd * a.inv_trunc);
+    const float b = sp * sm;
+    const bool m = z < z_cut;
+    const float w = (m ? b : 0.f) / den;
+    const float* c = rgb_pt + p * 3;
+    const float ak = gr[0] * c[0] + gr[1] * c[1] + gr[2] * c[2] + gd * z;
+    float gs = m ? (ak - aw) / den * (b * (sm - sp)) * a.inv_trunc : 0.f;
+    const bool front = z < lo, back = z > hi;
+    if (front) gs += up * sc.c_fs * 2.f * (sd - 1.f);
+    if (!front && !back && td > 0.f)
+      gs += up * sc.c_sdf * 2.f * a.trunc * ((z + sd * a.trunc) - td);
+    g_sdf[p] = gs;
+    g_rgb[p * 3] = gr[0] * w;
+    g_rgb[p * 3 + 1] = gr[1] * w;
+    g_rgb[p * 3 + 2] = gr[2] * w;
+  }
+}
+
+// g_rays_o = sum_k g_xyz_k, g_rays_d = sum_k z_k g_xyz_k   (xyz = o + d z)
+__global__ __launch_bounds__(kWaves * 64) void vox_ray_grad_kernel(
+    int n_rays, int s_cap, int64_t p_cap, const int* __restrict__ hit,
+    const int* __restrict__ cnt, const int* __restrict__ offs,
+    const float* __restrict__ s_depth, const float* __restrict__ g_xyz,
+    float* __restrict__ g_o, float* __restrict__ g_d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * kWaves + wave;
+  if (ray >= n_rays) return;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (hit[ray]) {
+    const int n = cnt[ray];
+    const int64_t p0 = offs[ray];
+    for (int s = lane; s < n; s += 64) {
+      if (p0 + s >= p_cap) break;
+      const float z = s_depth[(int64_t)ray * s_cap + s];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float g = g_xyz[(p0 + s) * 3 + k];
+        acc[k] += g;
+        acc[3 + k] += z * g;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g_o[ray * 3 + k] = acc[k];
+      g_d[ray * 3 + k] = acc[3 + k];
+    }
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
+using namespace xrd;
+
+extern "C" {
+
+int xrd_vox_meta_len(void) { return M_LEN; }
+
+int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
+                        int n_nodes, const float* centres,
+                        const int32_t* children, float voxel_size,
+                        float max_distance, float step_size, float trunc,
+                        float max_depth, const float* rays_o,
+                        const float* rays_d, const float* target_d,
+                        const float* noise, int32_t* hit_idx, float* hit_min,
+                        float* hit_max, float* probs, float* steps,
+                        int32_t* hit, int32_t* rank, int32_t* hit_rays,
+                        int32_t* s_idx, float* s_depth, int32_t* cnt,
+                        int32_t* offs, float* xyz, int32_t* vox, int32_t* meta,
+                        double* loss_acc, xrd_stream_t stream) {
+  if (n_rays < 0 || n_max < 1 || n_max > 64 || s_cap < 1 || p_cap < 1 ||
+      !(step_size > 0.f))
+    return XRD_ERR_ARG;
+  if (!meta || !loss_acc) return XRD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vox_meta_reset_kernel, dim3(1), dim3(64), 0, st, meta,
+                     loss_acc);
+  if (n_rays == 0) return check_launch("xrd_vox_sample_rays");
+  if (!rays_o || !rays_d || !target_d || !hit_idx || !hit_min || !hit_max ||
+      !probs || !steps || !hit || !rank || !hit_rays || !s_idx || !s_depth ||
+      !cnt || !offs || !xyz || !vox)
+    return XRD_ERR_ARG;
+  if (centres != nullptr) {  // NULL: hit_idx / hit_min / hit_max are given
+    const int rc = xrd_svo_intersect(1, n_nodes, n_rays, voxel_size, n_max, 1,
+                                     rays_o, rays_d, centres, children,
+                                     hit_idx, hit_min, hit_max,
+                                     meta + M_STACKOVF, stream);
+    if (rc != XRD_OK) return rc;
+  }
+  const dim3 grid((n_rays + kWaves - 1) / kWaves), block(kWaves * 64);
+  hipLaunchKernelGGL(vox_hit_sort_kernel, grid, block, 0, st, n_rays, n_max,
+                     max_distance, 1.0f / step_size, hit_idx, hit_min, hit_max,
+                     probs, steps, hit, meta);
+  hipLaunchKernelGGL(vox_ray_scan_kernel, dim3(1), dim3(1024), 0, st, n_rays,
+                     hit, rank, hit_rays, meta);
+  hipLaunchKernelGGL(vox_sample_kernel, grid, block, 0, st, n_rays, n_max,
+                     s_cap, hit_idx, hit_min, hit_max, probs, steps, noise,
+                     hit, rank, hit_rays, meta, s_idx, s_depth, cnt);
+  hipLaunchKernelGGL(vox_point_scan_kernel, dim3(1), dim3(1024), 0, st,
+                     n_rays, p_cap, cnt, offs, meta);
+  hipLaunchKernelGGL(vox_compact_kernel, grid, block, 0, st, n_rays, s_cap,
+                     p_cap, trunc, max_depth, rays_o, rays_d, target_d, hit,
+                     cnt, offs, s_idx, s_depth, xyz, vox, meta);
+  return check_launch("xrd_vox_sample_rays");
+}
+
+int xrd_vox_render_fwd(int n_rays, int s_cap, int64_t p_cap, float trunc,
+                       float max_depth, const int32_t* hit,
+                       const int32_t* cnt, const int32_t* offs,
+                       const float* s_depth, const float* sdf_pt,
+                       const float* rgb_pt, const float* target_d,
+                       const float* target_rgb, const int32_t* meta,
+                       float* depth, float* rgb, float* z_min, float* weights,
+                       double* loss_acc, float w_rgb, float w_depth,
+                       float w_sdf, float w_fs, float* loss, float* scale,
+                       xrd_stream_t stream) {
+  if (n_rays < 0 || s_cap < 1 || p_cap < 1 || !(trunc > 0.f))
+    return XRD_ERR_ARG;
+  if (n_rays == 0) return XRD_OK;
+  if (!hit || !cnt || !offs || !s_depth || !sdf_pt || !rgb_pt || !meta ||
+      !depth || !rgb)
+    return XRD_ERR_ARG;
+  if (loss_acc && (!target_d || !target_rgb || !loss || !scale))
+    return XRD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const RenderArgs a = {n_rays, s_cap, p_cap, trunc, 1.0f / trunc, max_depth};
+  hipLaunchKernelGGL(vox_render_fwd_kernel,
+                     dim3((n_rays + kWaves - 1) / kWaves), dim3(kWaves * 64),
+                     0, st, a, hit, cnt, offs, s_depth, sdf_pt, rgb_pt,
+                     target_d, target_rgb, meta, depth, rgb, z_min, weights,
+                     loss_acc);
+  if (loss_acc)
+    hipLaunchKernelGGL(vox_loss_finalize_kernel, dim3(1), dim3(64), 0, st,
+                       meta, s_cap, loss_acc, w_rgb, w_depth, w_sdf, w_fs,
+                       loss, reinterpret_cast<LossScale*>(scale));
+  return check_launch("xrd_vox_render_fwd");
+}
+
+int xrd_vox_render_bwd(int n_rays, int s_cap, int64_t p_cap, float trunc,
+                       float max_depth, const int32_t* hit,
+                       const int32_t* cnt, const int32_t* offs,
+                       const float* s_depth, const float* sdf_pt,
+                       const float* rgb_pt, const float* target_d,
+                       const float* target_rgb, const int32_t* meta,
+                       const float* scale, const float* g_loss, float* g_sdf,
+                       float* g_rgb, xrd_stream_t stream) {
+  if (n_rays < 0 || s_cap < 1 || p_cap < 1 || !(trunc > 0.f))
+    return XRD_ERR_ARG;
+  if (n_rays == 0) return XRD_OK;
+  if (!hit || !cnt || !offs || !s_depth || !sdf_pt || !rgb_pt || !target_d ||
+      !target_rgb || !meta || !scale || !g_sdf || !g_rgb)
+    return XRD_ERR_ARG;
+  const RenderArgs a = {n_rays, s_cap, p_cap, trunc, 1.0f / trunc, max_depth};
+  hipLaunchKernelGGL(vox_render_bwd_kernel,
+                     dim3((n_rays + kWaves - 1) / kWaves), dim3(kWaves * 64),
+                     0, (hipStream_t)stream, a, hit, cnt, offs, s_depth,
+                     sdf_pt, rgb_pt, target_d, target_rgb, meta,
+                     reinterpret_cast<const LossScale*>(scale), g_loss, g_sdf,
+                     g_rgb);
+  return check_launch("xrd_vox_render_bwd");
+}
+
+int xrd_vox_ray_grads(int n_rays, int s_cap, int64_t p_cap, const int32_t* hit,
+                      const int32_t* cnt, const int32_t* offs,
+                      const float* s_depth, const float* g_xyz,
+                      float* g_rays_o, float* g_rays_d, xrd_stream_t stream) {
+  if (n_rays < 0 || s_cap < 1 || p_cap < 1) return XRD_ERR_ARG;
+  if (n_rays == 0) return XRD_OK;
+  if (!hit || !cnt || !offs || !s_depth || !g_xyz || !g_rays_o || !g_rays_d)
+    return XRD_ERR_ARG;
+  hipLaunchKernelGGL(vox_ray_grad_kernel, dim3((n_rays + kWaves - 1) / kWaves),
+                     dim3(kWaves * 64), 0, (hipStream_t)stream, n_rays, s_cap,
+                     p_cap, hit, cnt, offs, s_depth, g_xyz, g_rays_o,
+                     g_rays_d);
+  return check_launch("xrd_vox_ray_grads");
+}
+
+}  // extern "C"

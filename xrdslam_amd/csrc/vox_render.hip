@@ -128,8 +128,10 @@ __global__ __launch_bounds__(VW * 64, 2) void vox_points_fwd_kernel(
     const float* __restrict__ pk, float* __restrict__ sdf,
     float* __restrict__ rgb, float* __restrict__ sx, float* __restrict__ sh1,
     float* __restrict__ sh2, float* __restrict__ sf, float* __restrict__ shc,
-    uint32_t* __restrict__ masks) {
+    uint32_t* __restrict__ masks, const int* __restrict__ n_dev) {
   using K = VoxPack;
+  // static-capacity launches: the live point count comes from the device
+  if (n_dev != nullptr) P = *n_dev < P ? (*n_dev > 0 ? *n_dev : 0) : P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -248,8 +250,10 @@ __global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
     const float* __restrict__ g_rgb, float* __restrict__ g_xyz,
     float* __restrict__ g_emb, float* __restrict__ gc3,
     float* __restrict__ ghc, float* __restrict__ gf, float* __restrict__ gh2,
-    float* __restrict__ gh1) {
+    float* __restrict__ gh1, const int* __restrict__ n_dev) {
   using K = VoxPack;
+  const int64_t P_cap = P;
+  if (n_dev != nullptr) P = *n_dev < P ? (*n_dev > 0 ? *n_dev : 0) : P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -389,6 +393,21 @@ __global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
       }
     }
   }
+  // static-capacity launches: the weight-gradient GEMMs run over all P_cap
+  // rows, so the operand rows of the unused tail are zeroed
+  if (n_dev != nullptr && gh1 != nullptr) {
+    const int64_t r0 = P * 128, r1 = P_cap * 128;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+         i < r1; i += (int64_t)gridDim.x * blockDim.x) {
+      ghc[i] = 0.f;
+      gf[i] = 0.f;
+      gh2[i] = 0.f;
+      gh1[i] = 0.f;
+    }
+    for (int64_t i = P * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+         i < P_cap * 4; i += (int64_t)gridDim.x * blockDim.x)
+      gc3[i] = 0.f;
+  }
 }
 
 // host: packed <- flat index table
@@ -477,7 +496,8 @@ int xrd_vox_points_fwd(int64_t n_points, const float* xyz,
                        float voxel_size, const float* packed, float* sdf,
                        float* rgb, float* save_x, float* save_h1,
                        float* save_h2, float* save_f, float* save_hc,
-                       uint32_t* masks, xrd_stream_t stream) {
+                       uint32_t* masks, const int32_t* n_points_dev,
+                       xrd_stream_t stream) {
   if (n_points < 0 || voxel_size <= 0.f) return XRD_ERR_ARG;
   if (n_points == 0) return XRD_OK;
   if (!xyz || !voxel_idx || !centres || !vertex_idx || !embeddings ||
@@ -495,7 +515,7 @@ int xrd_vox_points_fwd(int64_t n_points, const float* xyz,
                      vox_lds_bytes(), (hipStream_t)stream,
                      n_points, xyz, voxel_idx, centres, vertex_idx, embeddings,
                      voxel_size, packed, sdf, rgb, save_x, save_h1, save_h2,
-                     save_f, save_hc, masks);
+                     save_f, save_hc, masks, n_points_dev);
   return check_launch("xrd_vox_points_fwd");
 }
 
@@ -506,7 +526,8 @@ int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
                        const uint32_t* masks, const float* g_sdf,
                        const float* g_rgb, float* g_xyz, float* g_embeddings,
                        float* g_c3, float* g_hc, float* g_f, float* g_h2,
-                       float* g_h1, xrd_stream_t stream) {
+                       float* g_h1, const int32_t* n_points_dev,
+                       xrd_stream_t stream) {
   if (n_points < 0 || voxel_size <= 0.f) return XRD_ERR_ARG;
   if (n_points == 0) return XRD_OK;
   if (!xyz || !voxel_idx || !centres || !vertex_idx || !embeddings ||
@@ -524,7 +545,7 @@ int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
                      vox_lds_bytes(), (hipStream_t)stream,
                      n_points, xyz, voxel_idx, centres, vertex_idx, embeddings,
                      voxel_size, packed, rgb, masks, g_sdf, g_rgb, g_xyz,
-                     g_embeddings, g_c3, g_hc, g_f, g_h2, g_h1);
+                     g_embeddings, g_c3, g_hc, g_f, g_h2, g_h1, n_points_dev);
   return check_launch("xrd_vox_points_bwd");
 }
 

@@ -12,6 +12,8 @@ gradients are five GEMMs over the points on the operands the backward kernel
 writes (rocBLAS through ``torch.mm``: plain library GEMMs)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -107,7 +109,7 @@ class _VoxPointsFn(torch.autograd.Function):
             _lib.ptr(vertex_idx), _lib.ptr(emb_c), float(voxel_size),
             _lib.ptr(packed), _lib.ptr(sdf), _lib.ptr(rgb), _lib.ptr(sx),
             _lib.ptr(sh1), _lib.ptr(sh2), _lib.ptr(sf), _lib.ptr(shc),
-            _lib.ptr(masks), st), 'xrd_vox_points_fwd')
+            _lib.ptr(masks), None, st), 'xrd_vox_points_fwd')
         ctx.voxel_size, ctx.need_w = float(voxel_size), need_w
         ctx.save_for_backward(xyz, emb_c, vox_idx, centres, vertex_idx,
                               packed, rgb, masks, sx, sh1, sh2, sf, shc)
@@ -136,7 +138,7 @@ class _VoxPointsFn(torch.autograd.Function):
             _lib.ptr(vertex_idx), _lib.ptr(emb), ctx.voxel_size,
             _lib.ptr(packed), _lib.ptr(rgb), _lib.ptr(masks), _lib.ptr(gs),
             _lib.ptr(gr), _lib.ptr(g_xyz), _lib.ptr(g_emb), _lib.ptr(gc3),
-            _lib.ptr(ghc), _lib.ptr(gf), _lib.ptr(gh2), _lib.ptr(gh1),
+            _lib.ptr(ghc), _lib.ptr(gf), _lib.ptr(gh2), _lib.ptr(gh1), None,
             _lib.stream_ptr(dev)), 'xrd_vox_points_bwd')
         gp = [None] * 10
         if need_w:
@@ -165,3 +167,258 @@ def points(decoder, xyz, voxel_idx, map_states, voxel_size):
         map_states['voxel_center_xyz'].to(dev),
         map_states['voxel_vertex_idx'].to(dev), voxel_size, *ps)
     return {'sdf': sdf, 'color': rgb}
+
+
+# ---------------------------------------------------------------------------
+# The ray side of an iteration with static capacities (csrc/vox_rays.hip):
+# octree traversal -> hit sort -> inverse-CDF sampling -> point compaction ->
+# [voxel features + decoder] -> compositing + the four loss terms, and the
+# backward of all of it, as a fixed launch sequence without a host sync.
+# ---------------------------------------------------------------------------
+N_MAX_HITS = 50          # n_max of svo_ray_intersect (voxel_helpers :655)
+OVERFLOW_BITS = {1: 'samples per ray (s_cap)', 2: 'points (p_cap)',
+                 4: 'sample row with a hole'}
+
+
+class RayWorkspace:
+    """every buffer of one ray batch shape, allocated once: captured graphs
+    keep their addresses, and the rows of the decoder operands beyond the live
+    point count stay finite (the weight-gradient GEMMs run over the capacity)"""
+
+    def __init__(self, n_rays, s_cap, p_cap, need_w, device):
+        self.n, self.s_cap, self.p_cap, self.need_w = n_rays, s_cap, p_cap, \
+            need_w
+        dev = device
+        i = dict(dtype=torch.int32, device=dev)
+        f = dict(dtype=torch.float32, device=dev)
+        n, s, p = n_rays, s_cap, p_cap
+        self.hit_idx = torch.zeros(n, N_MAX_HITS, **i)
+        self.hit_min = torch.zeros(n, N_MAX_HITS, **f)
+        self.hit_max = torch.zeros(n, N_MAX_HITS, **f)
+        self.probs = torch.zeros(n, N_MAX_HITS, **f)
+        self.steps = torch.zeros(n, **f)
+        self.hit = torch.zeros(n, **i)
+        self.rank = torch.zeros(n, **i)
+        self.hit_rays = torch.zeros(n, **i)
+        self.s_idx = torch.zeros(n, s, **i)
+        self.s_depth = torch.zeros(n, s, **f)
+        self.cnt = torch.zeros(n, **i)
+        self.offs = torch.zeros(n + 1, **i)
+        self.xyz = torch.zeros(p, 3, **f)
+        self.vox = torch.zeros(p, **i)
+        self.meta = torch.zeros(_lib.lib().xrd_vox_meta_len(), **i)
+        self.acc = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.loss = torch.zeros(5, **f)
+        self.scale = torch.zeros(4, **f)
+        self.depth = torch.zeros(n, **f)
+        self.rgb = torch.zeros(n, 3, **f)
+        self.sdf_pt = torch.zeros(p, **f)
+        self.rgb_pt = torch.zeros(p, 3, **f)
+        self.masks = torch.zeros(p, 3, 4, **i)
+        self.g_sdf = torch.zeros(p, **f)
+        self.g_rgb = torch.zeros(p, 3, **f)
+        self.g_xyz = torch.zeros(p, 3, **f)
+        self.g_o = torch.zeros(n, 3, **f)
+        self.g_d = torch.zeros(n, 3, **f)
+        self.zero_n = torch.zeros(n, **f)
+        if need_w:
+            self.sx = torch.zeros(p, 16, **f)
+            self.sh1, self.sh2, self.sf, self.shc = (
+                torch.zeros(p, 128, **f) for _ in range(4))
+            self.gc3 = torch.zeros(p, 4, **f)
+            self.ghc, self.gf, self.gh2, self.gh1 = (
+                torch.zeros(p, 128, **f) for _ in range(4))
+        else:
+            self.sx = self.sh1 = self.sh2 = self.sf = self.shc = None
+            self.gc3 = self.ghc = self.gf = self.gh2 = self.gh1 = None
+
+    @property
+    def n_pts_dev(self):
+        return C.c_void_p(self.meta.data_ptr() + 4 * 4)
+
+    def overflow(self):
+        """(bits, meta list) — one device->host copy"""
+        m = self.meta.tolist()
+        return m[5] | (8 if m[10] else 0), m
+
+
+def _pack(params, like):
+    flat = torch.cat([p.detach().reshape(-1).float() for p in params] +
+                     [like.new_zeros(1)])
+    return flat[pack_index(like.device)]
+
+
+def sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise):
+    """hits, samples and points of a ray batch into ``ws``"""
+    lib = _lib.lib()
+    dev = rays_o.device
+    centres = ms['voxel_center_xyz']
+    children = ms['voxel_structure']
+    with _Timed(('vox_sample_rays', ws.n)):
+        _lib.check(lib.xrd_vox_sample_rays(
+            ws.n, N_MAX_HITS, ws.s_cap, ws.p_cap, centres.shape[0],
+            _lib.ptr(centres), _lib.ptr(children), float(cfg.voxel_size),
+            float(cfg.max_distance), float(cfg.step_size),
+            float(cfg.training_trunc * cfg.data_sc_factor),
+            float(cfg.max_dpeth), _lib.ptr(rays_o), _lib.ptr(rays_d),
+            _lib.ptr(target_d), _lib.ptr(noise), _lib.ptr(ws.hit_idx),
+            _lib.ptr(ws.hit_min), _lib.ptr(ws.hit_max), _lib.ptr(ws.probs),
+            _lib.ptr(ws.steps), _lib.ptr(ws.hit), _lib.ptr(ws.rank),
+            _lib.ptr(ws.hit_rays), _lib.ptr(ws.s_idx), _lib.ptr(ws.s_depth),
+            _lib.ptr(ws.cnt), _lib.ptr(ws.offs), _lib.ptr(ws.xyz),
+            _lib.ptr(ws.vox), _lib.ptr(ws.meta), _lib.ptr(ws.acc),
+            _lib.stream_ptr(dev)), 'xrd_vox_sample_rays')
+
+
+def _points_fwd(ws, ms, cfg, packed, save):
+    lib = _lib.lib()
+    dev = ws.xyz.device
+    with _Timed(('vox_points_fwd', ws.p_cap, save)):
+        _lib.check(lib.xrd_vox_points_fwd(
+            ws.p_cap, _lib.ptr(ws.xyz), _lib.ptr(ws.vox),
+            _lib.ptr(ms['voxel_center_xyz']), _lib.ptr(ms['voxel_vertex_idx']),
+            _lib.ptr(ms['voxel_vertex_emb'].detach()), float(cfg.voxel_size),
+            _lib.ptr(packed), _lib.ptr(ws.sdf_pt), _lib.ptr(ws.rgb_pt),
+            _lib.ptr(ws.sx if save else None),
+            _lib.ptr(ws.sh1 if save else None),
+            _lib.ptr(ws.sh2 if save else None),
+            _lib.ptr(ws.sf if save else None),
+            _lib.ptr(ws.shc if save else None), _lib.ptr(ws.masks),
+            ws.n_pts_dev, _lib.stream_ptr(dev)), 'xrd_vox_points_fwd')
+
+
+def _render_fwd(ws, cfg, target_d, target_s, with_loss, z_min=None,
+                weights=None):
+    lib = _lib.lib()
+    dev = ws.xyz.device
+    tr = float(cfg.training_trunc * cfg.data_sc_factor)
+    with _Timed(('vox_render_fwd', ws.n)):
+        _lib.check(lib.xrd_vox_render_fwd(
+            ws.n, ws.s_cap, ws.p_cap, tr, float(cfg.max_dpeth),
+            _lib.ptr(ws.hit), _lib.ptr(ws.cnt), _lib.ptr(ws.offs),
+            _lib.ptr(ws.s_depth), _lib.ptr(ws.sdf_pt), _lib.ptr(ws.rgb_pt),
+            _lib.ptr(target_d), _lib.ptr(target_s), _lib.ptr(ws.meta),
+            _lib.ptr(ws.depth), _lib.ptr(ws.rgb), _lib.ptr(z_min),
+            _lib.ptr(weights), _lib.ptr(ws.acc) if with_loss else None,
+            float(cfg.trainging_rgb_weight), float(cfg.trainging_depth_weight),
+            float(cfg.trainging_sdf_weight), float(cfg.trainging_fs_weight),
+            _lib.ptr(ws.loss), _lib.ptr(ws.scale), _lib.stream_ptr(dev)),
+            'xrd_vox_render_fwd')
+
+
+class _VoxRenderLossFn(torch.autograd.Function):
+    """(rays, embeddings, decoder) -> the summed Vox-Fusion loss of the batch:
+    SparseVoxel.get_outputs + get_loss_dict (sparse_voxel.py:103-143,160-275)
+    as ~12 launches each way"""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, emb, target_d, target_s, noise, ws, ms,
+                cfg, *params):
+        rays_o = rays_o.detach().float().contiguous()
+        rays_d = rays_d.detach().float().contiguous()
+        target_d = target_d.detach().float().reshape(-1).contiguous()
+        target_s = target_s.detach().float().contiguous()
+        need_w = any(ctx.needs_input_grad[9:])
+        assert not need_w or ws.need_w
+        packed = _pack(params, rays_o)
+        sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise)
+        _points_fwd(ws, ms, cfg, packed, need_w)
+        _render_fwd(ws, cfg, target_d, target_s, True)
+        ctx.ws, ctx.ms, ctx.cfg, ctx.need_w = ws, ms, cfg, need_w
+        ctx.save_for_backward(packed, target_d, target_s)
+        ctx.mark_non_differentiable(ws.loss, ws.depth, ws.rgb)
+        return ws.loss[4].clone(), ws.loss, ws.depth, ws.rgb
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        lib = _lib.lib()
+        ws, ms, cfg, need_w = ctx.ws, ctx.ms, ctx.cfg, ctx.need_w
+        packed, target_d, target_s = ctx.saved_tensors
+        dev = packed.device
+        st = _lib.stream_ptr(dev)
+        tr = float(cfg.training_trunc * cfg.data_sc_factor)
+        need_o, need_d, need_emb = ctx.needs_input_grad[:3]
+        g_up = g_loss.detach().float().contiguous()
+        with _Timed(('vox_render_bwd', ws.n)):
+            _lib.check(lib.xrd_vox_render_bwd(
+                ws.n, ws.s_cap, ws.p_cap, tr, float(cfg.max_dpeth),
+                _lib.ptr(ws.hit), _lib.ptr(ws.cnt), _lib.ptr(ws.offs),
+                _lib.ptr(ws.s_depth), _lib.ptr(ws.sdf_pt),
+                _lib.ptr(ws.rgb_pt), _lib.ptr(target_d), _lib.ptr(target_s),
+                _lib.ptr(ws.meta), _lib.ptr(ws.scale), _lib.ptr(g_up),
+                _lib.ptr(ws.g_sdf), _lib.ptr(ws.g_rgb), st),
+                'xrd_vox_render_bwd')
+        emb = ms['voxel_vertex_emb'].detach()
+        g_emb = torch.zeros_like(emb) if need_emb else None
+        need_xyz = need_o or need_d
+        with _Timed(('vox_points_bwd', ws.p_cap, need_w)):
+            _lib.check(lib.xrd_vox_points_bwd(
+                ws.p_cap, _lib.ptr(ws.xyz), _lib.ptr(ws.vox),
+                _lib.ptr(ms['voxel_center_xyz']),
+                _lib.ptr(ms['voxel_vertex_idx']), _lib.ptr(emb),
+                float(cfg.voxel_size), _lib.ptr(packed), _lib.ptr(ws.rgb_pt),
+                _lib.ptr(ws.masks), _lib.ptr(ws.g_sdf), _lib.ptr(ws.g_rgb),
+                _lib.ptr(ws.g_xyz if need_xyz else None), _lib.ptr(g_emb),
+                _lib.ptr(ws.gc3 if need_w else None),
+                _lib.ptr(ws.ghc if need_w else None),
+                _lib.ptr(ws.gf if need_w else None),
+                _lib.ptr(ws.gh2 if need_w else None),
+                _lib.ptr(ws.gh1 if need_w else None), ws.n_pts_dev, st),
+                'xrd_vox_points_bwd')
+        g_o = g_d = None
+        if need_xyz:
+            with _Timed(('vox_ray_grads', ws.n)):
+                _lib.check(lib.xrd_vox_ray_grads(
+                    ws.n, ws.s_cap, ws.p_cap, _lib.ptr(ws.hit),
+                    _lib.ptr(ws.cnt), _lib.ptr(ws.offs), _lib.ptr(ws.s_depth),
+                    _lib.ptr(ws.g_xyz), _lib.ptr(ws.g_o), _lib.ptr(ws.g_d),
+                    st), 'xrd_vox_ray_grads')
+            g_o, g_d = ws.g_o, ws.g_d
+        gp = [None] * 10
+        if need_w:
+            with _Timed(('vox_weight_gemms', ws.p_cap)):
+                gout = torch.cat([ws.gc3[:, 3:4], ws.gf], 1)        # [P,129]
+                g3 = ws.gc3[:, :3]
+                gp = [ws.gh1.t() @ ws.sx, ws.gh1.sum(0),
+                      ws.gh2.t() @ ws.sh1, ws.gh2.sum(0),
+                      gout.t() @ ws.sh2, gout.sum(0),
+                      ws.ghc.t() @ torch.cat([ws.sf, ws.sx], 1),
+                      ws.ghc.sum(0), g3.t() @ ws.shc, g3.sum(0)]
+            gp = [g if need else None
+                  for g, need in zip(gp, ctx.needs_input_grad[9:])]
+        return (g_o if need_o else None, g_d if need_d else None, g_emb, None,
+                None, None, None, None, None, *gp)
+
+
+def render_loss(decoder, ws, ms, cfg, rays_o, rays_d, target_d, target_s,
+                noise, map_grads=True):
+    """-> (loss, loss terms [5] = rgb, depth, sdf, fs, sum; depth [N]; rgb
+    [N,3]) or None when the decoder is not the shape the kernels cover.
+    ``map_grads`` False (tracking): only the ray gradients are produced (the
+    reference's autograd also fills the map gradients there, and never uses
+    them)"""
+    ps = decoder_params(decoder)
+    if ps is None or not rays_o.is_cuda:
+        return None
+    emb = ms['voxel_vertex_emb']
+    if not map_grads:
+        ps = [p.detach() for p in ps]
+        emb = emb.detach()
+    return _VoxRenderLossFn.apply(rays_o, rays_d, emb, target_d, target_s,
+                                  noise, ws, ms, cfg, *ps)
+
+
+@torch.no_grad()
+def render(decoder, ws, ms, cfg, rays_o, rays_d, noise, z_min=None,
+           weights=None):
+    """inference: depth [N], rgb [N,3] of a ray batch (views of ``ws``)"""
+    ps = decoder_params(decoder)
+    if ps is None or not rays_o.is_cuda:
+        return None
+    rays_o = rays_o.detach().float().contiguous()
+    rays_d = rays_d.detach().float().contiguous()
+    # the target depth only feeds the loss counters
+    sample_rays(ws, ms, cfg, rays_o, rays_d, ws.zero_n, noise)
+    _points_fwd(ws, ms, cfg, _pack(ps, rays_o), False)
+    _render_fwd(ws, cfg, None, None, False, z_min=z_min, weights=weights)
+    return ws.depth, ws.rgb

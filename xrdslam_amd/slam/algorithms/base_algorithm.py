@@ -230,6 +230,11 @@ class Algorithm:
     def after_mapping_update(self):
         """end of a mapping optimize_update (replayed graphs included)"""
 
+    def track_slot_key(self):
+        """whatever else the captured tracking iteration depends on (static
+        capacities, kernel-path switches)"""
+        return None
+
     def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
         """iterations with equal keys run identical device work (same stage,
         same learning rates) and may share one captured graph"""
@@ -297,7 +302,7 @@ class Algorithm:
         dev = self.device
         slot = getattr(self, '_track_slot', None)
         shape_key = (frame.h, frame.w, frame.separate_LR, frame.rot_rep,
-                     n_iters)
+                     n_iters, self.track_slot_key())
         if slot is not None and slot['key'] != shape_key:
             slot = None
         init = frame.get_pose().detach()

@@ -36,6 +36,10 @@ class VoxFusion(Algorithm):
         self.model.to(device)
         self.bundle_adjust = True
         self._rays_cam = None
+        # one launch sequence per iteration without host syncs
+        # (SparseVoxel.fused_loss); off = the plugin hooks get_outputs /
+        # get_loss_dict on the modular operators
+        self.fused_iteration = True
 
     def _camera_rays(self, device):
         """[H*W,3] camera-frame directions, OpenGL (precompute(), :37-52)"""
@@ -50,6 +54,37 @@ class VoxFusion(Algorithm):
                  -torch.ones_like(ix)], -1).float().reshape(-1, 3)
         return self._rays_cam
 
+    # the iteration's shapes depend on the window only through its length:
+    # mapping graphs are kept from call to call (static frame slots, map
+    # arrays updated in place, capacities keyed by capacity_version)
+    persistent_map_graph = True
+
+    def map_slot_key(self, n_iters, optimize_frames, coarse):
+        if not self.fused_iteration:
+            return None
+        f = optimize_frames[-1]
+        return (len(optimize_frames), n_iters, f.h, f.w, f.separate_LR,
+                f.rot_rep, self.config.mapping_sample,
+                self.model.capacity_version)
+
+    def track_slot_key(self):
+        return (self.model.capacity_version, self.fused_iteration)
+
+    def _graphs_ok(self, optimizers, is_mapping):
+        # the modular path syncs the host (hit counts, ragged lengths)
+        return self.fused_iteration and super()._graphs_ok(optimizers,
+                                                           is_mapping)
+
+    def optimize_update(self, n_iters, optimize_frames, is_mapping,
+                        coarse=False):
+        out = super().optimize_update(n_iters, optimize_frames, is_mapping,
+                                      coarse=coarse)
+        if self.fused_iteration:
+            # one read of the last batch's size record per call: grows the
+            # static capacities (and retires the graphs) if it did not fit
+            self.last_batch_sizes = self.model.check_capacity()
+        return out
+
     # -- hooks ---------------------------------------------------------------------
     def get_model_input(self, optimize_frames, is_mapping):
         cfg, dev = self.config, self.model.device
@@ -61,6 +96,8 @@ class VoxFusion(Algorithm):
         gen = _dist.state.shard_generator if sharded else None
         if sharded:
             n = _dist.state.shard_count(n)
+        if torch.device(dev).type == 'cuda' and self.fused_iteration:
+            return self._model_input_kernels(optimize_frames, n, gen, sharded)
         ro, rd, gd, gc = [], [], [], []
         for f in optimize_frames:
             o, d, dep, col = get_samples(self.camera, n, f.get_pose(), f.depth,
@@ -72,6 +109,24 @@ class VoxFusion(Algorithm):
             gc.append(col.float())
         return {'rays_o': torch.cat(ro), 'rays_d': torch.cat(rd),
                 'target_s': torch.cat(gc), 'target_d': torch.cat(gd),
+                'sharded': sharded}
+
+    def _model_input_kernels(self, frames, n, gen, sharded):
+        """get_samples of every window frame (common.py:188-227: pixels drawn
+        with replacement over the whole image, OpenGL rays through the frame's
+        pose) as one index draw + one launch per frame, differentiable w.r.t.
+        the poses (engine/slam_ops.SampleRaysFn)"""
+        from ...engine.slam_ops import SampleRaysFn
+        cam, dev = self.camera, self.model.device
+        idx = torch.randint(cam.height * cam.width, (len(frames), n),
+                            device=dev, generator=gen)
+        c2ws = torch.stack([f.get_pose().to(dev) for f in frames])
+        imgs = [f.device_images(dev) for f in frames]
+        big = 1e30
+        ro, rd, td, tc, _, _ = SampleRaysFn.apply(
+            c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
+            (0, 0, cam.width), (-big, big, -big, big, -big, big))
+        return {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
                 'sharded': sharded}
 
     def create_voxels(self, frame):
@@ -98,6 +153,11 @@ class VoxFusion(Algorithm):
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):
         inp = self.get_model_input(optimize_frames, is_mapping)
+        if self.fused_iteration and not inp['sharded']:
+            fused = self.model.fused_loss(inp, is_mapping)
+            if fused is not None:
+                self.last_loss_terms = fused[1]
+                return fused[0]
         out = self.model(inp)
         losses = self.model.get_loss_dict(out, inp, is_mapping, step)
         return functools.reduce(torch.add, losses.values())

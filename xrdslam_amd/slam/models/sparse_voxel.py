@@ -70,6 +70,13 @@ class SparseVoxel(Model):
                                self.config.voxel_size)
         self.map_states = None
         self.noise_fn = vh._uniform_noise  # replaceable for parity tests
+        # static capacities of the fused ray pipeline: sample slots per ray
+        # and mean points per ray (grown by check_capacity when a batch does
+        # not fit); capacity_version keys captured graphs
+        self.s_cap = 256
+        self.pts_per_ray = 96
+        self.capacity_version = 0
+        self._workspaces = {}
 
     def populate_modules(self):
         super().populate_modules()
@@ -265,17 +272,103 @@ class SparseVoxel(Model):
 
     @torch.enable_grad()
     def update_map_states(self):
-        """flat octree arrays on the device (:342-357)"""
+        """flat octree arrays on the device (:342-357).  They live in
+        capacity buffers that are updated IN PLACE (the octree only grows), so
+        that captured graphs keep valid addresses from frame to frame; the
+        buffers are re-allocated (and ``capacity_version`` bumped, which
+        retires the graphs) only when the node count outgrows them."""
         dev = self.embeddings.device
         voxels, children, features = self.svo.get_centres_and_children()
         centres = (voxels[:, :3] + voxels[:, -1:] / 2) * self.config.voxel_size
         children = torch.cat([children, voxels[:, -1:]], -1)
-        state = {'voxel_vertex_idx': features.to(dev),
-                 'voxel_center_xyz': centres.to(dev).float(),
-                 'voxel_structure': children.to(dev).int(),
+        T = voxels.shape[0]
+        buf = getattr(self, '_map_buf', None)
+        if buf is None or buf['cap'] < T or buf['device'] != dev:
+            cap = max(4096, 2 * T)
+            buf = {'cap': cap, 'device': dev,
+                   'vertex': torch.full((cap, 8), -1, dtype=torch.int32,
+                                        device=dev),
+                   'centres': torch.zeros(cap, 3, device=dev),
+                   'structure': torch.full((cap, 9), -1, dtype=torch.int32,
+                                           device=dev)}
+            self._map_buf = buf
+            self.capacity_version += 1
+        buf['vertex'][:T].copy_(features.to(dev), non_blocking=True)
+        buf['centres'][:T].copy_(centres.float().to(dev), non_blocking=True)
+        buf['structure'][:T].copy_(children.int().to(dev), non_blocking=True)
+        state = {'voxel_vertex_idx': buf['vertex'][:T],
+                 'voxel_center_xyz': buf['centres'][:T],
+                 'voxel_structure': buf['structure'][:T],
                  'voxel_vertex_emb': self.embeddings}
         with self.map_lock:
             self.map_states = state
+
+    # -- fused iteration (engine/vox.py, csrc/vox_rays.hip) ---------------------
+    def ray_workspace(self, n_rays, need_w):
+        """static buffers of one ray-batch shape at the current capacities"""
+        from ...engine import vox as _vox
+        key = (n_rays, self.s_cap, self.pts_per_ray, bool(need_w))
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = _vox.RayWorkspace(n_rays, self.s_cap,
+                                   n_rays * self.pts_per_ray, need_w,
+                                   self.embeddings.device)
+            self._workspaces[key] = ws
+        self._last_ws = ws
+        return ws
+
+    def draw_noise(self, ws):
+        """the sampler's uniform draws, one row per ray (None = fixed 0.5)"""
+        if self.noise_fn is None:
+            return None
+        return self.noise_fn((ws.n, ws.s_cap), ws.s_depth)
+
+    def fused_loss(self, inputs, is_mapping):
+        """get_outputs + get_loss_dict of one ray batch as a fixed sequence of
+        launches without a host sync -> (summed loss, [rgb, depth, sdf, fs,
+        sum]) or None when the kernels do not cover the configuration"""
+        from ...engine import vox as _vox
+        if not inputs['rays_o'].is_cuda or \
+                _vox.decoder_params(self.decoder) is None:
+            return None
+        need_w = is_mapping and torch.is_grad_enabled()
+        ws = self.ray_workspace(inputs['rays_o'].shape[0], need_w)
+        out = _vox.render_loss(
+            self.decoder, ws, self.map_states, self.config, inputs['rays_o'],
+            inputs['rays_d'], inputs['target_d'], inputs['target_s'],
+            self.draw_noise(ws), map_grads=need_w)
+        return out[0], out[1]
+
+    def check_capacity(self):
+        """one device->host read of the last batch's size record; grows the
+        static capacities when a batch did not fit (its result was computed
+        on the truncated samples) and retires graphs captured on the old
+        shapes.  Returns the record."""
+        ws = getattr(self, '_last_ws', None)
+        if ws is None:
+            return None
+        bits, meta = ws.overflow()
+        if bits & 4:
+            raise RuntimeError('vox sampler produced a sample row with a '
+                               'hole: the fused compaction assumes prefixes')
+        if bits & 8:
+            raise RuntimeError('octree traversal stack overflow')
+        grown = False
+        if bits & 1:
+            self.s_cap = int(-(-meta[2] * 5 // 4 // 64) * 64)
+            grown = True
+        if bits & 2:
+            per_ray = -(-int(ws.offs[-1]) // ws.n)
+            self.pts_per_ray = int(-(-per_ray * 5 // 4 // 16) * 16)
+            grown = True
+        if grown:
+            self.capacity_version += 1
+            self._workspaces.clear()
+            self._last_ws = None
+        return {'n_hit_rays': meta[1], 'max_hits': meta[0],
+                'row_len': meta[2], 's_max': meta[3], 'n_pts': meta[4],
+                'grown': grown, 's_cap': self.s_cap,
+                'pts_per_ray': self.pts_per_ray}
 
     def get_map_states(self):
         with self.map_lock:
