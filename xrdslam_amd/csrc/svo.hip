@@ -7,11 +7,13 @@
 // quirks) follow the reference exactly; voxel ids are bit-exact against
 // oracle/svo_oracle.c.  What is different is the mapping to the machine:
 //   * the reference launches <<<B, 2^floor(log2 M)>>> — 4 threads per block
-//     for 1024 rays — and needs the octree replicated B times; here one thread
-//     owns one ray in 64-thread blocks over a 2-D grid, and a tree may be
-//     shared by all batches (tree_batch_stride = 0);
+//     for 1024 rays — and needs the octree replicated B times; here one WAVE
+//     owns one ray (the 8 children of a node are tested on 8 lanes), a 2-D
+//     grid covers rays x batches, and a tree may be shared by all batches
+//     (tree_batch_stride = 0);
 //   * the DFS stack (int[256] of scratch per thread in the reference) lives in
-//     LDS, transposed so that a wave's pushes hit 64 different banks.
+//     LDS and holds only nodes the ray is known to enter, with their slab
+//     depths.
 #include "common.h"
 #include "svo_sample.h"
 
@@ -48,17 +50,26 @@ __device__ __forceinline__ void ray_aabb(const float (&o)[3],
   hi = f_high;
 }
 
-__global__ __launch_bounds__(kRaysPerBlock) void svo_intersect_kernel(
+// One WAVE per ray.  The reference pops a node, tests its box and pushes all
+// of its children; here the 8 children of a popped node are tested at once on
+// lanes 0-7 and only the ones the ray enters are pushed, in child order — the
+// nodes whose boxes are hit are therefore visited in the same LIFO order, and
+// leaves are recorded in the same order with the same (lo, hi), while a ray
+// takes one serial step per HIT internal node instead of one per node looked
+// at (8x fewer dependent loads).
+__global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
     int n, int m, float voxelsize, int n_max, int64_t tree_stride,
     const float* __restrict__ ray_start, const float* __restrict__ ray_dir,
     const float* __restrict__ points, const int* __restrict__ children,
     int* __restrict__ idx, float* __restrict__ min_depth,
     float* __restrict__ max_depth, int* __restrict__ overflow) {
-  __shared__ int stack[kStack][kRaysPerBlock];
+  __shared__ int s_node[4][kStack];
+  __shared__ int s_side[4][kStack];
+  __shared__ float s_lo[4][kStack], s_hi[4][kStack];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.y;
-  const int j = blockIdx.x * kRaysPerBlock + threadIdx.x;
+  const int j = blockIdx.x * 4 + wave;
   if (j >= m) return;
-  const int lane = threadIdx.x;
   const float* P = points + (int64_t)bi * tree_stride * 3;
   const int* C = children + (int64_t)bi * tree_stride * 9;
   const int64_t rbase = ((int64_t)bi * m + j);
@@ -71,37 +82,64 @@ __global__ __launch_bounds__(kRaysPerBlock) void svo_intersect_kernel(
   int* I = idx + rbase * n_max;
   float* MN = min_depth + rbase * n_max;
   float* MX = max_depth + rbase * n_max;
-  for (int l = 0; l < n_max; ++l) I[l] = -1;
   const float half_voxel = voxelsize * 0.5;
-  int ptr = 0, cnt = 0;
-  stack[0][lane] = 0;  // root is node 0
-  while (ptr > -1 && cnt < n_max) {
-    const int k = stack[ptr][lane];
-    const int side = C[k * 9 + 8];
+  int ptr = -1, cnt = 0;
+  {  // root is node 0
+    const int side = C[8];
     float lo, hi;
-    ray_aabb(o, d, P + k * 3, half_voxel * (float)side, lo, hi);
-    ptr--;
+    ray_aabb(o, d, P, half_voxel * (float)side, lo, hi);
     if (lo > -1.0f) {
-      if (side == 1) {  // terminal node
-        I[cnt] = k;
-        MN[cnt] = lo;
-        MX[cnt] = hi;
-        ++cnt;
-        continue;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = C[k * 9 + u];
-        if (c > -1) {
-          if (ptr + 1 >= kStack) {
-            if (overflow) *overflow = 1;
-          } else {
-            stack[++ptr][lane] = c;
-          }
-        }
+      ptr = 0;
+      if (lane == 0) {
+        s_node[wave][0] = 0;
+        s_side[wave][0] = side;
+        s_lo[wave][0] = lo;
+        s_hi[wave][0] = hi;
       }
     }
   }
+  wave_lds_sync();
+  while (ptr > -1 && cnt < n_max) {
+    const int k = s_node[wave][ptr];
+    const int side = s_side[wave][ptr];
+    if (side == 1) {  // terminal node
+      if (lane == 0) {
+        I[cnt] = k;
+        MN[cnt] = s_lo[wave][ptr];
+        MX[cnt] = s_hi[wave][ptr];
+      }
+      ++cnt;
+      --ptr;
+      continue;
+    }
+    --ptr;
+    int c = -1, cs = 0;
+    float lo = -1.f, hi = -1.f;
+    if (lane < 8) {
+      c = C[k * 9 + lane];
+      if (c > -1) {
+        cs = C[c * 9 + 8];
+        ray_aabb(o, d, P + c * 3, half_voxel * (float)cs, lo, hi);
+      }
+    }
+    const uint64_t mask = __ballot(c > -1 && lo > -1.0f);
+    const int n_push = __popcll(mask);
+    if (ptr + 1 + n_push > kStack) {
+      if (overflow && lane == 0) *overflow = 1;
+      break;
+    }
+    wave_lds_sync();  // every lane has read the popped entry
+    if ((mask >> lane) & 1) {
+      const int at = ptr + 1 + __popcll(mask & ((1ull << lane) - 1));
+      s_node[wave][at] = c;
+      s_side[wave][at] = cs;
+      s_lo[wave][at] = lo;
+      s_hi[wave][at] = hi;
+    }
+    ptr += n_push;
+    wave_lds_sync();
+  }
+  for (int l = cnt + lane; l < n_max; l += 64) I[l] = -1;  // unused slots
   (void)n;
 }
 
@@ -163,8 +201,8 @@ int xrd_svo_intersect(int b, int n_nodes, int m_rays, float voxelsize,
       !max_depth)
     return XRD_ERR_ARG;
   if (b > 65535) return XRD_ERR_UNSUPPORTED;
-  const dim3 grid((m_rays + kRaysPerBlock - 1) / kRaysPerBlock, b);
-  hipLaunchKernelGGL(svo_intersect_kernel, grid, dim3(kRaysPerBlock), 0,
+  const dim3 grid((m_rays + 3) / 4, b);
+  hipLaunchKernelGGL(svo_intersect_kernel, grid, dim3(kRaysPerBlock * 4), 0,
                      (hipStream_t)stream, n_nodes, m_rays, voxelsize, n_max,
                      (int64_t)(tree_shared ? 0 : n_nodes), ray_start, ray_dir,
                      points, children, idx, min_depth, max_depth,

@@ -53,10 +53,13 @@ enum Meta {
   M_LEN = 16
 };
 
-constexpr int kWaves = 4;          // rays per block
+constexpr int kWaves = 8;          // rays per block
 constexpr float kPadDepth = 10.f;  // MAX_DEPTH of the padded samples
 constexpr int kGroups = 200;       // G of InverseCDFRaySampling.forward
 
+// Per-ray contributions to the size record go through LDS first: one global
+// atomic per block and counter instead of one per ray (thousands of atomics
+// on ONE address serialise in L2 — measured 35-65 us a kernel at 6144 rays).
 __global__ void vox_meta_reset_kernel(int* meta, double* acc) {
   if (threadIdx.x < M_LEN) meta[threadIdx.x] = 0;
   if (threadIdx.x < 4) acc[threadIdx.x] = 0.0;
@@ -72,11 +75,14 @@ __global__ __launch_bounds__(kWaves * 64) void vox_hit_sort_kernel(
     int* __restrict__ hit, int* __restrict__ meta) {
   __shared__ int s_id[kWaves][64];
   __shared__ float s_a[kWaves][64], s_b[kWaves][64];
+  __shared__ int red[2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * kWaves + wave;
-  if (ray >= n_rays) return;
-  const int64_t row = (int64_t)ray * n_max;
-  const bool in = lane < n_max;
+  if (threadIdx.x < 2) red[threadIdx.x] = 0;
+  __syncthreads();
+  const bool live = ray < n_rays;
+  const int64_t row = (int64_t)(live ? ray : 0) * n_max;
+  const bool in = live && lane < n_max;
   int id = in ? idx[row + lane] : -1;
   float a = in ? mn[row + lane] : 0.f, b = in ? mx[row + lane] : 0.f;
   if (id == -1) a = b = max_distance;
@@ -112,16 +118,19 @@ __global__ __launch_bounds__(kWaves * 64) void vox_hit_sort_kernel(
     mx[row + lane] = b;
     probs[row + lane] = len / sum;
   }
-  if (lane == 0) {
+  if (live && lane == 0) {
     // torch divides by a python scalar as a multiplication with its reciprocal
     const float st = sum * inv_step;
     steps[ray] = st;
     hit[ray] = count > 0 ? 1 : 0;
     if (count > 0) {
-      atomicMax(meta + M_NHITCOL, count);
-      atomicMax(meta + M_MAXCEIL, (int)ceilf(st));
+      atomicMax(&red[0], count);
+      atomicMax(&red[1], (int)ceilf(st));
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && red[0] > 0) atomicMax(meta + M_NHITCOL, red[0]);
+  if (threadIdx.x == 1 && red[1] > 0) atomicMax(meta + M_MAXCEIL, red[1]);
 }
 
 // exclusive scan of v[0..n) by ONE block of 1024 threads; out[n] = total
@@ -178,19 +187,22 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
     int* __restrict__ meta, int* __restrict__ s_idx,
     float* __restrict__ s_depth, int* __restrict__ cnt) {
   __shared__ float cum_s[kWaves][64];
+  __shared__ int red[2];   // longest row, overflow bits
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * kWaves + wave;
-  if (ray >= n_rays) return;
-  int* SI = s_idx + (int64_t)ray * s_cap;
-  float* SD = s_depth + (int64_t)ray * s_cap;
-  for (int s = lane; s < s_cap; s += 64) {
-    SI[s] = -1;
-    SD[s] = kPadDepth;
-  }
-  if (!hit[ray]) {
-    if (lane == 0) cnt[ray] = 0;
-    return;
-  }
+  if (threadIdx.x < 2) red[threadIdx.x] = 0;
+  __syncthreads();
+  const bool live = ray < n_rays;
+  int* SI = s_idx + (int64_t)(live ? ray : 0) * s_cap;
+  float* SD = s_depth + (int64_t)(live ? ray : 0) * s_cap;
+  if (live)
+    for (int s = lane; s < s_cap; s += 64) {
+      SI[s] = -1;
+      SD[s] = kPadDepth;
+    }
+  const bool work = live && hit[ray] != 0;
+  if (live && !work && lane == 0) cnt[ray] = 0;
+  if (work) {
   __threadfence();  // the row initialisation lands before any sample
   const int n_hit_rays = meta[M_NHITRAYS];
   const int P = meta[M_NHITCOL];
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
   const int H = j * P;
   int max_steps = meta[M_MAXSTEPS];
   if (max_steps > s_cap) {
-    if (lane == 0) atomicOr(meta + M_OVERFLOW, 1);
+    if (lane == 0) atomicOr(&red[1], 1);
     max_steps = s_cap;
   }
   const int* own = idx + (int64_t)ray * n_max;
@@ -244,9 +256,13 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
     if (SI[s] == -1) SD[s] = kPadDepth;
   if (lane == 0) {
     cnt[ray] = count;
-    atomicMax(meta + M_SMAX, count);
-    if (last + 1 != count) atomicOr(meta + M_OVERFLOW, 4);
+    atomicMax(&red[0], count);
+    if (last + 1 != count) atomicOr(&red[1], 4);
   }
+  }  // work
+  __syncthreads();
+  if (threadIdx.x == 0 && red[0] > 0) atomicMax(meta + M_SMAX, red[0]);
+  if (threadIdx.x == 1 && red[1] != 0) atomicOr(meta + M_OVERFLOW, red[1]);
 }
 
 __global__ __launch_bounds__(1024) void vox_point_scan_kernel(
@@ -269,9 +285,12 @@ __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
     const int* __restrict__ cnt, const int* __restrict__ offs,
     const int* __restrict__ s_idx, const float* __restrict__ s_depth,
     float* __restrict__ xyz, int* __restrict__ vox, int* __restrict__ meta) {
+  __shared__ int red[3];   // front, band, usable-depth counts
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * kWaves + wave;
-  if (ray >= n_rays || !hit[ray]) return;
+  if (threadIdx.x < 3) red[threadIdx.x] = 0;
+  __syncthreads();
+  if (ray < n_rays && hit[ray]) {
   const int s_max = meta[M_SMAX] < s_cap ? meta[M_SMAX] : s_cap;
   const int n = cnt[ray];
   const int64_t p0 = offs[ray];
@@ -299,10 +318,14 @@ __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
     n_mid += __popcll(__ballot(in && !front && !back && td > 0.f));
   }
   if (lane == 0) {
-    if (n_front) atomicAdd(meta + M_NFRONT, n_front);
-    if (n_mid) atomicAdd(meta + M_NMID, n_mid);
-    if (td > 0.01f && td < max_depth) atomicAdd(meta + M_NVALID, 1);
+    if (n_front) atomicAdd(&red[0], n_front);
+    if (n_mid) atomicAdd(&red[1], n_mid);
+    if (td > 0.01f && td < max_depth) atomicAdd(&red[2], 1);
   }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && red[threadIdx.x] != 0)
+    atomicAdd(meta + M_NFRONT + threadIdx.x, red[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------- compositing
@@ -397,10 +420,12 @@ __global__ __launch_bounds__(kWaves * 64) void vox_render_fwd_kernel(
     const int* __restrict__ meta, float* __restrict__ depth_out,
     float* __restrict__ rgb_out, float* __restrict__ zmin_out,
     float* __restrict__ weights_out, double* __restrict__ acc) {
+  __shared__ float part[kWaves][4];   // this block's loss sums, per ray
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * kWaves + wave;
-  if (ray >= a.n_rays) return;
-  if (!hit[ray]) {
+  if (lane < 4) part[wave][lane] = 0.f;
+  const bool live = ray < a.n_rays;
+  if (live && !hit[ray]) {
     if (lane == 0) {
       depth_out[ray] = 0.f;
       rgb_out[ray * 3] = rgb_out[ray * 3 + 1] = rgb_out[ray * 3 + 2] = 0.f;
@@ -409,65 +434,75 @@ __global__ __launch_bounds__(kWaves * 64) void vox_render_fwd_kernel(
     if (weights_out)
       for (int s = lane; s < a.s_cap; s += 64)
         weights_out[(int64_t)ray * a.s_cap + s] = 0.f;
-    return;
   }
-  RayView v;
-  v.n = cnt[ray];
-  v.s_max = meta[M_SMAX] < a.s_cap ? meta[M_SMAX] : a.s_cap;
-  v.p0 = offs[ray];
-  v.p_cap = a.p_cap;
-  v.z = s_depth + (int64_t)ray * a.s_cap;
-  v.sdf = sdf_pt;
-  float z_min, U, rgb[3], depth;
-  composite_ray(v, lane, rgb_pt, a.inv_trunc, a.trunc, z_min, U, rgb, depth);
-  if (lane == 0) {
-    depth_out[ray] = depth;
-    rgb_out[ray * 3] = rgb[0];
-    rgb_out[ray * 3 + 1] = rgb[1];
-    rgb_out[ray * 3 + 2] = rgb[2];
-    if (zmin_out) zmin_out[ray] = z_min;
-  }
-  if (weights_out) {
-    const float den = U + 1e-8f, z_cut = z_min + a.trunc;
-    for (int s = lane; s < a.s_cap; s += 64) {
-      float w = 0.f;
-      if (v.live(s)) {
-        const float sd = v.sdf[v.p0 + s];
-        const float b =
-            sigmoidf(sd * a.inv_trunc) * sigmoidf(-sd * a.inv_trunc);
-        w = (v.z[s] < z_cut ? b : 0.f) / den;
+  if (live && hit[ray]) {
+    RayView v;
+    v.n = cnt[ray];
+    v.s_max = meta[M_SMAX] < a.s_cap ? meta[M_SMAX] : a.s_cap;
+    v.p0 = offs[ray];
+    v.p_cap = a.p_cap;
+    v.z = s_depth + (int64_t)ray * a.s_cap;
+    v.sdf = sdf_pt;
+    float z_min, U, rgb[3], depth;
+    composite_ray(v, lane, rgb_pt, a.inv_trunc, a.trunc, z_min, U, rgb, depth);
+    if (lane == 0) {
+      depth_out[ray] = depth;
+      rgb_out[ray * 3] = rgb[0];
+      rgb_out[ray * 3 + 1] = rgb[1];
+      rgb_out[ray * 3 + 2] = rgb[2];
+      if (zmin_out) zmin_out[ray] = z_min;
+    }
+    if (weights_out) {
+      const float den = U + 1e-8f, z_cut = z_min + a.trunc;
+      for (int s = lane; s < a.s_cap; s += 64) {
+        float w = 0.f;
+        if (v.live(s)) {
+          const float sd = v.sdf[v.p0 + s];
+          const float b =
+              sigmoidf(sd * a.inv_trunc) * sigmoidf(-sd * a.inv_trunc);
+          w = (v.z[s] < z_cut ? b : 0.f) / den;
+        }
+        weights_out[(int64_t)ray * a.s_cap + s] = w;
       }
-      weights_out[(int64_t)ray * a.s_cap + s] = w;
     }
-  }
-  if (acc == nullptr) return;
-  // the four loss sums of this ray (get_loss_dict :103-143)
-  const float td = target_d[ray];
-  const float wv = (td > 0.01f && td < a.max_depth) ? 1.f : 0.f;
-  const float lo = td - a.trunc, hi = td + a.trunc;
-  float fs = 0.f, sd2 = 0.f;
-  for (int s0 = 0; s0 < v.s_max; s0 += 64) {
-    const int s = s0 + lane;
-    if (s >= v.s_max) continue;
-    const float z = v.z_at(s), sd = v.sdf_at(s);
-    const bool front = z < lo, back = z > hi;
-    if (front) fs += (sd - 1.f) * (sd - 1.f);
-    if (!front && !back && td > 0.f) {
-      const float e = (z + sd * a.trunc) - td;
-      sd2 += e * e;
-    }
-  }
-  fs = wave_sum(fs);
-  sd2 = wave_sum(sd2);
-  if (lane == 0) {
-    float l_rgb = 0.f;
+    if (acc != nullptr) {
+      // the four loss sums of this ray (get_loss_dict :103-143)
+      const float td = target_d[ray];
+      const float wv = (td > 0.01f && td < a.max_depth) ? 1.f : 0.f;
+      const float lo = td - a.trunc, hi = td + a.trunc;
+      float fs = 0.f, sd2 = 0.f;
+      for (int s0 = 0; s0 < v.s_max; s0 += 64) {
+        const int s = s0 + lane;
+        if (s >= v.s_max) continue;
+        const float z = v.z_at(s), sd = v.sdf_at(s);
+        const bool front = z < lo, back = z > hi;
+        if (front) fs += (sd - 1.f) * (sd - 1.f);
+        if (!front && !back && td > 0.f) {
+          const float e = (z + sd * a.trunc) - td;
+          sd2 += e * e;
+        }
+      }
+      fs = wave_sum(fs);
+      sd2 = wave_sum(sd2);
+      if (lane == 0) {
+        float l_rgb = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      l_rgb += fabsf(rgb[k] * wv - target_rgb[ray * 3 + k] * wv);
-    atomicAdd(acc + 0, (double)l_rgb);
-    if (wv != 0.f) atomicAdd(acc + 1, (double)fabsf(depth - td));
-    if (fs != 0.f) atomicAdd(acc + 2, (double)fs);
-    if (sd2 != 0.f) atomicAdd(acc + 3, (double)sd2);
+        for (int k = 0; k < 3; ++k)
+          l_rgb += fabsf(rgb[k] * wv - target_rgb[ray * 3 + k] * wv);
+        part[wave][0] = l_rgb;
+        part[wave][1] = wv != 0.f ? fabsf(depth - td) : 0.f;
+        part[wave][2] = fs;
+        part[wave][3] = sd2;
+      }
+    }
+  }
+  if (acc == nullptr) return;   // uniform over the grid
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) t += (double)part[w][threadIdx.x];
+    if (t != 0.0) atomicAdd(acc + threadIdx.x, t);
   }
 }
 
