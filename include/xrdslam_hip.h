@@ -281,9 +281,8 @@ int xrd_inverse_cdf_sampling(int b, int num_rays, int max_hits, int max_steps,
  *   the points: dW = G^T A (engine/vox.py runs them in rocBLAS).
  * n_points_dev (NULL = unused): static-capacity launches (captured graphs) —
  *   n_points is the CAPACITY of the arrays and the live count is read from
- *   this device int (clamped to [0, n_points]); the backward zeroes the rows
- *   [count, n_points) of g_c3 / g_hc / g_f / g_h2 / g_h1 so that the GEMMs may
- *   run over the whole capacity.
+ *   this device int (clamped to [0, n_points]); rows beyond it are neither
+ *   read nor written.
  * ---------------------------------------------------------------------- */
 int xrd_vox_flat_len(void);
 int xrd_vox_pack_len(void);
@@ -305,6 +304,21 @@ int xrd_vox_points_bwd(int64_t n_points, const float* xyz,
                        float* g_c3, float* g_hc, float* g_f, float* g_h2,
                        float* g_h1, const int32_t* n_points_dev,
                        xrd_stream_t stream);
+
+/* The decoder's weight gradients from the operands above (autograd of
+ * decoder_voxfusion.py:123-149): dW = G^T A contracted over the points on
+ * MFMA, bias gradients = column sums.  g_flat [xrd_vox_flat_len()] receives
+ * the ten tensors in state_dict order (pts_linears.0.weight [128,16], .bias,
+ * pts_linears.1.weight [128,128], .bias, sdf_out.weight [129,128], .bias,
+ * color_out.0.weight [128,144], .bias, color_out.2.weight [3,128], .bias);
+ * workspace: xrd_vox_dw_ws_floats() floats.  n_points_dev as above. */
+int64_t xrd_vox_dw_ws_floats(void);
+int xrd_vox_dw(int64_t n_points, const int32_t* n_points_dev,
+               const float* save_x, const float* save_h1, const float* save_h2,
+               const float* save_f, const float* save_hc, const float* g_c3,
+               const float* g_hc, const float* g_f, const float* g_h2,
+               const float* g_h1, float* workspace, float* g_flat,
+               xrd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Vox-Fusion ray pipeline with STATIC capacities (csrc/vox_rays.hip) — what

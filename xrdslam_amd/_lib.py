@@ -94,6 +94,8 @@ _SIGS = {
                            [vp] * 11),
     'xrd_vox_points_bwd': (C.c_int, [i64, vp, vp, vp, vp, vp, f32] +
                            [vp] * 14),
+    'xrd_vox_dw_ws_floats': (i64, []),
+    'xrd_vox_dw': (C.c_int, [i64] + [vp] * 14),
     'xrd_vox_meta_len': (C.c_int, []),
     'xrd_vox_sample_rays': (C.c_int, [C.c_int, C.c_int, C.c_int, i64, C.c_int,
                                       vp, vp, f32, f32, f32, f32, f32] +

@@ -252,7 +252,6 @@ __global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
     float* __restrict__ ghc, float* __restrict__ gf, float* __restrict__ gh2,
     float* __restrict__ gh1, const int* __restrict__ n_dev) {
   using K = VoxPack;
-  const int64_t P_cap = P;
   if (n_dev != nullptr) P = *n_dev < P ? (*n_dev > 0 ? *n_dev : 0) : P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);
@@ -392,21 +391,6 @@ __global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
         if (valid && q == 0) g_xyz[pt * 3 + ax] = s;
       }
     }
-  }
-  // static-capacity launches: the weight-gradient GEMMs run over all P_cap
-  // rows, so the operand rows of the unused tail are zeroed
-  if (n_dev != nullptr && gh1 != nullptr) {
-    const int64_t r0 = P * 128, r1 = P_cap * 128;
-    for (int64_t i = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-         i < r1; i += (int64_t)gridDim.x * blockDim.x) {
-      ghc[i] = 0.f;
-      gf[i] = 0.f;
-      gh2[i] = 0.f;
-      gh1[i] = 0.f;
-    }
-    for (int64_t i = P * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-         i < P_cap * 4; i += (int64_t)gridDim.x * blockDim.x)
-      gc3[i] = 0.f;
   }
 }
 

@@ -8,8 +8,8 @@ reference (slam/models/sparse_voxel.py:230-238,
 voxel_helpers_voxfusion.py:109-123, decoder_voxfusion.py:123-149) for the
 model's default decoder (in_dim 16, width 128, depth 2, no positional
 encoding).  PyTorch is device memory + autograd plumbing; the decoder's weight
-gradients are five GEMMs over the points on the operands the backward kernel
-writes (rocBLAS through ``torch.mm``: plain library GEMMs)."""
+gradients are contracted over the points by xrd_vox_dw (csrc/vox_dw.hip) on
+the operands the forward / backward kernels leave in HBM."""
 from __future__ import annotations
 
 import ctypes as C
@@ -39,6 +39,22 @@ class _Timed:
         if self.key is not None:
             self.e1.record()
             PROFILE.setdefault(self.key, []).append((self.e0, self.e1))
+
+
+_PARAM_SHAPES = [(128, 16), (128, ), (128, 128), (128, ), (129, 128), (129, ),
+                 (128, 144), (128, ), (3, 128), (3, )]
+_PARAM_SIZES = [int(np.prod(s_)) for s_ in _PARAM_SHAPES]
+_dw_ws = {}
+
+
+def dw_workspace(device) -> torch.Tensor:
+    """per-block partials of xrd_vox_dw (one buffer per device; the kernel
+    pair that uses it runs on one stream)"""
+    key = str(device)
+    if key not in _dw_ws:
+        _dw_ws[key] = torch.empty(_lib.lib().xrd_vox_dw_ws_floats(),
+                                  dtype=torch.float32, device=device)
+    return _dw_ws[key]
 
 
 def pack_index(device) -> torch.Tensor:
@@ -142,14 +158,18 @@ class _VoxPointsFn(torch.autograd.Function):
             _lib.stream_ptr(dev)), 'xrd_vox_points_bwd')
         gp = [None] * 10
         if need_w:
-            # dW = G^T A over the points (plain GEMMs)
-            gout = torch.cat([gc3[:, 3:4], gf], 1)          # [P,129]
-            gp = [gh1.t() @ sx, gh1.sum(0), gh2.t() @ sh1, gh2.sum(0),
-                  gout.t() @ sh2, gout.sum(0),
-                  ghc.t() @ torch.cat([sf, sx], 1), ghc.sum(0),
-                  gc3[:, :3].t() @ shc, gc3[:, :3].sum(0)]
-            gp = [g if need else None
-                  for g, need in zip(gp, ctx.needs_input_grad[6:])]
+            # dW = G^T A over the points: xrd_vox_dw (csrc/vox_dw.hip)
+            flat = torch.empty(lib.xrd_vox_flat_len(), **f)
+            with _Timed(('vox_dw', P, True)):
+                _lib.check(lib.xrd_vox_dw(
+                    P, None, _lib.ptr(sx), _lib.ptr(sh1), _lib.ptr(sh2),
+                    _lib.ptr(sf), _lib.ptr(shc), _lib.ptr(gc3), _lib.ptr(ghc),
+                    _lib.ptr(gf), _lib.ptr(gh2), _lib.ptr(gh1),
+                    _lib.ptr(dw_workspace(dev)), _lib.ptr(flat),
+                    _lib.stream_ptr(dev)), 'xrd_vox_dw')
+            gp = [g.reshape(shp) if need else None for g, shp, need in zip(
+                flat.split(_PARAM_SIZES), _PARAM_SHAPES,
+                ctx.needs_input_grad[6:])]
         return (g_xyz, g_emb, None, None, None, None, *gp)
 
 
@@ -376,16 +396,19 @@ class _VoxRenderLossFn(torch.autograd.Function):
             g_o, g_d = ws.g_o, ws.g_d
         gp = [None] * 10
         if need_w:
-            with _Timed(('vox_weight_gemms', ws.p_cap)):
-                gout = torch.cat([ws.gc3[:, 3:4], ws.gf], 1)        # [P,129]
-                g3 = ws.gc3[:, :3]
-                gp = [ws.gh1.t() @ ws.sx, ws.gh1.sum(0),
-                      ws.gh2.t() @ ws.sh1, ws.gh2.sum(0),
-                      gout.t() @ ws.sh2, gout.sum(0),
-                      ws.ghc.t() @ torch.cat([ws.sf, ws.sx], 1),
-                      ws.ghc.sum(0), g3.t() @ ws.shc, g3.sum(0)]
-            gp = [g if need else None
-                  for g, need in zip(gp, ctx.needs_input_grad[9:])]
+            flat = torch.empty(lib.xrd_vox_flat_len(), dtype=torch.float32,
+                               device=dev)
+            with _Timed(('vox_dw', ws.p_cap, True)):
+                _lib.check(lib.xrd_vox_dw(
+                    ws.p_cap, ws.n_pts_dev, _lib.ptr(ws.sx), _lib.ptr(ws.sh1),
+                    _lib.ptr(ws.sh2), _lib.ptr(ws.sf), _lib.ptr(ws.shc),
+                    _lib.ptr(ws.gc3), _lib.ptr(ws.ghc), _lib.ptr(ws.gf),
+                    _lib.ptr(ws.gh2), _lib.ptr(ws.gh1),
+                    _lib.ptr(dw_workspace(dev)), _lib.ptr(flat), st),
+                    'xrd_vox_dw')
+            gp = [g.reshape(shp) if need else None for g, shp, need in zip(
+                flat.split(_PARAM_SIZES), _PARAM_SHAPES,
+                ctx.needs_input_grad[9:])]
         return (g_o if need_o else None, g_d if need_d else None, g_emb, None,
                 None, None, None, None, None, *gp)
 
