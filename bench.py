@@ -540,13 +540,17 @@ def run_voxfusion(args, dev, world=1):
             g_[1] += len(evs)
         per_launch = {f'{k[0]}[decoder_grad={int(k[1])}]': v[0] / v[1] * 1e3
                       for k, v in groups.items()}
-        (kern, need_w), (ms, calls) = max(groups.items(),
-                                          key=lambda kv: kv[1][0])
+        # the dominant MFMA launch (the ray-side launches are in launch_us)
+        (kern, need_w), (ms, calls) = max(
+            ((k, v) for k, v in groups.items()
+             if k[0].startswith(('vox_points', 'vox_dw'))),
+            key=lambda kv: kv[1][0])
         # live points of a launch: the size record of the probe's calls
         pts = np.mean([s_['n_pts'] for m_, s_ in log
                        if m_ == need_w and s_]) if log else 0.0
         bwd = kern.endswith('bwd')
         mlp = kern.startswith('vox_points')
+        dw = kern.startswith('vox_dw')
         flops = pts * VOX_FLOPS * (2 if bwd else 1)
         byts = pts * (VOX_BYTES + (1024 if bwd and need_w else 0))
         us = ms / calls * 1e3
@@ -557,7 +561,9 @@ def run_voxfusion(args, dev, world=1):
             'kernel': f'{kern}[decoder_grad={int(need_w)}]' + (
                 ' (launch: gather, trilinear feature, 16-128-128-129 / '
                 '144-128-3 decoder' + (', embedding scatter, dW operands'
-                                       if bwd else '') + ')' if mlp else ''),
+                                       if bwd else '') + ')' if mlp else
+                ' (launch: the five weight-gradient contractions over the '
+                'live points + bias sums)' if dw else ''),
             'avg_launch_us': us, 'launches': calls,
             'avg_points_per_launch': float(pts),
             'algorithmic_flops_per_point': VOX_FLOPS * (2 if bwd else 1),

@@ -203,18 +203,33 @@ __global__ __launch_bounds__(DW_WAVES * 64) void vox_dw_kernel(
   if (threadIdx.x == 3) out[F_BO] = S[3];
 }
 
+// flat[i] = sum over the live blocks of partial[b][i]: a block takes 64
+// columns x 4 groups of partials (independent chains), combined through LDS
 __global__ __launch_bounds__(256) void vox_dw_reduce_kernel(
     int64_t p_cap, const int* __restrict__ n_dev, int n_blocks,
     const float* __restrict__ partial, float* __restrict__ flat) {
+  __shared__ float red[4][64];
   int64_t n = p_cap;
   if (n_dev != nullptr) n = *n_dev < n ? (*n_dev > 0 ? *n_dev : 0) : n;
   const int64_t nchunks = (n + DW_CHUNK - 1) / DW_CHUNK;
   const int live = nchunks < n_blocks ? (int)nchunks : n_blocks;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= DW_LEN) return;
-  float s = 0.f;
-  for (int b = 0; b < live; ++b) s += partial[(int64_t)b * DW_LEN + i];
-  flat[i] = s;
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < DW_LEN) {
+    int b = grp;
+    for (; b + 12 < live; b += 16) {
+      s0 += partial[(int64_t)b * DW_LEN + i];
+      s1 += partial[(int64_t)(b + 4) * DW_LEN + i];
+      s2 += partial[(int64_t)(b + 8) * DW_LEN + i];
+      s3 += partial[(int64_t)(b + 12) * DW_LEN + i];
+    }
+    for (; b < live; b += 4) s0 += partial[(int64_t)b * DW_LEN + i];
+  }
+  red[grp][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < DW_LEN)
+    flat[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 }  // namespace
@@ -258,7 +273,7 @@ int xrd_vox_dw(int64_t n_points, const int32_t* n_points_dev,
                        save_f, save_hc, g_c3, g_hc, g_f, g_h2, g_h1,
                        workspace);
   }
-  hipLaunchKernelGGL(vox_dw_reduce_kernel, dim3((DW_LEN + 255) / 256),
+  hipLaunchKernelGGL(vox_dw_reduce_kernel, dim3((DW_LEN + 63) / 64),
                      dim3(256), 0, st, n_points, n_points_dev, nb, workspace,
                      g_flat);
   return check_launch("xrd_vox_dw");

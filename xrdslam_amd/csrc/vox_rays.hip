@@ -186,80 +186,87 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
     const int* __restrict__ rank, const int* __restrict__ hit_rays,
     int* __restrict__ meta, int* __restrict__ s_idx,
     float* __restrict__ s_depth, int* __restrict__ cnt) {
+  // the ray's sample row is assembled in LDS (scattered slot writes, then
+  // the count) and written out once, coalesced
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ float cum_s[kWaves][64];
   __shared__ int red[2];   // longest row, overflow bits
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * kWaves + wave;
+  int* LI = reinterpret_cast<int*>(smem_raw) + wave * s_cap;
+  float* LD = reinterpret_cast<float*>(smem_raw) + (kWaves + wave) * s_cap;
   if (threadIdx.x < 2) red[threadIdx.x] = 0;
   __syncthreads();
   const bool live = ray < n_rays;
-  int* SI = s_idx + (int64_t)(live ? ray : 0) * s_cap;
-  float* SD = s_depth + (int64_t)(live ? ray : 0) * s_cap;
-  if (live)
-    for (int s = lane; s < s_cap; s += 64) {
-      SI[s] = -1;
-      SD[s] = kPadDepth;
-    }
   const bool work = live && hit[ray] != 0;
   if (live && !work && lane == 0) cnt[ray] = 0;
   if (work) {
-  __threadfence();  // the row initialisation lands before any sample
-  const int n_hit_rays = meta[M_NHITRAYS];
-  const int P = meta[M_NHITCOL];
-  const int R = (n_hit_rays + kGroups - 1) / kGroups;  // rays per group
-  const int r = rank[ray];
-  const int g = r / R, j = r - g * R;
-  const int H = j * P;
-  int max_steps = meta[M_MAXSTEPS];
-  if (max_steps > s_cap) {
-    if (lane == 0) atomicOr(&red[1], 1);
-    max_steps = s_cap;
+    const int n_hit_rays = meta[M_NHITRAYS];
+    const int P = meta[M_NHITCOL];
+    const int R = (n_hit_rays + kGroups - 1) / kGroups;  // rays per group
+    const int r = rank[ray];
+    const int g = r / R, j = r - g * R;
+    const int H = j * P;
+    int max_steps = meta[M_MAXSTEPS];
+    if (max_steps > s_cap) {
+      if (lane == 0) atomicOr(&red[1], 1);
+      max_steps = s_cap;
+    }
+    for (int s = lane; s < max_steps; s += 64) {
+      LI[s] = -1;
+      LD[s] = kPadDepth;
+    }
+    wave_lds_sync();
+    const int* own = idx + (int64_t)ray * n_max;
+    const int64_t goff = (int64_t)g * R * P, total = (int64_t)kGroups * R * P;
+    const float* UN = noise ? noise + (int64_t)ray * s_cap : nullptr;
+    inverse_cdf_ray(
+        lane, cum_s[wave], P, R, H, mn + (int64_t)ray * n_max,
+        mx + (int64_t)ray * n_max, probs + (int64_t)ray * n_max, steps[ray],
+        -1.f,
+        [&](int i) -> int {
+          // flat index i of the group's [R, P] hit array
+          if (i >= H && i < H + P) return own[i - H];
+          if (goff + i >= total) return -1;
+          const int rr = i / P, col = i - rr * P;
+          // rows past the last hit ray are copies of the first one
+          const int q = g * R + rr;
+          const int src = hit_rays[q < n_hit_rays ? q : 0];
+          return idx[(int64_t)src * n_max + col];
+        },
+        [&](int c) -> float {
+          if (UN == nullptr || c >= s_cap) return 0.5f;
+          return fminf(fmaxf(UN[c], 0.001f), 0.999f);
+        },
+        [&](int slot, int id, float zhi, float zlo) {
+          if (slot < max_steps) {
+            LI[slot] = id;
+            LD[slot] = (zhi + zlo) * 0.5f;
+          }
+        });
+    wave_lds_sync();
+    // valid samples of the row (they form a prefix; anything else is
+    // reported); padded samples carry depth = MAX_DEPTH (ray_sample :709-711)
+    int* SI = s_idx + (int64_t)ray * s_cap;
+    float* SD = s_depth + (int64_t)ray * s_cap;
+    int count = 0, last = -1;
+    for (int s0 = 0; s0 < max_steps; s0 += 64) {
+      const int s = s0 + lane;
+      const int id = s < max_steps ? LI[s] : -1;
+      const uint64_t m = __ballot(id != -1);
+      count += __popcll(m);
+      if (m) last = s0 + 63 - __builtin_clzll(m);
+      if (s < max_steps) {
+        SI[s] = id;
+        SD[s] = id == -1 ? kPadDepth : LD[s];
+      }
+    }
+    if (lane == 0) {
+      cnt[ray] = count;
+      atomicMax(&red[0], count);
+      if (last + 1 != count) atomicOr(&red[1], 4);
+    }
   }
-  const int* own = idx + (int64_t)ray * n_max;
-  const int64_t goff = (int64_t)g * R * P, total = (int64_t)kGroups * R * P;
-  const float* UN = noise ? noise + (int64_t)ray * s_cap : nullptr;
-  inverse_cdf_ray(
-      lane, cum_s[wave], P, R, H, mn + (int64_t)ray * n_max,
-      mx + (int64_t)ray * n_max, probs + (int64_t)ray * n_max, steps[ray],
-      -1.f,
-      [&](int i) -> int {
-        // flat index i of the group's [R, P] hit array
-        const int rr = i / P, col = i - rr * P;
-        if (rr == j) return own[col];
-        if (goff + i >= total) return -1;
-        // rows past the last hit ray are copies of the first one
-        const int q = g * R + rr;
-        const int src = hit_rays[q < n_hit_rays ? q : 0];
-        return idx[(int64_t)src * n_max + col];
-      },
-      [&](int c) -> float {
-        if (UN == nullptr || c >= s_cap) return 0.5f;
-        return fminf(fmaxf(UN[c], 0.001f), 0.999f);
-      },
-      [&](int slot, int id, float zhi, float zlo) {
-        if (slot < max_steps) {
-          SI[slot] = id;
-          SD[slot] = (zhi + zlo) * 0.5f;
-        }
-      });
-  __threadfence();
-  // valid samples of the row (they form a prefix; anything else is reported)
-  int count = 0, last = -1;
-  for (int s0 = 0; s0 < max_steps; s0 += 64) {
-    const int s = s0 + lane;
-    const uint64_t m = __ballot(s < max_steps && SI[s] != -1);
-    count += __popcll(m);
-    if (m) last = s0 + 63 - __builtin_clzll(m);
-  }
-  // padded samples: depth = MAX_DEPTH (ray_sample, :709-711)
-  for (int s = lane; s < max_steps; s += 64)
-    if (SI[s] == -1) SD[s] = kPadDepth;
-  if (lane == 0) {
-    cnt[ray] = count;
-    atomicMax(&red[0], count);
-    if (last + 1 != count) atomicOr(&red[1], 4);
-  }
-  }  // work
   __syncthreads();
   if (threadIdx.x == 0 && red[0] > 0) atomicMax(meta + M_SMAX, red[0]);
   if (threadIdx.x == 1 && red[1] != 0) atomicOr(meta + M_OVERFLOW, red[1]);
@@ -668,6 +675,7 @@ int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
   if (n_rays < 0 || n_max < 1 || n_max > 64 || s_cap < 1 || p_cap < 1 ||
       !(step_size > 0.f))
     return XRD_ERR_ARG;
+  if (s_cap > 1024) return XRD_ERR_UNSUPPORTED;  // sample rows live in LDS
   if (!meta || !loss_acc) return XRD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(vox_meta_reset_kernel, dim3(1), dim3(64), 0, st, meta,
@@ -690,7 +698,8 @@ int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
                      probs, steps, hit, meta);
   hipLaunchKernelGGL(vox_ray_scan_kernel, dim3(1), dim3(1024), 0, st, n_rays,
                      hit, rank, hit_rays, meta);
-  hipLaunchKernelGGL(vox_sample_kernel, grid, block, 0, st, n_rays, n_max,
+  hipLaunchKernelGGL(vox_sample_kernel, grid, block,
+                     (size_t)kWaves * s_cap * 8, st, n_rays, n_max,
                      s_cap, hit_idx, hit_min, hit_max, probs, steps, noise,
                      hit, rank, hit_rays, meta, s_idx, s_depth, cnt);
   hipLaunchKernelGGL(vox_point_scan_kernel, dim3(1), dim3(1024), 0, st,

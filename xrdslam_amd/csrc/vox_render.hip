@@ -32,7 +32,7 @@ namespace xrd {
 namespace {
 
 constexpr int VW = 8;            // waves (16-point tiles) per block
-constexpr int kVoxBlocks = 256;  // persistent blocks: one per CU
+constexpr int kVoxBlocks = 512;  // persistent blocks: two per CU (74 KB LDS each)
 // per-wave LDS scratch of the embedding-gradient scatter (backward):
 // gt [16 points][17] | row [16][8] | w [16][8]
 constexpr int kVoxScatter = 16 * 17 + 16 * 8 + 16 * 8;
@@ -350,7 +350,10 @@ __global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
       // The tile is transposed through LDS; lane group k walks the 16 points
       // for corners 2k, 2k+1, merges runs that hit the same embedding row in
       // a register and issues one coalesced 64-byte atomic per run.
-      float* gt = wl + K::STAGE_MAX + wave * kVoxScatter;
+      // the scratch aliases the staged fragments (all waves are done with
+      // layer 0's; the next stage() starts with a barrier)
+      __syncthreads();
+      float* gt = wl + wave * kVoxScatter;
       int* rw = reinterpret_cast<int*>(gt + 16 * 17);
       float* ww = gt + 16 * 17 + 16 * 8;
       wave_lds_sync();
@@ -463,7 +466,8 @@ int xrd_vox_pack_index(int32_t* idx) {
 }
 
 static size_t vox_lds_bytes() {
-  return (size_t)(VoxPack::STAGE_MAX + VW * kVoxScatter) * sizeof(float);
+  static_assert(VW * kVoxScatter <= VoxPack::STAGE_MAX, "scatter scratch");
+  return (size_t)VoxPack::STAGE_MAX * sizeof(float);
 }
 
 static int vox_setup(const void* kern) {

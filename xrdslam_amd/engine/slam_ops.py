@@ -252,28 +252,85 @@ class FusedDenseAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps,
                                       weight_decay=weight_decay))
 
+    @staticmethod
+    def _consecutive(tensors):
+        """the tensors are back-to-back views of one float32 buffer"""
+        nxt = None
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                return False
+            if nxt is not None and t.data_ptr() != nxt:
+                return False
+            nxt = t.data_ptr() + 4 * t.numel()
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         lib = _lib.lib()
         for grp in self.param_groups:
             b1, b2 = grp['betas']
-            for p in grp['params']:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if not st:
-                    st['exp_avg'] = torch.zeros_like(p, dtype=torch.float32)
-                    st['exp_avg_sq'] = torch.zeros_like(p, dtype=torch.float32)
-                    st['step'] = torch.zeros(1, dtype=torch.int32,
-                                             device=p.device)
-                st['step'] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            live = [p for p in grp['params'] if p.grad is not None]
+            if not live:
+                continue
+            fresh = [p for p in live if not self.state[p]]
+            if fresh:
+                # parameters that start together share one device-side step
+                # counter (one increment launch instead of one each)
+                step = torch.zeros(1, dtype=torch.int32,
+                                   device=fresh[0].device)
+                flat = len(fresh) > 1 and self._consecutive(fresh)
+                if flat:
+                    n = sum(p.numel() for p in fresh)
+                    m = torch.zeros(n, dtype=torch.float32,
+                                    device=fresh[0].device)
+                    v = torch.zeros_like(m)
+                    off = 0
+                for p in fresh:
+                    st = self.state[p]
+                    if flat:
+                        st['exp_avg'] = m[off:off + p.numel()].view_as(p)
+                        st['exp_avg_sq'] = v[off:off + p.numel()].view_as(p)
+                        off += p.numel()
+                    else:
+                        st['exp_avg'] = torch.zeros_like(
+                            p, dtype=torch.float32)
+                        st['exp_avg_sq'] = torch.zeros_like(
+                            p, dtype=torch.float32)
+                    st['step'] = step
+            bumped = set()
+            for p in live:
+                st = self.state[p]['step']
+                if st.data_ptr() not in bumped:
+                    st += 1
+                    bumped.add(st.data_ptr())
+            args = (float(grp['lr']), float(b1), float(b2),
+                    float(grp['eps']), float(grp['weight_decay']))
+            grads = [p.grad if p.grad.is_contiguous() else
+                     p.grad.contiguous() for p in live]
+            # back-to-back parameters, gradients and moments sharing one
+            # counter (a decoder kept in one flat buffer whose gradient comes
+            # out of one kernel): ONE launch for the whole group
+            if len(live) > 1 and len(bumped) == 1 and \
+                    self._consecutive(live) and self._consecutive(grads) and \
+                    self._consecutive([self.state[p]['exp_avg']
+                                       for p in live]) and \
+                    self._consecutive([self.state[p]['exp_avg_sq']
+                                       for p in live]):
+                st = self.state[live[0]]
                 _lib.check(lib.xrd_adam_dense(
-                    _lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']),
-                    _lib.ptr(st['exp_avg_sq']), p.numel(), float(grp['lr']),
-                    float(b1), float(b2), float(grp['eps']),
-                    float(grp['weight_decay']), _lib.ptr(st['step']),
-                    _lib.stream_ptr(p.device)), 'xrd_adam_dense')
+                    _lib.ptr(live[0]), _lib.ptr(grads[0]),
+                    _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
+                    sum(p.numel() for p in live), *args, _lib.ptr(st['step']),
+                    _lib.stream_ptr(live[0].device)), 'xrd_adam_dense')
+            else:
+                for p, g in zip(live, grads):
+                    st = self.state[p]
+                    _lib.check(lib.xrd_adam_dense(
+                        _lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']),
+                        _lib.ptr(st['exp_avg_sq']), p.numel(), *args,
+                        _lib.ptr(st['step']), _lib.stream_ptr(p.device)),
+                        'xrd_adam_dense')
+            for p in live:
                 # the kernel writes through the raw pointer: torch's version
                 # counter does not see it; consumers that cache a derived
                 # layout (packed decoder weights) watch this counter instead

@@ -262,10 +262,33 @@ class RayWorkspace:
         return m[5] | (8 if m[10] else 0), m
 
 
+def flatten_decoder(params):
+    """re-seat the ten decoder tensors as back-to-back views of ONE buffer (+
+    a trailing zero the packing index points its padding at): packing becomes
+    one gather, and Adam steps the decoder with one launch (its gradient comes
+    out of xrd_vox_dw as one flat tensor too).  Idempotent; values kept."""
+    p0 = params[0]
+    flat = getattr(p0, '_xrd_flat', None)
+    nxt = flat.data_ptr() if flat is not None else None
+    ok = flat is not None
+    for p in params:
+        ok = ok and p.data_ptr() == nxt and p.is_contiguous()
+        nxt = (nxt or 0) + 4 * p.numel()
+    if ok:
+        return flat
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params] +
+                         [p0.new_zeros(1)])
+        off = 0
+        for p in params:
+            p.data = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+    p0._xrd_flat = flat
+    return flat
+
+
 def _pack(params, like):
-    flat = torch.cat([p.detach().reshape(-1).float() for p in params] +
-                     [like.new_zeros(1)])
-    return flat[pack_index(like.device)]
+    return flatten_decoder(params)[pack_index(like.device)]
 
 
 def sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise):
@@ -333,14 +356,14 @@ class _VoxRenderLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, emb, target_d, target_s, noise, ws, ms,
-                cfg, *params):
+                cfg, flat, *params):
         rays_o = rays_o.detach().float().contiguous()
         rays_d = rays_d.detach().float().contiguous()
         target_d = target_d.detach().float().reshape(-1).contiguous()
         target_s = target_s.detach().float().contiguous()
-        need_w = any(ctx.needs_input_grad[9:])
+        need_w = any(ctx.needs_input_grad[10:])
         assert not need_w or ws.need_w
-        packed = _pack(params, rays_o)
+        packed = flat.detach()[pack_index(rays_o.device)]
         sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise)
         _points_fwd(ws, ms, cfg, packed, need_w)
         _render_fwd(ws, cfg, target_d, target_s, True)
@@ -408,9 +431,9 @@ class _VoxRenderLossFn(torch.autograd.Function):
                     'xrd_vox_dw')
             gp = [g.reshape(shp) if need else None for g, shp, need in zip(
                 flat.split(_PARAM_SIZES), _PARAM_SHAPES,
-                ctx.needs_input_grad[9:])]
+                ctx.needs_input_grad[10:])]
         return (g_o if need_o else None, g_d if need_d else None, g_emb, None,
-                None, None, None, None, None, *gp)
+                None, None, None, None, None, None, *gp)
 
 
 def render_loss(decoder, ws, ms, cfg, rays_o, rays_d, target_d, target_s,
@@ -424,11 +447,12 @@ def render_loss(decoder, ws, ms, cfg, rays_o, rays_d, target_d, target_s,
     if ps is None or not rays_o.is_cuda:
         return None
     emb = ms['voxel_vertex_emb']
+    flat = flatten_decoder(ps)
     if not map_grads:
         ps = [p.detach() for p in ps]
         emb = emb.detach()
     return _VoxRenderLossFn.apply(rays_o, rays_d, emb, target_d, target_s,
-                                  noise, ws, ms, cfg, *ps)
+                                  noise, ws, ms, cfg, flat, *ps)
 
 
 @torch.no_grad()
@@ -442,6 +466,6 @@ def render(decoder, ws, ms, cfg, rays_o, rays_d, noise, z_min=None,
     rays_d = rays_d.detach().float().contiguous()
     # the target depth only feeds the loss counters
     sample_rays(ws, ms, cfg, rays_o, rays_d, ws.zero_n, noise)
-    _points_fwd(ws, ms, cfg, _pack(ps, rays_o), False)
+    _points_fwd(ws, ms, cfg, _pack(ps, rays_o), False)  # ps: the module's own
     _render_fwd(ws, cfg, None, None, False, z_min=z_min, weights=weights)
     return ws.depth, ws.rgb

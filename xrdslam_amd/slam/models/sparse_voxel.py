@@ -321,6 +321,8 @@ class SparseVoxel(Model):
         """the sampler's uniform draws, one row per ray (None = fixed 0.5)"""
         if self.noise_fn is None:
             return None
+        if self.noise_fn is vh._uniform_noise:
+            return torch.empty_like(ws.s_depth).uniform_()
         return self.noise_fn((ws.n, ws.s_cap), ws.s_depth)
 
     def fused_loss(self, inputs, is_mapping):
