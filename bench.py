@@ -510,6 +510,13 @@ def run_voxfusion(args, dev, world=1):
     elapsed = _timed_frames(slam, args, dev, world)
     t_track, t_map = slam.t_track, slam.t_map
     sizes = dict(getattr(algo, 'last_batch_sizes', None) or {})
+    pose = algo.get_estimate_c2w_list()[-1].to(dev)
+    algo.render_img(pose)
+    torch.cuda.synchronize(dev)
+    t_r = time.perf_counter()
+    algo.render_img(pose)
+    torch.cuda.synchronize(dev)
+    render_ms = (time.perf_counter() - t_r) * 1e3
     # per-launch HIP-event timing: replayed graph nodes cannot be event-timed,
     # so two more frames run eagerly (same kernels, same shapes) right after
     # the timed region
@@ -588,6 +595,7 @@ def run_voxfusion(args, dev, world=1):
                         'MLP',
             'track_ms_per_frame': t_track / args.steps * 1e3,
             'map_ms_per_frame': t_map / args.steps * 1e3,
+            'render_img_ms': render_ms,
             'ate_rmse_m': slam.ate_rmse(),
             'leaf_voxels': int(algo.model.svo.count_leaf_nodes()),
             'last_batch': sizes,

@@ -172,9 +172,28 @@ class VoxFusion(Algorithm):
             H, W = self.camera.height, self.camera.width
             depths, colors = [], []
             bs = self.config.ray_batch_size
+            from ...engine import vox as _vox
+            fused = self.fused_iteration and rays_o.is_cuda and \
+                _vox.decoder_params(self.model.decoder) is not None
             for i in range(0, rays_d.shape[0], bs):
                 td = None if gt_depth is None else gt_depth[i:i + bs]
                 n = rays_d[i:i + bs].shape[0]
+                if fused:
+                    # the same chunks through the fused ray pipeline (hits,
+                    # samples, decoder, compositing: 9 launches a chunk); a
+                    # chunk that outgrows the static capacities is redone
+                    m = self.model
+                    while True:
+                        ws = m.ray_workspace(n, False)
+                        d, c = _vox.render(
+                            m.decoder, ws, m.map_states, m.config,
+                            rays_o[i:i + bs], rays_d[i:i + bs],
+                            m.draw_noise(ws))
+                        if not m.check_capacity()['grown']:
+                            break
+                    depths.append(d.double())
+                    colors.append(c.clone())
+                    continue
                 out = self.model.render_rays(
                     rays_o[None, i:i + bs], rays_d[None, i:i + bs],
                     target_d=td)
