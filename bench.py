@@ -406,6 +406,24 @@ def _timed_frames(slam, args, dev, world):
     return elapsed
 
 
+def _rccl_report(world):
+    """what the exchange ran on and how fast it is: rank count as the
+    communicator sees it and the ring all-reduce bus bandwidth of an 8 MiB
+    fp32 bucket (2 (N-1)/N x bytes / time), so that a scaling run validates
+    itself; None on one GPU"""
+    if world <= 1:
+        return None
+    from xrdslam_amd.engine import dist as xdist
+    st = xdist.state
+    nbytes = 8 << 20
+    bw = st.measure_busbw(nbytes)
+    return {'ranks': st.comm.world if st.comm is not None else st.world,
+            'exchange': st.backend_name(),
+            'deterministic_shards': bool(st.deterministic),
+            'allreduce_bytes': nbytes, 'busbw_GBps': bw,
+            'xgmi_link_peak_GBps': 153.0}
+
+
 def _setup_dist(dev, world):
     if world > 1:
         from xrdslam_amd.engine import dist as xdist
@@ -839,8 +857,9 @@ def main():
             if args.algo == 'splaTAM' else run_pointslam(args, dev, world)
         res.update({'n_gpus': world, 'steps': args.steps,
                     'warmup': args.warmup, 'higher_is_better': True,
-                    'scaling': 'strong' if world > 1 else 'weak',
-                    'vs_baseline': None, 'data': 'synthetic'})
+                    'scaling': 'strong',
+                    'vs_baseline': None, 'data': 'synthetic',
+                    'rccl': _rccl_report(world)})
         if rank == 0:
             print(json.dumps(res), flush=True)
         if world > 1:
@@ -934,6 +953,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    rccl = _rccl_report(world)   # collective: every rank takes part
 
     if rank == 0:
         # per-kernel launch statistics of the timed region
@@ -1000,7 +1020,9 @@ def main():
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak',
+            # the per-iteration ray batch is fixed by the reference's config
+            # and split over the ranks: total work does not grow with N
+            'scaling': 'strong', 'rccl': rccl,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': 'NICE-SLAM Replica/office0-shaped 640x480 RGB-D: '

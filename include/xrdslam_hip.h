@@ -391,6 +391,33 @@ int xrd_vox_ray_grads(int n_rays, int s_cap, int64_t p_cap, const int32_t* hit,
                       float* g_rays_o, float* g_rays_d, xrd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Multi-GPU gradient exchange (the reference is single-GPU and
+ * has no collective).  One process per GPU; mapping rays are sharded over the
+ * ranks and ONE all-reduce (SUM) of a flat fp32 bucket (map + decoder + pose
+ * gradients) per iteration keeps the replicated Adam steps identical.  RCCL
+ * (over xGMI) is bound at run time: xrd_comm_load(path) dlopens the given
+ * librccl (NULL: "librccl.so.1"; a host process that already carries one —
+ * PyTorch bundles its own — passes that path and shares the instance).
+ * xrd_comm_unique_id fills xrd_comm_unique_id_bytes() bytes on ONE rank, the
+ * caller distributes them (any side channel) and every rank calls
+ * xrd_comm_create(id, rank, world) with its GPU current; NULL on failure
+ * (xrd_last_error).  xrd_allreduce_grads sums `bucket` [n] f32 in place over
+ * the ranks, enqueued on `stream` (ordered with the kernels around it; no
+ * host synchronisation).  xrd_allreduce_max_i32: element-wise MAX of small
+ * int32 records (the Vox-Fusion size record).
+ * ---------------------------------------------------------------------- */
+int xrd_comm_load(const char* rccl_path);
+int xrd_comm_unique_id_bytes(void);
+int xrd_comm_unique_id(void* out_id);
+void* xrd_comm_create(const void* id, int rank, int world);
+int xrd_comm_world(void* comm);
+int xrd_allreduce_grads(void* comm, float* bucket, int64_t n,
+                        xrd_stream_t stream);
+int xrd_allreduce_max_i32(void* comm, int32_t* values, int64_t n,
+                          xrd_stream_t stream);
+void xrd_comm_destroy(void* comm);
+
+/* ------------------------------------------------------------------------
  * SplaTAM Gaussian rasteriser — replaces the unvendored CUDA module
  * diff_gaussian_rasterization (-w-depth @ cb65e4b): GaussianRasterizer(
  * raster_settings)(means3D, means2D, opacities, colors_precomp, scales,

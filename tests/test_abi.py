@@ -126,11 +126,13 @@ def test_every_entry_point_survives_null_arguments():
                 else None for a in args]        # pointers of any kind: null
         r = getattr(lib, name)(*vals)
         if ret is not ctypes.c_int or name.endswith('_len') or \
-                name in ('xrd_abi_version', 'xrd_octree_has_voxel') or \
+                name in ('xrd_abi_version', 'xrd_octree_has_voxel',
+                         'xrd_comm_unique_id_bytes', 'xrd_comm_world') or \
                 'count' in name or 'get_' in name:
             continue
-        if name == 'xrd_nice_warmup':
-            assert r in (0, 2), (name, r)         # 2: no HIP device here
+        if name in ('xrd_nice_warmup', 'xrd_comm_load'):
+            # 2: no HIP device here / no librccl.so.1 to dlopen
+            assert r in (0, 2), (name, r)
         elif name in ok_when_empty:
             assert r == 0, (name, r)
         else:

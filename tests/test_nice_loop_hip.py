@@ -381,3 +381,43 @@ def test_ate_engine_equals_reference_arithmetic_loop():
     # with a large run-to-run spread; the engine must not be worse than it)
     assert ate_e <= 2.0 * ate_o + 0.01, line
     assert gap < 4 * max(ate_e, ate_o, 5e-3), line
+
+
+@pytest.mark.parametrize('world,fused', [(2, True), (3, True), (2, False)])
+def test_deterministic_shards_add_up_to_the_single_gpu_iteration(world,
+                                                                  fused):
+    """multi-GPU mapping, deterministic sharding (engine/dist.py): every rank
+    draws the SAME batch and renders its slice of every frame's rays with the
+    batch's max depth; the per-rank losses and gradients (grids, colour
+    decoder, BA poses) must add up to the single-process iteration.  The ranks
+    are played one after the other on this GPU — what an all-reduce (SUM)
+    would deliver is the sum taken here."""
+    from xrdslam_amd.engine import dist as xd
+    algo, frames = make()
+    single = grads(algo, frames, True, 50, fused=fused, fixed=True)
+    st = xd.state
+    saved = (st.enabled, st.rank, st.world, st.deterministic)
+    total = None
+    try:
+        for r in range(world):
+            st.enabled, st.rank, st.world, st.deterministic = \
+                True, r, world, True
+            g = grads(algo, frames, True, 50, fused=fused, fixed=True)
+            if total is None:
+                total = g
+                continue
+            total['loss'] += g['loss']
+            total['pose'] = [a + b for a, b in zip(total['pose'], g['pose'])]
+            for k in total['grids']:
+                total['grids'][k] += g['grids'][k]
+            if total['dec'] is not None:
+                total['dec'] += g['dec']
+    finally:
+        st.enabled, st.rank, st.world, st.deterministic = saved
+    assert abs(total['loss'] - single['loss']) <= 1e-4 * abs(single['loss'])
+    for a, b in zip(total['pose'], single['pose']):
+        assert close(a, b), (a, b)
+    for k in single['grids']:
+        assert close(total['grids'][k], single['grids'][k]), k
+    if single['dec'] is not None:
+        assert close(total['dec'], single['dec'])

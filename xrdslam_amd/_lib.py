@@ -105,6 +105,14 @@ _SIGS = {
     'xrd_vox_render_bwd': (C.c_int, [C.c_int, C.c_int, i64, f32, f32] +
                            [vp] * 14),
     'xrd_vox_ray_grads': (C.c_int, [C.c_int, C.c_int, i64] + [vp] * 8),
+    'xrd_comm_load': (C.c_int, [C.c_char_p]),
+    'xrd_comm_unique_id_bytes': (C.c_int, []),
+    'xrd_comm_unique_id': (C.c_int, [vp]),
+    'xrd_comm_create': (vp, [vp, C.c_int, C.c_int]),
+    'xrd_comm_world': (C.c_int, [vp]),
+    'xrd_allreduce_grads': (C.c_int, [vp, vp, i64, vp]),
+    'xrd_allreduce_max_i32': (C.c_int, [vp, vp, i64, vp]),
+    'xrd_comm_destroy': (None, [vp]),
     'xrd_gs_preprocess': (C.c_int, [vp, C.c_int] + [vp] * 11),
     'xrd_gs_duplicate_keys': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         vp]),

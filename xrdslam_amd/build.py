@@ -55,7 +55,7 @@ def build(force=False, verbose=True):
         raise RuntimeError(f'hipcc failed for {failed}')
     if procs or force or not os.path.exists(LIB):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB
-               ] + objs
+               ] + objs + ['-ldl']
         if verbose:
             print('[xrdslam_amd.build]', ' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -135,10 +135,15 @@ class NiceSLAM(Algorithm):
             n_pix = max(cfg.mapping_sample // len(optimize_frames),
                         cfg.min_sample_pixels)
             Hedge = Wedge = 0
-            n_pix = _dist.state.shard_count(n_pix)  # this rank's ray shard
-            gen = _dist.state.shard_generator
+            gen = None
+            if _dist.state.enabled and not _dist.state.deterministic:
+                # this rank's own 1/world of the rays, from its own stream
+                n_pix = _dist.state.shard_count(n_pix)
+                gen = _dist.state.shard_generator
         else:
             gen = None
+        det = is_mapping and _dist.state.enabled and \
+            _dist.state.deterministic
         ro, rd, gd, gc = [], [], [], []
         for frame in optimize_frames:
             c2w = frame.get_pose()
@@ -165,14 +170,41 @@ class NiceSLAM(Algorithm):
                 rays_d.detach().unsqueeze(-1)
             t_exit = t.max(dim=2)[0].min(dim=1)[0]
             keep = t_exit >= depth.squeeze(-1)
+        extra = {}
+        if det:
+            # deterministic sharding: every rank drew the SAME batch (shared
+            # RNG stream); this rank renders a contiguous slice of every
+            # frame's rays.  max(gt_depth) over the kept rays of the WHOLE
+            # batch bounds the sampling range (conv_onet.py:418,455), so it
+            # is taken before slicing.
+            with torch.no_grad():
+                extra['dmax'] = torch.where(
+                    keep, depth.squeeze(-1),
+                    torch.zeros_like(depth.squeeze(-1))).max()
+            sel = self._shard_rows(len(optimize_frames), n_pix, dev)
+            rays_o, rays_d = rays_o[sel], rays_d[sel]
+            depth, color, keep = depth[sel], color[sel], keep[sel]
         if getattr(self, 'fixed_shape_batches', False):
             # no compaction (no host sync, hipGraph friendly): the mask
             # travels with the batch and is applied in the loss
             return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': color,
-                    'target_d': depth, 'stage': self.stage, 'ray_mask': keep}
+                    'target_d': depth, 'stage': self.stage, 'ray_mask': keep,
+                    **extra}
         return {'rays_o': rays_o[keep], 'rays_d': rays_d[keep],
                 'target_s': color[keep], 'target_d': depth[keep],
-                'stage': self.stage}
+                'stage': self.stage, **extra}
+
+    def _shard_rows(self, n_frames, n_pix, dev):
+        """row indices of this rank's slice [lo, hi) of every frame's n_pix
+        rays in the frame-major batch (deterministic sharding)"""
+        lo, hi = _dist.state.shard_slice(n_pix)
+        key = (n_frames, n_pix, lo, hi, str(dev))
+        cache = self.__dict__.setdefault('_shard_row_cache', {})
+        if key not in cache:
+            cache[key] = (torch.arange(lo, hi, device=dev).unsqueeze(0) +
+                          n_pix * torch.arange(n_frames, device=dev)
+                          .unsqueeze(1)).reshape(-1)
+        return cache[key]
 
     def set_stage(self, is_mapping, step, n_iters, coarse=False):
         cfg = self.config
@@ -208,8 +240,11 @@ class NiceSLAM(Algorithm):
             n_pix = max(cfg.mapping_sample // len(optimize_frames),
                         cfg.min_sample_pixels)
             Hedge = Wedge = 0
-            n_pix = _dist.state.shard_count(n_pix)
-            gen = _dist.state.shard_generator
+            if _dist.state.enabled and not _dist.state.deterministic:
+                n_pix = _dist.state.shard_count(n_pix)
+                gen = _dist.state.shard_generator
+        det = is_mapping and _dist.state.enabled and \
+            _dist.state.deterministic
         wcrop = cam.width - 2 * Wedge
         cnt = (cam.height - 2 * Hedge) * wcrop
         F = len(optimize_frames)
@@ -242,6 +277,12 @@ class NiceSLAM(Algorithm):
             ro, rd, td, tc, keep, dmax = slam_ops.SampleRaysFn.apply(
                 c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
                 (Hedge, Wedge, wcrop), bound6)
+        if det:
+            # same batch on every rank, this rank renders its slice of every
+            # frame; dmax (max depth of the kept rays) stays the batch's
+            sel = self._shard_rows(F, n_pix, dev)
+            ro, rd = ro.index_select(0, sel), rd.index_select(0, sel)
+            td, tc, keep = td[sel], tc[sel], keep[sel]
         stage = self.stage
         depth, var, rgb = _en.nice_render(
             self.model.scene(), stage, ro, rd,

@@ -298,9 +298,9 @@ class ConvOnet(Model):
     def get_outputs(self, input) -> Dict[str, Union[torch.Tensor, List]]:
         stage = input['stage']
         target_d = None if stage == 'coarse' else input['target_d']
-        dmax = None
+        dmax = input.get('dmax')   # sharded batch: the whole batch's maximum
         keep = input.get('ray_mask')
-        if keep is not None and target_d is not None:
+        if dmax is None and keep is not None and target_d is not None:
             # un-compacted batch: rays with ray_mask=False are rendered but
             # take no part in max(gt_depth) (conv_onet.py:418,455) or the loss
             dmax = torch.where(keep, target_d.reshape(-1),
