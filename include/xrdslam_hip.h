@@ -453,6 +453,20 @@ int xrd_gs_duplicate_keys(int n, int image_width, const int32_t* rect,
 /* ranges[tile] = [start,end) in the sorted list; pre-zero ranges */
 int xrd_gs_tile_ranges(int64_t n_keys, const int64_t* sorted_keys,
                        int32_t* ranges, xrd_stream_t stream);
+/* The same binning as ONE call without a host sync (csrc/gs_bin.hip):
+ * inclusive scan of tiles_touched, key duplication into a static-capacity
+ * array (key_capacity pairs; slots past the live count sort last and are
+ * ignored), 64-bit radix sort restricted to the live key bits, per-tile
+ * ranges.  point_list [key_capacity] i32, ranges [tiles,2] i32 (zeroed here),
+ * n_keys: device i64 = the TRUE pair count of this pass (> key_capacity: the
+ * pass dropped pairs; the caller re-sizes).  workspace:
+ * xrd_gs_bin_ws_bytes(n, key_capacity, W, H) bytes. */
+int64_t xrd_gs_bin_ws_bytes(int n, int64_t key_capacity, int image_width,
+                            int image_height);
+int xrd_gs_bin(int n, int image_width, int image_height, const int32_t* rect,
+               const int32_t* tiles_touched, const float* depths,
+               int64_t key_capacity, void* workspace, int32_t* point_list,
+               int32_t* ranges, int64_t* n_keys, xrd_stream_t stream);
 int xrd_gs_render_fwd(const xrd_gs_camera* cam, const int32_t* ranges,
                       const int32_t* point_list, const float* xy,
                       const float* colors, const float* conic_opacity,

@@ -93,3 +93,71 @@ def test_rasterizer_empty_and_unsupported():
     with pytest.raises(NotImplementedError):
         dgr.GaussianRasterizer(rs)(means3D=means.to(dev), means2D=None,
                                    opacities=op.to(dev), shs=cols.to(dev))
+
+
+@pytest.mark.parametrize('N,H,W,cap_factor', [(300, 40, 56, 1.5),
+                                              (5000, 120, 160, 1.0),
+                                              (5000, 120, 160, 0.5)])
+def test_device_binning_equals_scan_sort_on_the_host_side(N, H, W, cap_factor):
+    """xrd_gs_bin (scan + static-capacity key list + radix sort + ranges, no
+    host sync) against the phase-by-phase path it replaced (torch.cumsum,
+    xrd_gs_duplicate_keys, stable torch.sort, xrd_gs_tile_ranges): identical
+    per-tile lists when the capacity holds the pass, the true count reported
+    when it does not"""
+    import ctypes as C
+
+    from xrdslam_amd import _lib
+    from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
+    lib = _lib.lib()
+    dev = torch.device('cuda:0')
+    means, cols, op, sc, rot, view, full, tfx, tfy = scene(N, H, W, 7)
+    rs = dgr.GaussianRasterizationSettings(
+        H, W, tfx, tfy, torch.zeros(3, device=dev), 1.0,
+        view.to(dev).unsqueeze(0), full.to(dev).unsqueeze(0), 0,
+        torch.zeros(3, device=dev), False)
+    cam = dgr._camera(rs)
+    st = _lib.stream_ptr(dev)
+    f = dict(dtype=torch.float32, device=dev)
+    i = dict(dtype=torch.int32, device=dev)
+    depths, xy = torch.zeros(N, **f), torch.zeros(N, 2, **f)
+    conic = torch.zeros(N, 4, **f)
+    radii, rect, tiles = torch.zeros(N, **i), torch.zeros(N, 4, **i), \
+        torch.zeros(N, **i)
+    _lib.check(lib.xrd_gs_preprocess(
+        C.byref(cam), N, _lib.ptr(means.to(dev)), _lib.ptr(sc.to(dev)),
+        _lib.ptr(rot.to(dev)), _lib.ptr(op.to(dev)), _lib.ptr(depths),
+        _lib.ptr(xy), _lib.ptr(conic), _lib.ptr(radii), _lib.ptr(rect),
+        _lib.ptr(tiles), st), 'preprocess')
+    offsets = torch.cumsum(tiles.long(), 0)
+    total = int(offsets[-1])
+    assert total > 0
+    keys = torch.empty(total, dtype=torch.int64, device=dev)
+    vals = torch.empty(total, **i)
+    _lib.check(lib.xrd_gs_duplicate_keys(
+        N, W, _lib.ptr(rect), _lib.ptr(offsets), _lib.ptr(depths),
+        _lib.ptr(keys), _lib.ptr(vals), st), 'dup')
+    keys, order = torch.sort(keys, stable=True)
+    ref_list = vals[order]
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    ref_ranges = torch.zeros(nt, 2, **i)
+    _lib.check(lib.xrd_gs_tile_ranges(total, _lib.ptr(keys),
+                                      _lib.ptr(ref_ranges), st), 'ranges')
+    cap = max(int(total * cap_factor), 1)
+    plist = torch.empty(cap, **i)
+    ranges = torch.empty(nt, 2, **i)
+    n_keys = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.xrd_gs_bin_ws_bytes(N, cap, W, H), dtype=torch.uint8,
+                     device=dev)
+    _lib.check(lib.xrd_gs_bin(
+        N, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths), cap,
+        _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges), _lib.ptr(n_keys), st),
+        'bin')
+    torch.cuda.synchronize()
+    assert int(n_keys) == total
+    if cap >= total:
+        assert torch.equal(ranges, ref_ranges)
+        assert torch.equal(plist[:total], ref_list)
+    else:
+        # an under-sized list keeps well-formed ranges inside the capacity
+        r = ranges.cpu().numpy()
+        assert (r[:, 1] >= r[:, 0]).all() and r.max() <= cap

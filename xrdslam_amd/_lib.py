@@ -117,6 +117,9 @@ _SIGS = {
     'xrd_gs_duplicate_keys': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         vp]),
     'xrd_gs_tile_ranges': (C.c_int, [i64, vp, vp, vp]),
+    'xrd_gs_bin_ws_bytes': (i64, [C.c_int, i64, C.c_int, C.c_int]),
+    'xrd_gs_bin': (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, vp,
+                             vp, vp, vp, vp]),
     'xrd_gs_render_fwd': (C.c_int, [vp] * 12),
     'xrd_gs_render_bwd': (C.c_int, [vp] * 14),
     'xrd_gs_preprocess_bwd': (C.c_int, [vp, C.c_int] + [vp] * 10),

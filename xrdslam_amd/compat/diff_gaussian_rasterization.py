@@ -79,6 +79,63 @@ def _build_camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
     return cam
 
 
+class _Binning:
+    """static capacity of the (Gaussian, tile) pair list per device.  A pass
+    leaves its true pair count in a device scalar; it is copied to pinned
+    host memory without waiting and read when the NEXT pass sizes its list
+    (by then it has long arrived).  The host waits only when there is no
+    usable history: first pass, or the number of Gaussians changed by more
+    than 2 % (densification / pruning: once per frame, not per pass)."""
+    HEADROOM = 1.3
+
+    def __init__(self):
+        self.state = {}
+        self.overflowed = 0     # passes that dropped pairs (diagnostic)
+
+    def capacity(self, dev, n, tiles):
+        key = str(dev)
+        st = self.state.get(key)
+        total = None
+        if st is not None:
+            if st['event'] is not None:
+                st['event'].synchronize()      # previous pass: done long ago
+                st['event'] = None
+                st['last'] = int(st['host'][0])
+                if st['last'] > st['last_cap']:
+                    self.overflowed += 1
+            if st['last'] is not None and \
+                    abs(n - st['n']) <= 0.02 * max(st['n'], 1):
+                total = st['last']
+        if total is None:
+            total = int(tiles.sum().item()) if n > 0 else 0   # host sync
+        need = max(int(total * self.HEADROOM) + 1024, 1 << 16)
+        if st is None:
+            st = self.state[key] = {
+                'cap': need, 'n': n, 'event': None, 'last': None,
+                'last_cap': need, 'ws': None,
+                'host': torch.zeros(1, dtype=torch.int64).pin_memory()}
+        if need > st['cap'] or need < st['cap'] // 3:
+            st['cap'] = need
+        return st['cap']
+
+    def workspace(self, dev, nbytes):
+        st = self.state[str(dev)]
+        if st['ws'] is None or st['ws'].numel() < nbytes:
+            st['ws'] = torch.empty(int(nbytes * 1.2) + 256, dtype=torch.uint8,
+                                   device=dev)
+        return st['ws']
+
+    def report(self, dev, n, cap, n_keys):
+        st = self.state[str(dev)]
+        st['host'].copy_(n_keys, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st['event'], st['n'], st['last_cap'] = ev, n, cap
+
+
+_BIN = _Binning()
+
+
 class _RasterizeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, colors, scales, rotations,
@@ -107,23 +164,21 @@ class _RasterizeFn(torch.autograd.Function):
             _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy), _lib.ptr(conic_o),
             _lib.ptr(radii), _lib.ptr(rect), _lib.ptr(tiles), st),
             'xrd_gs_preprocess')
-        offsets = torch.cumsum(tiles.long(), 0)
-        total = int(offsets[-1].item()) if n > 0 else 0
         gx, gy = (W + 15) // 16, (H + 15) // 16
-        ranges = torch.zeros(gx * gy, 2, **i)
-        if total > 0:
-            keys = torch.empty(total, dtype=torch.int64, device=dev)
-            vals = torch.empty(total, **i)
-            _lib.check(lib.xrd_gs_duplicate_keys(
-                n, W, _lib.ptr(rect), _lib.ptr(offsets), _lib.ptr(depths),
-                _lib.ptr(keys), _lib.ptr(vals), st), 'xrd_gs_duplicate_keys')
-            keys, order = torch.sort(keys, stable=True)
-            plist = vals[order].contiguous()
-            _lib.check(lib.xrd_gs_tile_ranges(total, _lib.ptr(keys),
-                                              _lib.ptr(ranges), st),
-                       'xrd_gs_tile_ranges')
-        else:
-            plist = torch.zeros(1, **i)
+        ranges = torch.empty(gx * gy, 2, **i)
+        # tile binning on the stream (scan, key duplication, radix sort,
+        # ranges: csrc/gs_bin.hip) into a static-capacity list; the capacity
+        # follows the pair count of the previous pass, read back
+        # asynchronously — no host sync in the pass
+        cap = _BIN.capacity(dev, n, tiles)
+        plist = torch.empty(cap, **i)
+        n_keys = torch.empty(1, dtype=torch.int64, device=dev)
+        ws = _BIN.workspace(dev, lib.xrd_gs_bin_ws_bytes(n, cap, W, H))
+        _lib.check(lib.xrd_gs_bin(
+            n, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths), cap,
+            _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges), _lib.ptr(n_keys),
+            st), 'xrd_gs_bin')
+        _BIN.report(dev, n, cap, n_keys)
         color = torch.empty(3, H, W, **f)
         depth = torch.empty(1, H, W, **f)
         final_T = torch.empty(H, W, **f)
