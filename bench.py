@@ -646,8 +646,7 @@ class _CvPoses:
 def run_splatam(args, dev):
     """SplaTAM frame loop: 40 tracking + 60 mapping iterations per frame, two
     full-image raster passes (colour; depth/silhouette) per iteration over
-    ~3e5 Gaussians.  Functional end-to-end path on the HIP rasteriser; no
-    roofline object yet."""
+    ~4e5 Gaussians, on the HIP rasteriser (tile binning on the device)."""
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.configs.input_config import cadence, splatam_config
@@ -677,6 +676,53 @@ def run_splatam(args, dev):
         slam.step(k)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    t_track, t_map = slam.t_track, slam.t_map
+    # per-launch HIP-event timing of one more frame (100 iterations, 200
+    # raster passes each way) right after the timed region
+    from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
+    dgr.PROFILE = {}
+    slam.step(1 + args.warmup + args.steps)
+    torch.cuda.synchronize()
+    prof, dgr.PROFILE = dgr.PROFILE, None
+    us = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e3
+          for k, v in prof.items() if k.startswith('gs_')}
+    pairs = float(torch.stack(prof['pairs']).double().mean())
+    keys = float(torch.stack(prof['keys']).double().mean())
+    n_g = float(np.mean(prof['gaussians']))
+    # per (pixel x contributing Gaussian) pair ~30 FLOP forward,
+    # ~80 backward (VALU fp32, same 157.3 TFLOP/s peak as v_mfma_f32); per
+    # Gaussian and pass 48 B read + ~64 B written by the preprocess, 16 B of
+    # key/value per (Gaussian x tile) pair through the sort
+    bwd_flops = pairs * 80.0
+    hbm_bytes = n_g * (48 + 64) + keys * 16 * 2
+    pre_us = us.get('gs_preprocess', 0.0) + us.get('gs_bin', 0.0)
+    roofline = {
+        'bound': 'mfma', 'achieved': bwd_flops / (us['gs_render_bwd'] * 1e-6)
+        / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+        'frac': bwd_flops / (us['gs_render_bwd'] * 1e-6) / MFMA_F32_PEAK,
+        'traffic': None,
+        'kernel': 'gs_render_bwd (tile-local blend backward: fp32 VALU, '
+                  'wave-reduced atomics to the per-Gaussian gradients; the '
+                  'peak is the fp32 FMA rate, equal to the f32 MFMA peak)',
+        'avg_launch_us': us['gs_render_bwd'],
+        'launches': len(prof['gs_render_bwd']),
+        'pixel_gaussian_pairs_per_pass': pairs,
+        'gaussian_tile_pairs_per_pass': keys, 'gaussians': n_g,
+        'algorithmic_flops_per_pair': 80,
+        'other_bound': {
+            'bound': 'hbm', 'unit': 'GB/s', 'what': 'preprocess + binning',
+            'achieved': hbm_bytes / (pre_us * 1e-6) / 1e9 if pre_us else None,
+            'frac': hbm_bytes / (pre_us * 1e-6) / HBM_PEAK if pre_us
+            else None},
+        'launch_us': us,
+        'gaussian_tile_pairs_per_s': keys / ((us['gs_render_fwd'] +
+                                              us['gs_render_bwd']) * 1e-6),
+        'timing_source': 'HIP events around the launches of the frame run '
+                         'right after the timed region'}
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = splatam_cpu_baseline(min(os.cpu_count() or 1, 16), n_g,
+                                   cam.height * cam.width)
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -684,12 +730,56 @@ def run_splatam(args, dev):
         'config': {
             'workload': 'SplaTAM 640x480 synthetic RGB-D: 40 tracking it + 60 '
                         'mapping it per frame, 2 raster passes each, window 24',
-            'track_ms_per_frame': slam.t_track / args.steps * 1e3,
-            'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+            'track_ms_per_frame': t_track / args.steps * 1e3,
+            'map_ms_per_frame': t_map / args.steps * 1e3,
             'ate_rmse_m': slam.ate_rmse(),
             'gaussians': int(algo.model.gaussian_cloud.params['means3D']
-                             .shape[0])},
-        'roofline': None, 'cpu_baseline': None}
+                             .shape[0]),
+            'binning_overflowed_passes': dgr._BIN.overflowed},
+        'roofline': roofline, 'cpu_baseline': cpu}
+
+
+def splatam_cpu_baseline(threads, n_gaussians, n_pixels):
+    """the torch oracle of the rasteriser (oracle/gs_oracle.py: a DENSE
+    per-pixel evaluation of every Gaussian, O(N H W) — the reference's
+    rasteriser is a CUDA-only dependency with no CPU path) forward+backward on
+    a bounded sample, scaled by N H W to the workload and by the 200 raster
+    passes of a frame"""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gs_oracle as go
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    N, H, W, fx = 1500, 48, 64, 40.0
+    means = (torch.randn(N, 3, generator=g) * torch.tensor([0.8, 0.6, 0.5]) +
+             torch.tensor([0.0, 0.0, 2.5])).requires_grad_()
+    cols = torch.rand(N, 3, generator=g).requires_grad_()
+    op = (torch.rand(N, 1, generator=g) * 0.9 + 0.05).requires_grad_()
+    sc = (torch.rand(N, 1, generator=g) * 0.1 + 0.02).repeat(1, 3) \
+        .requires_grad_()
+    rot = torch.tensor([[1.0, 0, 0, 0]]).repeat(N, 1).requires_grad_()
+    near, far = 0.01, 100.0
+    proj = torch.tensor([[2 * fx / W, 0, 0, 0], [0, 2 * fx / H, 0, 0],
+                         [0, 0, far / (far - near),
+                          -(far * near) / (far - near)], [0, 0, 1, 0]])
+    view = torch.eye(4)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 10.0 or reps < 2:
+        color, _, depth, _ = go.rasterize(means, cols, op, sc, rot, view,
+                                          proj.t().contiguous(), H, W,
+                                          W / (2 * fx), H / (2 * fx))
+        color.sum().backward()
+        reps += 1
+    t_pass = (time.perf_counter() - t0) / reps
+    scale = (n_gaussians * n_pixels) / float(N * H * W)
+    return {'value': 1.0 / (t_pass * scale * 200), 'unit': 'frames/s',
+            'cores': threads, 'kind': 'port',
+            'sample': f'{reps} forward+backward passes of the dense torch '
+                      f'oracle, {N} Gaussians x {W}x{H} pixels '
+                      f'({t_pass:.3f} s each); scaled by N*H*W to '
+                      f'{int(n_gaussians)} Gaussians x 640x480 and 200 '
+                      'passes per frame (the oracle evaluates every Gaussian '
+                      'at every pixel: it is a checker, not a rasteriser)'}
 
 
 class _NumpyImages:
@@ -715,7 +805,8 @@ def run_pointslam(args, dev, world=1):
     frame (every frame for the first 20) 300 mapping it x 5000 rays, 5 samples
     per ray, 8-NN feature interpolation from the neural point cloud.  Random-
     initialised decoders (the pretrained checkpoint is not available offline).
-    Functional end-to-end path on the HIP grid kNN; no roofline object yet."""
+    Functional end-to-end path on the HIP grid kNN (the rest of the chain is
+    torch ops: the fused render kernels are the next row to build)."""
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.configs.input_config import (cadence,
@@ -741,6 +832,44 @@ def run_pointslam(args, dev, world=1):
                           keyframe_every=cad.keyframe_every,
                           lazy_start=cad.lazy_start, pose_device=str(dev))
     elapsed = _timed_frames(slam, args, dev, world)
+    t_track, t_map = slam.t_track, slam.t_map
+    # the one native kernel of this path: per-launch timing of a further frame
+    from xrdslam_amd.engine import knn as eknn
+    eknn.PROFILE = []
+    slam.step(1 + args.warmup + args.steps)
+    torch.cuda.synchronize()
+    prof, eknn.PROFILE = eknn.PROFILE, None
+    roofline = None
+    if prof:
+        big = max(m for _, _, m, _ in prof)
+        sel = [(a.elapsed_time(b) * 1e3, m, n) for a, b, m, n in prof
+               if m == big]
+        us = float(np.mean([t for t, _, _ in sel]))
+        n_pts = float(np.mean([n for _, _, n in sel]))
+        # per sample 8 x (8 B id + 12 B position + 128 B + 128 B
+        # features) ~ 2.2 KB gathered downstream of the search; the search
+        # itself reads the 27 neighbouring cells of the query's cell
+        byts = big * 2200.0
+        roofline = {
+            'bound': 'hbm', 'achieved': byts / (us * 1e-6) / 1e9,
+            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+            'frac': byts / (us * 1e-6) / HBM_PEAK, 'traffic': None,
+            'kernel': 'knn_search_kernel<8> (exact uniform-grid 8-NN; the '
+                      'only HIP kernel of this path: interpolation, the '
+                      'three MLPs and compositing are torch ops, ~1000 '
+                      'launches per iteration)',
+            'avg_launch_us': us, 'launches': len(sel),
+            'queries_per_launch': big, 'neural_points': n_pts,
+            'algorithmic_bytes_per_query': 2200,
+            'timing_source': 'HIP events around the searches of the frame '
+                             'run right after the timed region'}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = pointslam_cpu_baseline(min(os.cpu_count() or 1, 16))
+        except Exception as e:   # the baseline must not take the line down
+            cpu = {'value': None, 'unit': 'frames/s', 'kind': 'port',
+                   'cores': 0, 'sample': f'failed: {type(e).__name__}: {e}'}
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -749,11 +878,64 @@ def run_pointslam(args, dev, world=1):
             'workload': 'Point-SLAM 640x480 synthetic RGB-D: 40 tracking it x '
                         '1500 rays + 300 mapping it x 5000 rays (every frame '
                         'during the first 20, then every 5th), 5 samples/ray',
-            'track_ms_per_frame': slam.t_track / args.steps * 1e3,
-            'map_ms_per_frame': slam.t_map / args.steps * 1e3,
+            'track_ms_per_frame': t_track / args.steps * 1e3,
+            'map_ms_per_frame': t_map / args.steps * 1e3,
             'ate_rmse_m': slam.ate_rmse(),
             'neural_points': int(algo.model.neural_point_cloud.pts_num())},
-        'roofline': None, 'cpu_baseline': None}
+        'roofline': roofline, 'cpu_baseline': cpu}
+
+
+def pointslam_cpu_baseline(threads):
+    """the host mirror of the reference's Point-SLAM model on the CPU with the
+    exact brute-force neighbour search the golden was made with
+    (oracle/faiss_standin.py; tests/test_pointslam_host.py pins this
+    configuration against the reference-made golden): frame 0 builds the
+    cloud, then ONE tracking iteration (1500 rays) and ONE mapping iteration
+    (5000 rays) are timed, forward+backward; converted with the reference
+    iteration counts (40 tracking it per frame + 300 mapping it every 5th)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import faiss_standin
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import (cadence,
+                                                       pointslam_config)
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.set_num_threads(threads)
+    cam = Camera(**CAM)
+    cfg = pointslam_config()
+    cfg.mapping_first_n_iters = 1
+    # a tenth of the rays (bounded sample: the full batch takes minutes per
+    # iteration on the host); times are scaled back by the ray count
+    shrink = 10
+    cfg.tracking_sample //= shrink
+    cfg.mapping_sample //= shrink
+    algo = cfg.setup(camera=cam, device='cpu')
+    algo.model.knn_factory = faiss_standin.TorchKNN
+    data = _NumpyImages(SyntheticRoom(
+        CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,
+        cy=cam.cy, n_frames=8, device='cpu'))
+    cad = cadence['point-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          lazy_start=cad.lazy_start, pose_device='cpu')
+    frame = slam.step(0)            # cloud from frame 0, 1 mapping iteration
+    t0 = time.perf_counter()
+    algo.optimize_update(1, [frame], is_mapping=False)
+    t_track = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    algo.optimize_update(1, [frame], is_mapping=True)
+    t_map = time.perf_counter() - t0
+    per_frame = shrink * (40 * t_track + 300 * t_map / 5)
+    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': threads,
+            'kind': 'port',
+            'sample': f'1 tracking iteration ({cfg.tracking_sample} rays x 5 '
+                      f'samples) + 1 mapping iteration ({cfg.mapping_sample} '
+                      'rays x 5 samples), fwd+bwd, '
+                      f'{int(algo.model.neural_point_cloud.pts_num())} neural '
+                      'points (cloud seeded from the same reduced batch), '
+                      f'exact brute-force 8-NN; scaled x{shrink} to the '
+                      'reference ray counts and by its iteration counts; '
+                      f'iter seconds track={t_track:.2f} map={t_map:.2f}'}
 
 
 def _files_ingest(room, n_frames, cam, dev):

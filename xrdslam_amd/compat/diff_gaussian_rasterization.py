@@ -79,6 +79,27 @@ def _build_camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
     return cam
 
 
+# bench.py: per-launch HIP-event timing, key -> [(start, end)], plus the
+# (pixel, contributing Gaussian) pair count of every forward pass
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, key):
+        self.key = key if PROFILE is not None else None
+
+    def __enter__(self):
+        if self.key is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.key is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1))
+
+
 class _Binning:
     """static capacity of the (Gaussian, tile) pair list per device.  A pass
     leaves its true pair count in a device scalar; it is copied to pinned
@@ -159,11 +180,12 @@ class _RasterizeFn(torch.autograd.Function):
         radii = torch.zeros(n, **i)
         rect = torch.zeros(n, 4, **i)
         tiles = torch.zeros(n, **i)
-        _lib.check(lib.xrd_gs_preprocess(
-            C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
-            _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy), _lib.ptr(conic_o),
-            _lib.ptr(radii), _lib.ptr(rect), _lib.ptr(tiles), st),
-            'xrd_gs_preprocess')
+        with _Timed('gs_preprocess'):
+            _lib.check(lib.xrd_gs_preprocess(
+                C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
+                _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy),
+                _lib.ptr(conic_o), _lib.ptr(radii), _lib.ptr(rect),
+                _lib.ptr(tiles), st), 'xrd_gs_preprocess')
         gx, gy = (W + 15) // 16, (H + 15) // 16
         ranges = torch.empty(gx * gy, 2, **i)
         # tile binning on the stream (scan, key duplication, radix sort,
@@ -174,20 +196,26 @@ class _RasterizeFn(torch.autograd.Function):
         plist = torch.empty(cap, **i)
         n_keys = torch.empty(1, dtype=torch.int64, device=dev)
         ws = _BIN.workspace(dev, lib.xrd_gs_bin_ws_bytes(n, cap, W, H))
-        _lib.check(lib.xrd_gs_bin(
-            n, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths), cap,
-            _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges), _lib.ptr(n_keys),
-            st), 'xrd_gs_bin')
+        with _Timed('gs_bin'):
+            _lib.check(lib.xrd_gs_bin(
+                n, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths),
+                cap, _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges),
+                _lib.ptr(n_keys), st), 'xrd_gs_bin')
         _BIN.report(dev, n, cap, n_keys)
         color = torch.empty(3, H, W, **f)
         depth = torch.empty(1, H, W, **f)
         final_T = torch.empty(H, W, **f)
         n_contrib = torch.empty(H, W, **i)
-        _lib.check(lib.xrd_gs_render_fwd(
-            C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
-            _lib.ptr(cl), _lib.ptr(conic_o), _lib.ptr(depths),
-            _lib.ptr(color), _lib.ptr(depth), _lib.ptr(final_T),
-            _lib.ptr(n_contrib), st), 'xrd_gs_render_fwd')
+        with _Timed('gs_render_fwd'):
+            _lib.check(lib.xrd_gs_render_fwd(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(cl), _lib.ptr(conic_o), _lib.ptr(depths),
+                _lib.ptr(color), _lib.ptr(depth), _lib.ptr(final_T),
+                _lib.ptr(n_contrib), st), 'xrd_gs_render_fwd')
+        if PROFILE is not None:
+            PROFILE.setdefault('pairs', []).append(n_contrib.sum())
+            PROFILE.setdefault('keys', []).append(n_keys.clone())
+            PROFILE.setdefault('gaussians', []).append(n)
         ctx.rs, ctx.n = rs, n
         ctx.save_for_backward(m3, sc, rt, cl, xy, conic_o, radii, ranges,
                               plist, final_T, n_contrib)
@@ -209,12 +237,13 @@ class _RasterizeFn(torch.autograd.Function):
         d_op = torch.zeros(n, 1, **f)
         d_col = torch.zeros(n, 3, **f)
         gc = g_color.float().contiguous()
-        _lib.check(lib.xrd_gs_render_bwd(
-            C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
-            _lib.ptr(conic_o), _lib.ptr(cl), _lib.ptr(final_T),
-            _lib.ptr(n_contrib), _lib.ptr(gc), _lib.ptr(d_mean2D),
-            _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_col), st),
-            'xrd_gs_render_bwd')
+        with _Timed('gs_render_bwd'):
+            _lib.check(lib.xrd_gs_render_bwd(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(conic_o), _lib.ptr(cl), _lib.ptr(final_T),
+                _lib.ptr(n_contrib), _lib.ptr(gc), _lib.ptr(d_mean2D),
+                _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_col), st),
+                'xrd_gs_render_bwd')
         d_means = torch.empty(n, 3, **f)
         d_scales = torch.empty(n, 3, **f)
         d_rots = torch.empty(n, 4, **f)

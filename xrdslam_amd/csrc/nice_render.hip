@@ -1669,6 +1669,76 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
   }
 }
 
+// Point queries (the mesher's query_fn / color_func, conv_onet.py:213-240 ->
+// NICE.forward with stage 'fine' / 'color', and ConvOnet.eval_points'
+// out-of-bound override conv_onet.py:358-370): raw [n,4] = (rgb raw or 0,
+// occupancy logit) of n free points.  One wave = 16 points, 8 waves a block,
+// the decoders' forward fragments staged once per group of 128 points.
+template <int STAGE>
+__global__ __launch_bounds__(8 * 64, 2) void nice_points_kernel(
+    xrd_nice_scene sc, int64_t n, const float* __restrict__ pts,
+    float* __restrict__ raw_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  const int64_t ngroups = (n + 127) / 128;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t pt = (grp * 8 + wave) * 16 + li;
+    const bool active = pt < n;
+    double p64[3] = {0.0, 0.0, 0.0};
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        p32[0][a] = pts[pt * 3 + a];
+        p64[a] = (double)p32[0][a];
+      }
+    }
+    const bool inb = in_bound(p64, sc.bound);
+    float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
+    uint64_t mdummy[1];
+    Tri tr;
+    f32x4 c_m[1][2];
+    tri_prepare(p64, sc.bound, 1.0, sc.gdim + 3, tr);
+    tri_gather(sc.grid[1], tr, q, c_m[0]);
+    stage_weights(wl, sc.dec[1], MlpPack<32, 1>::WHT);
+    {
+      float om[1][1];
+      mlp_fwd<1, 32, 1, false, false>(wl, lane, p32, c_m, om, mdummy, nullptr);
+      occ = om[0][0];
+    }
+    {
+      f32x4 c_f[1][4], cf[2];
+      tri_prepare(p64, sc.bound, 1.0, sc.gdim + 6, tr);
+      tri_gather(sc.grid[2], tr, q, cf);
+      c_f[0][0] = cf[0];
+      c_f[0][1] = cf[1];
+      c_f[0][2] = c_m[0][0];
+      c_f[0][3] = c_m[0][1];
+      stage_weights(wl, sc.dec[2], MlpPack<64, 1>::WHT);
+      float of[1][1];
+      mlp_fwd<1, 64, 1, false, false>(wl, lane, p32, c_f, of, mdummy, nullptr);
+      occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
+    }
+    if (STAGE == XRD_STAGE_COLOR) {
+      f32x4 c_c[1][2];
+      tri_prepare(p64, sc.bound, 1.0, sc.gdim + 9, tr);
+      tri_gather(sc.grid[3], tr, q, c_c[0]);
+      stage_weights(wl, sc.dec[3], MlpPack<32, 4>::WHT);
+      float oc[1][4];
+      mlp_fwd<1, 32, 4, false, false>(wl, lane, p32, c_c, oc, mdummy, nullptr);
+      col[0] = oc[0][0];
+      col[1] = oc[0][1];
+      col[2] = oc[0][2];
+    }
+    if (!inb) occ = 100.f;  // conv_onet.py:370
+    if (active && q == 0)
+      *reinterpret_cast<f32x4*>(raw_out + pt * 4) =
+          f32x4{col[0], col[1], col[2], occ};
+  }
+}
+
 // g_dec = sum of the dW replicas; g_rays_{o,d}[ray] = sum of the ray's tile
 // partials (fixed order: deterministic)
 __global__ __launch_bounds__(256) void nice_bwd_finish_kernel(
@@ -1837,6 +1907,42 @@ int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene) {
   if (scene == nullptr) return -1;
   return (int64_t)kCoarseRep * scene->gdim[0] * scene->gdim[1] *
          scene->gdim[2] * 32;
+}
+
+int xrd_nice_eval_points(const xrd_nice_scene* scene, int stage,
+                         int64_t n_points, const float* points, float* raw,
+                         xrd_stream_t stream) {
+  if (scene == nullptr || n_points < 0) return XRD_ERR_ARG;
+  if (stage != XRD_STAGE_FINE && stage != XRD_STAGE_COLOR)
+    return XRD_ERR_UNSUPPORTED;
+  for (int g = 1; g <= stage; ++g)
+    if (scene->grid[g] == nullptr || scene->dec[g] == nullptr)
+      return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  if (!points || !raw) return XRD_ERR_ARG;
+  const size_t lds = (size_t)kWMax * sizeof(float);
+  auto kf = nice_points_kernel<XRD_STAGE_FINE>;
+  auto kc = nice_points_kernel<XRD_STAGE_COLOR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kf),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kc),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr_set = true;
+  }
+  const int64_t ngroups = (n_points + 127) / 128;
+  const int nb = (int)(ngroups < 512 ? ngroups : 512);
+  if (stage == XRD_STAGE_FINE)
+    hipLaunchKernelGGL(kf, dim3(nb), dim3(512), lds, (hipStream_t)stream,
+                       *scene, n_points, points, raw);
+  else
+    hipLaunchKernelGGL(kc, dim3(nb), dim3(512), lds, (hipStream_t)stream,
+                       *scene, n_points, points, raw);
+  return check_launch("xrd_nice_eval_points");
 }
 
 int64_t xrd_nice_bwd_ws_floats(int n_rays) {

@@ -10,6 +10,9 @@ import torch
 from .. import _lib
 
 
+PROFILE = None   # bench.py: [(start event, end event, queries, points)]
+
+
 class GridKNN:
     """exact k=8 nearest neighbours within ``max_radius``"""
 
@@ -72,10 +75,17 @@ class GridKNN:
             return D, I
         if self._dirty:
             self._build()
+        if PROFILE is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.xrd_knn_search(
             m, _lib.ptr(q), _lib.ptr(self._sorted_pts),
             _lib.ptr(self._sorted_ids), self._origin.ctypes.data,
             self.max_radius, self._dims.ctypes.data, _lib.ptr(self._start),
             _lib.ptr(self._end), k, self.max_radius, _lib.ptr(D), _lib.ptr(I),
             _lib.stream_ptr(self.device)), 'xrd_knn_search')
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append((e0, e1, m, self.ntotal))
         return D, I
