@@ -98,6 +98,14 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
  * in the camera's cell: blocks scatter into 32 replicas that are summed into
  * g_grid[0] afterwards).  The buffer must be ZERO on entry and is left zero.
  * Pass it as `workspace`; NULL = scatter straight into g_grid[0]. */
+/* Point queries for the mesher (ConvOnet.query_fn / color_func,
+ * slam/models/conv_onet.py:213-240 -> NICE.forward, stage 'fine' / 'color';
+ * out-of-bound points get occupancy 100 like ConvOnet.eval_points :358-370):
+ * points [n,3] f32 -> raw [n,4] = (rgb raw (stage colour) or 0, occupancy
+ * logit = fine + middle).  stage: XRD_STAGE_FINE or XRD_STAGE_COLOR. */
+int xrd_nice_eval_points(const xrd_nice_scene* scene, int stage,
+                         int64_t n_points, const float* points, float* raw,
+                         xrd_stream_t stream);
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):

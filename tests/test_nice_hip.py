@@ -344,3 +344,40 @@ def test_fused_cell_adam_empty_selection_is_noop():
     opt.step()
     torch.cuda.synchronize()
     assert torch.equal(p.detach(), before)
+
+
+def test_point_queries_match_oracle_and_mesher_runs():
+    """xrd_nice_eval_points (the mesher's query_fn / color_func) against the
+    oracle's eval_points, incl. the out-of-bound override; then the mesher on
+    the model hooks"""
+    import nice_oracle as no
+    from xrdslam_amd.engine import nice as en
+    dev = torch.device('cuda:0')
+    g, bound, grids, decs, _ = load_nice_golden()
+    scene = en.NiceScene(bound, device=dev)
+    for k, v in grids.items():
+        scene.set_grid(k, en.to_channels_last_grid(v.to(dev)))
+    for kind, sd in decs.items():
+        scene.set_decoder(kind, en.flatten_state_dict(sd, kind).to(dev))
+    gen = torch.Generator().manual_seed(3)
+    lo, hi = bound[:, 0].float(), bound[:, 1].float()
+    p = lo + (hi - lo) * (torch.rand(5000, 3, generator=gen) * 1.2 - 0.1)
+    for stage in ('fine', 'color'):
+        ref = no.eval_points(p, grids, decs, bound, stage)
+        got = en.nice_eval_points(scene, stage, p.to(dev)).cpu()
+        cols = [3] if stage == 'fine' else [0, 1, 2, 3]
+        for c in cols:
+            assert rel_err(got[:, c], ref[:, c].detach()) < 1e-4, (stage, c)
+        outside = ((p < lo) | (p > hi)).any(1)
+        assert outside.any() and bool((got[outside, 3] == 100).all())
+    # the mesher over the hooks: a lattice strictly inside the bound
+    from xrdslam_amd.slam.common.mesher import Mesher, MesherConfig
+    inner = torch.stack([lo + 0.05 * (hi - lo), hi - 0.05 * (hi - lo)], 1)
+    m = Mesher(MesherConfig(resolution=24, points_batch_size=5000), None,
+               bound, inner)
+    mesh = m.get_mesh([], lambda q: en.nice_eval_points(scene, 'fine', q),
+                      lambda q: en.nice_eval_points(scene, 'color', q),
+                      device=dev)
+    if mesh is not None:    # random-init decoders may have no zero crossing
+        assert mesh.faces.max() < mesh.vertices.shape[0]
+        assert mesh.vertex_colors.shape[0] == mesh.vertices.shape[0]

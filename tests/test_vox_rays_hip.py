@@ -257,3 +257,14 @@ def test_voxfusion_loop_through_graphs():
     # lengths is taken in a different order; everything else agrees
     assert close.mean() > 0.999, close.mean()
     assert np.abs(d_f - d_m).max() < 0.05
+    # mesh of the mapped room: vertices inside the allocated voxels, colours
+    algo.fused_iteration = True
+    mesh = algo.get_mesh()
+    assert mesh is not None and mesh.faces.shape[0] > 100
+    assert mesh.faces.max() < mesh.vertices.shape[0]
+    assert mesh.vertex_colors.shape == (mesh.vertices.shape[0], 3)
+    ms = algo.model.map_states
+    leaf = ~ms['voxel_vertex_idx'].eq(-1).any(-1)
+    c = ms['voxel_center_xyz'][leaf].cpu().numpy()
+    lo, hi = c.min(0) - 0.1001, c.max(0) + 0.1001
+    assert (mesh.vertices >= lo).all() and (mesh.vertices <= hi).all()

@@ -48,6 +48,8 @@ _SIGS = {
     'xrd_nice_pack_index': (C.c_int, [C.c_int, vp]),
     'xrd_nice_render_fwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'xrd_nice_eval_points': (C.c_int, [C.POINTER(NiceScene), C.c_int, i64, vp,
+                                       vp, vp]),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,

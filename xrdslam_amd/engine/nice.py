@@ -338,3 +338,21 @@ def nice_render(scene: NiceScene, stage: str, rays_o: torch.Tensor,
     gl = [scene.grids[GRID_KEYS[i]] if i in used else empty for i in range(4)]
     return _NiceRenderFn.apply(rays_o, rays_d, flat, gl[0], gl[1], gl[2],
                                gl[3], scene, stage, gt_depth, dmax)
+
+
+@torch.no_grad()
+def nice_eval_points(scene: NiceScene, stage: str,
+                     points: torch.Tensor) -> torch.Tensor:
+    """decoder values at free points, [n,3] -> raw [n,4] = (rgb raw or 0,
+    occupancy logit); stage 'fine' or 'color' (the mesher's query_fn /
+    color_func, conv_onet.py:213-240)"""
+    if not points.is_cuda:
+        raise _lib.XrdError('nice_eval_points needs CUDA tensors')
+    st = {'fine': 2, 'color': 3}[stage]
+    p = points.detach().float().reshape(-1, 3).contiguous()
+    raw = torch.empty(p.shape[0], 4, dtype=torch.float32, device=p.device)
+    cs = scene.c_struct()
+    _lib.check(_lib.lib().xrd_nice_eval_points(
+        C.byref(cs), st, p.shape[0], _lib.ptr(p), _lib.ptr(raw),
+        _lib.stream_ptr(p.device)), 'xrd_nice_eval_points')
+    return raw

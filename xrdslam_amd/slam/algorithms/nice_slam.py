@@ -361,5 +361,22 @@ class NiceSLAM(Algorithm):
             return color.cpu().numpy(), depth.cpu().numpy()
 
     def get_mesh(self):
-        raise NotImplementedError('mesh extraction is out of the hot-path '
-                                  'scope (SURVEY.md §8f #3)')
+        """the fine-level occupancy level set over marching_cubes_bound,
+        coloured by the colour decoder (nice_slam.py:281-288)"""
+        with self.lock:
+            self.model.sync_decoders(force=True)
+            self.cur_mesh = self._mesher().get_mesh(
+                keyframe_graph=self.keyframe_graph,
+                query_fn=self.model.query_fn,
+                color_func=self.model.color_func, device=self.device)
+            return self.cur_mesh
+
+    def _mesher(self):
+        if getattr(self, 'mesher', None) is None:
+            from ..common.mesher import MesherConfig
+            cfg = getattr(self.config, 'mesher', None) or MesherConfig(
+                resolution=256, points_batch_size=30000)
+            self.mesher = cfg.setup(
+                camera=self.camera, bounding_box=self.bounding_box,
+                marching_cubes_bound=self.marching_cube_bound)
+        return self.mesher

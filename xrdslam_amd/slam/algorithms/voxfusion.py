@@ -214,6 +214,56 @@ class VoxFusion(Algorithm):
         return None
 
     def get_mesh(self):
-        raise NotImplementedError('mesh extraction (marching cubes per voxel) '
-                                  'is out of the hot-path scope '
-                                  '(SURVEY.md §8f)')
+        """per-voxel 8^3 lattices of the decoder's sdf, zero level set,
+        vertex colours from the colour head (voxfusion.py:173-278)"""
+        with self.lock, torch.no_grad():
+            return self.extract_mesh(clean_mesh=False, require_color=True,
+                                     res=8)
+
+    @torch.no_grad()
+    def extract_mesh(self, res=8, clean_mesh=False, require_color=False):
+        from ...engine import vox as _vox
+        from ..common.mesher import Mesh, marching_tetrahedra
+        m = self.model
+        ms, vs = m.map_states, m.config.voxel_size
+        dev = ms['voxel_center_xyz'].device
+        # leaf voxels: all eight vertices present (voxfusion.py:181-184)
+        ids = torch.nonzero(~ms['voxel_vertex_idx'].eq(-1).any(-1)).flatten()
+        n = int(ids.numel())
+        if n == 0:
+            return None
+        lin = torch.linspace(-0.5, 0.5, res, device=dev)
+        xx, yy, zz = torch.meshgrid(lin, lin, lin, indexing='ij')
+        offs = torch.stack([xx, yy, zz], -1).reshape(1, -1, 3) * vs
+        centres = ms['voxel_center_xyz'][ids]
+        xyz = (centres[:, None, :] + offs).reshape(-1, 3).contiguous()
+        vox = ids[:, None].expand(n, res**3).reshape(-1).int().contiguous()
+        out = _vox.points(m.decoder, xyz, vox, ms, vs)
+        if out is None:
+            raise NotImplementedError('mesh extraction needs the fused '
+                                      'decoder kernels (CUDA, default decoder)')
+        sdf = out['sdf'].reshape(n, res, res, res)
+        # every voxel is its own little volume (the reference runs marching
+        # cubes voxel by voxel, :254-277): stacked along x with a separator
+        # plane of inf, which the extraction skips
+        vol = torch.full((n, res + 1, res, res), float('inf'), device=dev)
+        vol[:, :res] = sdf
+        h = 1.0 / (res - 1)
+        verts, faces = marching_tetrahedra(vol.reshape(-1, res, res), 0.0,
+                                           (h, h, h))
+        if verts.shape[0] == 0:
+            return None
+        v = torch.from_numpy(verts).to(dev)
+        gx = v[:, 0] / h
+        # lattice x of voxel k spans [k (res+1), k (res+1) + res - 1]; the
+        # half-cell shift keeps rounding at the ends on the right voxel
+        k = torch.div(gx + 0.5, res + 1, rounding_mode='floor').long() \
+            .clamp(0, n - 1)
+        local = torch.stack([(gx - k * (res + 1)) * h, v[:, 1], v[:, 2]], -1)
+        world = ((local - 0.5) * vs + centres[k].double()).float()
+        colors = None
+        if require_color:
+            col = _vox.points(m.decoder, world.contiguous(),
+                              ids[k].int().contiguous(), ms, vs)['color']
+            colors = (col.clamp(0, 1) * 255).byte().cpu().numpy()
+        return Mesh(world.cpu().numpy().astype(np.float64), faces, colors)

@@ -377,9 +377,12 @@ class ConvOnet(Model):
                     torch.zeros((), dtype=c.dtype, device=c.device)).sum()
         return losses
 
-    # -- mesher hooks (conv_onet.py:213-240): next row, not built yet -------
+    # -- mesher hooks (conv_onet.py:213-240) -----------------------------------
     def query_fn(self, pi):
-        raise NotImplementedError('point queries for the mesher: SURVEY §8f #3')
+        """[N,3] -> [N,4] decoder values of stage 'fine' (the level set the
+        mesher extracts is column 3, the occupancy logit)"""
+        return _en.nice_eval_points(self.scene(), 'fine', pi)
 
     def color_func(self, pi):
-        raise NotImplementedError('point queries for the mesher: SURVEY §8f #3')
+        """[N,3] -> [N,4] of stage 'color' (vertex colours = columns 0-2)"""
+        return _en.nice_eval_points(self.scene(), 'color', pi)
