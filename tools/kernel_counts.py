@@ -46,7 +46,7 @@ def count(fn, tag):
                 else e.cuda_time
     print(f'== {tag}: {sum(c.values())} device activities, '
           f'{sum(t.values()):.0f} us')
-    for n, k in c.most_common(14):
+    for n, k in c.most_common(30):
         print(f'   {k:4d} x {n}  ({t[n]:.0f} us)')
 
 

@@ -404,12 +404,19 @@ class Algorithm:
         if slot is None:
             sfs = []
             for i, f in enumerate(frames):
-                sf = Frame(i - len(frames), f.rgb, f.depth,
+                # a frame that kept no images (Co-SLAM keyframes: pose and
+                # bank rays only) gets a pose-only stand-in
+                has_img = f.depth is not None or f._dev_cache is not None
+                shape_src = f if has_img else frames[-1]
+                sf = Frame(i - len(frames), shape_src.rgb, shape_src.depth,
                            init_pose=f.get_pose().detach().cpu().numpy(),
                            gt_pose=None, separate_LR=f.separate_LR,
                            rot_rep=f.rot_rep, device=str(dev))
-                fd, fc = f.device_images(dev)
-                sf._dev_cache = (torch.empty_like(fd), torch.empty_like(fc))
+                sf._slot_images = has_img
+                if has_img:
+                    fd, fc = f.device_images(dev)
+                    sf._dev_cache = (torch.empty_like(fd),
+                                     torch.empty_like(fc))
                 sfs.append(sf)
             slot = slots[key] = {'frames': sfs, 'opt': None, 'graphs': {}}
         slot['calls'] = slot.get('calls', 0) + 1
@@ -417,10 +424,11 @@ class Algorithm:
         sfs = slot['frames']
         with torch.no_grad():
             for sf, f in zip(sfs, frames):
-                fd, fc = f.device_images(dev)
-                sd, sc = sf._dev_cache
-                sd.copy_(fd, non_blocking=True)
-                sc.copy_(fc, non_blocking=True)
+                if getattr(sf, '_slot_images', True):
+                    fd, fc = f.device_images(dev)
+                    sd, sc = sf._dev_cache
+                    sd.copy_(fd, non_blocking=True)
+                    sc.copy_(fc, non_blocking=True)
                 for ps, pf in zip(sf.get_params(), f.get_params()):
                     ps.copy_(pf.detach().to(ps.device))
         self.pre_precessing(sfs[-1], True)
@@ -434,8 +442,7 @@ class Algorithm:
                 return False
         else:
             self.refresh_map_selection()
-            for opt in slot['opt'].optimizers.values():
-                reset_optimizer_state(opt)
+            self.reset_slot_optimizers(slot['opt'])
         opt, graphs = slot['opt'], slot['graphs']
         self.fixed_shape_batches = True
         split = _dist.state.enabled
@@ -489,24 +496,25 @@ class Algorithm:
                 _dist.run_grad_jobs(jobs)
                 gb.replay()
         elif first:
-            seg_key, seg_iter = None, 0
+            # per key: first occurrence eager (lazy state gets created),
+            # second captured, then replays — the occurrences need not be
+            # consecutive (Co-SLAM: every 5th iteration also steps the poses)
+            seen = set()
             for step in range(n_iters):
                 k = self.graph_segment_key(True, step, n_iters, coarse)
-                if k != seg_key:
-                    seg_key, seg_iter = k, 0
-                if seg_iter == 0:
+                if k in graphs:
+                    graphs[k].replay()
+                elif k not in seen:
+                    seen.add(k)
                     self._iteration(opt, sfs, True, step, n_iters, coarse,
                                     None)
-                elif k not in graphs:
+                else:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._iteration(opt, sfs, True, step, n_iters, coarse,
                                         None)
                     graphs[k] = g
                     g.replay()
-                else:
-                    graphs[k].replay()
-                seg_iter += 1
                 opt.scheduler_step_all()
             segs = {self.graph_segment_key(True, s, n_iters, coarse)
                     for s in range(n_iters)}
@@ -519,12 +527,24 @@ class Algorithm:
                 graphs[self.graph_segment_key(True, step, n_iters,
                                               coarse)].replay()
         self.fixed_shape_batches = False
+        self.before_slot_copy_out()
         if self.bundle_adjust:
             with torch.no_grad():
                 for sf, f in zip(sfs, frames):
                     for ps, pf in zip(sf.get_params(), f.get_params()):
                         pf.copy_(ps.detach().to(pf.device))
         return True
+
+    def reset_slot_optimizers(self, optimizers):
+        """replay-only mapping call: the state a freshly built Optimizers
+        object would have (the reference builds one per call)"""
+        from ..engine.optimizers import reset_optimizer_state
+        for opt in optimizers.optimizers.values():
+            reset_optimizer_state(opt)
+
+    def before_slot_copy_out(self):
+        """slot call: last chance to write results into the slot frames
+        before their poses are copied back to the real frames"""
 
     def refresh_map_selection(self):
         """replay-only mapping call: re-select what get_param_groups selected

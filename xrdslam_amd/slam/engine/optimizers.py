@@ -203,7 +203,10 @@ class Optimizers:
                 opt.step()
             elif (step + 1) % ocfg.accum_step == 0:
                 opt.step()
-                opt.zero_grad(set_to_none=True)
+                # static_grads (captured graphs): the accumulation buffer
+                # keeps its address and is zeroed in place
+                opt.zero_grad(
+                    set_to_none=not getattr(self, 'static_grads', False))
 
     def scheduler_step_all(self) -> None:
         for sch in self.schedulers.values():
