@@ -66,12 +66,12 @@ FWD_FLOPS = {'coarse': 12.4e3, 'middle': 31.0e3, 'fine': 72.0e3,
              'color': 103.0e3}
 
 
-def pmc_traffic(kernels):
+def pmc_traffic(kernels, which='r02_pmc.json'):
     """bytes per launch of a launch group from the committed PMC pass
-    (profiles/r02_pmc.json, made by tools/run_pmc.sh on this same workload):
+    (profiles/r02_pmc*.json, made by tools/run_pmc.sh on this same workload):
     sum over the group's kernels of 2 x FETCH_SIZE (gfx950 correction) +
     WRITE_SIZE; None when the file or a kernel is missing"""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
+    path = os.path.join(ROOT, 'profiles', which)
     if not os.path.exists(path):
         return None
     pmc = json.load(open(path))
@@ -582,7 +582,16 @@ def run_voxfusion(args, dev, world=1):
         roofline = {
             'bound': 'mfma', 'achieved': flops / (us * 1e-6) / 1e12,
             'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
-            'frac': flops / (us * 1e-6) / MFMA_F32_PEAK, 'traffic': None,
+            'frac': flops / (us * 1e-6) / MFMA_F32_PEAK,
+            # mean over the tracking- and mapping-sized launches of the PMC run
+            'traffic': pmc_traffic(
+                {'vox_dw': ['vox_dw_kernel', 'vox_dw_reduce_kernel'],
+                 'vox_points_fwd': ['vox_points_fwd_kernel'],
+                 'vox_points_bwd': ['vox_points_bwd_kernel']}[kern],
+                'r02_pmc_vox.json'),
+            'traffic_source': 'profiles/r02_pmc_vox.json (rocprofv3 --pmc '
+                              'FETCH_SIZE / WRITE_SIZE passes of this '
+                              'workload, FETCH x2 on gfx950)',
             'kernel': f'{kern}[decoder_grad={int(need_w)}]' + (
                 ' (launch: gather, trilinear feature, 16-128-128-129 / '
                 '144-128-3 decoder' + (', embedding scatter, dW operands'

@@ -27,7 +27,14 @@ def short_name(name):
               'coarse_rep_reduce_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
               'hash_chunk_scatter_kernel', 'coslam_reduce_kernel',
               'coslam_loss_grad_kernel', 'adam_dense_kernel',
-              'reduce_partials_kernel', 'hashgrid_kernel'):
+              'reduce_partials_kernel', 'hashgrid_kernel',
+              'vox_points_fwd_kernel', 'vox_points_bwd_kernel', 'vox_dw_kernel',
+              'vox_dw_reduce_kernel', 'vox_sample_kernel',
+              'svo_intersect_kernel', 'vox_hit_sort_kernel',
+              'vox_compact_kernel', 'vox_render_fwd_kernel',
+              'vox_render_bwd_kernel', 'vox_ray_grad_kernel',
+              'gs_render_fwd_kernel', 'gs_render_bwd_kernel',
+              'gs_preprocess_kernel', 'knn_search_kernel'):
         if k in name:
             return k
     return None
