@@ -122,7 +122,10 @@ class DistState:
             np.random.seed(seed * 7919 + 13)
 
     def shard_count(self, n: int) -> int:
-        """rays this rank draws out of n (ceil split, every rank the same)"""
+        """rays this rank draws out of n in the NON-deterministic mode (ceil
+        split, every rank the same: world * ceil(n / world) >= n rays in
+        total, so the summed gradient is that of a slightly larger batch; the
+        deterministic mode tiles the batch exactly, ``shard_slice``)"""
         return (n + self.world - 1) // self.world if self.enabled else n
 
     def shard_slice(self, n: int):

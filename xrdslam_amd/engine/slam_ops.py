@@ -248,9 +248,41 @@ class FusedDenseAdam(torch.optim.Optimizer):
     Parameters whose grad is None are skipped, like torch does."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, **_ignored):
+                 weight_decay=0.0, **other):
+        # torch.optim.Adam options this kernel does not implement must not be
+        # dropped silently (their defaults are accepted)
+        bad = {k: v for k, v in other.items()
+               if v not in (None, False) and not (k == 'foreach' and v)}
+        if bad:
+            raise ValueError(f'FusedDenseAdam: unsupported options {bad}')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps,
                                       weight_decay=weight_decay))
+
+    def state_dict(self):
+        """torch.optim.Adam-compatible: per-parameter exp_avg / exp_avg_sq and
+        ``step`` as a 0-d float tensor (the shared device counters are
+        expanded)"""
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            if 'step' in st:
+                st['step'] = st['step'].detach().reshape(()).float().cpu()
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if k in st:
+                    st[k] = st[k].detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """accepts torch.optim.Adam state (``step`` a tensor or a number)"""
+        super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            if 'step' in st:
+                v = st['step']
+                v = int(v.item()) if torch.is_tensor(v) else int(v)
+                st['step'] = torch.full((1, ), v, dtype=torch.int32,
+                                        device=p.device)
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if k in st:
+                    st[k] = st[k].to(p.device, torch.float32).contiguous()
 
     @staticmethod
     def _consecutive(tensors):

@@ -301,8 +301,14 @@ class Algorithm:
         from ..common.frame import Frame
         dev = self.device
         slot = getattr(self, '_track_slot', None)
+        # the captured launches bake in the learning rates and the sampling
+        # configuration: they are part of the key
+        lrs = tuple(sorted(
+            (k, float(v['optimizer'].lr)) for k, v in
+            self.config.optimizers.items() if k.startswith('tracking_pose')))
         shape_key = (frame.h, frame.w, frame.separate_LR, frame.rot_rep,
-                     n_iters, self.track_slot_key())
+                     n_iters, lrs, getattr(self.config, 'tracking_sample',
+                                           None), self.track_slot_key())
         if slot is not None and slot['key'] != shape_key:
             slot = None
         init = frame.get_pose().detach()
