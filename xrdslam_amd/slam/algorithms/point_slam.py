@@ -62,6 +62,15 @@ class PointSLAM(Algorithm):
         self.model = mc.setup(camera=camera)
         self.model.to(device)
         self.dynamic_r_query_allkeyframe = {}
+        if torch.device(device).type == 'cuda':
+            # the decoders' GEMMs are tall and thin ([2e5, 52] x [52, 128],
+            # [25 000, 128] x [128, 128]): rocBLAS picks better kernels for
+            # them than hipBLASLt (measured +13 % frames/s); they stay library
+            # GEMMs until the fused render kernels exist
+            try:
+                torch.backends.cuda.preferred_blas_library('cublas')
+            except Exception:
+                pass
 
     @property
     def _dev(self):

@@ -109,12 +109,16 @@ class _PointMLP(nn.Module):
                                         activation=out_act)
 
     def _interpolate(self, npc, p, npc_feats, is_tracker, dynamic_r_query,
-                     transform=None):
-        """-> (feature [n,c_dim], has_neighbors [n])"""
+                     transform=None, neighbors=None):
+        """-> (feature [n,c_dim], has_neighbors [n]).  ``neighbors``: the
+        (D, I, n_nb) of a search already made for these points (POINT.forward
+        searches once for both decoders; the reference searches twice with
+        the same result, decoder_pointslam.py:181,426)"""
         cloud = npc.cloud_tensor(p.device)
         p = p.reshape(-1, 3)
-        D, I, n_nb = npc.find_neighbors_faiss(p.detach().clone(), step='query',
-                                              dynamic_radius=dynamic_r_query)
+        D, I, n_nb = neighbors if neighbors is not None else \
+            npc.find_neighbors_faiss(p.detach().clone(), step='query',
+                                     dynamic_radius=dynamic_r_query)
         missing = I < 0
         I = I.clamp(min=0)
         bound = npc.get_radius_query()**2 if not self.use_dynamic_radius \
@@ -168,9 +172,9 @@ class MLP_geometry(_PointMLP):
         self._build_trunk(93, hidden_size, n_blocks, c_dim, 1, 'relu')
 
     def forward(self, p, npc, pts_num=16, is_tracker=False, pts_views_d=None,
-                dynamic_r_query=None):
+                dynamic_r_query=None, neighbors=None):
         c, has = self._interpolate(npc, p, npc.get_geo_feats(), is_tracker,
-                                   dynamic_r_query)
+                                   dynamic_r_query, neighbors=neighbors)
         # a ray is valid when at least half of its samples have neighbours
         valid_ray = ~(torch.sum(has.view(-1, pts_num), 1) <
                       int(self.N_surface / 2 + 1))
@@ -225,10 +229,11 @@ class MLP_color(_PointMLP):
         return self.mlp_col_neighbor(torch.cat([emb, feats], -1))
 
     def forward(self, p, npc, is_tracker=False, pts_views_d=None,
-                dynamic_r_query=None, exposure_feat=None):
+                dynamic_r_query=None, exposure_feat=None, neighbors=None):
         c, _ = self._interpolate(
             npc, p, npc.col_feats, is_tracker, dynamic_r_query,
-            transform=self._f_theta if self.encode_rel_pos_in_col else None)
+            transform=self._f_theta if self.encode_rel_pos_in_col else None,
+            neighbors=neighbors)
         emb = self.embedder(p.float().reshape(1, -1, 3))
         if self.use_view_direction:
             emb = torch.cat([emb, self.embedder_view_direction(
@@ -266,9 +271,15 @@ class POINT(nn.Module):
 
     def forward(self, p, npc, stage, pts_num=16, is_tracker=False,
                 pts_views_d=None, dynamic_r_query=None, exposure_feat=None):
+        # one neighbour search serves both decoders
+        nb = None
+        if stage != 'geometry':
+            nb = npc.find_neighbors_faiss(
+                p.reshape(-1, 3).detach().clone(), step='query',
+                dynamic_radius=dynamic_r_query)
         occ, ray_mask, point_mask = self.geo_decoder(
             p, npc, pts_num=pts_num, is_tracker=is_tracker,
-            dynamic_r_query=dynamic_r_query)
+            dynamic_r_query=dynamic_r_query, neighbors=nb)
         if stage == 'geometry':
             raw = torch.zeros(occ.shape[0], 4, dtype=torch.float,
                               device=occ.device)
@@ -277,5 +288,5 @@ class POINT(nn.Module):
         rgb = self.color_decoder(p=p, npc=npc, is_tracker=is_tracker,
                                  pts_views_d=pts_views_d,
                                  dynamic_r_query=dynamic_r_query,
-                                 exposure_feat=exposure_feat)
+                                 exposure_feat=exposure_feat, neighbors=nb)
         return torch.cat([rgb, occ.unsqueeze(-1)], -1), ray_mask, point_mask
