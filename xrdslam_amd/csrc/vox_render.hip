@@ -121,7 +121,7 @@ __device__ __forceinline__ void save128(float* __restrict__ dst, int64_t pt,
     *reinterpret_cast<f32x4*>(dst + pt * 128 + 16 * jt + 4 * q) = v[jt];
 }
 
-__global__ __launch_bounds__(VW * 64, 2) void vox_points_fwd_kernel(
+__global__ __launch_bounds__(VW * 64, 4) void vox_points_fwd_kernel(
     int64_t P, const float* __restrict__ xyz, const int* __restrict__ vox,
     const float* __restrict__ centres, const int* __restrict__ vertex_idx,
     const float* __restrict__ emb, float voxel_size,
@@ -241,7 +241,7 @@ __device__ __forceinline__ f32x4 mask4(const f32x4 g, uint32_t bits,
   return r;
 }
 
-__global__ __launch_bounds__(VW * 64, 2) void vox_points_bwd_kernel(
+__global__ __launch_bounds__(VW * 64, 4) void vox_points_bwd_kernel(
     int64_t P, const float* __restrict__ xyz, const int* __restrict__ vox,
     const float* __restrict__ centres, const int* __restrict__ vertex_idx,
     const float* __restrict__ emb, float voxel_size,

@@ -329,25 +329,31 @@ class FusedDenseAdam(torch.optim.Optimizer):
                         st['exp_avg_sq'] = torch.zeros_like(
                             p, dtype=torch.float32)
                     st['step'] = step
-            bumped = set()
-            for p in live:
-                st = self.state[p]['step']
-                if st.data_ptr() not in bumped:
-                    st += 1
-                    bumped.add(st.data_ptr())
+            steps = {id(self.state[p]['step']): self.state[p]['step']
+                     for p in live}
+            for st in steps.values():
+                st += 1
             args = (float(grp['lr']), float(b1), float(b2),
                     float(grp['eps']), float(grp['weight_decay']))
             grads = [p.grad if p.grad.is_contiguous() else
                      p.grad.contiguous() for p in live]
             # back-to-back parameters, gradients and moments sharing one
             # counter (a decoder kept in one flat buffer whose gradient comes
-            # out of one kernel): ONE launch for the whole group
-            if len(live) > 1 and len(bumped) == 1 and \
-                    self._consecutive(live) and self._consecutive(grads) and \
+            # out of one kernel): ONE launch for the whole group.  Whether the
+            # parameters and moments qualify is decided once per state set-up;
+            # the gradients are checked every step (they are new tensors)
+            key = (len(live), len(steps))
+            if fresh or grp.get('_flat_key') != key:
+                grp['_flat_key'] = key
+                grp['_flat_ok'] = (
+                    len(live) > 1 and len(steps) == 1 and
+                    len(live) == len(grp['params']) and
+                    self._consecutive(live) and
                     self._consecutive([self.state[p]['exp_avg']
-                                       for p in live]) and \
+                                       for p in live]) and
                     self._consecutive([self.state[p]['exp_avg_sq']
-                                       for p in live]):
+                                       for p in live]))
+            if grp['_flat_ok'] and self._consecutive(grads):
                 st = self.state[live[0]]
                 _lib.check(lib.xrd_adam_dense(
                     _lib.ptr(live[0]), _lib.ptr(grads[0]),
