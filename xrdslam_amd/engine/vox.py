@@ -208,6 +208,9 @@ class RayWorkspace:
     def __init__(self, n_rays, s_cap, p_cap, need_w, device):
         self.n, self.s_cap, self.p_cap, self.need_w = n_rays, s_cap, p_cap, \
             need_w
+        # sharded mapping: makes the loss normalisers of the size record
+        # batch-global between sampling and the loss (None = single process)
+        self.meta_sync = None
         dev = device
         i = dict(dtype=torch.int32, device=dev)
         f = dict(dtype=torch.float32, device=dev)
@@ -285,6 +288,25 @@ def flatten_decoder(params):
             off += p.numel()
     p0._xrd_flat = flat
     return flat
+
+
+# size-record slots (csrc/vox_rays.hip, enum Meta)
+META_SUM = [1, 6, 7, 8]   # hit rays, free-space / band samples, usable depths
+META_MAX = [3]            # longest sample row
+
+
+def allreduce_meta(meta):
+    """sharded mapping: the reference's losses are means over the hit rays /
+    the PADDED [hit rays, longest row] array with batch-global balancing
+    weights (sparse_voxel.py:103-143) — the counts are summed and the row
+    length maximised over the ranks before the loss kernels read them"""
+    import torch.distributed as dist
+    cnt = meta[META_SUM].contiguous()
+    mx = meta[META_MAX].contiguous()
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    meta[META_SUM] = cnt
+    meta[META_MAX] = mx
 
 
 def _pack(params, like):
@@ -365,6 +387,8 @@ class _VoxRenderLossFn(torch.autograd.Function):
         assert not need_w or ws.need_w
         packed = flat.detach()[pack_index(rays_o.device)]
         sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise)
+        if ws.meta_sync is not None:
+            ws.meta_sync(ws.meta)
         _points_fwd(ws, ms, cfg, packed, need_w)
         _render_fwd(ws, cfg, target_d, target_s, True)
         ctx.ws, ctx.ms, ctx.cfg, ctx.need_w = ws, ms, cfg, need_w

@@ -60,8 +60,8 @@ class VoxFusion(Algorithm):
     persistent_map_graph = True
 
     def map_slot_key(self, n_iters, optimize_frames, coarse):
-        if not self.fused_iteration:
-            return None
+        if not self.fused_iteration or _dist.state.enabled:
+            return None     # sharded mapping: collectives inside the iteration
         f = optimize_frames[-1]
         return (len(optimize_frames), n_iters, f.h, f.w, f.separate_LR,
                 f.rot_rep, self.config.mapping_sample,
@@ -71,9 +71,12 @@ class VoxFusion(Algorithm):
         return (self.model.capacity_version, self.fused_iteration)
 
     def _graphs_ok(self, optimizers, is_mapping):
-        # the modular path syncs the host (hit counts, ragged lengths)
-        return self.fused_iteration and super()._graphs_ok(optimizers,
-                                                           is_mapping)
+        # the modular path syncs the host (hit counts, ragged lengths);
+        # sharded (multi-GPU) mapping exchanges its batch-global loss
+        # normalisers in the middle of the iteration: eager
+        if not self.fused_iteration or (is_mapping and _dist.state.enabled):
+            return False
+        return super()._graphs_ok(optimizers, is_mapping)
 
     def optimize_update(self, n_iters, optimize_frames, is_mapping,
                         coarse=False):
@@ -93,8 +96,9 @@ class VoxFusion(Algorithm):
         # RNG stream; losses use batch-global normalisers, gradients are
         # summed in Optimizers.optimizer_step_all
         sharded = is_mapping and _dist.state.enabled
-        gen = _dist.state.shard_generator if sharded else None
-        if sharded:
+        det = sharded and _dist.state.deterministic
+        gen = _dist.state.shard_generator if sharded and not det else None
+        if sharded and not det:
             n = _dist.state.shard_count(n)
         if torch.device(dev).type == 'cuda' and self.fused_iteration:
             return self._model_input_kernels(optimize_frames, n, gen, sharded)
@@ -103,6 +107,9 @@ class VoxFusion(Algorithm):
             o, d, dep, col = get_samples(self.camera, n, f.get_pose(), f.depth,
                                          f.rgb, device=dev, frame=f,
                                          generator=gen)
+            if det:   # same draws on every rank, this rank's slice
+                lo, hi = _dist.state.shard_slice(n)
+                o, d, dep, col = o[lo:hi], d[lo:hi], dep[lo:hi], col[lo:hi]
             ro.append(o.float())
             rd.append(d.float())
             gd.append(dep.float())
@@ -126,6 +133,15 @@ class VoxFusion(Algorithm):
         ro, rd, td, tc, _, _ = SampleRaysFn.apply(
             c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
             (0, 0, cam.width), (-big, big, -big, big, -big, big))
+        if sharded and _dist.state.deterministic:
+            # every rank drew the SAME batch (shared RNG stream); this rank
+            # keeps a contiguous slice of every frame's rays
+            lo, hi = _dist.state.shard_slice(n)
+            sel = (torch.arange(lo, hi, device=dev).unsqueeze(0) +
+                   n * torch.arange(len(frames), device=dev).unsqueeze(1)
+                   ).reshape(-1)
+            ro, rd = ro.index_select(0, sel), rd.index_select(0, sel)
+            td, tc = td[sel], tc[sel]
         return {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
                 'sharded': sharded}
 
@@ -153,7 +169,9 @@ class VoxFusion(Algorithm):
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):
         inp = self.get_model_input(optimize_frames, is_mapping)
-        if self.fused_iteration and not inp['sharded']:
+        if self.fused_iteration:
+            # (a shard of the mapping rays included: the size record's loss
+            # normalisers are made batch-global inside, engine/vox.py)
             fused = self.model.fused_loss(inp, is_mapping)
             if fused is not None:
                 self.last_loss_terms = fused[1]

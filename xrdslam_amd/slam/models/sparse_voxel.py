@@ -73,6 +73,7 @@ class SparseVoxel(Model):
         # static capacities of the fused ray pipeline: sample slots per ray
         # and mean points per ray (grown by check_capacity when a batch does
         # not fit); capacity_version keys captured graphs
+        self.meta_sync = None   # replaceable (tests play the ranks in turn)
         self.s_cap = 256
         self.pts_per_ray = 96
         self.capacity_version = 0
@@ -335,6 +336,9 @@ class SparseVoxel(Model):
             return None
         need_w = is_mapping and torch.is_grad_enabled()
         ws = self.ray_workspace(inputs['rays_o'].shape[0], need_w)
+        # a shard of the mapping rays (multi-GPU): batch-global normalisers
+        ws.meta_sync = (self.meta_sync or _vox.allreduce_meta) \
+            if inputs.get('sharded', False) else None
         out = _vox.render_loss(
             self.decoder, ws, self.map_states, self.config, inputs['rays_o'],
             inputs['rays_d'], inputs['target_d'], inputs['target_s'],
