@@ -105,7 +105,7 @@ def test_render_matches_reference_golden(tag):
             want = g[key] if key in g else np.zeros(shape, np.float32)
             got = gf[off:off + n].reshape(shape)
             scale = max(np.abs(want).max(), 1e-6)
-            assert np.abs(got.numpy() - want).max() / scale < 2 * TOL, name
+            assert np.abs(got.numpy() - want).max() / scale < TOL, name
             off += n
 
 

@@ -87,9 +87,9 @@ def test_fused_iteration_equals_generic_hooks(is_mapping, step):
         if is_mapping:
             for k in a['grids']:
                 if a['grids'][k].abs().max() > 0:
-                    assert close(other['grids'][k], a['grids'][k], 2e-4), k
+                    assert close(other['grids'][k], a['grids'][k], 1e-4), k
             if a['dec'] is not None:
-                assert close(other['dec'], a['dec'], 2e-4)
+                assert close(other['dec'], a['dec'], 1e-4)
 
 
 def test_graph_replay_matches_eager_tracking():

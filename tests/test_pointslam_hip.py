@@ -23,11 +23,13 @@ def test_point_slam_model_vs_reference():
     errs = pg.run(g, 'cuda:0')
 
     def tol(k):
-        if 'g_rays' in k:
-            return 1e-3    # through the 1/d^2 interpolation weights
-        if k.startswith('track/'):
-            # the tracking loss divides by sqrt(rendered variance): rounding
-            # differences of the (tiny) variance are amplified
+        if k.startswith('track/') and ('g_dec' in k or 'loss' in k):
+            # the tracking loss divides by sqrt(rendered variance), a sum of
+            # w (z - depth)^2 over 5 samples within 2 % of the depth: its
+            # rounding (torch on the CPU for the golden, torch on the GPU
+            # here) is amplified into the loss (1.2e-4 measured) and the
+            # geometry-decoder gradients (up to 4.8e-4).  Everything else, the ray
+            # gradients through the 1/d^2 weights included, holds 1e-4.
             return 5e-4
         return TOL
     bad = {k: v for k, v in errs.items() if not v < tol(k)}
