@@ -16,6 +16,10 @@ the untimed set-up, and so does the generation of the synthetic frames: they
 are resident in HBM before the timed region starts (SyntheticRoom.preload).
 value = frames / second of the whole job.  Defaults: 100 timed frames after 10
 warm-up frames (20 / 5 for vox-fusion and splaTAM, 5 / 2 for point-slam).
+Python's cyclic garbage collector is paused inside the timed region (like
+``timeit``): a generation-2 pass over the frame / graph objects landed on a
+random frame and moved the Co-SLAM line between 138 and 167 frames/s
+(paused: 155-156 in four runs); reference counting frees everything else.
 
 N > 1: one process per GPU; tracking is replicated, the mapping rays are
 sharded over ranks and the selected-cell/decoder gradients are summed with one
@@ -294,6 +298,7 @@ def run_coslam(args, dev, with_cpu, world=1):
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()
+    gc_was = _gc_pause()
     t0 = time.perf_counter()
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
         slam.step(k)
@@ -301,6 +306,7 @@ def run_coslam(args, dev, with_cpu, world=1):
         tdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _gc_resume(gc_was)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -392,6 +398,7 @@ def _timed_frames(slam, args, dev, world):
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()
+    gc_was = _gc_pause()
     t0 = time.perf_counter()
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
         slam.step(k)
@@ -399,11 +406,29 @@ def _timed_frames(slam, args, dev, world):
         tdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _gc_resume(gc_was)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def _gc_pause():
+    """no cyclic-GC pass inside a timed region (a generation-2 collection over
+    the frame / graph objects costs tens of ms at a random frame); reference
+    counting still frees everything that is not a cycle"""
+    import gc
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    return was
+
+
+def _gc_resume(was):
+    import gc
+    if was:
+        gc.enable()
 
 
 def _rccl_report(world):
@@ -680,11 +705,13 @@ def run_splatam(args, dev):
         slam.step(k)
     slam.t_track = slam.t_map = 0.0
     torch.cuda.synchronize()
+    gc_was = _gc_pause()
     t0 = time.perf_counter()
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
         slam.step(k)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _gc_resume(gc_was)
     t_track, t_map = slam.t_track, slam.t_map
     # per-launch HIP-event timing of one more frame (100 iterations, 200
     # raster passes each way) right after the timed region
@@ -1112,6 +1139,7 @@ def main():
     en.PROFILE = {}
     slam.t_track = slam.t_map = 0.0
     barrier()
+    gc_was = _gc_pause()
     t0 = time.perf_counter()
     stamps = []
     frame = None
@@ -1120,6 +1148,7 @@ def main():
         stamps.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    _gc_resume(gc_was)
     ate = slam.ate_rmse()
     ate_aligned = slam.trajectory_stats()['absolute_translational_error.rmse']
     if frame is not None:
