@@ -490,6 +490,27 @@ int xrd_gs_render_bwd(const xrd_gs_camera* cam, const int32_t* ranges,
                       const float* dL_dcolor, float* dL_dmean2D,
                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
                       xrd_stream_t stream);
+/* The same with TWO colour sets blended by the same weights in one pass —
+ * SplaTAM's rgb render and its (z, 1, z^2) depth / silhouette render share
+ * every Gaussian's geometry and opacity
+ * (slam/model_components/gaussian_cloud_splatam.py:63-69): one preprocess,
+ * one binning, one forward and one backward instead of two of each. */
+int xrd_gs_render_fwd2(const xrd_gs_camera* c, const int32_t* ranges,
+                       const int32_t* point_list, const float* xy,
+                       const float* colors_a, const float* colors_b,
+                       const float* conic_opacity, const float* depths,
+                       float* out_color_a, float* out_color_b,
+                       float* out_depth, float* final_T, int32_t* n_contrib,
+                       xrd_stream_t stream);
+int xrd_gs_render_bwd2(const xrd_gs_camera* c, const int32_t* ranges,
+                       const int32_t* point_list, const float* xy,
+                       const float* conic_opacity, const float* colors_a,
+                       const float* colors_b, const float* final_T,
+                       const int32_t* n_contrib, const float* dL_dcolor_a,
+                       const float* dL_dcolor_b, float* dL_dmean2D,
+                       float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolors_a, float* dL_dcolors_b,
+                       xrd_stream_t stream);
 int xrd_gs_preprocess_bwd(const xrd_gs_camera* cam, int n,
                           const float* means3D, const float* scales,
                           const float* rotations, const int32_t* radii,

@@ -161,3 +161,50 @@ def test_device_binning_equals_scan_sort_on_the_host_side(N, H, W, cap_factor):
         # an under-sized list keeps well-formed ranges inside the capacity
         r = ranges.cpu().numpy()
         assert (r[:, 1] >= r[:, 0]).all() and r.max() <= cap
+
+
+@pytest.mark.parametrize('N,H,W', [(300, 40, 56), (4000, 120, 160)])
+def test_dual_pass_equals_two_single_passes(N, H, W):
+    """rasterize_dual (one preprocess / binning / blend each way with two
+    colour sets) against two GaussianRasterizer calls over the same Gaussians:
+    both images, the depth, and every gradient (the means2D gradient is the
+    sum of the two calls')"""
+    from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
+    means, cols, op, sc, rot, view, full, tfx, tfy = scene(N, H, W, 3)
+    g = torch.Generator().manual_seed(9)
+    cols_b = torch.rand(N, 3, generator=g) * torch.tensor([3.0, 1.0, 9.0])
+    wa = torch.rand(3, H, W, generator=g)
+    wb = torch.rand(3, H, W, generator=g)
+    dev = torch.device('cuda:0')
+    rs = dgr.GaussianRasterizationSettings(
+        H, W, tfx, tfy, torch.zeros(3, device=dev), 1.0,
+        view.to(dev).unsqueeze(0), full.to(dev).unsqueeze(0), 0,
+        torch.zeros(3, device=dev), False)
+
+    def leaves():
+        ts = [t.clone().to(dev).requires_grad_(True)
+              for t in (means, cols, cols_b, op, sc, rot)]
+        return ts, torch.zeros(N, 3, device=dev, requires_grad=True)
+
+    (m, ca, cb, o, s, r), m2 = leaves()
+    A, radii, depth = dgr.GaussianRasterizer(rs)(
+        means3D=m, means2D=m2, opacities=o, colors_precomp=ca, scales=s,
+        rotations=r)
+    B, _, _ = dgr.GaussianRasterizer(rs)(
+        means3D=m, means2D=m2, opacities=o, colors_precomp=cb, scales=s,
+        rotations=r)
+    ((A * wa.to(dev)).sum() + (B * wb.to(dev)).sum()).backward()
+    ref = [A, B, depth] + [t.grad for t in (m, ca, cb, o, s, r, m2)]
+    (m_, ca_, cb_, o_, s_, r_), m2_ = leaves()
+    A2, radii2, depth2, B2 = dgr.rasterize_dual(rs, m_, m2_, o_, ca_, cb_, s_,
+                                                r_)
+    ((A2 * wa.to(dev)).sum() + (B2 * wb.to(dev)).sum()).backward()
+    got = [A2, B2, depth2] + [t.grad for t in (m_, ca_, cb_, o_, s_, r_, m2_)]
+    assert torch.equal(radii, radii2)
+    names = ['img_a', 'img_b', 'depth', 'means3D', 'colors_a', 'colors_b',
+             'opacities', 'scales', 'rotations', 'means2D']
+    for name, a, b in zip(names, got, ref):
+        if b.abs().max() < 1e-12:
+            assert a.abs().max() < 1e-6, name
+        else:
+            assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-4, name

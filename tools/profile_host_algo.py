@@ -23,6 +23,7 @@ np.random.seed(0)
 cam = Camera(**bench.CAM)
 cfg = algorithm_configs[name]()
 algo = cfg.setup(camera=cam, device=dev)
+algo.use_graphs = name in ('co-slam', 'nice-slam', 'vox-fusion')
 data = SyntheticRoom(bench.CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx,
                      fy=cam.fy, cx=cam.cx, cy=cam.cy, n_frames=200, device=dev)
 if name == 'splaTAM':
@@ -34,15 +35,15 @@ slam = SequentialSLAM(algo, data, map_every=cad.map_every,
                       keyframe_every=cad.keyframe_every, pose_device=dev,
                       use_relative_pose=cad.use_relative_pose,
                       init_pose_offset=cad.init_pose_offset)
-for k in range(3):
+for k in range(21):
     slam.step(k)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for k in range(3, 6):
+for k in range(21, 31):
     slam.step(k)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(40)
 print(s.getvalue()[:6000])

@@ -124,6 +124,8 @@ _SIGS = {
                              vp, vp, vp, vp]),
     'xrd_gs_render_fwd': (C.c_int, [vp] * 12),
     'xrd_gs_render_bwd': (C.c_int, [vp] * 14),
+    'xrd_gs_render_fwd2': (C.c_int, [vp] * 14),
+    'xrd_gs_render_bwd2': (C.c_int, [vp] * 17),
     'xrd_gs_preprocess_bwd': (C.c_int, [vp, C.c_int] + [vp] * 10),
     'xrd_knn_cell_ids': (C.c_int, [i64, vp, vp, f32, vp, vp, vp]),
     'xrd_knn_cell_ranges': (C.c_int, [i64, vp, vp, vp, vp]),

@@ -157,6 +157,59 @@ class _Binning:
 _BIN = _Binning()
 
 
+def _geometry(lib, cam, dev, st, m3, sc, rt, op):
+    """preprocess + tile binning of one view: everything that does not
+    depend on the colours"""
+    H, W = cam.image_height, cam.image_width
+    n = m3.shape[0]
+    f = dict(dtype=torch.float32, device=dev)
+    i = dict(dtype=torch.int32, device=dev)
+    depths = torch.zeros(n, **f)
+    xy = torch.zeros(n, 2, **f)
+    conic_o = torch.zeros(n, 4, **f)
+    radii = torch.zeros(n, **i)
+    rect = torch.zeros(n, 4, **i)
+    tiles = torch.zeros(n, **i)
+    with _Timed('gs_preprocess'):
+        _lib.check(lib.xrd_gs_preprocess(
+            C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
+            _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy),
+            _lib.ptr(conic_o), _lib.ptr(radii), _lib.ptr(rect),
+            _lib.ptr(tiles), st), 'xrd_gs_preprocess')
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ranges = torch.empty(gx * gy, 2, **i)
+    # tile binning on the stream (scan, key duplication, radix sort,
+    # ranges: csrc/gs_bin.hip) into a static-capacity list; the capacity
+    # follows the pair count of the previous pass, read back
+    # asynchronously — no host sync in the pass
+    cap = _BIN.capacity(dev, n, tiles)
+    plist = torch.empty(cap, **i)
+    n_keys = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = _BIN.workspace(dev, lib.xrd_gs_bin_ws_bytes(n, cap, W, H))
+    with _Timed('gs_bin'):
+        _lib.check(lib.xrd_gs_bin(
+            n, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths),
+            cap, _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges),
+            _lib.ptr(n_keys), st), 'xrd_gs_bin')
+    _BIN.report(dev, n, cap, n_keys)
+    return depths, xy, conic_o, radii, ranges, plist, n_keys
+
+
+def _geometry_backward(lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D,
+                       d_conic):
+    f = dict(dtype=torch.float32, device=dev)
+    d_means = torch.empty(n, 3, **f)
+    d_scales = torch.empty(n, 3, **f)
+    d_rots = torch.empty(n, 4, **f)
+    _lib.check(lib.xrd_gs_preprocess_bwd(
+        C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
+        _lib.ptr(radii), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
+        _lib.ptr(d_means), _lib.ptr(d_scales), _lib.ptr(d_rots), st),
+        'xrd_gs_preprocess_bwd')
+    d_means2D = torch.cat([d_mean2D, torch.zeros(n, 1, **f)], 1)
+    return d_means, d_means2D, d_scales, d_rots
+
+
 class _RasterizeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, colors, scales, rotations,
@@ -174,34 +227,8 @@ class _RasterizeFn(torch.autograd.Function):
         cl = colors.detach().float().contiguous()
         f = dict(dtype=torch.float32, device=dev)
         i = dict(dtype=torch.int32, device=dev)
-        depths = torch.zeros(n, **f)
-        xy = torch.zeros(n, 2, **f)
-        conic_o = torch.zeros(n, 4, **f)
-        radii = torch.zeros(n, **i)
-        rect = torch.zeros(n, 4, **i)
-        tiles = torch.zeros(n, **i)
-        with _Timed('gs_preprocess'):
-            _lib.check(lib.xrd_gs_preprocess(
-                C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
-                _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy),
-                _lib.ptr(conic_o), _lib.ptr(radii), _lib.ptr(rect),
-                _lib.ptr(tiles), st), 'xrd_gs_preprocess')
-        gx, gy = (W + 15) // 16, (H + 15) // 16
-        ranges = torch.empty(gx * gy, 2, **i)
-        # tile binning on the stream (scan, key duplication, radix sort,
-        # ranges: csrc/gs_bin.hip) into a static-capacity list; the capacity
-        # follows the pair count of the previous pass, read back
-        # asynchronously — no host sync in the pass
-        cap = _BIN.capacity(dev, n, tiles)
-        plist = torch.empty(cap, **i)
-        n_keys = torch.empty(1, dtype=torch.int64, device=dev)
-        ws = _BIN.workspace(dev, lib.xrd_gs_bin_ws_bytes(n, cap, W, H))
-        with _Timed('gs_bin'):
-            _lib.check(lib.xrd_gs_bin(
-                n, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths),
-                cap, _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges),
-                _lib.ptr(n_keys), st), 'xrd_gs_bin')
-        _BIN.report(dev, n, cap, n_keys)
+        depths, xy, conic_o, radii, ranges, plist, n_keys = _geometry(
+            lib, cam, dev, st, m3, sc, rt, op)
         color = torch.empty(3, H, W, **f)
         depth = torch.empty(1, H, W, **f)
         final_T = torch.empty(H, W, **f)
@@ -244,16 +271,101 @@ class _RasterizeFn(torch.autograd.Function):
                 _lib.ptr(n_contrib), _lib.ptr(gc), _lib.ptr(d_mean2D),
                 _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_col), st),
                 'xrd_gs_render_bwd')
-        d_means = torch.empty(n, 3, **f)
-        d_scales = torch.empty(n, 3, **f)
-        d_rots = torch.empty(n, 4, **f)
-        _lib.check(lib.xrd_gs_preprocess_bwd(
-            C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
-            _lib.ptr(radii), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
-            _lib.ptr(d_means), _lib.ptr(d_scales), _lib.ptr(d_rots), st),
-            'xrd_gs_preprocess_bwd')
-        d_means2D = torch.cat([d_mean2D, torch.zeros(n, 1, **f)], 1)
+        d_means, d_means2D, d_scales, d_rots = _geometry_backward(
+            lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic)
         return d_means, d_means2D, d_op, d_col, d_scales, d_rots, None
+
+
+class _RasterizeDualFn(torch.autograd.Function):
+    """two colour sets over the same Gaussians in ONE pass each way
+    (xrd_gs_render_fwd2 / _bwd2): (color_a, radii, depth, color_b).  What
+    SplaTAM's two GaussianRasterizer calls per view compute
+    (gaussian_cloud_splatam.py:63-69), with one preprocess, one binning and
+    one blend instead of two."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, colors_a, colors_b, scales,
+                rotations, rs):
+        lib = _lib.lib()
+        dev = means3D.device
+        st = _lib.stream_ptr(dev)
+        cam = _camera(rs)
+        H, W = cam.image_height, cam.image_width
+        n = means3D.shape[0]
+        m3 = means3D.detach().float().contiguous()
+        sc = scales.detach().float().contiguous()
+        rt = rotations.detach().float().contiguous()
+        op = opacities.detach().float().contiguous()
+        ca = colors_a.detach().float().contiguous()
+        cb = colors_b.detach().float().contiguous()
+        f = dict(dtype=torch.float32, device=dev)
+        i = dict(dtype=torch.int32, device=dev)
+        depths, xy, conic_o, radii, ranges, plist, n_keys = _geometry(
+            lib, cam, dev, st, m3, sc, rt, op)
+        color_a = torch.empty(3, H, W, **f)
+        color_b = torch.empty(3, H, W, **f)
+        depth = torch.empty(1, H, W, **f)
+        final_T = torch.empty(H, W, **f)
+        n_contrib = torch.empty(H, W, **i)
+        with _Timed('gs_render_fwd'):
+            _lib.check(lib.xrd_gs_render_fwd2(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(conic_o),
+                _lib.ptr(depths), _lib.ptr(color_a), _lib.ptr(color_b),
+                _lib.ptr(depth), _lib.ptr(final_T), _lib.ptr(n_contrib), st),
+                'xrd_gs_render_fwd2')
+        if PROFILE is not None:
+            PROFILE.setdefault('pairs', []).append(n_contrib.sum())
+            PROFILE.setdefault('keys', []).append(n_keys.clone())
+            PROFILE.setdefault('gaussians', []).append(n)
+        ctx.rs, ctx.n = rs, n
+        ctx.save_for_backward(m3, sc, rt, ca, cb, xy, conic_o, radii, ranges,
+                              plist, final_T, n_contrib)
+        ctx.mark_non_differentiable(radii, depth)
+        return color_a, radii, depth, color_b
+
+    @staticmethod
+    def backward(ctx, g_a, g_radii, g_depth, g_b):
+        lib = _lib.lib()
+        (m3, sc, rt, ca, cb, xy, conic_o, radii, ranges, plist, final_T,
+         n_contrib) = ctx.saved_tensors
+        dev = m3.device
+        st = _lib.stream_ptr(dev)
+        cam = _camera(ctx.rs)
+        n = ctx.n
+        f = dict(dtype=torch.float32, device=dev)
+        d_mean2D = torch.zeros(n, 2, **f)
+        d_conic = torch.zeros(n, 3, **f)
+        d_op = torch.zeros(n, 1, **f)
+        d_ca = torch.zeros(n, 3, **f)
+        d_cb = torch.zeros(n, 3, **f)
+        H, W = cam.image_height, cam.image_width
+        ga = g_a.float().contiguous() if g_a is not None \
+            else torch.zeros(3, H, W, **f)
+        gb = g_b.float().contiguous() if g_b is not None \
+            else torch.zeros(3, H, W, **f)
+        with _Timed('gs_render_bwd'):
+            _lib.check(lib.xrd_gs_render_bwd2(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(conic_o), _lib.ptr(ca), _lib.ptr(cb),
+                _lib.ptr(final_T), _lib.ptr(n_contrib), _lib.ptr(ga),
+                _lib.ptr(gb), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
+                _lib.ptr(d_op), _lib.ptr(d_ca), _lib.ptr(d_cb), st),
+                'xrd_gs_render_bwd2')
+        d_means, d_means2D, d_scales, d_rots = _geometry_backward(
+            lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic)
+        return d_means, d_means2D, d_op, d_ca, d_cb, d_scales, d_rots, None
+
+
+def rasterize_dual(raster_settings, means3D, means2D, opacities, colors_a,
+                   colors_b, scales, rotations):
+    """-> (color_a [3,H,W], radii [N], depth [1,H,W], color_b [3,H,W]); equal
+    to GaussianRasterizer(raster_settings) called once with colors_a and once
+    with colors_b, the ``means2D`` gradient being the sum of both calls'"""
+    if not means3D.is_cuda:
+        raise _lib.XrdError('rasterize_dual needs CUDA tensors')
+    return _RasterizeDualFn.apply(means3D, means2D, opacities, colors_a,
+                                  colors_b, scales, rotations, raster_settings)
 
 
 class GaussianRasterizer(nn.Module):

@@ -194,15 +194,23 @@ __global__ void gs_ranges_kernel(int64_t L, const int64_t* __restrict__ keys,
   if (i == L - 1) ranges[tile * 2 + 1] = (int)L;
 }
 
+// DUAL: a second colour set blended with the SAME weights in the same pass.
+// SplaTAM renders every view twice with identical geometry — rgb, then
+// (z, 1, z^2) for depth / silhouette / depth^2
+// (gaussian_cloud_splatam.py:63-69) — and the weights, the tile lists and
+// the transmittance are the expensive part.
+template <bool DUAL>
 __global__ __launch_bounds__(BLOCK) void gs_render_fwd_kernel(
     Cam cam, const int* __restrict__ ranges, const int* __restrict__ plist,
     const float* __restrict__ xy, const float* __restrict__ colors,
-    const float* __restrict__ conic_o, const float* __restrict__ depths,
-    float* __restrict__ out_color, float* __restrict__ out_depth,
+    const float* __restrict__ colors_b, const float* __restrict__ conic_o,
+    const float* __restrict__ depths, float* __restrict__ out_color,
+    float* __restrict__ out_color_b, float* __restrict__ out_depth,
     float* __restrict__ final_T, int* __restrict__ n_contrib) {
   __shared__ float2 s_xy[BLOCK];
   __shared__ f32x4 s_co[BLOCK];
   __shared__ f32x4 s_cd[BLOCK];  // r,g,b,depth
+  __shared__ f32x4 s_cb[DUAL ? BLOCK : 1];
   const int gx = (cam.W + TILE - 1) / TILE;
   const int tile = blockIdx.y * gx + blockIdx.x;
   const int tid = threadIdx.y * TILE + threadIdx.x;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void gs_render_fwd_kernel(
   const int rounds = (r1 - r0 + BLOCK - 1) / BLOCK;
   int todo = r1 - r0;
   bool done = !inside;
-  float T = 1.f, C[3] = {0.f, 0.f, 0.f}, D = 0.f;
+  float T = 1.f, C[3] = {0.f, 0.f, 0.f}, Cb[3] = {0.f, 0.f, 0.f}, D = 0.f;
   int contributor = 0, last = 0;
   for (int rd = 0; rd < rounds; ++rd, todo -= BLOCK) {
     if (__syncthreads_count(done) == BLOCK) break;
@@ -224,6 +232,9 @@ __global__ __launch_bounds__(BLOCK) void gs_render_fwd_kernel(
       s_co[tid] = *reinterpret_cast<const f32x4*>(conic_o + g * 4);
       s_cd[tid] = f32x4{colors[g * 3], colors[g * 3 + 1], colors[g * 3 + 2],
                         depths[g]};
+      if (DUAL)
+        s_cb[tid] = f32x4{colors_b[g * 3], colors_b[g * 3 + 1],
+                          colors_b[g * 3 + 2], 0.f};
     }
     __syncthreads();
     for (int j = 0; !done && j < min(BLOCK, todo); ++j) {
@@ -245,6 +256,12 @@ __global__ __launch_bounds__(BLOCK) void gs_render_fwd_kernel(
       C[1] += cd[1] * w;
       C[2] += cd[2] * w;
       D += cd[3] * w;
+      if (DUAL) {
+        const f32x4 cb = s_cb[j];
+        Cb[0] += cb[0] * w;
+        Cb[1] += cb[1] * w;
+        Cb[2] += cb[2] * w;
+      }
       T = test_T;
       last = contributor;
     }
@@ -254,23 +271,29 @@ __global__ __launch_bounds__(BLOCK) void gs_render_fwd_kernel(
     final_T[pix] = T;
     n_contrib[pix] = last;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
+    for (int ch = 0; ch < 3; ++ch) {
       out_color[ch * cam.H * cam.W + pix] = C[ch] + T * cam.bg[ch];
+      if (DUAL) out_color_b[ch * cam.H * cam.W + pix] = Cb[ch] + T * cam.bg[ch];
+    }
     out_depth[pix] = D;
   }
 }
 
+template <bool DUAL>
 __global__ __launch_bounds__(BLOCK) void gs_render_bwd_kernel(
     Cam cam, const int* __restrict__ ranges, const int* __restrict__ plist,
     const float* __restrict__ xy, const float* __restrict__ conic_o,
-    const float* __restrict__ colors, const float* __restrict__ final_T,
-    const int* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+    const float* __restrict__ colors, const float* __restrict__ colors_b,
+    const float* __restrict__ final_T, const int* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_b,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-    float* __restrict__ dL_dopac, float* __restrict__ dL_dcolors) {
+    float* __restrict__ dL_dopac, float* __restrict__ dL_dcolors,
+    float* __restrict__ dL_dcolors_b) {
   __shared__ int s_id[BLOCK];
   __shared__ float2 s_xy[BLOCK];
   __shared__ f32x4 s_co[BLOCK];
   __shared__ f32x4 s_cd[BLOCK];
+  __shared__ f32x4 s_cb[DUAL ? BLOCK : 1];
   const int gx = (cam.W + TILE - 1) / TILE;
   const int tile = blockIdx.y * gx + blockIdx.x;
   const int tid = threadIdx.y * TILE + threadIdx.x;
@@ -287,12 +310,19 @@ __global__ __launch_bounds__(BLOCK) void gs_render_bwd_kernel(
   int contributor = todo;
   const int last_contributor = inside ? n_contrib[pix] : 0;
   float accum[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f};
+  float accum_b[3] = {0.f, 0.f, 0.f}, last_color_b[3] = {0.f, 0.f, 0.f};
   float last_alpha = 0.f, dpx[3] = {0.f, 0.f, 0.f};
+  float dpx_b[3] = {0.f, 0.f, 0.f};
   if (inside) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) dpx[ch] = dL_dpix[ch * cam.H * cam.W + pix];
+    for (int ch = 0; ch < 3; ++ch) {
+      dpx[ch] = dL_dpix[ch * cam.H * cam.W + pix];
+      if (DUAL) dpx_b[ch] = dL_dpix_b[ch * cam.H * cam.W + pix];
+    }
   }
-  const float bg_dot = cam.bg[0] * dpx[0] + cam.bg[1] * dpx[1] + cam.bg[2] * dpx[2];
+  float bg_dot = cam.bg[0] * dpx[0] + cam.bg[1] * dpx[1] + cam.bg[2] * dpx[2];
+  if (DUAL)
+    bg_dot += cam.bg[0] * dpx_b[0] + cam.bg[1] * dpx_b[1] + cam.bg[2] * dpx_b[2];
   const float ddx = 0.5f * cam.W, ddy = 0.5f * cam.H;
   for (int rd = 0; rd < rounds; ++rd, todo -= BLOCK) {
     __syncthreads();
@@ -303,12 +333,16 @@ __global__ __launch_bounds__(BLOCK) void gs_render_bwd_kernel(
       s_xy[tid] = make_float2(xy[g * 2], xy[g * 2 + 1]);
       s_co[tid] = *reinterpret_cast<const f32x4*>(conic_o + g * 4);
       s_cd[tid] = f32x4{colors[g * 3], colors[g * 3 + 1], colors[g * 3 + 2], 0.f};
+      if (DUAL)
+        s_cb[tid] = f32x4{colors_b[g * 3], colors_b[g * 3 + 1],
+                          colors_b[g * 3 + 2], 0.f};
     }
     __syncthreads();
     for (int j = 0; j < min(BLOCK, todo); ++j) {
       --contributor;
       float g_col[3] = {0.f, 0.f, 0.f}, g_m[2] = {0.f, 0.f},
             g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f;
+      float g_colb[3] = {0.f, 0.f, 0.f};
       bool active = inside && contributor < last_contributor;
       float dx = 0.f, dy = 0.f, G = 0.f, alpha = 0.f;
       f32x4 co = {0.f, 0.f, 0.f, 0.f};
@@ -337,6 +371,17 @@ __global__ __launch_bounds__(BLOCK) void gs_render_bwd_kernel(
           dL_dalpha += (cd[ch] - accum[ch]) * dpx[ch];
           g_col[ch] = dch * dpx[ch];
         }
+        if (DUAL) {
+          const f32x4 cb = s_cb[j];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            accum_b[ch] = last_alpha * last_color_b[ch] +
+                          (1.f - last_alpha) * accum_b[ch];
+            last_color_b[ch] = cb[ch];
+            dL_dalpha += (cb[ch] - accum_b[ch]) * dpx_b[ch];
+            g_colb[ch] = dch * dpx_b[ch];
+          }
+        }
         dL_dalpha *= T;
         last_alpha = alpha;
         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
@@ -357,6 +402,17 @@ __global__ __launch_bounds__(BLOCK) void gs_render_bwd_kernel(
                       g_con[0], g_con[1], g_con[2], g_op};
 #pragma unroll
         for (int k = 0; k < 9; ++k) v[k] = wave_sum_dpp(v[k]);
+        if (DUAL) {
+          float u[3] = {g_colb[0], g_colb[1], g_colb[2]};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) u[k] = wave_sum_dpp(u[k]);
+          if (lane == 0) {
+            const int g = s_id[j];
+            atomicAdd(dL_dcolors_b + g * 3 + 0, u[0]);
+            atomicAdd(dL_dcolors_b + g * 3 + 1, u[1]);
+            atomicAdd(dL_dcolors_b + g * 3 + 2, u[2]);
+          }
+        }
         if (lane == 0) {
           const int g = s_id[j];
           atomicAdd(dL_dcolors + g * 3 + 0, v[0]);
@@ -551,11 +607,32 @@ int xrd_gs_render_fwd(const xrd_gs_camera* c, const int32_t* ranges,
   if (rc) return rc;
   if (!ranges || !out_color || !out_depth || !final_T || !n_contrib) return XRD_ERR_ARG;
   const dim3 grid((cam.W + TILE - 1) / TILE, (cam.H + TILE - 1) / TILE);
-  hipLaunchKernelGGL(gs_render_fwd_kernel, grid, dim3(TILE, TILE), 0,
+  hipLaunchKernelGGL(gs_render_fwd_kernel<false>, grid, dim3(TILE, TILE), 0,
                      (hipStream_t)stream, cam, ranges, point_list, xy, colors,
-                     conic_opacity, depths, out_color, out_depth, final_T,
-                     n_contrib);
+                     nullptr, conic_opacity, depths, out_color, nullptr,
+                     out_depth, final_T, n_contrib);
   return check_launch("xrd_gs_render_fwd");
+}
+
+int xrd_gs_render_fwd2(const xrd_gs_camera* c, const int32_t* ranges,
+                       const int32_t* point_list, const float* xy,
+                       const float* colors_a, const float* colors_b,
+                       const float* conic_opacity, const float* depths,
+                       float* out_color_a, float* out_color_b,
+                       float* out_depth, float* final_T, int32_t* n_contrib,
+                       xrd_stream_t stream) {
+  Cam cam;
+  int rc = to_cam(c, cam);
+  if (rc) return rc;
+  if (!ranges || !out_color_a || !out_color_b || !out_depth || !final_T ||
+      !n_contrib)
+    return XRD_ERR_ARG;
+  const dim3 grid((cam.W + TILE - 1) / TILE, (cam.H + TILE - 1) / TILE);
+  hipLaunchKernelGGL(gs_render_fwd_kernel<true>, grid, dim3(TILE, TILE), 0,
+                     (hipStream_t)stream, cam, ranges, point_list, xy,
+                     colors_a, colors_b, conic_opacity, depths, out_color_a,
+                     out_color_b, out_depth, final_T, n_contrib);
+  return check_launch("xrd_gs_render_fwd2");
 }
 
 int xrd_gs_render_bwd(const xrd_gs_camera* c, const int32_t* ranges,
@@ -572,11 +649,37 @@ int xrd_gs_render_bwd(const xrd_gs_camera* c, const int32_t* ranges,
       !dL_dconic || !dL_dopacity || !dL_dcolors)
     return XRD_ERR_ARG;
   const dim3 grid((cam.W + TILE - 1) / TILE, (cam.H + TILE - 1) / TILE);
-  hipLaunchKernelGGL(gs_render_bwd_kernel, grid, dim3(TILE, TILE), 0,
+  hipLaunchKernelGGL(gs_render_bwd_kernel<false>, grid, dim3(TILE, TILE), 0,
                      (hipStream_t)stream, cam, ranges, point_list, xy,
-                     conic_opacity, colors, final_T, n_contrib, dL_dcolor,
-                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors);
+                     conic_opacity, colors, nullptr, final_T, n_contrib,
+                     dL_dcolor, nullptr, dL_dmean2D, dL_dconic, dL_dopacity,
+                     dL_dcolors, nullptr);
   return check_launch("xrd_gs_render_bwd");
+}
+
+int xrd_gs_render_bwd2(const xrd_gs_camera* c, const int32_t* ranges,
+                       const int32_t* point_list, const float* xy,
+                       const float* conic_opacity, const float* colors_a,
+                       const float* colors_b, const float* final_T,
+                       const int32_t* n_contrib, const float* dL_dcolor_a,
+                       const float* dL_dcolor_b, float* dL_dmean2D,
+                       float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolors_a, float* dL_dcolors_b,
+                       xrd_stream_t stream) {
+  Cam cam;
+  int rc = to_cam(c, cam);
+  if (rc) return rc;
+  if (!ranges || !final_T || !n_contrib || !dL_dcolor_a || !dL_dcolor_b ||
+      !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolors_a ||
+      !dL_dcolors_b)
+    return XRD_ERR_ARG;
+  const dim3 grid((cam.W + TILE - 1) / TILE, (cam.H + TILE - 1) / TILE);
+  hipLaunchKernelGGL(gs_render_bwd_kernel<true>, grid, dim3(TILE, TILE), 0,
+                     (hipStream_t)stream, cam, ranges, point_list, xy,
+                     conic_opacity, colors_a, colors_b, final_T, n_contrib,
+                     dL_dcolor_a, dL_dcolor_b, dL_dmean2D, dL_dconic,
+                     dL_dopacity, dL_dcolors_a, dL_dcolors_b);
+  return check_launch("xrd_gs_render_bwd2");
 }
 
 int xrd_gs_preprocess_bwd(const xrd_gs_camera* c, int n, const float* means3D,

@@ -38,6 +38,7 @@ class GaussianCloud(nn.Module):
                                          device=self.device)
         self.first_frame_w2c = w2c.detach()
         self.prune_dict, self.densify_dict = prune_dict, densify_dict
+        self.fused_passes = True   # one raster pass for rgb + depth/silhouette
         mask = (init_depth > 0).reshape(-1)
         pts, sq = self.get_pointcloud(init_rgb, init_depth, w2c, mask=mask)
         self.params, self.variables = self.initialize_params(pts, sq)
@@ -54,10 +55,22 @@ class GaussianCloud(nn.Module):
             self.params, self.first_frame_w2c, pts)
         if retain_grad:
             rv['means2D'].retain_grad()
-        im, radius, depth = _renderer(self.gaussian_cam)(**rv)
+        if self.fused_passes and pts.is_cuda:
+            # both renders share every Gaussian's geometry and opacity: one
+            # preprocess / binning / blend each way with two colour sets
+            # (compat.rasterize_dual).  The retained means2D gradient then
+            # carries BOTH renders' contributions; it only feeds the 3D-GS
+            # densification statistics, which switch this path off
+            # (fused_passes = not use_gaussian_splatting_densification)
+            im, radius, depth, depth_sil = _dgr.rasterize_dual(
+                self.gaussian_cam, rv['means3D'], rv['means2D'],
+                rv['opacities'], rv['colors_precomp'],
+                ds_rv['colors_precomp'], rv['scales'], rv['rotations'])
+        else:
+            im, radius, depth = _renderer(self.gaussian_cam)(**rv)
+            depth_sil, _, _ = _renderer(self.gaussian_cam)(**ds_rv)
         if retain_grad:
             self.variables['means2D'] = rv['means2D']
-        depth_sil, _, _ = _renderer(self.gaussian_cam)(**ds_rv)
         seen = radius > 0
         self.variables['max_2D_radius'][seen] = torch.max(
             radius[seen], self.variables['max_2D_radius'][seen])

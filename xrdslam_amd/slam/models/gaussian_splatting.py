@@ -73,6 +73,8 @@ class GaussianSplatting(Model):
                 init_rgb=rgb, init_depth=depth, w2c=w2c, camera=self.camera,
                 prune_dict=cfg.mapping_pruning_dict,
                 densify_dict=cfg.mapping_densify_dict)
+            self.gaussian_cloud.fused_passes = \
+                not cfg.mapping_use_gaussian_splatting_densification
         else:
             self.gaussian_cloud.add_new_gaussians(
                 gt_rgb=rgb, gt_depth=depth, curr_w2c=w2c,
