@@ -106,6 +106,38 @@ int xrd_nice_render_fwd(const xrd_nice_scene* scene, int stage, int n_rays,
 int xrd_nice_eval_points(const xrd_nice_scene* scene, int stage,
                          int64_t n_points, const float* points, float* raw,
                          xrd_stream_t stream);
+/* Point-SLAM geometry path — neighbour interpolation + geometry decoder
+ * (MLP_geometry.get_feature_at_pos / forward,
+ * slam/model_components/decoder_pointslam.py:162-273; half of the
+ * xrd_point_render_* pair of SURVEY §8b, the colour half is not built yet):
+ *   points [n,3] f32 sample positions, neighbors [n,8] i64 (ids into the
+ *   cloud, -1 = none; xrd_knn_search), n_neighbors [n] i32 (neighbours inside
+ *   the radius, as the search reports them), cloud [N,3], geo_feats [N,32],
+ *   feat_mask [N] u8 or NULL (the frustum mask of get_geo_feats), radius [n]
+ *   per-sample query radius or NULL -> radius_all, min_nn (samples with fewer
+ *   neighbours take empty_feat [32]), packed_decoder = the decoder in the
+ *   NICE 'middle' packing (xrd_nice_pack_index(XRD_STAGE_MIDDLE)) with
+ *   embedder._B scaled by 2 pi.
+ * fwd: occ [n] (occupancy logit), has [n] u8, relu_masks [n,4] u64 (for the
+ *   backward; NULL = inference).
+ * bwd: g_occ [n] -> g_points [n,3] (through the Fourier features AND the
+ *   recomputed neighbour distances; NULL = not wanted), g_geo_feats [N,32]
+ *   (ACCUMULATED with atomics, masked; NULL = not wanted). */
+int xrd_point_geo_fwd(int64_t n_points, const float* points,
+                      const int64_t* neighbors, const int32_t* n_neighbors,
+                      const float* cloud, const float* geo_feats,
+                      const uint8_t* feat_mask, const float* radius,
+                      float radius_all, int min_nn, const float* empty_feat,
+                      const float* packed_decoder, float* occ, uint8_t* has,
+                      uint64_t* relu_masks, xrd_stream_t stream);
+int xrd_point_geo_bwd(int64_t n_points, const float* points,
+                      const int64_t* neighbors, const int32_t* n_neighbors,
+                      const float* cloud, const float* geo_feats,
+                      const uint8_t* feat_mask, const float* radius,
+                      float radius_all, int min_nn, const float* empty_feat,
+                      const float* packed_decoder, const uint64_t* relu_masks,
+                      const float* g_occ, float* g_points, float* g_geo_feats,
+                      xrd_stream_t stream);
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):

@@ -16,7 +16,7 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def run(g, device, knn_factory=None):
+def run(g, device, knn_factory=None, freeze_fixed_decoders=False):
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.models.conv_onet_pointslam import (ConvOnet2,
                                                              ConvOnet2Config)
@@ -29,6 +29,10 @@ def run(g, device, knn_factory=None):
     model.decoder.color_decoder.embedder._B = torch.from_numpy(
         g['dec_attr/color_decoder.embedder._B'])
     model = model.to(device)
+    # False: every gradient the reference's autograd produces is compared
+    # (also those of the fixed geometry decoder); True: the engine's default,
+    # the geometry path on its fused kernels
+    model.freeze_fixed_decoders = freeze_fixed_decoders
     model.knn_factory = knn_factory
     draws = [torch.from_numpy(g[f'draw{i}'])
              for i in range(int(g['n_draws']))]
@@ -117,6 +121,6 @@ def run(g, device, knn_factory=None):
                                            g[f'{tag}/g_col'])
         for k2, p in model.decoder.named_parameters():
             key = f'{tag}/g_dec/{k2}'
-            if key in g.files:
+            if key in g.files and (p.grad is not None or p.requires_grad):
                 errs[key] = rel_err(p.grad.cpu(), g[key])
     return errs

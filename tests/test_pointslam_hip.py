@@ -18,9 +18,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def test_point_slam_model_vs_reference():
+@pytest.mark.parametrize('freeze', [False, True])
+def test_point_slam_model_vs_reference(freeze):
+    """freeze=False: the modular operators, every gradient of the reference;
+    freeze=True (the engine's default): the geometry path on its fused
+    kernels (xrd_point_geo_*), the fixed geometry decoder without gradients"""
     g = np.load(pg.GOLDEN)
-    errs = pg.run(g, 'cuda:0')
+    errs = pg.run(g, 'cuda:0', freeze_fixed_decoders=freeze)
 
     def tol(k):
         if k.startswith('track/') and ('g_dec' in k or 'loss' in k):
@@ -87,3 +91,80 @@ def test_pointslam_loop_runs_on_synthetic_room():
                                  gt_depth=data[5]['depth'], idx=5)
     gt = data[5]['depth']
     assert np.isfinite(depth).all() and np.abs(depth - gt)[gt > 0].mean() < 0.2
+
+
+def test_fused_geometry_path_matches_modular():
+    """xrd_point_geo_fwd / _bwd (neighbour interpolation + geometry decoder in
+    one kernel each way) against MLP_geometry's torch path on the same
+    neighbours: occupancy, neighbour flags, d/d positions (Fourier features
+    and recomputed distances), d/d geometric features (frustum-masked)"""
+    from xrdslam_amd.engine import point as ep
+    from xrdslam_amd.slam.model_components.decoder_pointslam import \
+        MLP_geometry
+    from xrdslam_amd.slam.model_components.neural_point_cloud import \
+        NeuralPointCloud
+    import inspect
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(4)
+    N, n = 6000, 5 * 1237
+    cloud = torch.rand(N, 3, generator=g) * torch.tensor([2.0, 1.5, 1.0])
+    q = cloud[torch.randint(N, (n, ), generator=g)] + \
+        0.04 * torch.randn(n, 3, generator=g)
+    q[:40] += 5.0                      # far away: no neighbours at all
+    torch.manual_seed(0)
+    dec = MLP_geometry(use_dynamic_radius=True,
+                       pointcloud_nn_weighting='distance',
+                       pointcloud_min_nn_num=2, rendering_n_surface=5,
+                       c_dim=32, hidden_size=32, n_blocks=5, skips=[2]).to(dev)
+    assert ep.supported(dec)
+    empty = (torch.randn(32, generator=g) * 0.01).to(dev)
+    dec.empty_feature_fn = lambda c, d: empty
+
+    class Cloud:                       # what the decoder needs of the cloud
+        def __init__(self):
+            from xrdslam_amd.engine.knn import GridKNN
+            self.index = GridKNN(0.16, dev)
+            self.index.add(cloud.to(dev))
+            self.geo_feats = torch.nn.Parameter(
+                (torch.randn(N, 32, generator=g) * 0.3).to(dev))
+            self.frustum_mask = (torch.rand(N, 1, generator=g) < 0.8).to(dev)
+            self._cloud = cloud.to(dev)
+
+        def cloud_tensor(self, device=None):
+            return self._cloud
+
+        def get_radius_query(self):
+            return 0.08
+
+        def get_geo_feats(self):
+            return self.geo_feats * self.frustum_mask
+
+        def find_neighbors_faiss(self, pos, step='query', dynamic_radius=None,
+                                 **kw):
+            D, I = self.index.search(pos.float(), 8)
+            n_nb = (D < dynamic_radius.reshape(-1, 1)**2).sum(-1).int()
+            return D, I, n_nb
+
+    npc = Cloud()
+    radius = (0.04 + 0.08 * torch.rand(n, generator=g)).to(dev)
+    w_out = torch.randn(n, generator=g).to(dev)
+
+    def run(fused):
+        dec.use_fused = fused
+        npc.geo_feats.grad = None
+        p = q.clone().to(dev).requires_grad_(True)
+        occ, valid_ray, has = dec(p.unsqueeze(0), npc, pts_num=5,
+                                  is_tracker=True, dynamic_r_query=radius)
+        (occ * w_out).sum().backward()
+        return {'occ': occ.detach(), 'has': has, 'valid_ray': valid_ray,
+                'g_p': p.grad.clone(), 'g_f': npc.geo_feats.grad.clone()}
+
+    ref, got = run(False), run(True)
+    assert torch.equal(got['has'], ref['has'])
+    assert torch.equal(got['valid_ray'], ref['valid_ray'])
+    assert 0 < int((~ref['has']).sum()) < n // 2
+    for k in ('occ', 'g_p', 'g_f'):
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-4, (k, err)
+    # rows of masked points receive no gradient
+    assert float(got['g_f'][~npc.frustum_mask.reshape(-1)].abs().max()) == 0

@@ -50,6 +50,10 @@ _SIGS = {
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'xrd_nice_eval_points': (C.c_int, [C.POINTER(NiceScene), C.c_int, i64, vp,
                                        vp, vp]),
+    'xrd_point_geo_fwd': (C.c_int, [i64] + [vp] * 7 + [f32, C.c_int] +
+                          [vp] * 6),
+    'xrd_point_geo_bwd': (C.c_int, [i64] + [vp] * 7 + [f32, C.c_int] +
+                          [vp] * 7),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,

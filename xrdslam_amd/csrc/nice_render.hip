@@ -1739,6 +1739,208 @@ __global__ __launch_bounds__(8 * 64, 2) void nice_points_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Point-SLAM geometry path: neighbour interpolation + the geometry decoder.
+//   MLP_geometry.get_feature_at_pos / forward
+//   (slam/model_components/decoder_pointslam.py:162-273): the <= 8 nearest
+//   neural points of a sample (ids from the kNN), inverse squared-distance
+//   weights zeroed beyond the query radius, L1-normalised; c = sum w f_geo;
+//   samples with fewer than min_nn neighbours inside the radius get the
+//   call's random feature.  The decoder is the NICE `MLP` (5 x 32 ReLU with
+//   the feature added after every layer, Fourier features sin(2 pi p B):
+//   2 pi is folded into the packed B) — mlp_fwd / mlp_bwd<.,32,1> as they
+//   are.  One wave = 16 samples; the distances are recomputed from the
+//   positions so that they carry the pose gradient (is_tracker, :181-186).
+struct PointNb {
+  int id[8];
+  float u[8];    // 1/(D + 1e-10), 0 beyond the radius / missing
+  float den;     // max(sum u, 1e-12)
+  bool has;
+};
+
+__device__ __forceinline__ void point_neighbors(
+    const int64_t* __restrict__ nbr, const float* __restrict__ cloud,
+    const int* __restrict__ n_nb, const float* __restrict__ radius,
+    float radius_all, int min_nn, int64_t pt, bool valid,
+    const float (&p)[3], PointNb& nb) {
+  float S = 0.f;
+  const float r = valid ? (radius ? radius[pt] : radius_all) : 0.f;
+  const float bound = r * r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t id = valid ? nbr[pt * 8 + k] : -1;
+    nb.id[k] = (int)id;
+    nb.u[k] = 0.f;
+    if (id >= 0) {
+      const float dx = cloud[id * 3] - p[0], dy = cloud[id * 3 + 1] - p[1],
+                  dz = cloud[id * 3 + 2] - p[2];
+      const float D = dx * dx + dy * dy + dz * dz;
+      if (!(D > bound)) nb.u[k] = 1.f / (D + 1e-10f);
+    }
+    S += nb.u[k];
+  }
+  nb.den = fmaxf(S, 1e-12f);
+  nb.has = valid && n_nb[pt] > min_nn - 1;
+}
+
+__device__ __forceinline__ void point_feature(
+    const PointNb& nb, const float* __restrict__ feats,
+    const uint8_t* __restrict__ fmask, const float* __restrict__ empty, int q,
+    f32x4 (&c)[1][2]) {
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  c[0][0] = z4;
+  c[0][1] = z4;
+  if (!nb.has) {
+    c[0][0] = *reinterpret_cast<const f32x4*>(empty + 4 * q);
+    c[0][1] = *reinterpret_cast<const f32x4*>(empty + 16 + 4 * q);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (nb.u[k] == 0.f) continue;
+    if (fmask != nullptr && fmask[nb.id[k]] == 0) continue;
+    const float w = nb.u[k] / nb.den;
+    const float* f = feats + (int64_t)nb.id[k] * 32 + 4 * q;
+    c[0][0] += *reinterpret_cast<const f32x4*>(f) * w;
+    c[0][1] += *reinterpret_cast<const f32x4*>(f + 16) * w;
+  }
+}
+
+__global__ __launch_bounds__(8 * 64, 2) void point_geo_fwd_kernel(
+    int64_t n, const float* __restrict__ pts, const int64_t* __restrict__ nbr,
+    const int* __restrict__ n_nb, const float* __restrict__ cloud,
+    const float* __restrict__ feats, const uint8_t* __restrict__ fmask,
+    const float* __restrict__ radius, float radius_all, int min_nn,
+    const float* __restrict__ empty, const float* __restrict__ dec,
+    float* __restrict__ occ, uint8_t* __restrict__ has_out,
+    uint64_t* __restrict__ masks) {
+  using PM = MlpPack<32, 1>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  stage_weights(wl, dec, PM::WHT);
+  const int64_t ngroups = (n + 127) / 128;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t pt = (grp * 8 + wave) * 16 + li;
+    const bool valid = pt < n;
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) p32[0][a] = pts[pt * 3 + a];
+    }
+    PointNb nb;
+    point_neighbors(nbr, cloud, n_nb, radius, radius_all, min_nn, pt, valid,
+                    p32[0], nb);
+    f32x4 c[1][2];
+    point_feature(nb, feats, fmask, empty, q, c);
+    float out[1][1];
+    uint64_t mask[1];
+    mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c, out, mask, nullptr);
+    if (valid) {
+      if (q == 0) {
+        occ[pt] = out[0][0];
+        has_out[pt] = nb.has ? 1 : 0;
+      }
+      if (masks != nullptr) masks[pt * 4 + q] = mask[0];
+    }
+  }
+}
+
+template <bool NEED_DP, bool NEED_DF>
+__global__ __launch_bounds__(8 * 64, 2) void point_geo_bwd_kernel(
+    int64_t n, const float* __restrict__ pts, const int64_t* __restrict__ nbr,
+    const int* __restrict__ n_nb, const float* __restrict__ cloud,
+    const float* __restrict__ feats, const uint8_t* __restrict__ fmask,
+    const float* __restrict__ radius, float radius_all, int min_nn,
+    const float* __restrict__ empty, const float* __restrict__ dec,
+    const uint64_t* __restrict__ masks, const float* __restrict__ g_occ,
+    float* __restrict__ g_pts, float* __restrict__ g_feats) {
+  using PM = MlpPack<32, 1>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  stage_weights(wl, dec + PM::EMB, (NEED_DP ? PM::LEN : PM::W0T) - PM::EMB);
+  const int64_t ngroups = (n + 127) / 128;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t pt = (grp * 8 + wave) * 16 + li;
+    const bool valid = pt < n;
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) p32[0][a] = pts[pt * 3 + a];
+    }
+    PointNb nb;
+    point_neighbors(nbr, cloud, n_nb, radius, radius_all, min_nn, pt, valid,
+                    p32[0], nb);
+    f32x4 c[1][2], gc[1][2];
+    point_feature(nb, feats, fmask, empty, q, c);
+    const float go[1][1] = {{valid ? g_occ[pt] : 0.f}};
+    const uint64_t mask[1] = {valid ? masks[pt * 4 + q] : 0};
+    float gp[1][3] = {{0.f, 0.f, 0.f}};
+    mlp_bwd<1, 32, 1, NEED_DP, NEED_DP>(wl - PM::EMB, lane, p32, c, go, mask,
+                                        gc, gp);
+    float gpos[3] = {0.f, 0.f, 0.f};
+    if (NEED_DP) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) gpos[a] = group4_sum(gp[0][a]);
+    }
+    // interpolation backward (nothing flows through the random feature)
+    float gw[8];
+    float aw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gw[k] = 0.f;
+      const bool live = nb.has && nb.u[k] != 0.f &&
+                        (fmask == nullptr || fmask[nb.id[k]] != 0);
+      const float w = nb.u[k] / nb.den;
+      if (live) {
+        const float* f = feats + (int64_t)nb.id[k] * 32 + 4 * q;
+        if (NEED_DP) {
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(f);
+          const f32x4 f1 = *reinterpret_cast<const f32x4*>(f + 16);
+          float d = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d += gc[0][0][r] * f0[r] + gc[0][1][r] * f1[r];
+          gw[k] = d;
+        }
+        if (NEED_DF) {
+          float* g = g_feats + (int64_t)nb.id[k] * 32 + 4 * q;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(g + r, w * gc[0][0][r]);
+            atomicAdd(g + 16 + r, w * gc[0][1][r]);
+          }
+        }
+      }
+      if (NEED_DP) {
+        gw[k] = group4_sum(gw[k]);   // every lane group holds 8 of 32 features
+        aw += gw[k] * w;
+      }
+    }
+    if (NEED_DP) {
+      if (nb.has) {
+        const bool norm = nb.den > 1e-12f;   // else the clamp: constant
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (nb.u[k] == 0.f) continue;
+          const float gu = (gw[k] - (norm ? aw : 0.f)) / nb.den;
+          const float gD = -nb.u[k] * nb.u[k] * gu;
+          const int64_t id = nb.id[k];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            gpos[a] += 2.f * (p32[0][a] - cloud[id * 3 + a]) * gD;
+        }
+      }
+      if (valid && q == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g_pts[pt * 3 + a] = gpos[a];
+      }
+    }
+  }
+}
+
 // g_dec = sum of the dW replicas; g_rays_{o,d}[ray] = sum of the ray's tile
 // partials (fixed order: deterministic)
 __global__ __launch_bounds__(256) void nice_bwd_finish_kernel(
@@ -1943,6 +2145,84 @@ int xrd_nice_eval_points(const xrd_nice_scene* scene, int stage,
     hipLaunchKernelGGL(kc, dim3(nb), dim3(512), lds, (hipStream_t)stream,
                        *scene, n_points, points, raw);
   return check_launch("xrd_nice_eval_points");
+}
+
+static int point_geo_attr() {
+  static bool done = false;
+  if (done) return XRD_OK;
+  const int lds = (int)(kWMax * sizeof(float));
+  const void* ks[] = {
+      reinterpret_cast<const void*>(point_geo_fwd_kernel),
+      reinterpret_cast<const void*>(point_geo_bwd_kernel<false, true>),
+      reinterpret_cast<const void*>(point_geo_bwd_kernel<true, false>),
+      reinterpret_cast<const void*>(point_geo_bwd_kernel<true, true>)};
+  for (const void* k : ks)
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+  done = true;
+  return XRD_OK;
+}
+
+int xrd_point_geo_fwd(int64_t n_points, const float* points,
+                      const int64_t* neighbors, const int32_t* n_neighbors,
+                      const float* cloud, const float* geo_feats,
+                      const uint8_t* feat_mask, const float* radius,
+                      float radius_all, int min_nn, const float* empty_feat,
+                      const float* packed_decoder, float* occ, uint8_t* has,
+                      uint64_t* relu_masks, xrd_stream_t stream) {
+  if (n_points < 0 || min_nn < 0) return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  if (!points || !neighbors || !n_neighbors || !cloud || !geo_feats ||
+      !empty_feat || !packed_decoder || !occ || !has)
+    return XRD_ERR_ARG;
+  int rc = point_geo_attr();
+  if (rc != XRD_OK) return rc;
+  const int64_t ngroups = (n_points + 127) / 128;
+  const int nb = (int)(ngroups < 512 ? ngroups : 512);
+  hipLaunchKernelGGL(point_geo_fwd_kernel, dim3(nb), dim3(512),
+                     kWMax * sizeof(float), (hipStream_t)stream, n_points,
+                     points, neighbors, n_neighbors, cloud, geo_feats,
+                     feat_mask, radius, radius_all, min_nn, empty_feat,
+                     packed_decoder, occ, has, relu_masks);
+  return check_launch("xrd_point_geo_fwd");
+}
+
+int xrd_point_geo_bwd(int64_t n_points, const float* points,
+                      const int64_t* neighbors, const int32_t* n_neighbors,
+                      const float* cloud, const float* geo_feats,
+                      const uint8_t* feat_mask, const float* radius,
+                      float radius_all, int min_nn, const float* empty_feat,
+                      const float* packed_decoder, const uint64_t* relu_masks,
+                      const float* g_occ, float* g_points, float* g_geo_feats,
+                      xrd_stream_t stream) {
+  if (n_points < 0 || min_nn < 0) return XRD_ERR_ARG;
+  if (n_points == 0) return XRD_OK;
+  if (!points || !neighbors || !n_neighbors || !cloud || !geo_feats ||
+      !empty_feat || !packed_decoder || !relu_masks || !g_occ)
+    return XRD_ERR_ARG;
+  if (!g_points && !g_geo_feats) return XRD_OK;
+  int rc = point_geo_attr();
+  if (rc != XRD_OK) return rc;
+  const int64_t ngroups = (n_points + 127) / 128;
+  const dim3 grid((unsigned)(ngroups < 512 ? ngroups : 512)), block(512);
+  const size_t lds = kWMax * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define XRD_PG_ARGS                                                          \
+  n_points, points, neighbors, n_neighbors, cloud, geo_feats, feat_mask,     \
+      radius, radius_all, min_nn, empty_feat, packed_decoder, relu_masks,    \
+      g_occ, g_points, g_geo_feats
+  if (g_points && g_geo_feats)
+    hipLaunchKernelGGL((point_geo_bwd_kernel<true, true>), grid, block, lds,
+                       st, XRD_PG_ARGS);
+  else if (g_points)
+    hipLaunchKernelGGL((point_geo_bwd_kernel<true, false>), grid, block, lds,
+                       st, XRD_PG_ARGS);
+  else
+    hipLaunchKernelGGL((point_geo_bwd_kernel<false, true>), grid, block, lds,
+                       st, XRD_PG_ARGS);
+#undef XRD_PG_ARGS
+  return check_launch("xrd_point_geo_bwd");
 }
 
 int64_t xrd_nice_bwd_ws_floats(int n_rays) {

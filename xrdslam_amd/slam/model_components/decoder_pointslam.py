@@ -171,8 +171,26 @@ class MLP_geometry(_PointMLP):
         self.mlp_col_neighbor = MLP_col_neighbor(c_dim, 20, hidden_size)
         self._build_trunk(93, hidden_size, n_blocks, c_dim, 1, 'relu')
 
+    use_fused = True   # neighbour interpolation + trunk as one kernel each way
+
     def forward(self, p, npc, pts_num=16, is_tracker=False, pts_views_d=None,
                 dynamic_r_query=None, neighbors=None):
+        if self.use_fused and p.is_cuda and is_tracker and \
+                not self.output_linear.weight.requires_grad:
+            # (a decoder that is being trained keeps the torch path: the
+            # kernels return no weight gradients)
+            from ...engine import point as _pt
+            if _pt.supported(self):
+                flat = p.reshape(-1, 3)
+                if neighbors is None:
+                    neighbors = npc.find_neighbors_faiss(
+                        flat.detach().clone(), step='query',
+                        dynamic_radius=dynamic_r_query)
+                occ, has = _pt.geometry(self, flat, neighbors, npc,
+                                        dynamic_r_query)
+                valid_ray = ~(torch.sum(has.view(-1, pts_num), 1) <
+                              int(self.N_surface / 2 + 1))
+                return occ, valid_ray, has
         c, has = self._interpolate(npc, p, npc.get_geo_feats(), is_tracker,
                                    dynamic_r_query, neighbors=neighbors)
         # a ray is valid when at least half of its samples have neighbours

@@ -62,6 +62,9 @@ class ConvOnet2Config(ModelConfig):
 
 
 class ConvOnet2(Model):
+    # engine option (not a reference config field): see get_param_groups
+    freeze_fixed_decoders = True
+
     config: ConvOnet2Config
 
     def __init__(self, config, camera, **kwargs) -> None:
@@ -177,6 +180,11 @@ class ConvOnet2(Model):
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         cfg = self.config
         dec = []
+        # a decoder no optimiser owns needs no gradients (the reference's
+        # autograd fills them and never reads them); without them the
+        # geometry path runs on its fused kernels (engine/point.py)
+        self.decoder.geo_decoder.requires_grad_(
+            not (cfg.mapping_fix_geo_decoder and self.freeze_fixed_decoders))
         if not cfg.mapping_fix_geo_decoder:
             dec += list(self.decoder.geo_decoder.parameters())
         if not cfg.mapping_fix_color_decoder:
