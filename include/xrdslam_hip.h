@@ -138,6 +138,51 @@ int xrd_point_geo_bwd(int64_t n_points, const float* points,
                       const float* packed_decoder, const uint64_t* relu_masks,
                       const float* g_occ, float* g_points, float* g_geo_feats,
                       xrd_stream_t stream);
+/* Point-SLAM colour path (MLP_color with its defaults: per-neighbour F_theta
+ * on [rel-pos embedding, colour feature], inverse-distance interpolation,
+ * 5 x 128 softplus trunk with the feature added after every layer, skip after
+ * the third, sigmoid; no view direction, no exposure code) replacing
+ * slam/model_components/decoder_pointslam.py:276-291,408-542.
+ *   flat parameter order (xrd_point_color_flat_len floats; the first
+ *   xrd_point_color_grad_len are trainable and form the flat gradient):
+ *     mlp_col_neighbor.linear1.weight [128,52], .bias, linear2.weight [32,128],
+ *     .bias, embedder_rel_pos._B [3,10], pts_linears.{0..4}.weight/.bias
+ *     ([128,40], [128,128] x2, [128,168], [128,128]), fc_c.{0..4}.weight
+ *     [128,32]/.bias, output_linear.weight [3,128], .bias, embedder._B [3,20].
+ *   packed = flat gathered through xrd_point_color_pack_index (int32
+ *   [xrd_point_color_pack_len], -1 = 0.0).
+ * fwd: rgb [n,3]; save_c [n,32], save_h [5,n,128], save_y [n,8,32] (the
+ *   interpolated feature, the trunk's layer outputs and F_theta's outputs, for
+ *   the backward; all NULL = inference).
+ * bwd: g_rgb [n,3] -> g_points [n,3] (Fourier features of p, relative-position
+ *   features and the recomputed neighbour distances; NULL = not wanted),
+ *   g_col_feats [N,32] (ACCUMULATED with atomics; NULL = not wanted), g_flat
+ *   [xrd_point_color_grad_len] (overwritten; NULL = no parameter gradients).
+ *   With g_flat: ops = xrd_point_color_ops_floats(n) floats of scratch (the
+ *   operands of the weight gradients), workspace = xrd_point_color_ws_floats()
+ *   floats (per-block partial products). */
+int xrd_point_color_flat_len(void);
+int xrd_point_color_grad_len(void);
+int xrd_point_color_pack_len(void);
+int xrd_point_color_pack_index(int32_t* index);
+int64_t xrd_point_color_ops_floats(int64_t n_points);
+int64_t xrd_point_color_ws_floats(void);
+int xrd_point_color_fwd(int64_t n_points, const float* points,
+                        const int64_t* neighbors, const int32_t* n_neighbors,
+                        const float* cloud, const float* col_feats,
+                        const float* radius, float radius_all, int min_nn,
+                        const float* empty_feat, const float* packed,
+                        float* rgb, float* save_c, float* save_h,
+                        float* save_y, xrd_stream_t stream);
+int xrd_point_color_bwd(int64_t n_points, const float* points,
+                        const int64_t* neighbors, const int32_t* n_neighbors,
+                        const float* cloud, const float* col_feats,
+                        const float* radius, float radius_all, int min_nn,
+                        const float* packed, const float* rgb,
+                        const float* save_c, const float* save_h,
+                        const float* save_y, const float* g_rgb,
+                        float* g_points, float* g_col_feats, float* g_flat,
+                        float* ops, float* workspace, xrd_stream_t stream);
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):

@@ -168,3 +168,84 @@ def test_fused_geometry_path_matches_modular():
         assert err < 1e-4, (k, err)
     # rows of masked points receive no gradient
     assert float(got['g_f'][~npc.frustum_mask.reshape(-1)].abs().max()) == 0
+
+
+def _color_case(dev, seed=7, N=6000, n=5 * 1237):
+    from xrdslam_amd.engine.knn import GridKNN
+    from xrdslam_amd.slam.model_components.decoder_pointslam import MLP_color
+    g = torch.Generator().manual_seed(seed)
+    cloud = torch.rand(N, 3, generator=g) * torch.tensor([2.0, 1.5, 1.0])
+    q = cloud[torch.randint(N, (n, ), generator=g)] + \
+        0.04 * torch.randn(n, 3, generator=g)
+    q[:40] += 5.0                      # far away: no neighbours at all
+    torch.manual_seed(seed)
+    dec = MLP_color(use_dynamic_radius=True,
+                    pointcloud_nn_weighting='distance',
+                    pointcloud_min_nn_num=2, rendering_n_surface=5,
+                    model_encode_rel_pos_in_col=True,
+                    model_encode_exposure=False, model_encode_viewd=True,
+                    model_exposure_dim=8, c_dim=32, hidden_size=128,
+                    n_blocks=5, skips=[2]).to(dev)
+    with torch.no_grad():              # biases off zero, like a trained net
+        for prm in dec.parameters():
+            if prm.dim() == 1:
+                prm.normal_(0, 0.05, generator=None)
+    empty = (torch.randn(32, generator=g) * 0.01).to(dev)
+    dec.empty_feature_fn = lambda c, d: empty
+
+    class Cloud:
+        def __init__(self):
+            self.index = GridKNN(0.16, dev)
+            self.index.add(cloud.to(dev))
+            self.col_feats = torch.nn.Parameter(
+                (torch.randn(N, 32, generator=g) * 0.3).to(dev))
+            self._cloud = cloud.to(dev)
+
+        def cloud_tensor(self, device=None):
+            return self._cloud
+
+        def get_radius_query(self):
+            return 0.08
+
+        def find_neighbors_faiss(self, pos, step='query', dynamic_radius=None,
+                                 **kw):
+            D, I = self.index.search(pos.float(), 8)
+            n_nb = (D < dynamic_radius.reshape(-1, 1)**2).sum(-1).int()
+            return D, I, n_nb
+
+    radius = (0.04 + 0.08 * torch.rand(n, generator=g)).to(dev)
+    w_out = torch.randn(n, 3, generator=g).to(dev)
+    return dec, Cloud(), q, radius, w_out
+
+
+@pytest.mark.gpu
+def test_fused_color_path_matches_modular():
+    """xrd_point_color_fwd / _bwd (F_theta per neighbour, interpolation and
+    the colour decoder in one kernel each way, weight gradients as
+    contractions over the saved operands) against MLP_color's torch path on
+    the same neighbours: colours, d/d positions, d/d colour features, d/d
+    every decoder parameter (incl. the learnable relative-position matrix)"""
+    from xrdslam_amd.engine import point as ep
+    dev = 'cuda:0'
+    dec, npc, q, radius, w_out = _color_case(dev)
+    assert ep.color_supported(dec)
+
+    def run(fused):
+        dec.use_fused = fused
+        npc.col_feats.grad = None
+        dec.zero_grad(set_to_none=True)
+        p = q.clone().to(dev).requires_grad_(True)
+        rgb = dec(p.unsqueeze(0), npc, is_tracker=True,
+                  dynamic_r_query=radius)
+        (rgb * w_out).sum().backward()
+        out = {'rgb': rgb.detach(), 'g_p': p.grad.clone(),
+               'g_f': npc.col_feats.grad.clone()}
+        for name, prm in dec.named_parameters():
+            out['g:' + name] = prm.grad.clone()
+        return out
+
+    ref, got = run(False), run(True)
+    assert set(ref) == set(got)
+    for k in ref:
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-4, (k, err)

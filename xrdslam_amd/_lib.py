@@ -54,6 +54,16 @@ _SIGS = {
                           [vp] * 6),
     'xrd_point_geo_bwd': (C.c_int, [i64] + [vp] * 7 + [f32, C.c_int] +
                           [vp] * 7),
+    'xrd_point_color_flat_len': (C.c_int, []),
+    'xrd_point_color_grad_len': (C.c_int, []),
+    'xrd_point_color_pack_len': (C.c_int, []),
+    'xrd_point_color_pack_index': (C.c_int, [vp]),
+    'xrd_point_color_ops_floats': (i64, [i64]),
+    'xrd_point_color_ws_floats': (i64, []),
+    'xrd_point_color_fwd': (C.c_int, [i64] + [vp] * 6 + [f32, C.c_int] +
+                            [vp] * 7),
+    'xrd_point_color_bwd': (C.c_int, [i64] + [vp] * 6 + [f32, C.c_int] +
+                            [vp] * 12),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,

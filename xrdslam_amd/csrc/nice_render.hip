@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "nice_layout.h"
+#include "point_common.h"
 
 namespace xrd {
 namespace {
@@ -1751,38 +1752,6 @@ __global__ __launch_bounds__(8 * 64, 2) void nice_points_kernel(
 //   2 pi is folded into the packed B) — mlp_fwd / mlp_bwd<.,32,1> as they
 //   are.  One wave = 16 samples; the distances are recomputed from the
 //   positions so that they carry the pose gradient (is_tracker, :181-186).
-struct PointNb {
-  int id[8];
-  float u[8];    // 1/(D + 1e-10), 0 beyond the radius / missing
-  float den;     // max(sum u, 1e-12)
-  bool has;
-};
-
-__device__ __forceinline__ void point_neighbors(
-    const int64_t* __restrict__ nbr, const float* __restrict__ cloud,
-    const int* __restrict__ n_nb, const float* __restrict__ radius,
-    float radius_all, int min_nn, int64_t pt, bool valid,
-    const float (&p)[3], PointNb& nb) {
-  float S = 0.f;
-  const float r = valid ? (radius ? radius[pt] : radius_all) : 0.f;
-  const float bound = r * r;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int64_t id = valid ? nbr[pt * 8 + k] : -1;
-    nb.id[k] = (int)id;
-    nb.u[k] = 0.f;
-    if (id >= 0) {
-      const float dx = cloud[id * 3] - p[0], dy = cloud[id * 3 + 1] - p[1],
-                  dz = cloud[id * 3 + 2] - p[2];
-      const float D = dx * dx + dy * dy + dz * dz;
-      if (!(D > bound)) nb.u[k] = 1.f / (D + 1e-10f);
-    }
-    S += nb.u[k];
-  }
-  nb.den = fmaxf(S, 1e-12f);
-  nb.has = valid && n_nb[pt] > min_nn - 1;
-}
-
 __device__ __forceinline__ void point_feature(
     const PointNb& nb, const float* __restrict__ feats,
     const uint8_t* __restrict__ fmask, const float* __restrict__ empty, int q,

@@ -118,3 +118,148 @@ def geometry(dec, p, neighbors, npc, dynamic_r_query):
         float(npc.get_radius_query()), dec.min_nn_num, empty,
         pack(dec, dev))
     return occ, has.bool()
+
+
+# ---- colour path (csrc/point_color.hip) ------------------------------------------
+def color_supported(dec) -> bool:
+    try:
+        return (dec.weighting == 'distance' and dec.c_dim == 32 and
+                list(dec.skips) == [2] and len(dec.pts_linears) == 5 and
+                dec.encode_rel_pos_in_col and not dec.use_view_direction and
+                not dec.encode_exposure and
+                isinstance(dec.actvn, torch.nn.Softplus) and
+                dec.actvn.beta == 100 and dec.actvn.threshold == 20 and
+                dec.pts_linears[0].weight.shape == (128, 40) and
+                dec.pts_linears[3].weight.shape == (128, 168) and
+                dec.output_linear.weight.shape == (3, 128) and
+                dec.mlp_col_neighbor.linear1.weight.shape == (128, 52) and
+                dec.embedder.mapping_size == 20 and dec.embedder.concat and
+                dec.embedder_rel_pos.mapping_size == 10)
+    except AttributeError:
+        return False
+
+
+def color_params(dec):
+    """the trainable tensors in the kernels' flat order"""
+    f = dec.mlp_col_neighbor
+    out = [f.linear1.weight, f.linear1.bias, f.linear2.weight, f.linear2.bias,
+           dec.embedder_rel_pos._B]
+    for layer in dec.pts_linears:
+        out += [layer.weight, layer.bias]
+    for layer in dec.fc_c:
+        out += [layer.weight, layer.bias]
+    return out + [dec.output_linear.weight, dec.output_linear.bias]
+
+
+_COLOR_INDEX = {}
+
+
+def _color_index(device):
+    dev = torch.device(device)
+    hit = _COLOR_INDEX.get(dev)
+    if hit is None:
+        lib = _lib.lib()
+        idx = torch.empty(lib.xrd_point_color_pack_len(), dtype=torch.int32)
+        _lib.check(lib.xrd_point_color_pack_index(_lib.ptr(idx)),
+                   'xrd_point_color_pack_index')
+        live = (idx >= 0).to(dev)
+        hit = (idx.clamp(min=0).long().to(dev), live)
+        _COLOR_INDEX[dev] = hit
+    return hit
+
+
+def pack_color(flat: torch.Tensor) -> torch.Tensor:
+    idx, live = _color_index(flat.device)
+    return torch.where(live, flat.detach()[idx], flat.new_zeros(()))
+
+
+_COLOR_SCRATCH = {}
+
+
+def _color_scratch(device, n):
+    """(operands of the weight gradients, per-block partial products): grown,
+    never shrunk, one pair per device (consumed on the stream that fills it)"""
+    lib = _lib.lib()
+    dev = torch.device(device)
+    ops, ws = _COLOR_SCRATCH.get(dev, (None, None))
+    need = lib.xrd_point_color_ops_floats(n)
+    if ops is None or ops.numel() < need:
+        ops = torch.empty(need, dtype=torch.float32, device=dev)
+    if ws is None:
+        ws = torch.empty(lib.xrd_point_color_ws_floats(), dtype=torch.float32,
+                         device=dev)
+    _COLOR_SCRATCH[dev] = (ops, ws)
+    return ops, ws
+
+
+class _ColFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, feats, flat, nbr, n_nb, cloud, radius, radius_all,
+                min_nn, empty):
+        lib = _lib.lib()
+        dev = p.device
+        p = p.detach().float().reshape(-1, 3).contiguous()
+        n = p.shape[0]
+        f = feats.detach().float().contiguous()
+        packed = pack_color(flat)
+        need = any(ctx.needs_input_grad[:3])
+        rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        save_c = save_h = save_y = None
+        if need:
+            save_c = torch.empty(n, 32, dtype=torch.float32, device=dev)
+            save_h = torch.empty(5, n, 128, dtype=torch.float32, device=dev)
+            save_y = torch.empty(n, 8, 32, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_point_color_fwd(
+            n, _lib.ptr(p), _lib.ptr(nbr), _lib.ptr(n_nb), _lib.ptr(cloud),
+            _lib.ptr(f), _lib.ptr(radius), float(radius_all), int(min_nn),
+            _lib.ptr(empty), _lib.ptr(packed), _lib.ptr(rgb),
+            _lib.ptr(save_c), _lib.ptr(save_h), _lib.ptr(save_y),
+            _lib.stream_ptr(dev)), 'xrd_point_color_fwd')
+        ctx.args = (float(radius_all), int(min_nn), flat.numel())
+        ctx.save_for_backward(p, f, nbr, n_nb, cloud, radius, packed, rgb,
+                              save_c, save_h, save_y)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        lib = _lib.lib()
+        p, f, nbr, n_nb, cloud, radius, packed, rgb, save_c, save_h, save_y \
+            = ctx.saved_tensors
+        radius_all, min_nn, flat_len = ctx.args
+        dev = p.device
+        need_p, need_f, need_w = ctx.needs_input_grad[:3]
+        n = p.shape[0]
+        g_p = torch.empty_like(p) if need_p else None
+        g_f = torch.zeros_like(f) if need_f else None
+        g_flat = ops = ws = None
+        if need_w:
+            # [0, grad_len) is written by the kernels, the tail (the fixed
+            # embedding matrix) has no gradient
+            g_flat = torch.zeros(flat_len, dtype=torch.float32, device=dev)
+            ops, ws = _color_scratch(dev, n)
+        _lib.check(lib.xrd_point_color_bwd(
+            n, _lib.ptr(p), _lib.ptr(nbr), _lib.ptr(n_nb), _lib.ptr(cloud),
+            _lib.ptr(f), _lib.ptr(radius), radius_all, min_nn,
+            _lib.ptr(packed), _lib.ptr(rgb), _lib.ptr(save_c),
+            _lib.ptr(save_h), _lib.ptr(save_y),
+            _lib.ptr(g_rgb.float().contiguous()), _lib.ptr(g_p),
+            _lib.ptr(g_f), _lib.ptr(g_flat), _lib.ptr(ops), _lib.ptr(ws),
+            _lib.stream_ptr(dev)), 'xrd_point_color_bwd')
+        return (g_p, g_f, g_flat) + (None, ) * 7
+
+
+def color(dec, p, neighbors, npc, dynamic_r_query):
+    """-> rgb [n,3].  ``neighbors`` = (D, I, n_nb) of the search for ``p``."""
+    dev = p.device
+    _, ids, n_nb = neighbors
+    cloud = npc.cloud_tensor(dev).float().contiguous()
+    radius = None
+    if dec.use_dynamic_radius and dynamic_r_query is not None:
+        radius = dynamic_r_query.detach().float().reshape(-1).contiguous()
+    empty = dec.empty_feature_fn(dec.c_dim, dev).float().contiguous()
+    flat = torch.cat([t.reshape(-1) for t in color_params(dec)] +
+                     [dec.embedder._B.detach().to(dev).reshape(-1)])
+    return _ColFn.apply(p.reshape(-1, 3), npc.col_feats, flat,
+                        ids.long().contiguous(), n_nb.int().contiguous(),
+                        cloud, radius, float(npc.get_radius_query()),
+                        dec.min_nn_num, empty)

@@ -246,8 +246,19 @@ class MLP_color(_PointMLP):
         emb = self.embedder_rel_pos(rel_pos.reshape(-1, 3)).reshape(n, -1, 20)
         return self.mlp_col_neighbor(torch.cat([emb, feats], -1))
 
+    use_fused = True   # F_theta + interpolation + trunk as one kernel each way
+
     def forward(self, p, npc, is_tracker=False, pts_views_d=None,
                 dynamic_r_query=None, exposure_feat=None, neighbors=None):
+        if self.use_fused and p.is_cuda and is_tracker:
+            from ...engine import point as _pt
+            if _pt.color_supported(self):
+                flat = p.reshape(-1, 3)
+                if neighbors is None:
+                    neighbors = npc.find_neighbors_faiss(
+                        flat.detach().clone(), step='query',
+                        dynamic_radius=dynamic_r_query)
+                return _pt.color(self, flat, neighbors, npc, dynamic_r_query)
         c, _ = self._interpolate(
             npc, p, npc.col_feats, is_tracker, dynamic_r_query,
             transform=self._f_theta if self.encode_rel_pos_in_col else None,
