@@ -47,68 +47,125 @@ __global__ void knn_ranges_kernel(int64_t n, const int64_t* __restrict__ sorted,
   if (i == n - 1 || sorted[i + 1] != c) end[c] = (int)i + 1;
 }
 
+// One wave per query.  The cells cx-reach .. cx+reach of a grid row are
+// consecutive cell ids, so their points are one contiguous range of the sorted
+// cloud: the wave reads it 64 points at a time (coalesced), keeps the points
+// within max_radius as 64-bit keys (distance bits : id) in an LDS list, and
+// selects the K smallest keys with K wave-wide minimum rounds.  A list that
+// would overflow is first reduced to its K best.  Ascending (distance, id)
+// order, exact: squared distances are non-negative floats, whose bit patterns
+// order like the values.
+constexpr int KNN_WAVES = 4, KNN_CAP = 512;
+constexpr unsigned long long KNN_NONE = ~0ull;
+
+__device__ __forceinline__ unsigned long long wave_min_u64(
+    unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(v, o);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// the K smallest keys of L[0, cnt) -> out (KNN_NONE where fewer); L is consumed
 template <int K>
-__global__ __launch_bounds__(128) void knn_search_kernel(
+__device__ __forceinline__ void knn_select(unsigned long long* L, int cnt,
+                                           int lane,
+                                           unsigned long long (&out)[K]) {
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    unsigned long long best = KNN_NONE;
+    for (int t = lane; t < cnt; t += 64) {
+      const unsigned long long v = L[t];
+      best = v < best ? v : best;
+    }
+    best = wave_min_u64(best);
+    out[r] = best;
+    if (best != KNN_NONE) {
+      for (int t = lane; t < cnt; t += 64)
+        if (L[t] == best) L[t] = KNN_NONE;
+      wave_lds_sync();
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     Grid g, int64_t m, const float* __restrict__ q, const float* __restrict__ pts,
     const int* __restrict__ ids, const int* __restrict__ start,
     const int* __restrict__ end, int reach, float r2max, float* __restrict__ D,
     int64_t* __restrict__ I) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+  __shared__ unsigned long long list[KNN_WAVES][KNN_CAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
+  if (i >= m) return;   // wave-uniform
+  unsigned long long* L = list[wave];
   const float x = q[i * 3], y = q[i * 3 + 1], z = q[i * 3 + 2];
-  float bd[K];
-  int bi[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    bd[k] = FLT_MAX;
-    bi[k] = -1;
-  }
   const int cx = cell_coord(x, g.origin[0], g.inv_cell, g.dims[0]);
   const int cy = cell_coord(y, g.origin[1], g.inv_cell, g.dims[1]);
   const int cz = cell_coord(z, g.origin[2], g.inv_cell, g.dims[2]);
+  const int xlo = cx - reach < 0 ? 0 : cx - reach;
+  const int xhi = cx + reach >= g.dims[0] ? g.dims[0] - 1 : cx + reach;
+  int cnt = 0;
+  unsigned long long best[K];
   for (int dz = -reach; dz <= reach; ++dz) {
     const int zz = cz + dz;
     if (zz < 0 || zz >= g.dims[2]) continue;
     for (int dy = -reach; dy <= reach; ++dy) {
       const int yy = cy + dy;
       if (yy < 0 || yy >= g.dims[1]) continue;
-      for (int dx = -reach; dx <= reach; ++dx) {
-        const int xx = cx + dx;
-        if (xx < 0 || xx >= g.dims[0]) continue;
-        const int64_t c = ((int64_t)zz * g.dims[1] + yy) * g.dims[0] + xx;
-        const int s = start[c], e = end[c];
-        for (int j = s; j < e; ++j) {
+      const int64_t c0 = ((int64_t)zz * g.dims[1] + yy) * g.dims[0];
+      int s = 0, e = 0;
+      for (int xx = xlo; xx <= xhi; ++xx) {
+        const int cs = start[c0 + xx], ce = end[c0 + xx];
+        if (ce > cs) {
+          if (e == 0) s = cs;
+          e = ce;
+        }
+      }
+      for (int j0 = s; j0 < e; j0 += 64) {
+        const int j = j0 + lane;
+        bool keep = false;
+        float d2 = 0.f;
+        if (j < e) {
           const float ddx = pts[j * 3] - x, ddy = pts[j * 3 + 1] - y,
                       ddz = pts[j * 3 + 2] - z;
-          const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-          if (d2 > r2max) continue;
-          const int id = ids[j];
-          // insert keeping (distance, id) ascending
-          if (d2 < bd[K - 1] || (d2 == bd[K - 1] && id < bi[K - 1])) {
-            float cd = d2;
-            int ci = id;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const bool before = cd < bd[k] || (cd == bd[k] && ci < bi[k]) ||
-                                  bi[k] < 0;
-              if (before) {
-                const float td = bd[k];
-                const int ti = bi[k];
-                bd[k] = cd;
-                bi[k] = ci;
-                cd = td;
-                ci = ti;
-              }
-            }
-          }
+          d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+          keep = !(d2 > r2max);
         }
+        const unsigned long long mask = __ballot(keep);
+        const int nk = __popcll(mask);
+        if (nk == 0) continue;
+        if (cnt + nk > KNN_CAP) {
+          knn_select<K>(L, cnt, lane, best);
+          cnt = 0;
+#pragma unroll
+          for (int r = 0; r < K; ++r)
+            if (best[r] != KNN_NONE) {
+              if (lane == 0) L[cnt] = best[r];
+              ++cnt;
+            }
+        }
+        if (keep) {
+          const int pos =
+              cnt + __popcll(mask & ((1ull << lane) - 1ull));
+          L[pos] = ((unsigned long long)__float_as_uint(d2) << 32) |
+                   (unsigned int)ids[j];
+        }
+        cnt += nk;
       }
     }
   }
+  knn_select<K>(L, cnt, lane, best);
+  if (lane < K) {
+    unsigned long long v = best[0];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    D[i * K + k] = bd[k];
-    I[i * K + k] = (int64_t)bi[k];
+    for (int r = 1; r < K; ++r) v = lane == r ? best[r] : v;
+    const bool none = v == KNN_NONE;
+    D[i * K + lane] = none ? FLT_MAX : __uint_as_float((unsigned int)(v >> 32));
+    I[i * K + lane] = none ? -1 : (int64_t)(unsigned int)(v & 0xffffffffu);
   }
 }
 
@@ -170,8 +227,9 @@ int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
       !out_d2 || !out_idx)
     return XRD_ERR_ARG;
   const int reach = (int)ceilf(max_radius / cell);
-  hipLaunchKernelGGL((knn_search_kernel<8>), dim3((unsigned)((m + 127) / 128)),
-                     dim3(128), 0, (hipStream_t)stream, g, m, queries,
+  hipLaunchKernelGGL((knn_search_kernel<8>),
+                     dim3((unsigned)((m + KNN_WAVES - 1) / KNN_WAVES)),
+                     dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, g, m, queries,
                      sorted_points, sorted_ids, cell_start, cell_end, reach,
                      max_radius * max_radius, out_d2, out_idx);
   return check_launch("xrd_knn_search");

@@ -35,13 +35,33 @@ constexpr int kTailLen = PcPack::FWD_LEN - PcPack::OW + 32;
 constexpr int kPcLds = (PcPack::STAGE_MAX + kTailLen) * (int)sizeof(float);
 constexpr float kTwoPi = 6.283185307179586f;
 
+// global -> LDS copy of n floats (n % 4 == 0) by the whole block: the loads of
+// a batch are all in flight before the first store (a load-wait-store loop is
+// latency-bound with 128..512 threads and ~100 KB per stage)
+__device__ __forceinline__ void pc_copy(float* __restrict__ wl,
+                                        const float* __restrict__ src, int n) {
+  constexpr int U = 8;
+  const int step = blockDim.x * 4;
+  int i = threadIdx.x * 4;
+  for (; i + (U - 1) * step < n; i += U * step) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      v[u] = *reinterpret_cast<const f32x4*>(src + i + u * step);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      *reinterpret_cast<f32x4*>(wl + i + u * step) = v[u];
+  }
+  for (; i < n; i += step)
+    *reinterpret_cast<f32x4*>(wl + i) =
+        *reinterpret_cast<const f32x4*>(src + i);
+}
+
 __device__ __forceinline__ void pc_stage(float* __restrict__ wl,
                                          const float* __restrict__ src,
                                          int n) {
   __syncthreads();
-  for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
-    *reinterpret_cast<f32x4*>(wl + i) =
-        *reinterpret_cast<const f32x4*>(src + i);
+  pc_copy(wl, src, n);
   __syncthreads();
 }
 
@@ -295,13 +315,6 @@ constexpr int kBwdRfOff = PcPack::FT_LEN;
 static_assert(kBwdRfOff + PcPack::RF_LEN <= kBwdTail, "F_theta stage fits");
 static_assert(PcPack::rlen(3) >= PcPack::rlen(4) &&
               PcPack::rlen(3) >= PcPack::rlen(0), "largest backward stage");
-
-__device__ __forceinline__ void pc_copy(float* __restrict__ wl,
-                                        const float* __restrict__ src, int n) {
-  for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
-    *reinterpret_cast<f32x4*>(wl + i) =
-        *reinterpret_cast<const f32x4*>(src + i);
-}
 
 template <int TILES>
 __device__ __forceinline__ void load_rows(const float* __restrict__ src,
@@ -596,27 +609,44 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_bwd_kernel(
 
 // ---- weight gradients: out[128][N] = G^T A over the rows ---------------------------
 // G [rows][128], A = [A1 | A2] [rows][w1 + w2] (N = w1 + w2 <= 16 NT).  A block of
-// 8 waves owns chunks of 64 rows (persistent) and keeps its share of the
-// product in MFMA accumulators (wave w: output rows 16w .. 16w+15, NT column
-// tiles); the chunk's rows are staged in LDS (row strides 144 / 176 floats:
-// the four row groups of a fragment read fall on distinct banks).  Column
-// sums of G and of A ride along (bias gradients).  Per-block partials
-// [blocks][128 * 16 NT + 128 + 16 NT] are summed by pc_dw_reduce_kernel into the
-// flat gradient.
+// 8 waves owns chunks of 64 rows and keeps its share of the product in MFMA
+// accumulators (wave w: output rows 16w .. 16w+15, NT column tiles); the
+// chunk's rows are staged in LDS (row strides 144 / 176 floats: the four row
+// groups of a fragment read fall on distinct banks).  Column sums of G and of
+// A ride along (bias gradients).  All 13 products of a backward run as ONE
+// launch over a job table (blocks of different jobs share the CUs), their
+// per-block partials [128 * 16 NT + 128 + 16 NT] are summed into the flat
+// gradient by one launch of pc_dw_reduce_kernel.
 constexpr int DW_WAVES = 8, DW_CHUNK = 64, DW_GS = 144, DW_AS = 176;
-constexpr int DW_BLOCKS = 256;
+constexpr int DW_JOBS = 13;
 constexpr int kDwLds = DW_CHUNK * (DW_GS + DW_AS) * (int)sizeof(float);
 __host__ __device__ constexpr int dw_plen(int nt) {
   return 128 * 16 * nt + 128 + 16 * nt;
 }
 
+struct DwJob {
+  const float *G, *A1, *A2;
+  int64_t rows, ws_off;      // partials of this job: ws + ws_off
+  int w1, w2, N, nt;
+  int blk0, nblk;            // blocks [blk0, blk0 + nblk) of the contraction
+  int red0;                  // first block of the reduction
+  // destination: product element (o, c < N) -> w_off + o * ldo + c, or
+  // (transposed) w_off + c * ldo + o; bias = column sums of G (128) or of A (N)
+  int w_off, ldo, transposed, b_off, b_from_a;
+};
+struct DwJobs {
+  DwJob j[DW_JOBS];
+};
+
 template <int NT>
-__global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
-    int64_t rows, const float* __restrict__ G, const float* __restrict__ A1,
-    int w1, const float* __restrict__ A2, int w2, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* Gs = reinterpret_cast<float*>(smem_raw);   // [64][144]
-  float* As = Gs + DW_CHUNK * DW_GS;                 // [64][176]
+__device__ __forceinline__ void dw_block(const DwJob& job, int blk,
+                                         float* __restrict__ ws, float* Gs,
+                                         float* As) {
+  const float* __restrict__ G = job.G;
+  const float* __restrict__ A1 = job.A1;
+  const float* __restrict__ A2 = job.A2;
+  const int64_t rows = job.rows;
+  const int w1 = job.w1, w2 = job.w2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -628,28 +658,38 @@ __global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
   float gsum = 0.f, asum0 = 0.f, asum1 = 0.f;
   const int64_t nchunks = (rows + DW_CHUNK - 1) / DW_CHUNK;
   const int k = lane >> 4, j = lane & 15;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  const int q1 = w1 >> 2, qq = q1 + (w2 >> 2);
+  for (int64_t ch = blk; ch < nchunks; ch += job.nblk) {
     const int64_t r0 = ch * DW_CHUNK;
     __syncthreads();
-    for (int i = threadIdx.x; i < DW_CHUNK * 32; i += DW_WAVES * 64) {
-      const int r = i >> 5, c4 = (i & 31) << 2;
+    {
+      // G: 64 x 32 float4 = 4 per thread, all loads in flight before the stores
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + u * DW_WAVES * 64;
+        const int r = i >> 5, c4 = (i & 31) << 2;
+        v[u] = r0 + r < rows
+                   ? *reinterpret_cast<const f32x4*>(G + (r0 + r) * 128 + c4)
+                   : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + u * DW_WAVES * 64;
+        *reinterpret_cast<f32x4*>(Gs + (i >> 5) * DW_GS + ((i & 31) << 2)) =
+            v[u];
+      }
+    }
+#pragma unroll 2
+    for (int i = threadIdx.x; i < DW_CHUNK * qq; i += DW_WAVES * 64) {
+      const int r = i / qq, c = i - r * qq;
       f32x4 v = z4;
       if (r0 + r < rows)
-        v = *reinterpret_cast<const f32x4*>(G + (r0 + r) * 128 + c4);
-      *reinterpret_cast<f32x4*>(Gs + r * DW_GS + c4) = v;
-    }
-    {
-      const int q1 = w1 >> 2, q2 = w2 >> 2, qq = q1 + q2;
-      for (int i = threadIdx.x; i < DW_CHUNK * qq; i += DW_WAVES * 64) {
-        const int r = i / qq, c = i - r * qq;
-        f32x4 v = z4;
-        if (r0 + r < rows)
-          v = c < q1 ? *reinterpret_cast<const f32x4*>(A1 + (r0 + r) * w1 +
-                                                       4 * c)
-                     : *reinterpret_cast<const f32x4*>(A2 + (r0 + r) * w2 +
-                                                       4 * (c - q1));
-        *reinterpret_cast<f32x4*>(As + r * DW_AS + 4 * c) = v;
-      }
+        v = c < q1
+                ? *reinterpret_cast<const f32x4*>(A1 + (r0 + r) * w1 + 4 * c)
+                : *reinterpret_cast<const f32x4*>(A2 + (r0 + r) * w2 +
+                                                  4 * (c - q1));
+      *reinterpret_cast<f32x4*>(As + r * DW_AS + 4 * c) = v;
     }
     __syncthreads();
 #pragma unroll 2
@@ -668,7 +708,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
         asum1 += As[(grp * 16 + r) * DW_AS + 128 + col];
     }
   }
-  float* out = partial + (int64_t)blockIdx.x * dw_plen(NT);
+  float* out = ws + job.ws_off + (int64_t)blk * dw_plen(NT);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o = 16 * wave + 4 * k + r;
@@ -694,18 +734,41 @@ __global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
   }
 }
 
-// flat[dst(i)] = sum over the blocks of partial[b][i]
-//   product element (o, c < N): normal  -> w_off + o * ldo + c
-//                               transposed -> w_off + c * ldo + o
-//   bias: column sums of G (b_from_a = 0, 128 values) or of A (N values)
+__global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
+    const DwJobs jobs, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Gs = reinterpret_cast<float*>(smem_raw);   // [64][144]
+  float* As = Gs + DW_CHUNK * DW_GS;                 // [64][176]
+  int ji = 0;
+#pragma unroll 1
+  for (int t = 1; t < DW_JOBS; ++t)
+    if ((int)blockIdx.x >= jobs.j[t].blk0) ji = t;
+  const DwJob& job = jobs.j[ji];
+  const int blk = blockIdx.x - job.blk0;
+  switch (job.nt) {
+    case 1: dw_block<1>(job, blk, ws, Gs, As); break;
+    case 2: dw_block<2>(job, blk, ws, Gs, As); break;
+    case 3: dw_block<3>(job, blk, ws, Gs, As); break;
+    case 4: dw_block<4>(job, blk, ws, Gs, As); break;
+    case 8: dw_block<8>(job, blk, ws, Gs, As); break;
+    default: dw_block<11>(job, blk, ws, Gs, As); break;
+  }
+}
+
+// flat[dst(i)] = sum over the job's blocks of partial[b][i]
 __global__ __launch_bounds__(256) void pc_dw_reduce_kernel(
-    int n_blocks, int nt, int N, const float* __restrict__ partial,
-    float* __restrict__ flat, int w_off, int ldo, int transposed, int b_off,
-    int b_from_a) {
+    const DwJobs jobs, const float* __restrict__ ws, float* __restrict__ flat) {
   __shared__ float red[4][64];
+  int ji = 0;
+#pragma unroll 1
+  for (int t = 1; t < DW_JOBS; ++t)
+    if ((int)blockIdx.x >= jobs.j[t].red0) ji = t;
+  const DwJob& job = jobs.j[ji];
+  const int nt = job.nt, N = job.N, n_blocks = job.nblk;
+  const float* __restrict__ partial = ws + job.ws_off;
   const int plen = dw_plen(nt);
   const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + c;
+  const int i = (blockIdx.x - job.red0) * 64 + c;
   float s0 = 0.f, s1 = 0.f;
   if (i < plen) {
     int b = grp;
@@ -722,14 +785,15 @@ __global__ __launch_bounds__(256) void pc_dw_reduce_kernel(
   const int wl = 128 * 16 * nt;
   if (i < wl) {
     const int o = i / (16 * nt), cc = i - o * (16 * nt);
-    if (cc < N) flat[transposed ? w_off + cc * ldo + o : w_off + o * ldo + cc] = v;
+    if (cc < N)
+      flat[job.transposed ? job.w_off + cc * job.ldo + o
+                          : job.w_off + o * job.ldo + cc] = v;
   } else if (i < wl + 128) {
-    if (!b_from_a) flat[b_off + (i - wl)] = v;
+    if (!job.b_from_a) flat[job.b_off + (i - wl)] = v;
   } else {
-    if (b_from_a && i - wl - 128 < N) flat[b_off + (i - wl - 128)] = v;
+    if (job.b_from_a && i - wl - 128 < N) flat[job.b_off + (i - wl - 128)] = v;
   }
 }
-
 
 // host: packed <- flat index table (-1 = zero)
 void build_pc_index(int32_t* idx) {
@@ -852,25 +916,59 @@ static int pc_fwd(int64_t n, const float* points, const int64_t* neighbors,
   return check_launch("xrd_point_color_fwd");
 }
 
-template <int NT>
-static int pc_dw(int64_t rows, const float* G, const float* A1, int w1,
-                 const float* A2, int w2, int N, float* ws, float* g_flat,
-                 int w_off, int ldo, int transposed, int b_off, int b_from_a,
-                 hipStream_t st) {
-  static bool ready = false;
-  if (!ready) {
-    int rc = pc_attr(pc_dw_kernel<NT>, kDwLds);
-    if (rc != XRD_OK) return rc;
-    ready = true;
+// blocks a job may use: its partials cost 128 x 16 NT floats per block, so the
+// short products (n rows) take fewer blocks than F_theta's (8 n rows)
+static int dw_cap(int64_t rows_per_point) { return rows_per_point > 1 ? 256 : 128; }
+
+struct DwPlan {
+  DwJobs jobs;
+  int n = 0, blocks = 0, red_blocks = 0;
+  int64_t ws = 0;
+  void add(int64_t rows, int cap, const float* G, const float* A1, int w1,
+           const float* A2, int w2, int N, int nt, int w_off, int ldo,
+           int transposed, int b_off, int b_from_a) {
+    DwJob& j = jobs.j[n++];
+    const int64_t nchunks = (rows + DW_CHUNK - 1) / DW_CHUNK;
+    j.G = G; j.A1 = A1; j.A2 = A2; j.rows = rows; j.ws_off = ws;
+    j.w1 = w1; j.w2 = w2; j.N = N; j.nt = nt;
+    j.blk0 = blocks; j.nblk = (int)(nchunks < cap ? nchunks : cap);
+    j.red0 = red_blocks;
+    j.w_off = w_off; j.ldo = ldo; j.transposed = transposed;
+    j.b_off = b_off; j.b_from_a = b_from_a;
+    blocks += j.nblk;
+    red_blocks += (dw_plen(nt) + 63) / 64;
+    ws += (int64_t)j.nblk * dw_plen(nt);
   }
-  const int64_t nchunks = (rows + DW_CHUNK - 1) / DW_CHUNK;
-  const int nb = (int)(nchunks < DW_BLOCKS ? nchunks : DW_BLOCKS);
-  hipLaunchKernelGGL(pc_dw_kernel<NT>, dim3(nb), dim3(DW_WAVES * 64), kDwLds,
-                     st, rows, G, A1, w1, A2, w2, ws);
-  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3((dw_plen(NT) + 63) / 64),
-                     dim3(256), 0, st, nb, NT, N, ws, g_flat, w_off, ldo,
-                     transposed, b_off, b_from_a);
-  return XRD_OK;
+};
+
+static void dw_plan(int64_t n, const float* save_c, const float* save_h,
+                    float* ops, DwPlan& p) {
+  using F = PcFlat;
+  const PcOps op(ops, n);
+  const int c1 = dw_cap(1), c8 = dw_cap(8);
+  for (int i = 0; i < 5; ++i) {
+    const float* gz = op.gz + (int64_t)i * n * 128;
+    const float* hp = save_h + (int64_t)(i - 1) * n * 128;
+    if (i == 0)
+      p.add(n, c1, gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(0), 40, 0, F::pb(0),
+            0);
+    else if (i == 3)
+      p.add(n, c1, gz, op.e40, 40, hp, 128, 168, 11, F::pw(3), 168, 0,
+            F::pb(3), 0);
+    else
+      p.add(n, c1, gz, hp, 128, nullptr, 0, 128, 8, F::pw(i), 128, 0, F::pb(i),
+            0);
+    p.add(n, c1, op.gh + (int64_t)i * n * 128, save_c, 32, nullptr, 0, 32, 2,
+          F::fcw(i), 32, 0, F::fcb(i), 0);
+  }
+  // output layer and F_theta's second layer: the 128-wide operand is G, the
+  // product comes out transposed
+  p.add(n, c1, save_h + 4 * n * 128, op.go, 4, nullptr, 0, 3, 1, F::OW, 128, 1,
+        F::OB, 1);
+  p.add(8 * n, c8, op.fh, op.fgy, 32, nullptr, 0, 32, 2, F::W2, 128, 1, F::B2,
+        1);
+  p.add(8 * n, c8, op.fga, op.fx, 52, nullptr, 0, 52, 4, F::W1, 52, 0, F::B1,
+        0);
 }
 
 template <int PW>
@@ -910,7 +1008,9 @@ int xrd_point_color_pack_index(int32_t* idx) {
 
 
 int64_t xrd_point_color_ws_floats(void) {
-  return (int64_t)DW_BLOCKS * dw_plen(11);
+  DwPlan p;   // the bound: every job at its block cap
+  dw_plan((int64_t)1 << 20, nullptr, nullptr, nullptr, p);
+  return p.ws;
 }
 
 
@@ -976,36 +1076,18 @@ int xrd_point_color_bwd(int64_t n_points, const float* points,
   }
 #undef XRD_PC_BWD
   if (rc != XRD_OK || g_flat == nullptr) return rc;
-  const PcOps op(ops, n);
-  float* ws = workspace;
-  for (int i = 0; i < 5 && rc == XRD_OK; ++i) {
-    const float* gz = op.gz + (int64_t)i * n * 128;
-    const float* hp = save_h + (int64_t)(i - 1) * n * 128;
-    if (i == 0)
-      rc = pc_dw<3>(n, gz, op.e40, 40, nullptr, 0, 40, ws, g_flat, F::pw(0),
-                    40, 0, F::pb(0), 0, st);
-    else if (i == 3)
-      rc = pc_dw<11>(n, gz, op.e40, 40, hp, 128, 168, ws, g_flat, F::pw(3),
-                     168, 0, F::pb(3), 0, st);
-    else
-      rc = pc_dw<8>(n, gz, hp, 128, nullptr, 0, 128, ws, g_flat, F::pw(i), 128,
-                    0, F::pb(i), 0, st);
-    if (rc == XRD_OK)
-      rc = pc_dw<2>(n, op.gh + (int64_t)i * n * 128, save_c, 32, nullptr, 0, 32,
-                    ws, g_flat, F::fcw(i), 32, 0, F::fcb(i), 0, st);
+  static bool ready = false;
+  if (!ready) {
+    rc = pc_attr(pc_dw_kernel, kDwLds);
+    if (rc != XRD_OK) return rc;
+    ready = true;
   }
-  // output layer and F_theta's second layer: the 128-wide operand is G, the
-  // product comes out transposed
-  if (rc == XRD_OK)
-    rc = pc_dw<1>(n, save_h + 4 * n * 128, op.go, 4, nullptr, 0, 3, ws, g_flat,
-                  F::OW, 128, 1, F::OB, 1, st);
-  if (rc == XRD_OK)
-    rc = pc_dw<2>(8 * n, op.fh, op.fgy, 32, nullptr, 0, 32, ws, g_flat, F::W2,
-                  128, 1, F::B2, 1, st);
-  if (rc == XRD_OK)
-    rc = pc_dw<4>(8 * n, op.fga, op.fx, 52, nullptr, 0, 52, ws, g_flat, F::W1,
-                  52, 0, F::B1, 0, st);
-  if (rc != XRD_OK) return rc;
+  DwPlan plan;
+  dw_plan(n, save_c, save_h, ops, plan);
+  hipLaunchKernelGGL(pc_dw_kernel, dim3(plan.blocks), dim3(DW_WAVES * 64),
+                     kDwLds, st, plan.jobs, workspace);
+  hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3(plan.red_blocks), dim3(256), 0,
+                     st, plan.jobs, workspace, g_flat);
   return check_launch("xrd_point_color_bwd (weights)");
 }
 
