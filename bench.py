@@ -848,8 +848,8 @@ def run_pointslam(args, dev, world=1):
     frame (every frame for the first 20) 300 mapping it x 5000 rays, 5 samples
     per ray, 8-NN feature interpolation from the neural point cloud.  Random-
     initialised decoders (the pretrained checkpoint is not available offline).
-    Functional end-to-end path on the HIP grid kNN (the rest of the chain is
-    torch ops: the fused render kernels are the next row to build)."""
+    kNN search, geometry path and colour path on the HIP kernels; the
+    iterations of a stage run as captured hipGraphs (fixed-shape batches)."""
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.configs.input_config import (cadence,
@@ -863,6 +863,7 @@ def run_pointslam(args, dev, world=1):
     if args.first_iters is not None:
         cfg.mapping_first_n_iters = args.first_iters
     algo = cfg.setup(camera=cam, device=str(dev))
+    algo.use_graphs = not args.no_graphs
     _setup_dist(dev, world)
     data = _NumpyImages(SyntheticRoom(
         CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,

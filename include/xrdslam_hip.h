@@ -145,10 +145,11 @@ int xrd_point_geo_bwd(int64_t n_points, const float* points,
  * slam/model_components/decoder_pointslam.py:276-291,408-542.
  *   flat parameter order (xrd_point_color_flat_len floats; the first
  *   xrd_point_color_grad_len are trainable and form the flat gradient):
- *     mlp_col_neighbor.linear1.weight [128,52], .bias, linear2.weight [32,128],
- *     .bias, embedder_rel_pos._B [3,10], pts_linears.{0..4}.weight/.bias
- *     ([128,40], [128,128] x2, [128,168], [128,128]), fc_c.{0..4}.weight
- *     [128,32]/.bias, output_linear.weight [3,128], .bias, embedder._B [3,20].
+ *     embedder_rel_pos._B [3,10], mlp_col_neighbor.linear1.weight [128,52],
+ *     .bias, linear2.weight [32,128], .bias, fc_c.{0..4}.weight [128,32]/.bias,
+ *     pts_linears.{0..4}.weight/.bias ([128,40], [128,128] x2, [128,168],
+ *     [128,128]), output_linear.weight [3,128], .bias  (= the order of
+ *     MLP_color.parameters()), then embedder._B [3,20].
  *   packed = flat gathered through xrd_point_color_pack_index (int32
  *   [xrd_point_color_pack_len], -1 = 0.0).
  * fwd: rgb [n,3]; save_c [n,32], save_h [5,n,128], save_y [n,8,32] (the

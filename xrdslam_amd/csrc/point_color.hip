@@ -30,7 +30,10 @@ namespace xrd {
 namespace {
 
 constexpr int kPcBlocks = 256;    // persistent blocks
-constexpr float kBeta = 100.f, kThresh = 20.f;
+#ifndef XRD_PC_VAR
+#define XRD_PC_VAR 0
+#endif
+constexpr float kBeta = 100.f;
 constexpr int kTailLen = PcPack::FWD_LEN - PcPack::OW + 32;
 constexpr int kPcLds = (PcPack::STAGE_MAX + kTailLen) * (int)sizeof(float);
 constexpr float kTwoPi = 6.283185307179586f;
@@ -40,6 +43,9 @@ constexpr float kTwoPi = 6.283185307179586f;
 // latency-bound with 128..512 threads and ~100 KB per stage)
 __device__ __forceinline__ void pc_copy(float* __restrict__ wl,
                                         const float* __restrict__ src, int n) {
+#if XRD_PC_VAR == 1
+  return;
+#endif
   constexpr int U = 8;
   const int step = blockDim.x * 4;
   int i = threadIdx.x * 4;
@@ -74,10 +80,27 @@ __device__ __forceinline__ T pick8(const T (&v)[8], int k) {
   return r;
 }
 
-// torch.nn.Softplus(beta=100): x if beta x > 20 else log1p(exp(beta x)) / beta
+// torch.nn.Softplus(beta=100): x if beta x > 20 else log1p(exp(beta x)) / beta,
+// evaluated in the stable form max(x, 0) + log1p(exp(-|beta x|)) / beta on the
+// hardware exp2 / log2 (1 ulp each; the two forms differ by < 1e-8 absolute,
+// the library expf / log1pf pair costs ~10x the instructions and made the
+// kernel VALU-bound)
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 __device__ __forceinline__ float softplus100(float x) {
-  const float bx = kBeta * x;
-  return bx > kThresh ? x : log1pf(expf(bx)) / kBeta;
+#if XRD_PC_VAR == 2
+  return fmaxf(x, 0.f);
+#endif
+  const float t = __builtin_amdgcn_exp2f(-fabsf(kBeta * x) * kLog2e);
+  return fmaf(__builtin_amdgcn_logf(1.f + t), kLn2 / kBeta, fmaxf(x, 0.f));
+}
+// d softplus / dx = sigmoid(beta x)
+__device__ __forceinline__ float softplus100_grad(float x) {
+  return __builtin_amdgcn_rcpf(
+      1.f + __builtin_amdgcn_exp2f(-kBeta * kLog2e * x));
+}
+// the same from the VALUE y = softplus(x): 1 - exp(-beta y)
+__device__ __forceinline__ float softplus100_grad_of_value(float y) {
+  return 1.f - __builtin_amdgcn_exp2f(-kBeta * kLog2e * fmaxf(y, 0.f));
 }
 
 __device__ __forceinline__ f32x4 softplus4(const f32x4 a) {
@@ -87,27 +110,51 @@ __device__ __forceinline__ f32x4 softplus4(const f32x4 a) {
 
 // acc[jt] += frag(jt, s0 + s) * in(s) for s < KS, JT output tiles, fragments
 // laid out (jt * KTOT + s); in: D-layout registers (dense_h) or one float per
-// K-step (dense_e)
+// K-step (dense_e).
+// A stage spans up to 123 KB of LDS while a ds_read reaches 64 KB beyond its
+// address register; left alone the compiler materialises one address VGPR per
+// read of the far part, runs out of registers and issues read - wait - MFMA
+// one at a time.  Two opaque lane offsets (tiles 0..3 / 4..7) keep every read
+// an immediate-offset read.
+extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+
+template <int JT, int KTOT>
+struct FragBase {
+  int lo, hi;
+  __device__ __forceinline__ FragBase(const float* w, int lane) {
+    lo = (int)(w - reinterpret_cast<const float*>(pc_smem)) + lane;
+    hi = lo + (JT > 4 ? 4 * KTOT * 64 : 0);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+  }
+  __device__ __forceinline__ float operator()(int jt, int s) const {
+    const float* base = reinterpret_cast<const float*>(pc_smem);
+    return JT > 4 && jt >= 4 ? base[hi + ((jt - 4) * KTOT + s) * 64]
+                             : base[lo + (jt * KTOT + s) * 64];
+  }
+};
+
 template <int JT, int KTOT, int KS>
 __device__ __forceinline__ void dense_h(const float* __restrict__ w, int lane,
                                         int s0, const f32x4* in, f32x4* acc) {
+  const FragBase<JT, KTOT> frag(w, lane);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const float v = in[s >> 2][s & 3];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
-      acc[jt] = XRD_MFMA4(w[(jt * KTOT + s0 + s) * 64 + lane], v, acc[jt]);
+      acc[jt] = XRD_MFMA4(frag(jt, s0 + s), v, acc[jt]);
   }
 }
 template <int JT, int KTOT, int KS>
 __device__ __forceinline__ void dense_e(const float* __restrict__ w, int lane,
                                         int s0, const float* in, f32x4* acc) {
+  const FragBase<JT, KTOT> frag(w, lane);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const float v = in[s];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
-      acc[jt] = XRD_MFMA4(w[(jt * KTOT + s0 + s) * 64 + lane], v, acc[jt]);
+      acc[jt] = XRD_MFMA4(frag(jt, s0 + s), v, acc[jt]);
   }
 }
 
@@ -170,8 +217,7 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_fwd_kernel(
     float* __restrict__ save_c, float* __restrict__ save_h,
     float* __restrict__ save_y) {
   using K = PcPack;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* wl = reinterpret_cast<float*>(smem_raw);
+  float* wl = reinterpret_cast<float*>(pc_smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = lane >> 4, li = lane & 15;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -339,8 +385,7 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_bwd_kernel(
     float* __restrict__ g_feats, float* __restrict__ g_flat,
     float* __restrict__ ops_base) {
   using K = PcPack;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* wl = reinterpret_cast<float*>(smem_raw);
+  float* wl = reinterpret_cast<float*>(pc_smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = lane >> 4, li = lane & 15;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -436,8 +481,7 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_bwd_kernel(
         for (int jt = 0; jt < 8; ++jt)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const float sp = fmaxf(h[jt][t] - cc[jt][t], 0.f);
-            g_h[jt][t] *= 1.f - expf(-kBeta * sp);
+            g_h[jt][t] *= softplus100_grad_of_value(h[jt][t] - cc[jt][t]);
           }
       }
       if (want_w && valid)
@@ -535,8 +579,7 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_bwd_kernel(
         for (int jt = 0; jt < 8; ++jt)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const float bx = kBeta * a[jt][t];
-            sp[jt][t] = bx > kThresh ? 1.f : 1.f / (1.f + expf(-bx));
+            sp[jt][t] = softplus100_grad(a[jt][t]);
             a[jt][t] = softplus100(a[jt][t]);
           }
         if (want_w && valid) save_rows<8>(ops.fh, 128, row, q, a);

@@ -24,12 +24,17 @@
 namespace xrd {
 
 struct PcFlat {
-  static constexpr int W1 = 0;                     // [128][52]
+  // = the order of MLP_color.parameters(): back-to-back parameters let Adam
+  // step the decoder with one launch on the flat gradient
+  static constexpr int BREL = 0;                   // [3][10]
+  static constexpr int W1 = BREL + 30;             // [128][52]
   static constexpr int B1 = W1 + 128 * 52;
   static constexpr int W2 = B1 + 128;              // [32][128]
   static constexpr int B2 = W2 + 32 * 128;
-  static constexpr int BREL = B2 + 32;             // [3][10]
-  static constexpr int P0W = BREL + 30;            // [128][40]
+  static constexpr int FC = B2 + 32;               // 5 x ([128][32] + [128])
+  static constexpr int fcw(int i) { return FC + i * (128 * 32 + 128); }
+  static constexpr int fcb(int i) { return fcw(i) + 128 * 32; }
+  static constexpr int P0W = FC + 5 * (128 * 32 + 128);   // [128][40]
   static constexpr int P0B = P0W + 128 * 40;
   static constexpr int P1W = P0B + 128;            // [128][128]
   static constexpr int P1B = P1W + 128 * 128;
@@ -39,10 +44,7 @@ struct PcFlat {
   static constexpr int P3B = P3W + 128 * 168;
   static constexpr int P4W = P3B + 128;
   static constexpr int P4B = P4W + 128 * 128;
-  static constexpr int FC = P4B + 128;             // 5 x ([128][32] + [128])
-  static constexpr int fcw(int i) { return FC + i * (128 * 32 + 128); }
-  static constexpr int fcb(int i) { return fcw(i) + 128 * 32; }
-  static constexpr int OW = FC + 5 * (128 * 32 + 128);   // [3][128]
+  static constexpr int OW = P4B + 128;             // [3][128]
   static constexpr int OB = OW + 3 * 128;
   static constexpr int BEMB = OB + 3;              // [3][20] (not a parameter)
   static constexpr int LEN = BEMB + 60;

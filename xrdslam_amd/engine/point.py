@@ -140,15 +140,44 @@ def color_supported(dec) -> bool:
 
 
 def color_params(dec):
-    """the trainable tensors in the kernels' flat order"""
+    """the trainable tensors in the kernels' flat order (= the order of
+    ``dec.parameters()``: Adam steps the re-seated decoder with one launch)"""
     f = dec.mlp_col_neighbor
-    out = [f.linear1.weight, f.linear1.bias, f.linear2.weight, f.linear2.bias,
-           dec.embedder_rel_pos._B]
-    for layer in dec.pts_linears:
-        out += [layer.weight, layer.bias]
+    out = [dec.embedder_rel_pos._B, f.linear1.weight, f.linear1.bias,
+           f.linear2.weight, f.linear2.bias]
     for layer in dec.fc_c:
         out += [layer.weight, layer.bias]
+    for layer in dec.pts_linears:
+        out += [layer.weight, layer.bias]
     return out + [dec.output_linear.weight, dec.output_linear.bias]
+
+
+def color_flat(dec, device):
+    """the decoder as ONE flat buffer [parameters | embedder._B]: the
+    parameters are re-seated as back-to-back views of it (values kept,
+    idempotent), so packing is one gather of current values and the flat
+    gradient of the kernels maps onto the parameters as views"""
+    params = color_params(dec)
+    p0 = params[0]
+    flat = getattr(dec, '_xrd_flat', None)
+    ok = flat is not None and flat.device == torch.device(device)
+    nxt = flat.data_ptr() if ok else 0
+    for p in params:
+        ok = ok and p.data_ptr() == nxt and p.is_contiguous()
+        nxt += 4 * p.numel()
+    if ok:
+        return flat
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1).float().to(device)
+                          for p in params] +
+                         [dec.embedder._B.detach().reshape(-1).float()
+                          .to(device)])
+        off = 0
+        for p in params:
+            p.data = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+    dec._xrd_flat = flat
+    return flat
 
 
 _COLOR_INDEX = {}
@@ -195,14 +224,17 @@ def _color_scratch(device, n):
 class _ColFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, feats, flat, nbr, n_nb, cloud, radius, radius_all,
-                min_nn, empty):
+                min_nn, empty, *params):
+        # ``params``: the tensors ``flat`` is the storage of (color_flat),
+        # passed so that autograd routes the flat gradient to them
         lib = _lib.lib()
         dev = p.device
         p = p.detach().float().reshape(-1, 3).contiguous()
         n = p.shape[0]
         f = feats.detach().float().contiguous()
         packed = pack_color(flat)
-        need = any(ctx.needs_input_grad[:3])
+        ctx.need_w = any(ctx.needs_input_grad[10:])
+        need = any(ctx.needs_input_grad[:2]) or ctx.need_w
         rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
         save_c = save_h = save_y = None
         if need:
@@ -215,7 +247,8 @@ class _ColFn(torch.autograd.Function):
             _lib.ptr(empty), _lib.ptr(packed), _lib.ptr(rgb),
             _lib.ptr(save_c), _lib.ptr(save_h), _lib.ptr(save_y),
             _lib.stream_ptr(dev)), 'xrd_point_color_fwd')
-        ctx.args = (float(radius_all), int(min_nn), flat.numel())
+        ctx.args = (float(radius_all), int(min_nn), flat.numel(),
+                    [t.shape for t in params])
         ctx.save_for_backward(p, f, nbr, n_nb, cloud, radius, packed, rgb,
                               save_c, save_h, save_y)
         return rgb
@@ -225,17 +258,17 @@ class _ColFn(torch.autograd.Function):
         lib = _lib.lib()
         p, f, nbr, n_nb, cloud, radius, packed, rgb, save_c, save_h, save_y \
             = ctx.saved_tensors
-        radius_all, min_nn, flat_len = ctx.args
+        radius_all, min_nn, flat_len, shapes = ctx.args
         dev = p.device
-        need_p, need_f, need_w = ctx.needs_input_grad[:3]
+        need_p, need_f = ctx.needs_input_grad[:2]
+        need_w = ctx.need_w
         n = p.shape[0]
         g_p = torch.empty_like(p) if need_p else None
         g_f = torch.zeros_like(f) if need_f else None
         g_flat = ops = ws = None
         if need_w:
-            # [0, grad_len) is written by the kernels, the tail (the fixed
-            # embedding matrix) has no gradient
-            g_flat = torch.zeros(flat_len, dtype=torch.float32, device=dev)
+            g_flat = torch.empty(lib.xrd_point_color_grad_len(),
+                                 dtype=torch.float32, device=dev)
             ops, ws = _color_scratch(dev, n)
         _lib.check(lib.xrd_point_color_bwd(
             n, _lib.ptr(p), _lib.ptr(nbr), _lib.ptr(n_nb), _lib.ptr(cloud),
@@ -245,7 +278,13 @@ class _ColFn(torch.autograd.Function):
             _lib.ptr(g_rgb.float().contiguous()), _lib.ptr(g_p),
             _lib.ptr(g_f), _lib.ptr(g_flat), _lib.ptr(ops), _lib.ptr(ws),
             _lib.stream_ptr(dev)), 'xrd_point_color_bwd')
-        return (g_p, g_f, g_flat) + (None, ) * 7
+        g_params = [None] * len(shapes)
+        if need_w:
+            off = 0
+            for k, shp in enumerate(shapes):
+                g_params[k] = g_flat[off:off + shp.numel()].view(shp)
+                off += shp.numel()
+        return (g_p, g_f) + (None, ) * 8 + tuple(g_params)
 
 
 def color(dec, p, neighbors, npc, dynamic_r_query):
@@ -257,9 +296,7 @@ def color(dec, p, neighbors, npc, dynamic_r_query):
     if dec.use_dynamic_radius and dynamic_r_query is not None:
         radius = dynamic_r_query.detach().float().reshape(-1).contiguous()
     empty = dec.empty_feature_fn(dec.c_dim, dev).float().contiguous()
-    flat = torch.cat([t.reshape(-1) for t in color_params(dec)] +
-                     [dec.embedder._B.detach().to(dev).reshape(-1)])
-    return _ColFn.apply(p.reshape(-1, 3), npc.col_feats, flat,
+    return _ColFn.apply(p.reshape(-1, 3), npc.col_feats, color_flat(dec, dev),
                         ids.long().contiguous(), n_nb.int().contiguous(),
                         cloud, radius, float(npc.get_radius_query()),
-                        dec.min_nn_num, empty)
+                        dec.min_nn_num, empty, *color_params(dec))

@@ -15,6 +15,7 @@ import torch
 
 from ...engine import dist as _dist
 from ..common.common import (color_gradient_magnitude, get_rays, get_samples,
+                             masked_lower_median,
                              get_samples_with_pixel_grad)
 from ..models.conv_onet_pointslam import ConvOnet2Config
 from .base_algorithm import Algorithm, AlgorithmConfig
@@ -80,7 +81,11 @@ class PointSLAM(Algorithm):
     def pre_precessing(self, cur_frame, is_mapping):
         cfg = self.config
         depth_np, color_np = cur_frame.depth, cur_frame.rgb
-        c2w, idx = cur_frame.get_pose(), cur_frame.fid
+        # (detached: the map is built from the pose's VALUE; rays that kept
+        # the pose's autograd graph would pin it inside the cloud's
+        # bookkeeping tensors, with its accumulation node bound to this
+        # stream, and break later hipGraph captures of the pose gradient)
+        c2w, idx = cur_frame.get_pose().detach(), cur_frame.fid
         r_add = None
         if cfg.use_dynamic_radius:
             r_add, r_query = self.cal_dynamic_radius(color_np)
@@ -145,17 +150,28 @@ class PointSLAM(Algorithm):
                 n = _dist.state.shard_count(n)
                 gen = _dist.state.shard_generator
         ro, rd, gd, gc, rq = [], [], [], [], []
+        # the per-frame depth filter (depth > 0) and the batch filter below
+        # are applied together, with ONE compaction (one size read-back per
+        # iteration instead of one per frame and tensor); the rays kept and
+        # their order are the reference's (get_samples(depth_filter=True) per
+        # frame, then the ``inside`` selection)
+        grad_sampler = not is_mapping and cfg.tracking_sample_with_color_grad
         for f in optimize_frames:
-            sampler = get_samples_with_pixel_grad \
-                if (not is_mapping and cfg.tracking_sample_with_color_grad) \
+            sampler = get_samples_with_pixel_grad if grad_sampler \
                 else functools.partial(get_samples, frame=f, generator=gen)
+            # keyframe poses only move under bundle adjustment: without it
+            # they are constants of the mapping iteration (no gradient to
+            # compute through the rays, the samples and the neighbour weights)
+            pose = f.get_pose()
+            if is_mapping and not getattr(self, 'bundle_adjust', False):
+                pose = pose.detach()
             o, d, dep, col, i, j = sampler(
-                self.camera, n, f.get_pose(), f.depth, f.rgb, device=dev,
-                Hedge=Hedge, Wedge=Wedge, depth_filter=True,
+                self.camera, n, pose, f.depth, f.rgb, device=dev,
+                Hedge=Hedge, Wedge=Wedge, depth_filter=grad_sampler,
                 return_index=True)
             ro.append(o.float())
             rd.append(d.float())
-            gd.append(dep.float())
+            gd.append(dep.float().reshape(-1))
             gc.append(col.float())
             if cfg.use_dynamic_radius:
                 rq.append(self.dynamic_r_query_allkeyframe[np.array2string(
@@ -163,11 +179,46 @@ class PointSLAM(Algorithm):
         ro, rd, gd, gc = (torch.cat(x) for x in (ro, rd, gd, gc))
         rq = torch.cat(rq) if cfg.use_dynamic_radius else None
         with torch.no_grad():
-            inside = gd <= torch.minimum(10 * gd.median(), 1.2 * torch.max(gd))
-        return {'rays_o': ro[inside], 'rays_d': rd[inside],
-                'target_s': gc[inside], 'target_d': gd[inside],
-                'batch_dynamic_r': rq[inside] if rq is not None else None,
-                'stage': self.stage}
+            valid = gd > 0
+            med = masked_lower_median(gd, valid)
+            top = torch.where(valid, gd,
+                              torch.full_like(gd, float('-inf'))).max()
+            inside = valid & (gd <= torch.minimum(10 * med, 1.2 * top))
+        if getattr(self, 'fixed_shape_batches', False):
+            # captured iterations (hipGraph): every sampled ray stays in the
+            # batch, the selection travels as a mask that the losses apply
+            # (same sums; the deselected rays cost a few % of extra work)
+            return {'rays_o': ro, 'rays_d': rd, 'target_s': gc, 'target_d': gd,
+                    'batch_dynamic_r': rq, 'stage': self.stage,
+                    'ray_valid': inside, 'static_shapes': True}
+        with torch.no_grad():
+            keep = torch.nonzero(inside).reshape(-1)   # the one read-back
+        if keep.numel() != inside.numel():
+            ro, rd, gc, gd = (t.index_select(0, keep) for t in (ro, rd, gc, gd))
+            rq = rq.index_select(0, keep) if rq is not None else None
+        # every ray kept carries a positive sensor depth
+        return {'rays_o': ro, 'rays_d': rd, 'target_s': gc, 'target_d': gd,
+                'batch_dynamic_r': rq, 'stage': self.stage,
+                'depth_positive': True}
+
+    # the cloud (positions, features, search grid) is re-allocated whenever
+    # points are added: graphs live for ONE tracking / mapping call
+    persistent_track_graph = False
+    persistent_map_graph = False
+
+    def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
+        """the stage decides the device work AND the learning rates
+        (PointSLAMScheduler switches at the same iteration)"""
+        saved = getattr(self, 'stage', None)
+        self.set_stage(is_mapping, step, n_iters)
+        key, self.stage = self.stage, saved
+        return key
+
+    def _graphs_ok(self, optimizers, is_mapping):
+        # sharded mapping keeps the eager path (per-rank ray counts differ)
+        if is_mapping and _dist.state.enabled:
+            return False
+        return super()._graphs_ok(optimizers, is_mapping)
 
     def set_stage(self, is_mapping, step, n_iters):
         if not is_mapping:

@@ -23,6 +23,15 @@ def get_rays_from_uv(i, j, c2w, fx, fy, cx, cy, device):
     c2w = c2w.to(device)
     dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)],
                        -1).to(device)
+    if c2w.is_cuda and c2w.requires_grad and c2w.dtype == torch.float32 and \
+            dirs.dim() == 2:
+        # one launch each way (xrd_pose_rays_*) instead of the broadcast
+        # multiply / sum / expand chain and its backward (whose pose-gradient
+        # tail also does not survive hipGraph capture on ROCm 7.2)
+        from ...engine import slam_ops
+        ids = torch.zeros(dirs.shape[0], dtype=torch.int64, device=dirs.device)
+        return slam_ops.PoseRaysFn.apply(c2w.unsqueeze(0),
+                                         dirs.float().contiguous(), ids)
     rays_d = (dirs.reshape(-1, 1, 3) * c2w[:3, :3]).sum(-1)
     rays_o = c2w[:3, -1].expand(rays_d.shape)
     return rays_o, rays_d
@@ -53,6 +62,18 @@ def get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0',
     return cols.float(), rows.float(), d[flat], c[flat]
 
 
+def masked_lower_median(x, valid):
+    """torch.median (the LOWER median) of x[valid] without compaction: sort
+    with the masked-out entries sent to +inf and read entry (count - 1) // 2
+    through a device-side index (no size read-back; NaN for an empty set)"""
+    flat = torch.where(valid, x, torch.full_like(x, float('inf'))).reshape(-1)
+    vals = torch.sort(flat).values
+    cnt = valid.sum()
+    k = torch.clamp((cnt - 1) // 2, min=0)
+    med = vals.gather(0, k.reshape(1)).reshape(())
+    return torch.where(cnt > 0, med, torch.full_like(med, float('nan')))
+
+
 def get_samples(camera, n, c2w, depth, color, device, Hedge=0, Wedge=0,
                 depth_filter=False, return_index=False, depth_limit=None,
                 frame=None, generator=None):
@@ -69,8 +90,11 @@ def get_samples(camera, n, c2w, depth, color, device, Hedge=0, Wedge=0,
         mask = sd > 0
         if depth_limit is not None:
             mask = mask & (sd < depth_limit)
-        rays_o, rays_d, sd, sc = rays_o[mask], rays_d[mask], sd[mask], sc[mask]
-        i, j = i[mask], j[mask]
+        # one compaction index (one size read-back) for all six tensors
+        keep = torch.nonzero(mask).reshape(-1)
+        if keep.numel() != mask.numel():
+            rays_o, rays_d, sd, sc, i, j = (t.index_select(0, keep) for t in (
+                rays_o, rays_d, sd, sc, i, j))
     if return_index:
         return rays_o, rays_d, sd, sc, i.to(torch.int64), j.to(torch.int64)
     return rays_o, rays_d, sd, sc

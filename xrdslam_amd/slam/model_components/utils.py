@@ -53,6 +53,20 @@ def get_sdf_loss(z_vals, target_d, predicted_sdf, truncation, loss_type=None,
     return fs_loss, sdf_loss
 
 
+def _exclusive_cumprod(x, ones):
+    """[1, x0, x0 x1, ...] along the last axis (= cumprod(cat([1, x]))[:, :-1]).
+    For the few samples per ray of Point-SLAM the running product is written
+    out: torch.cumprod's backward reads a flag back to the host (zero check),
+    which a captured hipGraph cannot do; same products in the same order."""
+    S = x.shape[-1]
+    if S > 16:
+        return torch.cumprod(torch.cat([ones, x], -1), dim=-1)[:, :-1]
+    cols = [ones[:, 0]]
+    for k in range(S - 1):
+        cols.append(cols[-1] * x[:, k])
+    return torch.stack(cols, -1)
+
+
 def raw2outputs_nerf_color2(raw, z_vals, rays_d, device='cuda:0', coef=0.1):
     """Point-SLAM compositing (reference: slam/model_components/utils.py:
     247-294): occupancy alpha = sigmoid(coef * logit) (written back into
@@ -62,9 +76,8 @@ def raw2outputs_nerf_color2(raw, z_vals, rays_d, device='cuda:0', coef=0.1):
     raw[..., -1] = torch.sigmoid(coef * raw[..., -1])
     alpha = raw[..., -1]
     ones = torch.ones((alpha.shape[0], 1), device=alpha.device).float()
-    weights = alpha.float() * torch.cumprod(
-        torch.cat([ones, (1. - alpha + 1e-10).float()], -1).float(),
-        dim=-1)[:, :-1]
+    weights = alpha.float() * _exclusive_cumprod(
+        (1. - alpha + 1e-10).float(), ones)
     wsum = torch.sum(weights, dim=-1).unsqueeze(-1) + 1e-10
     rgb_map = torch.sum(weights[..., None] * rgb, -2) / wsum
     depth_map = torch.sum(weights * z_vals, -1) / wsum.squeeze(-1)

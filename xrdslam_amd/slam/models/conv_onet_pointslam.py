@@ -16,6 +16,7 @@ from torch.nn import Parameter
 
 from ..model_components.decoder_pointslam import POINT
 from ..model_components.neural_point_cloud import NeuralPointCloud
+from ..common.common import masked_lower_median
 from ..model_components.utils import raw2outputs_nerf_color2
 from .base_model import Model, ModelConfig
 
@@ -143,7 +144,9 @@ class ConvOnet2(Model):
         out = self.render_batch_ray(
             rays_d=input['rays_d'], rays_o=input['rays_o'],
             stage=input['stage'], gt_depth=input['target_d'],
-            dynamic_r_query=input['batch_dynamic_r'])
+            dynamic_r_query=input['batch_dynamic_r'],
+            depth_positive=bool(input.get('depth_positive', False) or
+                                input.get('static_shapes', False)))
         out['stage'] = input['stage']
         return out
 
@@ -155,26 +158,47 @@ class ConvOnet2(Model):
         depth, color = outputs['depth'], outputs['rgb']
         uncertainty = outputs['uncertainty']
         losses = {}
+        # captured iterations keep the deselected rays in the batch: the
+        # selection arrives as a mask (point_slam.get_model_input)
+        ray_valid = inputs.get('ray_valid')
         if not is_mapping:
             uncertainty = uncertainty.detach()
             nan_mask = (~torch.isnan(depth)) & (~torch.isnan(uncertainty))
             err = torch.abs(target_d - depth)
             tmp = err / torch.sqrt(uncertainty + 1e-10) \
                 if cfg.tracking_handle_dynamic else err
-            mask = (tmp < 10 * tmp.median()) & (target_d > 0) & nan_mask
-            losses['geo_loss'] = torch.clamp(
-                err / torch.sqrt(uncertainty + 1e-10), min=0.0,
-                max=1e3)[mask].sum()
+            if ray_valid is None:
+                med = tmp.median()
+            else:
+                # (torch.median propagates a NaN in its input: so does this)
+                med = masked_lower_median(tmp.detach(), ray_valid)
+                med = torch.where((torch.isnan(tmp) & ray_valid).any(),
+                                  torch.full_like(med, float('nan')), med)
+                nan_mask = nan_mask & ray_valid
+            mask = (tmp < 10 * med) & (target_d > 0) & nan_mask
+            # masked sums without compaction; masked-out entries are replaced
+            # BEFORE the arithmetic so that a NaN there cannot reach the
+            # gradient through 0 * NaN
+            depth_s = torch.where(mask, depth, target_d)
+            unc_s = torch.where(mask, uncertainty, torch.ones_like(uncertainty))
+            losses['geo_loss'] = torch.where(mask, torch.clamp(
+                torch.abs(target_d - depth_s) / torch.sqrt(unc_s + 1e-10),
+                min=0.0, max=1e3), torch.zeros_like(depth)).sum()
             if cfg.tracking_use_color_in_tracking:
+                color_s = torch.where(mask[:, None], color, target_rgb)
                 losses['rgb_loss'] = cfg.tracking_w_color_loss * \
-                    torch.abs(target_rgb - color)[mask].sum()
+                    torch.abs(target_rgb - color_s).sum()
         else:
             m = (target_d > 0) & outputs['valid_ray_mask'] & \
                 (~torch.isnan(depth))
-            losses['geo_loss'] = torch.abs(target_d[m] - depth[m]).sum()
+            if ray_valid is not None:
+                m = m & ray_valid
+            depth_s = torch.where(m, depth, target_d)
+            losses['geo_loss'] = torch.abs(target_d - depth_s).sum()
             if outputs['stage'] == 'color':
+                color_s = torch.where(m[:, None], color, target_rgb)
                 losses['rgb_loss'] = cfg.mapping_w_color_loss * \
-                    torch.abs(target_rgb[m] - color[m]).sum()
+                    torch.abs(target_rgb - color_s).sum()
         return losses
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
@@ -221,8 +245,12 @@ class ConvOnet2(Model):
 
     def render_batch_ray(self, rays_d, rays_o, stage, gt_depth=None,
                          is_tracker=True, dynamic_r_query=None,
-                         exposure_feat=None):
-        """:302-461"""
+                         exposure_feat=None, depth_positive=False):
+        """:302-461.  ``depth_positive``: the caller guarantees gt_depth > 0 for
+        every ray (the optimisation batches are depth-filtered), which spares
+        the size read-back that decides the no-depth branch.  Masks are
+        applied with where / masked_fill instead of boolean indexing (same
+        values, no compaction, no host synchronisation)."""
         cfg, dev = self.config, self.device
         n_rays, S = rays_o.shape[0], cfg.rendering_n_surface
         if gt_depth is not None:
@@ -236,12 +264,12 @@ class ConvOnet2(Model):
             gt_depth = torch.zeros(n_rays, 1, device=dev)
         nonzero = (gt_depth > 0).squeeze(-1)
         near_pcl = torch.ones(n_rays, device=dev).type(torch.bool)
-        d = gt_depth[nonzero].repeat(1, S)
         t = torch.linspace(0.0, 1.0, steps=S, device=dev)
-        z_vals = torch.zeros(gt_depth.shape[0], S, device=dev)
-        z_vals[nonzero, :] = cfg.rendering_near_end_surface * d * (1. - t) + \
+        d = gt_depth.reshape(-1, 1).float()
+        z_vals = cfg.rendering_near_end_surface * d * (1. - t) + \
             cfg.rendering_far_end_surface * d * t
-        if nonzero.sum() < n_rays:
+        # (rays without depth sample at z = 0 either way: near * 0, far * 0)
+        if not depth_positive and nonzero.sum() < n_rays:
             if cfg.rendering_sample_near_pcl:
                 z0, not_near = self.neural_point_cloud.sample_near_pcl(
                     rays_o[~nonzero].detach().clone(),
@@ -265,13 +293,13 @@ class ConvOnet2(Model):
             pts_views_d=views, ray_pts_num=S, dynamic_r_query=dynamic_r_query,
             exposure_feat=exposure_feat)
         with torch.no_grad():
-            raw[torch.nonzero(~point_mask).flatten(), -1] = -100.0
+            raw[:, -1].masked_fill_(~point_mask, -100.0)
         raw = raw.reshape(n_rays, S, -1).to(dev)
         depth, uncertainty, color, _ = raw2outputs_nerf_color2(
             raw, z_vals, rays_d, device=dev,
             coef=cfg.rendering_sigmoid_coef_mapper)
         valid_ray_mask = valid_ray_mask.to(dev) & near_pcl
-        if not cfg.rendering_sample_near_pcl:
-            depth[~nonzero] = 0
+        if not cfg.rendering_sample_near_pcl and not depth_positive:
+            depth = depth.masked_fill(~nonzero, 0.0)
         return {'rgb': color, 'depth': depth, 'uncertainty': uncertainty,
                 'valid_ray_mask': valid_ray_mask}
