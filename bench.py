@@ -877,36 +877,51 @@ def run_pointslam(args, dev, world=1):
                           lazy_start=cad.lazy_start, pose_device=str(dev))
     elapsed = _timed_frames(slam, args, dev, world)
     t_track, t_map = slam.t_track, slam.t_map
-    # the one native kernel of this path: per-launch timing of a further frame
-    from xrdslam_amd.engine import knn as eknn
-    eknn.PROFILE = []
+    # the dominant launch of this path (the colour path's backward with weight
+    # gradients, once per mapping iteration): per-launch timing over a further
+    # frame run EAGERLY (events cannot be read back from inside a captured
+    # graph)
+    from xrdslam_amd.engine import point as epoint
+    algo.use_graphs = False
+    epoint.PROFILE = {}
     slam.step(1 + args.warmup + args.steps)
     torch.cuda.synchronize()
-    prof, eknn.PROFILE = eknn.PROFILE, None
+    prof, epoint.PROFILE = epoint.PROFILE, None
     roofline = None
-    if prof:
-        big = max(m for _, _, m, _ in prof)
-        sel = [(a.elapsed_time(b) * 1e3, m, n) for a, b, m, n in prof
-               if m == big]
-        us = float(np.mean([t for t, _, _ in sel]))
-        n_pts = float(np.mean([n for _, _, n in sel]))
-        # per sample 8 x (8 B id + 12 B position + 128 B + 128 B
-        # features) ~ 2.2 KB gathered downstream of the search; the search
-        # itself reads the 27 neighbouring cells of the query's cell
-        byts = big * 2200.0
+    key = 'color_bwd_w' if prof.get('color_bwd_w') else 'color_bwd'
+    if prof.get(key):
+        # mapping launches (the eager batches differ by a few rays: the
+        # batch filter compacts them), each priced with its own point count
+        top = max(n for _, _, n in prof[key])
+        rows = [(a.elapsed_time(b) * 1e3, n) for a, b, n in prof[key]
+                if n > 0.9 * top]
+        sel = [t for t, _ in rows]
+        us = float(np.mean(sel))
+        big = float(np.mean([n for _, n in rows]))
+        fwd = [a.elapsed_time(b) * 1e3 for a, b, n in prof.get('color_fwd', [])
+               if n > 0.9 * top]
+        # per sample point the colour path multiplies
+        # 8 x (52x128 + 128x32) (F_theta per neighbour) + 128 x (40 + 128 +
+        # 128 + 168 + 128) (trunk) + 5 x 32x128 (feature injections) + 3x128
+        # = 182 656 weights: 365 312 flop forward; the backward computes the
+        # input AND the weight gradient of each product: 730 624 flop
+        flop = 730624.0 * big
         roofline = {
-            'bound': 'hbm', 'achieved': byts / (us * 1e-6) / 1e9,
-            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-            'frac': byts / (us * 1e-6) / HBM_PEAK, 'traffic': None,
-            'kernel': 'knn_search_kernel<8> (exact uniform-grid 8-NN; the '
-                      'only HIP kernel of this path: interpolation, the '
-                      'three MLPs and compositing are torch ops, ~1000 '
-                      'launches per iteration)',
+            'bound': 'mfma', 'achieved': flop / (us * 1e-6) / 1e12,
+            'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+            'frac': flop / (us * 1e-6) / MFMA_F32_PEAK, 'traffic': None,
+            'kernel': 'xrd_point_color_bwd = point_color_bwd_kernel + '
+                      'pc_dw_kernel + pc_dw_reduce_kernel (colour path '
+                      'backward incl. all weight gradients, one call per '
+                      'mapping iteration)',
             'avg_launch_us': us, 'launches': len(sel),
-            'queries_per_launch': big, 'neural_points': n_pts,
-            'algorithmic_bytes_per_query': 2200,
-            'timing_source': 'HIP events around the searches of the frame '
-                             'run right after the timed region'}
+            'points_per_launch': big,
+            'algorithmic_flop_per_point': 730624,
+            'forward_avg_launch_us': float(np.mean(fwd)) if fwd else None,
+            'forward_frac': (365312.0 * big / (float(np.mean(fwd)) * 1e-6) /
+                             MFMA_F32_PEAK) if fwd else None,
+            'timing_source': 'HIP events around the calls of the (eager) '
+                             'frame run right after the timed region'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:

@@ -18,7 +18,7 @@ import torch
 from .. import _lib
 from . import nice as _nice
 
-PROFILE = None   # bench.py: key -> [(start, end)]
+PROFILE = None   # bench.py: key -> [(start event, end event, points)]
 
 
 def supported(dec) -> bool:
@@ -241,12 +241,19 @@ class _ColFn(torch.autograd.Function):
             save_c = torch.empty(n, 32, dtype=torch.float32, device=dev)
             save_h = torch.empty(5, n, 128, dtype=torch.float32, device=dev)
             save_y = torch.empty(n, 8, 32, dtype=torch.float32, device=dev)
+        if PROFILE is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.xrd_point_color_fwd(
             n, _lib.ptr(p), _lib.ptr(nbr), _lib.ptr(n_nb), _lib.ptr(cloud),
             _lib.ptr(f), _lib.ptr(radius), float(radius_all), int(min_nn),
             _lib.ptr(empty), _lib.ptr(packed), _lib.ptr(rgb),
             _lib.ptr(save_c), _lib.ptr(save_h), _lib.ptr(save_y),
             _lib.stream_ptr(dev)), 'xrd_point_color_fwd')
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.setdefault('color_fwd', []).append((e0, e1, n))
         ctx.args = (float(radius_all), int(min_nn), flat.numel(),
                     [t.shape for t in params])
         ctx.save_for_backward(p, f, nbr, n_nb, cloud, radius, packed, rgb,
@@ -270,6 +277,10 @@ class _ColFn(torch.autograd.Function):
             g_flat = torch.empty(lib.xrd_point_color_grad_len(),
                                  dtype=torch.float32, device=dev)
             ops, ws = _color_scratch(dev, n)
+        if PROFILE is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.xrd_point_color_bwd(
             n, _lib.ptr(p), _lib.ptr(nbr), _lib.ptr(n_nb), _lib.ptr(cloud),
             _lib.ptr(f), _lib.ptr(radius), radius_all, min_nn,
@@ -278,6 +289,10 @@ class _ColFn(torch.autograd.Function):
             _lib.ptr(g_rgb.float().contiguous()), _lib.ptr(g_p),
             _lib.ptr(g_f), _lib.ptr(g_flat), _lib.ptr(ops), _lib.ptr(ws),
             _lib.stream_ptr(dev)), 'xrd_point_color_bwd')
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.setdefault('color_bwd_w' if need_w else 'color_bwd',
+                               []).append((e0, e1, n))
         g_params = [None] * len(shapes)
         if need_w:
             off = 0
