@@ -184,6 +184,23 @@ int xrd_point_color_bwd(int64_t n_points, const float* points,
                         const float* save_y, const float* g_rgb,
                         float* g_points, float* g_col_feats, float* g_flat,
                         float* ops, float* workspace, xrd_stream_t stream);
+/* Point-SLAM mapping: compositing + mapping loss + their backward in one
+ * launch (raw2outputs_nerf_color2, slam/model_components/utils.py:247-294;
+ * get_loss_dict's mapping branch, slam/models/conv_onet_pointslam.py:190-204).
+ *   raw [n_rays*S,4] = [rgb, occupancy logit] per sample, point_mask [n_rays*S]
+ *   u8 (sample has neighbours; others composite with logit -100), z_vals
+ *   [n_rays,S], target_d [n_rays], target_rgb [n_rays,3] or NULL (geometry
+ *   stage: no colour term), ray_valid [n_rays] u8 or NULL.  A ray counts when
+ *   target_d > 0, at least min_valid_points samples have neighbours, its depth
+ *   is not NaN and ray_valid keeps it.
+ *   -> loss [2] = (sum |target_d - depth|, w_color sum |target_rgb - colour|),
+ *   g_raw [n_rays*S,4] = d (loss[0] + loss[1]) / d raw.  S <= 16. */
+int xrd_point_map_loss(int n_rays, int n_samples, const float* raw,
+                       const uint8_t* point_mask, const float* z_vals,
+                       const float* target_d, const float* target_rgb,
+                       const uint8_t* ray_valid, float sigmoid_coef,
+                       float w_color, int min_valid_points, float* loss,
+                       float* g_raw, xrd_stream_t stream);
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):

@@ -275,3 +275,52 @@ def test_pointslam_captured_iterations_match_eager():
         assert float((pe.cpu() - pg.cpu()).abs().max()) < 2e-2
     assert np.isfinite(s_g.ate_rmse()) and s_g.ate_rmse() < 0.05
     assert abs(s_g.ate_rmse() - s_e.ate_rmse()) < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stage', ['geometry', 'color'])
+def test_fused_map_loss_matches_hooks(stage):
+    """xrd_point_map_loss (compositing + mapping loss + backward, one launch)
+    behind ConvOnet2.fused_map_loss against get_outputs + get_loss_dict on the
+    same batch: loss and the gradients of the map features and the colour
+    decoder; with and without the batch mask of the captured iterations"""
+    algo, slam, data, _ = _pointslam_loop(False, 3)
+    frames = list(algo.keyframe_graph)[-2:]
+    npc = algo.model.neural_point_cloud
+    dec = algo.model.decoder.color_decoder
+    algo.model.get_param_groups()      # requires_grad flags as in mapping
+    for static in (False, True):
+        algo.fixed_shape_batches = static
+        algo.stage = stage
+        gen_state = torch.cuda.get_rng_state('cuda:0')
+        res = []
+        for fused in (False, True):
+            torch.cuda.set_rng_state(gen_state, 'cuda:0')
+            npc.geo_feats.grad = npc.col_feats.grad = None
+            dec.zero_grad(set_to_none=True)
+            inp = algo.get_model_input(frames, True)
+            if static:
+                # deselect a third of the rays through the batch mask
+                inp['ray_valid'] = inp['ray_valid'] & (
+                    torch.arange(inp['ray_valid'].numel(),
+                                 device='cuda:0') % 3 != 0)
+            if fused:
+                loss = algo.model.fused_map_loss(inp)
+            else:
+                out = algo.model(inp)
+                ls = algo.model.get_loss_dict(out, inp, True, stage)
+                loss = sum(ls.values())
+            loss.backward()
+            g = {'loss': loss.detach().reshape(1),
+                 'geo': npc.geo_feats.grad.clone()}
+            if stage == 'color':
+                g['col'] = npc.col_feats.grad.clone()
+                for name, prm in dec.named_parameters():
+                    g['dec:' + name] = prm.grad.clone()
+            res.append(g)
+        ref, got = res
+        assert float(ref['loss']) > 0
+        for k in ref:
+            err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+            assert err < 1e-4, (stage, static, k, err)
+    algo.fixed_shape_batches = False

@@ -64,6 +64,8 @@ _SIGS = {
                             [vp] * 7),
     'xrd_point_color_bwd': (C.c_int, [i64] + [vp] * 6 + [f32, C.c_int] +
                             [vp] * 12),
+    'xrd_point_map_loss': (C.c_int, [C.c_int, C.c_int] + [vp] * 6 +
+                           [f32, f32, C.c_int, vp, vp, vp]),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,

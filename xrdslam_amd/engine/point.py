@@ -315,3 +315,44 @@ def color(dec, p, neighbors, npc, dynamic_r_query):
                         ids.long().contiguous(), n_nb.int().contiguous(),
                         cloud, radius, float(npc.get_radius_query()),
                         dec.min_nn_num, empty, *color_params(dec))
+
+
+# ---- mapping loss (csrc/point_loss.hip) -------------------------------------------
+class _MapLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z_vals, target_d, target_rgb, point_mask, ray_valid,
+                coef, w_color, min_valid):
+        lib = _lib.lib()
+        dev = raw.device
+        n, S = z_vals.shape
+        r = raw.detach().float().contiguous()
+        assert r.shape == (n * S, 4)
+        z = z_vals.detach().float().contiguous()
+        td = target_d.detach().float().reshape(-1).contiguous()
+        tc = None if target_rgb is None else \
+            target_rgb.detach().float().contiguous()
+        pm = point_mask.reshape(-1).to(torch.uint8).contiguous()
+        rv = None if ray_valid is None else \
+            ray_valid.reshape(-1).to(torch.uint8).contiguous()
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        g_raw = torch.empty_like(r)
+        _lib.check(lib.xrd_point_map_loss(
+            n, S, _lib.ptr(r), _lib.ptr(pm), _lib.ptr(z), _lib.ptr(td),
+            _lib.ptr(tc), _lib.ptr(rv), float(coef), float(w_color),
+            int(min_valid), _lib.ptr(loss), _lib.ptr(g_raw),
+            _lib.stream_ptr(dev)), 'xrd_point_map_loss')
+        ctx.save_for_backward(g_raw)
+        return loss[0] + loss[1] if tc is not None else loss[0] + 0.0
+
+    @staticmethod
+    def backward(ctx, g):
+        g_raw, = ctx.saved_tensors
+        return (g_raw * g, ) + (None, ) * 8
+
+
+def map_loss(raw, z_vals, target_d, target_rgb, point_mask, ray_valid, coef,
+             w_color, min_valid):
+    """compositing + Point-SLAM's mapping loss (sum |d - depth| + w_color sum
+    |rgb - colour| over the rays that count), gradient w.r.t. ``raw``"""
+    return _MapLossFn.apply(raw, z_vals, target_d, target_rgb, point_mask,
+                            ray_valid, coef, w_color, min_valid)

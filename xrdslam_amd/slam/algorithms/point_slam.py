@@ -205,6 +205,8 @@ class PointSLAM(Algorithm):
     # points are added: graphs live for ONE tracking / mapping call
     persistent_track_graph = False
     persistent_map_graph = False
+    # mapping: compositing + loss + backward as one launch (engine/point.py)
+    fused_map_loss = True
 
     def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
         """the stage decides the device work AND the learning rates
@@ -232,6 +234,11 @@ class PointSLAM(Algorithm):
                  coarse=False):
         self.set_stage(is_mapping, step, n_iters)
         inp = self.get_model_input(optimize_frames, is_mapping)
+        if is_mapping and self.fused_map_loss and \
+                torch.device(self._dev).type == 'cuda' and \
+                (inp.get('depth_positive') or inp.get('static_shapes')) and \
+                not self.model.config.rendering_sample_near_pcl:
+            return self.model.fused_map_loss(inp)
         out = self.model(inp)
         losses = self.model.get_loss_dict(out, inp, is_mapping, self.stage)
         return functools.reduce(torch.add, losses.values())

@@ -201,6 +201,34 @@ class ConvOnet2(Model):
                     torch.abs(target_rgb - color_s).sum()
         return losses
 
+    def fused_map_loss(self, input) -> torch.Tensor:
+        """get_outputs + get_loss_dict of a MAPPING iteration whose rays all
+        carry a sensor depth (or are masked by ``ray_valid``): the decoders as
+        in render_batch_ray, then compositing, the loss and their backward as
+        ONE launch (engine/point.map_loss) instead of ~100 small kernels each
+        way.  Same arithmetic as the modular hooks
+        (tests/test_pointslam_hip.py)."""
+        from ...engine import point as _pt
+        cfg, dev = self.config, self.device
+        rays_o, rays_d = input['rays_o'], input['rays_d']
+        S = cfg.rendering_n_surface
+        d = input['target_d'].reshape(-1, 1).float()
+        t = torch.linspace(0.0, 1.0, steps=S, device=dev)
+        z_vals = cfg.rendering_near_end_surface * d * (1. - t) + \
+            cfg.rendering_far_end_surface * d * t
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        rq = input['batch_dynamic_r']
+        if cfg.use_dynamic_radius:
+            rq = rq.reshape(-1, 1).repeat_interleave(S, dim=0)
+        raw, _, point_mask = self.eval_points(
+            p=pts.reshape(-1, 3), stage=input['stage'], is_tracker=True,
+            ray_pts_num=S, dynamic_r_query=rq)
+        color = input['stage'] == 'color'
+        return _pt.map_loss(
+            raw, z_vals, d, input['target_s'] if color else None, point_mask,
+            input.get('ray_valid'), cfg.rendering_sigmoid_coef_mapper,
+            cfg.mapping_w_color_loss, int(S / 2 + 1))
+
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         cfg = self.config
         dec = []
