@@ -931,7 +931,13 @@ static int pc_attr(Kern kern, int lds) {
 
 // waves per block: a block stages a whole layer per group of 16 PW points, so
 // few points are spread over more, smaller blocks (one block per CU)
-static int pc_waves(int64_t n) { return n >= 32768 ? 8 : n >= 16384 ? 4 : 2; }
+// waves per block (a block stages a whole layer per group of 16 PW points).
+// Measured at 7 500 / 12 000 / 25 000 points (profiles/r02_pointslam_waves.txt):
+// 4 waves beat 2 even when 2 would give twice the blocks; the forward gains
+// from 8 (two waves per SIMD overlap) once 4 would need a second round of the
+// 256 blocks, the register-heavier backward only at several rounds.
+static int pc_waves_fwd(int64_t n) { return n > 16384 ? 8 : 4; }
+static int pc_waves_bwd(int64_t n) { return n > 49152 ? 8 : 4; }
 
 int64_t xrd_point_color_ops_floats(int64_t n_points) {
   return n_points < 0 ? 0 : n_points * kOpsPerPoint;
@@ -1074,11 +1080,8 @@ int xrd_point_color_fwd(int64_t n_points, const float* points,
   return pc_fwd<PW>(n_points, points, neighbors, n_neighbors, cloud,          \
                     col_feats, radius, radius_all, min_nn, empty_feat, packed, \
                     rgb, save_c, save_h, save_y, st)
-  switch (pc_waves(n_points)) {
-    case 8: XRD_PC_FWD(8);
-    case 4: XRD_PC_FWD(4);
-    default: XRD_PC_FWD(2);
-  }
+  if (pc_waves_fwd(n_points) == 8) XRD_PC_FWD(8);
+  XRD_PC_FWD(4);
 #undef XRD_PC_FWD
 }
 
@@ -1112,11 +1115,10 @@ int xrd_point_color_bwd(int64_t n_points, const float* points,
   rc = pc_bwd<PW>(n, points, neighbors, n_neighbors, cloud, col_feats, radius, \
                   radius_all, min_nn, packed, rgb, save_c, save_h, save_y,     \
                   g_rgb, g_points, g_col_feats, g_flat, o, st)
-  switch (pc_waves(n)) {
-    case 8: XRD_PC_BWD(8); break;
-    case 4: XRD_PC_BWD(4); break;
-    default: XRD_PC_BWD(2); break;
-  }
+  if (pc_waves_bwd(n) == 8)
+    XRD_PC_BWD(8);
+  else
+    XRD_PC_BWD(4);
 #undef XRD_PC_BWD
   if (rc != XRD_OK || g_flat == nullptr) return rc;
   static bool ready = false;

@@ -149,13 +149,18 @@ class PointSLAM(Algorithm):
                 # gradients are summed (Optimizers.optimizer_step_all)
                 n = _dist.state.shard_count(n)
                 gen = _dist.state.shard_generator
+        grad_sampler = not is_mapping and cfg.tracking_sample_with_color_grad
+        if self.batched_sampling and not grad_sampler and \
+                torch.device(dev).type == 'cuda':
+            ro, rd, gd, gc, rq = self._sample_window(
+                optimize_frames, n, Hedge, Wedge, gen, is_mapping)
+            return self._select_batch(ro, rd, gd, gc, rq)
         ro, rd, gd, gc, rq = [], [], [], [], []
         # the per-frame depth filter (depth > 0) and the batch filter below
         # are applied together, with ONE compaction (one size read-back per
         # iteration instead of one per frame and tensor); the rays kept and
         # their order are the reference's (get_samples(depth_filter=True) per
         # frame, then the ``inside`` selection)
-        grad_sampler = not is_mapping and cfg.tracking_sample_with_color_grad
         for f in optimize_frames:
             sampler = get_samples_with_pixel_grad if grad_sampler \
                 else functools.partial(get_samples, frame=f, generator=gen)
@@ -178,6 +183,61 @@ class PointSLAM(Algorithm):
                     np.asarray(f.fid))][j, i])
         ro, rd, gd, gc = (torch.cat(x) for x in (ro, rd, gd, gc))
         rq = torch.cat(rq) if cfg.use_dynamic_radius else None
+        return self._select_batch(ro, rd, gd, gc, rq)
+
+    batched_sampling = True   # the window's rays in one launch (CUDA)
+
+    def _sample_window(self, frames, n, Hedge, Wedge, gen, is_mapping):
+        """get_samples of every frame of the window (pixels drawn with
+        replacement inside the crop, OpenGL rays through the frame's pose,
+        sensor depth / colour / query radius of the pixel) as one index draw
+        and ONE launch for all frames (xrd_sample_rays_multi: it also builds
+        the camera matrices from the quaternion poses), instead of ~15 small
+        kernels per frame"""
+        from ...engine import slam_ops
+        from .nice_slam import NiceSLAM
+        cfg, cam, dev = self.config, self.camera, self._dev
+        wcrop = cam.width - 2 * Wedge
+        cnt = (cam.height - 2 * Hedge) * wcrop
+        F = len(frames)
+        idx = torch.randint(cnt, (F, n), device=dev, generator=gen)
+        imgs = [f.device_images(dev) for f in frames]
+        big = 1e30
+        bound6 = (-big, big, -big, big, -big, big)
+        detach = is_mapping and not getattr(self, 'bundle_adjust', False)
+        quat = NiceSLAM._quat_pose_params(frames, dev, detach)
+        if quat is not None:
+            ro, rd, td, tc, _, _ = slam_ops.SampleRaysPosesFn.apply(
+                idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
+                (Hedge, Wedge, wcrop), bound6, quat[0], *quat[1])
+        else:
+            poses = [f.get_pose().detach() if detach else f.get_pose()
+                     for f in frames]
+            c2ws = torch.stack([p.to(dev) for p in poses])
+            ro, rd, td, tc, _, _ = slam_ops.SampleRaysFn.apply(
+                c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
+                (Hedge, Wedge, wcrop), bound6)
+        rq = None
+        if cfg.use_dynamic_radius:
+            rows = Hedge + torch.div(idx, wcrop, rounding_mode='floor')
+            cols = Wedge + idx % wcrop
+            rq = self._radius_stack(frames).gather(
+                1, rows * cam.width + cols).reshape(-1)
+        return ro, rd, td.reshape(-1), tc, rq
+
+    def _radius_stack(self, frames):
+        """[F, H*W] query radii of the window's frames (built once per window:
+        the optimisation loop asks for the same frames every iteration)"""
+        keys = tuple(np.array2string(np.asarray(f.fid)) for f in frames)
+        hit = getattr(self, '_rq_stack', None)
+        if hit is None or hit[0] != keys:
+            maps = [self.dynamic_r_query_allkeyframe[k].reshape(-1)
+                    for k in keys]
+            hit = (keys, torch.stack(maps))
+            self._rq_stack = hit
+        return hit[1]
+
+    def _select_batch(self, ro, rd, gd, gc, rq):
         with torch.no_grad():
             valid = gd > 0
             med = masked_lower_median(gd, valid)
