@@ -1816,6 +1816,13 @@ __global__ __launch_bounds__(8 * 64, 2) void point_geo_fwd_kernel(
   }
 }
 
+// per-wave transposition tile of the feature-gradient scatter: the tail of
+// the staged-fragment region (the 32-wide decoder fills well under half of it)
+constexpr int kGeoTileLen = 16 * 33;
+constexpr int kGeoTile = kWMax - 8 * kGeoTileLen;
+static_assert(MlpPack<32, 1>::LEN - MlpPack<32, 1>::EMB <= kGeoTile,
+              "geometry decoder + scatter tiles fit");
+
 template <bool NEED_DP, bool NEED_DF>
 __global__ __launch_bounds__(8 * 64, 2) void point_geo_bwd_kernel(
     int64_t n, const float* __restrict__ pts, const int64_t* __restrict__ nbr,
@@ -1856,6 +1863,35 @@ __global__ __launch_bounds__(8 * 64, 2) void point_geo_bwd_kernel(
       for (int a = 0; a < 3; ++a) gpos[a] = group4_sum(gp[0][a]);
     }
     // interpolation backward (nothing flows through the random feature)
+    if (NEED_DF) {
+      // feature gradient: the tile's d/dc goes through LDS so that 32
+      // consecutive lanes add the 32 features of ONE neighbour (two 128-byte
+      // rows per atomic instruction instead of 16 rows x 16 bytes)
+      float* T = wl + kGeoTile + wave * kGeoTileLen;   // [16][33]
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T[li * 33 + 4 * q + r] = gc[0][0][r];
+        T[li * 33 + 16 + 4 * q + r] = gc[0][1][r];
+      }
+      wave_lds_sync();
+      const int f = lane & 31, half = lane >> 5;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool live = nb.has && nb.u[k] != 0.f &&
+                          (fmask == nullptr || fmask[nb.id[k]] != 0);
+        const float wk = live ? nb.u[k] / nb.den : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int pt2 = 2 * i + half;   // lane pt2 = (q 0, li pt2)
+          const float ww = __shfl(wk, pt2);
+          const int id2 = __shfl(nb.id[k], pt2);
+          if (ww != 0.f)
+            atomicAdd(g_feats + (int64_t)id2 * 32 + f, ww * T[pt2 * 33 + f]);
+        }
+      }
+      wave_lds_sync();
+    }
     float gw[8];
     float aw = 0.f;
 #pragma unroll
@@ -1873,14 +1909,6 @@ __global__ __launch_bounds__(8 * 64, 2) void point_geo_bwd_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) d += gc[0][0][r] * f0[r] + gc[0][1][r] * f1[r];
           gw[k] = d;
-        }
-        if (NEED_DF) {
-          float* g = g_feats + (int64_t)nb.id[k] * 32 + 4 * q;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(g + r, w * gc[0][0][r]);
-            atomicAdd(g + 16 + r, w * gc[0][1][r]);
-          }
         }
       }
       if (NEED_DP) {

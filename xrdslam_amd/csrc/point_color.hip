@@ -356,7 +356,10 @@ constexpr int64_t kOpsPerPoint = 1280 + 44 + 8 * 340;
 constexpr int kBwdFcOff = PcPack::rlen(3);               // forward FC frag + bias
 constexpr int kBwdTail = kBwdFcOff + 8 * 8 * 64 + 128;   // OW, OB, BEMB
 constexpr int kBwdTailLen = PcPack::FWD_LEN - PcPack::OW;
-constexpr int kBwdLds = (kBwdTail + kBwdTailLen) * (int)sizeof(float);
+constexpr int kTileLen = 16 * 33;                        // scatter tile per wave
+constexpr int kBwdTile = (kBwdTail + kBwdTailLen + 3) / 4 * 4;
+constexpr int kBwdLds = (kBwdTile + 8 * kTileLen) * (int)sizeof(float);
+static_assert(kBwdLds <= 160 * 1024, "backward LDS");
 constexpr int kBwdRfOff = PcPack::FT_LEN;
 static_assert(kBwdRfOff + PcPack::RF_LEN <= kBwdTail, "F_theta stage fits");
 static_assert(PcPack::rlen(3) >= PcPack::rlen(4) &&
@@ -604,13 +607,25 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_bwd_kernel(
         f32x4 g_f[2] = {z4, z4};
         dense_h<2, 32, 32>(wl + kBwdRfOff + (K::W1TF - K::RF), lane, 0, g_a,
                            g_f);
-        if (live) {
+        // through LDS: 32 consecutive lanes add the 32 features of one
+        // neighbour (two 128-byte rows per atomic instruction)
+        float* T = wl + kBwdTile + wave * kTileLen;   // [16][33]
 #pragma unroll
-          for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              atomicAdd(g_feats + id * 32 + 16 * jt + 4 * q + t, g_f[jt][t]);
+        for (int t = 0; t < 4; ++t) {
+          T[li * 33 + 4 * q + t] = g_f[0][t];
+          T[li * 33 + 16 + 4 * q + t] = g_f[1][t];
         }
+        wave_lds_sync();
+        const int idl = live ? (int)id : -1;
+        const int ff = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int pt2 = 2 * i + half;   // lane pt2 = (q 0, li pt2)
+          const int id2 = __shfl(idl, pt2);
+          if (id2 >= 0)
+            atomicAdd(g_feats + (int64_t)id2 * 32 + ff, T[pt2 * 33 + ff]);
+        }
+        wave_lds_sync();
       }
       f32x4 g_er[2] = {z4, z4};
       dense_h<2, 32, 32>(wl + kBwdRfOff + (K::W1TE - K::RF), lane, 0, g_a,
