@@ -201,6 +201,59 @@ int xrd_point_map_loss(int n_rays, int n_samples, const float* raw,
                        const uint8_t* ray_valid, float sigmoid_coef,
                        float w_color, int min_valid_points, float* loss,
                        float* g_raw, xrd_stream_t stream);
+/* Point-SLAM compositing alone (raw2outputs_nerf_color2, utils.py:247-294, with
+ * the no-neighbour override of render_batch_ray, conv_onet_pointslam.py:441):
+ *   rgb [n_rays*S rows, stride rgb_stride >= 3] or NULL, occ [n_rays*S rows,
+ *   stride occ_stride] (interleaved [rgb, occ] rows: rgb = raw, stride 4,
+ *   occ = raw + 3, stride 4), point_mask [n_rays*S] u8 or NULL, z_vals
+ *   [n_rays,S] -> depth [n_rays], var [n_rays], color [n_rays,3].
+ * bwd: g_depth / g_var [n_rays], g_color [n_rays,3] (each may be NULL = 0) ->
+ *   g_rgb (strided like rgb, may be NULL) and g_occ (strided).  S <= 16. */
+int xrd_point_composite_fwd(int n_rays, int n_samples, const float* rgb,
+                            int rgb_stride, const float* occ, int occ_stride,
+                            const uint8_t* point_mask, const float* z_vals,
+                            float sigmoid_coef, float* depth, float* var,
+                            float* color, xrd_stream_t stream);
+int xrd_point_composite_bwd(int n_rays, int n_samples, const float* rgb,
+                            int rgb_stride, const float* occ, int occ_stride,
+                            const uint8_t* point_mask, const float* z_vals,
+                            float sigmoid_coef, const float* g_depth,
+                            const float* g_var, const float* g_color,
+                            float* g_rgb, int g_rgb_stride, float* g_occ,
+                            int g_occ_stride, xrd_stream_t stream);
+/* Point-SLAM render as one call each way (render_batch_ray given the sample
+ * points [n_rays*S,3] and their neighbours, conv_onet_pointslam.py:302-461) =
+ * xrd_point_geo_* -> xrd_point_color_* (col_feats != NULL: colour stage) ->
+ * xrd_point_composite_*.  The per-point buffers (occ [m], has [m] u8,
+ * relu_masks [m,4] u64, rgb [m,3], save_c / save_h / save_y as in
+ * xrd_point_color_fwd; m = n_rays*S) are the caller's and carry the forward to
+ * the backward.  bwd: g_depth / g_var [n_rays], g_color [n_rays,3] (NULL = 0)
+ * -> g_points [m,3] (NULL = not wanted), g_geo_feats / g_col_feats
+ * (ACCUMULATED, NULL = not wanted), g_flat / ops / workspace as in
+ * xrd_point_color_bwd; scratch = xrd_point_render_scratch_floats(m) floats. */
+int64_t xrd_point_render_scratch_floats(int64_t n_points);
+int xrd_point_render_fwd(
+    int n_rays, int n_samples, const float* points, const int64_t* neighbors,
+    const int32_t* n_neighbors, const float* cloud, const float* geo_feats,
+    const uint8_t* feat_mask, const float* col_feats, const float* radius,
+    float radius_all, int min_nn, const float* empty_geo,
+    const float* empty_col, const float* packed_geo, const float* packed_col,
+    const float* z_vals, float sigmoid_coef, float* occ, uint8_t* has,
+    uint64_t* relu_masks, float* rgb, float* save_c, float* save_h,
+    float* save_y, float* depth, float* var, float* color,
+    xrd_stream_t stream);
+int xrd_point_render_bwd(
+    int n_rays, int n_samples, const float* points, const int64_t* neighbors,
+    const int32_t* n_neighbors, const float* cloud, const float* geo_feats,
+    const uint8_t* feat_mask, const float* col_feats, const float* radius,
+    float radius_all, int min_nn, const float* empty_geo,
+    const float* packed_geo, const float* packed_col, const float* z_vals,
+    float sigmoid_coef, const float* occ, const uint8_t* has,
+    const uint64_t* relu_masks, const float* rgb, const float* save_c,
+    const float* save_h, const float* save_y, const float* g_depth,
+    const float* g_var, const float* g_color, float* scratch, float* g_points,
+    float* g_geo_feats, float* g_col_feats, float* g_flat, float* ops,
+    float* workspace, xrd_stream_t stream);
 int64_t xrd_nice_coarse_ws_floats(const xrd_nice_scene* scene);
 /* Backward of the above.  g_depth,g_var [n] f64, g_rgb [n,3] f32 (any may be
  * NULL = zero).  Requested gradients (each may be NULL = not needed):

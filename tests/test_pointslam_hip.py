@@ -325,3 +325,138 @@ def test_fused_map_loss_matches_hooks(stage):
             err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
             assert err < 1e-4, (stage, static, k, err)
     algo.fixed_shape_batches = False
+
+
+@pytest.mark.gpu
+def test_composite_matches_raw2outputs():
+    """xrd_point_composite_fwd / _bwd against raw2outputs_nerf_color2 (with
+    the -100 override for samples without neighbours): depth, variance, colour
+    and d/d raw under random upstream gradients (incl. the variance's)"""
+    from xrdslam_amd.engine import point as ep
+    from xrdslam_amd.slam.model_components.utils import \
+        raw2outputs_nerf_color2
+    dev = 'cuda:0'
+    g = torch.Generator(device=dev).manual_seed(3)
+    n, S = 3001, 5
+    raw0 = torch.randn(n * S, 4, device=dev, generator=g)
+    raw0[:, 3] *= 30.0
+    raw0[:, :3] = torch.rand(n * S, 3, device=dev, generator=g)
+    z = (0.5 + torch.rand(n, 1, device=dev, generator=g)) * \
+        torch.linspace(0.9, 1.1, S, device=dev)
+    pm = torch.rand(n * S, device=dev, generator=g) > 0.15
+    ups = [torch.randn(n, device=dev, generator=g),
+           torch.randn(n, device=dev, generator=g),
+           torch.randn(n, 3, device=dev, generator=g)]
+
+    def run(fused):
+        raw = raw0.clone().requires_grad_(True)
+        if fused:
+            d, v, c = ep.composite(raw, z, pm, 0.1)
+        else:
+            r = raw * 1.0
+            with torch.no_grad():
+                r[:, -1].masked_fill_(~pm, -100.0)
+            d, v, c, _ = raw2outputs_nerf_color2(r.reshape(n, S, 4), z, None,
+                                                 device=dev, coef=0.1)
+        ((d * ups[0]).sum() + (v * ups[1]).sum() + (c * ups[2]).sum()
+         ).backward()
+        return {'depth': d.detach(), 'var': v.detach(), 'color': c.detach(),
+                'g_raw': raw.grad.clone()}
+    ref, got = run(False), run(True)
+    for k in ref:
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-4, (k, err)
+
+
+@pytest.mark.gpu
+def test_point_render_chain_through_the_abi():
+    """xrd_point_render_fwd / _bwd (geometry decoder -> colour decoder ->
+    compositing as ONE C call each way, caller-owned buffers) against the
+    module path (MLP_geometry / MLP_color on their fused kernels +
+    engine.point.composite): per-ray outputs and the gradients of the
+    positions, both feature sets and the colour decoder"""
+    import ctypes as C
+    from xrdslam_amd import _lib
+    from xrdslam_amd.engine import point as ep
+    from xrdslam_amd.slam.model_components.decoder_pointslam import \
+        MLP_geometry
+    dev = 'cuda:0'
+    S = 5
+    dec, npc, q, radius, _ = _color_case(dev, n=S * 400)
+    torch.manual_seed(1)
+    geo = MLP_geometry(use_dynamic_radius=True,
+                       pointcloud_nn_weighting='distance',
+                       pointcloud_min_nn_num=2, rendering_n_surface=S,
+                       c_dim=32, hidden_size=32, n_blocks=5,
+                       skips=[2]).to(dev)
+    geo.requires_grad_(False)
+    empty_g = (torch.randn(32) * 0.01).to(dev)
+    geo.empty_feature_fn = lambda c, d: empty_g
+    N = npc.col_feats.shape[0]
+    g0 = torch.Generator().manual_seed(5)
+    npc.geo_feats = torch.nn.Parameter(
+        (torch.randn(N, 32, generator=g0) * 0.3).to(dev))
+    npc.frustum_mask = (torch.rand(N, 1, generator=g0) < 0.8).to(dev)
+    npc.get_geo_feats = lambda: npc.geo_feats * npc.frustum_mask
+    m = q.shape[0]
+    n = m // S
+    z = ((0.5 + torch.rand(n, 1, generator=g0)) *
+         torch.linspace(0.9, 1.1, S)).to(dev)
+    ups = [torch.randn(n, generator=g0).to(dev),
+           torch.randn(n, generator=g0).to(dev),
+           torch.randn(n, 3, generator=g0).to(dev)]
+    p = q.clone().to(dev).requires_grad_(True)
+    nb = npc.find_neighbors_faiss(p.detach(), dynamic_radius=radius)
+    # ---- module path ------------------------------------------------------------
+    occ, _, has = geo(p.unsqueeze(0), npc, pts_num=S, is_tracker=True,
+                      dynamic_r_query=radius, neighbors=nb)
+    rgb = dec(p.unsqueeze(0), npc, is_tracker=True, dynamic_r_query=radius,
+              neighbors=nb)
+    raw = torch.cat([rgb, occ.unsqueeze(-1)], -1)
+    d, v, c = ep.composite(raw, z, has, 0.1)
+    ((d * ups[0]).sum() + (v * ups[1]).sum() + (c * ups[2]).sum()).backward()
+    ref = {'depth': d.detach(), 'var': v.detach(), 'color': c.detach(),
+           'g_p': p.grad.clone(), 'g_geo': npc.geo_feats.grad.clone(),
+           'g_col': npc.col_feats.grad.clone(),
+           'g_flat': torch.cat([t.grad.reshape(-1)
+                                for t in ep.color_params(dec)])}
+    # ---- one C call each way --------------------------------------------------------
+    lib = _lib.lib()
+    P, st = _lib.ptr, _lib.stream_ptr(torch.device(dev))
+
+    def f32(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+    pts = p.detach().contiguous()
+    ids, n_nb = nb[1].long().contiguous(), nb[2].int().contiguous()
+    cloud = npc.cloud_tensor(dev).float().contiguous()
+    fmask = npc.frustum_mask.reshape(-1).to(torch.uint8).contiguous()
+    gf, cf = npc.geo_feats.detach(), npc.col_feats.detach()
+    packed_g = ep.pack(geo, dev)
+    packed_c = ep.pack_color(ep.color_flat(dec, dev))
+    empty_c = dec.empty_feature_fn(32, dev).float().contiguous()
+    o_occ, o_has = f32(m), torch.empty(m, dtype=torch.uint8, device=dev)
+    masks = torch.empty(m, 4, dtype=torch.int64, device=dev)
+    o_rgb, sc, sh, sy = f32(m, 3), f32(m, 32), f32(5, m, 128), f32(m, 8, 32)
+    o_d, o_v, o_c = f32(n), f32(n), f32(n, 3)
+    _lib.check(lib.xrd_point_render_fwd(
+        n, S, P(pts), P(ids), P(n_nb), P(cloud), P(gf), P(fmask), P(cf),
+        P(radius), 0.08, 2, P(empty_g), P(empty_c), P(packed_g), P(packed_c),
+        P(z), 0.1, P(o_occ), P(o_has), P(masks), P(o_rgb), P(sc), P(sh),
+        P(sy), P(o_d), P(o_v), P(o_c), st), 'xrd_point_render_fwd')
+    scratch = f32(lib.xrd_point_render_scratch_floats(m))
+    g_p, g_geo, g_col = f32(m, 3), torch.zeros_like(gf), torch.zeros_like(cf)
+    g_flat = f32(lib.xrd_point_color_grad_len())
+    ops = f32(lib.xrd_point_color_ops_floats(m))
+    ws = f32(lib.xrd_point_color_ws_floats())
+    _lib.check(lib.xrd_point_render_bwd(
+        n, S, P(pts), P(ids), P(n_nb), P(cloud), P(gf), P(fmask), P(cf),
+        P(radius), 0.08, 2, P(empty_g), P(packed_g), P(packed_c), P(z), 0.1,
+        P(o_occ), P(o_has), P(masks), P(o_rgb), P(sc), P(sh), P(sy),
+        P(ups[0]), P(ups[1]), P(ups[2].contiguous()), P(scratch), P(g_p),
+        P(g_geo), P(g_col), P(g_flat), P(ops), P(ws), st),
+        'xrd_point_render_bwd')
+    got = {'depth': o_d, 'var': o_v, 'color': o_c, 'g_p': g_p, 'g_geo': g_geo,
+           'g_col': g_col, 'g_flat': g_flat}
+    for k in ref:
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-4, (k, err)

@@ -66,6 +66,17 @@ _SIGS = {
                             [vp] * 12),
     'xrd_point_map_loss': (C.c_int, [C.c_int, C.c_int] + [vp] * 6 +
                            [f32, f32, C.c_int, vp, vp, vp]),
+    'xrd_point_composite_fwd': (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp,
+                                          C.c_int, vp, vp, f32, vp, vp, vp,
+                                          vp]),
+    'xrd_point_composite_bwd': (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp,
+                                          C.c_int, vp, vp, f32, vp, vp, vp,
+                                          vp, C.c_int, vp, C.c_int, vp]),
+    'xrd_point_render_scratch_floats': (i64, [i64]),
+    'xrd_point_render_fwd': (C.c_int, [C.c_int, C.c_int] + [vp] * 8 +
+                             [f32, C.c_int] + [vp] * 5 + [f32] + [vp] * 11),
+    'xrd_point_render_bwd': (C.c_int, [C.c_int, C.c_int] + [vp] * 8 +
+                             [f32, C.c_int] + [vp] * 4 + [f32] + [vp] * 18),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,

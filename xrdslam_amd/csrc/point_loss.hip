@@ -135,3 +135,268 @@ extern "C" int xrd_point_map_loss(int n_rays, int n_samples, const float* raw,
                      w_color, min_valid_points, loss, g_raw);
   return check_launch("xrd_point_map_loss");
 }
+
+// ---- compositing alone (tracking, render_img, and the generic backward) ------------
+// raw2outputs_nerf_color2 (slam/model_components/utils.py:247-294) with the
+// no-neighbour override of render_batch_ray (conv_onet_pointslam.py:441):
+//   depth = sum w z / W, colour = sum w rgb / W, var = sum w (z - depth)^2.
+// rgb / occ are addressed with a stride so that both the interleaved
+// [rgb, occ] rows of the plugin path and separate kernel outputs fit.
+namespace xrd {
+namespace {
+
+struct RayW {
+  float alpha[kMaxS], T[kMaxS], w[kMaxS], z[kMaxS];
+  float W, depth;
+};
+
+__device__ __forceinline__ void ray_weights(int ray, int S,
+                                            const float* __restrict__ occ,
+                                            int occ_stride,
+                                            const uint8_t* __restrict__ pm,
+                                            const float* __restrict__ z_vals,
+                                            float coef, RayW& r) {
+  float run = 1.f, wsum = 0.f, A = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const bool has = pm == nullptr || pm[ray * S + s] != 0;
+    const float o = has ? occ[(int64_t)(ray * S + s) * occ_stride] : -100.f;
+    r.alpha[s] = 1.f / (1.f + expf(-(coef * o)));
+    r.T[s] = run;
+    r.w[s] = r.alpha[s] * run;
+    run = run * (1.f - r.alpha[s] + 1e-10f);
+    wsum += r.w[s];
+    r.z[s] = z_vals[ray * S + s];
+  }
+  r.W = wsum + 1e-10f;
+  for (int s = 0; s < S; ++s) A += r.w[s] * r.z[s];
+  r.depth = A / r.W;
+}
+
+__global__ __launch_bounds__(256) void point_composite_fwd_kernel(
+    int n, int S, const float* __restrict__ rgb, int rgb_stride,
+    const float* __restrict__ occ, int occ_stride,
+    const uint8_t* __restrict__ pm, const float* __restrict__ z_vals,
+    float coef, float* __restrict__ depth, float* __restrict__ var,
+    float* __restrict__ color) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n) return;
+  RayW r;
+  ray_weights(ray, S, occ, occ_stride, pm, z_vals, coef, r);
+  depth[ray] = r.depth;
+  float v = 0.f, col[3] = {0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const float t = r.z[s] - r.depth;
+    v += r.w[s] * t * t;
+    if (rgb != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        col[c] += r.w[s] * rgb[(int64_t)(ray * S + s) * rgb_stride + c];
+    }
+  }
+  var[ray] = v;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) color[ray * 3 + c] = col[c] / r.W;
+}
+
+__global__ __launch_bounds__(256) void point_composite_bwd_kernel(
+    int n, int S, const float* __restrict__ rgb, int rgb_stride,
+    const float* __restrict__ occ, int occ_stride,
+    const uint8_t* __restrict__ pm, const float* __restrict__ z_vals,
+    float coef, const float* __restrict__ g_depth,
+    const float* __restrict__ g_var, const float* __restrict__ g_color,
+    float* __restrict__ g_rgb, int g_rgb_stride, float* __restrict__ g_occ,
+    int g_occ_stride) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n) return;
+  RayW r;
+  ray_weights(ray, S, occ, occ_stride, pm, z_vals, coef, r);
+  const float gd = g_depth ? g_depth[ray] : 0.f;
+  const float gv = g_var ? g_var[ray] : 0.f;
+  float gc[3] = {0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
+  const bool color = rgb != nullptr && g_color != nullptr;
+  float S1 = 0.f;   // sum w (z - depth): d var / d depth = -2 S1
+  for (int s = 0; s < S; ++s) {
+    S1 += r.w[s] * (r.z[s] - r.depth);
+    if (color) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        col[c] += r.w[s] * rgb[(int64_t)(ray * S + s) * rgb_stride + c];
+    }
+  }
+  if (color) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      col[c] /= r.W;
+      gc[c] = g_color[ray * 3 + c];
+    }
+  }
+  const float gdep = gd - 2.f * gv * S1;   // total gradient reaching depth
+  float tail = 0.f;
+  for (int s = S - 1; s >= 0; --s) {
+    const float t = r.z[s] - r.depth;
+    float g_w = gdep * t / r.W + gv * t * t;
+    if (color) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = rgb[(int64_t)(ray * S + s) * rgb_stride + c];
+        g_w += gc[c] * (v - col[c]) / r.W;
+        if (g_rgb != nullptr)
+          g_rgb[(int64_t)(ray * S + s) * g_rgb_stride + c] =
+              gc[c] * r.w[s] / r.W;
+      }
+    } else if (g_rgb != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        g_rgb[(int64_t)(ray * S + s) * g_rgb_stride + c] = 0.f;
+    }
+    const float g_alpha = g_w * r.T[s] - tail / (1.f - r.alpha[s] + 1e-10f);
+    tail += g_w * r.w[s];
+    g_occ[(int64_t)(ray * S + s) * g_occ_stride] =
+        g_alpha * coef * r.alpha[s] * (1.f - r.alpha[s]);
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
+extern "C" {
+
+int xrd_point_composite_fwd(int n_rays, int n_samples, const float* rgb,
+                            int rgb_stride, const float* occ, int occ_stride,
+                            const uint8_t* point_mask, const float* z_vals,
+                            float sigmoid_coef, float* depth, float* var,
+                            float* color, xrd_stream_t stream) {
+  if (n_rays < 0 || n_samples < 1 || n_samples > kMaxS) return XRD_ERR_ARG;
+  if (n_rays == 0) return XRD_OK;
+  if (!occ || !z_vals || !depth || !var || !color || occ_stride < 1 ||
+      (rgb && rgb_stride < 3))
+    return XRD_ERR_ARG;
+  hipLaunchKernelGGL(point_composite_fwd_kernel, dim3((n_rays + 255) / 256),
+                     dim3(256), 0, (hipStream_t)stream, n_rays, n_samples, rgb,
+                     rgb_stride, occ, occ_stride, point_mask, z_vals,
+                     sigmoid_coef, depth, var, color);
+  return check_launch("xrd_point_composite_fwd");
+}
+
+int xrd_point_composite_bwd(int n_rays, int n_samples, const float* rgb,
+                            int rgb_stride, const float* occ, int occ_stride,
+                            const uint8_t* point_mask, const float* z_vals,
+                            float sigmoid_coef, const float* g_depth,
+                            const float* g_var, const float* g_color,
+                            float* g_rgb, int g_rgb_stride, float* g_occ,
+                            int g_occ_stride, xrd_stream_t stream) {
+  if (n_rays < 0 || n_samples < 1 || n_samples > kMaxS) return XRD_ERR_ARG;
+  if (n_rays == 0) return XRD_OK;
+  if (!occ || !z_vals || !g_occ || occ_stride < 1 || g_occ_stride < 1 ||
+      (rgb && rgb_stride < 3) || (g_rgb && g_rgb_stride < 3))
+    return XRD_ERR_ARG;
+  hipLaunchKernelGGL(point_composite_bwd_kernel, dim3((n_rays + 255) / 256),
+                     dim3(256), 0, (hipStream_t)stream, n_rays, n_samples, rgb,
+                     rgb_stride, occ, occ_stride, point_mask, z_vals,
+                     sigmoid_coef, g_depth, g_var, g_color, g_rgb,
+                     g_rgb_stride, g_occ, g_occ_stride);
+  return check_launch("xrd_point_composite_bwd");
+}
+
+}  // extern "C"
+
+// ---- the whole render as one call each way (xrd_point_render_*) ---------
+// render_batch_ray given the sample points and their neighbours
+// (conv_onet_pointslam.py:302-461): geometry decoder, colour decoder (colour
+// stage), compositing.  The per-point buffers belong to the caller and carry
+// the forward's results to the backward.
+namespace xrd {
+namespace {
+__global__ __launch_bounds__(256) void add_inplace_kernel(
+    int64_t n, float* __restrict__ a, const float* __restrict__ b) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+}  // namespace
+}  // namespace xrd
+
+extern "C" {
+
+int64_t xrd_point_render_scratch_floats(int64_t n_points) {
+  return n_points < 0 ? 0 : 7 * n_points;
+}
+
+int xrd_point_render_fwd(
+    int n_rays, int n_samples, const float* points, const int64_t* neighbors,
+    const int32_t* n_neighbors, const float* cloud, const float* geo_feats,
+    const uint8_t* feat_mask, const float* col_feats, const float* radius,
+    float radius_all, int min_nn, const float* empty_geo,
+    const float* empty_col, const float* packed_geo, const float* packed_col,
+    const float* z_vals, float sigmoid_coef, float* occ, uint8_t* has,
+    uint64_t* relu_masks, float* rgb, float* save_c, float* save_h,
+    float* save_y, float* depth, float* var, float* color,
+    xrd_stream_t stream) {
+  if (n_rays < 0 || n_samples < 1 || n_samples > kMaxS) return XRD_ERR_ARG;
+  const int64_t m = (int64_t)n_rays * n_samples;
+  if (m == 0) return XRD_OK;
+  if (!occ || !has || !z_vals || !depth || !var || !color) return XRD_ERR_ARG;
+  if (col_feats && (!rgb || !packed_col || !empty_col)) return XRD_ERR_ARG;
+  int rc = xrd_point_geo_fwd(m, points, neighbors, n_neighbors, cloud,
+                             geo_feats, feat_mask, radius, radius_all, min_nn,
+                             empty_geo, packed_geo, occ, has, relu_masks,
+                             stream);
+  if (rc != XRD_OK) return rc;
+  if (col_feats) {
+    rc = xrd_point_color_fwd(m, points, neighbors, n_neighbors, cloud,
+                             col_feats, radius, radius_all, min_nn, empty_col,
+                             packed_col, rgb, save_c, save_h, save_y, stream);
+    if (rc != XRD_OK) return rc;
+  }
+  return xrd_point_composite_fwd(n_rays, n_samples, col_feats ? rgb : nullptr,
+                                 3, occ, 1, has, z_vals, sigmoid_coef, depth,
+                                 var, color, stream);
+}
+
+int xrd_point_render_bwd(
+    int n_rays, int n_samples, const float* points, const int64_t* neighbors,
+    const int32_t* n_neighbors, const float* cloud, const float* geo_feats,
+    const uint8_t* feat_mask, const float* col_feats, const float* radius,
+    float radius_all, int min_nn, const float* empty_geo,
+    const float* packed_geo, const float* packed_col, const float* z_vals,
+    float sigmoid_coef, const float* occ, const uint8_t* has,
+    const uint64_t* relu_masks, const float* rgb, const float* save_c,
+    const float* save_h, const float* save_y, const float* g_depth,
+    const float* g_var, const float* g_color, float* scratch, float* g_points,
+    float* g_geo_feats, float* g_col_feats, float* g_flat, float* ops,
+    float* workspace, xrd_stream_t stream) {
+  if (n_rays < 0 || n_samples < 1 || n_samples > kMaxS) return XRD_ERR_ARG;
+  const int64_t m = (int64_t)n_rays * n_samples;
+  if (m == 0) return XRD_OK;
+  if (!occ || !has || !z_vals || !scratch) return XRD_ERR_ARG;
+  float* g_rgb = scratch;            // [m,3]
+  float* g_occ = scratch + 3 * m;    // [m]
+  float* g_pts2 = scratch + 4 * m;   // [m,3] colour path's share of d/d points
+  const bool col = col_feats != nullptr;
+  int rc = xrd_point_composite_bwd(n_rays, n_samples, col ? rgb : nullptr, 3,
+                                   occ, 1, has, z_vals, sigmoid_coef, g_depth,
+                                   g_var, col ? g_color : nullptr,
+                                   col ? g_rgb : nullptr, 3, g_occ, 1, stream);
+  if (rc != XRD_OK) return rc;
+  if (col) {
+    rc = xrd_point_color_bwd(m, points, neighbors, n_neighbors, cloud,
+                             col_feats, radius, radius_all, min_nn, packed_col,
+                             rgb, save_c, save_h, save_y, g_rgb,
+                             g_points ? g_pts2 : nullptr, g_col_feats, g_flat,
+                             ops, workspace, stream);
+    if (rc != XRD_OK) return rc;
+  }
+  rc = xrd_point_geo_bwd(m, points, neighbors, n_neighbors, cloud, geo_feats,
+                         feat_mask, radius, radius_all, min_nn, empty_geo,
+                         packed_geo, relu_masks, g_occ, g_points, g_geo_feats,
+                         stream);
+  if (rc != XRD_OK) return rc;
+  if (col && g_points) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((3 * m + 255) / 256)),
+                       dim3(256), 0, (hipStream_t)stream, 3 * m, g_points,
+                       g_pts2);
+    return check_launch("xrd_point_render_bwd");
+  }
+  return XRD_OK;
+}
+
+}  // extern "C"

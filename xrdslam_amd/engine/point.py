@@ -356,3 +356,51 @@ def map_loss(raw, z_vals, target_d, target_rgb, point_mask, ray_valid, coef,
     |rgb - colour| over the rays that count), gradient w.r.t. ``raw``"""
     return _MapLossFn.apply(raw, z_vals, target_d, target_rgb, point_mask,
                             ray_valid, coef, w_color, min_valid)
+
+
+# ---- compositing (csrc/point_loss.hip) --------------------------------------------
+class _CompositeFn(torch.autograd.Function):
+    """raw [m,4] = [rgb, occupancy logit] rows, z_vals [n,S], point_mask [m]
+    -> depth [n], var [n], colour [n,3] (raw2outputs_nerf_color2 with the
+    no-neighbour override)"""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, point_mask, coef):
+        lib = _lib.lib()
+        dev = raw.device
+        n, S = z_vals.shape
+        r = raw.detach().float().contiguous()
+        assert r.shape == (n * S, 4)
+        z = z_vals.detach().float().contiguous()
+        pm = point_mask.reshape(-1).to(torch.uint8).contiguous()
+        depth = torch.empty(n, dtype=torch.float32, device=dev)
+        var = torch.empty(n, dtype=torch.float32, device=dev)
+        color = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        _lib.check(lib.xrd_point_composite_fwd(
+            n, S, _lib.ptr(r), 4, r.data_ptr() + 12, 4, _lib.ptr(pm),
+            _lib.ptr(z), float(coef), _lib.ptr(depth), _lib.ptr(var),
+            _lib.ptr(color), _lib.stream_ptr(dev)), 'xrd_point_composite_fwd')
+        ctx.coef = float(coef)
+        ctx.save_for_backward(r, z, pm)
+        return depth, var, color
+
+    @staticmethod
+    def backward(ctx, g_depth, g_var, g_color):
+        lib = _lib.lib()
+        r, z, pm = ctx.saved_tensors
+        n, S = z.shape
+        g_raw = torch.empty_like(r)
+
+        def c(t):
+            return None if t is None else t.float().contiguous()
+        gd, gv, gc = c(g_depth), c(g_var), c(g_color)
+        _lib.check(lib.xrd_point_composite_bwd(
+            n, S, _lib.ptr(r), 4, r.data_ptr() + 12, 4, _lib.ptr(pm),
+            _lib.ptr(z), ctx.coef, _lib.ptr(gd), _lib.ptr(gv), _lib.ptr(gc),
+            _lib.ptr(g_raw), 4, g_raw.data_ptr() + 12, 4,
+            _lib.stream_ptr(r.device)), 'xrd_point_composite_bwd')
+        return g_raw, None, None, None
+
+
+def composite(raw, z_vals, point_mask, coef):
+    return _CompositeFn.apply(raw, z_vals, point_mask, coef)

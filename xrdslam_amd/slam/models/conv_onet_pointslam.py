@@ -201,6 +201,8 @@ class ConvOnet2(Model):
                     torch.abs(target_rgb - color_s).sum()
         return losses
 
+    fused_composite = True   # compositing on xrd_point_composite_* (CUDA)
+
     def fused_map_loss(self, input) -> torch.Tensor:
         """get_outputs + get_loss_dict of a MAPPING iteration whose rays all
         carry a sensor depth (or are masked by ``ray_valid``): the decoders as
@@ -320,12 +322,19 @@ class ConvOnet2(Model):
             p=pts.reshape(-1, 3), stage=stage, is_tracker=is_tracker,
             pts_views_d=views, ray_pts_num=S, dynamic_r_query=dynamic_r_query,
             exposure_feat=exposure_feat)
-        with torch.no_grad():
-            raw[:, -1].masked_fill_(~point_mask, -100.0)
-        raw = raw.reshape(n_rays, S, -1).to(dev)
-        depth, uncertainty, color, _ = raw2outputs_nerf_color2(
-            raw, z_vals, rays_d, device=dev,
-            coef=cfg.rendering_sigmoid_coef_mapper)
+        if raw.is_cuda and self.fused_composite and raw.shape[-1] == 4 and \
+                S <= 16:
+            # compositing as one launch each way (engine/point.composite)
+            from ...engine import point as _pt
+            depth, uncertainty, color = _pt.composite(
+                raw, z_vals, point_mask, cfg.rendering_sigmoid_coef_mapper)
+        else:
+            with torch.no_grad():
+                raw[:, -1].masked_fill_(~point_mask, -100.0)
+            raw = raw.reshape(n_rays, S, -1).to(dev)
+            depth, uncertainty, color, _ = raw2outputs_nerf_color2(
+                raw, z_vals, rays_d, device=dev,
+                coef=cfg.rendering_sigmoid_coef_mapper)
         valid_ray_mask = valid_ray_mask.to(dev) & near_pcl
         if not cfg.rendering_sample_near_pcl and not depth_positive:
             depth = depth.masked_fill(~nonzero, 0.0)
