@@ -41,3 +41,133 @@ def test_point_slam_config_and_dynamic_radius():
     assert r_add.shape == (48, 64)
     assert float(r_add[10, 5]) == 0.08 and float(r_query[10, 5]) == 0.16
     assert float(r_add[10, 32]) == 0.02  # on the edge: smallest radius
+
+
+def test_masked_lower_median_is_torch_median_of_the_selection():
+    """the sync-free median of the captured iterations (sort + device-side
+    index) returns what torch.median returns on the compacted selection"""
+    from xrdslam_amd.slam.common.common import masked_lower_median
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 2, 3, 10, 11, 1000, 1001):
+        x = torch.randn(n, generator=g)
+        v = torch.rand(n, generator=g) < 0.6
+        v[int(torch.randint(n, (1, ), generator=g))] = True
+        assert torch.equal(masked_lower_median(x, v), x[v].median()), n
+    assert torch.isnan(masked_lower_median(torch.randn(5),
+                                           torch.zeros(5, dtype=torch.bool)))
+
+
+def test_exclusive_cumprod_matches_cumprod():
+    from xrdslam_amd.slam.model_components.utils import _exclusive_cumprod
+    g = torch.Generator().manual_seed(1)
+    for S in (1, 5, 16, 40):
+        x = torch.rand(7, S, generator=g, dtype=torch.float64,
+                       requires_grad=True)
+        ones = torch.ones(7, 1, dtype=torch.float64)
+        a = _exclusive_cumprod(x, ones)
+        b = torch.cumprod(torch.cat([ones, x], -1), -1)[:, :-1]
+        assert torch.allclose(a, b, rtol=1e-12, atol=0)
+        if S == 1:
+            continue   # [1]: no dependence on x
+        ga, = torch.autograd.grad(a.sum(), x, retain_graph=True)
+        gb, = torch.autograd.grad(b.sum(), x)
+        assert torch.allclose(ga, gb, rtol=1e-10, atol=1e-14)
+
+
+def test_point_color_pack_index_covers_every_parameter():
+    """xrd_point_color_pack_index (host code of the C-ABI): every bias and
+    embedding entry is packed exactly once, every weight exactly twice (its
+    forward fragment and its transposed backward fragment), nothing else"""
+    from xrdslam_amd import _lib
+    lib = _lib.lib()
+    flat_len, grad_len = lib.xrd_point_color_flat_len(), \
+        lib.xrd_point_color_grad_len()
+    assert flat_len == grad_len + 60
+    idx = torch.empty(lib.xrd_point_color_pack_len(), dtype=torch.int32)
+    assert lib.xrd_point_color_pack_index(_lib.ptr(idx)) == 0
+    idx = idx.numpy()
+    assert idx.min() == -1 and idx.max() == flat_len - 1
+    cnt = np.bincount(idx[idx >= 0], minlength=flat_len)
+    # MLP_color.parameters() order (point_layout.h)
+    sizes = [('BREL', 30, 1), ('W1', 128 * 52, 2), ('B1', 128, 1),
+             ('W2', 32 * 128, 2), ('B2', 32, 1)]
+    sizes += [x for i in range(5) for x in ((f'FC{i}', 128 * 32, 2),
+                                            (f'FCB{i}', 128, 1))]
+    for i, w in enumerate((40, 128, 128, 168, 128)):
+        sizes += [(f'P{i}W', 128 * w, 2), (f'P{i}B', 128, 1)]
+    sizes += [('OW', 3 * 128, 1), ('OB', 3, 1), ('BEMB', 60, 1)]
+    assert sum(s for _, s, _ in sizes) == flat_len
+    off = 0
+    for name, size, times in sizes:
+        assert (cnt[off:off + size] == times).all(), name
+        off += size
+    # the decoder's parameters come in this order
+    from xrdslam_amd.engine import point as ep
+    from xrdslam_amd.slam.model_components.decoder_pointslam import MLP_color
+    dec = MLP_color(True, 'distance', 2, 5, True, False, True, 8)
+    assert [tuple(p.shape) for p in ep.color_params(dec)] == \
+        [tuple(p.shape) for p in dec.parameters()]
+    assert sum(p.numel() for p in dec.parameters()) == grad_len
+
+
+def test_fixed_shape_batch_equals_compacted_batch():
+    """captured iterations keep every sampled ray and pass the batch selection
+    as a mask: the model's losses (tracking: masked median; mapping: where-
+    sums) equal those of the compacted batch of the eager loop"""
+    import faiss_standin
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.conv_onet_pointslam import (ConvOnet2,
+                                                             ConvOnet2Config)
+    torch.manual_seed(0)
+    cam = Camera(40., 40., 31.5, 23.5, 64, 48)
+    model = ConvOnet2(ConvOnet2Config(mapping_pixels_based_on_color_grad=40),
+                      cam)
+    model.knn_factory = faiss_standin.TorchKNN
+    g = torch.Generator().manual_seed(2)
+    n = 300
+    d = torch.randn(n, 3, generator=g) * 0.2 + torch.tensor([0., 0., -1.])
+    o = torch.zeros(n, 3)
+    depth = 1.5 + 0.3 * torch.rand(n, generator=g)
+    color = torch.rand(n, 3, generator=g)
+    r = torch.full((n, ), 0.08)
+    model.model_update({
+        'batch_rays_o': o, 'batch_rays_d': d, 'batch_gt_depth': depth,
+        'batch_gt_color': color, 'batch_dynamic_r': r,
+        'batch_rays_o_grad': o[:40], 'batch_rays_d_grad': d[:40],
+        'batch_gt_depth_grad': depth[:40], 'batch_gt_color_grad': color[:40],
+        'batch_dynamic_r_grad': r[:40]})
+    npc = model.neural_point_cloud
+    with torch.no_grad():
+        npc.geo_feats.normal_(0, 0.3, generator=g)
+        npc.col_feats.normal_(0, 0.3, generator=g)
+    fixed = (torch.randn(32, generator=g) * 0.01, )
+    model.decoder.geo_decoder.empty_feature_fn = lambda c, dv: fixed[0]
+    model.decoder.color_decoder.empty_feature_fn = lambda c, dv: fixed[0]
+    keep = torch.rand(n, generator=g) < 0.7
+    td = depth * (1 + 0.02 * torch.randn(n, generator=g))
+    rq = torch.full((n, ), 0.16)
+    for is_mapping in (True, False):
+        res = []
+        for static in (False, True):
+            npc.geo_feats.grad = npc.col_feats.grad = None
+            if static:
+                inp = {'rays_o': o, 'rays_d': d, 'target_s': color,
+                       'target_d': td, 'batch_dynamic_r': rq,
+                       'stage': 'color', 'ray_valid': keep,
+                       'static_shapes': True}
+            else:
+                inp = {'rays_o': o[keep], 'rays_d': d[keep],
+                       'target_s': color[keep], 'target_d': td[keep],
+                       'batch_dynamic_r': rq[keep], 'stage': 'color',
+                       'depth_positive': True}
+            out = model(inp)
+            loss = sum(model.get_loss_dict(out, inp, is_mapping,
+                                           'color').values())
+            loss.backward()
+            res.append((loss.detach(), npc.geo_feats.grad.clone(),
+                        npc.col_feats.grad.clone()))
+        (l0, g0, c0), (l1, g1, c1) = res
+        assert float(l0) > 0
+        assert abs(float(l0 - l1)) < 1e-5 * abs(float(l0)), is_mapping
+        assert float((g0 - g1).abs().max()) < 1e-5 * float(g0.abs().max())
+        assert float((c0 - c1).abs().max()) < 1e-5 * float(c0.abs().max())
