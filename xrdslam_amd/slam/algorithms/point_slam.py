@@ -7,6 +7,7 @@ colour), tracking optimises the pose with uncertainty-normalised losses."""
 from __future__ import annotations
 
 import functools
+import os
 from dataclasses import dataclass, field
 from typing import Type
 
@@ -277,8 +278,12 @@ class PointSLAM(Algorithm):
         return key
 
     def _graphs_ok(self, optimizers, is_mapping):
-        # sharded mapping keeps the eager path (per-rank ray counts differ)
-        if is_mapping and _dist.state.enabled:
+        # sharded mapping: the fixed-shape batches have the same size on every
+        # rank, so the iteration splits into a gradient graph and a step graph
+        # around the eager all-reduce (base_algorithm.optimize_update);
+        # XRD_POINT_SHARDED_GRAPHS=0 keeps that case eager
+        if is_mapping and _dist.state.enabled and \
+                os.environ.get('XRD_POINT_SHARDED_GRAPHS', '1') == '0':
             return False
         return super()._graphs_ok(optimizers, is_mapping)
 
