@@ -6,8 +6,9 @@
 //
 // One wave = 16 sample points, activations stay in registers in D layout
 // (rows = features, columns = the 16 points; the accumulators of a layer are
-// the B operand of the next).  A block = 8 waves; it stages one layer's
-// fragments in LDS at a time (<= 103 KB) and loops over groups of 128 points.
+// the B operand of the next).  A block = 4 or 8 waves (pc_waves_*); it stages
+// one layer's fragments in LDS at a time (<= 103 KB forward, 123 KB backward)
+// and loops over groups of 16 points per wave.
 // Per point the 8 neighbours run through F_theta one after the other
 // (13 + 32 K-steps x 8 / 2 output tiles), their outputs are combined with the
 // interpolation weights, then the trunk follows (10/32/32/42/32 K-steps x 8
@@ -16,8 +17,9 @@
 // The backward recomputes F_theta per neighbour, reads the trunk's layer
 // outputs back from HBM, returns d loss / d positions (Fourier features of p,
 // relative-position features, neighbour distances), scatters the colour
-// feature gradients with atomics, and leaves the operands of the weight
-// gradients in HBM for xrd_dw_rows (one contraction per weight matrix).
+// feature gradients with atomics (tiles transposed through LDS: 128-byte rows
+// per instruction), and leaves the operands of the weight gradients in HBM for
+// pc_dw_kernel (all 13 products in one launch over a job table).
 //
 // Reference behaviour restated, never copied; parity: tests/test_pointslam_hip.py.
 #include <hip/hip_runtime.h>
@@ -30,9 +32,6 @@ namespace xrd {
 namespace {
 
 constexpr int kPcBlocks = 256;    // persistent blocks
-#ifndef XRD_PC_VAR
-#define XRD_PC_VAR 0
-#endif
 constexpr float kBeta = 100.f;
 constexpr int kTailLen = PcPack::FWD_LEN - PcPack::OW + 32;
 constexpr int kPcLds = (PcPack::STAGE_MAX + kTailLen) * (int)sizeof(float);
@@ -43,9 +42,6 @@ constexpr float kTwoPi = 6.283185307179586f;
 // latency-bound with 128..512 threads and ~100 KB per stage)
 __device__ __forceinline__ void pc_copy(float* __restrict__ wl,
                                         const float* __restrict__ src, int n) {
-#if XRD_PC_VAR == 1
-  return;
-#endif
   constexpr int U = 8;
   const int step = blockDim.x * 4;
   int i = threadIdx.x * 4;
@@ -87,9 +83,6 @@ __device__ __forceinline__ T pick8(const T (&v)[8], int k) {
 // kernel VALU-bound)
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 __device__ __forceinline__ float softplus100(float x) {
-#if XRD_PC_VAR == 2
-  return fmaxf(x, 0.f);
-#endif
   const float t = __builtin_amdgcn_exp2f(-fabsf(kBeta * x) * kLog2e);
   return fmaf(__builtin_amdgcn_logf(1.f + t), kLn2 / kBeta, fmaxf(x, 0.f));
 }
