@@ -112,8 +112,11 @@ def geometry(dec, p, neighbors, npc, dynamic_r_query):
     if dec.use_dynamic_radius and dynamic_r_query is not None:
         radius = dynamic_r_query.detach().float().reshape(-1).contiguous()
     empty = dec.empty_feature_fn(dec.c_dim, dev).float().contiguous()
+    # tracking optimises the pose only: no gradient to the map is computed
+    feats = npc.geo_feats if getattr(dec, 'map_gradients', True) \
+        else npc.geo_feats.detach()
     occ, has = _GeoFn.apply(
-        p.reshape(-1, 3), npc.geo_feats, ids.long().contiguous(),
+        p.reshape(-1, 3), feats, ids.long().contiguous(),
         n_nb.int().contiguous(), cloud, fmask, radius,
         float(npc.get_radius_query()), dec.min_nn_num, empty,
         pack(dec, dev))
@@ -311,10 +314,15 @@ def color(dec, p, neighbors, npc, dynamic_r_query):
     if dec.use_dynamic_radius and dynamic_r_query is not None:
         radius = dynamic_r_query.detach().float().reshape(-1).contiguous()
     empty = dec.empty_feature_fn(dec.c_dim, dev).float().contiguous()
-    return _ColFn.apply(p.reshape(-1, 3), npc.col_feats, color_flat(dec, dev),
+    feats, params = npc.col_feats, color_params(dec)
+    if not getattr(dec, 'map_gradients', True):
+        # tracking optimises the pose only: neither the feature scatter nor
+        # the weight products are computed
+        feats, params = feats.detach(), [t.detach() for t in params]
+    return _ColFn.apply(p.reshape(-1, 3), feats, color_flat(dec, dev),
                         ids.long().contiguous(), n_nb.int().contiguous(),
                         cloud, radius, float(npc.get_radius_query()),
-                        dec.min_nn_num, empty, *color_params(dec))
+                        dec.min_nn_num, empty, *params)
 
 
 # ---- mapping loss (csrc/point_loss.hip) -------------------------------------------

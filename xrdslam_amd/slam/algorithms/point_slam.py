@@ -299,6 +299,12 @@ class PointSLAM(Algorithm):
                  coarse=False):
         self.set_stage(is_mapping, step, n_iters)
         inp = self.get_model_input(optimize_frames, is_mapping)
+        # tracking steps the pose only: the fused decoders skip the gradients
+        # of the map features and the decoder weights (the reference computes
+        # and then discards them)
+        dec = self.model.decoder
+        dec.geo_decoder.map_gradients = dec.color_decoder.map_gradients = \
+            bool(is_mapping)
         if is_mapping and self.fused_map_loss and \
                 torch.device(self._dev).type == 'cuda' and \
                 (inp.get('depth_positive') or inp.get('static_shapes')) and \

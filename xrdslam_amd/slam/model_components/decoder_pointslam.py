@@ -172,6 +172,7 @@ class MLP_geometry(_PointMLP):
         self._build_trunk(93, hidden_size, n_blocks, c_dim, 1, 'relu')
 
     use_fused = True   # neighbour interpolation + trunk as one kernel each way
+    map_gradients = True   # False (tracking): no gradient to the map features
 
     def forward(self, p, npc, pts_num=16, is_tracker=False, pts_views_d=None,
                 dynamic_r_query=None, neighbors=None):
@@ -247,6 +248,7 @@ class MLP_color(_PointMLP):
         return self.mlp_col_neighbor(torch.cat([emb, feats], -1))
 
     use_fused = True   # F_theta + interpolation + trunk as one kernel each way
+    map_gradients = True   # False (tracking): no gradient to features / weights
 
     def forward(self, p, npc, is_tracker=False, pts_views_d=None,
                 dynamic_r_query=None, exposure_feat=None, neighbors=None):
