@@ -867,7 +867,7 @@ def run_pointslam(args, dev, world=1):
     _setup_dist(dev, world)
     data = _NumpyImages(SyntheticRoom(
         CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,
-        cy=cam.cy, n_frames=max(args.warmup + args.steps + 1, 200),
+        cy=cam.cy, n_frames=max(args.warmup + args.steps + 8, 200),
         device=dev))
     cad = cadence['point-slam']
     getattr(data, 'data', data).preload(
@@ -884,11 +884,15 @@ def run_pointslam(args, dev, world=1):
     from xrdslam_amd.engine import point as epoint
     algo.use_graphs = False
     epoint.PROFILE = {}
-    slam.step(1 + args.warmup + args.steps)
+    nxt = 1 + args.warmup + args.steps
+    for k in range(nxt, nxt + 6):      # until a mapping frame has been seen
+        slam.step(k)
+        if epoint.PROFILE.get('color_bwd_w'):
+            break
     torch.cuda.synchronize()
     prof, epoint.PROFILE = epoint.PROFILE, None
     roofline = None
-    key = 'color_bwd_w' if prof.get('color_bwd_w') else 'color_bwd'
+    key = 'color_bwd_w'
     if prof.get(key):
         # mapping launches (the eager batches differ by a few rays: the
         # batch filter compacts them), each priced with its own point count

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
           const float ddx = pts[j * 3] - x, ddy = pts[j * 3 + 1] - y,
                       ddz = pts[j * 3 + 2] - z;
           d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-          keep = !(d2 > r2max);
+          keep = d2 <= r2max;   // (a NaN distance is never a neighbour)
         }
         const unsigned long long mask = __ballot(keep);
         const int nk = __popcll(mask);
