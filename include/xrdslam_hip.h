@@ -284,6 +284,42 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
                         float* const g_grid[4], float* const g_dec[4],
                         float* ws, xrd_stream_t stream);
 
+/* One NICE-SLAM MAPPING iteration of a stage as one launch (+ one finishing
+ * launch): forward render, the mapping loss and the backward of everything it
+ * reaches — replaces, for Algorithm.optimize_update's mapping iterations
+ * (slam/algorithms/base_algorithm.py:239-275), the chain Model.get_outputs ->
+ * get_loss_dict -> loss.backward of slam/models/conv_onet.py:339-524 (render),
+ * :178-184 (the mapping losses: sum |gt_d - depth| over the rays with a valid
+ * sensor depth, + w_color * sum |gt_rgb - rgb| in the colour stage — plain
+ * sums over rays, so the gradient of a ray is known once it is composited)
+ * and slam/model_components/utils.py:189-244.  Inputs as xrd_nice_render_fwd
+ * (gt_depth [n] REQUIRED: the loss needs it also in the coarse stage, which
+ * does not sample with it; dmax [1] device, unused in the coarse stage),
+ * tgt_rgb [n,3] (colour stage), keep [n] uint8 or NULL: rays with keep == 0
+ * are rendered but contribute neither loss nor gradient (the reference drops
+ * them from the batch, slam/algorithms/nice_slam.py:181-194).  Outputs (each
+ * may be NULL): g_rays_o / g_rays_d [n,3] (overwritten; not in the coarse
+ * stage), g_grid[4] (ACCUMULATED, cells masked by scene->gmask),
+ * g_dec_color (flat colour-decoder gradient, overwritten; colour stage),
+ * loss [1] f64 = the summed loss terms.  ws: xrd_nice_map_ws_floats(scene,
+ * stage, n) floats, 16-byte aligned, ZERO before its first use and handed back
+ * unchanged afterwards (the call leaves its replica sections zeroed).
+ * 48 samples a ray (32 + 16) only: other sampling configs ->
+ * XRD_ERR_UNSUPPORTED (use xrd_nice_render_fwd / xrd_nice_loss /
+ * xrd_nice_render_bwd). */
+int64_t xrd_nice_map_ws_floats(const xrd_nice_scene* scene, int stage,
+                               int n_rays);
+int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
+                      const float* rays_o, const float* rays_d,
+                      const float* gt_depth, const float* dmax,
+                      const float* tgt_rgb, const uint8_t* keep,
+                      float w_color, float* g_rays_o, float* g_rays_d,
+                      float* const g_grid[4], float* g_dec_color, float* ws,
+                      double* loss, xrd_stream_t stream);
+/* kernel attributes (dynamic LDS) of the above; once per process, before
+ * capturing launches into a hipGraph */
+int xrd_nice_map_warmup(void);
+
 /* Fused Adam over a subset of 32-float cells of a channel-last grid
  * (frustum feature selection: conv_onet.py:94-130,187-211 optimise
  * val[mask] as a 1-D Parameter and write it back every iteration; here the

@@ -6,7 +6,16 @@ oracle of the two CUDA kernels) — on a small synthetic scene and stores
 inputs, the sampler's recorded noise, outputs, loss terms and gradients in
 tests/golden/voxfusion_render.npz.
 
-    python oracle/make_golden_voxfusion.py
+    python oracle/make_golden_voxfusion.py            # the small case
+    python oracle/make_golden_voxfusion.py office0    # BASELINE configs[2]
+
+``office0``: the shapes of the reference's vox-fusion configuration
+(slam/configs/input_config.py:158-197: 1024 mapping rays, default
+SparseVoxelConfig = 0.2 m voxels, 20000 embeddings) on a 640x480 camera inside
+a room whose visible surfaces give > 800 leaf voxels and ragged rows of up to
+~100 samples.  Inputs and the sampler's noise are regenerated from seeds on
+both sides (tests/voxfusion_golden_util.office0_inputs); the file holds the
+reference's outputs -> tests/golden/voxfusion_office0.npz.
 """
 import os
 import sys
@@ -126,5 +135,90 @@ def main():
           {k: float(v) for k, v in ld.items()})
 
 
+def office0_inputs():
+    """seeded inputs of the office0-shaped case (shared with the tests through
+    tests/voxfusion_golden_util.py)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import voxfusion_golden_util as vg
+    return vg.office0_inputs()
+
+
+def main_office0():
+    ref_harness.install()
+    sys.modules['grid'] = grid_standin.module()
+    build_ref_octree.load()
+    real_zeros = torch.zeros
+
+    def zeros_cpu(*a, **k):
+        if k.get('device') == 'cuda':
+            k['device'] = 'cpu'
+        return real_zeros(*a, **k)
+
+    torch.zeros = zeros_cpu
+    import slam.model_components.voxel_helpers_voxfusion as vh
+    vh._ext = sys.modules['grid']
+    from slam.common.camera import Camera
+    from slam.models.sparse_voxel import SparseVoxel, SparseVoxelConfig
+    inp = office0_inputs()
+    torch.manual_seed(0)
+    model = SparseVoxel(SparseVoxelConfig(), Camera(*inp['cam']), None)
+    torch.zeros = real_zeros
+    with torch.no_grad():
+        model.embeddings.copy_(inp['embeddings'])
+    model.insert_points(inp['points'])
+    ms = model.map_states
+    out = {f'dec/{k}': v.numpy().copy()
+           for k, v in model.decoder.state_dict().items()}
+    out.update({'map/voxel_vertex_idx': ms['voxel_vertex_idx'].numpy(),
+           'map/voxel_center_xyz': ms['voxel_center_xyz'].numpy(),
+           'map/voxel_structure': ms['voxel_structure'].numpy()})
+    leaves = int(ms['voxel_vertex_idx'].shape[0])
+    draws = []
+    gen = torch.Generator().manual_seed(inp['noise_seed'])
+    real_uniform = torch.Tensor.uniform_
+
+    def rec_uniform(self, *a, **k):
+        real_uniform(self, *a, generator=gen, **k)
+        draws.append(self.clone())
+        return self
+
+    torch.Tensor.uniform_ = rec_uniform
+    try:
+        ro = inp['rays_o'].clone().requires_grad_(True)
+        rd = inp['rays_d'].clone().requires_grad_(True)
+        minp = {'rays_o': ro, 'rays_d': rd, 'target_s': inp['target_s'],
+                'target_d': inp['target_d']}
+        res = model.get_outputs(minp)
+        ld = model.get_loss_dict(res, minp, True, 0)
+        sum(ld.values()).backward()
+    finally:
+        torch.Tensor.uniform_ = real_uniform
+    assert len(draws) == 1
+    out['noise_shape'] = np.array(draws[0].shape)
+    out['noise_sum'] = np.float64(draws[0].double().sum())
+    for k in ('depth', 'rgb', 'z_vals', 'ray_mask', 'weights', 'z_min'):
+        out[f'out/{k}'] = res[k].detach().numpy()
+    for k, v in ld.items():
+        out[f'loss/{k}'] = v.detach().numpy()
+    out['g_rays_o'] = ro.grad.numpy()
+    out['g_rays_d'] = rd.grad.numpy()
+    ge = model.embeddings.grad
+    rows = ge.abs().sum(1).nonzero().reshape(-1)
+    out['g_embeddings/rows'] = rows.numpy()
+    out['g_embeddings/vals'] = ge[rows].numpy().copy()
+    for k, p in model.decoder.named_parameters():
+        out[f'g_dec/{k}'] = p.grad.numpy().copy()
+    path = os.path.join(GOLD, 'voxfusion_office0.npz')
+    np.savez_compressed(path, **out)
+    zs = res['z_vals']
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB;', leaves,
+          'leaf voxels;', int(res['ray_mask'].sum()), 'of',
+          ro.shape[0], 'rays hit;', tuple(zs.shape), 'samples (padded);',
+          {k: float(v) for k, v in ld.items()})
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'office0':
+        main_office0()
+    else:
+        main()

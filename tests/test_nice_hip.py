@@ -297,6 +297,78 @@ def test_render_at_baseline_config_vs_oracle(tag, n_rays):
     parity.assert_all([(f'nice_office0/{tag}/{n}', a, b) for n, a, b in pairs])
 
 
+@pytest.mark.parametrize('stage,need_rays,need_dec', [
+    ('middle', True, False), ('fine', True, False), ('color', True, True),
+    ('color', False, True), ('middle', False, False), ('fine', False, False),
+    ('color', True, False), ('color', False, False), ('coarse', False, False)])
+def test_one_launch_mapping_iteration_vs_oracle(stage, need_rays, need_dec):
+    """xrd_nice_map_iter (forward + mapping loss + backward as ONE launch) at
+    BASELINE configs[1] (office0 grids, 1000 mapping rays, some of them masked
+    out like the bbox pre-filter does) against the CPU oracle: loss, ray
+    gradients, every grid gradient and the colour-decoder gradient; and twice
+    in a row on the same workspace (the call must leave it reusable)."""
+    import parity
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    n = 1000
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n, 11)
+    keep = torch.rand(n, generator=torch.Generator().manual_seed(4)) > 0.06
+    og = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+    od = {kind: {m: v.clone().requires_grad_(kind == 'color')
+                 for m, v in sd.items()} for kind, sd in decs.items()}
+    ro = rays_o.clone().requires_grad_(stage != 'coarse')
+    rd = rays_d.clone().requires_grad_(stage != 'coarse')
+    # the reference drops the masked rays from the batch; max(gt_depth) of
+    # the kept rays bounds the sampling range (conv_onet.py:418,455)
+    ref = no.render_batch_ray(ro[keep], rd[keep], depth[keep], og, od, bound,
+                              stage)
+    ref_loss = sum(no.loss_dict(ref, depth[keep], color[keep], True,
+                                stage).values())
+    ref_loss.backward()
+    scene, gl, flats = build_scene(bound, grids, decs, dev,
+                                   color_requires_grad=True,
+                                   grid_requires_grad=True)
+    dmax = depth[keep].max().to(dev)
+    for rep in range(2):
+        for g in gl.values():
+            if g.grad is not None:
+                g.grad.zero_()
+        loss, g_o, g_d, g_flat = en.nice_map_iter(
+            scene, stage, rays_o.to(dev), rays_d.to(dev), depth.to(dev), dmax,
+            color.to(dev), keep.to(dev).to(torch.uint8), 0.2, need_rays,
+            need_dec)
+        torch.cuda.synchronize()
+        pairs = [('loss', loss, ref_loss)]
+        if need_rays and stage != 'coarse':
+            assert float(g_o[~keep.to(dev)].abs().max()) == 0.0
+            pairs += [('g_rays_o', g_o[keep.to(dev)], ro.grad[keep]),
+                      ('g_rays_d', g_d[keep.to(dev)], rd.grad[keep])]
+        else:
+            assert g_o is None and g_d is None
+        for k, grid in gl.items():
+            want = og[k].grad
+            if want is None or float(want.abs().max()) == 0.0:
+                assert grid.grad is None or float(grid.grad.abs().max()) == 0
+                continue
+            pairs.append((f'g_{k}', grid.grad, want))
+        if need_dec:
+            gf, off = g_flat.cpu(), 0
+            for name, shape in en.param_shapes('color'):
+                m = int(np.prod(shape))
+                want = od['color'][name].grad
+                got = gf[off:off + m].reshape(shape)
+                off += m
+                if want is None:
+                    assert float(got.abs().max()) == 0.0, name
+                    continue
+                pairs.append((f'g_dec_color/{name}', got, want))
+        else:
+            assert g_flat is None
+        parity.assert_all([(f'nice_map_iter/{stage}/rays{int(need_rays)}/'
+                            f'rep{rep}/{m}', a, b) for m, a, b in pairs])
+
+
 def test_adam_cells_matches_torch():
     from xrdslam_amd import _lib
     dev = _cuda()

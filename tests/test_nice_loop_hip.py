@@ -35,7 +35,8 @@ def make(dev='cuda:0', seed=0):
     return algo, frames
 
 
-def grads(algo, frames, is_mapping, stage_step, fused, fixed):
+def grads(algo, frames, is_mapping, stage_step, fused, fixed, ba=True,
+          coarse=False):
     for f in frames:
         for p in f.get_params():
             p.grad = None
@@ -46,7 +47,7 @@ def grads(algo, frames, is_mapping, stage_step, fused, fixed):
     algo.fused_iteration = fused
     algo.batched_draws = False   # per-frame draws, like the generic hooks
     algo.fixed_shape_batches = fixed
-    algo.bundle_adjust = is_mapping
+    algo.bundle_adjust = is_mapping and ba and not coarse
     if is_mapping:
         algo.model.pre_precessing(frames[-1])
         algo.model.get_param_groups()
@@ -55,10 +56,13 @@ def grads(algo, frames, is_mapping, stage_step, fused, fixed):
         algo.model.set_grids_trainable(False)
     torch.manual_seed(123)
     use = frames if is_mapping else frames[-1:]
-    loss = algo.get_loss(use, is_mapping, stage_step, 60)
-    loss.backward()
+    loss = algo.get_loss(use, is_mapping, stage_step, 60, coarse=coarse)
+    if loss.requires_grad:
+        loss.backward()
+    # (else: the one-launch mapping iteration assigned every .grad itself)
     out = {'loss': float(loss)}
-    out['pose'] = [p.grad.clone() for f in use for p in f.get_params()]
+    out['pose'] = [p.grad.clone() for f in use for p in f.get_params()
+                   if p.grad is not None]
     if is_mapping:
         out['grids'] = {k: g.grad.clone() for k, g in
                         algo.model.scene().grids.items()
@@ -73,13 +77,23 @@ def close(a, b, tol=1e-4):
     return float((a - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-12)
 
 
-@pytest.mark.parametrize('is_mapping,step', [(False, 0), (True, 10), (True, 30),
-                                             (True, 50)])
-def test_fused_iteration_equals_generic_hooks(is_mapping, step):
+@pytest.mark.parametrize('is_mapping,step,ba,coarse', [
+    (False, 0, True, False), (True, 10, True, False), (True, 30, True, False),
+    (True, 50, True, False), (True, 10, False, False),
+    (True, 30, False, False), (True, 50, False, False),
+    (True, 5, False, True)])
+def test_fused_iteration_equals_generic_hooks(is_mapping, step, ba, coarse):
+    """mapping: the fused path is ONE render launch (forward + loss + backward,
+    xrd_nice_map_iter) — every stage, with and without bundle adjustment"""
     algo, frames = make()
-    a = grads(algo, frames, is_mapping, step, fused=False, fixed=True)
-    b = grads(algo, frames, is_mapping, step, fused=True, fixed=True)
-    c = grads(algo, frames, is_mapping, step, fused=False, fixed=False)
+    if coarse and not algo.model.config.coarse:
+        pytest.skip('configuration without a coarse level')
+    kw = dict(ba=ba, coarse=coarse)
+    a = grads(algo, frames, is_mapping, step, fused=False, fixed=True, **kw)
+    b = grads(algo, frames, is_mapping, step, fused=True, fixed=True, **kw)
+    c = grads(algo, frames, is_mapping, step, fused=False, fixed=False, **kw)
+    if is_mapping and ba:
+        assert len(b['pose']) == len(a['pose']) > 0
     for other in (b, c):  # fused == masked generic == compacted generic
         assert abs(other['loss'] - a['loss']) <= 1e-5 * abs(a['loss'])
         for x, y in zip(other['pose'], a['pose']):

@@ -37,9 +37,13 @@ def _noise_by_ray(noise_rows, hit, s_cap):
     return out
 
 
-def test_fused_iteration_vs_reference_golden():
+@pytest.mark.parametrize('which', ['small', 'office0'])
+def test_fused_iteration_vs_reference_golden(which):
+    """'office0' = BASELINE configs[2] shapes: 1024 rays of a 640x480 camera,
+    3546 leaf voxels, ragged rows of up to 121 samples (golden made by the
+    reference's SparseVoxel, oracle/make_golden_voxfusion.py office0)"""
     from xrdslam_amd.engine import vox as ev
-    g = np.load(vg.GOLDEN)
+    g = vg.Golden(vg.GOLDEN if which == 'small' else vg.GOLDEN_OFFICE0)
     model = vg.build_model(g, DEV)
     model.insert_points(torch.from_numpy(g['points']).to(DEV))
     noise = torch.from_numpy(g['noise'])           # [G, R, max_steps]
@@ -208,6 +212,29 @@ def test_capacity_overflow_is_reported_and_grows():
     assert not sizes2['grown'], sizes2
     assert sizes2['n_pts'] <= 512 * model.pts_per_ray
     assert torch.isfinite(loss2)
+
+
+def test_overflow_of_an_earlier_iteration_is_not_lost():
+    """the size record is reset by every launch; its overflow bits are folded
+    into sticky slots, so ONE read per optimize_update still sees a batch that
+    did not fit in an earlier iteration (advisor finding, round 2)"""
+    algo, f, inp = _room_model(512)
+    model = algo.model
+    model.s_cap, model.pts_per_ray = 64, 8   # far too small
+    model.noise_fn = None
+    model.fused_loss(inp, False)             # overflows
+    # a second iteration on the SAME workspace that fits: rays that leave
+    # the mapped view (nothing hit -> no samples)
+    away = dict(inp)
+    away['rays_d'] = -inp['rays_d']
+    model.fused_loss(away, False)
+    ws = model._last_ws
+    last = ws.meta.tolist()
+    assert last[5] == 0 and last[11] != 0, last   # last launch fits, sticky set
+    with pytest.warns(UserWarning, match='truncated'):
+        sizes = model.check_capacity()
+    assert sizes['grown']
+    assert model.s_cap >= sizes['row_len'] > 64
 
 
 def test_voxfusion_loop_through_graphs():

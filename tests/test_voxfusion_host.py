@@ -26,8 +26,12 @@ def oracle_grid(monkeypatch):
     monkeypatch.setattr(vh, '_ext', grid_standin.module())
 
 
-def test_sparse_voxel_vs_reference(oracle_grid):
-    g = np.load(vg.GOLDEN)
+@pytest.mark.parametrize('which', ['small', 'office0'])
+def test_sparse_voxel_vs_reference(oracle_grid, which):
+    """'office0': BASELINE configs[2] shapes — 640x480 camera, 1024 rays,
+    3546 leaf voxels, rows of up to 121 samples (oracle/
+    make_golden_voxfusion.py office0)"""
+    g = vg.Golden(vg.GOLDEN if which == 'small' else vg.GOLDEN_OFFICE0)
     model = vg.build_model(g, 'cpu')
     exact, errs = vg.run(model, g, 'cpu', dedup=False)
     assert all(exact.values()), exact

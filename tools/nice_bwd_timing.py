@@ -48,6 +48,46 @@ def timeit(fn, iters=30, warm=5):
 
 
 for n in [int(a) for a in sys.argv[1:]] or [200, 1000]:
+    if True:
+        # coarse stage: old chain (fwd + bwd incl. replica reduce) vs one launch
+        cs = scene.c_struct()
+        o = ((torch.rand(n, 3, device=dev) - 0.5) * 2.0).contiguous()
+        d = torch.randn(n, 3, device=dev)
+        d = (d / d.norm(dim=1, keepdim=True)).contiguous()
+        depth = (1.0 + 2.0 * torch.rand(n, device=dev)).contiguous()
+        dep = torch.empty(n, dtype=torch.float64, device=dev)
+        var = torch.empty_like(dep)
+        rgb = torch.empty(n, 3, device=dev)
+        raw = torch.empty(n, 32, 4, device=dev)
+        gdv = torch.ones(n, dtype=torch.float64, device=dev)
+        wsc = torch.zeros(lib.xrd_nice_coarse_ws_floats(C.byref(cs)),
+                          device=dev)
+        gg = (C.c_void_p * 4)()
+        gg[0] = grads['grid_coarse'].data_ptr()
+        gdec = (C.c_void_p * 4)()
+
+        def cf():
+            _lib.check(lib.xrd_nice_render_fwd(
+                C.byref(cs), 0, n, P(o), P(d), None, None, P(dep), P(var),
+                P(rgb), P(raw), st))
+
+        def cb():
+            _lib.check(lib.xrd_nice_render_bwd(
+                C.byref(cs), 0, n, P(o), P(d), None, None, P(raw), P(gdv),
+                None, None, None, None, C.byref(gg), C.byref(gdec), P(wsc),
+                st))
+        wsm = torch.zeros(lib.xrd_nice_map_ws_floats(C.byref(cs), 0, n),
+                          device=dev)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        keep = torch.ones(n, dtype=torch.uint8, device=dev)
+
+        def cm():
+            _lib.check(lib.xrd_nice_map_iter(
+                C.byref(cs), 0, n, P(o), P(d), P(depth), None, None, P(keep),
+                0.2, None, None, C.byref(gg), None, P(wsm), P(loss), st))
+        print(f'n={n:5d} coarse fwd {timeit(cf):7.1f} us | bwd+reduce '
+              f'{timeit(cb):7.1f} | map_iter (2 launches) {timeit(cm):7.1f}',
+              flush=True)
     o = ((torch.rand(n, 3, device=dev) - 0.5) * 2.0).contiguous()
     d = torch.randn(n, 3, device=dev)
     d = (d / d.norm(dim=1, keepdim=True)).contiguous()
@@ -93,4 +133,27 @@ for n in [int(a) for a in sys.argv[1:]] or [200, 1000]:
                             P(g_o) if dp else None, P(g_d) if dp else None,
                             C.byref(gg), C.byref(gdec), P(ws), st))
                     msg += f' grid{grid}dp{dp}dw{dw} {timeit(bwd):7.1f}'
+        print(msg, flush=True)
+        # the one-launch mapping iteration (forward + loss + backward)
+        tcol = torch.rand(n, 3, device=dev)
+        keep = torch.ones(n, dtype=torch.uint8, device=dev)
+        wsm = torch.zeros(lib.xrd_nice_map_ws_floats(C.byref(cs), si, n),
+                          device=dev)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        msg = f'n={n:5d} {stage:6s} map_iter (fwd+loss+bwd, 2 launches) |'
+        for dp in (0, 1):
+            for dw in ((0, 1) if stage == 'color' else (0, )):
+                gg = (C.c_void_p * 4)()
+                for gi, k in enumerate(('grid_coarse', 'grid_middle',
+                                        'grid_fine', 'grid_color')):
+                    if 1 <= gi <= si:
+                        gg[gi] = grads[k].data_ptr()
+
+                def mapit():
+                    _lib.check(lib.xrd_nice_map_iter(
+                        C.byref(cs), si, n, P(o), P(d), P(depth), P(dmax),
+                        P(tcol), P(keep), 0.2, P(g_o) if dp else None,
+                        P(g_d) if dp else None, C.byref(gg),
+                        P(g_flat) if dw else None, P(wsm), P(loss), st))
+                msg += f' grid1dp{dp}dw{dw} {timeit(mapit):7.1f}'
         print(msg, flush=True)

@@ -91,6 +91,11 @@ _SIGS = {
                                           f32, f32, f32, f32, vp, vp, C.c_int,
                                           vp]),
     'xrd_nice_warmup': (C.c_int, []),
+    'xrd_nice_map_ws_floats': (i64, [C.POINTER(NiceScene), C.c_int, C.c_int]),
+    'xrd_nice_map_iter': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
+                                    vp, vp, vp, vp, vp, vp, f32, vp, vp,
+                                    C.POINTER(vp * 4), vp, vp, vp, vp]),
+    'xrd_nice_map_warmup': (C.c_int, []),
     'xrd_hashgrid_levels': (C.c_int, [C.c_int, C.c_int, f32, C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp]),
     'xrd_hashgrid_fwd': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, vp, vp,

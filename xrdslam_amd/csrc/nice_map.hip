@@ -1,0 +1,970 @@
+// NICE-SLAM mapping iteration as ONE launch per stage (gfx950): forward render,
+// the mapping loss and the backward of everything it reaches.
+//
+// Why this is possible: the mapping losses are plain sums over rays
+// (slam/models/conv_onet.py:178-184: L1 depth on the rays with a valid sensor
+// depth, + 0.2 * L1 colour in the colour stage), so d loss / d (depth, rgb) of
+// a ray is known as soon as that ray is composited — no batch statistic like
+// the tracking loss's median sits between the forward and the backward.
+// Round 2 ran a forward launch, a loss launch, two torch elementwise launches
+// (the autograd scaling of the loss gradients) and a backward launch that
+// recomputed the whole forward; here a block owns WHOLE rays, runs every
+// decoder forward ONCE (keeping the ReLU masks, and the colour decoder's layer
+// outputs when its weights train), composites its rays in LDS, and walks the
+// decoders backwards: colour -> fine -> middle.
+//
+// Block geometry: one 16-sample tile per wave, 3 tiles per ray, 4 rays = 12
+// waves = 3 per SIMD a block; 1000 rays = 250 blocks = ONE round of the 256
+// CUs (round 2's 8-wave backward blocks took two: 375 groups on 256 CUs).
+//
+// Colour-decoder weight gradients (dW = sum over points of gradient x layer
+// input, the POINTS on the MFMA K dimension).  Round 2 contracted them inside
+// the layer loop through an LDS exchange (two block barriers per layer, the
+// layer outputs h_0..h_4 and 36+ accumulators alive in every tile wave: 256
+// registers = 2 waves per SIMD, +170 us).  Here the tile waves stay as light
+// as the variant without weight gradients: while a tile goes forward /
+// backward it drops the contraction's operands (c, h_0..h_4, dL/dh_0..4,
+// ReLU masks, Fourier features: 30 KB a tile) into a per-tile scratch as
+// feature-major matrices [32 features][16 points], and after the last decoder
+// of the group the block's 12 waves contract the group's 12 tiles — 62 16x16
+// blocks as 25 units that share their A / B operands, 4-6 accumulators a wave,
+// every operand one coalesced 16-byte load per lane and 4 MFMAs, no barrier —
+// and add their blocks to one of 8 replicas.  embedder._B (3 x 93) is reduced
+// on the VALU (row reductions + LDS adds) instead of 6 padded MFMA blocks.
+// The scratch is written and read once by the same CU a few microseconds
+// apart (L2 / Infinity-Cache traffic, 89 MB at 1000 rays).
+// Reference maths restated (never copied): conv_onet.py:339-524 (sampling,
+// eval_points, the stage's decoders), decoder_nice.py:103-234,
+// utils.py:189-244 (raw2outputs_nerf_color), conv_onet.py:145-185 (losses).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "nice_device.h"
+#include "nice_layout.h"
+
+namespace xrd {
+namespace {
+
+// Compositing of one ray (lane l = sample l) from its raw values in LDS, the
+// ray's mapping loss and the compositing backward.  Returns d loss / d
+// occupancy logit of the lane's sample, its weight and the ray's colour
+// gradient.  Same arithmetic as composite_bwd (f64 transmittance / suffix sums)
+// with g_var = 0 and g_depth, g_rgb = the signs the L1 terms produce.
+template <int S>
+__device__ __forceinline__ void map_composite(
+    const float* __restrict__ rawray, int lane, double zl, float gt_d,
+    const float* __restrict__ tgt, bool kept, bool use_color, float w_color,
+    float& gocc_s, float& w, float (&grgb)[3], double& loss) {
+  const bool valid = lane < S;
+  f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+  if (valid) rw = *reinterpret_cast<const f32x4*>(rawray + lane * 4);
+  float alpha = 0.f, oma = 1.f;
+  if (valid) {
+    const float e = expf(-10.f * fabsf(rw[3]));  // <= 1
+    const float hi = 1.f / (1.f + e), lo = e / (1.f + e);
+    alpha = rw[3] >= 0.f ? hi : lo;
+    oma = rw[3] >= 0.f ? lo : hi;
+  }
+  const double f = (double)oma + 1e-10;
+  double incl = valid ? f : 1.0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_up(incl, o);
+    if (lane >= o) incl *= u;
+  }
+  double T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.0;
+  const double wd = (double)alpha * T;
+  w = (float)wd;
+  const double dep = wave_sum(valid ? wd * zl : 0.0);
+  const double diff = (double)gt_d - dep;
+  const bool m = kept && gt_d > 0.f;
+  const double gdep = m ? (diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0)) : 0.0;
+  loss = m ? fabs(diff) : 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) grgb[a] = 0.f;
+  if (use_color) {
+    float lc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float c = wave_sum(valid ? w * rw[a] : 0.f);
+      if (kept) {
+        const float dc = tgt[a] - c;
+        lc += fabsf(dc);
+        grgb[a] = w_color * (dc > 0.f ? -1.f : (dc < 0.f ? 1.f : 0.f));
+      }
+    }
+    loss += (double)w_color * (double)lc;
+  }
+  double gw = 0.0;
+  if (valid)
+    gw = gdep * zl +
+         (double)(grgb[0] * rw[0] + grgb[1] * rw[1] + grgb[2] * rw[2]);
+  double suf = valid ? gw * wd : 0.0;  // inclusive suffix sum
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_down(suf, o);
+    if (lane + o < 64) suf += u;
+  }
+  double sexc = __shfl_down(suf, 1);
+  if (lane == 63) sexc = 0.0;
+  const float galpha = valid ? (float)(gw * T - sexc / f) : 0.f;
+  gocc_s = galpha * 10.f * alpha * oma;
+}
+
+// per-tile operand scratch of the deferred weight-gradient contraction
+// (floats): feature-major matrices M[f][pt] = 512 floats
+constexpr int SC_C = 0;                 // grid features c
+constexpr int SC_H = 512;               // h_0..h_4
+constexpr int SC_E = SC_H + 5 * 512;    // sin(p.B) [96][16] (rows >= 93: 0)
+constexpr int SC_G = SC_E + 96 * 16;    // dL/dh_0..4 (gh_i)
+constexpr int SC_M = SC_G + 5 * 512;    // ReLU masks: [5][32] words, bit = pt
+constexpr int SC_P = SC_M + 160;        // positions [16][4]
+constexpr int SC_GO = SC_P + 64;        // dL/d decoder output [16][4]
+constexpr int SC_TILE = SC_GO + 64;     // 7456 floats = 29 824 B
+static_assert(SC_TILE % 4 == 0, "16-byte aligned tiles");
+
+// write a D-layout register pair (features 16jt+4q+r of point li) to a
+// feature-major matrix
+__device__ __forceinline__ void scr_put(float* __restrict__ M, int lane,
+                                        const f32x4 (&v)[2]) {
+  const int q = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[(16 * jt + 4 * q + r) * 16 + li] = v[jt][r];
+}
+
+// Colour decoder backward of one tile (gc = d loss / d grid features, gp += d
+// loss / d position) that leaves the weight-gradient operands in the tile's
+// scratch and adds the tile's embedder._B gradient to embB (LDS [3][96]).
+// w: the staged backward fragments (MlpPack offsets).
+template <bool NEED_DP>
+__device__ __forceinline__ void color_bwd_emit(
+    const float* __restrict__ w, int lane, const float (&p)[1][3],
+    const float (&go)[1][4], uint64_t mask, float* __restrict__ tsc,
+    float* __restrict__ embB, f32x4 (&gc)[1][2], float (&gp)[1][3]) {
+  using P = MlpPack<32, 4>;
+  const int q = lane >> 4, li = lane & 15;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gh[2] = {z4, z4}, ga[2] = {z4, z4}, ga3[2] = {z4, z4};
+  gc[0][0] = z4;
+  gc[0][1] = z4;
+  if (q == 0) {
+    *reinterpret_cast<f32x4*>(tsc + SC_P + li * 4) =
+        f32x4{p[0][0], p[0][1], p[0][2], 0.f};
+    *reinterpret_cast<f32x4*>(tsc + SC_GO + li * 4) =
+        f32x4{go[0][0], go[0][1], go[0][2], go[0][3]};
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const f32x4 w0 =
+        *reinterpret_cast<const f32x4*>(w + P::WOUT + o * 32 + 4 * q);
+    const f32x4 w1 =
+        *reinterpret_cast<const f32x4*>(w + P::WOUT + o * 32 + 16 + 4 * q);
+    gh[0] += w0 * go[0][o];
+    gh[1] += w1 * go[0][o];
+  }
+  uint32_t* mw = reinterpret_cast<uint32_t*>(tsc + SC_M);
+#pragma unroll 1
+  for (int i = 4; i >= 0; --i) {
+    scr_put(tsc + SC_G + 512 * i, lane, gh);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on = (mask >> (i * 8 + jt * 4 + r)) & 1;
+        ga[jt][r] = on ? gh[jt][r] : 0.f;
+        // lane (q, li) -> ballot bit 16q+li: the 16 points of feature
+        // 16jt+4q+r are bits [16q, 16q+16)
+        const uint64_t b = __ballot(on);
+        if (li == 0)
+          mw[i * 32 + 16 * jt + 4 * q + r] = (uint32_t)(b >> (16 * q)) & 0xffffu;
+      }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float a = w[P::wct(i) + (kt * 8 + s) * 64 + lane];
+        gc[0][kt] = XRD_MFMA4(a, gh[s >> 2][s & 3], gc[0][kt]);
+      }
+    XRD_SB();
+    if (i == 3) {
+      ga3[0] = ga[0];
+      ga3[1] = ga[1];
+    }
+    if (i >= 1) {
+      f32x4 gprev[2] = {z4, z4};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float a = w[P::wht(i) + (kt * 8 + s) * 64 + lane];
+          gprev[kt] = XRD_MFMA4(a, ga[s >> 2][s & 3], gprev[kt]);
+        }
+      XRD_SB();
+      gh[0] = gprev[0];
+      gh[1] = gprev[1];
+    }
+  }
+  // ga holds the masked ga_0.  d loss / d sin(p.B) = W0^T ga0 + W3e^T ga3,
+  // through the sine; lane group q owns feature k = emap(4kt+r, q)
+#pragma unroll 1
+  for (int kt = 0; kt < 6; ++kt) {
+    f32x4 ge = z4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a3 = w[P::W3ET + (kt * 8 + s) * 64 + lane];
+      const float a0 = w[P::W0T + (kt * 8 + s) * 64 + lane];
+      ge = XRD_MFMA4(a3, ga3[s >> 2][s & 3], ge);
+      ge = XRD_MFMA4(a0, ga[s >> 2][s & 3], ge);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = emap(4 * kt + r, q);
+      const f32x4 bk = *reinterpret_cast<const f32x4*>(w + P::EMB + k * 4);
+      const float garg = ge[r] * cos_cw(embed_arg(p[0], bk));
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (NEED_DP) gp[0][a] += garg * bk[a];
+        // embedder._B[a][k] += sum over the tile's points of p_a * garg
+        const float v = row16_sum(p[0][a] * garg);
+        if (li == 0 && k < kEmbK) atomicAdd(embB + a * 96 + k, v);
+      }
+    }
+  }
+}
+
+// ---- deferred weight-gradient contraction ---------------------------------
+// lane (m = l & 15, q = l >> 4): an A operand row is feature 16jt+m, a B
+// operand column feature 16kt+m; K-step s of a tile = point 4q+s, i.e.
+// element s of the lane's 16-byte load from a feature-major matrix.
+__device__ __forceinline__ f32x4 ldm(const float* __restrict__ M, int f,
+                                     int q) {
+  return *reinterpret_cast<const f32x4*>(M + f * 16 + 4 * q);
+}
+__device__ __forceinline__ f32x4 mask4(f32x4 a, const float* __restrict__ T,
+                                       int layer, int f, int q) {
+  const uint32_t mw =
+      reinterpret_cast<const uint32_t*>(T + SC_M)[layer * 32 + f] >> (4 * q);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (!((mw >> s) & 1u)) a[s] = 0.f;
+  return a;
+}
+
+// The operands were written a few microseconds earlier by this CU but 9 MB
+// per XCD are in flight (L2: 4 MB): most loads come back from the Infinity
+// Cache (~1-2 us).  Every unit therefore issues the loads of a CHUNK of tiles
+// before its first MFMA (6 tiles: 72 registers in flight) instead of one tile
+// at a time (measured: 12 dependent round trips a unit, +120 us a launch).
+//
+// unit u of the 18 layer units: u < 10: fc_c.i (i = u >> 1), rows jt = u & 1,
+// A = gh_i, B = c; else pts_linears.i hidden part (i = 1 + ((u - 10) >> 1)),
+// A = ga_i = masked gh_i, B = h_{i-1}.  Both column tiles, the bias rows.
+__device__ __forceinline__ void dwb_layer_unit(
+    const float* __restrict__ scr, int ntiles, int u, int lane,
+    float* __restrict__ rep) {
+  using F = MlpFlat<32, 4>;
+  constexpr int CH = 6;
+  const int m = lane & 15, q = lane >> 4;
+  const bool hid = u >= 10;
+  const int i = hid ? 1 + ((u - 10) >> 1) : (u >> 1), jt = u & 1;
+  const int aoff = SC_G + 512 * i, boff = hid ? SC_H + 512 * (i - 1) : SC_C;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float bias = 0.f;
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntiles; t0 += CH) {
+    f32x4 a[CH], b0[CH], b1[CH];
+    uint32_t mw[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const bool live = t0 + c < ntiles;
+      const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
+      a[c] = ldm(T + aoff, 16 * jt + m, q);
+      b0[c] = ldm(T + boff, m, q);
+      b1[c] = ldm(T + boff, 16 + m, q);
+      mw[c] = hid ? reinterpret_cast<const uint32_t*>(T + SC_M)
+                            [i * 32 + 16 * jt + m] >> (4 * q)
+                  : 0xfu;
+      if (!live) mw[c] = 0u;  // a tile beyond the group: no contribution
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = ((mw[c] >> s) & 1u) ? a[c][s] : 0.f;  // ga: masked gh
+        acc0 = XRD_MFMA4(av, b0[c][s], acc0);
+        acc1 = XRD_MFMA4(av, b1[c][s], acc1);
+        bias += av;
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 16 * jt + 4 * q + r;
+    float* dst = hid ? rep + F::pw(i) + j * F::pstride(i) + F::pcol(i)
+                     : rep + F::fcw(i) + j * 32;
+    atomicAdd(dst + m, acc0[r]);
+    atomicAdd(dst + 16 + m, acc1[r]);
+  }
+  const float b = group4_sum(bias);
+  if (q == 0) atomicAdd(rep + (hid ? F::pb(i) : F::fcb(i)) + 16 * jt + m, b);
+}
+
+// Fourier parts of pts_linears.0 / .3, column tile kt6 (features 16kt6+m of
+// sin(p.B), left in the scratch by the forward): A = ga_0 / ga_3, both row
+// tiles = 4 blocks sharing one B.  kt6 == 0 also carries pts_linears.0.bias =
+// sum ga_0.
+__device__ __forceinline__ void dwb_fourier_unit(
+    const float* __restrict__ scr, int ntiles, int kt6, int lane,
+    float* __restrict__ rep) {
+  using F = MlpFlat<32, 4>;
+  constexpr int CH = 3;
+  const int m = lane & 15, q = lane >> 4;
+  const int k = 16 * kt6 + m;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4] = {z4, z4, z4, z4};
+  float b0 = 0.f, b1 = 0.f;
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntiles; t0 += CH) {
+    f32x4 e[CH], a00[CH], a01[CH], a30[CH], a31[CH];
+    uint32_t m00[CH], m01[CH], m30[CH], m31[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const bool live = t0 + c < ntiles;
+      const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
+      e[c] = ldm(T + SC_E, k, q);
+      a00[c] = ldm(T + SC_G, m, q);
+      a01[c] = ldm(T + SC_G, 16 + m, q);
+      a30[c] = ldm(T + SC_G + 3 * 512, m, q);
+      a31[c] = ldm(T + SC_G + 3 * 512, 16 + m, q);
+      const uint32_t* mw = reinterpret_cast<const uint32_t*>(T + SC_M);
+      const uint32_t on = live ? 0xfu : 0u;
+      m00[c] = (mw[m] >> (4 * q)) & on;
+      m01[c] = (mw[16 + m] >> (4 * q)) & on;
+      m30[c] = (mw[3 * 32 + m] >> (4 * q)) & on;
+      m31[c] = (mw[3 * 32 + 16 + m] >> (4 * q)) & on;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float v00 = ((m00[c] >> s) & 1u) ? a00[c][s] : 0.f;
+        const float v01 = ((m01[c] >> s) & 1u) ? a01[c][s] : 0.f;
+        const float v30 = ((m30[c] >> s) & 1u) ? a30[c][s] : 0.f;
+        const float v31 = ((m31[c] >> s) & 1u) ? a31[c][s] : 0.f;
+        acc[0] = XRD_MFMA4(v00, e[c][s], acc[0]);
+        acc[1] = XRD_MFMA4(v01, e[c][s], acc[1]);
+        acc[2] = XRD_MFMA4(v30, e[c][s], acc[2]);
+        acc[3] = XRD_MFMA4(v31, e[c][s], acc[3]);
+        b0 += v00;
+        b1 += v01;
+      }
+  }
+  if (k < kEmbK) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * q + r;
+        atomicAdd(rep + F::P0W + j * kEmbK + k, acc[jt][r]);
+        atomicAdd(rep + F::P3W + j * (kEmbK + 32) + k, acc[2 + jt][r]);
+      }
+  }
+  if (kt6 == 0) {
+    const float s0 = group4_sum(b0), s1 = group4_sum(b1);
+    if (q == 0) {
+      atomicAdd(rep + F::P0B + m, s0);
+      atomicAdd(rep + F::P0B + 16 + m, s1);
+    }
+  }
+}
+
+// output_linear: rows = the 4 outputs (A = d loss / d output), B = h_4
+__device__ __forceinline__ void dwb_output_unit(
+    const float* __restrict__ scr, int ntiles, int lane,
+    float* __restrict__ rep) {
+  using F = MlpFlat<32, 4>;
+  constexpr int CH = 6;
+  const int m = lane & 15, q = lane >> 4;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float bout = 0.f;
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntiles; t0 += CH) {
+    f32x4 b0[CH], b1[CH];
+    float av[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const bool live = t0 + c < ntiles;
+      const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
+      b0[c] = ldm(T + SC_H + 4 * 512, m, q);
+      b1[c] = ldm(T + SC_H + 4 * 512, 16 + m, q);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        av[c][s] = (live && m < 4) ? T[SC_GO + (4 * q + s) * 4 + (m & 3)] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc0 = XRD_MFMA4(av[c][s], b0[c][s], acc0);
+        acc1 = XRD_MFMA4(av[c][s], b1[c][s], acc1);
+        bout += av[c][s];
+      }
+  }
+  if (q == 0) {  // rows 0..3 of the accumulator = lane group 0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(rep + F::OW + r * 32 + m, acc0[r]);
+      atomicAdd(rep + F::OW + r * 32 + 16 + m, acc1[r]);
+    }
+  }
+  const float b = group4_sum(bout);
+  if (q == 0 && m < 4) atomicAdd(rep + F::OB + m, b);
+}
+
+// the 25 units over the 12 waves of a block (MFMAs per tile: layer unit 8,
+// Fourier unit 16, output unit 8): waves 0..5 one Fourier + one layer unit,
+// waves 6..11 two layer units, wave 6 also the output unit
+__device__ __forceinline__ void dw_contract(const float* __restrict__ scr,
+                                            int ntiles, int wave, int lane,
+                                            float* __restrict__ rep) {
+  if (wave < 6) {
+    dwb_fourier_unit(scr, ntiles, wave, lane, rep);
+    dwb_layer_unit(scr, ntiles, wave, lane, rep);
+  } else {
+    dwb_layer_unit(scr, ntiles, 6 + 2 * (wave - 6), lane, rep);
+    dwb_layer_unit(scr, ntiles, 7 + 2 * (wave - 6), lane, rep);
+    if (wave == 6) dwb_output_unit(scr, ntiles, lane, rep);
+  }
+}
+
+template <int NT>
+struct MapGeom {
+  static constexpr int RPBM = 4;             // rays per block
+  static constexpr int NW = RPBM * NT;       // waves = tiles of a group
+  static constexpr int RAW = kWMax;          // raw [RPBM][64][4]
+  static constexpr int WAVE0 = kWMax + RPBM * 256;  // per-wave scratch
+  static constexpr int EMBB = WAVE0 + NW * kScratch;  // embedder._B sums
+  static constexpr size_t LDS = (size_t)EMBB + 288;
+};
+static_assert(MapGeom<3>::LDS * 4 <= 163840, "LDS per CU");
+static_assert(MapGeom<3>::NW == 12, "the contraction's unit table: 12 waves");
+
+template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
+__global__ __launch_bounds__((MapGeom<NT>::NW * 64),
+                             ((MapGeom<NT>::NW + 3) / 4)) void
+nice_map_fused_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ dmax_p, const float* __restrict__ tgt_rgb,
+    const uint8_t* __restrict__ keep, float w_color, float* gg_middle,
+    float* gg_fine, float* gg_color, double* __restrict__ part,
+    float* __restrict__ dw_rep, float* __restrict__ dw_scr,
+    double* __restrict__ ray_loss) {
+  static_assert(!NEED_DW || STAGE == XRD_STAGE_COLOR, "dW: colour stage");
+  using G = MapGeom<NT>;
+  constexpr int S = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // staged fragments
+  float* rawbuf = wl + G::RAW;
+  const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+  const int slot = wave / NT, tile = wave % NT;
+  float* scratch = wl + G::WAVE0 + wave * kScratch;
+  float* embB = wl + G::EMBB;
+  double* zbuf = reinterpret_cast<double*>(scratch);
+  ScatterLds SL;
+  SL.gt = scratch + 256;
+  SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
+  SL.w = SL.gt + 16 * 33 + 16 * 8;
+  if (NEED_DW) {
+    for (int i = threadIdx.x; i < 288; i += blockDim.x) embB[i] = 0.f;
+    // (visible to every wave behind the first staging barrier)
+  }
+  using PM = MlpPack<32, 1>;
+  using PF = MlpPack<64, 1>;
+  using PC = MlpPack<32, 4>;
+  const int ngroups = (n + G::RPBM - 1) / G::RPBM;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * G::RPBM + slot);
+    const bool active = ray < n;
+    // the lane index is re-materialised per group and per decoder phase
+    // (empty asm): without it hipcc hoists the phases' LDS / scratch address
+    // arithmetic out of the group loop and keeps it in registers across every
+    // phase (0.7-0.8 KB of spills a lane in the weight-gradient variants)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int q = lane >> 4, li = lane & 15;
+    // this tile's operand scratch (weight-gradient contraction)
+    float* tsc = NEED_DW ? dw_scr + ((size_t)grp * G::NW + wave) * SC_TILE
+                         : nullptr;
+    double zl = 0.0;
+    float gd = 0.f;
+    TileGeom tg = {};
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
+    uint64_t mask_m[1] = {0}, mask_f[1] = {0}, mask_c[1] = {0};
+    f32x4 c_m[1][2], c_c[1][2];
+    Tri tr;
+    // ---- forward: middle -> fine -> colour, each decoder ONCE ------------
+    if (active) {
+      RayCtx rc;
+      load_ray(rays_o, rays_d, gt_depth, ray, true, rc);
+      gd = rc.gd;
+      zl = sample_z<S>(sc, rc, dmax_p[0], lane, zbuf, zbuf + 64);
+      tile_geom(rc, zbuf[64 + 16 * tile + li], sc.bound, tg);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) p32[0][a] = tg.p32[a];
+      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+      tri_gather(sc.grid[1], tr, q, c_m[0]);
+    }
+    stage_weights(wl, sc.dec[1], PM::WHT);
+    asm volatile("" : "+v"(lane));
+    if (active) {
+      float om[1][1];
+      mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask_m, nullptr);
+      occ = om[0][0];
+    }
+    if (STAGE >= XRD_STAGE_FINE) {
+      f32x4 c_f[1][4];
+      if (active) {
+        f32x4 cf[2];
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        tri_gather(sc.grid[2], tr, q, cf);
+        c_f[0][0] = cf[0];
+        c_f[0][1] = cf[1];
+        c_f[0][2] = c_m[0][0];
+        c_f[0][3] = c_m[0][1];
+      }
+      stage_weights(wl, sc.dec[2], PF::WHT);
+      asm volatile("" : "+v"(lane));
+      if (active) {
+        float of[1][1];
+        mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_f, of, mask_f,
+                                       nullptr);
+        occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
+      }
+    }
+    if (STAGE == XRD_STAGE_COLOR) {
+      if (active) {
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        tri_gather(sc.grid[3], tr, q, c_c[0]);
+        if (NEED_DW) scr_put(tsc + SC_C, lane, c_c[0]);
+      }
+      stage_weights(wl, sc.dec[3], PC::WHT);
+      asm volatile("" : "+v"(lane));
+      if (active) {
+        float oc[1][4];
+        mlp_fwd<1, 32, 4, true, false, NEED_DW>(wl, lane, p32, c_c, oc, mask_c,
+                                                nullptr, tsc + SC_H);
+        col[0] = oc[0][0];
+        col[1] = oc[0][1];
+        col[2] = oc[0][2];
+      }
+    }
+    if (active) {
+      if (!tg.inb) occ = 100.f;  // conv_onet.py:370
+      if (q == 0)
+        *reinterpret_cast<f32x4*>(rawbuf + (slot * 64 + 16 * tile + li) * 4) =
+            f32x4{col[0], col[1], col[2], occ};
+    }
+    __syncthreads();
+    // ---- compositing, loss, compositing backward (every wave: its ray) ----
+    float gocc = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+    if (active) {
+      float gocc_s, w, grgb[3];
+      double loss;
+      const bool kept = keep == nullptr || keep[ray] != 0;
+      map_composite<S>(rawbuf + slot * 256, lane, zl, gd, tgt_rgb + ray * 3,
+                       kept, STAGE == XRD_STAGE_COLOR, w_color, gocc_s, w,
+                       grgb, loss);
+      const int src = 16 * tile + li;
+      gocc = __shfl(gocc_s, src);
+      if (!tg.inb) gocc = 0.f;  // occupancy was overridden to 100
+      const float wsrc = __shfl(w, src);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) gcol[a] = grgb[a] * wsrc;
+      if (tile == 0 && lane == 0 && ray_loss != nullptr) ray_loss[ray] = loss;
+    }
+    // ---- backward: colour -> fine -> middle --------------------------------
+    asm volatile("" : "+v"(lane));
+    double gp64[3] = {0.0, 0.0, 0.0};
+    float gp32[1][3] = {{0.f, 0.f, 0.f}};
+    if (STAGE == XRD_STAGE_COLOR) {
+      f32x4 gc[1][2];
+      // channel 3 is overwritten by fine+middle occupancy -> no gradient
+      const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
+      stage_weights(wl, sc.dec[3] + PC::EMB,
+                    ((NEED_DP || NEED_DW) ? PC::LEN : PC::W0T) - PC::EMB);
+      if (NEED_DW) {
+        if (active)
+          color_bwd_emit<NEED_DP>(wl - PC::EMB, lane, p32, go, mask_c[0], tsc,
+                                  embB, gc, gp32);
+      } else if (active) {
+        mlp_bwd<1, 32, 4, NEED_DP, NEED_DP>(wl - PC::EMB, lane, p32, c_c, go,
+                                            mask_c, gc, gp32);
+      }
+      if (active) {
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
+        grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
+      }
+    }
+    if (STAGE >= XRD_STAGE_FINE) {
+      f32x4 c_f[1][4], gc[1][4];
+      const float go[1][1] = {{gocc}};
+      stage_weights(wl, sc.dec[2] + PF::EMB,
+                    (NEED_DP ? PF::LEN : PF::W0T) - PF::EMB);
+      asm volatile("" : "+v"(lane));
+      if (active) {
+        mlp_bwd<1, 64, 1, NEED_DP, NEED_DP>(wl - PF::EMB, lane, p32, c_f, go,
+                                            mask_f, gc, gp32);
+        const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
+        grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
+      }
+    }
+    {
+      const float go[1][1] = {{gocc}};
+      f32x4 gc[1][2];
+      stage_weights(wl, sc.dec[1] + PM::EMB,
+                    (NEED_DP ? PM::LEN : PM::W0T) - PM::EMB);
+      asm volatile("" : "+v"(lane));
+      if (active) {
+        mlp_bwd<1, 32, 1, NEED_DP, NEED_DP>(wl - PM::EMB, lane, p32, c_m, go,
+                                            mask_m, gc, gp32);
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+        if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
+        grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
+      }
+    }
+    if (NEED_DW) {
+      // every tile of the group has left its operands in the scratch
+      // (written by this CU, read once, never read before: no stale L1 line)
+      __threadfence();
+      __syncthreads();
+      const int rays_here = n - grp * G::RPBM < G::RPBM ? n - grp * G::RPBM
+                                                          : G::RPBM;
+      int lane_b = lane;
+      asm volatile("" : "+v"(lane_b));  // keep the contraction's address
+      // arithmetic inside the group loop (no hoisting into live registers)
+      dw_contract(dw_scr + (size_t)grp * G::NW * SC_TILE, rays_here * NT, wave,
+                  lane_b,
+                  dw_rep + (size_t)(blockIdx.x % kDwRep) * kColorFlat);
+    }
+    if (NEED_DP && active) {
+      const int tile_id = ray * NT + tile;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double g = gp64[a] + (double)gp32[0][a];
+        const double so = wave_sum(g), sd = wave_sum(g * tg.z);
+        if (lane == 0) {
+          part[(size_t)tile_id * 6 + a] = so;
+          part[(size_t)tile_id * 6 + 3 + a] = sd;
+        }
+      }
+    }
+  }
+  if (NEED_DW) {
+    __syncthreads();  // the LDS sums of embedder._B are complete
+    float* rep = dw_rep + (size_t)(blockIdx.x % kDwRep) * kColorFlat;
+    for (int i = threadIdx.x; i < 288; i += blockDim.x) {
+      const int a = i / 96, k = i % 96;
+      if (k < kEmbK && embB[i] != 0.f)
+        atomicAdd(rep + MlpFlat<32, 4>::EB + a * kEmbK + k, embB[i]);
+    }
+  }
+}
+
+// Coarse stage (grid_coarse is its only parameter, conv_onet.py:187-195; 32
+// uniform samples, no depth guidance): a block = one ray = two tile waves, the
+// decoder read from L2 (it is 6 KB a pass), the gradient scattered into one of
+// kCoarseRep replicas (coarse_rep_reduce).
+__global__ __launch_bounds__(2 * 64, 2) void nice_map_coarse_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const uint8_t* __restrict__ keep, float* gg_coarse,
+    float* __restrict__ rep, double* __restrict__ ray_loss) {
+  constexpr int NT = 2, S = 32;
+  __shared__ __attribute__((aligned(16))) float
+      smem[NT * (256 + kScatterFloats) + 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = lane >> 4, li = lane & 15;
+  float* R = smem + wave * (256 + kScatterFloats);
+  float* rawbuf = smem + NT * (256 + kScatterFloats);
+  double* zbuf = reinterpret_cast<double*>(R);
+  ScatterLds SL;
+  SL.gt = R + 256;
+  SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
+  SL.w = SL.gt + 16 * 33 + 16 * 8;
+  for (int ray = blockIdx.x; ray < n; ray += gridDim.x) {
+    RayCtx rc;
+    load_ray(rays_o, rays_d, nullptr, ray, false, rc);
+    const double zl = sample_z<S>(sc, rc, 0.f, lane, zbuf, zbuf + 64);
+    TileGeom tg;
+    tile_geom(rc, zbuf[64 + 16 * wave + li], sc.bound, tg);
+    f32x4 c_a[1][2], gc[1][2];
+    float o1[1];
+    uint64_t mask[1];
+    Tri tr;
+    tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+    tri_gather(sc.grid[0], tr, q, c_a[0]);
+    noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
+    if (q == 0)
+      *reinterpret_cast<f32x4*>(rawbuf + (16 * wave + li) * 4) =
+          f32x4{0.f, 0.f, 0.f, tg.inb ? o1[0] : 100.f};
+    __syncthreads();
+    float gocc_s, w, grgb[3];
+    double loss;
+    const bool kept = keep == nullptr || keep[ray] != 0;
+    map_composite<S>(rawbuf, lane, zl, gt_depth[ray], nullptr, kept, false,
+                     0.f, gocc_s, w, grgb, loss);
+    if (wave == 0 && lane == 0 && ray_loss != nullptr) ray_loss[ray] = loss;
+    float gocc = __shfl(gocc_s, 16 * wave + li);
+    if (!tg.inb) gocc = 0.f;
+    const float go[1] = {gocc};
+    noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
+    tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+    float* ggc = gg_coarse;
+    if (rep != nullptr && gg_coarse != nullptr)
+      ggc = rep + (size_t)(blockIdx.x & (kCoarseRep - 1)) *
+                      ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
+    grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
+    __syncthreads();  // rawbuf is rewritten by the next ray
+  }
+}
+
+// after the fused launch: decoder gradient = sum of the replicas (left zeroed
+// for the next call), ray gradients = sum of the ray's tile partials in a
+// fixed order, loss = sum of the per-ray losses (last block)
+__global__ __launch_bounds__(256) void nice_map_finish_kernel(
+    float* __restrict__ rep, int len, float* __restrict__ g_dec,
+    const double* __restrict__ part, int n_dp, int nt,
+    float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
+    const double* __restrict__ ray_loss, int n, double* __restrict__ loss) {
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    if (ray_loss != nullptr)
+      for (int i = threadIdx.x; i < n; i += 256) s += ray_loss[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss != nullptr)
+      loss[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < len) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < kDwRep; ++r) {
+      s += rep[(size_t)r * len + i];
+      rep[(size_t)r * len + i] = 0.f;
+    }
+    g_dec[i] = s;
+    return;
+  }
+  const int j = i - len;
+  if (j >= n_dp * 6) return;
+  const int ray = j / 6, a = j % 6;
+  double s = 0.0;
+  for (int t = 0; t < nt; ++t) s += part[((size_t)ray * nt + t) * 6 + a];
+  float* dst = a < 3 ? g_rays_o + ray * 3 + a : g_rays_d + ray * 3 + a - 3;
+  *dst = (float)s;
+}
+
+// grad += sum of the coarse replicas (left zeroed), loss = sum of ray losses
+__global__ __launch_bounds__(256) void nice_map_coarse_finish_kernel(
+    float* __restrict__ rep, int64_t ne, float* __restrict__ grad,
+    const double* __restrict__ ray_loss, int n, double* __restrict__ loss) {
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += ray_loss[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss != nullptr)
+      loss[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    return;
+  }
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ne || rep == nullptr) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < kCoarseRep; ++r) {
+    const float v = rep[(size_t)r * ne + i];
+    if (v != 0.f) {
+      s += v;
+      rep[(size_t)r * ne + i] = 0.f;
+    }
+  }
+  if (s != 0.f) grad[i] += s;
+}
+
+constexpr int kMapBlocks = 256;  // persistent: one block per CU
+
+template <int ST, bool DP, bool DW>
+int launch_map(const xrd_nice_scene* scene, int n, const float* rays_o,
+               const float* rays_d, const float* gt_depth, const float* dmax,
+               const float* tgt_rgb, const uint8_t* keep, float w_color,
+               float* const gg[4], double* part, float* dw_rep,
+               float* dw_scr, double* ray_loss, hipStream_t st) {
+  using G = MapGeom<3>;
+  auto kern = nice_map_fused_kernel<ST, 3, DP, DW>;
+  const size_t lds = G::LDS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr_set = true;
+  }
+  if (n == 0) return XRD_OK;  // warm-up call: attributes only
+  const int ngroups = (n + G::RPBM - 1) / G::RPBM;
+  const int nb = ngroups < kMapBlocks ? ngroups : kMapBlocks;
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(G::NW * 64), lds, st, *scene, n,
+                     rays_o, rays_d, gt_depth, dmax, tgt_rgb, keep, w_color,
+                     gg[1], gg[2], gg[3], part, dw_rep, dw_scr, ray_loss);
+  return check_launch("xrd_nice_map_iter");
+}
+
+#define MAP_ARGS                                                             \
+  scene, n_rays, rays_o, rays_d, gt_depth, dmax, tgt_rgb, keep, w_color, gg, \
+      part, dw_rep, dw_scr, ray_loss, st
+
+int map_dispatch(int stage, bool dp, bool dw, const xrd_nice_scene* scene,
+                 int n_rays, const float* rays_o, const float* rays_d,
+                 const float* gt_depth, const float* dmax,
+                 const float* tgt_rgb, const uint8_t* keep, float w_color,
+                 float* const gg[4], double* part, float* dw_rep,
+                 float* dw_scr, double* ray_loss, hipStream_t st) {
+  switch (stage) {
+    case XRD_STAGE_MIDDLE:
+      if (dp) return launch_map<XRD_STAGE_MIDDLE, true, false>(MAP_ARGS);
+      return launch_map<XRD_STAGE_MIDDLE, false, false>(MAP_ARGS);
+    case XRD_STAGE_FINE:
+      if (dp) return launch_map<XRD_STAGE_FINE, true, false>(MAP_ARGS);
+      return launch_map<XRD_STAGE_FINE, false, false>(MAP_ARGS);
+    case XRD_STAGE_COLOR:
+      if (dw) {
+        if (dp) return launch_map<XRD_STAGE_COLOR, true, true>(MAP_ARGS);
+        return launch_map<XRD_STAGE_COLOR, false, true>(MAP_ARGS);
+      }
+      if (dp) return launch_map<XRD_STAGE_COLOR, true, false>(MAP_ARGS);
+      return launch_map<XRD_STAGE_COLOR, false, false>(MAP_ARGS);
+  }
+  return XRD_ERR_ARG;
+}
+
+}  // namespace
+}  // namespace xrd
+
+using namespace xrd;
+
+extern "C" {
+
+int64_t xrd_nice_map_ws_floats(const xrd_nice_scene* scene, int stage,
+                               int n_rays) {
+  if (scene == nullptr || n_rays < 0) return -1;
+  if (stage == XRD_STAGE_COARSE)
+    return 2 * (int64_t)n_rays + 4 +
+           (int64_t)kCoarseRep * scene->gdim[0] * scene->gdim[1] *
+               scene->gdim[2] * 32;
+  // [n*3][6] f64 tile partials | [n] f64 ray losses | dW replicas | (colour
+  // stage) the contraction's operand scratch, one tile slot per wave and group
+  int64_t need = (int64_t)n_rays * 3 * 6 * 2 + 2 * (int64_t)n_rays + 4 +
+                 (int64_t)kDwRep * kColorFlat;
+  need = (need + 3) / 4 * 4;
+  if (stage == XRD_STAGE_COLOR)
+    need += ((int64_t)n_rays + 3) / 4 * 12 * SC_TILE;
+  return need;
+}
+
+int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
+                      const float* rays_o, const float* rays_d,
+                      const float* gt_depth, const float* dmax,
+                      const float* tgt_rgb, const uint8_t* keep,
+                      float w_color, float* g_rays_o, float* g_rays_d,
+                      float* const g_grid[4], float* g_dec_color, float* ws,
+                      double* loss, xrd_stream_t stream) {
+  if (scene == nullptr || n_rays < 0 || stage < 0 || stage > 3)
+    return XRD_ERR_ARG;
+  if (!rays_o || !rays_d || !gt_depth || !ws) return XRD_ERR_ARG;
+  if ((g_rays_o == nullptr) != (g_rays_d == nullptr)) return XRD_ERR_ARG;
+  if (scene->t_uniform == nullptr) return XRD_ERR_ARG;
+  const int need[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 1, 1, 0}, {0, 1, 1, 1}};
+  for (int g = 0; g < 4; ++g)
+    if (need[stage][g] && (scene->grid[g] == nullptr ||
+                           scene->dec[g] == nullptr))
+      return XRD_ERR_ARG;
+  float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (g_grid)
+    for (int g = 0; g < 4; ++g) gg[g] = g_grid[g];
+  hipStream_t st = (hipStream_t)stream;
+  if (stage == XRD_STAGE_COARSE) {
+    if (scene->n_samples != 32) return XRD_ERR_UNSUPPORTED;
+    if (g_rays_o != nullptr || g_dec_color != nullptr)
+      return XRD_ERR_UNSUPPORTED;  // the coarse stage never reaches them
+    if (n_rays == 0) return XRD_OK;
+    double* ray_loss = reinterpret_cast<double*>(ws);
+    float* rep = ws + 2 * (size_t)n_rays + 4;
+    const int64_t ne =
+        (int64_t)scene->gdim[0] * scene->gdim[1] * scene->gdim[2] * 32;
+    hipLaunchKernelGGL(nice_map_coarse_kernel, dim3(n_rays), dim3(128), 0, st,
+                       *scene, n_rays, rays_o, rays_d, gt_depth, keep, gg[0],
+                       gg[0] ? rep : nullptr, ray_loss);
+    int rc = check_launch("xrd_nice_map_iter/coarse");
+    if (rc != XRD_OK) return rc;
+    const int64_t nb = (gg[0] ? (ne + 255) / 256 : 0) + 1;
+    hipLaunchKernelGGL(nice_map_coarse_finish_kernel, dim3((unsigned)nb),
+                       dim3(256), 0, st, gg[0] ? rep : nullptr, ne, gg[0],
+                       ray_loss, n_rays, loss);
+    return check_launch("xrd_nice_map_iter/coarse_finish");
+  }
+  if (scene->n_samples != 32 || scene->n_surface != 16)
+    return XRD_ERR_UNSUPPORTED;  // 48 samples a ray = 3 tiles
+  if (!dmax || scene->t_surface == nullptr) return XRD_ERR_ARG;
+  const bool dw = g_dec_color != nullptr;
+  if (dw && stage != XRD_STAGE_COLOR) return XRD_ERR_ARG;
+  if (stage == XRD_STAGE_COLOR && !tgt_rgb) return XRD_ERR_ARG;
+  const bool dp = g_rays_o != nullptr;
+  if (n_rays == 0) return XRD_OK;
+  double* part = reinterpret_cast<double*>(ws);
+  double* ray_loss = part + (size_t)n_rays * 3 * 6;
+  const size_t rep_off = (size_t)n_rays * 3 * 6 * 2 + 2 * (size_t)n_rays + 4;
+  float* dw_rep = ws + rep_off;
+  float* dw_scr =
+      ws + (rep_off + (size_t)kDwRep * kColorFlat + 3) / 4 * 4;
+  int rc = map_dispatch(stage, dp, dw, scene, n_rays, rays_o, rays_d, gt_depth,
+                        dmax, tgt_rgb, keep, w_color, gg, part, dw_rep, dw_scr,
+                        ray_loss, st);
+  if (rc != XRD_OK) return rc;
+  const int len = dw ? kColorFlat : 0;
+  const int total = len + (dp ? n_rays * 6 : 0);
+  hipLaunchKernelGGL(nice_map_finish_kernel, dim3((total + 255) / 256 + 1),
+                     dim3(256), 0, st, dw_rep, len, g_dec_color, part,
+                     dp ? n_rays : 0, 3, g_rays_o, g_rays_d, ray_loss, n_rays,
+                     loss);
+  return check_launch("xrd_nice_map_iter/finish");
+}
+
+int xrd_nice_map_warmup(void) {
+  float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
+  xrd_nice_scene sc = {};
+  for (int stage = XRD_STAGE_MIDDLE; stage <= XRD_STAGE_COLOR; ++stage)
+    for (int dp = 0; dp < 2; ++dp)
+      for (int dw = 0; dw < 2; ++dw) {
+        if (dw && stage != XRD_STAGE_COLOR) continue;
+        int rc = map_dispatch(stage, dp, dw, &sc, 0, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, 0.f, gg, nullptr,
+                              nullptr, nullptr, nullptr, nullptr);
+        if (rc != XRD_OK) return rc;
+      }
+  return XRD_OK;
+}
+
+}  // extern "C"

@@ -50,6 +50,14 @@ enum Meta {
   M_NVALID = 8,    // hit rays with a usable sensor depth
   M_MAXCEIL = 9,   // max over hit rays of ceil(steps)
   M_STACKOVF = 10, // octree traversal stack overflow (xrd_svo_intersect)
+  // sticky part: NOT cleared by a launch — the record of every launch is
+  // folded in when the next launch resets the slots above, so a caller that
+  // reads once per optimize_update sees an overflow of ANY iteration (the
+  // caller clears these three after reading)
+  M_STICKY_OVF = 11,   // OR of M_OVERFLOW (| 8 for M_STACKOVF)
+  M_STICKY_ROW = 12,   // max of M_MAXSTEPS
+  M_STICKY_PTS = 13,   // max number of valid samples a launch wanted
+  M_WANT_PTS = 14,     // valid samples before clamping to the capacity
   M_LEN = 16
 };
 
@@ -61,7 +69,18 @@ constexpr int kGroups = 200;       // G of InverseCDFRaySampling.forward
 // atomic per block and counter instead of one per ray (thousands of atomics
 // on ONE address serialise in L2 — measured 35-65 us a kernel at 6144 rays).
 __global__ void vox_meta_reset_kernel(int* meta, double* acc) {
-  if (threadIdx.x < M_LEN) meta[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    // the previous launch's record -> sticky slots
+    meta[M_STICKY_OVF] |= meta[M_OVERFLOW] | (meta[M_STACKOVF] ? 8 : 0);
+    if (meta[M_MAXSTEPS] > meta[M_STICKY_ROW])
+      meta[M_STICKY_ROW] = meta[M_MAXSTEPS];
+    if (meta[M_WANT_PTS] > meta[M_STICKY_PTS])
+      meta[M_STICKY_PTS] = meta[M_WANT_PTS];
+  }
+  __syncthreads();
+  if (threadIdx.x < M_LEN &&
+      (threadIdx.x < M_STICKY_OVF || threadIdx.x > M_STICKY_PTS))
+    meta[threadIdx.x] = 0;
   if (threadIdx.x < 4) acc[threadIdx.x] = 0.0;
 }
 
@@ -281,6 +300,7 @@ __global__ __launch_bounds__(1024) void vox_point_scan_kernel(
     offs[n_rays] = total;
     if ((int64_t)total > p_cap) atomicOr(meta + M_OVERFLOW, 2);
     meta[M_NPTS] = (int64_t)total > p_cap ? (int)p_cap : total;
+    meta[M_WANT_PTS] = total;
   }
 }
 

@@ -163,6 +163,8 @@ class NiceScene:
         self.t_surface = torch.linspace(
             0., 1., steps=max(self.n_surface, 1)).double().to(self.device)
         _lib.check(_lib.lib().xrd_nice_warmup(), 'xrd_nice_warmup')
+        _lib.check(_lib.lib().xrd_nice_map_warmup(), 'xrd_nice_map_warmup')
+        self._map_ws: Dict[tuple, torch.Tensor] = {}
 
     def set_grid(self, key: str, val: torch.Tensor):
         assert key in GRID_KEYS
@@ -338,6 +340,74 @@ def nice_render(scene: NiceScene, stage: str, rays_o: torch.Tensor,
     gl = [scene.grids[GRID_KEYS[i]] if i in used else empty for i in range(4)]
     return _NiceRenderFn.apply(rays_o, rays_d, flat, gl[0], gl[1], gl[2],
                                gl[3], scene, stage, gt_depth, dmax)
+
+
+@torch.no_grad()
+def nice_map_iter(scene: NiceScene, stage: str, rays_o: torch.Tensor,
+                  rays_d: torch.Tensor, gt_depth: torch.Tensor,
+                  dmax: Optional[torch.Tensor], tgt_rgb: torch.Tensor,
+                  keep: Optional[torch.Tensor], w_color: float,
+                  need_rays: bool, need_dec: bool):
+    """One mapping iteration of ``stage`` as one launch (+ one finishing
+    launch): render, the mapping loss of conv_onet.py:178-184 and every
+    gradient (``xrd_nice_map_iter``).  Grid gradients are accumulated into
+    ``grid.grad`` of the stage's grids that require grad; returns
+    (loss f64 [], g_rays_o, g_rays_d, g_dec_color) — the last three None when
+    not asked for.  No autograd graph is built: the caller owns the chain
+    rule beyond the rays (pose parameters) and assigns ``.grad`` itself."""
+    lib = _lib.lib()
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    if not rays_o.is_cuda:
+        raise _lib.XrdError('nice_map_iter needs CUDA tensors (no CPU '
+                            'fallback)')
+    rays_o = rays_o.detach().float().contiguous()
+    rays_d = rays_d.detach().float().contiguous()
+    gd = gt_depth.detach().float().reshape(-1).contiguous()
+    tc = tgt_rgb.detach().float().contiguous() if tgt_rgb is not None \
+        else None
+    if stage != 'coarse' and dmax is None:
+        dmax = gd.max()
+    dm = dmax.detach().float().reshape(1) if dmax is not None else None
+    cs = scene.c_struct()
+    # one workspace per ray count serves the middle / fine / colour stages
+    # (sized for the colour stage, the largest); the coarse stage has its own
+    key = (stage == 'coarse', n)
+    ws = scene._map_ws.get(key)
+    if ws is None or ws.device != dev:
+        # zero before the first use; every call leaves it reusable
+        ws = scene._map_ws[key] = torch.zeros(
+            lib.xrd_nice_map_ws_floats(
+                C.byref(cs), STAGES['coarse' if stage == 'coarse' else
+                                    'color'], n),
+            dtype=torch.float32, device=dev)
+    need_rays = bool(need_rays) and stage != 'coarse'
+    need_dec = bool(need_dec) and stage == 'color'
+    g_o = torch.empty(n, 3, dtype=torch.float32, device=dev) \
+        if need_rays else None
+    g_d = torch.empty(n, 3, dtype=torch.float32, device=dev) \
+        if need_rays else None
+    g_flat = torch.empty(lib.xrd_nice_flat_len(3), dtype=torch.float32,
+                         device=dev) if need_dec else None
+    loss = torch.empty((), dtype=torch.float64, device=dev)
+    gg = (C.c_void_p * 4)()
+    used = {'coarse': (0, ), 'middle': (1, ), 'fine': (1, 2),
+            'color': (1, 2, 3)}[stage]
+    grid_grads = False
+    for gi in used:
+        g = scene.grids[GRID_KEYS[gi]]
+        if g is not None and g.requires_grad:
+            gg[gi] = _grid_grad_buffer(g).data_ptr()
+            g._xrd_grad_fresh = True  # torch.Adam skips grad=None
+            grid_grads = True
+    with _Timed(('nice_map', stage, n, need_rays, need_dec, grid_grads)):
+        _lib.check(lib.xrd_nice_map_iter(
+            C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o), _lib.ptr(rays_d),
+            _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(tc), _lib.ptr(keep),
+            float(w_color), _lib.ptr(g_o), _lib.ptr(g_d), C.byref(gg),
+            _lib.ptr(g_flat), _lib.ptr(ws), _lib.ptr(loss),
+            _lib.stream_ptr(dev)), 'xrd_nice_map_iter')
+    return loss, g_o, g_d, g_flat
 
 
 @torch.no_grad()

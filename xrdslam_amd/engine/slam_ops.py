@@ -143,6 +143,72 @@ class SampleRaysFn(torch.autograd.Function):
         return g_c2w, None, None, None, None, None, None
 
 
+def sample_rays_poses(idx, depth_imgs, rgb_imgs, cam, crop, bound6, layout,
+                      pose_params):
+    """plain (no autograd) form of SampleRaysPosesFn.forward: returns
+    ((rays_o, rays_d, target_d, target_rgb, keep, dmax), ctx) — ``ctx`` goes
+    to sample_rays_poses_bwd"""
+    lib = _lib.lib()
+    F, n = idx.shape
+    dev = idx.device
+    N = F * n
+    tp, qp, k = [], [], 0
+    for lay in layout:
+        if lay == '7':
+            d = pose_params[k]
+            tp.append(d.data_ptr())
+            qp.append(d.data_ptr() + 12)
+            k += 1
+        else:
+            tp.append(pose_params[k].data_ptr())
+            qp.append(pose_params[k + 1].data_ptr())
+            k += 2
+    arr = C.c_void_p * F
+    tp, qp = arr(*tp), arr(*qp)
+    dp = arr(*[t.data_ptr() for t in depth_imgs])
+    cp = arr(*[t.data_ptr() for t in rgb_imgs])
+    ro = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    rd = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    td = torch.empty(N, 1, dtype=torch.float32, device=dev)
+    tc = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    keep = torch.empty(N, dtype=torch.uint8, device=dev)
+    dmax = torch.zeros(1, dtype=torch.float32, device=dev)   # atomicMax
+    c2ws = torch.empty(F, 4, 4, dtype=torch.float32, device=dev)
+    H0, W0, wcrop = crop
+    b6 = (C.c_double * 6)(*bound6)
+    _lib.check(lib.xrd_sample_rays_multi(
+        F, n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
+        b6, _lib.ptr(idx), dp, cp, tp, qp, _lib.ptr(c2ws), _lib.ptr(ro),
+        _lib.ptr(rd), _lib.ptr(td), _lib.ptr(tc), _lib.ptr(keep),
+        _lib.ptr(dmax), _lib.stream_ptr(dev)), 'xrd_sample_rays_multi')
+    return (ro, rd, td, tc, keep, dmax), (cam, crop, F, n, layout, tp, qp,
+                                          idx)
+
+
+def sample_rays_poses_bwd(ctx, g_ro, g_rd):
+    """[F,7] gradient of the frames' (t, q) pose parameters"""
+    cam, (H0, W0, wcrop), F, n, layout, tp, qp, idx = ctx
+    dev = idx.device
+    g7 = torch.empty(F, 7, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().xrd_sample_rays_multi_bwd(
+        F, n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
+        _lib.ptr(idx), tp, qp, _lib.ptr(g_ro.float().contiguous()),
+        _lib.ptr(g_rd.float().contiguous()), _lib.ptr(g7),
+        _lib.stream_ptr(dev)), 'xrd_sample_rays_multi_bwd')
+    return g7
+
+
+def pose_param_grads(g7, layout):
+    """views of g7 in pose-parameter order (no launches)"""
+    grads = []
+    for f, lay in enumerate(layout):
+        if lay == '7':
+            grads.append(g7[f])
+        else:
+            grads.extend([g7[f, :3], g7[f, 3:]])
+    return grads
+
+
 class SampleRaysPosesFn(torch.autograd.Function):
     """SampleRaysFn with the poses given as PARAMETERS (quaternion poses): one
     launch builds the F camera matrices and samples the F frames, one launch
@@ -153,63 +219,17 @@ class SampleRaysPosesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, depth_imgs, rgb_imgs, cam, crop, bound6, layout,
                 *pose_params):
-        lib = _lib.lib()
-        F, n = idx.shape
-        dev = idx.device
-        N = F * n
-        tp, qp, k = [], [], 0
-        for lay in layout:
-            if lay == '7':
-                d = pose_params[k]
-                tp.append(d.data_ptr())
-                qp.append(d.data_ptr() + 12)
-                k += 1
-            else:
-                tp.append(pose_params[k].data_ptr())
-                qp.append(pose_params[k + 1].data_ptr())
-                k += 2
-        arr = C.c_void_p * F
-        tp, qp = arr(*tp), arr(*qp)
-        dp = arr(*[t.data_ptr() for t in depth_imgs])
-        cp = arr(*[t.data_ptr() for t in rgb_imgs])
-        ro = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        rd = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        td = torch.empty(N, 1, dtype=torch.float32, device=dev)
-        tc = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        keep = torch.empty(N, dtype=torch.uint8, device=dev)
-        dmax = torch.zeros(1, dtype=torch.float32, device=dev)
-        c2ws = torch.empty(F, 4, 4, dtype=torch.float32, device=dev)
-        H0, W0, wcrop = crop
-        b6 = (C.c_double * 6)(*bound6)
-        _lib.check(lib.xrd_sample_rays_multi(
-            F, n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
-            b6, _lib.ptr(idx), dp, cp, tp, qp, _lib.ptr(c2ws), _lib.ptr(ro),
-            _lib.ptr(rd), _lib.ptr(td), _lib.ptr(tc), _lib.ptr(keep),
-            _lib.ptr(dmax), _lib.stream_ptr(dev)), 'xrd_sample_rays_multi')
-        ctx.args = (cam, crop, F, n, layout, tp, qp)
+        outs, ctx.args = sample_rays_poses(idx, depth_imgs, rgb_imgs, cam,
+                                           crop, bound6, layout, pose_params)
         ctx.save_for_backward(idx, *pose_params)
-        ctx.mark_non_differentiable(td, tc, keep, dmax)
-        return ro, rd, td, tc, keep, dmax
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
 
     @staticmethod
     def backward(ctx, g_ro, g_rd, *unused):
-        lib = _lib.lib()
-        idx = ctx.saved_tensors[0]
-        cam, (H0, W0, wcrop), F, n, layout, tp, qp = ctx.args
-        dev = idx.device
-        g7 = torch.empty(F, 7, dtype=torch.float32, device=dev)
-        _lib.check(lib.xrd_sample_rays_multi_bwd(
-            F, n, cam.width, H0, W0, wcrop, cam.fx, cam.fy, cam.cx, cam.cy,
-            _lib.ptr(idx), tp, qp, _lib.ptr(g_ro.float().contiguous()),
-            _lib.ptr(g_rd.float().contiguous()), _lib.ptr(g7),
-            _lib.stream_ptr(dev)), 'xrd_sample_rays_multi_bwd')
-        grads = []
-        for f, lay in enumerate(layout):   # views of g7: no launches
-            if lay == '7':
-                grads.append(g7[f])
-            else:
-                grads.extend([g7[f, :3], g7[f, 3:]])
-        return (None, None, None, None, None, None, None, *grads)
+        g7 = sample_rays_poses_bwd(ctx.args, g_ro, g_rd)
+        return (None, None, None, None, None, None, None,
+                *pose_param_grads(g7, ctx.args[4]))
 
 
 class NiceLossFn(torch.autograd.Function):

@@ -260,9 +260,18 @@ class RayWorkspace:
         return C.c_void_p(self.meta.data_ptr() + 4 * 4)
 
     def overflow(self):
-        """(bits, meta list) — one device->host copy"""
+        """(bits, meta list) — one device->host copy.  ``bits`` covers EVERY
+        launch since the last call (the sticky slots 11..13 of the record,
+        csrc/vox_rays.hip), not only the last one; row_len (m[2]) and the
+        wanted sample count (m[14]) are the maxima over those launches.  The
+        sticky slots are cleared here."""
         m = self.meta.tolist()
-        return m[5] | (8 if m[10] else 0), m
+        bits = m[5] | (8 if m[10] else 0) | m[11]
+        m[2] = max(m[2], m[12])
+        m[14] = max(m[14], m[13])
+        if m[11] or m[12] or m[13]:
+            self.meta[11:14].zero_()
+        return bits, m
 
 
 def flatten_decoder(params):

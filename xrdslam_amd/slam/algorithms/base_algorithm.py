@@ -282,7 +282,11 @@ class Algorithm:
                 track['c2w'].copy_(torch.where(better, cur, track['c2w']))
                 track['loss'].copy_(torch.where(better, lval, track['loss']))
                 track['valid'].logical_or_(better)
-        loss.backward(retain_graph=(self.config.retain_graph and is_mapping))
+        if loss.requires_grad:
+            loss.backward(retain_graph=(self.config.retain_graph and
+                                        is_mapping))
+        # else: a fused iteration computed the loss AND assigned every .grad
+        # (NiceSLAM._fused_map_step): nothing to back-propagate
         self.post_processing(step, is_mapping, optimizers.optimizers,
                              coarse=coarse)
         if part == 'grad':

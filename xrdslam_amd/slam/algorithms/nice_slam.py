@@ -260,6 +260,11 @@ class NiceSLAM(Algorithm):
         bound6 = self.bounding_box.reshape(-1).tolist()
         detach = is_mapping and not self.bundle_adjust
         quat = self._quat_pose_params(optimize_frames, dev, detach)
+        if quat is not None and is_mapping and self.fused_map_launch and \
+                mcfg.rendering_n_samples == 32 and \
+                mcfg.rendering_n_surface == 16:
+            return self._fused_map_step(idx, imgs, quat, bound6, det, n_pix,
+                                        (Hedge, Wedge, wcrop), detach)
         if quat is not None:
             # poses as parameters: matrices + sampling of all frames in ONE
             # launch (and one for the pose gradients)
@@ -296,7 +301,54 @@ class NiceSLAM(Algorithm):
                                          is_mapping, use_color,
                                          mcfg.tracking_handle_dynamic, w)
 
+    def _fused_map_step(self, idx, imgs, quat, bound6, det, n_pix, crop,
+                        detach):
+        """a mapping iteration's sampling, render, loss and EVERY gradient as
+        four launches (sampling, the fused render+loss+backward, its
+        finishing launch, the pose-parameter gradients): nothing goes through
+        autograd — the gradients are assigned to ``.grad`` here and the
+        returned loss carries no graph (``_iteration`` skips backward)."""
+        from ...engine import nice as _en
+        from ...engine import slam_ops
+        cam, dev, mcfg = self.camera, self.model.device, self.model.config
+        layout, params = quat
+        (ro, rd, td, tc, keep, dmax), sctx = slam_ops.sample_rays_poses(
+            idx, [i[0] for i in imgs], [i[1] for i in imgs], cam, crop,
+            bound6, layout, params)
+        F = len(imgs)
+        sel = None
+        if det:
+            sel = self._shard_rows(F, n_pix, dev)
+            ro_s, rd_s = ro.index_select(0, sel), rd.index_select(0, sel)
+            td_s, tc_s, keep_s = td[sel], tc[sel], keep[sel]
+        else:
+            ro_s, rd_s, td_s, tc_s, keep_s = ro, rd, td, tc, keep
+        stage = self.stage
+        scene = self.model.scene()
+        need_rays = (not detach) and stage != 'coarse' and \
+            any(p.requires_grad for p in params)
+        need_dec = stage == 'color' and \
+            getattr(scene, 'decoder_trainable', True) and \
+            scene.dec_flat.get('color') is not None and \
+            scene.dec_flat['color'].requires_grad
+        loss, g_o, g_d, g_flat = _en.nice_map_iter(
+            scene, stage, ro_s, rd_s, td_s, dmax, tc_s, keep_s,
+            mcfg.mapping_w_color_loss, need_rays, need_dec)
+        if need_dec:
+            scene.dec_flat['color'].grad = g_flat
+        if need_rays:
+            if sel is not None:
+                g_o = torch.zeros_like(ro).index_copy_(0, sel, g_o)
+                g_d = torch.zeros_like(rd).index_copy_(0, sel, g_d)
+            g7 = slam_ops.sample_rays_poses_bwd(sctx, g_o, g_d)
+            for p, g in zip(params, slam_ops.pose_param_grads(g7, layout)):
+                if p.requires_grad:
+                    p.grad = g
+        return loss
+
     fused_iteration = True  # use the fused launches when the batch shape is fixed
+    # mapping iterations as ONE render launch (forward + loss + backward)
+    fused_map_launch = True
     batched_draws = True    # one randint launch for the whole window
 
     @staticmethod

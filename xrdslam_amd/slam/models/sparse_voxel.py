@@ -364,10 +364,16 @@ class SparseVoxel(Model):
             self.s_cap = int(-(-meta[2] * 5 // 4 // 64) * 64)
             grown = True
         if bits & 2:
-            per_ray = -(-int(ws.offs[-1]) // ws.n)
+            per_ray = -(-int(meta[14]) // ws.n)
             self.pts_per_ray = int(-(-per_ray * 5 // 4 // 16) * 16)
             grown = True
         if grown:
+            import warnings
+            warnings.warn(
+                'Vox-Fusion fused ray pipeline: a batch since the last check '
+                f'did not fit the static capacities (bits {bits}); those '
+                'iterations ran on truncated sample rows.  Capacities grown '
+                f'to s_cap={self.s_cap}, pts_per_ray={self.pts_per_ray}.')
             self.capacity_version += 1
             self._workspaces.clear()
             self._last_ws = None
