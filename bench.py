@@ -70,7 +70,7 @@ FWD_FLOPS = {'coarse': 12.4e3, 'middle': 31.0e3, 'fine': 72.0e3,
              'color': 103.0e3}
 
 
-def pmc_traffic(kernels, which='r02_pmc.json'):
+def pmc_traffic(kernels, which='r03_pmc.json'):
     """bytes per launch of a launch group from the committed PMC pass
     (profiles/r02_pmc*.json, made by tools/run_pmc.sh on this same workload):
     sum over the group's kernels of 2 x FETCH_SIZE (gfx950 correction) +
@@ -90,11 +90,18 @@ def pmc_traffic(kernels, which='r02_pmc.json'):
 
 
 def nice_group_kernels(kernel, stage, need_pose, need_dec):
-    """rocprof kernel names behind one xrd_nice_render_fwd/bwd call"""
-    if kernel != 'nice_bwd':
-        return None
+    """rocprof kernel names behind one xrd_nice_render_fwd/bwd call, or one
+    xrd_nice_map_iter call (forward + loss + backward)"""
     dp = 'true' if need_pose else 'false'
     dw = 'true' if (need_dec and stage == 'color') else 'false'
+    if kernel == 'nice_map':
+        if stage == 'coarse':
+            return ['nice_map_coarse_kernel', 'nice_map_coarse_finish_kernel']
+        st = {'middle': 1, 'fine': 2, 'color': 3}[stage]
+        return [f'nice_map_fused<stage={st},NT=3,dp={dp},dw={dw}>',
+                'nice_map_finish_kernel']
+    if kernel != 'nice_bwd':
+        return None
     if stage == 'coarse':
         return ['nice_bwd_coarse_kernel', 'coarse_rep_reduce_kernel']
     st = {'middle': 1, 'fine': 2, 'color': 3}[stage]
@@ -105,8 +112,12 @@ def nice_group_kernels(kernel, stage, need_pose, need_dec):
 
 
 def algorithmic_flops(kernel, stage, n_rays):
+    """unit = one ray-sample point; forward FWD_FLOPS, backward
+    ~2x forward.  'nice_map' = the one-launch mapping iteration: forward +
+    backward of the sample (8d: "fwd+bwd ~ 310 kFLOP" for the colour stage)"""
     S = 32 if stage == 'coarse' else 48
-    return n_rays * S * FWD_FLOPS[stage] * (2.0 if kernel == 'nice_bwd' else 1.0)
+    mult = {'nice_bwd': 2.0, 'nice_map': 3.0}.get(kernel, 1.0)
+    return n_rays * S * FWD_FLOPS[stage] * mult
 
 
 def algorithmic_bytes(kernel, stage, n_rays, grid_grads):
@@ -114,6 +125,9 @@ def algorithmic_bytes(kernel, stage, n_rays, grid_grads):
     per_sample = GRIDS_PER_STAGE[stage] * 8 * 32 * 4
     if kernel == 'nice_bwd' and grid_grads:
         per_sample *= 2  # mapping: cells read + gradient read-modify-write
+    if kernel == 'nice_map':
+        # forward read + (mapping) gradient read-modify-write of the cells
+        per_sample *= 3 if grid_grads else 2
     return n_rays * S * per_sample
 
 
@@ -1231,7 +1245,7 @@ def main():
                                                        need_pose, need_dec))
                         if nice_group_kernels(kernel, stage, need_pose,
                                               need_dec) else None),
-            'traffic_source': 'profiles/r02_pmc.json (rocprofv3 --pmc '
+            'traffic_source': 'profiles/r03_pmc.json (rocprofv3 --pmc '
                               'FETCH_SIZE, WRITE_SIZE passes of this workload;'
                               ' bytes per launch group, FETCH x2 on gfx950)',
             'intensity_flop_per_byte': aflops / abytes,

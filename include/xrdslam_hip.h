@@ -320,6 +320,25 @@ int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
  * capturing launches into a hipGraph */
 int xrd_nice_map_warmup(void);
 
+/* NICE-SLAM frustum feature selection on the device — replaces, per mapping
+ * call, ConvOnet.pre_precessing -> get_mask_from_c2w
+ * (slam/models/conv_onet.py:94-130, slam/model_components/utils.py:298-375:
+ * numpy + cv2.remap on the host) for n_grids <= 4 grids in two launches.
+ * Per grid g: dims_zyx[3g..] = (Z, Y, X); axes[3g + a] = the lattice
+ * coordinates along x, y, z (float32, lengths X, Y, Z: the reference's
+ * torch.linspace of the bound); sampled[g] float [ZYX] scratch; outputs:
+ * mask[g] uint8 [Z][Y][X] (1 = the cell is optimised), cells[g] int32 (room
+ * for ZYX entries; the selected cells in ARBITRARY order), count[g] int32 [1].
+ * c2w: device float[16] row-major camera-to-world; depth: device float
+ * [H, W]; ws: device int32[4] scratch. */
+int xrd_nice_frustum_cells(int n_grids, const int32_t* dims_zyx,
+                           const float* const* axes, const float* c2w,
+                           const float* depth, int H, int W, float fx,
+                           float fy, float cx, float cy,
+                           float* const* sampled, uint8_t* const* mask,
+                           int32_t* const* cells, int32_t* const* count,
+                           int32_t* ws, xrd_stream_t stream);
+
 /* Fused Adam over a subset of 32-float cells of a channel-last grid
  * (frustum feature selection: conv_onet.py:94-130,187-211 optimise
  * val[mask] as a 1-D Parameter and write it back every iteration; here the
@@ -349,6 +368,20 @@ int xrd_adam_cells_devcount(float* param, float* g, float* m, float* v,
                             float beta2, float eps, const int32_t* step_dev,
                             const int32_t* n_cells_dev, int zero_grad,
                             xrd_stream_t stream);
+
+/* xrd_adam_cells with a self-advancing device step counter: step_ticket =
+ * {steps taken so far, ticket (0 between launches)} int32[2]; this launch is
+ * step step_ticket[0] + 1 and its last block to finish stores that number —
+ * replaces the separate increment launch in front of xrd_adam_cells_devstep /
+ * _devcount (the reference: torch.optim.Adam's per-step counter,
+ * slam/engine/optimizers.py:63-171).  n_cells_dev NULL: n_cells is the exact
+ * count; else the capacity, with the valid count read on the device. */
+int xrd_adam_cells_tick(float* param, float* g, float* m, float* v,
+                        const int32_t* cell_idx, int64_t n_cells,
+                        int cell_floats, float lr, float beta1, float beta2,
+                        float eps, int32_t* step_ticket,
+                        const int32_t* n_cells_dev, int zero_grad,
+                        xrd_stream_t stream);
 
 /* one-time set-up of kernel attributes (dynamic LDS sizes); call once per
  * process before capturing launches into a hipGraph */
@@ -807,6 +840,14 @@ int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
                    int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, const int32_t* step_dev,
                    xrd_stream_t stream);
+/* xrd_adam_dense with the self-advancing counter of xrd_adam_cells_tick: this
+ * launch is step step_ticket[0] + 1; advance != 0: its last block stores that
+ * number (the LAST launch of a group of parameters sharing the counter passes
+ * 1, the others 0) */
+int xrd_adam_dense_tick(float* param, const float* grad, float* m, float* v,
+                        int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int32_t* step_ticket,
+                        int advance, xrd_stream_t stream);
 /* keep the pose with the lowest loss (base_algorithm.py:262-265) on device */
 int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
                    float* best_c2w16, uint8_t* valid, xrd_stream_t stream);

@@ -6,7 +6,16 @@ the geometry and colour stages, tracking and mapping losses, all gradients,
 and every random draw (feature initialisation, empty-neighbour features) in
 tests/golden/pointslam_render.npz.
 
-    python oracle/make_golden_pointslam.py
+    python oracle/make_golden_pointslam.py          # the small case
+    python oracle/make_golden_pointslam.py tum      # BASELINE configs[4]
+
+``tum``: the shapes of the reference's point-slam configuration
+(slam/configs/input_config.py:297-340: 1500 tracking rays, 5000 mapping rays,
+5 samples a ray) on a TUM-fr1-like 640x480 camera, with a cloud of > 15 000
+neural points grown over two frames.  Inputs and feature draws are regenerated
+from seeds on both sides (tests/pointslam_golden_util.tum_inputs); the file
+holds the reference's outputs (gradients of the point features as the rows of
+a seeded subset + column sums) -> tests/golden/pointslam_tum.npz.
 """
 import os
 import sys
@@ -142,5 +151,97 @@ def main():
           {k2: float(v.detach()) for k2, v in ld.items()})
 
 
+def main_tum():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import pointslam_golden_util as pg
+    ref_harness.install()
+    sys.modules['faiss'] = faiss_standin.module()
+    import slam.model_components.neural_point_cloud as npc_mod
+    npc_mod.faiss = sys.modules['faiss']
+    from slam.common.camera import Camera
+    from slam.models.conv_onet_pointslam import ConvOnet2, ConvOnet2Config
+    ConvOnet2.load_pretrain = lambda self: None  # LFS pointer only
+    torch.manual_seed(0)
+    model = ConvOnet2(ConvOnet2Config(), Camera(*pg.TUM_CAM))
+    out = {}
+    for k, v in model.decoder.state_dict().items():
+        out[f'dec/{k}'] = v.numpy().copy()
+    out['dec_attr/color_decoder.embedder._B'] = \
+        model.decoder.color_decoder.embedder._B.numpy().copy()
+    gen = torch.Generator().manual_seed(pg.TUM_DRAW_SEED)
+    real_normal = torch.Tensor.normal_
+    shapes = []
+
+    def rec_normal(self, mean=0, std=1, **k):
+        real_normal(self, mean=mean, std=std, generator=gen)
+        shapes.append(tuple(self.shape))
+        return self
+
+    torch.Tensor.normal_ = rec_normal
+    try:
+        for k in range(2):
+            model.model_update(pg.tum_add_inputs(k))
+            npc = model.neural_point_cloud
+            out[f'add{k}/n_cloud'] = np.int64(len(npc._cloud_pos))
+            out[f'add{k}/n_input'] = np.int64(len(npc._input_pos))
+        cloud = np.array(npc._cloud_pos, np.float32)
+        out['cloud_sum'] = cloud.astype(np.float64).sum(0)
+        out['cloud_rows'] = cloud[pg.subset(cloud.shape[0])]
+        fm = pg.tum_frustum_mask(npc.pts_num())
+        model.masked_indices = fm
+        model.get_param_groups()
+        for tag, stage, is_mapping in (('map_geo', 'geometry', True),
+                                       ('map_col', 'color', True),
+                                       ('track', 'color', False)):
+            q = pg.tum_query(is_mapping)
+            for p in model.parameters():
+                p.grad = None
+            npc.geo_feats.grad = npc.col_feats.grad = None
+            ro = q['o'].clone().requires_grad_(True)
+            rd = q['d'].clone().requires_grad_(True)
+            n0 = len(shapes)
+            inp = {'rays_o': ro, 'rays_d': rd, 'target_s': q['color'],
+                   'target_d': q['depth'].reshape(-1, 1), 'stage': stage,
+                   'batch_dynamic_r': q['r']}
+            res = model.get_outputs(inp)
+            ld = model.get_loss_dict(res, inp, is_mapping, stage)
+            sum(ld.values()).backward()
+            out[f'{tag}/n_draws'] = np.int64(len(shapes) - n0)
+            for k2 in ('rgb', 'depth', 'uncertainty', 'valid_ray_mask'):
+                out[f'{tag}/{k2}'] = res[k2].detach().numpy()
+            for k2, v in ld.items():
+                out[f'{tag}/loss_{k2}'] = v.detach().numpy()
+            out[f'{tag}/g_rays_o'] = ro.grad.numpy()
+            out[f'{tag}/g_rays_d'] = rd.grad.numpy()
+            for name, t in (('g_geo', npc.geo_feats.grad),
+                            ('g_col', npc.col_feats.grad)):
+                if t is None:
+                    continue
+                a = t.numpy()
+                out[f'{tag}/{name}/rows'] = a[pg.subset(a.shape[0])].copy()
+                out[f'{tag}/{name}/colsum'] = a.astype(np.float64).sum(0)
+                out[f'{tag}/{name}/abssum'] = np.abs(a.astype(
+                    np.float64)).sum(1)[pg.subset(a.shape[0], 7, 4000)]
+            for k2, p in model.decoder.named_parameters():
+                if p.grad is not None:
+                    out[f'{tag}/g_dec/{k2}'] = p.grad.numpy().copy()
+    finally:
+        torch.Tensor.normal_ = real_normal
+    out['draw_shapes'] = np.array([list(sh) + [0] * (2 - len(sh))
+                                   for sh in shapes], np.int64)
+    path = os.path.join(GOLD, 'pointslam_tum.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB; points',
+          int(out['add0/n_cloud']), '->', int(out['add1/n_cloud']), 'draws',
+          len(shapes), 'valid rays (map_col)',
+          int(out['map_col/valid_ray_mask'].sum()), 'of',
+          out['map_col/valid_ray_mask'].shape[0], '(track)',
+          int(out['track/valid_ray_mask'].sum()),
+          {k2: float(v.detach()) for k2, v in ld.items()})
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'tum':
+        main_tum()
+    else:
+        main()

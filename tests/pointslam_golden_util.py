@@ -10,6 +10,70 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden',
                       'pointslam_render.npz')
 
 
+GOLDEN_TUM = os.path.join(os.path.dirname(__file__), 'golden',
+                          'pointslam_tum.npz')
+# TUM fr1 intrinsics, 640x480
+TUM_CAM = (517.3, 516.5, 318.6, 255.3, 640, 480)
+TUM_DRAW_SEED = 21
+
+
+def subset(n, seed=5, k=2000):
+    """seeded row subset: the TUM-shaped golden stores the rows of the point
+    feature gradients at these indices (+ column sums) instead of 2 MB each"""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randperm(n, generator=g)[:min(k, n)].sort().values.numpy()
+
+
+def _tum_rays(k, n, g):
+    """n pixels of a TUM-fr1-like camera at a desk scene: a desk plane
+    (y = -0.45 below the camera) in front of a wall (z = -2.4), camera k moved
+    by a few centimetres; OpenGL convention (looks down -z)"""
+    fx, fy, cx, cy, W, H = TUM_CAM
+    pix = torch.randint(0, W * H, (n, ), generator=g)
+    col, row = (pix % W).float(), (pix // W).float()
+    d = torch.stack([(col - cx) / fx, -(row - cy) / fy, -torch.ones(n)], -1)
+    o = torch.tensor([0.04 * k, 0.01 * k, 0.03 * k]).repeat(n, 1)
+    t_wall = (-2.4 - o[:, 2]) / d[:, 2]
+    t_desk = torch.where(d[:, 1] < -1e-3, (-0.45 - o[:, 1]) / d[:, 1],
+                         torch.full((n, ), 1e9))
+    t = torch.minimum(t_wall, t_desk)          # depth along -z_cam (|d_z| = 1)
+    depth = t * (1 + 0.005 * torch.randn(n, generator=g))
+    color = torch.rand(n, 3, generator=g)
+    r_add = 0.02 + 0.06 * torch.rand(n, generator=g).double()
+    return o.float(), d.float(), depth.float(), color.float(), r_add
+
+
+def tum_add_inputs(k):
+    """model_update inputs of frame k: pixels_adding = 6000 rays + 1000
+    colour-gradient rays (slam/algorithms/point_slam.py:26,99-126)"""
+    g = torch.Generator().manual_seed(400 + k)
+    o, d, depth, color, r = _tum_rays(k, 6000, g)
+    o2, d2, depth2, color2, r2 = _tum_rays(k, 1000, g)
+    return {'batch_rays_o': o, 'batch_rays_d': d, 'batch_gt_depth': depth,
+            'batch_gt_color': color, 'batch_dynamic_r': r,
+            'batch_rays_o_grad': o2, 'batch_rays_d_grad': d2,
+            'batch_gt_depth_grad': depth2, 'batch_gt_color_grad': color2,
+            'batch_dynamic_r_grad': r2}
+
+
+def tum_frustum_mask(n):
+    fm = torch.ones(n, dtype=torch.bool)
+    fm[::3] = False
+    return fm
+
+
+def tum_query(is_mapping):
+    """the reference batch sizes: 5000 mapping rays / 1500 tracking rays
+    (input_config.py:312-313), 5 samples a ray; some pixels without sensor
+    depth, some rays that look away from every point"""
+    n = 5000 if is_mapping else 1500
+    g = torch.Generator().manual_seed(900 + int(is_mapping))
+    o, d, depth, color, r = _tum_rays(1, n, g)
+    depth[5:40] = 0.0
+    d[n - 60:, 2] = 1.0
+    return {'o': o, 'd': d, 'depth': depth, 'color': color, 'r': 2 * r}
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)

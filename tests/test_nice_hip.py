@@ -398,6 +398,69 @@ def test_adam_cells_matches_torch():
     assert torch.equal(p[mask], p0[mask])
 
 
+def test_fused_dense_adam_matches_torch_incl_skipped_parameters():
+    """FusedDenseAdam (self-advancing device step counters, one launch per
+    parameter or per flat group) against torch.optim.Adam over 7 steps,
+    including a parameter whose grad is None in some steps: torch does not
+    advance a skipped parameter's step (advisor finding, round 2: the shared
+    counter did), and state_dict() reports the same step numbers."""
+    from xrdslam_amd.engine.slam_ops import FusedDenseAdam
+    dev = _cuda()
+    torch.manual_seed(3)
+    shapes = [(7, ), (4, 3), (33, ), (2, 5, 3)]
+    ref = [torch.randn(*sh, device=dev).requires_grad_(True) for sh in shapes]
+    mine = [r.detach().clone().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.Adam(ref, lr=0.02, betas=(0.9, 0.999), eps=1e-8)
+    o_mine = FusedDenseAdam(mine, lr=0.02, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(7):
+        for k, (a, b) in enumerate(zip(ref, mine)):
+            if k == 2 and step in (2, 3, 5):     # stage-gated parameter
+                a.grad = b.grad = None
+                continue
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        o_ref.step()
+        o_mine.step()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, mine):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()
+    sd_r, sd_m = o_ref.state_dict()['state'], o_mine.state_dict()['state']
+    for k in sd_r:
+        assert float(sd_m[k]['step']) == float(sd_r[k]['step']), k
+        assert torch.allclose(sd_m[k]['exp_avg'], sd_r[k]['exp_avg'],
+                              rtol=2e-6, atol=1e-7)
+
+
+def test_fused_cell_adam_self_advancing_counter_matches_torch():
+    """FusedCellAdam through xrd_adam_cells_tick (the kernel advances its own
+    step counter): 5 steps against torch.optim.Adam over val[mask]"""
+    from xrdslam_amd.engine import nice as en
+    from xrdslam_amd.slam.engine.optimizers import FusedCellAdam
+    dev = _cuda()
+    torch.manual_seed(1)
+    p = en.to_channels_last_grid(torch.randn(1, 32, 5, 6, 7, device=dev))
+    p.requires_grad_(True)
+    ncell = 5 * 6 * 7
+    idx = torch.randperm(ncell, device=dev)[:61].int().sort().values
+    cells = p.detach().permute(0, 2, 3, 4, 1).reshape(ncell, 32)
+    p_ref = cells[idx.long()].clone().requires_grad_(True)
+    o_ref = torch.optim.Adam([p_ref], lr=0.01)
+    p._xrd_cells, p._xrd_cells_count = idx, None
+    opt = FusedCellAdam([p], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(5):
+        g = torch.randn(ncell, 32, device=dev)
+        p_ref.grad = g[idx.long()].clone()
+        o_ref.step()
+        p.grad = g.reshape(1, 5, 6, 7, 32).permute(0, 4, 1, 2, 3)
+        assert en._is_cl(p.grad)
+        p._xrd_grad_fresh = True
+        opt.step()
+    torch.cuda.synchronize()
+    assert int(opt._step_dev[0]) == 5 and int(opt._step_dev[1]) == 0
+    got = p.detach().permute(0, 2, 3, 4, 1).reshape(ncell, 32)[idx.long()]
+    assert torch.allclose(got, p_ref.detach(), rtol=1e-5, atol=1e-6)
+
+
 def test_fused_cell_adam_empty_selection_is_noop():
     """a frustum mask that selects no cell of a grid: the reference's Adam over
     an empty ``val[mask]`` does nothing; so must the fused one (zero-sized

@@ -106,6 +106,52 @@ def test_fused_iteration_equals_generic_hooks(is_mapping, step, ba, coarse):
                 assert close(other['dec'], a['dec'], 1e-4)
 
 
+def test_frustum_selection_kernel_matches_the_reference_pinned_mask():
+    """xrd_nice_frustum_cells (two launches for all grids) against
+    frustum_cell_mask, the torch restatement that
+    tests/test_reference_host_parity.py pins cell for cell to the reference's
+    get_mask_from_c2w (utils.py:298-375): byte mask, selected-cell list (any
+    order) and count, at the office0 grid sizes with a 640x480 depth image."""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.common.frame import Frame
+    from xrdslam_amd.slam.configs.input_config import nice_slam_config
+    from xrdslam_amd.slam.models.conv_onet import frustum_cell_mask
+    dev = 'cuda:0'
+    bound = [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]]
+    cam = Camera(320., 320., 319.5, 239.5, 640, 480)
+    algo = nice_slam_config(bound).setup(camera=cam, device=dev)
+    model = algo.model
+    data = SyntheticRoom(bound, H=480, W=640, fx=320., fy=320., cx=319.5,
+                         cy=239.5, n_frames=40, device=dev)
+    for k in (0, 17):
+        d = data[k]
+        f = Frame(k, d['rgb'], d['depth'], init_pose=d['c2w'],
+                  gt_pose=d['c2w'], separate_LR=False, rot_rep='quat',
+                  device=dev)
+        model.scene()
+        model.device_selection = True
+        model.pre_precessing(f)
+        depth_dev, _ = f.device_images(dev)
+        for key, g in model.grid_c.items():
+            if key == 'grid_coarse':
+                assert model.grid_opti_mask[key] is None
+                continue
+            want = frustum_cell_mask(cam, model.bounding_box, f.get_pose(),
+                                     g.shape[2:], depth_dev)
+            got = model.grid_opti_mask[key]
+            st = model._sel_static[key]
+            n = int(st['count'])
+            # a lattice point whose projection lands within rounding of an
+            # image / depth border may fall on either side in two float
+            # evaluations: allow a handful of the ~3e5 cells
+            diff = int((want != got).sum())
+            assert diff <= 3, (key, diff, int(want.sum()))
+            assert 0 < n == int(got.sum())
+            cells = st['cells'][:n].long().sort().values
+            assert torch.equal(cells, got.reshape(-1).nonzero().reshape(-1))
+
+
 def test_graph_replay_matches_eager_tracking():
     algo, frames = make(seed=1)
     algo2, frames2 = make(seed=1)
@@ -207,15 +253,17 @@ def test_persistent_mapping_graphs_match_per_call_graphs():
             'grid_color': segs.count('color'), 'decoder': segs.count('color')}
     for name, n in want.items():
         opt = slot['opt'].optimizers[name]
-        got = int(opt._step_dev) if hasattr(opt, '_step_dev') else \
-            int(next(iter(opt.state.values()))['step'])
+        got = int(opt._step_dev[0]) if hasattr(opt, '_step_dev') else \
+            int(next(iter(opt.state.values()))['step'][0])
         assert got == n, (name, got, n)
     for k in ('grid_middle', 'grid_fine', 'grid_color'):
         st = a.model._sel_static[k]
         mask = a.model.grid_opti_mask[k].reshape(-1)
         assert int(st['count']) == int(mask.sum())
-        assert torch.equal(st['cells'][:int(st['count'])].long(),
-                           mask.nonzero().reshape(-1))
+        # (the device-side selection appends in arbitrary order)
+        assert torch.equal(
+            st['cells'][:int(st['count'])].long().sort().values,
+            mask.nonzero().reshape(-1))
         g_new = a.model.grid_c[k].detach()
         changed = (g_new != grids[k]).permute(0, 2, 3, 4, 1).reshape(
             -1, 32).any(1)                       # per cell, [Z][Y][X] order

@@ -20,10 +20,16 @@ def short_name(name):
     if m:
         return (f'nice_bwd_fused<stage={m.group(1)},NT={m.group(2)},'
                 f'dp={m.group(3)},dw={m.group(4)}>')
+    m = re.search(r'nice_map_fused_kernel<(\d+), (\d+), (\w+), (\w+)>', name)
+    if m:
+        return (f'nice_map_fused<stage={m.group(1)},NT={m.group(2)},'
+                f'dp={m.group(3)},dw={m.group(4)}>')
     m = re.search(r'coslam_bwd_kernel<(\w+), (\w+)>', name)
     if m:
         return f'coslam_bwd<dp={m.group(1)},dg={m.group(2)}>'
-    for k in ('nice_bwd_coarse_kernel', 'nice_bwd_finish_kernel',
+    for k in ('nice_map_coarse_finish_kernel', 'nice_map_coarse_kernel',
+              'nice_map_finish_kernel',
+              'nice_bwd_coarse_kernel', 'nice_bwd_finish_kernel',
               'coarse_rep_reduce_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
               'hash_chunk_scatter_kernel', 'coslam_reduce_kernel',
               'coslam_loss_grad_kernel', 'adam_dense_kernel',

@@ -90,12 +90,17 @@ _SIGS = {
     'xrd_adam_cells_devcount': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int,
                                           f32, f32, f32, f32, vp, vp, C.c_int,
                                           vp]),
+    'xrd_adam_cells_tick': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32,
+                                      f32, f32, f32, vp, vp, C.c_int, vp]),
     'xrd_nice_warmup': (C.c_int, []),
     'xrd_nice_map_ws_floats': (i64, [C.POINTER(NiceScene), C.c_int, C.c_int]),
     'xrd_nice_map_iter': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
                                     vp, vp, vp, vp, vp, vp, f32, vp, vp,
                                     C.POINTER(vp * 4), vp, vp, vp, vp]),
     'xrd_nice_map_warmup': (C.c_int, []),
+    'xrd_nice_frustum_cells': (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int,
+                                         C.c_int, f32, f32, f32, f32, vp, vp,
+                                         vp, vp, vp, vp]),
     'xrd_hashgrid_levels': (C.c_int, [C.c_int, C.c_int, f32, C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp]),
     'xrd_hashgrid_fwd': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, vp, vp,
@@ -176,6 +181,8 @@ _SIGS = {
     'xrd_pose_aa_bwd': (C.c_int, [C.c_int, vp, vp, vp, vp, vp]),
     'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
                                  vp, vp]),
+    'xrd_adam_dense_tick': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32,
+                                      f32, vp, C.c_int, vp]),
     'xrd_track_best': (C.c_int, [vp] * 6),
     'xrd_coslam_flat_len': (C.c_int, []),
     'xrd_coslam_pack_len': (C.c_int, []),

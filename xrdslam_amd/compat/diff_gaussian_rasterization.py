@@ -51,14 +51,23 @@ _CAM_CACHE: "dict[int, tuple]" = {}
 _CAM_CACHE_MAX = 32
 
 
+def _cam_key(rs):
+    """the reference extension reads the settings' tensors on every call: a
+    caller that updates viewmatrix / projmatrix / bg IN PLACE (same
+    NamedTuple) must not keep rendering with the cached host copy"""
+    return tuple((t.data_ptr(), t._version) for t in
+                 (rs.viewmatrix, rs.projmatrix, rs.bg))
+
+
 def _camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
     hit = _CAM_CACHE.get(id(rs))
-    if hit is not None and hit[0] is rs:
+    key = _cam_key(rs)
+    if hit is not None and hit[0] is rs and hit[2] == key:
         return hit[1]
     cam = _build_camera(rs)
     if len(_CAM_CACHE) >= _CAM_CACHE_MAX:
         _CAM_CACHE.pop(next(iter(_CAM_CACHE)))
-    _CAM_CACHE[id(rs)] = (rs, cam)
+    _CAM_CACHE[id(rs)] = (rs, cam, key)
     return cam
 
 
@@ -106,34 +115,59 @@ class _Binning:
     host memory without waiting and read when the NEXT pass sizes its list
     (by then it has long arrived).  The host waits only when there is no
     usable history: first pass, or the number of Gaussians changed by more
-    than 2 % (densification / pruning: once per frame, not per pass)."""
+    than 2 % (densification / pruning: once per frame, not per pass).
+
+    SplaTAM's mapping alternates between views with different pair counts
+    (same Gaussians transformed to the current frame or a keyframe): the
+    capacity is therefore a HIGH-WATER mark — HEADROOM x the largest count
+    seen while the number of Gaussians stayed within 2 % — and never follows
+    a smaller view down.  A pass that still overflows (xrd_gs_bin drops the
+    pairs beyond the capacity) is a hard condition: it is reported with a
+    warning one pass later (the count arrives asynchronously), the capacity
+    grows to fit it, and ``overflowed`` counts it.  ``exact = True`` sizes
+    every pass from its own count with a host sync — what the reference
+    extension does (it reads num_rendered back in every forward)."""
     HEADROOM = 1.3
+    exact = False
 
     def __init__(self):
         self.state = {}
-        self.overflowed = 0     # passes that dropped pairs (diagnostic)
+        self.overflowed = 0     # passes that dropped pairs
 
     def capacity(self, dev, n, tiles):
         key = str(dev)
         st = self.state.get(key)
         total = None
-        if st is not None:
+        if st is not None and not self.exact:
             if st['event'] is not None:
                 st['event'].synchronize()      # previous pass: done long ago
                 st['event'] = None
                 st['last'] = int(st['host'][0])
                 if st['last'] > st['last_cap']:
                     self.overflowed += 1
-            if st['last'] is not None and \
-                    abs(n - st['n']) <= 0.02 * max(st['n'], 1):
-                total = st['last']
+                    import warnings
+                    warnings.warn(
+                        f'Gaussian rasteriser: the previous pass produced '
+                        f'{st["last"]} (Gaussian, tile) pairs for a list of '
+                        f'{st["last_cap"]}: pairs were dropped from its '
+                        'image and gradients.  Capacity raised; set '
+                        'xrdslam_amd.compat.diff_gaussian_rasterization.'
+                        '_BIN.exact = True for a per-pass exact size.')
+            same_n = abs(n - st['n']) <= 0.02 * max(st['n'], 1)
+            if st['last'] is not None and same_n:
+                st['high'] = max(st.get('high', 0), st['last'])
+                total = st['high']
+            else:
+                st['high'] = 0
         if total is None:
             total = int(tiles.sum().item()) if n > 0 else 0   # host sync
+            if st is not None:
+                st['high'] = max(st.get('high', 0), total)
         need = max(int(total * self.HEADROOM) + 1024, 1 << 16)
         if st is None:
             st = self.state[key] = {
                 'cap': need, 'n': n, 'event': None, 'last': None,
-                'last_cap': need, 'ws': None,
+                'last_cap': need, 'ws': None, 'high': total,
                 'host': torch.zeros(1, dtype=torch.int64).pin_memory()}
         if need > st['cap'] or need < st['cap'] // 3:
             st['cap'] = need
@@ -148,10 +182,14 @@ class _Binning:
 
     def report(self, dev, n, cap, n_keys):
         st = self.state[str(dev)]
+        st['n'], st['last_cap'] = n, cap
+        if self.exact:
+            st['event'] = None
+            return
         st['host'].copy_(n_keys, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        st['event'], st['n'], st['last_cap'] = ev, n, cap
+        st['event'] = ev
 
 
 _BIN = _Binning()

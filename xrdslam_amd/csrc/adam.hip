@@ -20,11 +20,15 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, const int32_t* __restrict__ cell_idx,
     int64_t n_cells, int vec_per_cell, float lr, float beta1, float beta2,
-    float eps, int step_host, const int32_t* __restrict__ step_dev,
+    float eps, int step_host, int32_t* __restrict__ step_dev, int tick,
     const int32_t* __restrict__ n_cells_dev, int zero_grad) {
   __shared__ float s_coef[2];
+  // tick != 0: step_dev = {steps taken so far, ticket}; this launch is step
+  // t = step_dev[0] + 1 and the LAST block to finish stores t (every block
+  // has read the counter by then) — no separate increment launch
+  const int t_now = step_dev ? step_dev[0] + (tick ? 1 : 0) : step_host;
   if (threadIdx.x == 0) {
-    const int t = step_dev ? step_dev[0] : step_host;
+    const int t = t_now;
     const double bc1 = 1.0 - pow((double)beta1, (double)t);
     const double bc2 = 1.0 - pow((double)beta2, (double)t);
     s_coef[0] = (float)((double)lr / bc1);
@@ -61,6 +65,14 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
     if (zero_grad)
       *reinterpret_cast<f32x4*>(g + off) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  if (tick) {
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        atomicAdd(step_dev + 1, 1) == (int)gridDim.x - 1) {
+      step_dev[1] = 0;
+      step_dev[0] = t_now;
+    }
+  }
 }
 
 }  // namespace
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(256) void adam_cells_kernel(
 static int adam_launch(float* param, float* g, float* m, float* v,
                        const int32_t* cell_idx, int64_t n_cells,
                        int cell_floats, float lr, float beta1, float beta2,
-                       float eps, int step, const int32_t* step_dev,
+                       float eps, int step, int32_t* step_dev, int tick,
                        const int32_t* n_cells_dev, int zero_grad,
                        xrd_stream_t stream) {
   if (n_cells < 0 || cell_floats <= 0 || (cell_floats & 3) ||
@@ -85,8 +97,8 @@ static int adam_launch(float* param, float* g, float* m, float* v,
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(xrd::adam_cells_kernel, dim3((unsigned)blocks), dim3(256),
                      0, (hipStream_t)stream, param, g, m, v, cell_idx, n_cells,
-                     vec, lr, beta1, beta2, eps, step, step_dev, n_cells_dev,
-                     zero_grad);
+                     vec, lr, beta1, beta2, eps, step, step_dev, tick,
+                     n_cells_dev, zero_grad);
   return xrd::check_launch("xrd_adam_cells");
 }
 
@@ -96,7 +108,7 @@ extern "C" int xrd_adam_cells(float* param, float* g, float* m, float* v,
                               float beta2, float eps, int step, int zero_grad,
                               xrd_stream_t stream) {
   return adam_launch(param, g, m, v, cell_idx, n_cells, cell_floats, lr, beta1,
-                     beta2, eps, step, nullptr, nullptr, zero_grad, stream);
+                     beta2, eps, step, nullptr, 0, nullptr, zero_grad, stream);
 }
 
 extern "C" int xrd_adam_cells_devstep(float* param, float* g, float* m,
@@ -107,7 +119,8 @@ extern "C" int xrd_adam_cells_devstep(float* param, float* g, float* m,
                                       int zero_grad, xrd_stream_t stream) {
   if (!step_dev) return XRD_ERR_ARG;
   return adam_launch(param, g, m, v, cell_idx, n_cells, cell_floats, lr, beta1,
-                     beta2, eps, 0, step_dev, nullptr, zero_grad, stream);
+                     beta2, eps, 0, const_cast<int32_t*>(step_dev), 0, nullptr,
+                     zero_grad, stream);
 }
 
 extern "C" int xrd_adam_cells_devcount(float* param, float* g, float* m,
@@ -119,6 +132,19 @@ extern "C" int xrd_adam_cells_devcount(float* param, float* g, float* m,
                                        int zero_grad, xrd_stream_t stream) {
   if (!step_dev || !n_cells_dev || !cell_idx) return XRD_ERR_ARG;
   return adam_launch(param, g, m, v, cell_idx, capacity, cell_floats, lr,
-                     beta1, beta2, eps, 0, step_dev, n_cells_dev, zero_grad,
+                     beta1, beta2, eps, 0, const_cast<int32_t*>(step_dev), 0,
+                     n_cells_dev, zero_grad, stream);
+}
+
+extern "C" int xrd_adam_cells_tick(float* param, float* g, float* m, float* v,
+                                   const int32_t* cell_idx, int64_t n_cells,
+                                   int cell_floats, float lr, float beta1,
+                                   float beta2, float eps,
+                                   int32_t* step_ticket,
+                                   const int32_t* n_cells_dev, int zero_grad,
+                                   xrd_stream_t stream) {
+  if (!step_ticket || (n_cells_dev && !cell_idx)) return XRD_ERR_ARG;
+  return adam_launch(param, g, m, v, cell_idx, n_cells, cell_floats, lr, beta1,
+                     beta2, eps, 0, step_ticket, 2, n_cells_dev, zero_grad,
                      stream);
 }

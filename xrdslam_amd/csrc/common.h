@@ -68,6 +68,20 @@ __device__ __forceinline__ float group4_sum(float v) {
   v += __shfl_xor(v, 32);
   return v;
 }
+// sum over the 16 lanes of a row (same l>>4) on DPP (full-rate VALU, no LDS
+// crossbar round trips): every lane of the row gets the row's sum
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+#define XRD_DPP_ADD(CTRL)                                                     \
+  v += __builtin_bit_cast(                                                    \
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, \
+                                         0xf, 0xf, false))
+  XRD_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+  XRD_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+  XRD_DPP_ADD(0x141);  // row_half_mirror
+  XRD_DPP_ADD(0x140);  // row_mirror
+#undef XRD_DPP_ADD
+  return v;
+}
 // sum over the 16 lanes of a row (same l>>4)
 __device__ __forceinline__ float row16_sum(float v) {
 #pragma unroll

@@ -202,9 +202,8 @@ __device__ __forceinline__ float embed_arg(const float (&p)[3], const f32x4 b) {
 }
 
 // EMIT_H: the layer outputs h_0..h_4 are written to ``hsc`` as five
-// feature-major matrices [32 features][16 points] (512 floats each), followed
-// by the Fourier features sin(p.B) [96][16]: the operand layout of the
-// deferred weight-gradient contraction (nice_map.hip)
+// feature-major matrices [32 features][16 points] (512 floats each): the
+// operand layout of the deferred weight-gradient contraction (nice_map.hip)
 template <int NT, int CD, int OD, bool SAVE_MASK, bool SAVE_H,
           bool EMIT_H = false>
 __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
@@ -247,9 +246,6 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float e = sin_cw(embed_arg(p[t], bk));
-      // EMIT_H: Fourier features as a feature-major matrix [96][16] behind
-      // the five h matrices
-      if (EMIT_H) hsc[5 * 512 + emap(s, q) * 16 + (lane & 15)] = e;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         acc[t][jt] = XRD_MFMA4(a0[jt], e, acc[t][jt]);

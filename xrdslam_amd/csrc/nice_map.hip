@@ -24,7 +24,7 @@
 // registers = 2 waves per SIMD, +170 us).  Here the tile waves stay as light
 // as the variant without weight gradients: while a tile goes forward /
 // backward it drops the contraction's operands (c, h_0..h_4, dL/dh_0..4,
-// ReLU masks, Fourier features: 30 KB a tile) into a per-tile scratch as
+// ReLU masks, positions: 23 KB a tile) into a per-tile scratch as
 // feature-major matrices [32 features][16 points], and after the last decoder
 // of the group the block's 12 waves contract the group's 12 tiles — 62 16x16
 // blocks as 25 units that share their A / B operands, 4-6 accumulators a wave,
@@ -32,7 +32,7 @@
 // and add their blocks to one of 8 replicas.  embedder._B (3 x 93) is reduced
 // on the VALU (row reductions + LDS adds) instead of 6 padded MFMA blocks.
 // The scratch is written and read once by the same CU a few microseconds
-// apart (L2 / Infinity-Cache traffic, 89 MB at 1000 rays).
+// apart (L2 / Infinity-Cache traffic, 71 MB at 1000 rays).
 // Reference maths restated (never copied): conv_onet.py:339-524 (sampling,
 // eval_points, the stage's decoders), decoder_nice.py:103-234,
 // utils.py:189-244 (raw2outputs_nerf_color), conv_onet.py:145-185 (losses).
@@ -116,12 +116,11 @@ __device__ __forceinline__ void map_composite(
 // (floats): feature-major matrices M[f][pt] = 512 floats
 constexpr int SC_C = 0;                 // grid features c
 constexpr int SC_H = 512;               // h_0..h_4
-constexpr int SC_E = SC_H + 5 * 512;    // sin(p.B) [96][16] (rows >= 93: 0)
-constexpr int SC_G = SC_E + 96 * 16;    // dL/dh_0..4 (gh_i)
+constexpr int SC_G = SC_H + 5 * 512;    // dL/dh_0..4 (gh_i)
 constexpr int SC_M = SC_G + 5 * 512;    // ReLU masks: [5][32] words, bit = pt
 constexpr int SC_P = SC_M + 160;        // positions [16][4]
 constexpr int SC_GO = SC_P + 64;        // dL/d decoder output [16][4]
-constexpr int SC_TILE = SC_GO + 64;     // 7456 floats = 29 824 B
+constexpr int SC_TILE = SC_GO + 64;     // 5920 floats = 23 680 B
 static_assert(SC_TILE % 4 == 0, "16-byte aligned tiles");
 
 // write a D-layout register pair (features 16jt+4q+r of point li) to a
@@ -143,11 +142,15 @@ template <bool NEED_DP>
 __device__ __forceinline__ void color_bwd_emit(
     const float* __restrict__ w, int lane, const float (&p)[1][3],
     const float (&go)[1][4], uint64_t mask, float* __restrict__ tsc,
-    float* __restrict__ embB, f32x4 (&gc)[1][2], float (&gp)[1][3]) {
+    float* __restrict__ embB, float* __restrict__ park,
+    f32x4 (&gc)[1][2], float (&gp)[1][3]) {
   using P = MlpPack<32, 4>;
   const int q = lane >> 4, li = lane & 15;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 gh[2] = {z4, z4}, ga[2] = {z4, z4}, ga3[2] = {z4, z4};
+  // ga_3 waits for the embedding backward in the wave's LDS scatter tile
+  // (park, 512 floats, idle until grid_scatter) instead of 8 registers held
+  // across three layers
+  f32x4 gh[2] = {z4, z4}, ga[2] = {z4, z4};
   gc[0][0] = z4;
   gc[0][1] = z4;
   if (q == 0) {
@@ -190,8 +193,8 @@ __device__ __forceinline__ void color_bwd_emit(
       }
     XRD_SB();
     if (i == 3) {
-      ga3[0] = ga[0];
-      ga3[1] = ga[1];
+      *reinterpret_cast<f32x4*>(park + lane * 8) = ga[0];
+      *reinterpret_cast<f32x4*>(park + lane * 8 + 4) = ga[1];
     }
     if (i >= 1) {
       f32x4 gprev[2] = {z4, z4};
@@ -209,6 +212,8 @@ __device__ __forceinline__ void color_bwd_emit(
   }
   // ga holds the masked ga_0.  d loss / d sin(p.B) = W0^T ga0 + W3e^T ga3,
   // through the sine; lane group q owns feature k = emap(4kt+r, q)
+  const f32x4 ga3[2] = {*reinterpret_cast<const f32x4*>(park + lane * 8),
+                        *reinterpret_cast<const f32x4*>(park + lane * 8 + 4)};
 #pragma unroll 1
   for (int kt = 0; kt < 6; ++kt) {
     f32x4 ge = z4;
@@ -228,7 +233,7 @@ __device__ __forceinline__ void color_bwd_emit(
       for (int a = 0; a < 3; ++a) {
         if (NEED_DP) gp[0][a] += garg * bk[a];
         // embedder._B[a][k] += sum over the tile's points of p_a * garg
-        const float v = row16_sum(p[0][a] * garg);
+        const float v = row16_sum_dpp(p[0][a] * garg);
         if (li == 0 && k < kEmbK) atomicAdd(embB + a * 96 + k, v);
       }
     }
@@ -257,8 +262,19 @@ __device__ __forceinline__ f32x4 mask4(f32x4 a, const float* __restrict__ T,
 // per XCD are in flight (L2: 4 MB): most loads come back from the Infinity
 // Cache (~1-2 us).  Every unit therefore issues the loads of a CHUNK of tiles
 // before its first MFMA (6 tiles: 72 registers in flight) instead of one tile
-// at a time (measured: 12 dependent round trips a unit, +120 us a launch).
+// at a time.  Measured (profiles/r03_nice_map_timing.txt): the launch time
+// follows the scratch VOLUME (~13 us per 1000 floats a tile: writing the
+// Fourier features out instead of recomputing their sines cost +19 us), not
+// the number of dependent round trips.
 //
+// A block adds its weight-gradient blocks to ITS row of a [blocks][flat]
+// partial buffer with plain loads and stores (nobody else touches the row; the
+// finishing launch sums the rows): measured, the same adds as float atomics
+// into 8 shared replicas cost 29 us a launch.
+__device__ __forceinline__ void padd(float* __restrict__ p, float v) {
+  *p += v;
+}
+
 // unit u of the 18 layer units: u < 10: fc_c.i (i = u >> 1), rows jt = u & 1,
 // A = gh_i, B = c; else pts_linears.i hidden part (i = 1 + ((u - 10) >> 1)),
 // A = ga_i = masked gh_i, B = h_{i-1}.  Both column tiles, the bias rows.
@@ -266,7 +282,7 @@ __device__ __forceinline__ void dwb_layer_unit(
     const float* __restrict__ scr, int ntiles, int u, int lane,
     float* __restrict__ rep) {
   using F = MlpFlat<32, 4>;
-  constexpr int CH = 6;
+  constexpr int CH = 2;
   const int m = lane & 15, q = lane >> 4;
   const bool hid = u >= 10;
   const int i = hid ? 1 + ((u - 10) >> 1) : (u >> 1), jt = u & 1;
@@ -304,36 +320,39 @@ __device__ __forceinline__ void dwb_layer_unit(
     const int j = 16 * jt + 4 * q + r;
     float* dst = hid ? rep + F::pw(i) + j * F::pstride(i) + F::pcol(i)
                      : rep + F::fcw(i) + j * 32;
-    atomicAdd(dst + m, acc0[r]);
-    atomicAdd(dst + 16 + m, acc1[r]);
+    padd(dst + m, acc0[r]);
+    padd(dst + 16 + m, acc1[r]);
   }
   const float b = group4_sum(bias);
-  if (q == 0) atomicAdd(rep + (hid ? F::pb(i) : F::fcb(i)) + 16 * jt + m, b);
+  if (q == 0) padd(rep + (hid ? F::pb(i) : F::fcb(i)) + 16 * jt + m, b);
 }
 
 // Fourier parts of pts_linears.0 / .3, column tile kt6 (features 16kt6+m of
-// sin(p.B), left in the scratch by the forward): A = ga_0 / ga_3, both row
-// tiles = 4 blocks sharing one B.  kt6 == 0 also carries pts_linears.0.bias =
-// sum ga_0.
+// sin(p.B), recomputed): A = ga_0 / ga_3, both row tiles = 4 blocks sharing
+// one B.  kt6 == 0 also carries pts_linears.0.bias = sum ga_0.
 __device__ __forceinline__ void dwb_fourier_unit(
     const float* __restrict__ scr, int ntiles, int kt6, int lane,
-    float* __restrict__ rep) {
+    const float* __restrict__ dec, float* __restrict__ rep) {
   using F = MlpFlat<32, 4>;
-  constexpr int CH = 3;
+  using P = MlpPack<32, 4>;
+  constexpr int CH = 2;
   const int m = lane & 15, q = lane >> 4;
   const int k = 16 * kt6 + m;
+  const f32x4 bk = *reinterpret_cast<const f32x4*>(dec + P::EMB + k * 4);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4] = {z4, z4, z4, z4};
   float b0 = 0.f, b1 = 0.f;
 #pragma unroll 1
   for (int t0 = 0; t0 < ntiles; t0 += CH) {
-    f32x4 e[CH], a00[CH], a01[CH], a30[CH], a31[CH];
+    f32x4 pp[CH][4], a00[CH], a01[CH], a30[CH], a31[CH];
     uint32_t m00[CH], m01[CH], m30[CH], m31[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const bool live = t0 + c < ntiles;
       const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
-      e[c] = ldm(T + SC_E, k, q);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        pp[c][s] = *reinterpret_cast<const f32x4*>(T + SC_P + (4 * q + s) * 4);
       a00[c] = ldm(T + SC_G, m, q);
       a01[c] = ldm(T + SC_G, 16 + m, q);
       a30[c] = ldm(T + SC_G + 3 * 512, m, q);
@@ -349,14 +368,16 @@ __device__ __forceinline__ void dwb_fourier_unit(
     for (int c = 0; c < CH; ++c)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        const float pv[3] = {pp[c][s][0], pp[c][s][1], pp[c][s][2]};
+        const float e = sin_cw(embed_arg(pv, bk));
         const float v00 = ((m00[c] >> s) & 1u) ? a00[c][s] : 0.f;
         const float v01 = ((m01[c] >> s) & 1u) ? a01[c][s] : 0.f;
         const float v30 = ((m30[c] >> s) & 1u) ? a30[c][s] : 0.f;
         const float v31 = ((m31[c] >> s) & 1u) ? a31[c][s] : 0.f;
-        acc[0] = XRD_MFMA4(v00, e[c][s], acc[0]);
-        acc[1] = XRD_MFMA4(v01, e[c][s], acc[1]);
-        acc[2] = XRD_MFMA4(v30, e[c][s], acc[2]);
-        acc[3] = XRD_MFMA4(v31, e[c][s], acc[3]);
+        acc[0] = XRD_MFMA4(v00, e, acc[0]);
+        acc[1] = XRD_MFMA4(v01, e, acc[1]);
+        acc[2] = XRD_MFMA4(v30, e, acc[2]);
+        acc[3] = XRD_MFMA4(v31, e, acc[3]);
         b0 += v00;
         b1 += v01;
       }
@@ -367,15 +388,15 @@ __device__ __forceinline__ void dwb_fourier_unit(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jt + 4 * q + r;
-        atomicAdd(rep + F::P0W + j * kEmbK + k, acc[jt][r]);
-        atomicAdd(rep + F::P3W + j * (kEmbK + 32) + k, acc[2 + jt][r]);
+        padd(rep + F::P0W + j * kEmbK + k, acc[jt][r]);
+        padd(rep + F::P3W + j * (kEmbK + 32) + k, acc[2 + jt][r]);
       }
   }
   if (kt6 == 0) {
     const float s0 = group4_sum(b0), s1 = group4_sum(b1);
     if (q == 0) {
-      atomicAdd(rep + F::P0B + m, s0);
-      atomicAdd(rep + F::P0B + 16 + m, s1);
+      padd(rep + F::P0B + m, s0);
+      padd(rep + F::P0B + 16 + m, s1);
     }
   }
 }
@@ -385,7 +406,7 @@ __device__ __forceinline__ void dwb_output_unit(
     const float* __restrict__ scr, int ntiles, int lane,
     float* __restrict__ rep) {
   using F = MlpFlat<32, 4>;
-  constexpr int CH = 6;
+  constexpr int CH = 2;
   const int m = lane & 15, q = lane >> 4;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   float bout = 0.f;
@@ -415,12 +436,12 @@ __device__ __forceinline__ void dwb_output_unit(
   if (q == 0) {  // rows 0..3 of the accumulator = lane group 0
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(rep + F::OW + r * 32 + m, acc0[r]);
-      atomicAdd(rep + F::OW + r * 32 + 16 + m, acc1[r]);
+      padd(rep + F::OW + r * 32 + m, acc0[r]);
+      padd(rep + F::OW + r * 32 + 16 + m, acc1[r]);
     }
   }
   const float b = group4_sum(bout);
-  if (q == 0 && m < 4) atomicAdd(rep + F::OB + m, b);
+  if (q == 0 && m < 4) padd(rep + F::OB + m, b);
 }
 
 // the 25 units over the 12 waves of a block (MFMAs per tile: layer unit 8,
@@ -428,9 +449,10 @@ __device__ __forceinline__ void dwb_output_unit(
 // waves 6..11 two layer units, wave 6 also the output unit
 __device__ __forceinline__ void dw_contract(const float* __restrict__ scr,
                                             int ntiles, int wave, int lane,
+                                            const float* __restrict__ dec,
                                             float* __restrict__ rep) {
   if (wave < 6) {
-    dwb_fourier_unit(scr, ntiles, wave, lane, rep);
+    dwb_fourier_unit(scr, ntiles, wave, lane, dec, rep);
     dwb_layer_unit(scr, ntiles, wave, lane, rep);
   } else {
     dwb_layer_unit(scr, ntiles, 6 + 2 * (wave - 6), lane, rep);
@@ -599,7 +621,7 @@ nice_map_fused_kernel(
       if (NEED_DW) {
         if (active)
           color_bwd_emit<NEED_DP>(wl - PC::EMB, lane, p32, go, mask_c[0], tsc,
-                                  embB, gc, gp32);
+                                  embB, SL.gt, gc, gp32);
       } else if (active) {
         mlp_bwd<1, 32, 4, NEED_DP, NEED_DP>(wl - PC::EMB, lane, p32, c_c, go,
                                             mask_c, gc, gp32);
@@ -640,9 +662,12 @@ nice_map_fused_kernel(
       }
     }
     if (NEED_DW) {
-      // every tile of the group has left its operands in the scratch
-      // (written by this CU, read once, never read before: no stale L1 line)
-      __threadfence();
+      // every tile of the group has left its operands in the scratch.
+      // Writers and readers are waves of ONE workgroup: the block barrier's
+      // workgroup-scope release / acquire is enough (the lines were never
+      // read before: no stale L1 copy).  An agent-scope __threadfence() here
+      // makes every block write its XCD's dirty L2 lines back (the L2s of the
+      // 8 XCDs are not coherent with each other): measured +55 us a launch.
       __syncthreads();
       const int rays_here = n - grp * G::RPBM < G::RPBM ? n - grp * G::RPBM
                                                           : G::RPBM;
@@ -650,8 +675,8 @@ nice_map_fused_kernel(
       asm volatile("" : "+v"(lane_b));  // keep the contraction's address
       // arithmetic inside the group loop (no hoisting into live registers)
       dw_contract(dw_scr + (size_t)grp * G::NW * SC_TILE, rays_here * NT, wave,
-                  lane_b,
-                  dw_rep + (size_t)(blockIdx.x % kDwRep) * kColorFlat);
+                  lane_b, sc.dec[3],
+                  dw_rep + (size_t)blockIdx.x * kColorFlat);
     }
     if (NEED_DP && active) {
       const int tile_id = ray * NT + tile;
@@ -668,11 +693,10 @@ nice_map_fused_kernel(
   }
   if (NEED_DW) {
     __syncthreads();  // the LDS sums of embedder._B are complete
-    float* rep = dw_rep + (size_t)(blockIdx.x % kDwRep) * kColorFlat;
+    float* rep = dw_rep + (size_t)blockIdx.x * kColorFlat;
     for (int i = threadIdx.x; i < 288; i += blockDim.x) {
       const int a = i / 96, k = i % 96;
-      if (k < kEmbK && embB[i] != 0.f)
-        atomicAdd(rep + MlpFlat<32, 4>::EB + a * kEmbK + k, embB[i]);
+      if (k < kEmbK) rep[MlpFlat<32, 4>::EB + a * kEmbK + k] += embB[i];
     }
   }
 }
@@ -735,16 +759,18 @@ __global__ __launch_bounds__(2 * 64, 2) void nice_map_coarse_kernel(
   }
 }
 
-// after the fused launch: decoder gradient = sum of the replicas (left zeroed
-// for the next call), ray gradients = sum of the ray's tile partials in a
-// fixed order, loss = sum of the per-ray losses (last block)
+// after the fused launch: decoder gradient = sum of the blocks' partial rows
+// (left zeroed for the next call: 64 columns a block, the rows split over its
+// four waves), ray gradients = sum of the ray's tile partials in a fixed
+// order, loss = sum of the per-ray losses (last block)
 __global__ __launch_bounds__(256) void nice_map_finish_kernel(
-    float* __restrict__ rep, int len, float* __restrict__ g_dec,
-    const double* __restrict__ part, int n_dp, int nt,
-    float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
+    float* __restrict__ rep, int n_rep, int len, int dec_blocks,
+    float* __restrict__ g_dec, const double* __restrict__ part, int n_dp,
+    int nt, float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
     const double* __restrict__ ray_loss, int n, double* __restrict__ loss) {
+  __shared__ double sh[4];
+  __shared__ float shf[4][64];
   if (blockIdx.x == gridDim.x - 1) {
-    __shared__ double sh[4];
     double s = 0.0;
     if (ray_loss != nullptr)
       for (int i = threadIdx.x; i < n; i += 256) s += ray_loss[i];
@@ -755,18 +781,24 @@ __global__ __launch_bounds__(256) void nice_map_finish_kernel(
       loss[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
     return;
   }
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < len) {
+  if ((int)blockIdx.x < dec_blocks) {
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
     float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < kDwRep; ++r) {
-      s += rep[(size_t)r * len + i];
-      rep[(size_t)r * len + i] = 0.f;
+    if (i < len) {
+#pragma unroll 4
+      for (int r = w; r < n_rep; r += 4) {
+        s += rep[(size_t)r * len + i];
+        rep[(size_t)r * len + i] = 0.f;
+      }
     }
-    g_dec[i] = s;
+    shf[w][c] = s;
+    __syncthreads();
+    if (w == 0 && i < len)
+      g_dec[i] = (shf[0][c] + shf[1][c]) + (shf[2][c] + shf[3][c]);
     return;
   }
-  const int j = i - len;
+  const int j = ((int)blockIdx.x - dec_blocks) * 256 + threadIdx.x;
   if (j >= n_dp * 6) return;
   const int ray = j / 6, a = j % 6;
   double s = 0.0;
@@ -874,10 +906,10 @@ int64_t xrd_nice_map_ws_floats(const xrd_nice_scene* scene, int stage,
     return 2 * (int64_t)n_rays + 4 +
            (int64_t)kCoarseRep * scene->gdim[0] * scene->gdim[1] *
                scene->gdim[2] * 32;
-  // [n*3][6] f64 tile partials | [n] f64 ray losses | dW replicas | (colour
+  // [n*3][6] f64 tile partials | [n] f64 ray losses | the blocks' dW rows | (colour
   // stage) the contraction's operand scratch, one tile slot per wave and group
   int64_t need = (int64_t)n_rays * 3 * 6 * 2 + 2 * (int64_t)n_rays + 4 +
-                 (int64_t)kDwRep * kColorFlat;
+                 (int64_t)kMapBlocks * kColorFlat;
   need = (need + 3) / 4 * 4;
   if (stage == XRD_STAGE_COLOR)
     need += ((int64_t)n_rays + 3) / 4 * 12 * SC_TILE;
@@ -938,15 +970,19 @@ int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
   const size_t rep_off = (size_t)n_rays * 3 * 6 * 2 + 2 * (size_t)n_rays + 4;
   float* dw_rep = ws + rep_off;
   float* dw_scr =
-      ws + (rep_off + (size_t)kDwRep * kColorFlat + 3) / 4 * 4;
+      ws + (rep_off + (size_t)kMapBlocks * kColorFlat + 3) / 4 * 4;
   int rc = map_dispatch(stage, dp, dw, scene, n_rays, rays_o, rays_d, gt_depth,
                         dmax, tgt_rgb, keep, w_color, gg, part, dw_rep, dw_scr,
                         ray_loss, st);
   if (rc != XRD_OK) return rc;
   const int len = dw ? kColorFlat : 0;
-  const int total = len + (dp ? n_rays * 6 : 0);
-  hipLaunchKernelGGL(nice_map_finish_kernel, dim3((total + 255) / 256 + 1),
-                     dim3(256), 0, st, dw_rep, len, g_dec_color, part,
+  const int ngroups_map = (n_rays + 3) / 4;   // MapGeom::RPBM rays a group
+  const int nb_map = ngroups_map < kMapBlocks ? ngroups_map : kMapBlocks;
+  const int dec_blocks = (len + 63) / 64;
+  const int ray_blocks = dp ? (n_rays * 6 + 255) / 256 : 0;
+  hipLaunchKernelGGL(nice_map_finish_kernel,
+                     dim3(dec_blocks + ray_blocks + 1), dim3(256), 0, st,
+                     dw_rep, nb_map, len, dec_blocks, g_dec_color, part,
                      dp ? n_rays : 0, 3, g_rays_o, g_rays_d, ray_loss, n_rays,
                      loss);
   return check_launch("xrd_nice_map_iter/finish");

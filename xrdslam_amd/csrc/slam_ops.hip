@@ -374,10 +374,15 @@ __global__ __launch_bounds__(256) void sample_rays_multi_bwd_kernel(
 __global__ __launch_bounds__(256) void adam_dense_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-    float wd, const int32_t* __restrict__ step_dev) {
+    float wd, int32_t* __restrict__ step_dev, int tick) {
   __shared__ float coef[2];
+  // tick: 0 = step_dev[0] is this step's number (incremented by the caller);
+  // 1 = this step is step_dev[0] + 1; 2 = same, and the last block to finish
+  // stores it (step_dev = {steps taken, ticket}): the last launch of a group
+  // of parameters that share the counter advances it
+  const int t_now = step_dev[0] + (tick ? 1 : 0);
   if (threadIdx.x == 0) {
-    const int t = step_dev[0];
+    const int t = t_now;
     coef[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
     coef[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
   }
@@ -391,6 +396,14 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(
     m[i] = mi;
     v[i] = vi;
     p[i] = p[i] - coef[0] * (mi / (sqrtf(vi) * coef[1] + eps));
+  }
+  if (tick == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        atomicAdd(step_dev + 1, 1) == (int)gridDim.x - 1) {
+      step_dev[1] = 0;
+      step_dev[0] = t_now;
+    }
   }
 }
 
@@ -760,8 +773,24 @@ int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, step_dev);
+                     beta2, eps, weight_decay, const_cast<int32_t*>(step_dev),
+                     0);
   return check_launch("xrd_adam_dense");
+}
+
+int xrd_adam_dense_tick(float* param, const float* grad, float* m, float* v,
+                        int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int32_t* step_ticket,
+                        int advance, xrd_stream_t stream) {
+  if (n < 0 || !step_ticket) return XRD_ERR_ARG;
+  if (n == 0) return XRD_OK;
+  if (!param || !grad || !m || !v) return XRD_ERR_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, step_ticket, advance ? 2 : 1);
+  return check_launch("xrd_adam_dense_tick");
 }
 
 int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,

@@ -411,6 +411,63 @@ def nice_map_iter(scene: NiceScene, stage: str, rays_o: torch.Tensor,
 
 
 @torch.no_grad()
+def nice_track_iter(scene: NiceScene, rays_o: torch.Tensor,
+                    rays_d: torch.Tensor, gt_depth: torch.Tensor,
+                    dmax: Optional[torch.Tensor], tgt_rgb: torch.Tensor,
+                    keep: Optional[torch.Tensor], use_color: bool,
+                    handle_dynamic: bool, w_color: float):
+    """One TRACKING iteration (colour stage) without autograd: forward render,
+    the robust tracking loss of conv_onet.py:145-176 (its batch median needs
+    the whole batch: a launch of its own) and the backward to the rays — the
+    launches of nice_render + NiceLossFn + backward, minus the ~10 torch fill /
+    scale / clone kernels autograd wraps around them.  Returns
+    (loss f64 [], g_rays_o, g_rays_d)."""
+    lib = _lib.lib()
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    if not rays_o.is_cuda:
+        raise _lib.XrdError('nice_track_iter needs CUDA tensors (no CPU '
+                            'fallback)')
+    rays_o = rays_o.detach().float().contiguous()
+    rays_d = rays_d.detach().float().contiguous()
+    gd = gt_depth.detach().float().reshape(-1).contiguous()
+    tc = tgt_rgb.detach().float().contiguous()
+    dm = (dmax.detach().float().reshape(1) if dmax is not None
+          else gd.max().reshape(1))
+    S = scene.n_total('color', True)
+    f64 = dict(dtype=torch.float64, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    depth, var = torch.empty(n, **f64), torch.empty(n, **f64)
+    rgb, raw = torch.empty(n, 3, **f32), torch.empty(n, S, 4, **f32)
+    loss, g_dep = torch.empty((), **f64), torch.empty(n, **f64)
+    g_rgb = torch.empty(n, 3, **f32)
+    g_o, g_d = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+    ws = torch.empty(lib.xrd_nice_bwd_ws_floats(n), **f32)
+    cs = scene.c_struct()
+    st = _lib.stream_ptr(dev)
+    with _Timed(('nice_fwd', 'color', n, False, False, False)):
+        _lib.check(lib.xrd_nice_render_fwd(
+            C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
+            _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(depth),
+            _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(raw), st),
+            'xrd_nice_render_fwd')
+    _lib.check(lib.xrd_nice_loss(
+        n, 0, int(use_color), int(handle_dynamic), float(w_color),
+        _lib.ptr(depth), _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(gd),
+        _lib.ptr(tc), _lib.ptr(keep), _lib.ptr(loss), _lib.ptr(g_dep),
+        _lib.ptr(g_rgb), st), 'xrd_nice_loss')
+    gg, gdec = (C.c_void_p * 4)(), (C.c_void_p * 4)()
+    with _Timed(('nice_bwd', 'color', n, True, False, False)):
+        _lib.check(lib.xrd_nice_render_bwd(
+            C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
+            _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(raw),
+            _lib.ptr(g_dep), None, _lib.ptr(g_rgb), _lib.ptr(g_o),
+            _lib.ptr(g_d), C.byref(gg), C.byref(gdec), _lib.ptr(ws), st),
+            'xrd_nice_render_bwd')
+    return loss, g_o, g_d
+
+
+@torch.no_grad()
 def nice_eval_points(scene: NiceScene, stage: str,
                      points: torch.Tensor) -> torch.Tensor:
     """decoder values at free points, [n,3] -> raw [n,4] = (rgb raw or 0,

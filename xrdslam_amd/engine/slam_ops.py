@@ -285,7 +285,7 @@ class FusedDenseAdam(torch.optim.Optimizer):
         sd = super().state_dict()
         for st in sd['state'].values():
             if 'step' in st:
-                st['step'] = st['step'].detach().reshape(()).float().cpu()
+                st['step'] = st['step'].detach()[0].float().cpu()
             for k in ('exp_avg', 'exp_avg_sq'):
                 if k in st:
                     st[k] = st[k].detach().clone()
@@ -298,8 +298,9 @@ class FusedDenseAdam(torch.optim.Optimizer):
             if 'step' in st:
                 v = st['step']
                 v = int(v.item()) if torch.is_tensor(v) else int(v)
-                st['step'] = torch.full((1, ), v, dtype=torch.int32,
-                                        device=p.device)
+                st['step'] = torch.tensor([v, 0], dtype=torch.int32,
+                                          device=p.device)
+                st['step']._xrd_members = [p]
             for k in ('exp_avg', 'exp_avg_sq'):
                 if k in st:
                     st[k] = st[k].to(p.device, torch.float32).contiguous()
@@ -327,9 +328,11 @@ class FusedDenseAdam(torch.optim.Optimizer):
             fresh = [p for p in live if not self.state[p]]
             if fresh:
                 # parameters that start together share one device-side step
-                # counter (one increment launch instead of one each)
-                step = torch.zeros(1, dtype=torch.int32,
+                # counter {steps taken, ticket}; the last launch of the group
+                # advances it (xrd_adam_dense_tick)
+                step = torch.zeros(2, dtype=torch.int32,
                                    device=fresh[0].device)
+                step._xrd_members = list(fresh)
                 flat = len(fresh) > 1 and self._consecutive(fresh)
                 if flat:
                     n = sum(p.numel() for p in fresh)
@@ -349,14 +352,25 @@ class FusedDenseAdam(torch.optim.Optimizer):
                         st['exp_avg_sq'] = torch.zeros_like(
                             p, dtype=torch.float32)
                     st['step'] = step
-            steps = {id(self.state[p]['step']): self.state[p]['step']
-                     for p in live}
-            for st in steps.values():
-                st += 1
+            # torch.optim.Adam does not advance a parameter it skips (grad is
+            # None): a shared counter is only right while ALL its members
+            # step together — otherwise every member gets its own copy
+            by_counter = {}
+            for p in live:
+                by_counter.setdefault(id(self.state[p]['step']), []).append(p)
+            for ps in by_counter.values():
+                cnt = self.state[ps[0]]['step']
+                members = getattr(cnt, '_xrd_members', ps)
+                if len(members) != len(ps):
+                    for q in members:
+                        own = cnt.clone()
+                        own._xrd_members = [q]
+                        self.state[q]['step'] = own
             args = (float(grp['lr']), float(b1), float(b2),
                     float(grp['eps']), float(grp['weight_decay']))
             grads = [p.grad if p.grad.is_contiguous() else
                      p.grad.contiguous() for p in live]
+            steps = {id(self.state[p]['step']) for p in live}
             # back-to-back parameters, gradients and moments sharing one
             # counter (a decoder kept in one flat buffer whose gradient comes
             # out of one kernel): ONE launch for the whole group.  Whether the
@@ -375,19 +389,25 @@ class FusedDenseAdam(torch.optim.Optimizer):
                                        for p in live]))
             if grp['_flat_ok'] and self._consecutive(grads):
                 st = self.state[live[0]]
-                _lib.check(lib.xrd_adam_dense(
+                _lib.check(lib.xrd_adam_dense_tick(
                     _lib.ptr(live[0]), _lib.ptr(grads[0]),
                     _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
                     sum(p.numel() for p in live), *args, _lib.ptr(st['step']),
-                    _lib.stream_ptr(live[0].device)), 'xrd_adam_dense')
+                    1, _lib.stream_ptr(live[0].device)),
+                    'xrd_adam_dense_tick')
             else:
-                for p, g in zip(live, grads):
+                # the last launch that uses a counter advances it
+                last = {}
+                for i, p in enumerate(live):
+                    last[id(self.state[p]['step'])] = i
+                for i, (p, g) in enumerate(zip(live, grads)):
                     st = self.state[p]
-                    _lib.check(lib.xrd_adam_dense(
+                    _lib.check(lib.xrd_adam_dense_tick(
                         _lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']),
                         _lib.ptr(st['exp_avg_sq']), p.numel(), *args,
-                        _lib.ptr(st['step']), _lib.stream_ptr(p.device)),
-                        'xrd_adam_dense')
+                        _lib.ptr(st['step']),
+                        int(last[id(st['step'])] == i),
+                        _lib.stream_ptr(p.device)), 'xrd_adam_dense_tick')
             for p in live:
                 # the kernel writes through the raw pointer: torch's version
                 # counter does not see it; consumers that cache a derived

@@ -265,6 +265,10 @@ class NiceSLAM(Algorithm):
                 mcfg.rendering_n_surface == 16:
             return self._fused_map_step(idx, imgs, quat, bound6, det, n_pix,
                                         (Hedge, Wedge, wcrop), detach)
+        if quat is not None and not is_mapping and self.fused_map_launch \
+                and not det and all(p.requires_grad for p in quat[1]):
+            return self._fused_track_step(idx, imgs, quat, bound6,
+                                          (Hedge, Wedge, wcrop))
         if quat is not None:
             # poses as parameters: matrices + sampling of all frames in ONE
             # launch (and one for the pose gradients)
@@ -344,6 +348,26 @@ class NiceSLAM(Algorithm):
             for p, g in zip(params, slam_ops.pose_param_grads(g7, layout)):
                 if p.requires_grad:
                     p.grad = g
+        return loss
+
+    def _fused_track_step(self, idx, imgs, quat, bound6, crop):
+        """a tracking iteration without autograd: sampling, forward, robust
+        loss, backward to the rays, pose-parameter gradients (five launches +
+        the backward's finishing launch); ``.grad`` is assigned here"""
+        from ...engine import nice as _en
+        from ...engine import slam_ops
+        mcfg = self.model.config
+        layout, params = quat
+        (ro, rd, td, tc, keep, dmax), sctx = slam_ops.sample_rays_poses(
+            idx, [i[0] for i in imgs], [i[1] for i in imgs], self.camera,
+            crop, bound6, layout, params)
+        loss, g_o, g_d = _en.nice_track_iter(
+            self.model.scene(), ro, rd, td, dmax, tc, keep,
+            mcfg.tracking_use_color_in_tracking, mcfg.tracking_handle_dynamic,
+            mcfg.tracking_w_color_loss)
+        g7 = slam_ops.sample_rays_poses_bwd(sctx, g_o, g_d)
+        for p, g in zip(params, slam_ops.pose_param_grads(g7, layout)):
+            p.grad = g
         return loss
 
     fused_iteration = True  # use the fused launches when the batch shape is fixed

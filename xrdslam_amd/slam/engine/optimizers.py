@@ -99,25 +99,17 @@ class FusedCellAdam(torch.optim.Optimizer):
         if self._m is None:
             self._m = torch.zeros(n * cf, dtype=torch.float32, device=p.device)
             self._v = torch.zeros_like(self._m)
-            self._step_dev = torch.zeros(1, dtype=torch.int32,
+            # {steps taken, ticket}: the kernel advances it (replayable from
+            # a hipGraph, no separate increment launch)
+            self._step_dev = torch.zeros(2, dtype=torch.int32,
                                          device=p.device)
-        self._step_dev += 1  # on the stream: replayable from a hipGraph
         b1, b2 = grp['betas']
-        if count is not None:
-            _lib.check(_lib.lib().xrd_adam_cells_devcount(
-                _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
-                _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
-                float(b1), float(b2), float(grp['eps']),
-                _lib.ptr(self._step_dev), _lib.ptr(count), 1,
-                _lib.stream_ptr(p.device)), 'xrd_adam_cells_devcount')
-            if not torch.cuda.is_current_stream_capturing():
-                p._xrd_grad_fresh = False
-            return
-        _lib.check(_lib.lib().xrd_adam_cells_devstep(
+        _lib.check(_lib.lib().xrd_adam_cells_tick(
             _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
             _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
-            float(b1), float(b2), float(grp['eps']), _lib.ptr(self._step_dev),
-            1, _lib.stream_ptr(p.device)), 'xrd_adam_cells_devstep')
+            float(b1), float(b2), float(grp['eps']),
+            _lib.ptr(self._step_dev), _lib.ptr(count), 1,
+            _lib.stream_ptr(p.device)), 'xrd_adam_cells_tick')
         if not torch.cuda.is_current_stream_capturing():
             p._xrd_grad_fresh = False
 

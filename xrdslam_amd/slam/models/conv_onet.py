@@ -205,10 +205,77 @@ class ConvOnet(Model):
                 self._packed_version[kind] = ver
 
     # -- frustum feature selection ----------------------------------------
+    # frustum feature selection as two launches for all grids
+    # (xrd_nice_frustum_cells) instead of ~25 torch launches, a 4x4 inverse
+    # and a nonzero() host sync per grid
+    device_selection = True
+
+    def _select_on_device(self, cur_frame):
+        import ctypes as C
+
+        from ... import _lib
+        from ...engine import dist as _dist
+        dev = torch.device(self.device)
+        depth_dev, _ = cur_frame.device_images(dev)
+        c2w = cur_frame.get_pose().detach().to(dev).float().contiguous()
+        keys = [k for k in self.grid_c if k != 'grid_coarse']
+        st = self.__dict__.setdefault('_sel_static', {})
+        b = self.bounding_box
+        for key in keys:
+            if key in st and 'axes' in st[key]:
+                continue
+            Z, Y, X = self.grid_c[key].shape[2:]
+            n = Z * Y * X
+            i32 = dict(dtype=torch.int32, device=dev)
+            st[key] = {
+                # the lattice of utils.py:316-325 (float32 linspace)
+                'axes': [torch.linspace(b[a, 0], b[a, 1], m, device=dev)
+                         .float().contiguous()
+                         for a, m in ((0, X), (1, Y), (2, Z))],
+                'sampled': torch.empty(n, dtype=torch.float32, device=dev),
+                'cells': torch.zeros(n, **i32),
+                'count': torch.zeros(1, **i32),
+                'mask': torch.zeros(n, dtype=torch.uint8, device=dev)}
+        ws = self.__dict__.get('_sel_ws')
+        if ws is None or ws.device != dev:
+            ws = self._sel_ws = torch.zeros(4, dtype=torch.int32, device=dev)
+        n_g = len(keys)
+        dims = (C.c_int32 * (3 * n_g))(*[
+            d for k in keys for d in self.grid_c[k].shape[2:]])
+        vp = C.c_void_p
+        axes = (vp * (3 * n_g))(*[a.data_ptr() for k in keys
+                                   for a in st[k]['axes']])
+        arr = lambda name: (vp * n_g)(*[st[k][name].data_ptr()  # noqa: E731
+                                         for k in keys])
+        cam = self.camera
+        _lib.check(_lib.lib().xrd_nice_frustum_cells(
+            n_g, dims, axes, _lib.ptr(c2w), _lib.ptr(depth_dev), cam.height,
+            cam.width, float(cam.fx), float(cam.fy), float(cam.cx),
+            float(cam.cy), arr('sampled'), arr('mask'), arr('cells'),
+            arr('count'), _lib.ptr(ws), _lib.stream_ptr(dev)),
+            'xrd_nice_frustum_cells')
+        for key in keys:
+            Z, Y, X = self.grid_c[key].shape[2:]
+            self.grid_opti_mask[key] = st[key]['mask'].view(
+                torch.bool).reshape(Z, Y, X)
+            st[key]['device_selected'] = True
+            if _dist.state.enabled:
+                # the exchange lays the selected cells out in list order:
+                # every rank needs the SAME order (and the host the length)
+                n_sel = int(st[key]['count'].item())
+                st[key]['cells'][:n_sel] = \
+                    st[key]['cells'][:n_sel].sort().values
+                st[key]['n_sel'] = n_sel
+        self.grid_opti_mask['grid_coarse'] = None  # all cells
+
     def pre_precessing(self, cur_frame):
         if not self.config.mapping_frustum_feature_selection:
             return
         dev = self.device
+        if self.device_selection and torch.device(dev).type == 'cuda':
+            return self._select_on_device(cur_frame)
+        for stt in self.__dict__.get('_sel_static', {}).values():
+            stt['device_selected'] = False
         depth_dev, _ = cur_frame.device_images(dev)
         c2w = cur_frame.get_pose()
         for key, val in self.grid_c.items():
@@ -270,6 +337,14 @@ class ConvOnet(Model):
                 g._xrd_cells = g._xrd_cells_count = None
                 sc.gmask[key] = None
                 continue
+            stt = self.__dict__.get('_sel_static', {}).get(key)
+            if stt is not None and stt.get('device_selected'):
+                # selected on the device into buffers that keep their address
+                # (capacity = all cells, valid count on the device)
+                g._xrd_cells, g._xrd_cells_count = stt['cells'], stt['count']
+                g._xrd_cells_n = stt.get('n_sel')
+                sc.gmask[key] = stt['mask']
+                continue
             flat = mask.reshape(-1)
             idx = flat.nonzero().reshape(-1).int()
             if not self.static_selection:
@@ -279,7 +354,7 @@ class ConvOnet(Model):
             if not hasattr(self, '_sel_static'):
                 self._sel_static = {}
             st = self._sel_static.get(key)
-            if st is None:
+            if st is None or 'cells' not in st:
                 st = self._sel_static[key] = {
                     'cells': torch.zeros(flat.numel(), dtype=torch.int32,
                                          device=flat.device),
