@@ -1047,6 +1047,40 @@ def _files_ingest(room, n_frames, cam, dev):
     return fds.Prefetcher(fds.Replica(path), dev, depth=3)
 
 
+def _ingest_files_leg(cfg, cam, dev, cad, n_timed=30, n_warm=5):
+    """NICE-SLAM frames/s with the sequence read back from Replica-format
+    files INSIDE the timed region (decode, pinned staging, one H2D per frame
+    on a side stream): a second, short run next to the headline's
+    HBM-resident one"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    random.seed(0)
+    algo = cfg.setup(camera=cam, device=str(dev))
+    algo.use_graphs = True
+    n_frames = n_timed + n_warm + 1
+    room = SyntheticRoom(BOUND, H=cam.height, W=cam.width, fx=cam.fx,
+                         fy=cam.fy, cx=cam.cx, cy=cam.cy, n_frames=200,
+                         device=dev)
+    data = _files_ingest(room, n_frames, cam, dev)
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device=str(dev))
+    for k in range(1 + n_warm):
+        slam.step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1 + n_warm, n_frames):
+        slam.step(k)
+    torch.cuda.synchronize()
+    return {'value': n_timed / (time.perf_counter() - t0),
+            'unit': 'frames/s', 'steps': n_timed, 'warmup': n_warm,
+            'note': 'file dataset + prefetching loader inside the timed '
+                    'region (PIL decode, pinned staging, H2D on a side '
+                    'stream)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--algo', default='nice-slam',
@@ -1071,6 +1105,9 @@ def main():
                          'staging, one H2D per frame on a side stream)')
     ap.add_argument('--no-coslam', action='store_true',
                     help='skip the Co-SLAM leg of the default run')
+    ap.add_argument('--no-others', action='store_true',
+                    help='default run: skip the Vox-Fusion / SplaTAM / '
+                         'Point-SLAM objects and the files-ingest leg')
     ap.add_argument('--no-graphs', action='store_true',
                     help='run every iteration eagerly (no hipGraph capture)')
     ap.add_argument('--first-iters', type=int, default=None,
@@ -1316,12 +1353,38 @@ def main():
             # not a product path)
             'torch_gpu_baseline': torch_gpu,
         }
+        if world == 1 and args.ingest == 'resident' and not args.no_others:
+            out['config']['ingest_files_fps'] = _ingest_files_leg(
+                cfg, cam, dev, cad)
         if world == 1 and not args.no_coslam:
             # the second algorithm the north star names, same frame loop
             co_args = argparse.Namespace(**vars(args))
             co_args.first_iters = None
             co = run_coslam(co_args, dev, not args.no_cpu_baseline)
             out['co_slam'] = co
+        if world == 1 and not args.no_others:
+            # BASELINE configs[2..4] in the same (driver-run) line, each on a
+            # budget that keeps the whole default run within a few minutes:
+            # every object carries its own steps / warm-up, roofline and
+            # cpu_baseline
+            for name, fn, steps, warm, first in (
+                    ('vox_fusion', run_voxfusion, 20, 5, None),
+                    ('splatam', run_splatam, 10, 3, None),
+                    ('point_slam', run_pointslam, 5, 2, 300)):
+                a2 = argparse.Namespace(**vars(args))
+                a2.steps, a2.warmup, a2.first_iters = steps, warm, first
+                a2.ingest = 'resident'
+                t_leg = time.perf_counter()
+                try:
+                    res = fn(a2, dev)
+                except Exception as e:   # one leg must not lose the line
+                    res = {'error': f'{type(e).__name__}: {e}'}
+                res.update({'steps': steps, 'warmup': warm,
+                            'leg_wall_s': time.perf_counter() - t_leg})
+                if first is not None:
+                    res['first_iters_override'] = first
+                out[name] = res
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

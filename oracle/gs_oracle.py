@@ -8,7 +8,18 @@ the published algorithm: per-Gaussian EWA projection
 blending of depth-sorted Gaussians restricted to the Gaussian's tile rectangle
 (alpha = min(.99, o*exp(p)), skip alpha < 1/255, stop before T < 1e-4), colour
 and depth outputs.  Gradients come from autograd on this forward; the gradient
-the CUDA code reports for the dummy ``means2D`` input is d loss / d ndc.xy."""
+the CUDA code reports for the dummy ``means2D`` input is d loss / d ndc.xy.
+
+The clamp ``alpha = min(0.99, o * G)``: the published backward does not
+branch on it (``dL_dG = o * dL_dalpha`` and ``dL_do = G * dL_dalpha`` whether
+or not alpha saturated), i.e. the gradient PASSES THROUGH the clamp; the
+forward below clamps the value and keeps the unclamped derivative (round 2
+used torch.clamp, whose autograd zeroes it — the HIP kernel follows the
+published code, tests/test_gs_hip.py covers the saturated case).
+
+``window=(x0, y0, w, h)`` evaluates only those pixels (and skips Gaussians
+whose tile rectangle misses them): the dense evaluation is O(N H W), a crop of
+a 640x480 image with 1e5 Gaussians is seconds."""
 from __future__ import annotations
 
 import math
@@ -28,7 +39,8 @@ def quat_to_rot(q):
 
 
 def rasterize(means3D, colors, opacities, scales, rotations, viewmatrix,
-              projmatrix, H, W, tanfovx, tanfovy, bg=None, scale_modifier=1.0):
+              projmatrix, H, W, tanfovx, tanfovy, bg=None, scale_modifier=1.0,
+              window=None):
     """viewmatrix / projmatrix are the [4,4] TRANSPOSED matrices the reference
     passes (common.py:599,605-606: w2c^T and (P w2c)^T).  Returns
     color [3,H,W], radii [N] int, depth [1,H,W], ndc [N,2] (retain_grad-able)."""
@@ -89,23 +101,35 @@ def rasterize(means3D, colors, opacities, scales, rotations, viewmatrix,
         ((rmaxx - rminx) * (rmaxy - rminy) > 0)
     radii = torch.where(visible, radius, torch.zeros_like(radius)).int()
     order = torch.argsort(tz.detach(), stable=True)
-    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=dt),
-                            torch.arange(W, device=dev, dtype=dt),
+    x0, y0, ww, wh = (0, 0, W, H) if window is None else window
+    ys, xs = torch.meshgrid(torch.arange(y0, y0 + wh, device=dev, dtype=dt),
+                            torch.arange(x0, x0 + ww, device=dev, dtype=dt),
                             indexing='ij')
     tile_x, tile_y = torch.floor(xs / TILE), torch.floor(ys / TILE)
-    Tcur = torch.ones(H, W, dtype=dt, device=dev)
-    done = torch.zeros(H, W, dtype=torch.bool, device=dev)
-    C = torch.zeros(3, H, W, dtype=dt, device=dev)
-    D = torch.zeros(H, W, dtype=dt, device=dev)
-    for g in order.tolist():
-        if not bool(visible[g]):
-            continue
-        in_rect = (tile_x >= rminx[g]) & (tile_x < rmaxx[g]) & \
-            (tile_y >= rminy[g]) & (tile_y < rmaxy[g])
-        dx, dy = pix[g, 0] - xs, pix[g, 1] - ys
-        power = -0.5 * (conic[g, 0] * dx * dx + conic[g, 2] * dy * dy) - \
-            conic[g, 1] * dx * dy
-        alpha = torch.clamp(opacities[g, 0] * torch.exp(power), max=0.99)
+    Tcur = torch.ones(wh, ww, dtype=dt, device=dev)
+    done = torch.zeros(wh, ww, dtype=torch.bool, device=dev)
+    C = torch.zeros(3, wh, ww, dtype=dt, device=dev)
+    D = torch.zeros(wh, ww, dtype=dt, device=dev)
+    # Gaussians whose tile rectangle touches the window (speed only)
+    tx0, tx1 = x0 // TILE, (x0 + ww - 1) // TILE
+    ty0, ty1 = y0 // TILE, (y0 + wh - 1) // TILE
+    touch = visible & (rminx <= tx1) & (rmaxx > tx0) & (rminy <= ty1) & \
+        (rmaxy > ty0)
+    # the touching Gaussians in depth order, gathered ONCE (an index into an
+    # N-sized tensor inside the loop costs an N-sized zero fill in backward)
+    sel = order[touch[order]]
+    pix_s, conic_s, op_s = pix[sel], conic[sel], opacities[sel, 0]
+    col_s, tz_s = colors[sel], tz[sel]
+    rx0, rx1, ry0, ry1 = rminx[sel], rmaxx[sel], rminy[sel], rmaxy[sel]
+    for j in range(sel.shape[0]):
+        in_rect = (tile_x >= rx0[j]) & (tile_x < rx1[j]) & \
+            (tile_y >= ry0[j]) & (tile_y < ry1[j])
+        dx, dy = pix_s[j, 0] - xs, pix_s[j, 1] - ys
+        power = -0.5 * (conic_s[j, 0] * dx * dx + conic_s[j, 2] * dy * dy) - \
+            conic_s[j, 1] * dx * dy
+        a_raw = op_s[j] * torch.exp(power)
+        # value clamped, derivative passed through (see the module docstring)
+        alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()
         ok = in_rect & ~done & (power.detach() <= 0) & \
             (alpha.detach() >= 1.0 / 255.0)
         test_T = Tcur * (1 - alpha)
@@ -113,8 +137,8 @@ def rasterize(means3D, colors, opacities, scales, rotations, viewmatrix,
         done = done | stop
         use = ok & ~stop
         w = torch.where(use, alpha * Tcur, torch.zeros_like(alpha))
-        C = C + colors[g][:, None, None] * w
-        D = D + tz[g] * w
+        C = C + col_s[j][:, None, None] * w
+        D = D + tz_s[j] * w
         Tcur = torch.where(use, test_T, Tcur)
     if bg is not None:
         C = C + Tcur * bg.reshape(3, 1, 1)

@@ -188,3 +188,120 @@ def run(g, device, knn_factory=None, freeze_fixed_decoders=False):
             if key in g.files and (p.grad is not None or p.requires_grad):
                 errs[key] = rel_err(p.grad.cpu(), g[key])
     return errs
+
+
+def run_tum(g, device, knn_factory=None, freeze_fixed_decoders=False):
+    """the TUM-shaped golden (BASELINE configs[4] shapes: 19 389 neural
+    points, 5000 x 5 mapping / 1500 x 5 tracking samples): inputs and feature
+    draws regenerated from seeds, outputs compared with the reference's"""
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.conv_onet_pointslam import (ConvOnet2,
+                                                             ConvOnet2Config)
+    model = ConvOnet2(ConvOnet2Config(), Camera(*TUM_CAM))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files
+          if k.startswith('dec/')}
+    model.decoder.load_state_dict(sd)
+    model.decoder.color_decoder.embedder._B = torch.from_numpy(
+        g['dec_attr/color_decoder.embedder._B'])
+    model = model.to(device)
+    model.freeze_fixed_decoders = freeze_fixed_decoders
+    model.knn_factory = knn_factory
+    # the reference's draws in call order: point features N(0, 0.1) [n, 32],
+    # empty-neighbourhood features N(0, 0.01) [32] (neural_point_cloud.py:
+    # 183-188, decoder_pointslam.py:205-208), one CPU generator stream
+    gen = torch.Generator().manual_seed(TUM_DRAW_SEED)
+    shapes = [tuple(int(x) for x in row if x) for row in g['draw_shapes']]
+    it = iter(shapes)
+
+    def draw(shape):
+        want = next(it)
+        assert tuple(shape) == want, (shape, want)
+        return torch.empty(shape).normal_(
+            mean=0, std=0.1 if len(shape) == 2 else 0.01, generator=gen)
+
+    def feat_init(n, c):
+        return draw((n, c))
+
+    def empty_feat(c, dev):
+        return draw((c, )).to(dev)
+
+    model.decoder.geo_decoder.empty_feature_fn = empty_feat
+    model.decoder.color_decoder.empty_feature_fn = empty_feat
+    errs = {}
+    from xrdslam_amd.slam.model_components import neural_point_cloud as npm
+    real = npm._feature_init
+    npm._feature_init = feat_init
+    try:
+        for k in range(2):
+            inp = {kk: v.to(device) for kk, v in tum_add_inputs(k).items()}
+            model.model_update(inp)
+            model.neural_point_cloud.feature_init_fn = feat_init
+            npc = model.neural_point_cloud
+            errs[f'add{k}/count'] = abs(npc.cloud_tensor().shape[0] -
+                                        int(g[f'add{k}/n_cloud']))
+            errs[f'add{k}/n_input'] = abs(npc._input_pos.shape[0] -
+                                          int(g[f'add{k}/n_input']))
+    finally:
+        npm._feature_init = real
+    cloud = npc.cloud_tensor().cpu().numpy()
+    if errs['add1/count'] == 0:
+        errs['cloud_rows'] = rel_err(cloud[subset(cloud.shape[0])],
+                                     g['cloud_rows'])
+        errs['cloud_sum'] = rel_err(cloud.astype(np.float64).sum(0),
+                                    g['cloud_sum'])
+    model.masked_indices = tum_frustum_mask(npc.pts_num()).to(device)
+    model.get_param_groups()
+    for tag, stage, is_mapping in (('map_geo', 'geometry', True),
+                                   ('map_col', 'color', True),
+                                   ('track', 'color', False)):
+        q = {kk: v.to(device) for kk, v in tum_query(is_mapping).items()}
+        for p in model.parameters():
+            p.grad = None
+        npc.geo_feats.grad = npc.col_feats.grad = None
+        ro = q['o'].clone().requires_grad_(True)
+        rd = q['d'].clone().requires_grad_(True)
+        inp = {'rays_o': ro, 'rays_d': rd, 'target_s': q['color'],
+               'target_d': q['depth'].reshape(-1, 1), 'stage': stage,
+               'batch_dynamic_r': q['r']}
+        res = model.get_outputs(inp)
+        ld = model.get_loss_dict(res, inp, is_mapping, stage)
+        sum(ld.values()).backward()
+        errs[f'{tag}/valid_ray_mask'] = float(np.any(
+            res['valid_ray_mask'].cpu().numpy() != g[f'{tag}/valid_ray_mask']))
+        for k2 in ('rgb', 'depth', 'uncertainty'):
+            errs[f'{tag}/{k2}'] = rel_err(res[k2].detach().cpu(),
+                                          g[f'{tag}/{k2}'])
+        for k2, v in ld.items():
+            errs[f'{tag}/loss_{k2}'] = rel_err(v.detach().cpu(),
+                                               g[f'{tag}/loss_{k2}'])
+        errs[f'{tag}/g_rays_o'] = rel_err(ro.grad.cpu(), g[f'{tag}/g_rays_o'])
+        errs[f'{tag}/g_rays_d'] = rel_err(rd.grad.cpu(), g[f'{tag}/g_rays_d'])
+        # '#frac': share of rows (rays / points) deviating by more than 1e-4
+        # of the largest entry (tests/parity.row_outliers)
+        for nm, got in (('g_rays_o', ro.grad), ('g_rays_d', rd.grad)):
+            want = np.asarray(g[f'{tag}/{nm}'], np.float64)
+            dev_ = np.abs(got.cpu().numpy() - want).max(1) / \
+                max(np.abs(want).max(), 1e-30)
+            errs[f'{tag}/{nm}#frac'] = float((dev_ > 1e-4).mean())
+        for name, t in (('g_geo', npc.geo_feats.grad),
+                        ('g_col', npc.col_feats.grad)):
+            if f'{tag}/{name}/rows' not in g.files:
+                continue
+            a = t.detach().cpu().numpy()
+            # scale of the whole gradient: the stored rows are a subset
+            big = float(np.abs(g[f'{tag}/{name}/rows']).max())
+            drow = np.abs(a[subset(a.shape[0])] -
+                          g[f'{tag}/{name}/rows']).max(1) / max(big, 1e-30)
+            errs[f'{tag}/{name}/rows'] = float(drow.max())
+            errs[f'{tag}/{name}/rows#frac'] = float((drow > 1e-4).mean())
+            errs[f'{tag}/{name}/colsum'] = rel_err(
+                a.astype(np.float64).sum(0), g[f'{tag}/{name}/colsum'])
+            errs[f'{tag}/{name}/abssum'] = rel_err(
+                np.abs(a.astype(np.float64)).sum(1)[subset(a.shape[0], 7,
+                                                            4000)],
+                g[f'{tag}/{name}/abssum'])
+        for k2, p in model.decoder.named_parameters():
+            key = f'{tag}/g_dec/{k2}'
+            if key in g.files and (p.grad is not None or p.requires_grad):
+                errs[key] = rel_err(p.grad.cpu(), g[key])
+    return errs

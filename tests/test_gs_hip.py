@@ -76,6 +76,84 @@ def test_rasterizer_matches_oracle(N, H, W, iso):
     assert m2d.grad[:, 2].abs().max() == 0
 
 
+def _big_scene(N, seed):
+    """640x480 SplaTAM-shaped view (BASELINE configs[3]): N isotropic
+    Gaussians of a few pixels radius spread over the frustum in depth 1-4 m"""
+    H, W, fx = 480, 640, 320.0
+    g = torch.Generator().manual_seed(seed)
+    z = 1.0 + 3.0 * torch.rand(N, generator=g)
+    u = (torch.rand(N, generator=g) * 1.1 - 0.05) * W
+    v = (torch.rand(N, generator=g) * 1.1 - 0.05) * H
+    means = torch.stack([(u - 319.5) / fx * z, (v - 239.5) / fx * z, z], -1)
+    cols = torch.rand(N, 3, generator=g)
+    op = torch.rand(N, 1, generator=g) * 0.9 + 0.05
+    sc = (0.004 + 0.012 * torch.rand(N, 1, generator=g)).repeat(1, 3) * \
+        z[:, None] / 2.0
+    rot = torch.tensor([[1.0, 0, 0, 0]]).repeat(N, 1)
+    w2c = torch.eye(4)
+    near, far = 0.01, 100.0
+    cx, cy = 319.5, 239.5
+    proj = torch.tensor([[2 * fx / W, 0, -(W - 2 * cx) / W, 0],
+                         [0, 2 * fx / H, -(H - 2 * cy) / H, 0],
+                         [0, 0, far / (far - near), -(far * near) / (far - near)],
+                         [0, 0, 1, 0]])
+    return (means, cols, op, sc, rot, w2c.t().contiguous(),
+            (proj @ w2c).t().contiguous(), W / (2 * fx), H / (2 * fx), H, W)
+
+
+def test_rasterizer_at_baseline_shape_vs_oracle_crops():
+    """640x480, 120 000 Gaussians (BASELINE configs[3]: SplaTAM renders the
+    whole image of ~4e5 Gaussians per pass; the dense oracle is O(N H W), so
+    it evaluates six 32x32 crops): colour, depth and — with a loss that weights
+    only the crops' pixels — every gradient.  A fifth of the Gaussians have
+    opacity 0.999, so alpha saturates at 0.99 near their centres: the
+    published backward passes the gradient through that clamp."""
+    from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
+    N = 120000
+    means, cols, op, sc, rot, view, full, tfx, tfy, H, W = _big_scene(N, 3)
+    op[::5] = 0.999
+    crops = [(0, 0), (304, 224), (608, 448), (96, 400), (512, 64), (320, 16)]
+    gw = torch.Generator().manual_seed(9)
+    wc = torch.zeros(3, H, W)
+    for x0, y0 in crops:
+        wc[:, y0:y0 + 32, x0:x0 + 32] = torch.rand(3, 32, 32, generator=gw)
+    dev = torch.device('cuda:0')
+    gl = [t.clone().to(dev).requires_grad_(True)
+          for t in (means, cols, op, sc, rot)]
+    m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+    rs = dgr.GaussianRasterizationSettings(
+        H, W, tfx, tfy, torch.zeros(3, device=dev), 1.0,
+        view.to(dev).unsqueeze(0), full.to(dev).unsqueeze(0), 0,
+        torch.zeros(3, device=dev), False)
+    color, radii, depth = dgr.GaussianRasterizer(rs)(
+        means3D=gl[0], means2D=m2d, opacities=gl[2], colors_precomp=gl[1],
+        scales=gl[3], rotations=gl[4])
+    (color * wc.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    leaves = [t.clone().requires_grad_(True) for t in (means, cols, op, sc, rot)]
+    ndc_grad = torch.zeros(N, 2)
+    saturated = 0
+    for x0, y0 in crops:
+        C_ref, radii_ref, D_ref, ndc = go.rasterize(
+            *leaves, view, full, H, W, tfx, tfy, window=(x0, y0, 32, 32))
+        (C_ref * wc[:, y0:y0 + 32, x0:x0 + 32]).sum().backward()
+        ndc_grad += ndc.grad
+        got_c = color[:, y0:y0 + 32, x0:x0 + 32].detach().cpu()
+        got_d = depth[:, y0:y0 + 32, x0:x0 + 32].detach().cpu()
+        assert rel_err(got_c, C_ref.detach()) < 1e-4, (x0, y0)
+        assert rel_err(got_d, D_ref.detach()) < 1e-4, (x0, y0)
+    assert torch.equal(radii.cpu(), radii_ref)
+    names = ['means3D', 'colors', 'opacities', 'scales']
+    for name, a, b in zip(names, gl, leaves):
+        assert float(b.grad.abs().max()) > 0, name
+        assert rel_err(a.grad.cpu(), b.grad) < 1e-4, name
+    assert rel_err(m2d.grad[:, :2].cpu(), ndc_grad) < 1e-4
+    # the saturated branch was exercised: some opacity-0.999 Gaussian centre
+    # lies inside a crop and received gradient
+    hit = (leaves[2].grad[::5].abs() > 0).sum()
+    assert int(hit) > 10, int(hit)
+
+
 def test_rasterizer_empty_and_unsupported():
     from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
     dev = torch.device('cuda:0')

@@ -40,6 +40,45 @@ def test_point_slam_model_vs_reference(freeze):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('freeze', [False, True])
+def test_point_slam_model_vs_reference_tum_shapes(freeze):
+    """BASELINE configs[4] shapes: a cloud of 19 389 neural points grown over
+    two 640x480 TUM-fr1-like frames (6000 + 1000 rays each), 5000 x 5 mapping
+    and 1500 x 5 tracking samples, against the golden made by the REFERENCE's
+    ConvOnet2 / NeuralPointCloud / POINT decoders
+    (oracle/make_golden_pointslam.py tum): cloud growth, renders, losses and
+    every gradient (point-feature gradients: 2000 seeded rows + column sums +
+    4000 row norms)."""
+    g = np.load(pg.GOLDEN_TUM)
+    errs = pg.run_tum(g, 'cuda:0', freeze_fixed_decoders=freeze)
+    report = os.environ.get('XRD_PARITY_REPORT')
+    if report:
+        with open(report, 'a') as f:
+            for k, v in sorted(errs.items()):
+                f.write(f'pointslam_tum/freeze={int(freeze)}/{k} {v:.3e}\n')
+
+    def tol(k):
+        if k.endswith('#frac'):
+            # share of rays / points off by more than 1e-4: none on the
+            # modular operators; <= 1 % on the fused geometry kernels, whose
+            # MFMA chain rounds the 32-wide ReLU decoder's pre-activations
+            # differently from torch's GEMMs — measured: 0.13 % of the 25 000
+            # samples land on the other side of a ReLU kink (their occupancy
+            # agrees to 4e-5, their gradient jumps by one unit's share), the
+            # same phenomenon the NICE-SLAM decoders show (DESIGN.md 2)
+            return 0.01 if freeze else 1e-9
+        if freeze and ('g_rays' in k or '/rows' in k or 'abssum' in k or
+                       'colsum' in k):
+            # ... and those rows / the sums that contain them: bounded by a
+            # flipped unit's share of the largest gradient
+            return 0.15 if ('g_rays' in k or '/rows' in k) else 1e-2
+        if k.startswith('track/') and ('g_dec' in k or 'loss' in k):
+            return 5e-4   # see test_point_slam_model_vs_reference
+        return TOL
+    bad = {k: v for k, v in errs.items() if not v < tol(k)}
+    assert not bad, bad
+
+
 def _pointslam_loop(use_graphs, frames):
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera

@@ -335,7 +335,14 @@ class Prefetcher:
         ev = item.pop('_event', None)
         item.pop('_pinned', None)
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            # allocated on the side stream, consumed on this one: without
+            # record_stream the caching allocator hands the block back to the
+            # side stream's pool when the Frame frees it, and the next
+            # prefetch copy could overwrite memory queued kernels still read
+            for k2 in ('depth_dev', 'rgb_dev'):
+                item[k2].record_stream(cur)
         return item
 
     def close(self):
