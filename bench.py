@@ -349,7 +349,7 @@ def run_coslam(args, dev, with_cpu, world=1):
             (['coslam_reduce_kernel', 'hash_chunk_scatter_kernel']
              if map_grads else [])) if kernel == 'coslam_bwd'
         else pmc_traffic(['coslam_fwd_kernel']),
-        'traffic_source': 'profiles/r02_pmc.json (see NICE line)',
+        'traffic_source': 'profiles/r03_pmc.json (see NICE line)',
         'intensity_flop_per_byte': aflops / abytes,
         'kernel': f'{kernel}[rays={n_rays},ray_grad={int(ray_grads)},'
                   f'map_grad={int(map_grads)}] (launch group: zero-fill, '
@@ -627,8 +627,8 @@ def run_voxfusion(args, dev, world=1):
                 {'vox_dw': ['vox_dw_kernel', 'vox_dw_reduce_kernel'],
                  'vox_points_fwd': ['vox_points_fwd_kernel'],
                  'vox_points_bwd': ['vox_points_bwd_kernel']}[kern],
-                'r02_pmc_vox.json'),
-            'traffic_source': 'profiles/r02_pmc_vox.json (rocprofv3 --pmc '
+                'r03_pmc_vox.json'),
+            'traffic_source': 'profiles/r03_pmc_vox.json (rocprofv3 --pmc '
                               'FETCH_SIZE / WRITE_SIZE passes of this '
                               'workload, FETCH x2 on gfx950)',
             'kernel': f'{kern}[decoder_grad={int(need_w)}]' + (
@@ -754,7 +754,11 @@ def run_splatam(args, dev):
         'bound': 'mfma', 'achieved': bwd_flops / (us['gs_render_bwd'] * 1e-6)
         / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
         'frac': bwd_flops / (us['gs_render_bwd'] * 1e-6) / MFMA_F32_PEAK,
-        'traffic': None,
+        'traffic': pmc_traffic(['gs_render_bwd_kernel'],
+                               'r03_pmc_splatam.json'),
+        'traffic_source': 'profiles/r03_pmc_splatam.json (rocprofv3 --pmc '
+                          'FETCH_SIZE / WRITE_SIZE passes of this workload, '
+                          'FETCH x2 on gfx950)',
         'kernel': 'gs_render_bwd<dual> (tile-local blend backward of the rgb '
                   'and the depth/silhouette colours in one pass: fp32 VALU, '
                   'wave-reduced atomics to the per-Gaussian gradients; the '
@@ -927,7 +931,14 @@ def run_pointslam(args, dev, world=1):
         roofline = {
             'bound': 'mfma', 'achieved': flop / (us * 1e-6) / 1e12,
             'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
-            'frac': flop / (us * 1e-6) / MFMA_F32_PEAK, 'traffic': None,
+            'frac': flop / (us * 1e-6) / MFMA_F32_PEAK,
+            'traffic': pmc_traffic(['point_color_bwd_kernel', 'pc_dw_kernel',
+                                    'pc_dw_reduce_kernel'],
+                                   'r03_pmc_pointslam.json'),
+            'traffic_source': 'profiles/r03_pmc_pointslam.json (rocprofv3 '
+                              '--pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                              'workload, FETCH x2 on gfx950; mean over the '
+                              "passes' launches)",
             'kernel': 'xrd_point_color_bwd = point_color_bwd_kernel + '
                       'pc_dw_kernel + pc_dw_reduce_kernel (colour path '
                       'backward incl. all weight gradients, one call per '

@@ -40,7 +40,11 @@ def short_name(name):
               'vox_compact_kernel', 'vox_render_fwd_kernel',
               'vox_render_bwd_kernel', 'vox_ray_grad_kernel',
               'gs_render_fwd_kernel', 'gs_render_bwd_kernel',
-              'gs_preprocess_kernel', 'knn_search_kernel'):
+              'gs_preprocess_kernel', 'knn_search_kernel',
+              'point_color_bwd_kernel', 'point_color_fwd_kernel',
+              'pc_dw_reduce_kernel', 'pc_dw_kernel', 'point_geo_bwd_kernel',
+              'point_geo_fwd_kernel', 'point_map_loss_kernel',
+              'gs_bin', 'frustum_select_kernel', 'frustum_depth_kernel'):
         if k in name:
             return k
     return None
