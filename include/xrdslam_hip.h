@@ -692,6 +692,51 @@ int xrd_gs_bin(int n, int image_width, int image_height, const int32_t* rect,
                const int32_t* tiles_touched, const float* depths,
                int64_t key_capacity, void* workspace, int32_t* point_list,
                int32_t* ranges, int64_t* n_keys, xrd_stream_t stream);
+/* xrd_gs_bin that also returns what a per-Gaussian gradient reduction needs:
+ * key_pos [key_capacity] int32 — sorted position of pre-sort key k (the keys
+ * of Gaussian i are the pre-sort indices [offsets[i-1], offsets[i])) — and
+ * offsets [n] int64, the inclusive scan of tiles_touched. */
+int xrd_gs_bin2(int n, int image_width, int image_height, const int32_t* rect,
+                const int32_t* tiles_touched, const float* depths,
+                int64_t key_capacity, void* workspace, int32_t* point_list,
+                int32_t* ranges, int64_t* n_keys, int32_t* key_pos,
+                int64_t* offsets, xrd_stream_t stream);
+
+/* Tile blend, second formulation (csrc/gs_blend.hip; same call sites of the
+ * reference as xrd_gs_render_fwd / _bwd: the forward / backward of
+ * GaussianRasterizer, slam/model_components/gaussian_cloud_splatam.py:63-69,
+ * 267-268).  colors_b / out_color_b / dL_dcolor_b / dL_dcolors_b NULL: one
+ * colour set; else two sets blended with the same weights (SplaTAM's rgb and
+ * depth / silhouette renders).
+ *   forward: as xrd_gs_render_fwd[2]; ckpt (xrd_gs_blend_ckpt_floats floats,
+ *     or NULL) receives every pixel's transmittance and colour prefix sums in
+ *     front of every 64th Gaussian of its tile.
+ *   backward: one lane per Gaussian (64 a wave), the tile's pixels streamed
+ *     through the lanes; key_grad [key_capacity][12] scratch (one gradient
+ *     row per (Gaussian, tile) key); the per-Gaussian outputs are OVERWRITTEN
+ *     (no atomics, nothing to zero): dL_dmean2D [n,2], dL_dconic [n,3],
+ *     dL_dopacity [n], dL_dcolors_a/_b [n,3].  out_color_a/_b: the forward's
+ *     images. */
+int64_t xrd_gs_blend_ckpt_floats(int64_t key_capacity, int image_width,
+                                 int image_height);
+int xrd_gs_blend_fwd(const xrd_gs_camera* c, const int32_t* ranges,
+                     const int32_t* point_list, const float* xy,
+                     const float* colors_a, const float* colors_b,
+                     const float* conic_opacity, const float* depths,
+                     float* out_color_a, float* out_color_b, float* out_depth,
+                     float* final_T, int32_t* n_contrib, float* ckpt,
+                     xrd_stream_t stream);
+int xrd_gs_blend_bwd(const xrd_gs_camera* c, int n, int64_t key_capacity,
+                     const int32_t* ranges, const int32_t* point_list,
+                     const int32_t* key_pos, const int64_t* offsets,
+                     const float* xy, const float* conic_opacity,
+                     const float* colors_a, const float* colors_b,
+                     const float* final_T, const int32_t* n_contrib,
+                     const float* out_color_a, const float* out_color_b,
+                     const float* dL_dcolor_a, const float* dL_dcolor_b,
+                     const float* ckpt, float* key_grad, float* dL_dmean2D,
+                     float* dL_dconic, float* dL_dopacity, float* dL_dcolors_a,
+                     float* dL_dcolors_b, xrd_stream_t stream);
 int xrd_gs_render_fwd(const xrd_gs_camera* cam, const int32_t* ranges,
                       const int32_t* point_list, const float* xy,
                       const float* colors, const float* conic_opacity,

@@ -159,6 +159,11 @@ _SIGS = {
     'xrd_gs_bin_ws_bytes': (i64, [C.c_int, i64, C.c_int, C.c_int]),
     'xrd_gs_bin': (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, vp,
                              vp, vp, vp, vp]),
+    'xrd_gs_bin2': (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, vp,
+                              vp, vp, vp, vp, vp, vp]),
+    'xrd_gs_blend_ckpt_floats': (i64, [i64, C.c_int, C.c_int]),
+    'xrd_gs_blend_fwd': (C.c_int, [vp] * 15),
+    'xrd_gs_blend_bwd': (C.c_int, [vp, C.c_int, i64] + [vp] * 22),
     'xrd_gs_render_fwd': (C.c_int, [vp] * 12),
     'xrd_gs_render_bwd': (C.c_int, [vp] * 14),
     'xrd_gs_render_fwd2': (C.c_int, [vp] * 14),

@@ -224,13 +224,106 @@ def _geometry(lib, cam, dev, st, m3, sc, rt, op):
     plist = torch.empty(cap, **i)
     n_keys = torch.empty(1, dtype=torch.int64, device=dev)
     ws = _BIN.workspace(dev, lib.xrd_gs_bin_ws_bytes(n, cap, W, H))
+    # inverse map of the sort + the scan (the lane-per-Gaussian blend backward
+    # sums a Gaussian's per-key gradient rows through them)
+    key_pos = torch.empty(cap, **i)
+    offsets = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     with _Timed('gs_bin'):
-        _lib.check(lib.xrd_gs_bin(
+        _lib.check(lib.xrd_gs_bin2(
             n, W, H, _lib.ptr(rect), _lib.ptr(tiles), _lib.ptr(depths),
             cap, _lib.ptr(ws), _lib.ptr(plist), _lib.ptr(ranges),
-            _lib.ptr(n_keys), st), 'xrd_gs_bin')
+            _lib.ptr(n_keys), _lib.ptr(key_pos), _lib.ptr(offsets), st),
+            'xrd_gs_bin2')
     _BIN.report(dev, n, cap, n_keys)
-    return depths, xy, conic_o, radii, ranges, plist, n_keys
+    return depths, xy, conic_o, radii, ranges, plist, n_keys, \
+        (cap, key_pos, offsets)
+
+
+# the blend: True = forward with per-bucket checkpoints + lane-per-Gaussian
+# backward (csrc/gs_blend.hip); False = round 2's pixel-per-thread kernels
+# (csrc/gs_raster.hip: wave reductions + atomics in the backward)
+BUCKET_BLEND = True
+
+
+def _blend_fwd(lib, cam, dev, st, H, W, ranges, plist, xy, ca, cb, conic_o,
+               depths, cap):
+    f = dict(dtype=torch.float32, device=dev)
+    i = dict(dtype=torch.int32, device=dev)
+    color_a = torch.empty(3, H, W, **f)
+    color_b = torch.empty(3, H, W, **f) if cb is not None else None
+    depth = torch.empty(1, H, W, **f)
+    final_T = torch.empty(H, W, **f)
+    n_contrib = torch.empty(H, W, **i)
+    ckpt = None
+    with _Timed('gs_render_fwd'):
+        if BUCKET_BLEND:
+            ckpt = torch.empty(lib.xrd_gs_blend_ckpt_floats(cap, W, H), **f)
+            _lib.check(lib.xrd_gs_blend_fwd(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(conic_o),
+                _lib.ptr(depths), _lib.ptr(color_a), _lib.ptr(color_b),
+                _lib.ptr(depth), _lib.ptr(final_T), _lib.ptr(n_contrib),
+                _lib.ptr(ckpt), st), 'xrd_gs_blend_fwd')
+        elif cb is not None:
+            _lib.check(lib.xrd_gs_render_fwd2(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(conic_o),
+                _lib.ptr(depths), _lib.ptr(color_a), _lib.ptr(color_b),
+                _lib.ptr(depth), _lib.ptr(final_T), _lib.ptr(n_contrib), st),
+                'xrd_gs_render_fwd2')
+        else:
+            _lib.check(lib.xrd_gs_render_fwd(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(ca), _lib.ptr(conic_o), _lib.ptr(depths),
+                _lib.ptr(color_a), _lib.ptr(depth), _lib.ptr(final_T),
+                _lib.ptr(n_contrib), st), 'xrd_gs_render_fwd')
+    return color_a, color_b, depth, final_T, n_contrib, ckpt
+
+
+def _blend_bwd(lib, cam, dev, st, n, ranges, plist, xy, conic_o, ca, cb,
+               final_T, n_contrib, color_a, color_b, ga, gb, ckpt, bins):
+    """-> d_mean2D [n,2], d_conic [n,3], d_op [n,1], d_ca [n,3], d_cb"""
+    f = dict(dtype=torch.float32, device=dev)
+    with _Timed('gs_render_bwd'):
+        if ckpt is not None:
+            cap, key_pos, offsets = bins
+            d_mean2D = torch.empty(n, 2, **f)
+            d_conic = torch.empty(n, 3, **f)
+            d_op = torch.empty(n, 1, **f)
+            d_ca = torch.empty(n, 3, **f)
+            d_cb = torch.empty(n, 3, **f) if cb is not None else None
+            key_grad = torch.empty(cap, 12, **f)
+            _lib.check(lib.xrd_gs_blend_bwd(
+                C.byref(cam), n, cap, _lib.ptr(ranges), _lib.ptr(plist),
+                _lib.ptr(key_pos), _lib.ptr(offsets), _lib.ptr(xy),
+                _lib.ptr(conic_o), _lib.ptr(ca), _lib.ptr(cb),
+                _lib.ptr(final_T), _lib.ptr(n_contrib), _lib.ptr(color_a),
+                _lib.ptr(color_b), _lib.ptr(ga), _lib.ptr(gb),
+                _lib.ptr(ckpt), _lib.ptr(key_grad), _lib.ptr(d_mean2D),
+                _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_ca),
+                _lib.ptr(d_cb), st), 'xrd_gs_blend_bwd')
+            return d_mean2D, d_conic, d_op, d_ca, d_cb
+        d_mean2D = torch.zeros(n, 2, **f)
+        d_conic = torch.zeros(n, 3, **f)
+        d_op = torch.zeros(n, 1, **f)
+        d_ca = torch.zeros(n, 3, **f)
+        if cb is not None:
+            d_cb = torch.zeros(n, 3, **f)
+            _lib.check(lib.xrd_gs_render_bwd2(
+                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+                _lib.ptr(conic_o), _lib.ptr(ca), _lib.ptr(cb),
+                _lib.ptr(final_T), _lib.ptr(n_contrib), _lib.ptr(ga),
+                _lib.ptr(gb), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
+                _lib.ptr(d_op), _lib.ptr(d_ca), _lib.ptr(d_cb), st),
+                'xrd_gs_render_bwd2')
+            return d_mean2D, d_conic, d_op, d_ca, d_cb
+        _lib.check(lib.xrd_gs_render_bwd(
+            C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
+            _lib.ptr(conic_o), _lib.ptr(ca), _lib.ptr(final_T),
+            _lib.ptr(n_contrib), _lib.ptr(ga), _lib.ptr(d_mean2D),
+            _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_ca), st),
+            'xrd_gs_render_bwd')
+        return d_mean2D, d_conic, d_op, d_ca, None
 
 
 def _geometry_backward(lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D,
@@ -265,25 +358,20 @@ class _RasterizeFn(torch.autograd.Function):
         cl = colors.detach().float().contiguous()
         f = dict(dtype=torch.float32, device=dev)
         i = dict(dtype=torch.int32, device=dev)
-        depths, xy, conic_o, radii, ranges, plist, n_keys = _geometry(
+        depths, xy, conic_o, radii, ranges, plist, n_keys, bins = _geometry(
             lib, cam, dev, st, m3, sc, rt, op)
-        color = torch.empty(3, H, W, **f)
-        depth = torch.empty(1, H, W, **f)
-        final_T = torch.empty(H, W, **f)
-        n_contrib = torch.empty(H, W, **i)
-        with _Timed('gs_render_fwd'):
-            _lib.check(lib.xrd_gs_render_fwd(
-                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
-                _lib.ptr(cl), _lib.ptr(conic_o), _lib.ptr(depths),
-                _lib.ptr(color), _lib.ptr(depth), _lib.ptr(final_T),
-                _lib.ptr(n_contrib), st), 'xrd_gs_render_fwd')
+        color, _, depth, final_T, n_contrib, ckpt = _blend_fwd(
+            lib, cam, dev, st, H, W, ranges, plist, xy, cl, None, conic_o,
+            depths, bins[0])
         if PROFILE is not None:
             PROFILE.setdefault('pairs', []).append(n_contrib.sum())
             PROFILE.setdefault('keys', []).append(n_keys.clone())
             PROFILE.setdefault('gaussians', []).append(n)
-        ctx.rs, ctx.n = rs, n
+        ctx.rs, ctx.n, ctx.cap = rs, n, bins[0]
+        ctx.has_ckpt = ckpt is not None
+        extra = [ckpt, bins[1], bins[2], color] if ckpt is not None else []
         ctx.save_for_backward(m3, sc, rt, cl, xy, conic_o, radii, ranges,
-                              plist, final_T, n_contrib)
+                              plist, final_T, n_contrib, *extra)
         ctx.mark_non_differentiable(radii, depth)
         return color, radii, depth
 
@@ -291,24 +379,19 @@ class _RasterizeFn(torch.autograd.Function):
     def backward(ctx, g_color, g_radii, g_depth):
         lib = _lib.lib()
         (m3, sc, rt, cl, xy, conic_o, radii, ranges, plist, final_T,
-         n_contrib) = ctx.saved_tensors
+         n_contrib) = ctx.saved_tensors[:11]
+        ckpt = key_pos = offsets = color = None
+        if ctx.has_ckpt:
+            ckpt, key_pos, offsets, color = ctx.saved_tensors[11:]
         dev = m3.device
         st = _lib.stream_ptr(dev)
         cam = _camera(ctx.rs)
         n = ctx.n
-        f = dict(dtype=torch.float32, device=dev)
-        d_mean2D = torch.zeros(n, 2, **f)
-        d_conic = torch.zeros(n, 3, **f)
-        d_op = torch.zeros(n, 1, **f)
-        d_col = torch.zeros(n, 3, **f)
         gc = g_color.float().contiguous()
-        with _Timed('gs_render_bwd'):
-            _lib.check(lib.xrd_gs_render_bwd(
-                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
-                _lib.ptr(conic_o), _lib.ptr(cl), _lib.ptr(final_T),
-                _lib.ptr(n_contrib), _lib.ptr(gc), _lib.ptr(d_mean2D),
-                _lib.ptr(d_conic), _lib.ptr(d_op), _lib.ptr(d_col), st),
-                'xrd_gs_render_bwd')
+        d_mean2D, d_conic, d_op, d_col, _ = _blend_bwd(
+            lib, cam, dev, st, n, ranges, plist, xy, conic_o, cl, None,
+            final_T, n_contrib, color, None, gc, None, ckpt,
+            (ctx.cap, key_pos, offsets))
         d_means, d_means2D, d_scales, d_rots = _geometry_backward(
             lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic)
         return d_means, d_means2D, d_op, d_col, d_scales, d_rots, None
@@ -338,27 +421,21 @@ class _RasterizeDualFn(torch.autograd.Function):
         cb = colors_b.detach().float().contiguous()
         f = dict(dtype=torch.float32, device=dev)
         i = dict(dtype=torch.int32, device=dev)
-        depths, xy, conic_o, radii, ranges, plist, n_keys = _geometry(
+        depths, xy, conic_o, radii, ranges, plist, n_keys, bins = _geometry(
             lib, cam, dev, st, m3, sc, rt, op)
-        color_a = torch.empty(3, H, W, **f)
-        color_b = torch.empty(3, H, W, **f)
-        depth = torch.empty(1, H, W, **f)
-        final_T = torch.empty(H, W, **f)
-        n_contrib = torch.empty(H, W, **i)
-        with _Timed('gs_render_fwd'):
-            _lib.check(lib.xrd_gs_render_fwd2(
-                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
-                _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(conic_o),
-                _lib.ptr(depths), _lib.ptr(color_a), _lib.ptr(color_b),
-                _lib.ptr(depth), _lib.ptr(final_T), _lib.ptr(n_contrib), st),
-                'xrd_gs_render_fwd2')
+        color_a, color_b, depth, final_T, n_contrib, ckpt = _blend_fwd(
+            lib, cam, dev, st, H, W, ranges, plist, xy, ca, cb, conic_o,
+            depths, bins[0])
         if PROFILE is not None:
             PROFILE.setdefault('pairs', []).append(n_contrib.sum())
             PROFILE.setdefault('keys', []).append(n_keys.clone())
             PROFILE.setdefault('gaussians', []).append(n)
-        ctx.rs, ctx.n = rs, n
+        ctx.rs, ctx.n, ctx.cap = rs, n, bins[0]
+        ctx.has_ckpt = ckpt is not None
+        extra = [ckpt, bins[1], bins[2], color_a, color_b] \
+            if ckpt is not None else []
         ctx.save_for_backward(m3, sc, rt, ca, cb, xy, conic_o, radii, ranges,
-                              plist, final_T, n_contrib)
+                              plist, final_T, n_contrib, *extra)
         ctx.mark_non_differentiable(radii, depth)
         return color_a, radii, depth, color_b
 
@@ -366,30 +443,24 @@ class _RasterizeDualFn(torch.autograd.Function):
     def backward(ctx, g_a, g_radii, g_depth, g_b):
         lib = _lib.lib()
         (m3, sc, rt, ca, cb, xy, conic_o, radii, ranges, plist, final_T,
-         n_contrib) = ctx.saved_tensors
+         n_contrib) = ctx.saved_tensors[:12]
+        ckpt = key_pos = offsets = color_a = color_b = None
+        if ctx.has_ckpt:
+            ckpt, key_pos, offsets, color_a, color_b = ctx.saved_tensors[12:]
         dev = m3.device
         st = _lib.stream_ptr(dev)
         cam = _camera(ctx.rs)
         n = ctx.n
         f = dict(dtype=torch.float32, device=dev)
-        d_mean2D = torch.zeros(n, 2, **f)
-        d_conic = torch.zeros(n, 3, **f)
-        d_op = torch.zeros(n, 1, **f)
-        d_ca = torch.zeros(n, 3, **f)
-        d_cb = torch.zeros(n, 3, **f)
         H, W = cam.image_height, cam.image_width
         ga = g_a.float().contiguous() if g_a is not None \
             else torch.zeros(3, H, W, **f)
         gb = g_b.float().contiguous() if g_b is not None \
             else torch.zeros(3, H, W, **f)
-        with _Timed('gs_render_bwd'):
-            _lib.check(lib.xrd_gs_render_bwd2(
-                C.byref(cam), _lib.ptr(ranges), _lib.ptr(plist), _lib.ptr(xy),
-                _lib.ptr(conic_o), _lib.ptr(ca), _lib.ptr(cb),
-                _lib.ptr(final_T), _lib.ptr(n_contrib), _lib.ptr(ga),
-                _lib.ptr(gb), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
-                _lib.ptr(d_op), _lib.ptr(d_ca), _lib.ptr(d_cb), st),
-                'xrd_gs_render_bwd2')
+        d_mean2D, d_conic, d_op, d_ca, d_cb = _blend_bwd(
+            lib, cam, dev, st, n, ranges, plist, xy, conic_o, ca, cb, final_T,
+            n_contrib, color_a, color_b, ga, gb, ckpt,
+            (ctx.cap, key_pos, offsets))
         d_means, d_means2D, d_scales, d_rots = _geometry_backward(
             lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic)
         return d_means, d_means2D, d_op, d_ca, d_cb, d_scales, d_rots, None
