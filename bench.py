@@ -754,15 +754,18 @@ def run_splatam(args, dev):
         'bound': 'mfma', 'achieved': bwd_flops / (us['gs_render_bwd'] * 1e-6)
         / 1e12, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
         'frac': bwd_flops / (us['gs_render_bwd'] * 1e-6) / MFMA_F32_PEAK,
-        'traffic': pmc_traffic(['gs_render_bwd_kernel'],
+        'traffic': pmc_traffic(['gs_blend_bwd_kernel',
+                                'gs_key_reduce_kernel'],
                                'r03_pmc_splatam.json'),
         'traffic_source': 'profiles/r03_pmc_splatam.json (rocprofv3 --pmc '
                           'FETCH_SIZE / WRITE_SIZE passes of this workload, '
                           'FETCH x2 on gfx950)',
-        'kernel': 'gs_render_bwd<dual> (tile-local blend backward of the rgb '
-                  'and the depth/silhouette colours in one pass: fp32 VALU, '
-                  'wave-reduced atomics to the per-Gaussian gradients; the '
-                  'peak is the fp32 FMA rate, equal to the f32 MFMA peak)',
+        'kernel': 'xrd_gs_blend_bwd<dual> = gs_blend_bwd_kernel + '
+                  'gs_key_reduce_kernel (blend backward of the rgb and the '
+                  'depth/silhouette colours in one pass: one lane per '
+                  'Gaussian, the tile\'s pixels streamed through the lanes, '
+                  'no reductions or atomics; fp32 VALU — the peak is the fp32 '
+                  'FMA rate, equal to the f32 MFMA peak)',
         'avg_launch_us': us['gs_render_bwd'],
         'launches': len(prof['gs_render_bwd']),
         'pixel_gaussian_pairs_per_pass': pairs,
@@ -1191,6 +1194,8 @@ def main():
     cam = Camera(**CAM)
     algo = cfg.setup(camera=cam, device=str(dev))
     algo.use_graphs = not args.no_graphs
+    # --no-graphs (counter passes): same kernels as the captured iterations
+    algo.eager_fixed_shapes = bool(args.no_graphs)
     if os.environ.get('XRD_PERSISTENT_SHARDED') == '0':   # A/B switch
         algo.persistent_map_graph_sharded = False
     xdist.state.setup(dev, seed=0)

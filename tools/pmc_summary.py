@@ -11,19 +11,18 @@ acc = collections.defaultdict(list)
 
 
 def short_name(name):
-    m = re.search(r'nice_(fwd|bwd)_kernel<(\d+), (\d+)(?:, (\w+), (\w+))?>',
-                  name)
-    if m:
-        return (f'nice_{m.group(1)}<dec/stage={m.group(2)},NT={m.group(3)},'
-                f'dp={m.group(4)},dw={m.group(5)}>')
-    m = re.search(r'nice_bwd_fused_kernel<(\d+), (\d+), (\w+), (\w+)>', name)
-    if m:
-        return (f'nice_bwd_fused<stage={m.group(1)},NT={m.group(2)},'
-                f'dp={m.group(3)},dw={m.group(4)}>')
     m = re.search(r'nice_map_fused_kernel<(\d+), (\d+), (\w+), (\w+)>', name)
     if m:
         return (f'nice_map_fused<stage={m.group(1)},NT={m.group(2)},'
                 f'dp={m.group(3)},dw={m.group(4)}>')
+    m = re.search(r'nice_bwd_fused_kernel<(\d+), (\d+), (\w+), (\w+)'
+                  r'(?:, \d+)?>', name)
+    if m:
+        return (f'nice_bwd_fused<stage={m.group(1)},NT={m.group(2)},'
+                f'dp={m.group(3)},dw={m.group(4)}>')
+    m = re.search(r'nice_fwd_kernel<(\d+), (\d+)(?:, \d+)?>', name)
+    if m:
+        return f'nice_fwd<stage={m.group(1)},NT={m.group(2)}>'
     m = re.search(r'coslam_bwd_kernel<(\w+), (\w+)>', name)
     if m:
         return f'coslam_bwd<dp={m.group(1)},dg={m.group(2)}>'
@@ -44,7 +43,9 @@ def short_name(name):
               'point_color_bwd_kernel', 'point_color_fwd_kernel',
               'pc_dw_reduce_kernel', 'pc_dw_kernel', 'point_geo_bwd_kernel',
               'point_geo_fwd_kernel', 'point_map_loss_kernel',
-              'gs_bin', 'frustum_select_kernel', 'frustum_depth_kernel'):
+              'gs_blend_fwd_kernel', 'gs_blend_bwd_kernel',
+              'gs_key_reduce_kernel', 'frustum_select_kernel',
+              'frustum_depth_kernel'):
         if k in name:
             return k
     return None

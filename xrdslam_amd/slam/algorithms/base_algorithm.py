@@ -598,7 +598,12 @@ class Algorithm:
                     'c2w': torch.zeros(4, 4, device=pdev),
                     'valid': torch.zeros((), dtype=torch.bool, device=pdev)}
             graphed = self._graphs_ok(optimizers, is_mapping)
-            self.fixed_shape_batches = graphed
+            # eager_fixed_shapes: the un-compacted batches (and with them the
+            # fused iteration kernels) without graph capture — what a counter
+            # pass profiles (rocprofv3 --pmc with --no-graphs)
+            self.fixed_shape_batches = graphed or \
+                (getattr(self, 'eager_fixed_shapes', False) and
+                 torch.device(self.device).type == 'cuda')
             # multi-GPU mapping: the per-iteration all-reduce stays eager
             # between a "gradient" graph and a "step" graph
             split = graphed and is_mapping and _dist.state.enabled
