@@ -1122,6 +1122,9 @@ def main():
     ap.add_argument('--no-others', action='store_true',
                     help='default run: skip the Vox-Fusion / SplaTAM / '
                          'Point-SLAM objects and the files-ingest leg')
+    ap.add_argument('--random-decoders', action='store_true',
+                    help='NICE-SLAM: random-init decoders instead of the '
+                         'checkpoint pre-trained on the synthetic room')
     ap.add_argument('--no-graphs', action='store_true',
                     help='run every iteration eagerly (no hipGraph capture)')
     ap.add_argument('--first-iters', type=int, default=None,
@@ -1191,6 +1194,13 @@ def main():
     cfg = nice_slam_config(BOUND)
     if args.first_iters is not None:
         cfg.mapping_first_n_iters = args.first_iters
+    # decoders with an occupancy prior (tools/pretrain_nice_decoders.py: the
+    # reference loads pretrained/{coarse,middle_fine}.pt, LFS pointers in its
+    # tree); same architecture and work per iteration as random init
+    pre = os.path.join(ROOT, 'xrdslam_amd', 'data', 'pretrained',
+                       'nice_decoders_synth.pt')
+    if os.path.exists(pre) and not args.random_decoders:
+        cfg.model.pretrained_decoders_xrd = pre
     cam = Camera(**CAM)
     algo = cfg.setup(camera=cam, device=str(dev))
     algo.use_graphs = not args.no_graphs
@@ -1363,7 +1373,12 @@ def main():
                            'one H2D per frame on a side stream)'),
                 'ate_rmse_m': ate,
                 # after rigid alignment, the number ds-eval reports
-                'ate_rmse_aligned_m': ate_aligned},
+                'ate_rmse_aligned_m': ate_aligned,
+                'decoders': ('pre-trained on the synthetic room (tools/'
+                             'pretrain_nice_decoders.py), middle/fine fixed '
+                             'like the reference' if
+                             cfg.model.pretrained_decoders_xrd else
+                             'random init (seeded)')},
             'roofline': roofline, 'cpu_baseline': cpu,
             # the oracle's unfused torch ops on this GPU (a second baseline,
             # not a product path)

@@ -13,7 +13,7 @@ of the synthetic sequence at their ground-truth poses (the bench runs frames
 0..110 of the same room: the prior is scene-specific, as the checkpoint's
 name says); only the DECODERS are kept.
 
-    python tools/pretrain_nice_decoders.py [iters]
+    python tools/pretrain_nice_decoders.py [iters [out.pt]]
 """
 import os
 import sys
@@ -37,6 +37,7 @@ OUT = os.path.join(ROOT, 'xrdslam_amd', 'data', 'pretrained',
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
+    out_path = sys.argv[2] if len(sys.argv) > 2 else OUT
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     np.random.seed(0)
@@ -102,10 +103,10 @@ def main():
         if it % 250 == 0 or it == iters - 1:
             print(f'it {it:5d} {stage:6s} loss/ray {float(loss):.4f} '
                   f'({time.time() - t0:.0f} s)', flush=True)
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     torch.save({kind: {n: v.detach().cpu() for n, v in sd.items()}
-                for kind, sd in decs.items()}, OUT)
-    print('wrote', OUT, os.path.getsize(OUT) // 1024, 'KiB')
+                for kind, sd in decs.items()}, out_path)
+    print('wrote', out_path, os.path.getsize(out_path) // 1024, 'KiB')
 
 
 if __name__ == '__main__':

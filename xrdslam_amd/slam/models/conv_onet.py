@@ -36,6 +36,10 @@ class ConvOnetConfig(ModelConfig):
     occupancy: bool = True
     pretrained_decoders_coarse: Optional[Path] = None
     pretrained_decoders_middle_fine: Optional[Path] = None
+    # {kind: state_dict} of all four decoders in one file (made by
+    # tools/pretrain_nice_decoders.py on the synthetic room: the reference's
+    # own checkpoints are git-LFS pointers)
+    pretrained_decoders_xrd: Optional[Path] = None
     data_dim: int = 3
     model_c_dim: int = 32
     model_pos_embedding_method: str = 'fourier'
@@ -134,6 +138,12 @@ class ConvOnet(Model):
         293-322); with no path the seeded random initialisation is kept (the
         shipped pretrained/*.pt are git-LFS pointers)."""
         cfg = self.config
+        x = cfg.pretrained_decoders_xrd
+        if x is not None and Path(x).is_file():
+            ckpt = torch.load(x, map_location='cpu')
+            for kind, dec in self.decoder.decoders().items():
+                if kind in ckpt:
+                    dec.load_state_dict(ckpt[kind])
         if cfg.coarse and cfg.pretrained_decoders_coarse is not None and \
                 Path(cfg.pretrained_decoders_coarse).is_file():
             ckpt = torch.load(cfg.pretrained_decoders_coarse,
