@@ -737,6 +737,56 @@ int xrd_gs_blend_bwd(const xrd_gs_camera* c, int n, int64_t key_capacity,
                      const float* ckpt, float* key_grad, float* dL_dmean2D,
                      float* dL_dconic, float* dL_dopacity, float* dL_dcolors_a,
                      float* dL_dcolors_b, xrd_stream_t stream);
+/* SplaTAM per-iteration glue around the raster pass, one launch each way.
+ *
+ * xrd_gs_prepare_fwd: transform_to_frame + both render-variable dictionaries
+ * (slam/model_components/slam_helpers_splatam.py:263-292, 205-260; call site
+ * gaussian_cloud_splatam.py:47-62).  pose [4,4] row-major is w2c
+ * (pose_is_c2w = 0) or the frame's c2w (pose_is_c2w = 1: the rigid inverse
+ * [R^T | -R^T t] is evaluated in the kernel, replacing torch.inverse of
+ * slam/algorithms/splatam.py:63).  Outputs: pts [N,3] camera-frame centres,
+ * rotations [N,4] = normalize(unnorm_rot), opacities [N] = sigmoid,
+ * scales [N,3] = exp(log_scales) tiled, ds_colors [N,3] = (z, 1, z^2) with z
+ * the depth of pts under first_w2c (third row used).
+ * xrd_gs_prepare_bwd: any upstream gradient may be NULL (zero); Gaussian
+ * gradients are written when their output pointer is non-NULL; g_pose [16]
+ * (gradient w.r.t. the matrix that was passed in, bottom row 0) when non-NULL,
+ * then acc [16] (zero on entry, zero again on return) is required. */
+int xrd_gs_prepare_fwd(int n, const float* means3D, const float* unnorm_rot,
+                       const float* logit_opacities, const float* log_scales,
+                       const float* pose, int pose_is_c2w,
+                       const float* first_w2c, float* pts, float* rotations,
+                       float* opacities, float* scales, float* ds_colors,
+                       xrd_stream_t stream);
+int xrd_gs_prepare_bwd(int n, const float* means3D, const float* unnorm_rot,
+                       const float* logit_opacities, const float* log_scales,
+                       const float* pose, int pose_is_c2w,
+                       const float* first_w2c, const float* g_pts,
+                       const float* g_rotations, const float* g_opacities,
+                       const float* g_scales, const float* g_ds_colors,
+                       float* g_means3D, float* g_unnorm_rot,
+                       float* g_logit_opacities, float* g_log_scales,
+                       float* acc, float* g_pose, xrd_stream_t stream);
+/* GaussianSplatting.get_loss_dict (slam/models/gaussian_splatting.py:102-160)
+ * for use_l1 = True, ignore_outlier_depth_loss = False: masked L1 depth and
+ * L1 colour — tracking: sums (colour over the same mask when use_sil);
+ * mapping: means (colour x rgb_l1_scale, 0.8 in the reference; the SSIM part
+ * is the caller's) — times the weights.  rgb / depth_sil [3,H,W] renders,
+ * target_d [H,W], target_rgb [H,W,3].  stats [8] doubles (sums and counts)
+ * is kept for the backward; no host read-back, no boolean-mask indexing. */
+int xrd_gs_loss_fwd(int H, int W, int is_mapping, int use_sil, float sil_thres,
+                    float w_depth, float w_rgb, float rgb_l1_scale,
+                    const float* rgb, const float* depth_sil,
+                    const float* target_d, const float* target_rgb,
+                    double* stats, float* loss_depth, float* loss_rgb,
+                    xrd_stream_t stream);
+int xrd_gs_loss_bwd(int H, int W, int is_mapping, int use_sil, float sil_thres,
+                    float w_depth, float w_rgb, float rgb_l1_scale,
+                    const float* rgb, const float* depth_sil,
+                    const float* target_d, const float* target_rgb,
+                    const double* stats, const float* g_loss_depth,
+                    const float* g_loss_rgb, float* g_rgb, float* g_depth_sil,
+                    xrd_stream_t stream);
 int xrd_gs_render_fwd(const xrd_gs_camera* cam, const int32_t* ranges,
                       const int32_t* point_list, const float* xy,
                       const float* colors, const float* conic_opacity,

@@ -17,11 +17,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def test_gaussian_splatting_vs_reference():
+@pytest.mark.parametrize('c2w_input', [False, True])
+def test_gaussian_splatting_vs_reference(c2w_input):
     from xrdslam_amd.slam.engine.optimizers import AdamOptimizerConfig
     g = np.load(sg.GOLDEN)
     errs = sg.run(g, 'cuda:0',
-                  lambda p: AdamOptimizerConfig(lr=1e-3).setup(p))
+                  lambda p: AdamOptimizerConfig(lr=1e-3).setup(p),
+                  c2w_input=c2w_input)
     # growth / pruning decisions are thresholded renders: counts must agree
     # exactly; values and gradients at 1e-4
     bad = {k: v for k, v in errs.items()
@@ -107,3 +109,140 @@ def test_splatam_loop_tracks_synthetic_room():
     gt = data[6]['depth']
     assert np.abs(depth - gt)[gt > 0].mean() < 0.05
     assert np.abs(rgb - data[6]['rgb'])[gt > 0].mean() < 0.1
+
+
+def _rand_rigid(gen):
+    q = torch.randn(4, generator=gen, dtype=torch.float64)
+    q = q / q.norm()
+    r, i, j, k = q
+    R = torch.stack([
+        1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r),
+        2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r),
+        2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)
+    ]).reshape(3, 3)
+    M = torch.eye(4, dtype=torch.float64)
+    M[:3, :3] = R
+    M[:3, 3] = torch.randn(3, generator=gen, dtype=torch.float64)
+    return M
+
+
+@pytest.mark.parametrize('mode', ['track_c2w', 'track_w2c', 'map', 'ba'])
+def test_prepare_kernel_vs_torch_helpers(mode):
+    """xrd_gs_prepare_fwd/_bwd against the reference's op sequence
+    (transform_to_frame + the two render-variable dictionaries,
+    slam_helpers_splatam.py:205-292) in float64 on the host"""
+    from xrdslam_amd.engine.gs import GsPrepareFn
+    from xrdslam_amd.slam.model_components import slam_helpers_splatam as sh
+    gen = torch.Generator().manual_seed(3)
+    n = 5001
+    P = {'means3D': torch.randn(n, 3, generator=gen, dtype=torch.float64) * 2,
+         'unnorm_rotations': torch.randn(n, 4, generator=gen,
+                                         dtype=torch.float64),
+         'logit_opacities': torch.randn(n, 1, generator=gen,
+                                        dtype=torch.float64),
+         'log_scales': torch.randn(n, 1, generator=gen,
+                                   dtype=torch.float64) - 3,
+         'rgb_colors': torch.rand(n, 3, generator=gen, dtype=torch.float64)}
+    c2w = _rand_rigid(gen)
+    first = torch.inverse(_rand_rigid(gen))
+    ups = [torch.randn(n, k, generator=gen, dtype=torch.float64)
+           for k in (3, 4, 1, 3, 3)]
+    g_grad = mode in ('map', 'ba')
+    c_grad = mode != 'map'
+    # float64 chain
+    Pr = {k: v.clone().requires_grad_(g_grad) for k, v in P.items()}
+    c2w_r = c2w.clone().requires_grad_(c_grad)
+    w2c_r = torch.inverse(c2w_r)
+    if mode == 'track_w2c':
+        w2c_r = torch.inverse(c2w).requires_grad_(True)
+    pts = sh.transform_to_frame(Pr['means3D'], w2c_r, g_grad, c_grad)
+    rv = sh.transformed_params2rendervar(Pr, pts)
+    ds = sh.transformed_params2depthplussilhouette(Pr, first, pts)
+    outs_r = [rv['means3D'], rv['rotations'], rv['opacities'], rv['scales'],
+              ds['colors_precomp']]
+    sum((o * u).sum() for o, u in zip(outs_r, ups)).backward()
+    # kernel
+    dev = 'cuda:0'
+    Pk = {k: v.float().to(dev).requires_grad_(g_grad) for k, v in P.items()}
+    pose = (torch.inverse(c2w) if mode == 'track_w2c' else c2w).float() \
+        .to(dev).requires_grad_(c_grad)
+    outs = GsPrepareFn.apply(
+        Pk['means3D'], Pk['unnorm_rotations'], Pk['logit_opacities'],
+        Pk['log_scales'], pose, first.float().to(dev), mode != 'track_w2c',
+        g_grad, c_grad)
+    sum((o * u.float().to(dev)).sum() for o, u in zip(outs, ups)).backward()
+    for o, r in zip(outs, outs_r):
+        assert sg.rel_err(o.detach().cpu(), r.detach()) < 1e-5
+    if g_grad:
+        for k in ('means3D', 'unnorm_rotations', 'logit_opacities',
+                  'log_scales'):
+            assert sg.rel_err(Pk[k].grad.cpu(), Pr[k].grad) < 1e-5, k
+    if c_grad:
+        ref = (w2c_r if mode == 'track_w2c' else c2w_r).grad
+
+        def proj(gr):
+            # c2w: the kernel differentiates the rigid inverse, the chain
+            # above torch.inverse of the full matrix — same projection on
+            # the pose's tangent space (splatam_golden_util.se3_tangent)
+            gr = gr.detach().cpu().numpy()
+            return gr[:3] if mode == 'track_w2c' else \
+                sg.se3_tangent(c2w.numpy(), gr)
+        assert sg.rel_err(proj(pose.grad), proj(ref)) < 1e-4
+    # a second backward reuses the zeroed accumulator
+    if c_grad:
+        pose2 = pose.detach().clone().requires_grad_(True)
+        outs = GsPrepareFn.apply(
+            Pk['means3D'].detach(), Pk['unnorm_rotations'].detach(),
+            Pk['logit_opacities'].detach(), Pk['log_scales'].detach(), pose2,
+            first.float().to(dev), mode != 'track_w2c', False, True)
+        sum((o * u.float().to(dev)).sum()
+            for o, u in zip(outs, ups)).backward()
+        if mode != 'ba':
+            assert sg.rel_err(proj(pose2.grad), proj(ref)) < 1e-4
+
+
+@pytest.mark.parametrize('is_mapping,use_sil', [(False, True), (False, False),
+                                                (True, False)])
+def test_loss_kernel_vs_reference_formulation(is_mapping, use_sil):
+    """xrd_gs_loss_* against the boolean-mask formulation of
+    gaussian_splatting.py:102-160 (this repo's host mirror of it on the CPU),
+    NaN renders and empty-depth pixels included"""
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.gaussian_splatting import (
+        GaussianSplatting, GaussianSplattingConfig)
+    gen = torch.Generator().manual_seed(5)
+    H, W = 60, 81
+    rgb = torch.rand(3, H, W, generator=gen)
+    ds = torch.rand(3, H, W, generator=gen)
+    ds[0] = ds[0] * 3
+    ds[1] = 0.9 + 0.1 * ds[1] * 1.08        # around the 0.99 threshold
+    ds[2] = ds[0]**2 + 0.01 * ds[2]
+    ds[0, 3, 5] = float('nan')
+    ds[2, 7, 9] = float('nan')
+    td = torch.rand(H, W, generator=gen) * 3
+    td[torch.rand(H, W, generator=gen) < 0.2] = 0
+    tc = torch.rand(H, W, 3, generator=gen)
+    cfg = GaussianSplattingConfig()
+    cfg.tracking_use_sil_for_loss = use_sil
+    cam = Camera(50., 50., 40., 30., W, H)
+    res = {}
+    for dev in ('cpu', 'cuda:0'):
+        model = GaussianSplatting(cfg, cam, None).to(dev)
+        r = rgb.clone().to(dev).requires_grad_(True)
+        d = ds.clone().to(dev).requires_grad_(True)
+        ld = model.get_loss_dict({'rgb': r, 'depth_sil': d},
+                                 {'target_d': td.numpy(),
+                                  'target_s': tc.numpy()}, is_mapping)
+        (ld['depth'] * 1.7 + ld['rgb'] * 0.6).backward()
+        res[dev] = (ld['depth'].item(), ld['rgb'].item(), r.grad.cpu(),
+                    d.grad.cpu())
+    a, b = res['cuda:0'], res['cpu']
+    assert abs(a[0] - b[0]) < 1e-5 * abs(b[0])
+    assert abs(a[1] - b[1]) < 1e-5 * abs(b[1])
+    ga, gb = torch.nan_to_num(a[3]), torch.nan_to_num(b[3])
+    assert sg.rel_err(ga, gb) < 1e-5
+    if is_mapping:
+        # SSIM part: fused kernel vs convolutions
+        assert sg.rel_err(a[2], b[2]) < 1e-4
+    else:
+        assert sg.rel_err(a[2], b[2]) < 1e-5

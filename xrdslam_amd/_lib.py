@@ -164,6 +164,12 @@ _SIGS = {
     'xrd_gs_blend_ckpt_floats': (i64, [i64, C.c_int, C.c_int]),
     'xrd_gs_blend_fwd': (C.c_int, [vp] * 15),
     'xrd_gs_blend_bwd': (C.c_int, [vp, C.c_int, i64] + [vp] * 22),
+    'xrd_gs_prepare_fwd': (C.c_int, [C.c_int] + [vp] * 5 + [C.c_int] +
+                           [vp] * 7),
+    'xrd_gs_prepare_bwd': (C.c_int, [C.c_int] + [vp] * 5 + [C.c_int] +
+                           [vp] * 13),
+    'xrd_gs_loss_fwd': (C.c_int, [C.c_int] * 4 + [f32] * 4 + [vp] * 8),
+    'xrd_gs_loss_bwd': (C.c_int, [C.c_int] * 4 + [f32] * 4 + [vp] * 10),
     'xrd_gs_render_fwd': (C.c_int, [vp] * 12),
     'xrd_gs_render_bwd': (C.c_int, [vp] * 14),
     'xrd_gs_render_fwd2': (C.c_int, [vp] * 14),

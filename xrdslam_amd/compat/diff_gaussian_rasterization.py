@@ -202,12 +202,13 @@ def _geometry(lib, cam, dev, st, m3, sc, rt, op):
     n = m3.shape[0]
     f = dict(dtype=torch.float32, device=dev)
     i = dict(dtype=torch.int32, device=dev)
-    depths = torch.zeros(n, **f)
-    xy = torch.zeros(n, 2, **f)
-    conic_o = torch.zeros(n, 4, **f)
-    radii = torch.zeros(n, **i)
-    rect = torch.zeros(n, 4, **i)
-    tiles = torch.zeros(n, **i)
+    # xrd_gs_preprocess writes every row (zeros for culled Gaussians)
+    depths = torch.empty(n, **f)
+    xy = torch.empty(n, 2, **f)
+    conic_o = torch.empty(n, 4, **f)
+    radii = torch.empty(n, **i)
+    rect = torch.empty(n, 4, **i)
+    tiles = torch.empty(n, **i)
     with _Timed('gs_preprocess'):
         _lib.check(lib.xrd_gs_preprocess(
             C.byref(cam), n, _lib.ptr(m3), _lib.ptr(sc), _lib.ptr(rt),
@@ -327,7 +328,7 @@ def _blend_bwd(lib, cam, dev, st, n, ranges, plist, xy, conic_o, ca, cb,
 
 
 def _geometry_backward(lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D,
-                       d_conic):
+                       d_conic, want_means2D=True):
     f = dict(dtype=torch.float32, device=dev)
     d_means = torch.empty(n, 3, **f)
     d_scales = torch.empty(n, 3, **f)
@@ -337,7 +338,8 @@ def _geometry_backward(lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D,
         _lib.ptr(radii), _lib.ptr(d_mean2D), _lib.ptr(d_conic),
         _lib.ptr(d_means), _lib.ptr(d_scales), _lib.ptr(d_rots), st),
         'xrd_gs_preprocess_bwd')
-    d_means2D = torch.cat([d_mean2D, torch.zeros(n, 1, **f)], 1)
+    d_means2D = torch.cat([d_mean2D, torch.zeros(n, 1, **f)], 1) \
+        if want_means2D else None
     return d_means, d_means2D, d_scales, d_rots
 
 
@@ -393,7 +395,8 @@ class _RasterizeFn(torch.autograd.Function):
             final_T, n_contrib, color, None, gc, None, ckpt,
             (ctx.cap, key_pos, offsets))
         d_means, d_means2D, d_scales, d_rots = _geometry_backward(
-            lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic)
+            lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic,
+            ctx.needs_input_grad[1])
         return d_means, d_means2D, d_op, d_col, d_scales, d_rots, None
 
 
@@ -462,7 +465,8 @@ class _RasterizeDualFn(torch.autograd.Function):
             n_contrib, color_a, color_b, ga, gb, ckpt,
             (ctx.cap, key_pos, offsets))
         d_means, d_means2D, d_scales, d_rots = _geometry_backward(
-            lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic)
+            lib, cam, dev, st, n, m3, sc, rt, radii, d_mean2D, d_conic,
+            ctx.needs_input_grad[1])
         return d_means, d_means2D, d_op, d_ca, d_cb, d_scales, d_rots, None
 
 

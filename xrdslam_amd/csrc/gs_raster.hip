@@ -125,6 +125,11 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(
   radii[i] = 0;
   tiles[i] = 0;
   rect[i * 4 + 0] = rect[i * 4 + 1] = rect[i * 4 + 2] = rect[i * 4 + 3] = 0;
+  // every output row is written: callers hand over uninitialised buffers
+  depths[i] = 0.f;
+  xy[i * 2 + 0] = xy[i * 2 + 1] = 0.f;
+  conic_o[i * 4 + 0] = conic_o[i * 4 + 1] = conic_o[i * 4 + 2] =
+      conic_o[i * 4 + 3] = 0.f;
   Proj P;
   project(cam, means + i * 3, scales + i * 3, rots + i * 4, P);
   if (P.pv[2] <= 0.2f) return;

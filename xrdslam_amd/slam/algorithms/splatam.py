@@ -49,9 +49,17 @@ class SplaTAM(Algorithm):
 
     def get_model_input(self, optimize_frames, is_mapping):
         f = optimize_frames[np.random.randint(0, len(optimize_frames))]
-        return {'w2c': torch.inverse(f.get_pose().to(self.device)),
-                'target_s': f.rgb, 'target_d': f.depth,
-                'is_mapping': is_mapping, 'retain_grad': True}
+        inp = {'target_s': f.rgb, 'target_d': f.depth, 'frame': f,
+               'is_mapping': is_mapping, 'retain_grad': True}
+        pose = f.get_pose().to(self.device)
+        if pose.is_cuda:
+            # the rigid inverse is taken inside the preparation kernel
+            # (csrc/gs_prepare.hip) — torch.inverse is an LU factorisation
+            # with a host sync per iteration
+            inp['c2w'] = pose
+        else:
+            inp['w2c'] = torch.inverse(pose)
+        return inp
 
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):
@@ -75,8 +83,11 @@ class SplaTAM(Algorithm):
         with torch.no_grad():
             if isinstance(c2w, np.ndarray):
                 c2w = torch.from_numpy(c2w)
-            out = self.model({'w2c': torch.inverse(c2w.to(self.device)),
-                              'is_mapping': True, 'retain_grad': False})
+            c2w = c2w.to(self.device)
+            pose = {'c2w': c2w} if c2w.is_cuda else \
+                {'w2c': torch.inverse(c2w)}
+            out = self.model({**pose, 'is_mapping': True,
+                              'retain_grad': False})
             rdepth = out['depth_sil'][0] if use_sil_depth \
                 else out['depth'].squeeze(0)
             valid = torch.as_tensor(gt_depth > 0).to(self.device) & \

@@ -64,4 +64,14 @@ class Frame(nn.Module):
             d = torch.as_tensor(self.depth, dtype=torch.float32).to(device)
             c = torch.as_tensor(self.rgb, dtype=torch.float32).to(device)
             self._dev_cache = (d.reshape(-1, 1), c.reshape(-1, 3))
+            self._dev_chw = None
         return self._dev_cache
+
+    def device_rgb_chw(self, device):
+        """rgb as [3,H,W] f32 on ``device`` (SplaTAM's image-space losses),
+        permuted once per frame"""
+        _, c = self.device_images(device)
+        if getattr(self, '_dev_chw', None) is None:
+            self._dev_chw = c.reshape(self.h, self.w, 3).permute(2, 0, 1) \
+                .contiguous()
+        return self._dev_chw

@@ -46,7 +46,13 @@ class GaussianCloud(nn.Module):
 
     # -- rendering ---------------------------------------------------------------
     def render(self, w2c, gaussians_grad=False, camera_grad=False,
-               retain_grad=True):
+               retain_grad=True, c2w=None):
+        """``w2c`` [4,4], or ``c2w`` (then the rigid inverse is taken inside
+        the preparation kernel instead of a torch.inverse per iteration)"""
+        if self.fused_passes and self.params['means3D'].is_cuda:
+            return self._render_fused(w2c, c2w, gaussians_grad, camera_grad)
+        if w2c is None:
+            w2c = torch.inverse(c2w)
         pts = transform_to_frame(self.params['means3D'], w2c,
                                  gaussians_grad=gaussians_grad,
                                  camera_grad=camera_grad)
@@ -55,26 +61,39 @@ class GaussianCloud(nn.Module):
             self.params, self.first_frame_w2c, pts)
         if retain_grad:
             rv['means2D'].retain_grad()
-        if self.fused_passes and pts.is_cuda:
-            # both renders share every Gaussian's geometry and opacity: one
-            # preprocess / binning / blend each way with two colour sets
-            # (compat.rasterize_dual).  The retained means2D gradient then
-            # carries BOTH renders' contributions; it only feeds the 3D-GS
-            # densification statistics, which switch this path off
-            # (fused_passes = not use_gaussian_splatting_densification)
-            im, radius, depth, depth_sil = _dgr.rasterize_dual(
-                self.gaussian_cam, rv['means3D'], rv['means2D'],
-                rv['opacities'], rv['colors_precomp'],
-                ds_rv['colors_precomp'], rv['scales'], rv['rotations'])
-        else:
-            im, radius, depth = _renderer(self.gaussian_cam)(**rv)
-            depth_sil, _, _ = _renderer(self.gaussian_cam)(**ds_rv)
+        im, radius, depth = _renderer(self.gaussian_cam)(**rv)
+        depth_sil, _, _ = _renderer(self.gaussian_cam)(**ds_rv)
         if retain_grad:
             self.variables['means2D'] = rv['means2D']
         seen = radius > 0
         self.variables['max_2D_radius'][seen] = torch.max(
             radius[seen], self.variables['max_2D_radius'][seen])
         self.variables['seen'] = seen
+        return {'rgb': im, 'depth_sil': depth_sil, 'depth': depth}
+
+    def _render_fused(self, w2c, c2w, gaussians_grad, camera_grad):
+        """MI355X path: one preparation launch (csrc/gs_prepare.hip) + one
+        raster pass with two colour sets (compat.rasterize_dual): both
+        renders share every Gaussian's geometry and opacity.  means2D
+        carries no gradient here — it only feeds the 3D-GS densification
+        statistics, which switch this path off (fused_passes = not
+        use_gaussian_splatting_densification)."""
+        from ...engine.gs import GsPrepareFn
+        p = self.params
+        pose, is_c2w = (c2w, True) if c2w is not None else (w2c, False)
+        pts, rot, opac, scales, dscol = GsPrepareFn.apply(
+            p['means3D'], p['unnorm_rotations'], p['logit_opacities'],
+            p['log_scales'], pose, self.first_frame_w2c, is_c2w,
+            gaussians_grad, camera_grad)
+        colors = p['rgb_colors'] if gaussians_grad else \
+            p['rgb_colors'].detach()
+        im, radius, depth, depth_sil = _dgr.rasterize_dual(
+            self.gaussian_cam, pts, None, opac, colors, dscol, scales, rot)
+        # max over the seen Gaussians == max over all (unseen: radius 0)
+        mr = self.variables['max_2D_radius']
+        torch.maximum(mr, radius, out=mr)
+        self.variables['radius'] = radius
+        self.variables.pop('seen', None)
         return {'rgb': im, 'depth_sil': depth_sil, 'depth': depth}
 
     # -- optimiser surgery -------------------------------------------------------

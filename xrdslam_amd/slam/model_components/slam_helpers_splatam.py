@@ -57,7 +57,8 @@ def calc_ssim(img1, img2, window_size=11, size_average=True):
 
 
 def accumulate_mean2d_gradient(variables):
-    seen = variables['seen']
+    seen = variables['seen'] if 'seen' in variables else \
+        variables['radius'] > 0
     variables['means2D_gradient_accum'][seen] += torch.norm(
         variables['means2D'].grad[seen, :2], dim=-1)
     variables['denom'][seen] += 1

@@ -99,8 +99,8 @@ class GaussianSplatting(Model):
             g_grad, c_grad = True, False       # Gaussians only
         if not retain:                         # plain image rendering
             g_grad = c_grad = False
-        return self.gaussian_cloud.render(input['w2c'], g_grad, c_grad,
-                                          retain)
+        return self.gaussian_cloud.render(input.get('w2c'), g_grad, c_grad,
+                                          retain, c2w=input.get('c2w'))
 
     def get_loss_dict(self, outputs, inputs, is_mapping,
                       stage=None) -> Dict[str, torch.Tensor]:
@@ -112,10 +112,13 @@ class GaussianSplatting(Model):
         ignore_outlier = getattr(cfg, f'{mode}_ignore_outlier_depth_loss')
         weights = getattr(cfg, f'{mode}_loss_weights')
         dev = self.device
+        rgb, depth_sil = outputs['rgb'], outputs['depth_sil']
+        if rgb.is_cuda and use_l1 and not ignore_outlier:
+            return self._loss_dict_fused(outputs, inputs, is_mapping, use_sil,
+                                         sil_thres, weights)
         target_d = torch.as_tensor(inputs['target_d']).to(dev).unsqueeze(0)
         target_rgb = torch.permute(
             torch.as_tensor(inputs['target_s']).to(dev), (2, 0, 1)).float()
-        rgb, depth_sil = outputs['rgb'], outputs['depth_sil']
         depth = depth_sil[0].unsqueeze(0)
         presence = depth_sil[1] > sil_thres
         uncertainty = (depth_sil[2].unsqueeze(0) - depth**2).detach()
@@ -142,6 +145,34 @@ class GaussianSplatting(Model):
             losses['rgb'] = 0.8 * l1_loss_v1(rgb, target_rgb) + \
                 0.2 * (1.0 - calc_ssim(rgb, target_rgb))
         return {k: v * weights[k] for k, v in losses.items()}
+
+    def _loss_dict_fused(self, outputs, inputs, is_mapping, use_sil,
+                         sil_thres, weights):
+        """the same losses as one statistics launch + one gradient launch
+        (csrc/gs_prepare.hip: xrd_gs_loss_*), targets read from the frame's
+        device-resident images: no boolean-mask gathers (a host sync and a
+        sort in their backward), no per-iteration upload / permute"""
+        from ...engine.gs import GsLossFn
+        from ...engine import slam_ops
+        dev = self.device
+        frame = inputs.get('frame')
+        if frame is not None:
+            target_d, target_rgb = frame.device_images(dev)
+        else:
+            target_d = torch.as_tensor(inputs['target_d']).to(dev).float()
+            target_rgb = torch.as_tensor(inputs['target_s']).to(dev).float()
+        rgb, depth_sil = outputs['rgb'], outputs['depth_sil']
+        ld, lc = GsLossFn.apply(
+            rgb, depth_sil, target_d, target_rgb, is_mapping,
+            (not is_mapping) and use_sil, sil_thres, weights['depth'],
+            weights['rgb'], 0.8 if is_mapping else 1.0)
+        if is_mapping:
+            chw = frame.device_rgb_chw(dev) if frame is not None else \
+                target_rgb.reshape(rgb.shape[1], rgb.shape[2], 3) \
+                .permute(2, 0, 1).contiguous()
+            ssim = slam_ops.SsimMapFn.apply(rgb, chw).mean()
+            lc = lc + (0.2 * weights['rgb']) * (1.0 - ssim)
+        return {'depth': ld, 'rgb': lc}
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         return {k: [v.to(self.device)]
