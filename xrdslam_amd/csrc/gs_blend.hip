@@ -1,6 +1,7 @@
-// Tile blend of the 3-D Gaussian rasteriser, third formulation (gfx950):
-// one WAVE per 8x8 SUB-TILE with exact sub-tile culling, both directions
-// front-to-back, per-Gaussian gradients reduced in-wave and summed in LDS.
+// Tile blend of the 3-D Gaussian rasteriser, fourth formulation (gfx950):
+// one WAVE per 8x8 SUB-TILE with exact sub-tile culling, the list entries read
+// as packed records through the SCALAR path, both directions front-to-back,
+// per-Gaussian gradients reduced in-wave and summed in LDS.
 //
 // Replaces the blend part of the unvendored CUDA dependency
 // diff-gaussian-rasterization-w-depth @ cb65e4b (reference call sites
@@ -8,19 +9,28 @@
 // SURVEY.md App. C.3, oracle: oracle/gs_oracle.py, parity unpinned).
 //
 // What bounds this work on MI355X.  Both blends are fp32-VALU bound on
-// (Gaussian, pixel) evaluations.  The published kernels (and the two earlier
+// (Gaussian, pixel) evaluations.  The published kernels (and the first two
 // formulations here) evaluate every Gaussian of a 16x16 tile's list at all 256
 // pixels; SplaTAM's Gaussians are ~1 px sigma, a tile-list entry reaches
 // ~30 of the 256 pixels and the rest fail the alpha >= 1/255 test after the
-// full evaluation (measured: 185 M evaluations per 640x480 pass, 98 M up to
-// the last contributor, < 20 M contributing).  Here the 16x16 tile's block is
-// four waves, one per 8x8 sub-tile.  Per bucket of 64 list entries (staged in
-// LDS once per block) each wave tests entry l against its sub-tile in lane l
-// — the axis-aligned bound of { alpha >= 1/255 } = { power >= -ln(255 op) },
-// widened by a margin — and walks only the set bits of the ballot.  The test
-// can only drop evaluations whose alpha test fails: the set of contributing
-// (Gaussian, pixel) pairs, their order and therefore the image and the
-// gradients are those of the 16x16 formulation.
+// full evaluation (measured at 640x480 / 320 k Gaussians: 185 M evaluations a
+// pass, 98 M up to the last contributor, < 20 M contributing).  Here the
+// 16x16 tile's block is four waves, one per 8x8 sub-tile.  Per chunk of 64
+// list entries a wave tests entry l against its sub-tile in lane l — the
+// axis-aligned bound of { alpha >= 1/255 } = { power >= -ln(255 op) }, widened
+// by a margin — and walks only the set bits of the ballot (measured: 1.75 of
+// the 4 sub-tiles per entry).  The test can only drop evaluations whose alpha
+// test fails: the set of contributing (Gaussian, pixel) pairs, their order and
+// therefore the image and the gradients are those of the 16x16 formulation.
+//
+// Records.  gs_pack writes one 64-byte record per sorted (Gaussian, tile) key:
+// centre, reach, conic pre-scaled by log2(e) (G = v_exp_f32 of one fma
+// chain), opacity, both colour sets, depth.  The entry a wave works on is the
+// same for its 64 lanes: its record is fetched with ONE s_load_dwordx16 into
+// SGPRs (the third formulation staged it in LDS and broadcast-read 52 B per
+// lane and entry — the LDS pipe, not the VALU, was the bound), the next
+// entry's record is in flight while the current one is blended.  The forward
+// has no LDS and no barrier at all.
 //
 // Backward, front to back.  With
 //   dL/dalpha_i = T_i q_i - (R - A_i - q_i alpha_i T_i) / (1 - alpha_i),
@@ -30,12 +40,13 @@
 // forward's image) a pixel needs nothing from the Gaussians behind the current
 // one: the backward walks the list in the forward's order with T and A in
 // registers — no per-pixel history, no checkpoints.  Per entry a wave reduces
-// twelve per-pixel values over its 64 pixels with a transposed DPP merge
-// (12 -> 6 -> 3 registers, then two row shifts; 33 VALU instead of 72) and
-// adds them to the entry's LDS row; after the bucket the block writes one
-// finished gradient row per (Gaussian, tile) key.  gs_key_reduce sums a
-// Gaussian's rows through the inverse map of the binning sort (gs_bin.hip).
-// No global atomics anywhere.
+// twelve per-pixel values over its 64 pixels with a transposed merge
+// (v_permlane32_swap / v_permlane16_swap / DPP: 27 VALU instead of 72 for
+// twelve butterflies) that leaves each sum in its own lane, and adds them to
+// the entry's LDS row with one conflict-free ds_add; after 256 entries the
+// block writes one finished gradient row per (Gaussian, tile) key.
+// gs_key_reduce sums a Gaussian's rows through the inverse map of the binning
+// sort (gs_bin.hip).  No global atomics anywhere.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -45,12 +56,9 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int BLOCK = TILE * TILE;
-#ifndef XRD_GS_BUCKET
-#define XRD_GS_BUCKET 64
-#endif
-constexpr int BUCKET = XRD_GS_BUCKET;  // list entries staged per barrier
-constexpr int CHUNKS = BUCKET / 64;     // 64-entry chunks, one ballot each
-constexpr int KEYROW = 12;  // col a 3, col b 3, mean2D 2, conic 3, opacity 1
+constexpr int BUCKET = 256;  // entries per LDS row block of the backward
+constexpr int KEYROW = 12;   // col a 3, col b 3, mean2D 2, conic 3, opacity 1
+constexpr int REC = 16;      // floats per record
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -59,102 +67,89 @@ struct BCam {
   float bg[3];
 };
 
-// one bucket of a tile's list in LDS
-template <bool DUAL, bool BWD>
-struct Stage {
-  float2 xy[BUCKET];
-  float2 ext[BUCKET];  // half extents of { alpha >= 1/255 } + margin
-  f32x4 q[BUCKET];     // -0.5 log2e A, -log2e B, -0.5 log2e C, opacity
-  f32x4 ca[BUCKET];    // r, g, b, depth
-  f32x4 cb[DUAL ? BUCKET : 1];
-  f32x4 con[BWD ? BUCKET : 1];           // A, B, C, opacity
-  float acc[BWD ? BUCKET * KEYROW : 1];  // per entry: the twelve sums
-};
-
-// wave w of the block fills its share of bucket `b` of the list [r0, r1)
-template <bool DUAL, bool BWD>
-__device__ __forceinline__ void stage_bucket(
-    Stage<DUAL, BWD>& S, int wave, int lane, int r0, int r1, int b,
-    const int* __restrict__ plist, const float* __restrict__ xy,
-    const float* __restrict__ conic_o, const float* __restrict__ colors,
-    const float* __restrict__ colors_b, const float* __restrict__ depths) {
-#pragma unroll
-  for (int c = 0; c < CHUNKS; ++c) {
-  const int e = c * 64 + lane;
-  const int k = r0 + b * BUCKET + e;
-  const bool have = k < r1;
-  const int g = have ? plist[k] : 0;
-  if (wave == 0) {
-    float2 p = make_float2(0.f, 0.f);
-    float2 ex = make_float2(-INFINITY, -INFINITY);  // reaches no pixel
-    if (have) {
-      p = make_float2(xy[g * 2], xy[g * 2 + 1]);
-      const f32x4 co = *reinterpret_cast<const f32x4*>(conic_o + g * 4);
-      const float det = co[0] * co[2] - co[1] * co[1];
-      // alpha = min(.99, op G) >= 1/255 needs -power <= ln(255 op) = tau:
-      // inside the ellipse (1/2) d^T conic d <= tau, whose axis-aligned
-      // half extents are sqrt(2 tau C / det), sqrt(2 tau A / det).  Widened
-      // (1 % + 0.05 in tau, half a pixel) so that rounding in the kernels'
-      // own evaluation can never disagree; anything not provably outside
-      // (NaN, degenerate conic) is evaluated.
-      const float o255 = 255.f * co[3];
-      if (o255 < 0.999f) {
-        // alpha <= op < 1/255 everywhere
-      } else if (det > 0.f && co[0] > 0.f && co[2] > 0.f && o255 < 1e30f) {
-        const float tau = 1.01f * kLn2 * __builtin_amdgcn_logf(o255) + 0.05f;
-        const float s = 2.f * tau / det;
-        ex = make_float2(sqrtf(s * co[2]) + 0.5f, sqrtf(s * co[0]) + 0.5f);
-        if (!(ex.x == ex.x) || !(ex.y == ex.y))
-          ex = make_float2(INFINITY, INFINITY);
-      } else {
-        ex = make_float2(INFINITY, INFINITY);
-      }
+// record of one sorted key:
+//  0 x   1 y   2 ex  3 ey     centre, half extents of { alpha >= 1/255 }
+//  4 q0  5 q1  6 q2  7 op     -0.5 log2e A, -log2e B, -0.5 log2e C, opacity
+//  8 r   9 g  10 b  11 depth
+// 12..14 second colour set, 15 unused
+__global__ __launch_bounds__(256) void gs_pack_kernel(
+    const int* __restrict__ ranges, const int* __restrict__ plist,
+    const float* __restrict__ xy, const float* __restrict__ conic_o,
+    const float* __restrict__ colors, const float* __restrict__ colors_b,
+    const float* __restrict__ depths, float* __restrict__ rec) {
+  const int tile = blockIdx.x;
+  const int r0 = ranges[tile * 2], r1 = ranges[tile * 2 + 1];
+  for (int k = r0 + threadIdx.x; k < r1; k += 256) {
+    const int g = plist[k];
+    const f32x4 co = *reinterpret_cast<const f32x4*>(conic_o + g * 4);
+    float ex = -INFINITY, ey = -INFINITY;   // reaches no pixel
+    const float det = co[0] * co[2] - co[1] * co[1];
+    // alpha = min(.99, op G) >= 1/255 needs -power <= ln(255 op) = tau:
+    // inside the ellipse (1/2) d^T conic d <= tau, whose axis-aligned half
+    // extents are sqrt(2 tau C / det), sqrt(2 tau A / det).  Widened (1 % +
+    // 0.05 in tau, half a pixel) so that rounding in the kernels' own
+    // evaluation can never disagree; anything not provably outside (NaN,
+    // degenerate conic) is evaluated.
+    const float o255 = 255.f * co[3];
+    if (o255 < 0.999f) {
+      // alpha <= op < 1/255 everywhere
+    } else if (det > 0.f && co[0] > 0.f && co[2] > 0.f && o255 < 1e30f) {
+      const float tau = 1.01f * kLn2 * __builtin_amdgcn_logf(o255) + 0.05f;
+      const float s = 2.f * tau / det;
+      ex = sqrtf(s * co[2]) + 0.5f;
+      ey = sqrtf(s * co[0]) + 0.5f;
+      if (!(ex == ex) || !(ey == ey)) ex = ey = INFINITY;
+    } else {
+      ex = ey = INFINITY;
     }
-    S.xy[e] = p;
-    S.ext[e] = ex;
-  } else if (wave == 1) {
-    f32x4 co = {0.f, 0.f, 0.f, 0.f};
-    if (have) co = *reinterpret_cast<const f32x4*>(conic_o + g * 4);
-    S.q[e] = f32x4{-0.5f * kLog2e * co[0], -kLog2e * co[1],
-                      -0.5f * kLog2e * co[2], co[3]};
-    if (BWD) S.con[e] = co;
-  } else if (wave == 2) {
-    f32x4 c = {0.f, 0.f, 0.f, 0.f};
-    if (have)
-      c = f32x4{colors[g * 3], colors[g * 3 + 1], colors[g * 3 + 2],
-                depths ? depths[g] : 0.f};
-    S.ca[e] = c;
-  } else if (DUAL) {
-    f32x4 c = {0.f, 0.f, 0.f, 0.f};
-    if (have)
-      c = f32x4{colors_b[g * 3], colors_b[g * 3 + 1], colors_b[g * 3 + 2],
-                0.f};
-    S.cb[e] = c;
-  }
+    f32x4* out = reinterpret_cast<f32x4*>(rec + (int64_t)k * REC);
+    out[0] = f32x4{xy[g * 2], xy[g * 2 + 1], ex, ey};
+    out[1] = f32x4{-0.5f * kLog2e * co[0], -kLog2e * co[1],
+                   -0.5f * kLog2e * co[2], co[3]};
+    out[2] = f32x4{colors[g * 3], colors[g * 3 + 1], colors[g * 3 + 2],
+                   depths[g]};
+    out[3] = colors_b ? f32x4{colors_b[g * 3], colors_b[g * 3 + 1],
+                              colors_b[g * 3 + 2], 0.f}
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
-// entries of the bucket that can reach the 8x8 sub-tile whose first pixel
-// centre is (sx0, sy0): bit l = entry l
-template <bool DUAL, bool BWD>
-__device__ __forceinline__ uint64_t reach_mask(const Stage<DUAL, BWD>& S,
-                                               int lane, int chunk,
-                                               float sx0, float sy0) {
-  const float2 p = S.xy[chunk * 64 + lane];
-  const float2 e = S.ext[chunk * 64 + lane];
-  const bool hit = p.x + e.x >= sx0 && p.x - e.x <= sx0 + 7.f &&
-                   p.y + e.y >= sy0 && p.y - e.y <= sy0 + 7.f;
+struct Rec {
+  f32x4 a, b, c, d;
+};
+
+// record j of the tile's list: j is wave-uniform, the loads are scalar
+__device__ __forceinline__ Rec load_rec(const float* __restrict__ base,
+                                        int j) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(
+      base + (int64_t)__builtin_amdgcn_readfirstlane(j) * REC);
+  return Rec{p[0], p[1], p[2], p[3]};
+}
+
+// lane l: centre and reach of entry `e` of the list (nothing beyond `len`)
+__device__ __forceinline__ f32x4 load_head(const float* __restrict__ base,
+                                           int e, int len) {
+  if (e >= len) return f32x4{0.f, 0.f, -INFINITY, -INFINITY};
+  return *reinterpret_cast<const f32x4*>(base + (int64_t)e * REC);
+}
+
+// entries of the chunk that can reach the 8x8 sub-tile whose first pixel
+// centre is (sx0, sy0): bit l = lane l's entry
+__device__ __forceinline__ uint64_t reach_mask(const f32x4& h, float sx0,
+                                               float sy0) {
+  const bool hit = h[0] + h[2] >= sx0 && h[0] - h[2] <= sx0 + 7.f &&
+                   h[1] + h[3] >= sy0 && h[1] - h[3] <= sy0 + 7.f;
   return __ballot(hit);
 }
 
-// G = exp(power) of entry (gxy, q) at the pixel, as 2^(log2e power); the
-// forward and the backward share it: same skip decisions
-__device__ __forceinline__ float gauss_weight(float2 gxy, const f32x4& q,
-                                              float pfx, float pfy, float& dx,
-                                              float& dy, float& p2) {
-  dx = gxy.x - pfx;
-  dy = gxy.y - pfy;
-  p2 = dx * (q[0] * dx + q[1] * dy) + q[2] * (dy * dy);
+// G = exp(power) of the record at the pixel, as 2^(log2e power); the forward
+// and the backward share it: same skip decisions
+__device__ __forceinline__ float gauss_weight(const Rec& r, float pfx,
+                                              float pfy, float& dx, float& dy,
+                                              float& p2) {
+  dx = r.a[0] - pfx;
+  dy = r.a[1] - pfy;
+  p2 = dx * (r.b[0] * dx + r.b[1] * dy) + r.b[2] * (dy * dy);
   return __builtin_amdgcn_exp2f(p2);
 }
 
@@ -183,13 +178,10 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
 // and (z, 1, z^2) with identical geometry)
 template <bool DUAL>
 __global__ __launch_bounds__(BLOCK) void gs_blend_fwd_kernel(
-    BCam cam, const int* __restrict__ ranges, const int* __restrict__ plist,
-    const float* __restrict__ xy, const float* __restrict__ colors,
-    const float* __restrict__ colors_b, const float* __restrict__ conic_o,
-    const float* __restrict__ depths, float* __restrict__ out_color,
-    float* __restrict__ out_color_b, float* __restrict__ out_depth,
-    float* __restrict__ final_T, int* __restrict__ n_contrib) {
-  __shared__ Stage<DUAL, false> S;
+    BCam cam, const int* __restrict__ ranges, const float* __restrict__ rec,
+    float* __restrict__ out_color, float* __restrict__ out_color_b,
+    float* __restrict__ out_depth, float* __restrict__ final_T,
+    int* __restrict__ n_contrib) {
   const int gx = (cam.W + TILE - 1) / TILE;
   const int tile = blockIdx.y * gx + blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -199,56 +191,50 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_fwd_kernel(
   const bool inside = px < cam.W && py < cam.H;
   const float pfx = (float)px, pfy = (float)py;
   const int r0 = ranges[tile * 2], r1 = ranges[tile * 2 + 1];
-  const int n_buckets = (r1 - r0 + BUCKET - 1) / BUCKET;
+  const int len = r1 - r0;
+  const float* __restrict__ base = rec + (int64_t)r0 * REC;
+  const int n_chunks = (len + 63) / 64;
   bool done = !inside;
   float T = 1.f, C[3] = {0.f, 0.f, 0.f}, Cb[3] = {0.f, 0.f, 0.f}, D = 0.f;
   int last = 0;
-  for (int b = 0; b < n_buckets; ++b) {
-    if (__syncthreads_count(done) == BLOCK) break;  // also: S is free
-    stage_bucket<DUAL, false>(S, wave, lane, r0, r1, b, plist, xy, conic_o,
-                              colors, colors_b, depths);
-    __syncthreads();
-    for (int c = 0; c < CHUNKS; ++c) {
-      if (__ballot(!done) == 0) break;
-      uint64_t m = reach_mask(S, lane, c, (float)sx0, (float)sy0);
-      if (m == 0) continue;
-      // the next entry's data is read while the current one is blended
-      int j = c * 64 + __builtin_ctzll(m);
-      f32x4 q = S.q[j], cd = S.ca[j], cb = DUAL ? S.cb[j] : f32x4{};
-      float2 gxy = S.xy[j];
-      while (true) {
-        m &= m - 1;
-        const int jn = m ? c * 64 + __builtin_ctzll(m) : j;
-        const f32x4 qn = S.q[jn], cdn = S.ca[jn],
-                    cbn = DUAL ? S.cb[jn] : f32x4{};
-        const float2 gxyn = S.xy[jn];
-        float dx, dy, p2;
-        const float G = gauss_weight(gxy, q, pfx, pfy, dx, dy, p2);
-        const float alpha = fminf(0.99f, q[3] * G);
-        const float test_T = T * (1.f - alpha);
-        const bool use = !done && p2 <= 0.f && alpha >= 1.f / 255.f;
-        if (use && test_T < 0.0001f) done = true;
-        if (use && !done) {
-          const float w = alpha * T;
-          C[0] += cd[0] * w;
-          C[1] += cd[1] * w;
-          C[2] += cd[2] * w;
-          D += cd[3] * w;
-          if (DUAL) {
-            Cb[0] += cb[0] * w;
-            Cb[1] += cb[1] * w;
-            Cb[2] += cb[2] * w;
-          }
-          T = test_T;
-          last = b * BUCKET + j + 1;
+  f32x4 head = load_head(base, lane, len);
+  for (int c = 0; c < n_chunks; ++c) {
+    if (__ballot(!done) == 0) break;
+    uint64_t m = reach_mask(head, (float)sx0, (float)sy0);
+    if (c + 1 < n_chunks) head = load_head(base, (c + 1) * 64 + lane, len);
+    if (m == 0) continue;
+    // the next entry's record is fetched while the current one is blended
+    // (a two-entry-deep variant measured the same: the loop is not bound by
+    // the scalar loads)
+    int j = c * 64 + __builtin_ctzll(m);
+    Rec r = load_rec(base, j);
+    while (true) {
+      m &= m - 1;
+      const int jn = m ? c * 64 + __builtin_ctzll(m) : j;
+      const Rec rn = load_rec(base, jn);
+      float dx, dy, p2;
+      const float G = gauss_weight(r, pfx, pfy, dx, dy, p2);
+      const float alpha = fminf(0.99f, r.b[3] * G);
+      const float test_T = T * (1.f - alpha);
+      const bool use = !done && p2 <= 0.f && alpha >= 1.f / 255.f;
+      if (use && test_T < 0.0001f) done = true;
+      if (use && !done) {
+        const float w = alpha * T;
+        C[0] += r.c[0] * w;
+        C[1] += r.c[1] * w;
+        C[2] += r.c[2] * w;
+        D += r.c[3] * w;
+        if (DUAL) {
+          Cb[0] += r.d[0] * w;
+          Cb[1] += r.d[1] * w;
+          Cb[2] += r.d[2] * w;
         }
-        if (m == 0 || __ballot(!done) == 0) break;
-        j = jn;
-        q = qn;
-        cd = cdn;
-        cb = cbn;
-        gxy = gxyn;
+        T = test_T;
+        last = j + 1;
       }
+      if (m == 0 || __ballot(!done) == 0) break;
+      j = jn;
+      r = rn;
     }
   }
   if (inside) {
@@ -265,45 +251,85 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_fwd_kernel(
   }
 }
 
-// v[0..11] per lane -> t[0..2]: lanes 12..15 of every 16-lane row hold the
-// row's sum of v[4k + (lane & 3)] in t[k]
-__device__ __forceinline__ void merge_reduce12(const float (&v)[12], int lane,
-                                               float (&t)[3]) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float u[6];
+// ---- transposed wave reduction ------------------------------------------
+// Transposed merge steps over the wave halves / the 16-lane row pairs:
+// v_permlane32_swap(a, b) leaves {a.lo, b.lo} in a and {a.hi, b.hi} in b, so
+// a + b is "a summed over {l, l+32}" in lanes [0,32) and the same of b in
+// lanes [32,64); v_permlane16_swap does it for the row pairs.  Inline asm:
+// this toolchain's __builtin_amdgcn_permlane{16,32}_swap drops the second
+// result (both elements of the returned pair read the first register).
+// Independent swaps are issued back to back; the s_nop cover the VALU ->
+// swap and swap -> VALU wait states (inline asm is opaque to the hazard
+// recogniser).
+__device__ __forceinline__ void swap32x6(float (&v)[12]) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_permlane32_swap_b32 %0, %1\n"
+      "v_permlane32_swap_b32 %2, %3\n"
+      "v_permlane32_swap_b32 %4, %5\n"
+      "v_permlane32_swap_b32 %6, %7\n"
+      "v_permlane32_swap_b32 %8, %9\n"
+      "v_permlane32_swap_b32 %10, %11\n"
+      "s_nop 1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]),
+        "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+        "+v"(v[10]), "+v"(v[11]));
+}
+__device__ __forceinline__ void swap16x3(float (&u)[6]) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_permlane16_swap_b32 %0, %1\n"
+      "v_permlane16_swap_b32 %2, %3\n"
+      "v_permlane16_swap_b32 %4, %5\n"
+      "s_nop 1"
+      : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]),
+        "+v"(u[5]));
+}
+
+// which of the twelve sums lane l holds after merge_reduce12 (every lane of
+// a quad the same; lanes with bits 2 and 3 both set repeat 8..11)
+__device__ __forceinline__ int merge_slot(int lane) {
+  const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1;
+  return (lane & 4) ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
+}
+
+// v[0..11] per lane -> the sum over the wave of v[merge_slot(lane)]
+__device__ __forceinline__ float merge_reduce12(float (&v)[12], int lane) {
+  float u[6], t[3];
+  swap32x6(v);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float keep = b0 ? v[2 * k + 1] : v[2 * k];
-    const float give = b0 ? v[2 * k] : v[2 * k + 1];
-    u[k] = keep + dpp_get<0xB1>(give);  // quad_perm [1,0,3,2]
-  }
+  for (int k = 0; k < 6; ++k) u[k] = v[2 * k] + v[2 * k + 1];
+  swap16x3(u);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float keep = b1 ? u[2 * k + 1] : u[2 * k];
-    const float give = b1 ? u[2 * k] : u[2 * k + 1];
-    float s = keep + dpp_get<0x4E>(give);  // quad_perm [2,3,0,1]
-    s += dpp_get<0x114>(s);                // row_shr:4 (zeros shifted in)
-    s += dpp_get<0x118>(s);                // row_shr:8
-    t[k] = s;
-  }
+  for (int k = 0; k < 3; ++k) t[k] = u[2 * k] + u[2 * k + 1];
+  // t[k]: slot 4k + 2 b4 + b5, summed over lane bits 4, 5
+  const bool b3 = lane & 8, b2 = lane & 4;
+  const float w0 = (b3 ? t[1] : t[0]) +
+                   dpp_get<0x128>(b3 ? t[0] : t[1]);   // row_ror:8
+  const float w1 = t[2] + dpp_get<0x128>(t[2]);
+  // lanes l <-> l ^ 7 (row_half_mirror): opposite bit 2, same bits 3..5
+  float z = (b2 ? w1 : w0) + dpp_get<0x141>(b2 ? w0 : w1);
+  z += dpp_get<0xB1>(z);   // quad_perm [1,0,3,2]
+  z += dpp_get<0x4E>(z);   // quad_perm [2,3,0,1]
+  return z;
 }
 
 template <bool DUAL>
 __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
-    BCam cam, const int* __restrict__ ranges, const int* __restrict__ plist,
-    const float* __restrict__ xy, const float* __restrict__ conic_o,
-    const float* __restrict__ colors, const float* __restrict__ colors_b,
+    BCam cam, const int* __restrict__ ranges, const float* __restrict__ rec,
     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_color_b,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_b,
     float* __restrict__ key_grad) {
-  __shared__ Stage<DUAL, true> S;
+  __shared__ float s_acc[BUCKET * KEYROW];
   __shared__ int s_max;
   const int gx = (cam.W + TILE - 1) / TILE;
   const int tile = blockIdx.y * gx + blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r0 = ranges[tile * 2], r1 = ranges[tile * 2 + 1];
   if (r1 <= r0) return;
+  const int len = r1 - r0;
+  const float* __restrict__ base = rec + (int64_t)r0 * REC;
   const int sx0 = blockIdx.x * TILE + (wave & 1) * 8,
             sy0 = blockIdx.y * TILE + (wave >> 1) * 8;
   const int px = sx0 + (lane & 7), py = sy0 + (lane >> 3);
@@ -311,6 +337,9 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
   const float pfx = (float)px, pfy = (float)py;
   const int HW = cam.H * cam.W;
   if (tid == 0) s_max = 0;
+#pragma unroll
+  for (int k = 0; k < BUCKET * KEYROW / BLOCK; ++k)
+    s_acc[k * BLOCK + tid] = 0.f;
   __syncthreads();
   // per-pixel constants: dL/dC of both colour sets, R, last contributor
   float dLa[3] = {0.f, 0.f, 0.f}, dLb[3] = {0.f, 0.f, 0.f}, R = 0.f;
@@ -337,40 +366,36 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
   if (lane == 0) atomicMax(&s_max, wave_nc);
   __syncthreads();
   const int max_nc = s_max;  // Gaussians behind it contribute to no pixel
-  const int n_buckets = (min(r1 - r0, max_nc) + BUCKET - 1) / BUCKET;
+  const int n_live = min(len, max_nc);
+  const int n_buckets = (n_live + BUCKET - 1) / BUCKET;
   const float ddx = 0.5f * cam.W, ddy = 0.5f * cam.H;
+  const int slot = merge_slot(lane);
+  const bool owner = (lane & 3) == 0 && (lane & 12) != 12;
   float T = 1.f, A = 0.f;
+  f32x4 head = load_head(base, lane, len);
   for (int b = 0; b < n_buckets; ++b) {
-    stage_bucket<DUAL, true>(S, wave, lane, r0, r1, b, plist, xy, conic_o,
-                             colors, colors_b, nullptr);
-#pragma unroll
-    for (int k = 0; k < BUCKET * KEYROW / BLOCK; ++k)
-      S.acc[k * BLOCK + tid] = 0.f;
-    __syncthreads();
-    for (int c = 0; c < CHUNKS; ++c) {
-      if (b * BUCKET + c * 64 >= wave_nc) break;
-      uint64_t m = reach_mask(S, lane, c, (float)sx0, (float)sy0);
+    for (int cc = 0; cc < BUCKET / 64; ++cc) {
+      const int e0 = b * BUCKET + cc * 64;   // first entry of the chunk
+      if (e0 >= wave_nc) break;
+      uint64_t m = reach_mask(head, (float)sx0, (float)sy0);
+      if (e0 + 64 < wave_nc) head = load_head(base, e0 + 64 + lane, len);
       // entries behind the wave's last contributor reach nothing
-      const int left = wave_nc - (b * BUCKET + c * 64);
-      if (left < 64) m &= (1ull << left) - 1ull;
+      if (wave_nc - e0 < 64) m &= (1ull << (wave_nc - e0)) - 1ull;
       if (m == 0) continue;
-      int j = c * 64 + __builtin_ctzll(m);
-      f32x4 q = S.q[j], ca = S.ca[j], cb = DUAL ? S.cb[j] : f32x4{};
-      float2 gxy = S.xy[j];
+      int j = e0 + __builtin_ctzll(m);
+      Rec r = load_rec(base, j);
       while (true) {
         m &= m - 1;
-        const int jn = m ? c * 64 + __builtin_ctzll(m) : j;
-        const f32x4 qn = S.q[jn], can = S.ca[jn],
-                    cbn = DUAL ? S.cb[jn] : f32x4{};
-        const float2 gxyn = S.xy[jn];
-        const int pos = b * BUCKET + j;
+        const int jn = m ? e0 + __builtin_ctzll(m) : j;
+        const Rec rn = load_rec(base, jn);
         float dx, dy, p2;
-        const float G = gauss_weight(gxy, q, pfx, pfy, dx, dy, p2);
-        const float alpha = fminf(0.99f, q[3] * G);
-        const bool act = pos < nc && p2 <= 0.f && alpha >= 1.f / 255.f;
+        const float G = gauss_weight(r, pfx, pfy, dx, dy, p2);
+        const float alpha = fminf(0.99f, r.b[3] * G);
+        const bool act = j < nc && p2 <= 0.f && alpha >= 1.f / 255.f;
         if (__ballot(act) != 0) {
-          float qd = ca[0] * dLa[0] + ca[1] * dLa[1] + ca[2] * dLa[2];
-          if (DUAL) qd += cb[0] * dLb[0] + cb[1] * dLb[1] + cb[2] * dLb[2];
+          float qd = r.c[0] * dLa[0] + r.c[1] * dLa[1] + r.c[2] * dLa[2];
+          if (DUAL)
+            qd += r.d[0] * dLb[0] + r.d[1] * dLb[1] + r.d[2] * dLb[2];
           const float w = act ? alpha * T : 0.f;
           const float qw = qd * w;
           const float om = 1.f - alpha;
@@ -378,42 +403,42 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
               T * qd - (R - A - qw) * __builtin_amdgcn_rcpf(om);
           const float h = act ? G * dL_dalpha : 0.f;
           const float hx = h * dx, hy = h * dy;
-          const float v[12] = {w * dLa[0], w * dLa[1], w * dLa[2], w * dLb[0],
+          float v[12] = {w * dLa[0], w * dLa[1], w * dLa[2], w * dLb[0],
                                w * dLb[1], w * dLb[2], h,          hx,
                                hy,         hx * dx,    hx * dy,    hy * dy};
-          float t[3];
-          merge_reduce12(v, lane, t);
-          if ((lane & 12) == 12) {
-            float* row = S.acc + j * KEYROW + (lane & 3);
-            atomicAdd(row, t[0]);
-            atomicAdd(row + 4, t[1]);
-            atomicAdd(row + 8, t[2]);
-          }
+          const float z = merge_reduce12(v, lane);
+          if (owner) atomicAdd(s_acc + (j - b * BUCKET) * KEYROW + slot, z);
           T = act ? T * om : T;
           A += qw;
         }
         if (m == 0) break;
         j = jn;
-        q = qn;
-        ca = can;
-        cb = cbn;
-        gxy = gxyn;
+        r = rn;
       }
     }
     __syncthreads();
     // finished rows of the bucket: sums -> gradients w.r.t. colours, mean2D
-    // (ndc), conic (true partials), opacity
-    for (int e = tid; e < BUCKET; e += BLOCK) {
-      const int k = b * BUCKET + e;
-      if (r0 + k < r1) {
-        const float* s = S.acc + e * KEYROW;
-        const f32x4 co = S.con[e];
-        const float o = co[3];
+    // (ndc), conic (true partials), opacity; the row is cleared for the next
+    // bucket
+    {
+      const int k = b * BUCKET + tid;
+      if (k < len) {
+        float s[KEYROW];
+#pragma unroll
+        for (int c = 0; c < KEYROW; ++c) {
+          s[c] = s_acc[tid * KEYROW + c];
+          s_acc[tid * KEYROW + c] = 0.f;
+        }
+        const f32x4 q = *reinterpret_cast<const f32x4*>(
+            base + (int64_t)k * REC + 4);
+        const float o = q[3];
+        const float cA = q[0] * (-2.f / kLog2e), cB = q[1] * (-1.f / kLog2e),
+                    cC = q[2] * (-2.f / kLog2e);
         float* row = key_grad + (int64_t)(r0 + k) * KEYROW;
         *reinterpret_cast<f32x4*>(row) = f32x4{s[0], s[1], s[2], s[3]};
         *reinterpret_cast<f32x4*>(row + 4) =
-            f32x4{s[4], s[5], -o * (co[0] * s[7] + co[1] * s[8]) * ddx,
-                  -o * (co[2] * s[8] + co[1] * s[7]) * ddy};
+            f32x4{s[4], s[5], -o * (cA * s[7] + cB * s[8]) * ddx,
+                  -o * (cC * s[8] + cB * s[7]) * ddy};
         *reinterpret_cast<f32x4*>(row + 8) =
             f32x4{-0.5f * o * s[9], -o * s[10], -0.5f * o * s[11], s[6]};
       }
@@ -421,7 +446,7 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
     __syncthreads();
   }
   // keys of this tile behind the last contributor: zero rows
-  for (int k = n_buckets * BUCKET + tid; k < r1 - r0; k += BLOCK) {
+  for (int k = n_buckets * BUCKET + tid; k < len; k += BLOCK) {
     float* row = key_grad + (int64_t)(r0 + k) * KEYROW;
 #pragma unroll
     for (int c = 0; c < KEYROW; c += 4)
@@ -486,7 +511,7 @@ extern "C" {
 int64_t xrd_gs_blend_ckpt_floats(int64_t key_capacity, int image_width,
                                  int image_height) {
   if (key_capacity < 0 || image_width < 1 || image_height < 1) return -1;
-  return 64;  // the front-to-back backward keeps no checkpoints
+  return (key_capacity + 1) * REC;  // one packed record per key
 }
 
 int xrd_gs_blend_fwd(const xrd_gs_camera* c, const int32_t* ranges,
@@ -496,24 +521,29 @@ int xrd_gs_blend_fwd(const xrd_gs_camera* c, const int32_t* ranges,
                      float* out_color_a, float* out_color_b, float* out_depth,
                      float* final_T, int32_t* n_contrib, float* ckpt,
                      xrd_stream_t stream) {
-  (void)ckpt;
   BCam cam;
   int rc = to_bcam(c, cam);
   if (rc) return rc;
-  if (!ranges || !out_color_a || !out_depth || !final_T || !n_contrib)
+  if (!ranges || !out_color_a || !out_depth || !final_T || !n_contrib ||
+      !ckpt)
     return XRD_ERR_ARG;
   if ((colors_b == nullptr) != (out_color_b == nullptr)) return XRD_ERR_ARG;
   const dim3 grid((cam.W + TILE - 1) / TILE, (cam.H + TILE - 1) / TILE);
+  hipStream_t st = (hipStream_t)stream;
+  if (point_list) {
+    if (!xy || !colors_a || !conic_opacity || !depths) return XRD_ERR_ARG;
+    hipLaunchKernelGGL(gs_pack_kernel, dim3(grid.x * grid.y), dim3(256), 0, st,
+                       ranges, point_list, xy, conic_opacity, colors_a,
+                       colors_b, depths, ckpt);
+  }
   if (colors_b)
-    hipLaunchKernelGGL(gs_blend_fwd_kernel<true>, grid, dim3(BLOCK), 0,
-                       (hipStream_t)stream, cam, ranges, point_list, xy,
-                       colors_a, colors_b, conic_opacity, depths, out_color_a,
-                       out_color_b, out_depth, final_T, n_contrib);
+    hipLaunchKernelGGL(gs_blend_fwd_kernel<true>, grid, dim3(BLOCK), 0, st,
+                       cam, ranges, ckpt, out_color_a, out_color_b, out_depth,
+                       final_T, n_contrib);
   else
-    hipLaunchKernelGGL(gs_blend_fwd_kernel<false>, grid, dim3(BLOCK), 0,
-                       (hipStream_t)stream, cam, ranges, point_list, xy,
-                       colors_a, nullptr, conic_opacity, depths, out_color_a,
-                       nullptr, out_depth, final_T, n_contrib);
+    hipLaunchKernelGGL(gs_blend_fwd_kernel<false>, grid, dim3(BLOCK), 0, st,
+                       cam, ranges, ckpt, out_color_a, nullptr, out_depth,
+                       final_T, n_contrib);
   return check_launch("xrd_gs_blend_fwd");
 }
 
@@ -528,7 +558,6 @@ int xrd_gs_blend_bwd(const xrd_gs_camera* c, int n, int64_t key_capacity,
                      const float* ckpt, float* key_grad, float* dL_dmean2D,
                      float* dL_dconic, float* dL_dopacity, float* dL_dcolors_a,
                      float* dL_dcolors_b, xrd_stream_t stream) {
-  (void)ckpt;
   BCam cam;
   int rc = to_bcam(c, cam);
   if (rc) return rc;
@@ -536,7 +565,7 @@ int xrd_gs_blend_bwd(const xrd_gs_camera* c, int n, int64_t key_capacity,
   if (n == 0) return XRD_OK;
   if (!ranges || !point_list || !key_pos || !offsets || !xy ||
       !conic_opacity || !colors_a || !final_T || !n_contrib || !out_color_a ||
-      !dL_dcolor_a || !key_grad || !dL_dmean2D || !dL_dconic ||
+      !dL_dcolor_a || !ckpt || !key_grad || !dL_dmean2D || !dL_dconic ||
       !dL_dopacity || !dL_dcolors_a)
     return XRD_ERR_ARG;
   const bool dual = colors_b != nullptr;
@@ -546,18 +575,16 @@ int xrd_gs_blend_bwd(const xrd_gs_camera* c, int n, int64_t key_capacity,
   const dim3 grid((cam.W + TILE - 1) / TILE, (cam.H + TILE - 1) / TILE);
   if (dual) {
     hipLaunchKernelGGL(gs_blend_bwd_kernel<true>, grid, dim3(BLOCK), 0, st,
-                       cam, ranges, point_list, xy, conic_opacity, colors_a,
-                       colors_b, final_T, n_contrib, out_color_a, out_color_b,
-                       dL_dcolor_a, dL_dcolor_b, key_grad);
+                       cam, ranges, ckpt, final_T, n_contrib, out_color_a,
+                       out_color_b, dL_dcolor_a, dL_dcolor_b, key_grad);
     hipLaunchKernelGGL(gs_key_reduce_kernel<true>, dim3((n + 255) / 256),
                        dim3(256), 0, st, n, key_capacity, offsets, key_pos,
                        key_grad, dL_dmean2D, dL_dconic, dL_dopacity,
                        dL_dcolors_a, dL_dcolors_b);
   } else {
     hipLaunchKernelGGL(gs_blend_bwd_kernel<false>, grid, dim3(BLOCK), 0, st,
-                       cam, ranges, point_list, xy, conic_opacity, colors_a,
-                       nullptr, final_T, n_contrib, out_color_a, nullptr,
-                       dL_dcolor_a, nullptr, key_grad);
+                       cam, ranges, ckpt, final_T, n_contrib, out_color_a,
+                       nullptr, dL_dcolor_a, nullptr, key_grad);
     hipLaunchKernelGGL(gs_key_reduce_kernel<false>, dim3((n + 255) / 256),
                        dim3(256), 0, st, n, key_capacity, offsets, key_pos,
                        key_grad, dL_dmean2D, dL_dconic, dL_dopacity,
