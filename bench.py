@@ -704,6 +704,7 @@ def run_splatam(args, dev):
     random.seed(0)   # keyframe window sampling: same on every rank
     cam = Camera(**CAM)
     algo = splatam_config().setup(camera=cam, device=str(dev))
+    algo.use_graphs = not args.no_graphs
     data = _CvPoses(SyntheticRoom(
         CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,
         cy=cam.cy, n_frames=max(args.warmup + args.steps + 1, 200),
@@ -729,7 +730,9 @@ def run_splatam(args, dev):
     t_track, t_map = slam.t_track, slam.t_map
     # per-launch HIP-event timing of one more frame (100 iterations, 200
     # raster passes each way) right after the timed region
+    # (eagerly: events cannot be read back from inside a captured graph)
     from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
+    algo.use_graphs = False
     dgr.PROFILE = {}
     slam.step(1 + args.warmup + args.steps)
     torch.cuda.synchronize()

@@ -137,6 +137,11 @@ class _Binning:
     def capacity(self, dev, n, tiles):
         key = str(dev)
         st = self.state.get(key)
+        if st is not None and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture: the list size is frozen at what the
+            # eager passes before it established (the pass count of every
+            # replay is folded into ``peak``, see check_replays)
+            return st['cap']
         total = None
         if st is not None and not self.exact:
             if st['event'] is not None:
@@ -168,6 +173,7 @@ class _Binning:
             st = self.state[key] = {
                 'cap': need, 'n': n, 'event': None, 'last': None,
                 'last_cap': need, 'ws': None, 'high': total,
+                'peak': torch.zeros(1, dtype=torch.int64, device=dev),
                 'host': torch.zeros(1, dtype=torch.int64).pin_memory()}
         if need > st['cap'] or need < st['cap'] // 3:
             st['cap'] = need
@@ -182,6 +188,10 @@ class _Binning:
 
     def report(self, dev, n, cap, n_keys):
         st = self.state[str(dev)]
+        if torch.cuda.is_current_stream_capturing():
+            torch.maximum(st['peak'], n_keys, out=st['peak'])
+            st['graph_cap'] = min(cap, st.get('graph_cap', cap))
+            return
         st['n'], st['last_cap'] = n, cap
         if self.exact:
             st['event'] = None
@@ -190,6 +200,26 @@ class _Binning:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         st['event'] = ev
+
+
+    def check_replays(self, dev):
+        """after captured passes were replayed: the largest pair count any
+        of them produced (one host read) against the frozen list size"""
+        st = self.state.get(str(dev))
+        if st is None or 'graph_cap' not in st:
+            return
+        peak = int(st['peak'].item())
+        st['peak'].zero_()
+        cap = st.pop('graph_cap')
+        st['high'] = max(st.get('high', 0), peak)
+        if peak > cap:
+            self.overflowed += 1
+            import warnings
+            warnings.warn(
+                f'Gaussian rasteriser: a replayed pass produced {peak} '
+                f'(Gaussian, tile) pairs for a list of {cap}: pairs were '
+                'dropped from its image and gradients.  Capacity raised for '
+                'the following passes.')
 
 
 _BIN = _Binning()

@@ -240,6 +240,12 @@ class Algorithm:
         same learning rates) and may share one captured graph"""
         return 0
 
+    def host_pre_iteration(self, optimize_frames, is_mapping, step):
+        """host-side work of an iteration that must not be frozen into a
+        captured graph (e.g. SplaTAM's random choice of the frame an
+        iteration renders): called before EVERY iteration — eager, captured
+        or replayed — outside the capture"""
+
     def _graphs_ok(self, optimizers, is_mapping):
         if not self.use_graphs or not torch.cuda.is_available():
             return False
@@ -611,6 +617,7 @@ class Algorithm:
             graph_b, jobs = None, None
             args = (optimizers, optimize_frames, is_mapping)
             for step in range(n_iters):
+                self.host_pre_iteration(optimize_frames, is_mapping, step)
                 if graphed and split:
                     key = self.graph_segment_key(is_mapping, step, n_iters,
                                                  coarse)

@@ -24,6 +24,22 @@ class SplaTAMConfig(AlgorithmConfig):
     render_mode: str = 'color'
 
 
+class _FrameSlot:
+    """static device buffers a captured mapping iteration reads its frame
+    from; quacks like ``Frame`` for GaussianSplatting's fused loss"""
+
+    def __init__(self, d, c, chw):
+        self.d, self.c, self.chw = (torch.empty_like(d), torch.empty_like(c),
+                                    torch.empty_like(chw))
+        self.c2w = torch.empty(4, 4, device=d.device)
+
+    def device_images(self, device):
+        return self.d, self.c
+
+    def device_rgb_chw(self, device):
+        return self.chw
+
+
 class SplaTAM(Algorithm):
     config: SplaTAMConfig
 
@@ -47,10 +63,67 @@ class SplaTAM(Algorithm):
             frames = frames + [cur_frame]
         return frames
 
-    def get_model_input(self, optimize_frames, is_mapping):
+    # ---- hipGraph support (MI355X) ---------------------------------------
+    # N changes with every frame (add_new_gaussians): no graph survives a
+    # frame; within a frame the iterations between two pruning steps share
+    # one captured graph.
+    persistent_track_graph = False
+
+    def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
+        if not is_mapping:
+            return 0
+        cfg = self.model.config
+        if cfg.mapping_use_gaussian_splatting_densification:
+            return step             # statistics + surgery every iteration
+        d = cfg.mapping_pruning_dict
+
+        def surgery(it):
+            if it > d['stop_after']:
+                return False
+            return (it >= d['start_after'] and it % d['prune_every'] == 0) \
+                or (it > 0 and d['reset_opacities'] and
+                    it % d['reset_opacities_every'] == 0)
+        # an iteration that changes the number of Gaussians (or swaps
+        # parameters) is a segment of its own; the ones after it start a new
+        # one
+        before = sum(1 for it in range(step) if surgery(it))
+        return 2 * before + (1 if surgery(step) else 0)
+
+    def host_pre_iteration(self, optimize_frames, is_mapping, step):
+        """the frame this iteration renders (splatam.py:63: one random frame
+        of the window per iteration).  Under graph capture / replay the
+        chosen keyframe's pose and images are copied into static slot
+        buffers the captured iteration reads."""
         f = optimize_frames[np.random.randint(0, len(optimize_frames))]
+        self._chosen = f
+        if not (getattr(self, 'fixed_shape_batches', False) and is_mapping):
+            self._slot_live = False
+            return
+        dev = self.device
+        d, c = f.device_images(dev)
+        chw = f.device_rgb_chw(dev)
+        slot = getattr(self, '_slot', None)
+        if slot is None or slot.d.shape != d.shape:
+            slot = self._slot = _FrameSlot(d, c, chw)
+        with torch.no_grad():
+            slot.d.copy_(d)
+            slot.c.copy_(c)
+            slot.chw.copy_(chw)
+            slot.c2w.copy_(f.get_pose().detach().to(dev))
+        self._slot_live = True
+
+    def get_model_input(self, optimize_frames, is_mapping):
+        f = getattr(self, '_chosen', None)
+        self._chosen = None
+        if f is None:     # called outside the optimiser loop
+            f = optimize_frames[np.random.randint(0, len(optimize_frames))]
         inp = {'target_s': f.rgb, 'target_d': f.depth, 'frame': f,
                'is_mapping': is_mapping, 'retain_grad': True}
+        if getattr(self, '_slot_live', False) and is_mapping and \
+                not self.model.config.mapping_do_ba:
+            inp['frame'] = self._slot
+            inp['c2w'] = self._slot.c2w
+            return inp
         pose = f.get_pose().to(self.device)
         if pose.is_cuda:
             # the rigid inverse is taken inside the preparation kernel
@@ -60,6 +133,15 @@ class SplaTAM(Algorithm):
         else:
             inp['w2c'] = torch.inverse(pose)
         return inp
+
+    def optimize_update(self, n_iters, optimize_frames, is_mapping,
+                        coarse=False):
+        out = super().optimize_update(n_iters, optimize_frames, is_mapping,
+                                      coarse=coarse)
+        if self.use_graphs and torch.device(self.device).type == 'cuda':
+            from ...compat import diff_gaussian_rasterization as dgr
+            dgr._BIN.check_replays(torch.device(self.device))
+        return out
 
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):
