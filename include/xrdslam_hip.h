@@ -1022,6 +1022,12 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
  * pose ids into c2w[n_pose,4,4] (the reference's poses[ids] gather, multiply
  * and sum); backward accumulates d/dc2w per pose (g_c2w overwritten, rows 0..2
  * of every 4x4 used). dirs rows are dir_stride floats apart (bank rows: 7). */
+/* ..._dev: n_total is read from DEVICE memory at execution time (a captured
+ * mapping iteration samples a bank that grows between its replays); same
+ * permutation as xrd_sample_distinct for the same n_total and keys. */
+int xrd_sample_distinct_dev(const int64_t* n_total, int n_out,
+                            const int64_t* keys4, int64_t* out_idx,
+                            xrd_stream_t stream);
 int xrd_sample_distinct(int64_t n_total, int n_out, const int64_t* keys4,
                         int64_t* out_idx, xrd_stream_t stream);
 int xrd_pose_rays_fwd(int n, const float* dirs, int dir_stride,
@@ -1044,6 +1050,19 @@ int xrd_coslam_loss(int n_rays, int n_samples, float w_rgb, float w_depth,
                     const float* raw, const float* target_d,
                     const float* target_rgb, float* loss5, float* g_maps,
                     float* g_raw, float* workspace, xrd_stream_t stream);
+/* xrd_coslam_loss with the batch size read on the device: the first *n_live
+ * of the n_rays rows are the batch (normalisers, balancing weights), the rows
+ * behind it get zero gradients — a persistent mapping graph renders a
+ * capacity batch whose current-frame part (mapping_sample // n_keyframes rays,
+ * slam/algorithms/coslam.py:166-170) shrinks as keyframes are added. */
+int xrd_coslam_loss_live(int n_rays, int n_samples, float w_rgb, float w_depth,
+                         float w_sdf, float w_fs, float trunc,
+                         float depth_trunc, float rgb_missing,
+                         const float* maps, const float* z_vals,
+                         const float* raw, const float* target_d,
+                         const float* target_rgb, const int32_t* n_live,
+                         float* loss5, float* g_maps, float* g_raw,
+                         float* workspace, xrd_stream_t stream);
 /* The same in two steps, for a batch SHARDED over ranks (multi-GPU mapping):
  * stats[n,8] per ray = {n_fs, n_sdf, S_fs, S_sdf, valid, depth err^2, rgb
  * err^2, w}; the caller sums columns 0..6 over its rays, all-reduces the seven

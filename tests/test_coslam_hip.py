@@ -264,3 +264,100 @@ def test_coslam_loop_tracks_synthetic_room():
         data[10]['depth']) else data[10]['depth'])
     err = np.abs(depth - gt)[gt > 0].mean()
     assert err < 0.1, err
+
+
+def test_live_count_loss_equals_the_trimmed_batch():
+    """xrd_coslam_loss_live on a capacity batch (live count on the device) =
+    xrd_coslam_loss on the first n_live rows: loss terms, gradients of the
+    live rows; zero gradients behind them"""
+    from xrdslam_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    n, S, live = 333, 43, 250
+    dev = 'cuda:0'
+    maps = torch.rand(n, 8, generator=g).to(dev)
+    z = torch.sort(torch.rand(n, S, generator=g) * 4, dim=1).values.to(dev)
+    raw = torch.randn(n, S, 4, generator=g).to(dev)
+    td = (1.0 + 2 * torch.rand(n, generator=g))
+    td[::9] = 0.0
+    td = td.to(dev)
+    tc = torch.rand(n, 3, generator=g).to(dev)
+    cfg = (5.0, 0.1, 1000.0, 10.0, 0.1, 100.0, 0.05)
+    st = _lib.stream_ptr(torch.device(dev))
+    P = _lib.ptr
+    l5 = torch.empty(5, device=dev)
+    gm, gr = torch.empty(live, 8, device=dev), \
+        torch.empty(live, S, 4, device=dev)
+    ws = torch.empty(n * 8, device=dev)
+    _lib.check(lib.xrd_coslam_loss(
+        live, S, *cfg, P(maps[:live].contiguous()), P(z[:live].contiguous()),
+        P(raw[:live].contiguous()), P(td[:live].contiguous()),
+        P(tc[:live].contiguous()), P(l5), P(gm), P(gr), P(ws), st), 'loss')
+    nl = torch.tensor([live], dtype=torch.int32, device=dev)
+    l5b = torch.empty(5, device=dev)
+    gmb = torch.full((n, 8), 7.0, device=dev)
+    grb = torch.full((n, S, 4), 7.0, device=dev)
+    _lib.check(lib.xrd_coslam_loss_live(
+        n, S, *cfg, P(maps), P(z), P(raw), P(td), P(tc), P(nl), P(l5b),
+        P(gmb), P(grb), P(ws), st), 'loss_live')
+    assert torch.allclose(l5b, l5, rtol=1e-6)
+    assert torch.allclose(gmb[:live], gm, rtol=1e-6, atol=1e-12)
+    assert torch.allclose(grb[:live], gr, rtol=1e-6, atol=1e-12)
+    assert float(gmb[live:].abs().max()) == 0.0
+    assert float(grb[live:].abs().max()) == 0.0
+
+
+def test_sample_distinct_dev_equals_host_sized_call():
+    from xrdslam_amd.engine import slam_ops
+    for total, n in ((15360 * 7, 2048), (307200, 2048), (5000, 5000)):
+        torch.manual_seed(3)
+        a = slam_ops.sample_distinct(total, n, 'cuda:0')
+        torch.manual_seed(3)
+        b = slam_ops.sample_distinct_dev(
+            torch.tensor([total], dtype=torch.int64, device='cuda:0'), n,
+            'cuda:0')
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('persistent', [False, True])
+def test_coslam_mapping_graph_slot(persistent):
+    """Co-SLAM with mapping through the persistent capacity slot (pose stacks,
+    bank and current-frame part at fixed addresses, sizes read on the device;
+    replay-only calls from the second call of a bucket on) tracks like the
+    per-call path; the two draw the same batches (same RNG consumption, the
+    live rows are the per-call batch)."""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import cadence, coslam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    bound = [[-3, 3], [-4, 2.5], [-2, 2.5]]
+    cam = Camera(fx=150., fy=150., cx=79.5, cy=59.5, width=160, height=120)
+    cfg = coslam_config(bound)
+    cfg.mapping_first_n_iters = 100
+    cfg.tracking_Wedge = cfg.tracking_Hedge = 5
+    cfg.mapping_sample = 768
+    algo = cfg.setup(camera=cam, device='cuda:0')
+    algo.use_graphs = True
+    algo.persistent_map = persistent
+    data = SyntheticRoom(bound, H=120, W=160, fx=150., fy=150., cx=79.5,
+                         cy=59.5, n_frames=200, device='cuda:0')
+    cad = cadence['co-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device='cuda:0')
+    for k in range(41):
+        slam.step(k)
+    assert len(algo.keyframe_graph) == 9
+    if persistent:
+        slots = algo._pslots
+        # 768 // K rays of the current frame: buckets 1024, 512, 256, 128
+        assert set(slots) <= {128, 256, 512, 1024}
+        assert any(len(s['graphs']) == 2 for s in slots.values())
+    ate = slam.ate_rmse()
+    assert ate < 0.02, ate
+    # bundle adjustment wrote the keyframe poses back
+    kf = algo.keyframe_graph[3]
+    gt = torch.as_tensor(data[kf.fid]['c2w'])[:3, 3]
+    assert (kf.get_pose().detach().cpu()[:3, 3] - gt).norm() < 0.03

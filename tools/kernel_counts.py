@@ -1,72 +1,110 @@
-"""kernel launches of ONE eager NICE-SLAM iteration per stage and of one
-tracking iteration (torch profiler, grouped by kernel name)"""
+"""device activities of ONE optimisation iteration per algorithm and stage
+(torch profiler, grouped by kernel name), with the share of launches / device
+time in this repo's own kernels (xrd::) vs torch's.  The iterations are taken
+from a normal run with the captured iterations' fixed shapes, eagerly.
+
+    python tools/kernel_counts.py [algo ...]     (default: all five)"""
+import collections
 import os
 import sys
-import collections
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import torch
-from torch.profiler import ProfilerActivity, profile
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
-from xrdslam_amd.data.synthetic import SyntheticRoom
-from xrdslam_amd.slam.common.camera import Camera
-from xrdslam_amd.slam.common.frame import Frame
-from xrdslam_amd.slam.configs.input_config import nice_slam_config
-from xrdslam_amd.slam.pipeline import SequentialSLAM
+import bench  # noqa: E402
+from xrdslam_amd.data.synthetic import SyntheticRoom  # noqa: E402
+from xrdslam_amd.slam.common.camera import Camera  # noqa: E402
+from xrdslam_amd.slam.configs import input_config as ic  # noqa: E402
+from xrdslam_amd.slam.pipeline import SequentialSLAM  # noqa: E402
 
-BOUND = [[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]]
 dev = 'cuda:0'
-torch.manual_seed(0)
-cfg = nice_slam_config(BOUND)
-cfg.mapping_first_n_iters = 60
-cam = Camera(320., 320., 319.5, 239.5, 640, 480)
-algo = cfg.setup(camera=cam, device=dev)
-algo.use_graphs = False
-data = SyntheticRoom(BOUND, n_frames=200, device=dev)
-slam = SequentialSLAM(algo, data, pose_device=dev)
-for k in range(6):
-    slam.step(k)
-frame = slam.step(6)
-algo.fixed_shape_batches = True
+# (config factory, bound, frames to run, wrap dataset, {tag: (is_mapping,
+# step)} taken from the LAST frame that reaches them)
+SPEC = {
+    'nice-slam': (lambda: ic.nice_slam_config(bench.BOUND), bench.BOUND, 11,
+                  None, {'track': (False, 3), 'map middle': (True, 3),
+                         'map fine': (True, 33), 'map color': (True, 53)}),
+    'co-slam': (lambda: ic.coslam_config(bench.CO_BOUND), bench.CO_BOUND, 11,
+                None, {'track': (False, 3), 'map': (True, 3)}),
+    'vox-fusion': (ic.voxfusion_config, bench.CO_BOUND, 6, bench._CvPoses,
+                   {'track': (False, 3), 'map': (True, 3)}),
+    'splaTAM': (ic.splatam_config, bench.CO_BOUND, 4, bench._CvPoses,
+                {'track': (False, 3), 'map': (True, 3)}),
+    'point-slam': (ic.pointslam_config, bench.CO_BOUND, 3, bench._NumpyImages,
+                   {'track': (False, 3), 'map geometry': (True, 3),
+                    'map color': (True, 200)}),
+}
 
 
-def count(fn, tag):
-    fn()
-    torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as p:
-        fn()
-        torch.cuda.synchronize()
-    c = collections.Counter()
-    t = collections.Counter()
+def report(tag, p):
+    c, t = collections.Counter(), collections.Counter()
     for e in p.events():
-        if e.device_type == torch.autograd.DeviceType.CUDA:
-            c[e.name[:70]] += 1
-            t[e.name[:70]] += e.device_time if hasattr(e, 'device_time') \
+        if e.device_type == torch.autograd.DeviceType.CUDA and \
+                '#' not in e.name:          # Optimizer.step#... ranges
+            c[e.name[:64]] += 1
+            t[e.name[:64]] += e.device_time if hasattr(e, 'device_time') \
                 else e.cuda_time
-    print(f'== {tag}: {sum(c.values())} device activities, '
-          f'{sum(t.values()):.0f} us')
-    for n, k in c.most_common(30):
+    own_n = sum(k for n, k in c.items() if 'xrd::' in n)
+    own_t = sum(v for n, v in t.items() if 'xrd::' in n)
+    tot_n, tot_t = sum(c.values()), sum(t.values())
+    print(f'== {tag}: {tot_n} device activities, {tot_t:.0f} us; own kernels '
+          f'{own_n} launches ({100.0 * own_n / max(tot_n, 1):.0f} %), '
+          f'{100.0 * own_t / max(tot_t, 1e-9):.1f} % of device time')
+    for n, k in sorted(c.items(), key=lambda x: -t[x[0]])[:40]:
         print(f'   {k:4d} x {n}  ({t[n]:.0f} us)')
 
 
-frames = algo.select_optimize_frames(frame, 'overlap')
-for stage_step, tag in ((0, 'map middle'), (30, 'map fine'), (50, 'map color')):
-    opt = algo.setup_optimizers(60, frames, is_mapping=True)
-    algo.pre_precessing(frame, True)
-    count(lambda: algo._iteration(opt, frames, True, stage_step, 60, False,
-                                  None), tag)
-opt = algo.setup_optimizers(60, frames, is_mapping=True, coarse=True)
-count(lambda: algo._iteration(opt, frames, True, 0, 60, True, None),
-      'map coarse')
-f = Frame(fid=7, rgb=data[7]['rgb'], depth=data[7]['depth'],
-          gt_pose=data[7]['c2w'].astype(np.float32),
-          init_pose=data[6]['c2w'].astype(np.float32),
-          separate_LR=algo.is_separate_LR(), rot_rep=algo.get_rot_rep(),
-          device=dev)
-algo.pre_precessing(f, False)
-opt = algo.setup_optimizers(10, [f], is_mapping=False)
-track = {'loss': torch.full((), 1e10, dtype=torch.float64, device=dev),
-         'c2w': torch.zeros(4, 4, device=dev),
-         'valid': torch.zeros((), dtype=torch.bool, device=dev)}
-count(lambda: algo._iteration(opt, [f], False, 0, 10, False, track), 'track')
+def run(name):
+    make, bound, n_frames, wrap, targets = SPEC[name]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = make()
+    if hasattr(cfg, 'mapping_first_n_iters'):
+        cfg.mapping_first_n_iters = min(cfg.mapping_first_n_iters, 300)
+    cam = Camera(**bench.CAM)
+    algo = cfg.setup(camera=cam, device=dev)
+    algo.use_graphs = False
+    algo.eager_fixed_shapes = True
+    data = SyntheticRoom(bound, H=cam.height, W=cam.width, fx=cam.fx,
+                         fy=cam.fy, cx=cam.cx, cy=cam.cy, n_frames=200,
+                         device=dev)
+    if wrap is not None:
+        data = wrap(data)
+    cad = ic.cadence[name]
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          lazy_start=cad.lazy_start, pose_device=dev,
+                          use_relative_pose=cad.use_relative_pose,
+                          init_pose_offset=cad.init_pose_offset)
+    state = {'on': False, 'seen': {}}
+    orig = algo._iteration
+
+    def wrapped(optimizers, frames, is_mapping, step, *a, **kw):
+        for tag, key in targets.items():
+            if state['on'] and key == (is_mapping, step) and \
+                    tag not in state['seen']:
+                torch.cuda.synchronize()
+                with profile(activities=[ProfilerActivity.CUDA,
+                                         ProfilerActivity.CPU]) as p:
+                    out = orig(optimizers, frames, is_mapping, step, *a, **kw)
+                    torch.cuda.synchronize()
+                state['seen'][tag] = p
+                return out
+        return orig(optimizers, frames, is_mapping, step, *a, **kw)
+    algo._iteration = wrapped
+    for k in range(n_frames):
+        state['on'] = k == n_frames - 1
+        slam.step(k)
+    print(f'#### {name} (frame {n_frames - 1})')
+    for tag in targets:
+        if tag in state['seen']:
+            report(f'{name} {tag}', state['seen'][tag])
+        else:
+            print(f'== {name} {tag}: not reached')
+
+
+if __name__ == '__main__':
+    for name in (sys.argv[1:] or list(SPEC)):
+        run(name)

@@ -8,9 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# XRD_LIB: kernel-experiment builds (tools/build_variant.sh) only
-LIB_PATH = os.environ.get('XRD_LIB') or os.path.join(_HERE,
-                                                   'libxrdslam_hip.so')
+LIB_PATH = os.path.join(_HERE, 'libxrdslam_hip.so')
 
 _lib = None
 
@@ -205,10 +203,13 @@ _SIGS = {
     'xrd_coslam_render_bwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
                               [vp] * 12),
     'xrd_sample_distinct': (C.c_int, [i64, C.c_int, vp, vp, vp]),
+    'xrd_sample_distinct_dev': (C.c_int, [vp, C.c_int, vp, vp, vp]),
     'xrd_pose_rays_fwd': (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
     'xrd_pose_rays_bwd': (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp,
                                     vp, vp]),
     'xrd_coslam_loss': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 + [vp] * 10),
+    'xrd_coslam_loss_live': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 +
+                             [vp] * 11),
     'xrd_coslam_loss_stats': (C.c_int, [C.c_int, C.c_int] + [f32] * 3 +
                               [vp] * 7),
     'xrd_coslam_loss_grads': (C.c_int, [C.c_int, C.c_int] + [f32] * 7 +

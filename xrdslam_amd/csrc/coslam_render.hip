@@ -737,10 +737,16 @@ __global__ __launch_bounds__(256) void coslam_loss_stats_kernel(
     LossCfg L, int n, const float* __restrict__ maps,
     const float* __restrict__ z_vals, const float* __restrict__ raw,
     const float* __restrict__ tgt_d, const float* __restrict__ tgt_rgb,
-    float* __restrict__ stats) {
+    const int* __restrict__ n_live, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= n) return;
+  if (n_live != nullptr && ray >= *n_live) {
+    // capacity batch (persistent mapping graph): a ray behind the live
+    // count is not part of the batch
+    if (lane < 8) stats[(size_t)ray * 8 + lane] = 0.f;
+    return;
+  }
   const float d = tgt_d[ray];
   float nfs = 0.f, nsdf = 0.f, sfs = 0.f, ssdf = 0.f;
   if (lane < L.S) {
@@ -785,9 +791,12 @@ __global__ __launch_bounds__(1024) void coslam_loss_grad_kernel(
     const float* __restrict__ z_vals, const float* __restrict__ raw,
     const float* __restrict__ tgt_d, const float* __restrict__ tgt_rgb,
     const float* __restrict__ stats, const double* __restrict__ totals,
-    int64_t n_total, float* __restrict__ loss_out,
-    float* __restrict__ g_maps, float* __restrict__ g_raw) {
+    int64_t n_total, const int* __restrict__ n_live,
+    float* __restrict__ loss_out, float* __restrict__ g_maps,
+    float* __restrict__ g_raw) {
   __shared__ double red[16][7];
+  const int live = n_live != nullptr ? min(n, *n_live) : n;
+  if (n_live != nullptr && totals == nullptr) n_total = live;
   __shared__ double tot[7];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -830,6 +839,15 @@ __global__ __launch_bounds__(1024) void coslam_loss_grad_kernel(
   }
   const int ray = blockIdx.x * 16 + wave;
   if (ray >= n) return;
+  if (ray >= live) {
+    if (lane < L.S)
+      *reinterpret_cast<float4*>(g_raw + ((size_t)ray * L.S + lane) * 4) =
+          make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < 2)
+      *reinterpret_cast<float4*>(g_maps + (size_t)ray * 8 + lane * 4) =
+          make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const float d = tgt_d[ray];
   if (lane < L.S) {
     const size_t o = (size_t)ray * L.S + lane;
@@ -1037,7 +1055,7 @@ int xrd_coslam_loss_stats(int n_rays, int n_samples, float trunc,
                   n_samples};
   hipLaunchKernelGGL(coslam_loss_stats_kernel, dim3((n_rays + 3) / 4), dim3(256),
                      0, (hipStream_t)stream, L, n_rays, maps, z_vals, raw,
-                     target_d, target_rgb, stats);
+                     target_d, target_rgb, (const int*)nullptr, stats);
   return check_launch("xrd_coslam_loss_stats");
 }
 
@@ -1061,8 +1079,33 @@ int xrd_coslam_loss_grads(int n_rays, int n_samples, float w_rgb, float w_depth,
   hipLaunchKernelGGL(coslam_loss_grad_kernel, dim3((n_rays + 15) / 16),
                      dim3(1024), 0, (hipStream_t)stream, L, n_rays, maps, z_vals,
                      raw, target_d, target_rgb, stats, totals7, n_rays_total,
-                     loss5, g_maps, g_raw);
+                     (const int*)nullptr, loss5, g_maps, g_raw);
   return check_launch("xrd_coslam_loss_grads");
+}
+
+int xrd_coslam_loss_live(int n_rays, int n_samples, float w_rgb, float w_depth,
+                         float w_sdf, float w_fs, float trunc,
+                         float depth_trunc, float rgb_missing,
+                         const float* maps, const float* z_vals,
+                         const float* raw, const float* target_d,
+                         const float* target_rgb, const int32_t* n_live,
+                         float* loss5, float* g_maps, float* g_raw,
+                         float* workspace, xrd_stream_t stream) {
+  int rc = coslam_loss_check(n_rays, n_samples, maps, z_vals, raw, target_d,
+                             target_rgb, workspace);
+  if (rc != XRD_OK) return rc;
+  if (!n_live || !loss5 || !g_maps || !g_raw) return XRD_ERR_ARG;
+  const LossCfg L{w_rgb, w_depth, w_sdf, w_fs, trunc, depth_trunc, rgb_missing,
+                  n_samples};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(coslam_loss_stats_kernel, dim3((n_rays + 3) / 4), dim3(256),
+                     0, st, L, n_rays, maps, z_vals, raw, target_d, target_rgb,
+                     n_live, workspace);
+  hipLaunchKernelGGL(coslam_loss_grad_kernel, dim3((n_rays + 15) / 16),
+                     dim3(1024), 0, st, L, n_rays, maps, z_vals, raw, target_d,
+                     target_rgb, workspace, (const double*)nullptr,
+                     (int64_t)n_rays, n_live, loss5, g_maps, g_raw);
+  return check_launch("xrd_coslam_loss_live");
 }
 
 int xrd_coslam_loss(int n_rays, int n_samples, float w_rgb, float w_depth,

@@ -546,6 +546,39 @@ __global__ __launch_bounds__(256) void sample_distinct_kernel(
   out[i] = (int64_t)y;
 }
 
+// the same with the population size read on the device (a persistent graph
+// samples a bank that grows between its replays)
+__global__ __launch_bounds__(256) void sample_distinct_dev_kernel(
+    const int64_t* __restrict__ n_dev, int n_out,
+    const int64_t* __restrict__ keys, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const int64_t n = n_dev[0];
+  if (n <= i) {   // fewer than n_out items: no distinct sample exists
+    out[i] = n > 0 ? (int64_t)i % n : 0;
+    return;
+  }
+  int bits = 1;
+  while ((1ll << bits) < n) ++bits;
+  const int half_bits = (bits + 1) / 2;
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint64_t k[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) k[r] = (uint64_t)keys[r];
+  uint64_t y = (uint64_t)i;
+  do {
+    uint32_t L = (uint32_t)(y >> half_bits) & mask, R = (uint32_t)y & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t t = L ^ (feistel_round(R, k[r]) & mask);
+      L = R;
+      R = t;
+    }
+    y = ((uint64_t)L << half_bits) | R;
+  } while (y >= (uint64_t)n);
+  out[i] = (int64_t)y;
+}
+
 // rays_d = R[id] dir, rays_o = t[id] for per-ray pose ids
 __global__ __launch_bounds__(256) void pose_rays_fwd_kernel(
     int n, const float* __restrict__ dirs, int dir_stride,
@@ -830,6 +863,18 @@ int xrd_sample_distinct(int64_t n_total, int n_out, const int64_t* keys4,
   hipLaunchKernelGGL(sample_distinct_kernel, dim3((n_out + 255) / 256), dim3(256),
                      0, (hipStream_t)stream, n_total, n_out, half, keys4, out_idx);
   return check_launch("xrd_sample_distinct");
+}
+
+int xrd_sample_distinct_dev(const int64_t* n_total, int n_out,
+                            const int64_t* keys4, int64_t* out_idx,
+                            xrd_stream_t stream) {
+  if (n_out < 0 || !n_total || !keys4 || (n_out && !out_idx))
+    return XRD_ERR_ARG;
+  if (n_out == 0) return XRD_OK;
+  hipLaunchKernelGGL(sample_distinct_dev_kernel, dim3((n_out + 255) / 256),
+                     dim3(256), 0, (hipStream_t)stream, n_total, n_out, keys4,
+                     out_idx);
+  return check_launch("xrd_sample_distinct_dev");
 }
 
 int xrd_pose_rays_fwd(int n, const float* dirs, int dir_stride,

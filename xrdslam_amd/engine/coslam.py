@@ -218,7 +218,8 @@ class _CoslamLossFn(torch.autograd.Function):
     and the batch-global balancing weights are those of the whole batch."""
 
     @staticmethod
-    def forward(ctx, maps, z_vals, raw, target_d, target_rgb, cfgv, sharded):
+    def forward(ctx, maps, z_vals, raw, target_d, target_rgb, cfgv, sharded,
+                n_live=None):
         lib = _lib.lib()
         dev = maps.device
         n, S = z_vals.shape
@@ -233,6 +234,21 @@ class _CoslamLossFn(torch.autograd.Function):
         stats = torch.empty(n, 8, dtype=torch.float32, device=dev)
         w_rgb, w_d, w_sdf, w_fs, trunc, dtrunc, miss = [float(v) for v in cfgv]
         st = _lib.stream_ptr(dev)
+        if n_live is not None:
+            # capacity batch of a persistent mapping graph: the live ray
+            # count is read on the device
+            if sharded:
+                raise _lib.XrdError('live-count batches are not sharded')
+            assert n_live.dtype == torch.int32 and n_live.is_cuda
+            _lib.check(lib.xrd_coslam_loss_live(
+                n, S, w_rgb, w_d, w_sdf, w_fs, trunc, dtrunc, miss,
+                _lib.ptr(m), _lib.ptr(z), _lib.ptr(r), _lib.ptr(td),
+                _lib.ptr(tc), _lib.ptr(n_live), _lib.ptr(loss5),
+                _lib.ptr(g_maps), _lib.ptr(g_raw), _lib.ptr(stats), st),
+                'xrd_coslam_loss_live')
+            ctx.save_for_backward(g_maps, g_raw)
+            ctx.mark_non_differentiable(loss5)
+            return loss5[0], loss5
         _lib.check(lib.xrd_coslam_loss_stats(
             n, S, trunc, dtrunc, miss, _lib.ptr(m), _lib.ptr(z), _lib.ptr(r),
             _lib.ptr(td), _lib.ptr(tc), _lib.ptr(stats), st),
@@ -257,10 +273,10 @@ class _CoslamLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g5):
         g_maps, g_raw = ctx.saved_tensors
-        return g * g_maps, None, g * g_raw, None, None, None, None
+        return g * g_maps, None, g * g_raw, None, None, None, None, None
 
 
-def loss(model, outputs, target_d, target_rgb, sharded=False):
+def loss(model, outputs, target_d, target_rgb, sharded=False, n_live=None):
     """-> (total with autograd, loss5 = [total, rgb, depth, sdf, fs]).  With
     ``sharded`` every rank gets the GLOBAL loss value and the gradient of its
     own rays; summing the gradients over ranks gives the single-GPU one."""
@@ -271,4 +287,4 @@ def loss(model, outputs, target_d, target_rgb, sharded=False):
             cfg.training_rgb_missing)
     return _CoslamLossFn.apply(outputs['_maps'], outputs['z_vals'],
                                outputs['raw'], target_d, target_rgb, cfgv,
-                               bool(sharded))
+                               bool(sharded), n_live)

@@ -436,6 +436,20 @@ def sample_distinct(n_total: int, n_out: int, device, generator=None):
     return out
 
 
+def sample_distinct_dev(n_total_dev, n_out: int, device, generator=None):
+    """sample_distinct with the population size in a device tensor (int64
+    [1]) read when the launch executes: replayable from a hipGraph while the
+    population grows between replays"""
+    keys = torch.randint(-2**62, 2**62, (4, ), device=device,
+                         dtype=torch.int64, generator=generator)
+    out = torch.empty(n_out, dtype=torch.int64, device=device)
+    assert n_total_dev.dtype == torch.int64 and n_total_dev.is_cuda
+    _lib.check(_lib.lib().xrd_sample_distinct_dev(
+        _lib.ptr(n_total_dev), int(n_out), _lib.ptr(keys), _lib.ptr(out),
+        _lib.stream_ptr(torch.device(device))), 'xrd_sample_distinct_dev')
+    return out
+
+
 class PoseRaysFn(torch.autograd.Function):
     """rays_o, rays_d of rays with per-ray pose ids: rays_d = R[id] dir,
     rays_o = t[id]; differentiable w.r.t. c2w [n_pose,4,4].  ``rows`` [n,>=3]

@@ -181,8 +181,22 @@ class CoSLAM(Algorithm):
         with self.lock:
             rays = self.sample_single_keyframe_rays(keyframe,
                                                     self.num_rays_to_save)
-            self.rays = rays if self.rays is None else torch.cat(
-                [self.rays, rays], 0)
+            # capacity buffer (doubling): the bank keeps its address while
+            # keyframes are appended, so a captured mapping iteration can
+            # sample it on every replay
+            n_have = 0 if self.rays is None else self.rays.shape[0]
+            bank = getattr(self, '_bank', None)
+            if bank is None or n_have + rays.shape[0] > bank.shape[0]:
+                cap = max(32 * self.num_rays_to_save,
+                          2 * (n_have + rays.shape[0]))
+                new = torch.empty(cap, rays.shape[1], dtype=rays.dtype,
+                                  device=rays.device)
+                if n_have:
+                    new[:n_have] = self.rays
+                self._bank = bank = new
+                self._bank_version = getattr(self, '_bank_version', 0) + 1
+            bank[n_have:n_have + rays.shape[0]] = rays
+            self.rays = bank[:n_have + rays.shape[0]]
             # only pose and rays are kept (coslam.py:135-137)
             keyframe.rgb = None
             keyframe.depth = None
@@ -260,6 +274,9 @@ class CoSLAM(Algorithm):
         from ...engine import slam_ops
         from ..utils.opt_pose import axis_angle_translation_to_matrix
         cfg, dev = self.config, self.model.device
+        slot = getattr(self, '_pslot', None)
+        if slot is not None:
+            return self._slot_map_input(slot)
         cur = optimize_frames[-1]
         K = len(self.keyframe_graph)
         ba = getattr(self, '_ba', None)
@@ -295,6 +312,167 @@ class CoSLAM(Algorithm):
         return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': rows[:, 3:6],
                 'target_d': rows[:, 6:7], 'first': K == 0,
                 'sharded': sharded}
+
+    # -- persistent mapping graphs (MI355X) -----------------------------------
+    # A mapping call is 10 iterations; built per call, its optimisers, eager
+    # first iterations and captures cost as much as the iterations.  A slot
+    # keeps everything a captured iteration touches at fixed addresses with
+    # CAPACITIES instead of sizes — pose stacks of K_cap rows, the bank's
+    # capacity buffer, a current-frame part of `bucket` rays — and reads the
+    # sizes on the device: bank population (xrd_sample_distinct_dev), id of
+    # the current frame's pose row, live ray count (xrd_coslam_loss_live: the
+    # rows behind it take part in nothing).  One slot serves every call whose
+    # current-frame ray count falls in its bucket; from the 21st keyframe on
+    # that count is constant (min_sample_pixels).
+    persistent_map = True
+    _BUCKETS = (128, 256, 512, 1024, 2048)
+
+    def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
+        if not is_mapping:
+            return 0
+        acc = self.config.optimizers['mapping_pose_r']['optimizer'].accum_step
+        return int(acc is not None and (step + 1) % acc == 0)
+
+    def _persistent_map_ok(self, n_iters, frames):
+        dev = torch.device(self.model.device)
+        K = len(self.keyframe_graph)
+        return (self.persistent_map and self.use_graphs and
+                self.fused_iteration and dev.type == 'cuda' and
+                not _dist.state.enabled and self.is_initialized() and
+                self.bundle_adjust and K >= 1 and len(frames) == K + 1 and
+                self.config.separate_LR and
+                self.config.rot_rep == 'axis_angle' and
+                self.model._fused_tables(dev) is not None and
+                all(f is g for f, g in zip(frames, self.keyframe_graph)))
+
+    def _slot_map_input(self, slot):
+        from ...engine import slam_ops
+        from ..utils.opt_pose import axis_angle_translation_to_matrix
+        cfg, dev = self.config, self.model.device
+        c2w = axis_angle_translation_to_matrix(slot['r'], slot['t'])
+        c2w = torch.where(slot['fixed'], c2w.detach(), c2w)
+        idx = slam_ops.sample_distinct_dev(slot['n_bank'],
+                                           cfg.mapping_sample, dev)
+        bank = self._bank[idx]
+        fid = torch.div(idx, self.num_rays_to_save, rounding_mode='floor')
+        n = self.camera.height * self.camera.width
+        pix = self._distinct(n, slot['bucket'], dev)
+        cur = torch.cat([self._ray_dirs()[pix], slot['rgb'][pix],
+                         slot['depth'][pix]], -1)
+        rows = torch.cat([bank, cur], 0)
+        ids = torch.cat([fid, slot['cur_id'].expand(slot['bucket'])], 0)
+        rays_o, rays_d = slam_ops.PoseRaysFn.apply(c2w, rows, ids)
+        return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': rows[:, 3:6],
+                'target_d': rows[:, 6:7], 'first': False, 'sharded': False,
+                'n_live': slot['n_live']}
+
+    def _persistent_map(self, n_iters, frames):
+        """one mapping call through a capacity slot; False = not usable
+        (the caller takes the per-call path)"""
+        from ..engine.optimizers import reset_optimizer_state
+        cfg = self.config
+        dev = torch.device(self.model.device)
+        K = len(self.keyframe_graph)
+        cur = frames[-1]
+        n_cur = max(cfg.mapping_sample // K, cfg.min_sample_pixels)
+        bucket = next((b for b in self._BUCKETS if b >= n_cur), None)
+        if bucket is None:
+            return False
+        slots = self.__dict__.setdefault('_pslots', {})
+        slot = slots.get(bucket)
+        d_img, c_img = cur.device_images(dev)
+        if slot is not None and (
+                K + 1 > slot['r'].shape[0] or
+                slot['bank_version'] != self._bank_version or
+                slot['depth'].shape != d_img.shape):
+            slot = None                      # capacities outgrown
+        if self.model_optimizers is None:
+            self.model_optimizers = Optimizers(
+                dict(cfg.optimizers), {**self.model.get_param_groups()})
+        if slot is None:
+            kcap = max(64, 2 * (K + 1))
+            r = torch.nn.Parameter(torch.zeros(kcap, 3, device=dev))
+            t = torch.nn.Parameter(torch.zeros(kcap, 3, device=dev))
+            r.grad, t.grad = torch.zeros_like(r), torch.zeros_like(t)
+            fixed = torch.zeros(kcap, 1, 1, dtype=torch.bool, device=dev)
+            fixed[0] = True
+            pose_opt = Optimizers(dict(cfg.optimizers),
+                                  {'mapping_pose_r': [r],
+                                   'mapping_pose_t': [t]})
+            opt = pose_opt + self.model_optimizers
+            opt.parameters = {**pose_opt.parameters,
+                              **self.model_optimizers.parameters}
+            opt.static_grads = True
+            slot = slots[bucket] = {
+                'bucket': bucket, 'r': r, 't': t, 'fixed': fixed,
+                'pose_opt': pose_opt, 'opt': opt, 'graphs': {},
+                'bank_version': self._bank_version,
+                'depth': torch.empty_like(d_img),
+                'rgb': torch.empty_like(c_img),
+                'n_bank': torch.zeros(1, dtype=torch.int64, device=dev),
+                'cur_id': torch.zeros(1, dtype=torch.int64, device=dev),
+                'n_live': torch.zeros(1, dtype=torch.int32, device=dev)}
+        with torch.no_grad():
+            slot['r'].zero_()
+            slot['t'].zero_()
+            slot['r'][:K + 1] = torch.stack(
+                [f.pose.data_r.detach().to(dev) for f in frames])
+            slot['t'][:K + 1] = torch.stack(
+                [f.pose.data_t.detach().to(dev) for f in frames])
+            slot['r'].grad.zero_()
+            slot['t'].grad.zero_()
+            slot['depth'].copy_(d_img)
+            slot['rgb'].copy_(c_img)
+            slot['n_bank'].fill_(K * self.num_rays_to_save)
+            slot['cur_id'].fill_(K)
+            slot['n_live'].fill_(cfg.mapping_sample + n_cur)
+        # the reference builds the pose optimisers per call: fresh Adam state
+        for o in slot['pose_opt'].optimizers.values():
+            reset_optimizer_state(o)
+        opt, graphs = slot['opt'], slot['graphs']
+        self._pslot = slot
+        self.fixed_shape_batches = True
+        try:
+            seen = slot.setdefault('seen', set())
+            for step in range(n_iters):
+                # two kinds of iteration: with / without the pose step
+                # (5-step gradient accumulation)
+                k = self.graph_segment_key(True, step, n_iters)
+                if k in graphs:
+                    graphs[k].replay()
+                elif k not in seen:
+                    seen.add(k)        # lazy state (Adam moments) is created
+                    self._iteration(opt, frames, True, step, n_iters, False,
+                                    None)
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._iteration(opt, frames, True, step, n_iters,
+                                        False, None)
+                    graphs[k] = g
+                    g.replay()
+        finally:
+            self._pslot = None
+            self.fixed_shape_batches = False
+        with torch.no_grad():
+            rs, ts = slot['r'].detach(), slot['t'].detach()
+            dst = [f.pose.data_r for f in frames[1:]] + \
+                  [f.pose.data_t for f in frames[1:]]
+            src = [x.to(d.device) for x, d in zip(
+                list(rs[1:K + 1].unbind(0)) + list(ts[1:K + 1].unbind(0)),
+                dst)]
+            torch._foreach_copy_(dst, src)
+        self.after_mapping_update()
+        return True
+
+    def optimize_update(self, n_iters, optimize_frames, is_mapping,
+                        coarse=False):
+        if is_mapping and self._persistent_map_ok(n_iters, optimize_frames):
+            with self.lock:
+                if self._persistent_map(n_iters, optimize_frames):
+                    return None
+        return super().optimize_update(n_iters, optimize_frames, is_mapping,
+                                       coarse=coarse)
 
     def get_loss(self, optimize_frames, is_mapping, step=None, n_iters=None,
                  coarse=False):

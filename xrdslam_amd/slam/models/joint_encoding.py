@@ -127,7 +127,7 @@ class JointEncoding(Model):
             # are kept (detached) in self.last_loss_terms
             from ...engine import coslam as ec
             total, l5 = ec.loss(self, outputs, target_d, target_rgb,
-                                sharded=sharded)
+                                sharded=sharded, n_live=inputs.get('n_live'))
             self.last_loss_terms = l5
             losses = {'data_loss': total}
             if is_mapping and not inputs['first']:
