@@ -315,8 +315,9 @@ def run_coslam(args, dev, with_cpu, world=1):
     torch.cuda.synchronize()
     gc_was = _gc_pause()
     t0 = time.perf_counter()
+    frame = None
     for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
-        slam.step(k)
+        frame = slam.step(k)
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()
@@ -326,6 +327,15 @@ def run_coslam(args, dev, with_cpu, world=1):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if frame is not None and getattr(algo, 'persistent_map', False):
+        # launches inside replayed hipGraphs cannot be event-timed one by
+        # one: right after the timed region, three mapping calls on the
+        # per-call (eager) path feed the per-launch statistics
+        algo.persistent_map = False
+        for _ in range(3):
+            algo.do_mapping(frame)
+        torch.cuda.synchronize()
+        algo.persistent_map = True
     prof, ec.PROFILE = ec.PROFILE, None
     stats = []
     for key, evs in prof.items():
