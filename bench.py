@@ -776,10 +776,14 @@ def run_splatam(args, dev):
                           'FETCH x2 on gfx950)',
         'kernel': 'xrd_gs_blend_bwd<dual> = gs_blend_bwd_kernel + '
                   'gs_key_reduce_kernel (blend backward of the rgb and the '
-                  'depth/silhouette colours in one pass: one lane per '
-                  'Gaussian, the tile\'s pixels streamed through the lanes, '
-                  'no reductions or atomics; fp32 VALU — the peak is the fp32 '
-                  'FMA rate, equal to the f32 MFMA peak)',
+                  'depth/silhouette colours in one pass, front to back: one '
+                  'wave per 8x8 sub-tile with exact sub-tile culling, list '
+                  'entries as packed records through the scalar path, '
+                  'transposed in-wave reduction + LDS rows, no global '
+                  'atomics; fp32 VALU — the peak is the fp32 FMA rate, equal '
+                  'to the f32 MFMA peak; algorithmic pairs = Gaussians up to '
+                  'each pixel\'s last contributor, as the published kernels '
+                  'evaluate them)',
         'avg_launch_us': us['gs_render_bwd'],
         'launches': len(prof['gs_render_bwd']),
         'pixel_gaussian_pairs_per_pass': pairs,

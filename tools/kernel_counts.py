@@ -54,6 +54,26 @@ def report(tag, p):
           f'{100.0 * own_t / max(tot_t, 1e-9):.1f} % of device time')
     for n, k in sorted(c.items(), key=lambda x: -t[x[0]])[:40]:
         print(f'   {k:4d} x {n}  ({t[n]:.0f} us)')
+    if os.environ.get('XRD_KC_STACK'):
+        # where the small torch launches come from (python frames)
+        src = collections.Counter()
+        for e in p.events():
+            if e.device_type != torch.autograd.DeviceType.CUDA and \
+                    e.name in ('aten::fill_', 'aten::zero_', 'aten::copy_',
+                               'aten::cat', 'aten::add', 'aten::mul',
+                               'aten::where', 'aten::sum', 'aten::index',
+                               'aten::sort', 'aten::clone', 'aten::sub',
+                               'aten::div', 'aten::abs', 'aten::lt',
+                               'aten::gt', 'aten::bitwise_and',
+                               'aten::randint', 'aten::rand',
+                               'aten::normal_', 'aten::_to_copy',
+                               'aten::masked_fill_', 'aten::index_put_'):
+                fr = [f for f in (e.stack or []) if 'xrdslam_amd' in f or
+                      'bench.py' in f]
+                src[(e.name, fr[0].split('xrdslam_amd/')[-1] if fr else '?')] \
+                    += 1
+        for (op, where), k in src.most_common(60):
+            print(f'      {k:3d} {op:22s} {where}')
 
 
 def run(name):
@@ -87,7 +107,9 @@ def run(name):
                     tag not in state['seen']:
                 torch.cuda.synchronize()
                 with profile(activities=[ProfilerActivity.CUDA,
-                                         ProfilerActivity.CPU]) as p:
+                                         ProfilerActivity.CPU],
+                             with_stack=bool(os.environ.get(
+                                 'XRD_KC_STACK'))) as p:
                     out = orig(optimizers, frames, is_mapping, step, *a, **kw)
                     torch.cuda.synchronize()
                 state['seen'][tag] = p

@@ -44,7 +44,10 @@ def short_name(name):
               'pc_dw_reduce_kernel', 'pc_dw_kernel', 'point_geo_bwd_kernel',
               'point_geo_fwd_kernel', 'point_map_loss_kernel',
               'gs_blend_fwd_kernel', 'gs_blend_bwd_kernel',
-              'gs_key_reduce_kernel', 'frustum_select_kernel',
+              'gs_key_reduce_kernel', 'gs_pack_kernel',
+              'gs_prepare_fwd_kernel', 'gs_prepare_bwd_kernel',
+              'gs_loss_stats_kernel', 'gs_loss_grad_kernel',
+              'frustum_select_kernel',
               'frustum_depth_kernel'):
         if k in name:
             return k

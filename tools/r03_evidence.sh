@@ -24,7 +24,7 @@ echo "pmc point-slam done $((SECONDS-t0))s"
 XRD_PMC_STEPS=2 XRD_PMC_WARMUP=1 timeout 400 bash tools/run_pmc.sh $tag/pmc_splatam --algo splaTAM > $out/pmc_spl_tail.txt 2>&1
 echo "pmc splatam done $((SECONDS-t0))s"
 timeout 100 python tools/nice_bwd_timing.py 1000 200 > $out/nice_map_timing.txt 2>&1
-timeout 100 python tools/kernel_counts.py > $out/kernel_counts.txt 2>&1
+timeout 400 python tools/kernel_counts.py > $out/kernel_counts.txt 2> $out/kernel_counts_err.txt
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
 tail -1 $out/smoke.txt
 echo "all done $((SECONDS-t0))s"
