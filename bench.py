@@ -297,7 +297,7 @@ def run_coslam(args, dev, with_cpu, world=1):
         xdist.state.setup(dev, seed=0)
     data = SyntheticRoom(CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx,
                          fy=cam.fy, cx=cam.cx, cy=cam.cy,
-                         n_frames=max(args.warmup + args.steps + 1, 200),
+                         n_frames=max(args.warmup + args.steps + 12, 200),
                          device=dev)
     cad = cadence['co-slam']
     getattr(data, 'data', data).preload(
@@ -329,11 +329,12 @@ def run_coslam(args, dev, with_cpu, world=1):
         elapsed = float(t.item())
     if frame is not None and getattr(algo, 'persistent_map', False):
         # launches inside replayed hipGraphs cannot be event-timed one by
-        # one: right after the timed region, three mapping calls on the
-        # per-call (eager) path feed the per-launch statistics
+        # one: right after the timed region, ten more frames with mapping on
+        # the per-call (eager) path feed the per-launch statistics
         algo.persistent_map = False
-        for _ in range(3):
-            algo.do_mapping(frame)
+        nxt = 1 + args.warmup + args.steps
+        for k in range(nxt, nxt + 10):        # two mapping calls
+            slam.step(k)
         torch.cuda.synchronize()
         algo.persistent_map = True
     prof, ec.PROFILE = ec.PROFILE, None
