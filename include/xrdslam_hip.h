@@ -693,30 +693,32 @@ int xrd_gs_bin(int n, int image_width, int image_height, const int32_t* rect,
                int64_t key_capacity, void* workspace, int32_t* point_list,
                int32_t* ranges, int64_t* n_keys, xrd_stream_t stream);
 /* xrd_gs_bin that also returns what a per-Gaussian gradient reduction needs:
- * key_pos [key_capacity] int32 — sorted position of pre-sort key k (the keys
- * of Gaussian i are the pre-sort indices [offsets[i-1], offsets[i])) — and
- * offsets [n] int64, the inclusive scan of tiles_touched. */
+ * offsets [n] int64, the inclusive scan of tiles_touched — the (Gaussian,
+ * tile) pairs of Gaussian i carry the PRE-SORT indices [offsets[i-1],
+ * offsets[i]) — and key_pos [2 * key_capacity] int32: entries [0, cap) map a
+ * sorted position to its pair's pre-sort index, entries [cap, 2 cap) map a
+ * pre-sort index to the Gaussian id, or -1 for a pair a full list dropped. */
 int xrd_gs_bin2(int n, int image_width, int image_height, const int32_t* rect,
                 const int32_t* tiles_touched, const float* depths,
                 int64_t key_capacity, void* workspace, int32_t* point_list,
                 int32_t* ranges, int64_t* n_keys, int32_t* key_pos,
                 int64_t* offsets, xrd_stream_t stream);
 
-/* Tile blend, second formulation (csrc/gs_blend.hip; same call sites of the
+/* Tile blend, fourth formulation (csrc/gs_blend.hip; same call sites of the
  * reference as xrd_gs_render_fwd / _bwd: the forward / backward of
  * GaussianRasterizer, slam/model_components/gaussian_cloud_splatam.py:63-69,
  * 267-268).  colors_b / out_color_b / dL_dcolor_b / dL_dcolors_b NULL: one
  * colour set; else two sets blended with the same weights (SplaTAM's rgb and
  * depth / silhouette renders).
- *   forward: as xrd_gs_render_fwd[2]; ckpt (xrd_gs_blend_ckpt_floats floats,
- *     or NULL) receives every pixel's transmittance and colour prefix sums in
- *     front of every 64th Gaussian of its tile.
- *   backward: one lane per Gaussian (64 a wave), the tile's pixels streamed
- *     through the lanes; key_grad [key_capacity][12] scratch (one gradient
- *     row per (Gaussian, tile) key); the per-Gaussian outputs are OVERWRITTEN
- *     (no atomics, nothing to zero): dL_dmean2D [n,2], dL_dconic [n,3],
- *     dL_dopacity [n], dL_dcolors_a/_b [n,3].  out_color_a/_b: the forward's
- *     images. */
+ *   forward: as xrd_gs_render_fwd[2]; ckpt (xrd_gs_blend_ckpt_floats floats:
+ *     one packed 64-byte record per sorted key) is written by the forward
+ *     (point_list non-NULL) and read by both directions.
+ *   backward: front to back, one wave per 8x8 sub-tile; key_grad
+ *     [key_capacity][12] scratch (one gradient row per (Gaussian, tile) pair,
+ *     filed under the pair's pre-sort index: key_pos / offsets of
+ *     xrd_gs_bin2); the per-Gaussian outputs are OVERWRITTEN (no atomics,
+ *     nothing to zero): dL_dmean2D [n,2], dL_dconic [n,3], dL_dopacity [n],
+ *     dL_dcolors_a/_b [n,3].  out_color_a/_b: the forward's images. */
 int64_t xrd_gs_blend_ckpt_floats(int64_t key_capacity, int image_width,
                                  int image_height);
 int xrd_gs_blend_fwd(const xrd_gs_camera* c, const int32_t* ranges,

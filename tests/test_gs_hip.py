@@ -175,7 +175,10 @@ def test_rasterizer_empty_and_unsupported():
 
 @pytest.mark.parametrize('N,H,W,cap_factor', [(300, 40, 56, 1.5),
                                               (5000, 120, 160, 1.0),
-                                              (5000, 120, 160, 0.5)])
+                                              (5000, 120, 160, 0.5),
+                                              # > 4096 entries a tile: the
+                                              # global rank-sort path
+                                              (30000, 32, 48, 1.0)])
 def test_device_binning_equals_scan_sort_on_the_host_side(N, H, W, cap_factor):
     """xrd_gs_bin (scan + static-capacity key list + radix sort + ranges, no
     host sync) against the phase-by-phase path it replaced (torch.cumsum,

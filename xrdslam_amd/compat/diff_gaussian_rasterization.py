@@ -257,7 +257,9 @@ def _geometry(lib, cam, dev, st, m3, sc, rt, op):
     ws = _BIN.workspace(dev, lib.xrd_gs_bin_ws_bytes(n, cap, W, H))
     # inverse map of the sort + the scan (the lane-per-Gaussian blend backward
     # sums a Gaussian's per-key gradient rows through them)
-    key_pos = torch.empty(cap, **i)
+    # [0,cap): sorted position -> pre-sort pair index; [cap,2cap): pre-sort
+    # pair index -> Gaussian id, -1 for a pair dropped by a full list
+    key_pos = torch.empty(2 * cap, **i)
     offsets = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     with _Timed('gs_bin'):
         _lib.check(lib.xrd_gs_bin2(

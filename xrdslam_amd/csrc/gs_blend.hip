@@ -45,8 +45,8 @@
 // twelve butterflies) that leaves each sum in its own lane, and adds them to
 // the entry's LDS row with one conflict-free ds_add; after 256 entries the
 // block writes one finished gradient row per (Gaussian, tile) key.
-// gs_key_reduce sums a Gaussian's rows through the inverse map of the binning
-// sort (gs_bin.hip).  No global atomics anywhere.
+// gs_key_reduce sums a Gaussian's rows — filed under the pairs' pre-sort
+// index (gs_bin.hip), hence contiguous.  No global atomics anywhere.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_color_b,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_b,
-    float* __restrict__ key_grad) {
+    const int* __restrict__ key_pos, float* __restrict__ key_grad) {
   __shared__ float s_acc[BUCKET * KEYROW];
   __shared__ int s_max;
   const int gx = (cam.W + TILE - 1) / TILE;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
         const float o = q[3];
         const float cA = q[0] * (-2.f / kLog2e), cB = q[1] * (-1.f / kLog2e),
                     cC = q[2] * (-2.f / kLog2e);
-        float* row = key_grad + (int64_t)(r0 + k) * KEYROW;
+        float* row = key_grad + (int64_t)key_pos[r0 + k] * KEYROW;
         *reinterpret_cast<f32x4*>(row) = f32x4{s[0], s[1], s[2], s[3]};
         *reinterpret_cast<f32x4*>(row + 4) =
             f32x4{s[4], s[5], -o * (cA * s[7] + cB * s[8]) * ddx,
@@ -447,19 +447,20 @@ __global__ __launch_bounds__(BLOCK) void gs_blend_bwd_kernel(
   }
   // keys of this tile behind the last contributor: zero rows
   for (int k = n_buckets * BUCKET + tid; k < len; k += BLOCK) {
-    float* row = key_grad + (int64_t)(r0 + k) * KEYROW;
+    float* row = key_grad + (int64_t)key_pos[r0 + k] * KEYROW;
 #pragma unroll
     for (int c = 0; c < KEYROW; c += 4)
       *reinterpret_cast<f32x4*>(row + c) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
-// gradients of Gaussian i = sum of the rows of its keys: pre-sort keys
-// [offsets[i-1], offsets[i]) through key_pos (sorted position)
+// gradients of Gaussian i = sum of the rows of its pairs: rows are filed
+// under the pre-sort pair index, a Gaussian's are [offsets[i-1], offsets[i])
+// (pairs numbered behind the capacity were dropped by gs_bin.hip)
 template <bool DUAL>
 __global__ __launch_bounds__(256) void gs_key_reduce_kernel(
     int n, int64_t cap, const int64_t* __restrict__ offsets,
-    const int* __restrict__ key_pos, const float* __restrict__ key_grad,
+    const int* __restrict__ live_pre, const float* __restrict__ key_grad,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopac, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dcolors_b) {
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void gs_key_reduce_kernel(
   int64_t k0 = i == 0 ? 0 : offsets[i - 1], k1 = offsets[i];
   if (k1 > cap) k1 = cap;  // keys beyond the capacity were dropped
   for (int64_t k = k0; k < k1; ++k) {
-    const float* row = key_grad + (int64_t)key_pos[k] * KEYROW;
+    const float* row = key_grad + k * KEYROW;
     const f32x4 a = *reinterpret_cast<const f32x4*>(row);
     const f32x4 b = *reinterpret_cast<const f32x4*>(row + 4);
     const f32x4 c = *reinterpret_cast<const f32x4*>(row + 8);
@@ -576,19 +577,20 @@ int xrd_gs_blend_bwd(const xrd_gs_camera* c, int n, int64_t key_capacity,
   if (dual) {
     hipLaunchKernelGGL(gs_blend_bwd_kernel<true>, grid, dim3(BLOCK), 0, st,
                        cam, ranges, ckpt, final_T, n_contrib, out_color_a,
-                       out_color_b, dL_dcolor_a, dL_dcolor_b, key_grad);
+                       out_color_b, dL_dcolor_a, dL_dcolor_b, key_pos,
+                       key_grad);
     hipLaunchKernelGGL(gs_key_reduce_kernel<true>, dim3((n + 255) / 256),
-                       dim3(256), 0, st, n, key_capacity, offsets, key_pos,
-                       key_grad, dL_dmean2D, dL_dconic, dL_dopacity,
-                       dL_dcolors_a, dL_dcolors_b);
+                       dim3(256), 0, st, n, key_capacity, offsets,
+                       key_pos + key_capacity, key_grad, dL_dmean2D, dL_dconic,
+                       dL_dopacity, dL_dcolors_a, dL_dcolors_b);
   } else {
     hipLaunchKernelGGL(gs_blend_bwd_kernel<false>, grid, dim3(BLOCK), 0, st,
                        cam, ranges, ckpt, final_T, n_contrib, out_color_a,
-                       nullptr, dL_dcolor_a, nullptr, key_grad);
+                       nullptr, dL_dcolor_a, nullptr, key_pos, key_grad);
     hipLaunchKernelGGL(gs_key_reduce_kernel<false>, dim3((n + 255) / 256),
-                       dim3(256), 0, st, n, key_capacity, offsets, key_pos,
-                       key_grad, dL_dmean2D, dL_dconic, dL_dopacity,
-                       dL_dcolors_a, nullptr);
+                       dim3(256), 0, st, n, key_capacity, offsets,
+                       key_pos + key_capacity, key_grad, dL_dmean2D, dL_dconic,
+                       dL_dopacity, dL_dcolors_a, nullptr);
   }
   return check_launch("xrd_gs_blend_bwd");
 }
