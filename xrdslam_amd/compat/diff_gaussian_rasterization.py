@@ -407,6 +407,9 @@ class _RasterizeFn(torch.autograd.Function):
         ctx.save_for_backward(m3, sc, rt, cl, xy, conic_o, radii, ranges,
                               plist, final_T, n_contrib, *extra)
         ctx.mark_non_differentiable(radii, depth)
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return color, radii, depth
 
     @staticmethod
@@ -421,7 +424,9 @@ class _RasterizeFn(torch.autograd.Function):
         st = _lib.stream_ptr(dev)
         cam = _camera(ctx.rs)
         n = ctx.n
-        gc = g_color.float().contiguous()
+        gc = g_color.float().contiguous() if g_color is not None else \
+            torch.zeros(3, cam.image_height, cam.image_width,
+                        dtype=torch.float32, device=dev)
         d_mean2D, d_conic, d_op, d_col, _ = _blend_bwd(
             lib, cam, dev, st, n, ranges, plist, xy, conic_o, cl, None,
             final_T, n_contrib, color, None, gc, None, ckpt,
@@ -472,6 +477,9 @@ class _RasterizeDualFn(torch.autograd.Function):
         ctx.save_for_backward(m3, sc, rt, ca, cb, xy, conic_o, radii, ranges,
                               plist, final_T, n_contrib, *extra)
         ctx.mark_non_differentiable(radii, depth)
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return color_a, radii, depth, color_b
 
     @staticmethod

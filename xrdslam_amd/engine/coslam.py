@@ -161,6 +161,9 @@ class _CoslamRenderFn(torch.autograd.Function):
         ctx.sc, ctx.tables = sc, tables
         ctx.save_for_backward(ro, rd, z_vals, raw, table, pack)
         ctx.mark_non_differentiable(z_vals)
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return maps, z_vals, raw
 
     @staticmethod
@@ -248,6 +251,7 @@ class _CoslamLossFn(torch.autograd.Function):
                 'xrd_coslam_loss_live')
             ctx.save_for_backward(g_maps, g_raw)
             ctx.mark_non_differentiable(loss5)
+            ctx.set_materialize_grads(False)
             return loss5[0], loss5
         _lib.check(lib.xrd_coslam_loss_stats(
             n, S, trunc, dtrunc, miss, _lib.ptr(m), _lib.ptr(z), _lib.ptr(r),
@@ -268,6 +272,7 @@ class _CoslamLossFn(torch.autograd.Function):
             _lib.ptr(g_maps), _lib.ptr(g_raw), st), 'xrd_coslam_loss_grads')
         ctx.save_for_backward(g_maps, g_raw)
         ctx.mark_non_differentiable(loss5)
+        ctx.set_materialize_grads(False)
         return loss5[0], loss5
 
     @staticmethod

@@ -77,6 +77,9 @@ class _GeoFn(torch.autograd.Function):
         ctx.save_for_backward(p, f, nbr, n_nb, cloud, fmask, radius, empty,
                               packed, masks)
         ctx.mark_non_differentiable(has)
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return occ, has
 
     @staticmethod

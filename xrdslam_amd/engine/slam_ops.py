@@ -122,6 +122,9 @@ class SampleRaysFn(torch.autograd.Function):
         ctx.args = (cam, crop, F, n)
         ctx.save_for_backward(idx)
         ctx.mark_non_differentiable(td, tc, keep, dmax)
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return ro, rd, td, tc, keep, dmax
 
     @staticmethod
@@ -130,8 +133,11 @@ class SampleRaysFn(torch.autograd.Function):
         idx, = ctx.saved_tensors
         cam, (H0, W0, wcrop), F, n = ctx.args
         dev = idx.device
-        g_ro = g_ro.float().contiguous()
-        g_rd = g_rd.float().contiguous()
+        z = None
+        if g_ro is None or g_rd is None:
+            z = torch.zeros(F * n, 3, dtype=torch.float32, device=dev)
+        g_ro = z if g_ro is None else g_ro.float().contiguous()
+        g_rd = z if g_rd is None else g_rd.float().contiguous()
         g_c2w = torch.empty(F, 4, 4, dtype=torch.float32, device=dev)
         st = _lib.stream_ptr(dev)
         for f in range(F):
@@ -223,10 +229,17 @@ class SampleRaysPosesFn(torch.autograd.Function):
                                            crop, bound6, layout, pose_params)
         ctx.save_for_backward(idx, *pose_params)
         ctx.mark_non_differentiable(*outs[2:])
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return outs
 
     @staticmethod
     def backward(ctx, g_ro, g_rd, *unused):
+        if g_ro is None or g_rd is None:
+            z = torch.zeros_like(g_rd if g_ro is None else g_ro)
+            g_ro = z if g_ro is None else g_ro
+            g_rd = z if g_rd is None else g_rd
         g7 = sample_rays_poses_bwd(ctx.args, g_ro, g_rd)
         return (None, None, None, None, None, None, None,
                 *pose_param_grads(g7, ctx.args[4]))

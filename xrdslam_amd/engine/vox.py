@@ -403,6 +403,9 @@ class _VoxRenderLossFn(torch.autograd.Function):
         ctx.ws, ctx.ms, ctx.cfg, ctx.need_w = ws, ms, cfg, need_w
         ctx.save_for_backward(packed, target_d, target_s)
         ctx.mark_non_differentiable(ws.loss, ws.depth, ws.rgb)
+        # gradients of the non-differentiable outputs arrive as None instead
+        # of materialised zero tensors (one fill launch each)
+        ctx.set_materialize_grads(False)
         return ws.loss[4].clone(), ws.loss, ws.depth, ws.rgb
 
     @staticmethod
