@@ -201,6 +201,25 @@ int xrd_point_map_loss(int n_rays, int n_samples, const float* raw,
                        const uint8_t* ray_valid, float sigmoid_coef,
                        float w_color, int min_valid_points, float* loss,
                        float* g_raw, xrd_stream_t stream);
+/* Point-SLAM batch selection + sample placement, one launch (single block):
+ * the filter of PointSLAM.get_model_input (slam/algorithms/point_slam.py:
+ * 246-300: valid = d > 0, keep = valid & d <= min(10 median(d[valid]),
+ * 1.2 max(d[valid])), torch.median = LOWER median) — as a mask, the batch
+ * keeps its shape — and render_batch_ray's samples
+ * (slam/models/conv_onet_pointslam.py:330-347): z = near d (1 - t) + far d t,
+ * t = linspace(0, 1, S), pts = o + dir z.  radius_stack [F, image_pixels]
+ * (NULL: no radii): the rays' dynamic query radii, looked up at pixel
+ * (hedge + idx / crop_width, wedge + idx % crop_width) of frame
+ * ray / rays_per_frame, per ray and repeated per sample.  stats [2] (NULL or)
+ * = (median, max). */
+int xrd_point_batch(int n_rays, int n_samples, const float* rays_o,
+                    const float* rays_d, const float* target_d,
+                    const float* radius_stack, const int64_t* pixel_idx,
+                    int rays_per_frame, int crop_width, int hedge, int wedge,
+                    int image_width, int64_t image_pixels, float near_coef,
+                    float far_coef, uint8_t* keep, float* radius,
+                    float* z_vals, float* pts, float* radius_pts, float* stats,
+                    xrd_stream_t stream);
 /* Point-SLAM compositing alone (raw2outputs_nerf_color2, utils.py:247-294, with
  * the no-neighbour override of render_batch_ray, conv_onet_pointslam.py:441):
  *   rgb [n_rays*S rows, stride rgb_stride >= 3] or NULL, occ [n_rays*S rows,

@@ -499,3 +499,61 @@ def test_point_render_chain_through_the_abi():
     for k in ref:
         err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
         assert err < 1e-4, (k, err)
+
+
+@pytest.mark.parametrize('n_per,F,S,empty', [(1500, 1, 5, False),
+                                             (1000, 5, 5, False),
+                                             (333, 3, 8, False),
+                                             (200, 1, 5, True)])
+def test_batch_kernel_equals_torch_formulation(n_per, F, S, empty):
+    """xrd_point_batch (batch filter with a radix-select median, sample
+    placement, per-point radii) against the torch ops it replaces
+    (PointSLAM._select_batch + _sample_window's radius gather +
+    ConvOnet2.fused_map_loss's placement): mask, z, points and radii
+    bit-exact; gradients w.r.t. the rays"""
+    from xrdslam_amd.engine import point as ep
+    from xrdslam_amd.slam.common.common import masked_lower_median
+    g = torch.Generator().manual_seed(11)
+    dev = 'cuda:0'
+    H, W, hedge, wedge = 48, 64, 3, 5
+    wcrop = W - 2 * wedge
+    n = n_per * F
+    ro = torch.randn(n, 3, generator=g).to(dev).requires_grad_(True)
+    rd = torch.randn(n, 3, generator=g).to(dev).requires_grad_(True)
+    gd = torch.rand(n, generator=g) * 4
+    gd[torch.rand(n, generator=g) < 0.15] = 0.0
+    gd[7] = 60.0                      # beyond 10 x median
+    if empty:
+        gd[:] = 0.0
+    gd = gd.to(dev)
+    idx = torch.randint((H - 2 * hedge) * wcrop, (F, n_per), generator=g) \
+        .to(dev)
+    stack = (0.01 + torch.rand(F, H * W, generator=g)).to(dev)
+    near, far = 0.98, 1.02
+    # torch formulation
+    valid = gd > 0
+    med = masked_lower_median(gd, valid)
+    top = torch.where(valid, gd, torch.full_like(gd, float('-inf'))).max()
+    inside = valid & (gd <= torch.minimum(10 * med, 1.2 * top))
+    rows = hedge + torch.div(idx, wcrop, rounding_mode='floor')
+    cols = wedge + idx % wcrop
+    rq = stack.gather(1, rows * W + cols).reshape(-1)
+    d = gd.reshape(-1, 1)
+    t = torch.linspace(0.0, 1.0, steps=S, device=dev)
+    z = near * d * (1. - t) + far * d * t
+    pts = ro[..., None, :] + rd[..., None, :] * z[..., :, None]
+    w = torch.randn(n * S, 3, generator=g).to(dev)
+    (pts.reshape(-1, 3) * w).sum().backward()
+    ref_g = (ro.grad.clone(), rd.grad.clone())
+    ro.grad = rd.grad = None
+    out = ep.batch(ro, rd, gd, stack, idx.reshape(-1),
+                   (n_per, wcrop, hedge, wedge, W, H * W), S, near, far)
+    (out['pts'] * w).sum().backward()
+    assert torch.equal(out['ray_valid'], inside)
+    assert torch.equal(out['z_vals'], z)
+    assert torch.equal(out['pts'], pts.reshape(-1, 3).detach())
+    assert torch.equal(out['batch_dynamic_r'], rq)
+    assert torch.equal(out['rq_pts'],
+                       rq.reshape(-1, 1).repeat_interleave(S, dim=0))
+    assert torch.allclose(ro.grad, ref_g[0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rd.grad, ref_g[1], rtol=1e-5, atol=1e-5)

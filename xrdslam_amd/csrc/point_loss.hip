@@ -136,6 +136,160 @@ extern "C" int xrd_point_map_loss(int n_rays, int n_samples, const float* raw,
   return check_launch("xrd_point_map_loss");
 }
 
+// ---- batch selection + sample points -----------------------------------------------
+// PointSLAM.get_model_input after the per-frame sampling
+// (slam/algorithms/point_slam.py:246-300) + the sample placement of
+// render_batch_ray (slam/models/conv_onet_pointslam.py:330-347) as ONE launch:
+//   valid = d > 0; med = lower median of d[valid]; top = max d[valid];
+//   keep  = valid & (d <= min(10 med, 1.2 top))       (the batch filter)
+//   z     = near d (1 - t) + far d t, t = linspace(0, 1, S)
+//   pts   = o + dir z;  per-point query radius = the pixel's radius
+// The median is a 4-pass radix select over the depth bits in one block (the
+// torch formulation sorts the batch); arithmetic as separate roundings like
+// the torch ops it replaces.
+namespace xrd {
+namespace {
+
+constexpr int BATCH_THREADS = 1024;
+
+__global__ __launch_bounds__(BATCH_THREADS) void point_batch_kernel(
+    int n, int S, const float* __restrict__ ro, const float* __restrict__ rd,
+    const float* __restrict__ d, const float* __restrict__ radius_stack,
+    const int64_t* __restrict__ idx, int n_per, int wcrop, int hedge,
+    int wedge, int width, int64_t hw, float near_c, float far_c,
+    uint8_t* __restrict__ keep, float* __restrict__ radius,
+    float* __restrict__ z_vals, float* __restrict__ pts,
+    float* __restrict__ radius_pts, float* __restrict__ stats) {
+  // separate roundings like the torch ops this replaces (plain operators:
+  // the __f*_rn intrinsics inline WITH the library's contract flag and are
+  // fused again)
+#pragma clang fp contract(off)
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix, s_k, s_cnt, s_top;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_cnt = 0;
+    s_top = 0;
+  }
+  __syncthreads();
+  unsigned cnt = 0, top = 0;
+  for (int i = tid; i < n; i += BATCH_THREADS) {
+    const float v = d[i];
+    if (v > 0.f) {
+      ++cnt;
+      top = max(top, __float_as_uint(v));   // positive floats order as bits
+    }
+  }
+  if (cnt != 0) {
+    atomicAdd(&s_cnt, cnt);
+    atomicMax(&s_top, top);
+  }
+  __syncthreads();
+  const unsigned total = s_cnt;
+  if (tid == 0) {
+    s_prefix = 0;
+    s_k = total > 0 ? (total - 1) / 2 : 0;
+  }
+  // radix select of the k-th smallest valid depth, 8 bits a pass
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < n; i += BATCH_THREADS) {
+      const float v = d[i];
+      const unsigned b = __float_as_uint(v);
+      if (v > 0.f && (b & himask) == prefix)
+        atomicAdd(&hist[(b >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned k = s_k, acc = 0;
+      int bin = 255;
+      for (int h = 0; h < 256; ++h) {
+        if (acc + (unsigned)hist[h] > k) {
+          bin = h;
+          break;
+        }
+        acc += (unsigned)hist[h];
+      }
+      s_k = k - acc;
+      s_prefix = prefix | ((unsigned)bin << shift);
+    }
+    __syncthreads();
+  }
+  const float med = total > 0 ? __uint_as_float(s_prefix) : NAN;
+  const float topf = total > 0 ? __uint_as_float(s_top) : -INFINITY;
+  // torch.minimum propagates NaN; every comparison with it is false
+  const float lim = fminf(10.f * med, 1.2f * topf);
+  if (tid == 0 && stats != nullptr) {
+    stats[0] = med;
+    stats[1] = topf;
+  }
+  const float step = S > 1 ? 1.f / (float)(S - 1) : 0.f;
+  for (int i = tid; i < n; i += BATCH_THREADS) {
+    const float v = d[i];
+    keep[i] = (total > 0 && v > 0.f && v <= lim) ? 1 : 0;
+    float r = 0.f;
+    if (radius_stack != nullptr) {
+      const int64_t e = idx[i];
+      const int64_t row = hedge + e / wcrop, col = wedge + e % wcrop;
+      r = radius_stack[(int64_t)(i / n_per) * hw + row * width + col];
+      radius[i] = r;
+    }
+    const float a = near_c * v, b = far_c * v;
+    const float o0 = ro[i * 3], o1 = ro[i * 3 + 1], o2 = ro[i * 3 + 2];
+    const float d0 = rd[i * 3], d1 = rd[i * 3 + 1], d2 = rd[i * 3 + 2];
+    for (int s = 0; s < S; ++s) {
+      // torch.linspace: from the start in the first half, from the end in
+      // the second
+      float t;
+      if (s < S / 2) {
+        t = step * (float)s;
+      } else {
+        const float back = step * (float)(S - 1 - s);
+        t = 1.f - back;
+      }
+      const float u = 1.f - t;
+      const float za = a * u, zb = b * t;
+      const float z = za + zb;
+      const int64_t m = (int64_t)i * S + s;
+      z_vals[m] = z;
+      const float p0 = d0 * z, p1 = d1 * z, p2 = d2 * z;
+      pts[m * 3] = o0 + p0;
+      pts[m * 3 + 1] = o1 + p1;
+      pts[m * 3 + 2] = o2 + p2;
+      if (radius_stack != nullptr) radius_pts[m] = r;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
+extern "C" int xrd_point_batch(
+    int n_rays, int n_samples, const float* rays_o, const float* rays_d,
+    const float* target_d, const float* radius_stack, const int64_t* pixel_idx,
+    int rays_per_frame, int crop_width, int hedge, int wedge, int image_width,
+    int64_t image_pixels, float near_coef, float far_coef, uint8_t* keep,
+    float* radius, float* z_vals, float* pts, float* radius_pts, float* stats,
+    xrd_stream_t stream) {
+  if (n_rays < 1 || n_samples < 1 || n_samples > 64) return XRD_ERR_ARG;
+  if (!rays_o || !rays_d || !target_d || !keep || !z_vals || !pts)
+    return XRD_ERR_ARG;
+  if (radius_stack != nullptr &&
+      (!pixel_idx || !radius || !radius_pts || rays_per_frame < 1 ||
+       crop_width < 1 || image_width < 1 || image_pixels < 1))
+    return XRD_ERR_ARG;
+  hipLaunchKernelGGL(xrd::point_batch_kernel, dim3(1),
+                     dim3(xrd::BATCH_THREADS), 0, (hipStream_t)stream, n_rays,
+                     n_samples, rays_o, rays_d, target_d, radius_stack,
+                     pixel_idx, rays_per_frame, crop_width, hedge, wedge,
+                     image_width, image_pixels, near_coef, far_coef, keep,
+                     radius, z_vals, pts, radius_pts, stats);
+  return xrd::check_launch("xrd_point_batch");
+}
+
 // ---- compositing alone (tracking, render_img, and the generic backward) ------------
 // raw2outputs_nerf_color2 (slam/model_components/utils.py:247-294) with the
 // no-neighbour override of render_batch_ray (conv_onet_pointslam.py:441):

@@ -361,6 +361,65 @@ class _MapLossFn(torch.autograd.Function):
         return (g_raw * g, ) + (None, ) * 8
 
 
+class _BatchFn(torch.autograd.Function):
+    """batch filter + sample placement of a Point-SLAM iteration
+    (xrd_point_batch): (rays_o, rays_d) -> (keep, radius, z_vals, pts,
+    radius_pts); differentiable w.r.t. the rays through pts = o + dir z"""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, target_d, radius_stack, idx, geom, S,
+                near, far):
+        lib = _lib.lib()
+        dev = rays_o.device
+        ro = rays_o.detach().float().contiguous()
+        rd = rays_d.detach().float().contiguous()
+        td = target_d.detach().float().reshape(-1).contiguous()
+        n = ro.shape[0]
+        n_per, wcrop, hedge, wedge, width, hw = geom
+        f = dict(dtype=torch.float32, device=dev)
+        keep = torch.empty(n, dtype=torch.uint8, device=dev)
+        z = torch.empty(n, S, **f)
+        pts = torch.empty(n * S, 3, **f)
+        rq = rq_pts = None
+        if radius_stack is not None:
+            rq = torch.empty(n, **f)
+            rq_pts = torch.empty(n * S, 1, **f)
+            assert idx.dtype == torch.int64 and idx.numel() == n
+        _lib.check(lib.xrd_point_batch(
+            n, int(S), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(td),
+            _lib.ptr(radius_stack), _lib.ptr(idx), int(n_per), int(wcrop),
+            int(hedge), int(wedge), int(width), int(hw), float(near),
+            float(far), _lib.ptr(keep), _lib.ptr(rq), _lib.ptr(z),
+            _lib.ptr(pts), _lib.ptr(rq_pts), None, _lib.stream_ptr(dev)),
+            'xrd_point_batch')
+        ctx.save_for_backward(z)
+        ctx.set_materialize_grads(False)
+        keep = keep.view(torch.bool)
+        outs = (keep, z, pts) if rq is None else (keep, z, pts, rq, rq_pts)
+        ctx.mark_non_differentiable(*[o for o in outs if o is not pts])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g_pts = grads[2]
+        if g_pts is None:
+            return (None, ) * 9
+        z, = ctx.saved_tensors
+        n, S = z.shape
+        g = g_pts.reshape(n, S, 3)
+        return (g.sum(1), (g * z[..., None]).sum(1)) + (None, ) * 7
+
+
+def batch(rays_o, rays_d, target_d, radius_stack, idx, geom, S, near, far):
+    """-> dict(ray_valid, z_vals, pts [, batch_dynamic_r, rq_pts])"""
+    out = _BatchFn.apply(rays_o, rays_d, target_d, radius_stack, idx, geom,
+                         S, near, far)
+    res = {'ray_valid': out[0], 'z_vals': out[1], 'pts': out[2]}
+    if len(out) == 5:
+        res['batch_dynamic_r'], res['rq_pts'] = out[3], out[4]
+    return res
+
+
 def map_loss(raw, z_vals, target_d, target_rgb, point_mask, ray_valid, coef,
              w_color, min_valid):
     """compositing + Point-SLAM's mapping loss (sum |d - depth| + w_color sum

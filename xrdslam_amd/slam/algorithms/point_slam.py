@@ -153,6 +153,10 @@ class PointSLAM(Algorithm):
         grad_sampler = not is_mapping and cfg.tracking_sample_with_color_grad
         if self.batched_sampling and not grad_sampler and \
                 torch.device(dev).type == 'cuda':
+            if self.fused_batch and getattr(self, 'fixed_shape_batches',
+                                            False):
+                return self._fused_batch(optimize_frames, n, Hedge, Wedge,
+                                         gen, is_mapping)
             ro, rd, gd, gc, rq = self._sample_window(
                 optimize_frames, n, Hedge, Wedge, gen, is_mapping)
             return self._select_batch(ro, rd, gd, gc, rq)
@@ -187,8 +191,28 @@ class PointSLAM(Algorithm):
         return self._select_batch(ro, rd, gd, gc, rq)
 
     batched_sampling = True   # the window's rays in one launch (CUDA)
+    # captured iterations: batch filter, sample points and query radii in one
+    # more launch (engine/point.batch) instead of ~35 torch launches
+    fused_batch = True
 
-    def _sample_window(self, frames, n, Hedge, Wedge, gen, is_mapping):
+    def _fused_batch(self, frames, n, Hedge, Wedge, gen, is_mapping):
+        from ...engine import point as _pt
+        cfg, cam, mc = self.config, self.camera, self.model.config
+        ro, rd, td, tc, idx, wcrop = self._sample_window(
+            frames, n, Hedge, Wedge, gen, is_mapping, want_radius=False)
+        stack = self._radius_stack(frames) if cfg.use_dynamic_radius else None
+        geom = (n, wcrop, Hedge, Wedge, cam.width, cam.height * cam.width)
+        out = _pt.batch(ro, rd, td, stack, idx.reshape(-1), geom,
+                        mc.rendering_n_surface, mc.rendering_near_end_surface,
+                        mc.rendering_far_end_surface)
+        out.update({'rays_o': ro, 'rays_d': rd, 'target_s': tc,
+                    'target_d': td, 'stage': self.stage,
+                    'static_shapes': True})
+        out.setdefault('batch_dynamic_r', None)
+        return out
+
+    def _sample_window(self, frames, n, Hedge, Wedge, gen, is_mapping,
+                       want_radius=True):
         """get_samples of every frame of the window (pixels drawn with
         replacement inside the crop, OpenGL rays through the frame's pose,
         sensor depth / colour / query radius of the pixel) as one index draw
@@ -218,6 +242,8 @@ class PointSLAM(Algorithm):
             ro, rd, td, tc, _, _ = slam_ops.SampleRaysFn.apply(
                 c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
                 (Hedge, Wedge, wcrop), bound6)
+        if not want_radius:
+            return ro, rd, td.reshape(-1), tc, idx, wcrop
         rq = None
         if cfg.use_dynamic_radius:
             rows = Hedge + torch.div(idx, wcrop, rounding_mode='floor')

@@ -146,7 +146,9 @@ class ConvOnet2(Model):
             stage=input['stage'], gt_depth=input['target_d'],
             dynamic_r_query=input['batch_dynamic_r'],
             depth_positive=bool(input.get('depth_positive', False) or
-                                input.get('static_shapes', False)))
+                                input.get('static_shapes', False)),
+            placed=(input['z_vals'], input['pts'], input.get('rq_pts'))
+            if 'pts' in input else None)
         out['stage'] = input['stage']
         return out
 
@@ -215,13 +217,20 @@ class ConvOnet2(Model):
         rays_o, rays_d = input['rays_o'], input['rays_d']
         S = cfg.rendering_n_surface
         d = input['target_d'].reshape(-1, 1).float()
-        t = torch.linspace(0.0, 1.0, steps=S, device=dev)
-        z_vals = cfg.rendering_near_end_surface * d * (1. - t) + \
-            cfg.rendering_far_end_surface * d * t
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-        rq = input['batch_dynamic_r']
-        if cfg.use_dynamic_radius:
-            rq = rq.reshape(-1, 1).repeat_interleave(S, dim=0)
+        if 'pts' in input:
+            # placed by the batch kernel (engine/point.batch)
+            z_vals, pts = input['z_vals'], input['pts']
+            rq = input['rq_pts'] if cfg.use_dynamic_radius \
+                else input['batch_dynamic_r']
+        else:
+            t = torch.linspace(0.0, 1.0, steps=S, device=dev)
+            z_vals = cfg.rendering_near_end_surface * d * (1. - t) + \
+                cfg.rendering_far_end_surface * d * t
+            pts = rays_o[..., None, :] + \
+                rays_d[..., None, :] * z_vals[..., :, None]
+            rq = input['batch_dynamic_r']
+            if cfg.use_dynamic_radius:
+                rq = rq.reshape(-1, 1).repeat_interleave(S, dim=0)
         raw, _, point_mask = self.eval_points(
             p=pts.reshape(-1, 3), stage=input['stage'], is_tracker=True,
             ray_pts_num=S, dynamic_r_query=rq)
@@ -275,7 +284,8 @@ class ConvOnet2(Model):
 
     def render_batch_ray(self, rays_d, rays_o, stage, gt_depth=None,
                          is_tracker=True, dynamic_r_query=None,
-                         exposure_feat=None, depth_positive=False):
+                         exposure_feat=None, depth_positive=False,
+                         placed=None):
         """:302-461.  ``depth_positive``: the caller guarantees gt_depth > 0 for
         every ray (the optimisation batches are depth-filtered), which spares
         the size read-back that decides the no-depth branch.  Masks are
@@ -283,6 +293,18 @@ class ConvOnet2(Model):
         values, no compaction, no host synchronisation)."""
         cfg, dev = self.config, self.device
         n_rays, S = rays_o.shape[0], cfg.rendering_n_surface
+        if placed is not None and depth_positive and gt_depth is not None \
+                and not cfg.model_use_view_direction:
+            # samples, points and per-point radii already placed by the
+            # batch kernel (engine/point.batch): same values as below
+            z_vals, pts, rq_pts = placed
+            raw, valid_ray_mask, point_mask = self.eval_points(
+                p=pts.reshape(-1, 3), stage=stage, is_tracker=is_tracker,
+                pts_views_d=None, ray_pts_num=S,
+                dynamic_r_query=rq_pts if cfg.use_dynamic_radius
+                else dynamic_r_query, exposure_feat=exposure_feat)
+            return self._composite(raw, z_vals, rays_d, point_mask,
+                                   valid_ray_mask.to(dev), n_rays, S)
         if gt_depth is not None:
             far = torch.minimum(5 * gt_depth.mean(),
                                 torch.max(gt_depth * 1.2)).repeat(
@@ -322,6 +344,15 @@ class ConvOnet2(Model):
             p=pts.reshape(-1, 3), stage=stage, is_tracker=is_tracker,
             pts_views_d=views, ray_pts_num=S, dynamic_r_query=dynamic_r_query,
             exposure_feat=exposure_feat)
+        out = self._composite(raw, z_vals, rays_d, point_mask,
+                              valid_ray_mask.to(dev) & near_pcl, n_rays, S)
+        if not cfg.rendering_sample_near_pcl and not depth_positive:
+            out['depth'] = out['depth'].masked_fill(~nonzero, 0.0)
+        return out
+
+    def _composite(self, raw, z_vals, rays_d, point_mask, valid_ray_mask,
+                   n_rays, S):
+        cfg, dev = self.config, self.device
         if raw.is_cuda and self.fused_composite and raw.shape[-1] == 4 and \
                 S <= 16:
             # compositing as one launch each way (engine/point.composite)
@@ -335,8 +366,5 @@ class ConvOnet2(Model):
             depth, uncertainty, color, _ = raw2outputs_nerf_color2(
                 raw, z_vals, rays_d, device=dev,
                 coef=cfg.rendering_sigmoid_coef_mapper)
-        valid_ray_mask = valid_ray_mask.to(dev) & near_pcl
-        if not cfg.rendering_sample_near_pcl and not depth_positive:
-            depth = depth.masked_fill(~nonzero, 0.0)
         return {'rgb': color, 'depth': depth, 'uncertainty': uncertainty,
                 'valid_ray_mask': valid_ray_mask}
