@@ -877,6 +877,20 @@ int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
                    const int32_t* cell_end, int k, float max_radius,
                    float* out_d2, int64_t* out_idx, xrd_stream_t stream);
 
+/* xrd_knn_search that also counts, per query, the neighbours strictly inside
+ * the query's own radius (radius_q [m], or radius_all when NULL):
+ * NeuralPointCloud.find_neighbors_faiss's (D < r^2).sum(-1)
+ * (slam/model_components/neural_point_cloud.py:268-274) without the four
+ * torch launches. */
+int xrd_knn_search_count(int64_t m, const float* queries,
+                         const float* sorted_points, const int32_t* sorted_ids,
+                         const float* origin, float cell, const int32_t* dims,
+                         const int32_t* cell_start, const int32_t* cell_end,
+                         int k, float max_radius, float* out_d2,
+                         int64_t* out_idx, const float* radius_q,
+                         float radius_all, int32_t* n_within,
+                         xrd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * One-launch replacements for the small-op chains around the render call of a
  * NICE-SLAM iteration (each is ~20-60 tiny torch kernels in the reference).

@@ -70,3 +70,23 @@ def test_knn_empty_index_and_far_queries():
     D, I = idx.search(torch.tensor([[5.0, 5.0, 5.0], [0.05, 0.0, 0.0]]))
     assert I[0].tolist() == [-1] * 8 and I[1, 0] == 0 and (I[1, 1:] == -1).all()
     assert abs(float(D[1, 0]) - 0.0025) < 1e-7
+
+
+def test_search_count_equals_the_torch_count():
+    """xrd_knn_search_count: the neighbours strictly inside the query's own
+    radius, counted in the search launch = (D < r^2).sum(-1) of
+    NeuralPointCloud.find_neighbors_faiss"""
+    import torch
+    from xrdslam_amd.engine.knn import GridKNN
+    g = torch.Generator().manual_seed(2)
+    pts = torch.rand(20000, 3, generator=g) * 2
+    q = torch.rand(5000, 3, generator=g) * 2
+    knn = GridKNN(0.16, 'cuda:0')
+    knn.add(pts.cuda())
+    D, I = knn.search(q.cuda(), 8)
+    r = (0.02 + 0.1 * torch.rand(5000, generator=g)).cuda()
+    D2, I2, c = knn.search_count(q.cuda(), 8, r)
+    assert torch.equal(D, D2) and torch.equal(I, I2)
+    assert torch.equal(c, (D < r.reshape(-1, 1)**2).sum(-1).int())
+    _, _, c2 = knn.search_count(q.cuda(), 8, 0.08)
+    assert torch.equal(c2, (D < 0.08**2).sum(-1).int())

@@ -179,6 +179,9 @@ _SIGS = {
     'xrd_knn_cell_ranges': (C.c_int, [i64, vp, vp, vp, vp]),
     'xrd_knn_search': (C.c_int, [i64, vp, vp, vp, vp, f32, vp, vp, vp,
                                  C.c_int, f32, vp, vp, vp]),
+    'xrd_knn_search_count': (C.c_int, [i64, vp, vp, vp, vp, f32, vp, vp, vp,
+                                       C.c_int, f32, vp, vp, vp, f32, vp,
+                                       vp]),
     'xrd_sample_rays': (C.c_int, [C.c_int] * 5 + [f32] * 4 + [vp] * 12),
     'xrd_sample_rays_bwd': (C.c_int, [C.c_int] * 5 + [f32] * 4 + [vp] * 5),
     'xrd_sample_rays_multi': (C.c_int,

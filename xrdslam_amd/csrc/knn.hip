@@ -96,7 +96,8 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     Grid g, int64_t m, const float* __restrict__ q, const float* __restrict__ pts,
     const int* __restrict__ ids, const int* __restrict__ start,
     const int* __restrict__ end, int reach, float r2max, float* __restrict__ D,
-    int64_t* __restrict__ I) {
+    int64_t* __restrict__ I, const float* __restrict__ radius_q,
+    float radius_all, int* __restrict__ n_within) {
   __shared__ unsigned long long list[KNN_WAVES][KNN_CAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
@@ -167,6 +168,20 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     D[i * K + lane] = none ? FLT_MAX : __uint_as_float((unsigned int)(v >> 32));
     I[i * K + lane] = none ? -1 : (int64_t)(unsigned int)(v & 0xffffffffu);
   }
+  if (n_within != nullptr && lane == 0) {
+    // neighbours strictly inside the query's own radius
+    // (neural_point_cloud.py:268-274: (D < r^2).sum(-1))
+    const float r = radius_q != nullptr ? radius_q[i] : radius_all;
+    const float r2 = r * r;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      c += (best[k] != KNN_NONE &&
+            __uint_as_float((unsigned int)(best[k] >> 32)) < r2)
+               ? 1
+               : 0;
+    n_within[i] = c;
+  }
 }
 
 int make_grid(const float* origin, float cell, const int32_t* dims, Grid& g) {
@@ -212,11 +227,15 @@ int xrd_knn_cell_ranges(int64_t n, const int64_t* sorted_cell_ids,
   return check_launch("xrd_knn_cell_ranges");
 }
 
-int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
-                   const int32_t* sorted_ids, const float* origin, float cell,
-                   const int32_t* dims, const int32_t* cell_start,
-                   const int32_t* cell_end, int k, float max_radius,
-                   float* out_d2, int64_t* out_idx, xrd_stream_t stream) {
+static int knn_search_impl(int64_t m, const float* queries,
+                           const float* sorted_points,
+                           const int32_t* sorted_ids, const float* origin,
+                           float cell, const int32_t* dims,
+                           const int32_t* cell_start, const int32_t* cell_end,
+                           int k, float max_radius, float* out_d2,
+                           int64_t* out_idx, const float* radius_q,
+                           float radius_all, int32_t* n_within,
+                           xrd_stream_t stream) {
   Grid g;
   int rc = make_grid(origin, cell, dims, g);
   if (rc) return rc;
@@ -231,8 +250,33 @@ int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
                      dim3((unsigned)((m + KNN_WAVES - 1) / KNN_WAVES)),
                      dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, g, m, queries,
                      sorted_points, sorted_ids, cell_start, cell_end, reach,
-                     max_radius * max_radius, out_d2, out_idx);
+                     max_radius * max_radius, out_d2, out_idx, radius_q,
+                     radius_all, n_within);
   return check_launch("xrd_knn_search");
+}
+
+int xrd_knn_search(int64_t m, const float* queries, const float* sorted_points,
+                   const int32_t* sorted_ids, const float* origin, float cell,
+                   const int32_t* dims, const int32_t* cell_start,
+                   const int32_t* cell_end, int k, float max_radius,
+                   float* out_d2, int64_t* out_idx, xrd_stream_t stream) {
+  return knn_search_impl(m, queries, sorted_points, sorted_ids, origin, cell,
+                         dims, cell_start, cell_end, k, max_radius, out_d2,
+                         out_idx, nullptr, 0.f, nullptr, stream);
+}
+
+int xrd_knn_search_count(int64_t m, const float* queries,
+                         const float* sorted_points, const int32_t* sorted_ids,
+                         const float* origin, float cell, const int32_t* dims,
+                         const int32_t* cell_start, const int32_t* cell_end,
+                         int k, float max_radius, float* out_d2,
+                         int64_t* out_idx, const float* radius_q,
+                         float radius_all, int32_t* n_within,
+                         xrd_stream_t stream) {
+  if (m > 0 && !n_within) return XRD_ERR_ARG;
+  return knn_search_impl(m, queries, sorted_points, sorted_ids, origin, cell,
+                         dims, cell_start, cell_end, k, max_radius, out_d2,
+                         out_idx, radius_q, radius_all, n_within, stream);
 }
 
 }  // extern "C"

@@ -64,28 +64,51 @@ class GridKNN:
     def search(self, queries: torch.Tensor, k: int = 8):
         """-> (squared distances [m,k] f32 ascending, ids [m,k] i64; FLT_MAX/-1
         where fewer than k points lie within max_radius)"""
+        return self.search_count(queries, k, None)[:2]
+
+    def search_count(self, queries: torch.Tensor, k: int = 8, radius=None):
+        """search + (radius: float or per-query tensor [m]) the number of
+        neighbours strictly inside the radius, int32 [m] (None without a
+        radius) — one launch"""
         lib = _lib.lib()
         q = queries.detach().to(self.device, torch.float32).reshape(
             -1, 3).contiguous()
         m = q.shape[0]
-        D = torch.full((m, k), torch.finfo(torch.float32).max,
-                       device=self.device)
-        I = torch.full((m, k), -1, dtype=torch.int64, device=self.device)
         if self.ntotal == 0 or m == 0:
-            return D, I
+            D = torch.full((m, k), torch.finfo(torch.float32).max,
+                           device=self.device)
+            I = torch.full((m, k), -1, dtype=torch.int64, device=self.device)
+            cnt = None if radius is None else torch.zeros(
+                m, dtype=torch.int32, device=self.device)
+            return D, I, cnt
+        # the kernel writes every entry (FLT_MAX / -1 where there is none)
+        D = torch.empty(m, k, dtype=torch.float32, device=self.device)
+        I = torch.empty(m, k, dtype=torch.int64, device=self.device)
+        cnt = rq = None
+        r_all = 0.0
+        if radius is not None:
+            cnt = torch.empty(m, dtype=torch.int32, device=self.device)
+            if torch.is_tensor(radius):
+                rq = radius.detach().to(self.device, torch.float32).reshape(
+                    -1).contiguous()
+                assert rq.numel() == m
+            else:
+                r_all = float(radius)
         if self._dirty:
             self._build()
         if PROFILE is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(lib.xrd_knn_search(
+        _lib.check(lib.xrd_knn_search_count(
             m, _lib.ptr(q), _lib.ptr(self._sorted_pts),
             _lib.ptr(self._sorted_ids), self._origin.ctypes.data,
             self.max_radius, self._dims.ctypes.data, _lib.ptr(self._start),
             _lib.ptr(self._end), k, self.max_radius, _lib.ptr(D), _lib.ptr(I),
-            _lib.stream_ptr(self.device)), 'xrd_knn_search')
+            _lib.ptr(rq), r_all, _lib.ptr(cnt) if cnt is not None else
+            _lib.ptr(torch.empty(m, dtype=torch.int32, device=self.device)),
+            _lib.stream_ptr(self.device)), 'xrd_knn_search_count')
         if PROFILE is not None:
             e1.record()
             PROFILE.append((e0, e1, m, self.ntotal))
-        return D, I
+        return D, I, cnt

@@ -185,7 +185,7 @@ class MLP_geometry(_PointMLP):
                 flat = p.reshape(-1, 3)
                 if neighbors is None:
                     neighbors = npc.find_neighbors_faiss(
-                        flat.detach().clone(), step='query',
+                        flat.detach(), step='query',
                         dynamic_radius=dynamic_r_query)
                 occ, has = _pt.geometry(self, flat, neighbors, npc,
                                         dynamic_r_query)
@@ -258,7 +258,7 @@ class MLP_color(_PointMLP):
                 flat = p.reshape(-1, 3)
                 if neighbors is None:
                     neighbors = npc.find_neighbors_faiss(
-                        flat.detach().clone(), step='query',
+                        flat.detach(), step='query',
                         dynamic_radius=dynamic_r_query)
                 return _pt.color(self, flat, neighbors, npc, dynamic_r_query)
         c, _ = self._interpolate(
@@ -306,7 +306,7 @@ class POINT(nn.Module):
         nb = None
         if stage != 'geometry':
             nb = npc.find_neighbors_faiss(
-                p.reshape(-1, 3).detach().clone(), step='query',
+                p.reshape(-1, 3).detach(), step='query',
                 dynamic_radius=dynamic_r_query)
         occ, ray_mask, point_mask = self.geo_decoder(
             p, npc, pts_num=pts_num, is_tracker=is_tracker,

@@ -162,13 +162,24 @@ class NeuralPointCloud(nn.Module):
         """-> (squared distances [n,8] ascending, ids [n,8] (-1 = none),
         number of neighbours inside the radius [n]) (:223-282)"""
         assert step in ('add', 'query')
-        with self.lock:
-            D, ids = self.index.search(pos.float().detach(), self.nn_num)
-        D, ids = D.to(self.device), ids.to(self.device)
         if step == 'query':
             radius = self.radius_query
         else:
             radius = self.radius_min if is_pts_grad else self.radius_add
+        counted = getattr(self.index, 'search_count', None)
+        if counted is not None and pos.is_cuda:
+            # the HIP grid kNN counts the neighbours inside the (per-query)
+            # radius in the search launch
+            if dynamic_radius is not None:
+                assert pos.shape[0] == dynamic_radius.shape[0]
+            with self.lock:
+                D, ids, n_nb = counted(
+                    pos.float().detach(), self.nn_num,
+                    dynamic_radius if dynamic_radius is not None else radius)
+            return D, ids, n_nb
+        with self.lock:
+            D, ids = self.index.search(pos.float().detach(), self.nn_num)
+        D, ids = D.to(self.device), ids.to(self.device)
         if dynamic_radius is not None:
             dynamic_radius = dynamic_radius.to(self.device)
             assert pos.shape[0] == dynamic_radius.shape[0]

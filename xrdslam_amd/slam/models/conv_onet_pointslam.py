@@ -279,6 +279,8 @@ class ConvOnet2(Model):
             rets.append(ret)
             ray_masks.append(ray_mask)
             point_masks.append(point_mask)
+        if len(rets) == 1:      # one chunk: nothing to concatenate
+            return rets[0], ray_masks[0], point_masks[0]
         return torch.cat(rets, 0), torch.cat(ray_masks, 0), \
             torch.cat(point_masks, 0)
 
