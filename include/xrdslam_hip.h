@@ -220,6 +220,19 @@ int xrd_point_batch(int n_rays, int n_samples, const float* rays_o,
                     float far_coef, uint8_t* keep, float* radius,
                     float* z_vals, float* pts, float* radius_pts, float* stats,
                     xrd_stream_t stream);
+/* Point-SLAM tracking loss, one launch (single block): the tracking branch of
+ * ConvOnet2.get_loss_dict (slam/models/conv_onet_pointslam.py:144-189) on a
+ * batch that kept its shape (ray_valid [n] = the batch filter, or NULL):
+ * uncertainty-normalised depth error with the batch-median outlier rejection
+ * (LOWER median, NaN-propagating like torch.median) and the masked L1 colour
+ * term.  -> loss [2] = (geo, w_color * rgb), g_depth [n], g_color [n,3] =
+ * gradients of loss[0] + loss[1] (the variance is detached). */
+int xrd_point_track_loss(int n_rays, int handle_dynamic, int use_color,
+                         float w_color, const float* depth, const float* var,
+                         const float* color, const float* target_d,
+                         const float* target_rgb, const uint8_t* ray_valid,
+                         float* loss, float* g_depth, float* g_color,
+                         xrd_stream_t stream);
 /* Point-SLAM compositing alone (raw2outputs_nerf_color2, utils.py:247-294, with
  * the no-neighbour override of render_batch_ray, conv_onet_pointslam.py:441):
  *   rgb [n_rays*S rows, stride rgb_stride >= 3] or NULL, occ [n_rays*S rows,

@@ -557,3 +557,55 @@ def test_batch_kernel_equals_torch_formulation(n_per, F, S, empty):
                        rq.reshape(-1, 1).repeat_interleave(S, dim=0))
     assert torch.allclose(ro.grad, ref_g[0], rtol=1e-5, atol=1e-6)
     assert torch.allclose(rd.grad, ref_g[1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('handle_dynamic,with_valid,poison',
+                         [(True, True, False), (True, False, False),
+                          (False, True, False), (True, True, True)])
+def test_track_loss_kernel_equals_torch_formulation(handle_dynamic,
+                                                    with_valid, poison):
+    """xrd_point_track_loss against ConvOnet2.get_loss_dict's torch ops
+    (tracking branch): both loss terms and the gradients w.r.t. depth and
+    colour, incl. NaN renders and the NaN-propagating median"""
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.conv_onet_pointslam import (ConvOnet2,
+                                                             ConvOnet2Config)
+    g = torch.Generator().manual_seed(21)
+    n, dev = 1500, 'cuda:0'
+    td = (0.5 + 3 * torch.rand(n, generator=g))
+    td[::11] = 0.0
+    depth = td + 0.05 * torch.randn(n, generator=g)
+    depth[5] += 3.0                      # rejected by the median test
+    depth[17] = float('nan')
+    var = 1e-4 + 1e-3 * torch.rand(n, generator=g)
+    var[23] = float('nan')
+    color = torch.rand(n, 3, generator=g)
+    tc = torch.rand(n, 3, generator=g)
+    rv = torch.rand(n, generator=g) < 0.9
+    rv[17] = rv[23] = poison            # NaN rows inside the batch or not
+    cfg = ConvOnet2Config()
+    cfg.tracking_handle_dynamic = handle_dynamic
+    model = ConvOnet2(cfg, Camera(50., 50., 32., 24., 64, 48)).to(dev)
+    res = {}
+    for fused in (False, True):
+        model.fused_track_loss = fused
+        d = depth.clone().to(dev).requires_grad_(True)
+        c = color.clone().to(dev).requires_grad_(True)
+        inp = {'target_d': td.to(dev), 'target_s': tc.to(dev)}
+        if with_valid:
+            inp['ray_valid'] = rv.to(dev)
+        ld = model.get_loss_dict(
+            {'depth': d, 'rgb': c, 'uncertainty': var.to(dev)}, inp, False)
+        (ld['geo_loss'] + ld['rgb_loss']).backward()
+        res[fused] = (float(ld['geo_loss']), float(ld['rgb_loss']),
+                      torch.nan_to_num(d.grad).cpu(),
+                      torch.nan_to_num(c.grad).cpu())
+    a, b = res[True], res[False]
+    if poison or not with_valid:
+        # a NaN inside the batch poisons the median: nothing is kept
+        assert a[0] == b[0] == 0.0 and a[1] == b[1] == 0.0
+    else:
+        assert b[0] > 0 and abs(a[0] - b[0]) < 1e-5 * b[0]
+        assert abs(a[1] - b[1]) < 1e-5 * b[1]
+    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(a[3], b[3], rtol=1e-6, atol=1e-8)

@@ -62,6 +62,7 @@ _SIGS = {
                             [vp] * 7),
     'xrd_point_color_bwd': (C.c_int, [i64] + [vp] * 6 + [f32, C.c_int] +
                             [vp] * 12),
+    'xrd_point_track_loss': (C.c_int, [C.c_int] * 3 + [f32] + [vp] * 10),
     'xrd_point_batch': (C.c_int, [C.c_int, C.c_int] + [vp] * 5 +
                         [C.c_int] * 5 + [i64, f32, f32] + [vp] * 7),
     'xrd_point_map_loss': (C.c_int, [C.c_int, C.c_int] + [vp] * 6 +

@@ -290,6 +290,143 @@ extern "C" int xrd_point_batch(
   return xrd::check_launch("xrd_point_batch");
 }
 
+// ---- tracking loss ------------------------------------------------------------------
+// ConvOnet2.get_loss_dict, tracking branch (slam/models/conv_onet_pointslam.py:
+// 144-189) on a batch that kept its shape (the batch filter arrives as
+// ray_valid): tmp = |d - depth| / sqrt(var + 1e-10) (handle_dynamic; else
+// |d - depth|), med = LOWER median of tmp over the rays of the batch (NaN if
+// one of them is NaN), mask = tmp < 10 med & d > 0 & depth, var not NaN &
+// ray_valid;  geo = sum_mask clamp(|d - depth| / sqrt(var + 1e-10), 0, 1e3),
+// rgb = w_color sum_mask |rgb - colour|_1.  One block: radix-select median,
+// sums, and the gradients w.r.t. depth and colour (var is detached).
+namespace xrd {
+namespace {
+
+__global__ __launch_bounds__(BATCH_THREADS) void point_track_loss_kernel(
+    int n, int handle_dynamic, int use_color, float w_color,
+    const float* __restrict__ depth, const float* __restrict__ var,
+    const float* __restrict__ color, const float* __restrict__ tgt_d,
+    const float* __restrict__ tgt_rgb, const uint8_t* __restrict__ ray_valid,
+    float* __restrict__ loss, float* __restrict__ g_depth,
+    float* __restrict__ g_color) {
+#pragma clang fp contract(off)
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix, s_k, s_cnt, s_nan;
+  __shared__ double s_sum[2];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_cnt = 0;
+    s_nan = 0;
+    s_sum[0] = s_sum[1] = 0.0;
+  }
+  __syncthreads();
+  auto tmp_of = [&](int i) {
+    const float e = fabsf(tgt_d[i] - depth[i]);
+    return handle_dynamic ? e / sqrtf(var[i] + 1e-10f) : e;
+  };
+  unsigned cnt = 0, any_nan = 0;
+  for (int i = tid; i < n; i += BATCH_THREADS) {
+    if (ray_valid != nullptr && !ray_valid[i]) continue;
+    ++cnt;
+    const float t = tmp_of(i);
+    if (t != t) any_nan = 1;
+  }
+  if (cnt) atomicAdd(&s_cnt, cnt);
+  if (any_nan) atomicOr(&s_nan, 1u);
+  __syncthreads();
+  const unsigned total = s_cnt;
+  const bool poisoned = s_nan != 0 || total == 0;
+  if (tid == 0) {
+    s_prefix = 0;
+    s_k = total > 0 ? (total - 1) / 2 : 0;
+  }
+  for (int shift = 24; shift >= 0 && !poisoned; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < n; i += BATCH_THREADS) {
+      if (ray_valid != nullptr && !ray_valid[i]) continue;
+      // tmp >= 0 (or +inf): its bits order like the values; -0 -> +0
+      const unsigned b = __float_as_uint(tmp_of(i)) & 0x7fffffffu;
+      if ((b & himask) == prefix) atomicAdd(&hist[(b >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned k = s_k, acc = 0;
+      int bin = 255;
+      for (int h = 0; h < 256; ++h) {
+        if (acc + (unsigned)hist[h] > k) {
+          bin = h;
+          break;
+        }
+        acc += (unsigned)hist[h];
+      }
+      s_k = k - acc;
+      s_prefix = prefix | ((unsigned)bin << shift);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const float med = poisoned ? NAN : __uint_as_float(s_prefix);
+  const float lim = 10.f * med;
+  double geo = 0.0, rgb = 0.0;
+  for (int i = tid; i < n; i += BATCH_THREADS) {
+    const float d = tgt_d[i], dep = depth[i], v = var[i];
+    const float t = tmp_of(i);
+    const bool m = t < lim && d > 0.f && dep == dep && v == v &&
+                   (ray_valid == nullptr || ray_valid[i] != 0);
+    float gd = 0.f;
+    if (m) {
+      const float s = sqrtf(v + 1e-10f);
+      const float q = fabsf(d - dep) / s;
+      geo += (double)fminf(fmaxf(q, 0.f), 1e3f);
+      // clamp passes the gradient inside [0, 1e3]; |x|' = sign(x)
+      if (q >= 0.f && q <= 1e3f && d != dep)
+        gd = (d - dep > 0.f ? -1.f : 1.f) / s;
+    }
+    g_depth[i] = gd;
+    if (use_color) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float e = tgt_rgb[i * 3 + c] - color[i * 3 + c];
+        if (m) rgb += (double)fabsf(e);
+        g_color[i * 3 + c] =
+            m ? (e > 0.f ? -w_color : (e < 0.f ? w_color : 0.f)) : 0.f;
+      }
+    }
+  }
+  geo = wave_sum(geo);
+  rgb = wave_sum(rgb);
+  if ((tid & 63) == 0) {
+    atomicAdd(&s_sum[0], geo);
+    atomicAdd(&s_sum[1], rgb);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    loss[0] = (float)s_sum[0];
+    loss[1] = use_color ? w_color * (float)s_sum[1] : 0.f;
+  }
+}
+
+}  // namespace
+}  // namespace xrd
+
+extern "C" int xrd_point_track_loss(
+    int n_rays, int handle_dynamic, int use_color, float w_color,
+    const float* depth, const float* var, const float* color,
+    const float* target_d, const float* target_rgb, const uint8_t* ray_valid,
+    float* loss, float* g_depth, float* g_color, xrd_stream_t stream) {
+  if (n_rays < 1) return XRD_ERR_ARG;
+  if (!depth || !var || !target_d || !loss || !g_depth) return XRD_ERR_ARG;
+  if (use_color && (!color || !target_rgb || !g_color)) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(xrd::point_track_loss_kernel, dim3(1),
+                     dim3(xrd::BATCH_THREADS), 0, (hipStream_t)stream, n_rays,
+                     handle_dynamic, use_color, w_color, depth, var, color,
+                     target_d, target_rgb, ray_valid, loss, g_depth, g_color);
+  return xrd::check_launch("xrd_point_track_loss");
+}
+
 // ---- compositing alone (tracking, render_img, and the generic backward) ------------
 // raw2outputs_nerf_color2 (slam/model_components/utils.py:247-294) with the
 // no-neighbour override of render_batch_ray (conv_onet_pointslam.py:441):

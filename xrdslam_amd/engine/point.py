@@ -361,6 +361,53 @@ class _MapLossFn(torch.autograd.Function):
         return (g_raw * g, ) + (None, ) * 8
 
 
+class _TrackLossFn(torch.autograd.Function):
+    """(depth [n], var [n], colour [n,3]) -> (geo, rgb) of ConvOnet2's
+    tracking loss on a shape-preserving batch (xrd_point_track_loss)"""
+
+    @staticmethod
+    def forward(ctx, depth, var, color, target_d, target_rgb, ray_valid,
+                handle_dynamic, use_color, w_color):
+        lib = _lib.lib()
+        dev = depth.device
+        n = depth.shape[0]
+        d = depth.detach().float().contiguous()
+        v = var.detach().float().contiguous()
+        c = color.detach().float().contiguous() if use_color else None
+        td = target_d.detach().float().reshape(-1).contiguous()
+        tc = target_rgb.detach().float().contiguous() if use_color else None
+        rv = None if ray_valid is None else \
+            ray_valid.reshape(-1).to(torch.uint8).contiguous()
+        f = dict(dtype=torch.float32, device=dev)
+        loss = torch.empty(2, **f)
+        g_d = torch.empty(n, **f)
+        g_c = torch.empty(n, 3, **f) if use_color else None
+        _lib.check(lib.xrd_point_track_loss(
+            n, int(bool(handle_dynamic)), int(bool(use_color)),
+            float(w_color), _lib.ptr(d), _lib.ptr(v), _lib.ptr(c),
+            _lib.ptr(td), _lib.ptr(tc), _lib.ptr(rv), _lib.ptr(loss),
+            _lib.ptr(g_d), _lib.ptr(g_c), _lib.stream_ptr(dev)),
+            'xrd_point_track_loss')
+        ctx.save_for_backward(g_d, g_c)
+        ctx.use_color = bool(use_color)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g_geo, g_rgb):
+        g_d, g_c = ctx.saved_tensors
+        # the kernel's gradients are those of geo + rgb; both upstream
+        # factors are the same scalar in the optimisation loop (a plain sum)
+        gd = g_d * g_geo
+        gc = g_c * g_rgb if ctx.use_color and g_c is not None else None
+        return gd, None, gc, None, None, None, None, None, None
+
+
+def track_loss(depth, var, color, target_d, target_rgb, ray_valid,
+               handle_dynamic, use_color, w_color):
+    return _TrackLossFn.apply(depth, var, color, target_d, target_rgb,
+                              ray_valid, handle_dynamic, use_color, w_color)
+
+
 class _BatchFn(torch.autograd.Function):
     """batch filter + sample placement of a Point-SLAM iteration
     (xrd_point_batch): (rays_o, rays_d) -> (keep, radius, z_vals, pts,

@@ -163,6 +163,20 @@ class ConvOnet2(Model):
         # captured iterations keep the deselected rays in the batch: the
         # selection arrives as a mask (point_slam.get_model_input)
         ray_valid = inputs.get('ray_valid')
+        if not is_mapping and depth.is_cuda and self.fused_track_loss and \
+                depth.dtype == torch.float32:
+            # median-rejected depth term + masked colour term and their
+            # gradients as ONE launch (engine/point.track_loss) instead of
+            # ~35 torch launches each way
+            from ...engine import point as _pt
+            geo, rgb = _pt.track_loss(
+                depth, uncertainty, color, target_d, target_rgb, ray_valid,
+                cfg.tracking_handle_dynamic,
+                cfg.tracking_use_color_in_tracking, cfg.tracking_w_color_loss)
+            losses['geo_loss'] = geo
+            if cfg.tracking_use_color_in_tracking:
+                losses['rgb_loss'] = rgb
+            return losses
         if not is_mapping:
             uncertainty = uncertainty.detach()
             nan_mask = (~torch.isnan(depth)) & (~torch.isnan(uncertainty))
@@ -204,6 +218,7 @@ class ConvOnet2(Model):
         return losses
 
     fused_composite = True   # compositing on xrd_point_composite_* (CUDA)
+    fused_track_loss = True  # tracking loss on xrd_point_track_loss (CUDA)
 
     def fused_map_loss(self, input) -> torch.Tensor:
         """get_outputs + get_loss_dict of a MAPPING iteration whose rays all
