@@ -151,6 +151,55 @@ namespace xrd {
 namespace {
 
 constexpr int BATCH_THREADS = 1024;
+constexpr int BATCH_RAYS = 256;   // rays placed by one block of the batch kernel
+constexpr int SEL_REGS = 16;      // values a thread caches for the select
+
+// k-th smallest (k = s_k) of the non-negative floats whose bit patterns the
+// threads hold in key[0..cnt) (each thread its own), 8 bits a pass over an LDS
+// histogram; every thread of the block returns the bits of the result.
+// `hist` [256] and the two words are LDS scratch; s_k holds k on entry.
+__device__ __forceinline__ unsigned radix_select_block(
+    const unsigned (&key)[SEL_REGS], int cnt, int* hist, unsigned* s_prefix,
+    unsigned* s_k) {
+  const int tid = threadIdx.x;
+  if (tid == 0) *s_prefix = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = *s_prefix;
+    const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+    for (int r = 0; r < SEL_REGS; ++r)
+      if (r < cnt && (key[r] & himask) == prefix)
+        atomicAdd(&hist[(key[r] >> shift) & 255], 1);
+    __syncthreads();
+    if (tid < 64) {
+      // wave 0: lane l owns bins 4l..4l+3; exclusive prefix over the lanes
+      const int h0 = hist[tid * 4], h1 = hist[tid * 4 + 1],
+                h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (tid >= d) incl += o;
+      }
+      const unsigned k = *s_k;
+      const unsigned excl = (unsigned)(incl - mine);
+      if (excl <= k && k < (unsigned)incl) {   // exactly one lane
+        unsigned acc = excl;
+        int bin = tid * 4;
+        if (acc + (unsigned)h0 <= k) { acc += h0; ++bin;
+          if (acc + (unsigned)h1 <= k) { acc += h1; ++bin;
+            if (acc + (unsigned)h2 <= k) { acc += h2; ++bin; } } }
+        *s_k = k - acc;
+        *s_prefix = prefix | ((unsigned)bin << shift);
+      }
+    }
+    __syncthreads();
+  }
+  return *s_prefix;
+}
 
 __global__ __launch_bounds__(BATCH_THREADS) void point_batch_kernel(
     int n, int S, const float* __restrict__ ro, const float* __restrict__ rd,
@@ -172,95 +221,76 @@ __global__ __launch_bounds__(BATCH_THREADS) void point_batch_kernel(
     s_top = 0;
   }
   __syncthreads();
-  unsigned cnt = 0, top = 0;
+  // every block selects the median of the whole batch (n <= 16 K values, a
+  // few KB from L2) and then places its own 256 rays
+  unsigned key[SEL_REGS];
+  int cnt = 0;
+  unsigned top = 0;
   for (int i = tid; i < n; i += BATCH_THREADS) {
     const float v = d[i];
     if (v > 0.f) {
+      const unsigned b = __float_as_uint(v);   // positive floats order as bits
+      top = max(top, b);
+#pragma unroll
+      for (int r = 0; r < SEL_REGS; ++r)
+        if (r == cnt) key[r] = b;
       ++cnt;
-      top = max(top, __float_as_uint(v));   // positive floats order as bits
     }
   }
   if (cnt != 0) {
-    atomicAdd(&s_cnt, cnt);
+    atomicAdd(&s_cnt, (unsigned)cnt);
     atomicMax(&s_top, top);
   }
   __syncthreads();
   const unsigned total = s_cnt;
-  if (tid == 0) {
-    s_prefix = 0;
-    s_k = total > 0 ? (total - 1) / 2 : 0;
-  }
-  // radix select of the k-th smallest valid depth, 8 bits a pass
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    const unsigned prefix = s_prefix;
-    const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-    for (int i = tid; i < n; i += BATCH_THREADS) {
-      const float v = d[i];
-      const unsigned b = __float_as_uint(v);
-      if (v > 0.f && (b & himask) == prefix)
-        atomicAdd(&hist[(b >> shift) & 255], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned k = s_k, acc = 0;
-      int bin = 255;
-      for (int h = 0; h < 256; ++h) {
-        if (acc + (unsigned)hist[h] > k) {
-          bin = h;
-          break;
-        }
-        acc += (unsigned)hist[h];
-      }
-      s_k = k - acc;
-      s_prefix = prefix | ((unsigned)bin << shift);
-    }
-    __syncthreads();
-  }
-  const float med = total > 0 ? __uint_as_float(s_prefix) : NAN;
+  if (tid == 0) s_k = total > 0 ? (total - 1) / 2 : 0;
+  __syncthreads();
+  const unsigned mbits = radix_select_block(key, cnt, hist, &s_prefix, &s_k);
+  const float med = total > 0 ? __uint_as_float(mbits) : NAN;
   const float topf = total > 0 ? __uint_as_float(s_top) : -INFINITY;
   // torch.minimum propagates NaN; every comparison with it is false
   const float lim = fminf(10.f * med, 1.2f * topf);
-  if (tid == 0 && stats != nullptr) {
+  if (blockIdx.x == 0 && tid == 0 && stats != nullptr) {
     stats[0] = med;
     stats[1] = topf;
   }
   const float step = S > 1 ? 1.f / (float)(S - 1) : 0.f;
-  for (int i = tid; i < n; i += BATCH_THREADS) {
-    const float v = d[i];
+  const int i = blockIdx.x * BATCH_RAYS + (tid >> 2);
+  if (i >= n) return;
+  const float v = d[i];
+  float r = 0.f;
+  if (radius_stack != nullptr) {
+    const int64_t e = idx[i];
+    const int64_t row = hedge + e / wcrop, col = wedge + e % wcrop;
+    r = radius_stack[(int64_t)(i / n_per) * hw + row * width + col];
+  }
+  if ((tid & 3) == 0) {
     keep[i] = (total > 0 && v > 0.f && v <= lim) ? 1 : 0;
-    float r = 0.f;
-    if (radius_stack != nullptr) {
-      const int64_t e = idx[i];
-      const int64_t row = hedge + e / wcrop, col = wedge + e % wcrop;
-      r = radius_stack[(int64_t)(i / n_per) * hw + row * width + col];
-      radius[i] = r;
+    if (radius_stack != nullptr) radius[i] = r;
+  }
+  const float a = near_c * v, b = far_c * v;
+  const float o0 = ro[i * 3], o1 = ro[i * 3 + 1], o2 = ro[i * 3 + 2];
+  const float d0 = rd[i * 3], d1 = rd[i * 3 + 1], d2 = rd[i * 3 + 2];
+  for (int s = tid & 3; s < S; s += 4) {
+    // torch.linspace: from the start in the first half, from the end in
+    // the second
+    float t;
+    if (s < S / 2) {
+      t = step * (float)s;
+    } else {
+      const float back = step * (float)(S - 1 - s);
+      t = 1.f - back;
     }
-    const float a = near_c * v, b = far_c * v;
-    const float o0 = ro[i * 3], o1 = ro[i * 3 + 1], o2 = ro[i * 3 + 2];
-    const float d0 = rd[i * 3], d1 = rd[i * 3 + 1], d2 = rd[i * 3 + 2];
-    for (int s = 0; s < S; ++s) {
-      // torch.linspace: from the start in the first half, from the end in
-      // the second
-      float t;
-      if (s < S / 2) {
-        t = step * (float)s;
-      } else {
-        const float back = step * (float)(S - 1 - s);
-        t = 1.f - back;
-      }
-      const float u = 1.f - t;
-      const float za = a * u, zb = b * t;
-      const float z = za + zb;
-      const int64_t m = (int64_t)i * S + s;
-      z_vals[m] = z;
-      const float p0 = d0 * z, p1 = d1 * z, p2 = d2 * z;
-      pts[m * 3] = o0 + p0;
-      pts[m * 3 + 1] = o1 + p1;
-      pts[m * 3 + 2] = o2 + p2;
-      if (radius_stack != nullptr) radius_pts[m] = r;
-    }
+    const float u = 1.f - t;
+    const float za = a * u, zb = b * t;
+    const float z = za + zb;
+    const int64_t m = (int64_t)i * S + s;
+    z_vals[m] = z;
+    const float p0 = d0 * z, p1 = d1 * z, p2 = d2 * z;
+    pts[m * 3] = o0 + p0;
+    pts[m * 3 + 1] = o1 + p1;
+    pts[m * 3 + 2] = o2 + p2;
+    if (radius_stack != nullptr) radius_pts[m] = r;
   }
 }
 
@@ -275,13 +305,15 @@ extern "C" int xrd_point_batch(
     float* radius, float* z_vals, float* pts, float* radius_pts, float* stats,
     xrd_stream_t stream) {
   if (n_rays < 1 || n_samples < 1 || n_samples > 64) return XRD_ERR_ARG;
+  if (n_rays > xrd::BATCH_THREADS * xrd::SEL_REGS) return XRD_ERR_UNSUPPORTED;
   if (!rays_o || !rays_d || !target_d || !keep || !z_vals || !pts)
     return XRD_ERR_ARG;
   if (radius_stack != nullptr &&
       (!pixel_idx || !radius || !radius_pts || rays_per_frame < 1 ||
        crop_width < 1 || image_width < 1 || image_pixels < 1))
     return XRD_ERR_ARG;
-  hipLaunchKernelGGL(xrd::point_batch_kernel, dim3(1),
+  hipLaunchKernelGGL(xrd::point_batch_kernel,
+                     dim3((n_rays + xrd::BATCH_RAYS - 1) / xrd::BATCH_RAYS),
                      dim3(xrd::BATCH_THREADS), 0, (hipStream_t)stream, n_rays,
                      n_samples, rays_o, rays_d, target_d, radius_stack,
                      pixel_idx, rays_per_frame, crop_width, hedge, wedge,
@@ -324,51 +356,31 @@ __global__ __launch_bounds__(BATCH_THREADS) void point_track_loss_kernel(
     const float e = fabsf(tgt_d[i] - depth[i]);
     return handle_dynamic ? e / sqrtf(var[i] + 1e-10f) : e;
   };
-  unsigned cnt = 0, any_nan = 0;
+  unsigned key[SEL_REGS];
+  int cnt = 0;
+  unsigned any_nan = 0;
   for (int i = tid; i < n; i += BATCH_THREADS) {
     if (ray_valid != nullptr && !ray_valid[i]) continue;
-    ++cnt;
     const float t = tmp_of(i);
     if (t != t) any_nan = 1;
+    // tmp >= 0 (or +inf): its bits order like the values; -0 -> +0
+    const unsigned b = __float_as_uint(t) & 0x7fffffffu;
+#pragma unroll
+    for (int r = 0; r < SEL_REGS; ++r)
+      if (r == cnt) key[r] = b;
+    ++cnt;
   }
-  if (cnt) atomicAdd(&s_cnt, cnt);
+  if (cnt) atomicAdd(&s_cnt, (unsigned)cnt);
   if (any_nan) atomicOr(&s_nan, 1u);
   __syncthreads();
   const unsigned total = s_cnt;
   const bool poisoned = s_nan != 0 || total == 0;
-  if (tid == 0) {
-    s_prefix = 0;
-    s_k = total > 0 ? (total - 1) / 2 : 0;
-  }
-  for (int shift = 24; shift >= 0 && !poisoned; shift -= 8) {
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    const unsigned prefix = s_prefix;
-    const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-    for (int i = tid; i < n; i += BATCH_THREADS) {
-      if (ray_valid != nullptr && !ray_valid[i]) continue;
-      // tmp >= 0 (or +inf): its bits order like the values; -0 -> +0
-      const unsigned b = __float_as_uint(tmp_of(i)) & 0x7fffffffu;
-      if ((b & himask) == prefix) atomicAdd(&hist[(b >> shift) & 255], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned k = s_k, acc = 0;
-      int bin = 255;
-      for (int h = 0; h < 256; ++h) {
-        if (acc + (unsigned)hist[h] > k) {
-          bin = h;
-          break;
-        }
-        acc += (unsigned)hist[h];
-      }
-      s_k = k - acc;
-      s_prefix = prefix | ((unsigned)bin << shift);
-    }
-    __syncthreads();
-  }
+  if (tid == 0) s_k = total > 0 ? (total - 1) / 2 : 0;
   __syncthreads();
-  const float med = poisoned ? NAN : __uint_as_float(s_prefix);
+  unsigned mbits = 0;
+  if (!poisoned)   // block-uniform
+    mbits = radix_select_block(key, cnt, hist, &s_prefix, &s_k);
+  const float med = poisoned ? NAN : __uint_as_float(mbits);
   const float lim = 10.f * med;
   double geo = 0.0, rgb = 0.0;
   for (int i = tid; i < n; i += BATCH_THREADS) {
@@ -418,6 +430,7 @@ extern "C" int xrd_point_track_loss(
     const float* target_d, const float* target_rgb, const uint8_t* ray_valid,
     float* loss, float* g_depth, float* g_color, xrd_stream_t stream) {
   if (n_rays < 1) return XRD_ERR_ARG;
+  if (n_rays > xrd::BATCH_THREADS * xrd::SEL_REGS) return XRD_ERR_UNSUPPORTED;
   if (!depth || !var || !target_d || !loss || !g_depth) return XRD_ERR_ARG;
   if (use_color && (!color || !target_rgb || !g_color)) return XRD_ERR_ARG;
   hipLaunchKernelGGL(xrd::point_track_loss_kernel, dim3(1),
