@@ -387,15 +387,45 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(
     coef[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
   }
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    if (wd != 0.f) gi += wd * p[i];
-    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+  const float c0 = coef[0], c1 = coef[1];
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    if (wd != 0.f) gi += wd * pi;
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    pi = pi - c0 * (mi / (sqrtf(vi) * c1 + eps));
+  };
+  // four elements a thread and step (16-byte accesses) when the arrays allow
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) |
+                     reinterpret_cast<uintptr_t>(g) |
+                     reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = pv[k], mk = mv[k], vk = vv[k];
+      upd(pk, gv[k], mk, vk);
+      pv[k] = pk;
+      mv[k] = mk;
+      vv[k] = vk;
+    }
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i < n; i += stride) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(pi, g[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
-    p[i] = p[i] - coef[0] * (mi / (sqrtf(vi) * coef[1] + eps));
+    p[i] = pi;
   }
   if (tick == 2) {
     __syncthreads();
@@ -802,8 +832,8 @@ int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
   if (n < 0 || !step_dev) return XRD_ERR_ARG;
   if (n == 0) return XRD_OK;
   if (!param || !grad || !m || !v) return XRD_ERR_ARG;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, const_cast<int32_t*>(step_dev),
@@ -818,8 +848,9 @@ int xrd_adam_dense_tick(float* param, const float* grad, float* m, float* v,
   if (n < 0 || !step_ticket) return XRD_ERR_ARG;
   if (n == 0) return XRD_OK;
   if (!param || !grad || !m || !v) return XRD_ERR_ARG;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  // (the ticket costs one same-address atomic a block)
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, step_ticket, advance ? 2 : 1);
