@@ -609,3 +609,145 @@ def test_track_loss_kernel_equals_torch_formulation(handle_dynamic,
         assert abs(a[1] - b[1]) < 1e-5 * b[1]
     assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7)
     assert torch.allclose(a[3], b[3], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_pointslam_tracking_graph_equals_eager_on_recorded_draws(monkeypatch):
+    """The SAME random draws fed to the eager loop and to the captured /
+    replayed loop (a replayed graph advances torch's Philox stream differently,
+    so the draws — pixel indices, the feature given to samples without
+    neighbours — are read from recorded pools through a device-side counter
+    that the graph replays too): a whole tracking call (10 iterations: batch
+    kernel, masked-median loss, Adam on the pose) must arrive at the same
+    pose."""
+    from xrdslam_amd.slam.common.frame import Frame
+    algo, slam, data, _ = _pointslam_loop(False, 3)
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    cfg = algo.config
+    cam = algo.camera
+    cnt = (cam.height - 2 * cfg.tracking_Hedge) * \
+        (cam.width - 2 * cfg.tracking_Wedge)
+    pool_idx = torch.randint(cnt, (64, 1, cfg.tracking_sample),
+                             generator=g).to(dev)
+    pool_feat = (0.01 * torch.randn(256, 32, generator=g)).to(dev)
+    state = {}
+    real_randint = torch.randint
+
+    def fake_randint(high, size, *a, **kw):
+        if tuple(size) == (1, cfg.tracking_sample) and 'ctr_i' in state:
+            out = torch.index_select(pool_idx, 0, state['ctr_i'])[0]
+            state['ctr_i'] += 1
+            return out
+        return real_randint(high, size, *a, **kw)
+
+    def fake_feature(c_dim, device):
+        out = torch.index_select(pool_feat, 0, state['ctr_f'])[0]
+        state['ctr_f'] += 1
+        return out
+    monkeypatch.setattr(torch, 'randint', fake_randint)
+    dec = algo.model.decoder
+    monkeypatch.setattr(dec.geo_decoder, 'empty_feature_fn', fake_feature)
+    monkeypatch.setattr(dec.color_decoder, 'empty_feature_fn', fake_feature)
+    it = data[3]
+    prev = algo.get_estimate_c2w_list()[2].detach().cpu().numpy()
+    poses = {}
+    for graphs in (False, True):
+        state['ctr_i'] = torch.zeros(1, dtype=torch.int64, device=dev)
+        state['ctr_f'] = torch.zeros(1, dtype=torch.int64, device=dev)
+        f = Frame(fid=3, rgb=it['rgb'], depth=it['depth'],
+                  gt_pose=it['c2w'].astype(np.float32),
+                  init_pose=prev.astype(np.float32),
+                  separate_LR=algo.is_separate_LR(),
+                  rot_rep=algo.get_rot_rep(), device='cuda:0')
+        algo.use_graphs = graphs
+        algo.eager_fixed_shapes = True      # the captured iterations' batches
+        best = algo.do_tracking(f)
+        assert best is not None
+        # the pose after the last Adam step and the lowest-loss pose
+        poses[graphs] = (f.get_pose().detach().cpu().double().numpy(),
+                         np.asarray(best, np.float64))
+        assert int(state['ctr_i']) == cfg.tracking_n_iters
+    gap = np.abs(poses[True][0] - poses[False][0]).max()
+    moved = np.abs(poses[False][0] - prev).max()
+    assert moved > 1e-3                       # the call did optimise the pose
+    assert gap < 1e-4 * max(1.0, np.abs(poses[False][0]).max()), (gap, moved)
+    assert np.abs(poses[True][1] - poses[False][1]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_pointslam_mapping_graph_equals_eager_on_recorded_draws(monkeypatch):
+    """a whole mapping call (20 iterations, geometry then colour stage: batch
+    kernel, kNN, fused decoders, fused map loss, Adam on features and colour
+    decoder) eager and as captured / replayed graphs on the SAME recorded
+    draws, from the same map state.  The feature-gradient scatter uses float
+    atomics, so two EAGER runs already differ (measured: 1.3e-3 of the max
+    norm on single geometry features, 6e-5 colour features, 1.4e-5 decoder):
+    graph-vs-eager must stay at that floor."""
+    algo, slam, data, _ = _pointslam_loop(False, 3)
+    dev = torch.device('cuda:0')
+    pools, ctrs = {}, {}
+    real = torch.randint
+    gen = torch.Generator().manual_seed(5)
+
+    def fake_randint(high, size, *a, **kw):
+        key = (int(high), tuple(size))
+        if key not in pools:
+            pools[key] = real(high, (400, ) + tuple(size),
+                              generator=gen).to(dev)
+            ctrs[key] = torch.zeros(1, dtype=torch.int64, device=dev)
+        out = torch.index_select(pools[key], 0, ctrs[key])[0]
+        ctrs[key] += 1
+        return out
+    pf = (0.01 * torch.randn(2048, 32, generator=gen)).to(dev)
+    cf = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def fake_feature(c_dim, device):
+        out = torch.index_select(pf, 0, cf)[0]
+        cf.add_(1)
+        return out
+    frame = slam.step(3)
+    monkeypatch.setattr(torch, 'randint', fake_randint)
+    dec = algo.model.decoder
+    monkeypatch.setattr(dec.geo_decoder, 'empty_feature_fn', fake_feature)
+    monkeypatch.setattr(dec.color_decoder, 'empty_feature_fn', fake_feature)
+    # the cloud stays as frame 3 left it: the calls below only optimise
+    monkeypatch.setattr(algo, 'pre_precessing', lambda *a, **k: None)
+    npc = algo.model.neural_point_cloud
+
+    def snapshot():
+        return {'geo': npc.geo_feats.detach().clone(),
+                'col': npc.col_feats.detach().clone(),
+                'dec': [p.detach().clone()
+                        for p in dec.color_decoder.parameters()]}
+
+    def restore(s):
+        with torch.no_grad():
+            npc.geo_feats.copy_(s['geo'])
+            npc.col_feats.copy_(s['col'])
+            for p, q in zip(dec.color_decoder.parameters(), s['dec']):
+                p.copy_(q)
+    base = snapshot()
+    frames = algo.select_optimize_frames(
+        frame, algo.config.keyframe_selection_method)
+    res = {}
+    for graphs in (False, True):
+        restore(base)
+        for c in ctrs.values():
+            c.zero_()
+        cf.zero_()
+        algo.use_graphs = graphs
+        algo.eager_fixed_shapes = True
+        algo.optimize_update(20, frames, is_mapping=True)
+        res[graphs] = snapshot()
+
+    def gap(a, b):
+        out = {k: float((a[k] - b[k]).abs().max() / b[k].abs().max())
+               for k in ('geo', 'col')}
+        out['dec'] = max(float((x - y).abs().max() / y.abs().max())
+                         for x, y in zip(a['dec'], b['dec']))
+        return out
+    moved = gap(res[False], base)
+    assert min(moved.values()) > 0.05          # the call did train the map
+    g = gap(res[True], res[False])
+    assert g['col'] < 2e-4 and g['dec'] < 2e-4 and g['geo'] < 5e-3, g
