@@ -110,11 +110,17 @@ __global__ __launch_bounds__(256) void gs_prepare_bwd_kernel(
     float* __restrict__ g_logit, float* __restrict__ g_lscale,
     float* __restrict__ acc, float* __restrict__ g_pose) {
   __shared__ float red[4][12];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   Rigid g;
   load_rigid(pose, pose_is_c2w, first_w2c, g);
-  float gq[3] = {0.f, 0.f, 0.f}, p[3] = {0.f, 0.f, 0.f};
-  if (i < n) {
+  // d loss / d w2c, rows a: gq[a] * p (R part), gq[a] (t part), summed over
+  // the thread's Gaussians (grid-stride: the pose sums cost 12 same-address
+  // atomics and a ticket per BLOCK, ~25 ns each — one block a CU)
+  float v[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) v[k] = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    float gq[3], p[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) p[a] = means[i * 3 + a];
     float q[3];
@@ -158,16 +164,16 @@ __global__ __launch_bounds__(256) void gs_prepare_bwd_kernel(
                                 g_scales[i * 3 + 2]) * s
                              : 0.f;
     }
+    if (g_pose != nullptr) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) v[a * 4 + b] += gq[a] * p[b];
+        v[a * 4 + 3] += gq[a];
+      }
+    }
   }
   if (g_pose == nullptr) return;
-  // d loss / d w2c: rows a: gq[a] * p (R part), gq[a] (t part)
-  float v[12];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int b = 0; b < 3; ++b) v[a * 4 + b] = gq[a] * p[b];
-    v[a * 4 + 3] = gq[a];
-  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
@@ -347,7 +353,9 @@ int xrd_gs_prepare_bwd(int n, const float* means3D, const float* unnorm_rot,
       !first_w2c)
     return XRD_ERR_ARG;
   if (g_pose != nullptr && acc == nullptr) return XRD_ERR_ARG;
-  hipLaunchKernelGGL(gs_prepare_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0,
+  int blocks = (n + 255) / 256;
+  if (g_pose != nullptr && blocks > 256) blocks = 256;   // see the kernel
+  hipLaunchKernelGGL(gs_prepare_bwd_kernel, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, n, means3D, unnorm_rot,
                      logit_opacities, log_scales, pose, pose_is_c2w, first_w2c,
                      g_pts, g_rotations, g_opacities, g_scales, g_ds_colors,
@@ -373,7 +381,7 @@ int xrd_gs_loss_fwd(int H, int W, int is_mapping, int use_sil, float sil_thres,
   if (rc != XRD_OK) return rc;
   const int HW = H * W;
   int blocks = (HW + 255) / 256;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 128) blocks = 128;   // 4 same-address atomics a block
   hipLaunchKernelGGL(gs_loss_stats_kernel, dim3(blocks), dim3(256), 0, st, a,
                      rgb, depth_sil, target_d, target_rgb, stats);
   hipLaunchKernelGGL(gs_loss_finalize_kernel, dim3(1), dim3(64), 0, st, a,

@@ -833,7 +833,7 @@ int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
   if (n == 0) return XRD_OK;
   if (!param || !grad || !m || !v) return XRD_ERR_ARG;
   int64_t blocks = (n + 1023) / 1024;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, const_cast<int32_t*>(step_dev),
@@ -850,7 +850,7 @@ int xrd_adam_dense_tick(float* param, const float* grad, float* m, float* v,
   if (!param || !grad || !m || !v) return XRD_ERR_ARG;
   // (the ticket costs one same-address atomic a block)
   int64_t blocks = (n + 1023) / 1024;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, step_ticket, advance ? 2 : 1);
