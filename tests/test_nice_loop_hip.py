@@ -241,6 +241,14 @@ def test_persistent_mapping_graphs_match_per_call_graphs():
     sa.step(45)                                   # a map frame (45 % 5 == 0)
     del a.model.select_cells
     assert len(seen) == 2                         # main pass, coarse pass
+    # (the coarse pass is enqueued first, on its own stream, and does not
+    # re-select: NiceSLAM._coarse_on_side_stream)
+    sel_main = seen[1] if a._coarse_side_ok() else seen[0]
+    a.join_coarse()
+    torch.cuda.synchronize()
+    # the coarse pass (second stream) did train its grid
+    assert (a.model.grid_c['grid_coarse'].detach() !=
+            grids['grid_coarse']).any()
     key = a._last_map_slot_key
     main = [k for k in slots if not k[3] and slots[k].get('calls', 0) >
             calls.get(k, 0)]
@@ -268,9 +276,9 @@ def test_persistent_mapping_graphs_match_per_call_graphs():
         changed = (g_new != grids[k]).permute(0, 2, 3, 4, 1).reshape(
             -1, 32).any(1)                       # per cell, [Z][Y][X] order
         assert changed.any()
-        # only cells the MAIN pass selected moved (the coarse pass re-selects
-        # for the bundle-adjusted pose but only steps grid_coarse)
-        assert not (changed & ~seen[0][k].reshape(-1)).any(), k
+        # only cells the MAIN pass selected moved (the coarse pass only
+        # steps grid_coarse)
+        assert not (changed & ~sel_main[k].reshape(-1)).any(), k
     assert not torch.equal(a.model.decoder.color_decoder.flat.detach(), flat0)
     # bundle adjustment wrote poses back to the real keyframes (all but the
     # oldest of the window) and left the others alone

@@ -67,17 +67,75 @@ class NiceSLAM(Algorithm):
             cfg.mapping_fine_iter_ratio = 0.0
             self.model.config.mapping_fix_color = True
             self.model.config.mapping_frustum_feature_selection = False
-        for _ in range(outer):
+        side = cfg.coarse and outer == 1 and self._coarse_side_ok()
+        frames = None
+        if side:
+            # window selections in the usual order (they consume the host RNG)
             with torch.no_grad():
                 frames = self.select_optimize_frames(
                     cur_frame, cfg.keyframe_selection_method)
+            frames_c = self.select_optimize_frames(cur_frame, 'random')
+            self._coarse_on_side_stream(n_iters, frames_c)
+        for _ in range(outer):
+            if frames is None:
+                with torch.no_grad():
+                    frames = self.select_optimize_frames(
+                        cur_frame, cfg.keyframe_selection_method)
             self.optimize_update(n_iters, frames, is_mapping=True,
                                  coarse=False)
-        if cfg.coarse:
+            frames = None
+        if cfg.coarse and not side:
             frames = self.select_optimize_frames(cur_frame, 'random')
             self.optimize_update(n_iters, frames, is_mapping=True, coarse=True)
         if not self.is_initialized():
             self.set_initialized()
+
+    # ---- the coarse mapper next to the mapper (MI355X) -----------------------
+    # The reference runs the coarse-level mapper as a process of its own,
+    # concurrently with the mapper (slam/pipeline: coarse_mapper).  Its work —
+    # 60 iterations on grid_coarse alone, ~1/3 of a mapping call's device time
+    # at 1000 rays (blocks of ONE ray: far too little to fill 256 CUs) —
+    # touches nothing the mapper or the tracker reads: its replayed graphs
+    # are enqueued on a second HIP stream BEFORE the mapper's and run under
+    # them.  The host still issues the two calls one after the other.
+    concurrent_coarse = True
+
+    def _coarse_side_ok(self):
+        return (self.concurrent_coarse and self.use_graphs and
+                self.persistent_map_graph and self.is_initialized() and
+                not _dist.state.enabled and
+                torch.device(self.device).type == 'cuda')
+
+    def _coarse_on_side_stream(self, n_iters, frames):
+        dev = torch.device(self.device)
+        side = self.__dict__.get('_coarse_stream')
+        if side is None:
+            side = self._coarse_stream = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        # the frustum selection belongs to the mapper's grids (grid_coarse is
+        # optimised whole) and the packed decoders to the mapper / tracker:
+        # the coarse call must not rewrite either under their launches
+        self.model.selection_frozen = True
+        self._coarse_call = True
+        try:
+            with torch.cuda.stream(side):
+                for f in frames:
+                    for t in f.device_images(dev):
+                        t.record_stream(side)
+                self.optimize_update(n_iters, frames, is_mapping=True,
+                                     coarse=True)
+        finally:
+            self.model.selection_frozen = False
+            self._coarse_call = False
+
+    def join_coarse(self):
+        """make the current stream wait for the coarse mapper's work (before
+        anything reads grid_coarse: rendering through the coarse stage,
+        meshing, checkpoints)"""
+        side = self.__dict__.get('_coarse_stream')
+        if side is not None:
+            torch.cuda.current_stream(torch.device(self.device)) \
+                .wait_stream(side)
 
     # the mapping work of a call depends on the window only through data that
     # fits static buffers (images, poses, cell selection): keep its graphs
@@ -94,8 +152,10 @@ class NiceSLAM(Algorithm):
                 m.mapping_fix_color, m.mapping_frustum_feature_selection)
 
     def after_mapping_update(self):
-        # the tracking graph reads the packed decoder weights in place
-        self.model.sync_decoders(force=True)
+        # the tracking graph reads the packed decoder weights in place (the
+        # coarse pass trains no decoder)
+        if not getattr(self, '_coarse_call', False):
+            self.model.sync_decoders(force=True)
 
     def optimizer_config_update(self, max_iters, coarse=False):
         """nice_slam.py:114-132: BA once >4 keyframes (never in the coarse
@@ -413,6 +473,7 @@ class NiceSLAM(Algorithm):
     def render_img(self, c2w, gt_depth=None, idx=None):
         """full-image render in ray_batch_size chunks (nice_slam.py:234-279);
         like the reference this runs under no_grad without taking the lock."""
+        self.join_coarse()
         with torch.no_grad():
             dev = self.model.device
             rays_o, rays_d = get_rays(self.camera, c2w, device=dev)
@@ -439,6 +500,7 @@ class NiceSLAM(Algorithm):
     def get_mesh(self):
         """the fine-level occupancy level set over marching_cubes_bound,
         coloured by the colour decoder (nice_slam.py:281-288)"""
+        self.join_coarse()
         with self.lock:
             self.model.sync_decoders(force=True)
             self.cur_mesh = self._mesher().get_mesh(

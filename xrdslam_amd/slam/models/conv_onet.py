@@ -278,8 +278,11 @@ class ConvOnet(Model):
                 st[key]['n_sel'] = n_sel
         self.grid_opti_mask['grid_coarse'] = None  # all cells
 
+    selection_frozen = False   # NiceSLAM._coarse_on_side_stream
+
     def pre_precessing(self, cur_frame):
-        if not self.config.mapping_frustum_feature_selection:
+        if not self.config.mapping_frustum_feature_selection or \
+                self.selection_frozen:
             return
         dev = self.device
         if self.device_selection and torch.device(dev).type == 'cuda':
