@@ -26,18 +26,22 @@ class Frame(nn.Module):
         self._dev_cache = None
         self.pose = None
         if init_pose is not None:
-            self.set_pose(init_pose, separate_LR, rot_rep)
-            Rt = torch.as_tensor(init_pose, dtype=torch.float32)
-            if not torch.allclose(Rt, self.pose.matrix().detach().cpu(),
-                                  atol=1e-3):
-                raise ValueError('Transformation inconsistency detected!', Rt,
-                                 self.pose.matrix())
+            self.set_pose(init_pose, separate_LR, rot_rep, check=True)
 
-    def set_pose(self, pose_np, separate_LR=False, rot_rep='axis_angle'):
-        Rt = torch.as_tensor(pose_np, dtype=torch.float32).to(
-            self.pose_device)
-        self.pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,
-                                                rot_rep=rot_rep)
+    def set_pose(self, pose_np, separate_LR=False, rot_rep='axis_angle',
+                 check=False):
+        """pose parameters from a 4x4 matrix.  Built (and, for the initial
+        pose, checked: frame.py:24-29) on the host, then moved to the pose
+        device with one upload per parameter — on the device the conversion
+        costs two host syncs and ~15 tiny launches per frame."""
+        Rt = torch.as_tensor(pose_np, dtype=torch.float32).cpu()
+        pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,
+                                           rot_rep=rot_rep)
+        if check and not torch.allclose(Rt, pose.matrix().detach(),
+                                        atol=1e-3):
+            raise ValueError('Transformation inconsistency detected!', Rt,
+                             pose.matrix())
+        self.pose = pose.to(self.pose_device)
 
     def get_pose(self):
         return self.pose.matrix()

@@ -162,9 +162,15 @@ class OptimizablePose(nn.Module):
 
     @classmethod
     def from_matrix(cls, Rt, separate_LR=True, rot_rep='axis_angle'):
-        R, u = Rt[:3, :3], Rt[:3, 3]
+        # the conversion branches on values (largest quaternion component,
+        # sign): on a device tensor that is two host syncs and ~15 tiny
+        # launches per frame — evaluated on the host, ONE upload of the
+        # parameter vector (same float32 arithmetic)
+        dev = Rt.device
+        Rc = Rt.detach().to('cpu') if dev.type != 'cpu' else Rt
+        R, u = Rc[:3, :3], Rc[:3, 3]
         quat = matrix_to_quaternion(R)
         rot = quaternion_to_axis_angle(quat) if rot_rep == 'axis_angle' \
             else quat
-        return cls(torch.cat([u, rot], dim=-1).detach().clone(),
-                   separate_LR=separate_LR, rot_rep=rot_rep)
+        vec = torch.cat([u, rot], dim=-1).detach().clone()
+        return cls(vec.to(dev), separate_LR=separate_LR, rot_rep=rot_rep)
