@@ -7,7 +7,6 @@ silhouette is empty or the depth disagrees, pruned by opacity / size.
 
 The rasteriser is ``xrdslam_amd.compat.diff_gaussian_rasterization`` (HIP,
 ``xrd_gs_*``).  Parameters live on the device the first frame arrives on."""
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -107,7 +106,16 @@ class GaussianCloud(nn.Module):
         Adam moments are re-keyed to the OLD parameter object before the new
         one is swapped in, so a pruned parameter continues with a fresh Adam
         state."""
-        keep = ~to_remove
+        # ONE compaction index for the five parameters, their Adam moments
+        # and the statistics (boolean-mask indexing would compact — and read
+        # a size back to the host — once per tensor: 19 times)
+        idx = torch.nonzero(~to_remove.reshape(-1)).reshape(-1)
+        if idx.numel() == to_remove.numel():
+            idx = None                  # nothing to drop: same rows, new
+        #                                 Parameter objects like the reference
+
+        def rows(t):
+            return t if idx is None else t.index_select(0, idx)
         for name, opt in optimizer.items():
             if 'pose' in name:
                 continue
@@ -115,16 +123,17 @@ class GaussianCloud(nn.Module):
             old = group['params'][0]
             state = opt.state.get(old, None)
             if state is not None:
-                state['exp_avg'] = state['exp_avg'][keep]
-                state['exp_avg_sq'] = state['exp_avg_sq'][keep]
+                state['exp_avg'] = rows(state['exp_avg'])
+                state['exp_avg_sq'] = rows(state['exp_avg_sq'])
                 del opt.state[old]
                 opt.state[old] = state
-            group['params'][0] = nn.Parameter(old[keep].requires_grad_(True))
+            group['params'][0] = nn.Parameter(
+                rows(old.detach()).requires_grad_(True))
             self.params[name] = group['params'][0]
         for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius',
                   'timestep'):
             if k in self.variables:
-                self.variables[k] = self.variables[k][keep]
+                self.variables[k] = rows(self.variables[k])
 
     def update_params_and_optimizer(self, new_params, optimizer):
         """replace whole parameters, moments reset to zero (:113-123)"""
@@ -260,7 +269,7 @@ class GaussianCloud(nn.Module):
             'means3D': pt_cld[:, :3],
             'rgb_colors': pt_cld[:, 3:6],
             'unnorm_rotations': torch.tensor(
-                np.tile([1, 0, 0, 0], (n, 1))),
+                [1., 0., 0., 0.], device=dev).repeat(n, 1),
             'logit_opacities': torch.zeros((n, 1), dtype=torch.float,
                                            device=dev),
             'log_scales': torch.log(torch.sqrt(mean3_sq_dist))[..., None],
@@ -295,7 +304,8 @@ class GaussianCloud(nn.Module):
             sq = (z / ((cam.fx + cam.fy) / 2))**2
         cloud = torch.cat((pts, color.reshape(-1, 3)), -1)
         if mask is not None:
-            cloud = cloud[mask]
+            idx = torch.nonzero(mask.reshape(-1)).reshape(-1)
+            cloud = cloud.index_select(0, idx)
             if sq is not None:
-                sq = sq[mask]
+                sq = sq.index_select(0, idx)
         return cloud, sq
