@@ -1148,6 +1148,73 @@ int xrd_ssim_bwd(int channels, int height, int width, const float* img1,
                  const float* d_e11, const float* d_e12, float* g_img1,
                  xrd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Map maintenance between iterations (csrc/map_ops.hip).
+ * ---------------------------------------------------------------------- */
+/* Stable compaction of n rows of up to 24 arrays by ONE keep mask — the
+ * reference's chains of `tensor[mask]` (one compaction and one size read-back
+ * per tensor): SplaTAM remove_points / get_pointcloud(mask)
+ * (slam/model_components/gaussian_cloud_splatam.py:84-111,355-399), Point-SLAM
+ * and Vox-Fusion row selections.  keep [n] u8; array j has row_words[j] 4-byte
+ * words a row, src[j] -> dst[j] (dst rows [0, count) are written; dst may be
+ * sized n); ws: xrd_compact_ws_ints(n) i32; count: device i32 = rows kept.
+ * n_arrays == 0 only counts. */
+int64_t xrd_compact_ws_ints(int64_t n);
+int xrd_compact_rows(int64_t n, const uint8_t* keep, int n_arrays,
+                     const void* const* src, void* const* dst,
+                     const int32_t* row_words, int32_t* ws, int32_t* count,
+                     xrd_stream_t stream);
+/* first[i] = 1 when row i of voxels [n,3] i32 is the first occurrence of its
+ * voxel — replaces torch.unique(dim=0) + first-index scatter in front of the
+ * octree insertion (slam/models/sparse_voxel.py:333-340; the octree creates a
+ * node for a voxel's first occurrence only, so first-occurrence order keeps
+ * node and vertex ids).  Open-addressing table: table_keys [table_size] u64,
+ * table_rows [table_size] i32, table_size a power of two >= 2 n; err: device
+ * i32, 0 on success (1: coordinate outside +-2^20, 2: table full). */
+int xrd_voxel_first_flags(int64_t n, const int32_t* voxels, uint8_t* first,
+                          uint64_t* table_keys, int32_t* table_rows,
+                          int64_t table_size, int32_t* err,
+                          xrd_stream_t stream);
+/* Point-SLAM cal_dynamic_radius (slam/algorithms/point_slam.py:326-354 with
+ * slam/common/common.py:74-88): luma of the f32 image rgb [H,W,3], Sobel
+ * magnitude with reflected borders in f64, clipped to [0, thresh],
+ * np.interp over (0, 0.01, thresh) -> (add_max, add_max, add_min) and the same
+ * times query_ratio; r_add, r_query [H,W] f64. */
+int xrd_point_dynamic_radius(int H, int W, const float* rgb, double thresh,
+                             double add_max, double add_min,
+                             double query_ratio, double* r_add,
+                             double* r_query, xrd_stream_t stream);
+/* Point-SLAM add_neural_points (slam/model_components/neural_point_cloud.py:
+ * 109-221) in two launches around the neighbour count: sensor points
+ * pts = o + d * depth [n,3]; then, with n_within [n] i32 = neural points
+ * inside the add radius of each sensor point (xrd_knn_search_count; NULL: the
+ * cloud is empty), rays with depth > 0 and no neighbour append, in ray order,
+ * their sensor point (out_pos), colour * 255 (out_rgb) and n_add points along
+ * the ray (out_pts [.., n_add, 3]): z = depth + lin[j] (fix_interval) or
+ * near_end * depth * (1 - lin[j]) + far_end * depth * lin[j].  Outputs sized
+ * for n rays; count: device i32 = rays kept. */
+int xrd_point_sensor_points(int64_t n, const float* rays_o, const float* rays_d,
+                            const float* depth, float* pts,
+                            xrd_stream_t stream);
+int xrd_point_insert(int n, const float* rays_o, const float* rays_d,
+                     const float* depth, const float* color,
+                     const float* pts_gt, const int32_t* n_within,
+                     const float* lin, int n_add, int fix_interval,
+                     float near_end, float far_end, float* out_pos,
+                     float* out_rgb, float* out_pts, int32_t* count,
+                     xrd_stream_t stream);
+/* Point-SLAM get_mask_from_c2w (slam/algorithms/point_slam.py:356-420): mask[i]
+ * = neural point i [n,3] f32 projects inside the image minus `edge` pixels, in
+ * front of the camera and not behind the bilinearly sampled depth (zero
+ * border; pixels without depth take the maximum sampled depth) + 0.5 m.
+ * w2c [3,4] f64 device row-major (top rows of the inverse pose); depth [H,W];
+ * ws_f [n*3] f32, ws_d [n] f64, ws_i [1] i32 scratch; mask [n] u8. */
+int xrd_point_frustum_mask(int64_t n, const float* points, const double* w2c,
+                           const float* depth, int H, int W, double fx,
+                           double fy, double cx, double cy, int edge,
+                           float* ws_f, double* ws_d, int32_t* ws_i,
+                           uint8_t* mask, xrd_stream_t stream);
+
 /* self test of the MFMA operand/accumulator lane mapping the kernels rely on
  * (v_mfma_f32_16x16x4_f32); out[16*16] f32 device = A(16x4)·B(4x16) */
 int xrd_selftest_mfma(const float* a16x4, const float* b4x16, float* out,

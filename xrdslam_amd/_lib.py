@@ -223,6 +223,16 @@ _SIGS = {
     'xrd_ssim_fwd': (C.c_int, [C.c_int] * 3 + [vp] * 7),
     'xrd_ssim_bwd': (C.c_int, [C.c_int] * 3 + [vp] * 8),
     'xrd_selftest_mfma': (C.c_int, [vp, vp, vp, vp]),
+    'xrd_compact_ws_ints': (i64, [i64]),
+    'xrd_compact_rows': (C.c_int, [i64, vp, C.c_int] + [vp] * 6),
+    'xrd_voxel_first_flags': (C.c_int, [i64, vp, vp, vp, vp, i64, vp, vp]),
+    'xrd_point_dynamic_radius': (C.c_int, [C.c_int, C.c_int, vp] + [f64] * 4 +
+                                 [vp] * 3),
+    'xrd_point_sensor_points': (C.c_int, [i64] + [vp] * 5),
+    'xrd_point_insert': (C.c_int, [C.c_int] + [vp] * 7 + [C.c_int, C.c_int,
+                                                          f32, f32] + [vp] * 5),
+    'xrd_point_frustum_mask': (C.c_int, [i64, vp, vp, vp, C.c_int, C.c_int] +
+                               [f64] * 4 + [C.c_int] + [vp] * 5),
 }
 
 

@@ -89,7 +89,8 @@ class PointSLAM(Algorithm):
         c2w, idx = cur_frame.get_pose().detach(), cur_frame.fid
         r_add = None
         if cfg.use_dynamic_radius:
-            r_add, r_query = self.cal_dynamic_radius(color_np)
+            r_add, r_query = self.cal_dynamic_radius(color_np,
+                                                     frame=cur_frame)
             self.dynamic_r_query_allkeyframe[np.array2string(
                 np.asarray(idx))] = r_query
         if not is_mapping:
@@ -367,10 +368,31 @@ class PointSLAM(Algorithm):
                 torch.cat(depths).reshape(H, W).cpu().numpy()
 
     # -- helpers ------------------------------------------------------------------
-    def cal_dynamic_radius(self, gt_color_np):
+    def cal_dynamic_radius(self, gt_color_np, frame=None):
         """per-pixel add / query radius from the colour-gradient magnitude:
         flat regions get the largest radius, textured ones the smallest
-        (piece-wise linear in the clipped gradient, :326-354)"""
+        (piece-wise linear in the clipped gradient, :326-354).  With the
+        frame's device-resident f32 image: one kernel
+        (xrd_point_dynamic_radius, same f64 arithmetic), computed once per
+        frame; otherwise numpy on the host like the reference."""
+        cfg = self.config
+        if frame is not None and torch.device(self._dev).type == 'cuda' and \
+                isinstance(frame.rgb, np.ndarray) and \
+                frame.rgb.dtype == np.float32:
+            cached = getattr(frame, '_dynamic_radius', None)
+            if cached is None:
+                from ..engine.map_ops import point_dynamic_radius
+                _, rgb = frame.device_images(self._dev)
+                cached = frame._dynamic_radius = point_dynamic_radius(
+                    rgb.reshape(frame.h, frame.w, 3),
+                    cfg.pointcloud_color_grad_threshold,
+                    cfg.pointcloud_radius_add_max,
+                    cfg.pointcloud_radius_add_min,
+                    cfg.pointcloud_radius_query_ratio)
+            return cached
+        return self.cal_dynamic_radius_host(gt_color_np)
+
+    def cal_dynamic_radius_host(self, gt_color_np):
         cfg = self.config
         color = gt_color_np.cpu().numpy() if torch.is_tensor(gt_color_np) \
             else np.asarray(gt_color_np)
@@ -388,7 +410,19 @@ class PointSLAM(Algorithm):
     def get_mask_from_c2w(self, c2w, depth):
         """bool per neural point: projects inside the image (+4 px) and not
         behind the measured depth + 0.5 m (:356-420; bilinear depth lookup with
-        zero border in place of cv2.remap, evaluated on the device)"""
+        zero border in place of cv2.remap).  On the GPU two launches
+        (xrd_point_frustum_mask), else ``get_mask_from_c2w_torch``."""
+        cam, dev = self.camera, self._dev
+        if torch.device(dev).type == 'cuda':
+            from ..engine.map_ops import point_frustum_mask
+            w2c = torch.linalg.inv(c2w.detach().to(dev).double())
+            return point_frustum_mask(
+                self.model.neural_point_cloud.cloud_tensor(dev), w2c,
+                torch.as_tensor(depth).to(dev), cam.height, cam.width, cam.fx,
+                cam.fy, cam.cx, cam.cy, self.config.mapping_frustum_edge)
+        return self.get_mask_from_c2w_torch(c2w, depth)
+
+    def get_mask_from_c2w_torch(self, c2w, depth):
         cam, dev = self.camera, self._dev
         H, W, edge = cam.height, cam.width, self.config.mapping_frustum_edge
         pts = self.model.neural_point_cloud.cloud_tensor(dev).double()

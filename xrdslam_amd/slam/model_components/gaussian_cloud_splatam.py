@@ -106,16 +106,12 @@ class GaussianCloud(nn.Module):
         Adam moments are re-keyed to the OLD parameter object before the new
         one is swapped in, so a pruned parameter continues with a fresh Adam
         state."""
-        # ONE compaction index for the five parameters, their Adam moments
-        # and the statistics (boolean-mask indexing would compact — and read
-        # a size back to the host — once per tensor: 19 times)
-        idx = torch.nonzero(~to_remove.reshape(-1)).reshape(-1)
-        if idx.numel() == to_remove.numel():
-            idx = None                  # nothing to drop: same rows, new
-        #                                 Parameter objects like the reference
-
-        def rows(t):
-            return t if idx is None else t.index_select(0, idx)
+        # ONE compaction for the five parameters, their Adam moments and the
+        # statistics (boolean-mask indexing would compact — and read a size
+        # back to the host — once per tensor: 19 times).  On the GPU:
+        # xrd_compact_rows, three launches and one size read-back for all.
+        keep = ~to_remove.reshape(-1)
+        slots = []          # (setter, tensor)
         for name, opt in optimizer.items():
             if 'pose' in name:
                 continue
@@ -123,17 +119,33 @@ class GaussianCloud(nn.Module):
             old = group['params'][0]
             state = opt.state.get(old, None)
             if state is not None:
-                state['exp_avg'] = rows(state['exp_avg'])
-                state['exp_avg_sq'] = rows(state['exp_avg_sq'])
-                del opt.state[old]
-                opt.state[old] = state
-            group['params'][0] = nn.Parameter(
-                rows(old.detach()).requires_grad_(True))
-            self.params[name] = group['params'][0]
+                slots.append(((state, 'exp_avg'), state['exp_avg']))
+                slots.append(((state, 'exp_avg_sq'), state['exp_avg_sq']))
+            slots.append(((opt, name), old.detach()))
         for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius',
                   'timestep'):
             if k in self.variables:
-                self.variables[k] = rows(self.variables[k])
+                slots.append(((self.variables, k), self.variables[k]))
+        tensors = [t for _, t in slots]
+        if keep.is_cuda and all(t.element_size() == 4 for t in tensors):
+            from ...engine.map_ops import compact_rows
+            rows, _ = compact_rows(keep, tensors)
+        else:
+            idx = torch.nonzero(keep).reshape(-1)
+            rows = [t.index_select(0, idx) for t in tensors]
+        for ((owner, key), _), new in zip(slots, rows):
+            if isinstance(owner, dict):
+                owner[key] = new
+                continue
+            # the parameter itself: moments re-keyed to the OLD object first
+            group = owner.param_groups[0]
+            old = group['params'][0]
+            state = owner.state.get(old, None)
+            if state is not None:
+                del owner.state[old]
+                owner.state[old] = state
+            group['params'][0] = nn.Parameter(new.requires_grad_(True))
+            self.params[key] = group['params'][0]
 
     def update_params_and_optimizer(self, new_params, optimizer):
         """replace whole parameters, moments reset to zero (:113-123)"""
@@ -304,8 +316,13 @@ class GaussianCloud(nn.Module):
             sq = (z / ((cam.fx + cam.fy) / 2))**2
         cloud = torch.cat((pts, color.reshape(-1, 3)), -1)
         if mask is not None:
-            idx = torch.nonzero(mask.reshape(-1)).reshape(-1)
-            cloud = cloud.index_select(0, idx)
-            if sq is not None:
-                sq = sq.index_select(0, idx)
+            if cloud.is_cuda and sq is not None:
+                from ...engine.map_ops import compact_rows
+                (cloud, sq), _ = compact_rows(mask.reshape(-1),
+                                              [cloud, sq.contiguous()])
+            else:
+                idx = torch.nonzero(mask.reshape(-1)).reshape(-1)
+                cloud = cloud.index_select(0, idx)
+                if sq is not None:
+                    sq = sq.index_select(0, idx)
         return cloud, sq

@@ -53,6 +53,7 @@ class NeuralPointCloud(nn.Module):
         self.lock = threading.Lock()
         self.index = knn_factory(device)
         self.feature_init_fn = _feature_init  # replaceable for parity tests
+        self.device_insert = True   # selection + placement as kernels (GPU)
 
     # -- accessors (the reference returns Python lists) ---------------------------
     def cloud_tensor(self, device=None):
@@ -108,30 +109,16 @@ class NeuralPointCloud(nn.Module):
         if not batch_rays_o.shape[0]:
             return 0
         dev = self.device
-        valid = batch_gt_depth > 0
-        color = (batch_gt_color * 255)[valid]
-        rays_o, rays_d = batch_rays_o[valid].to(dev), batch_rays_d[valid].to(dev)
-        depth = batch_gt_depth[valid].to(dev)
-        pts_gt = (rays_o[..., None, :] + rays_d[..., None, :] *
-                  depth[..., None, None]).reshape(-1, 3)
-        keep = torch.ones(pts_gt.shape[0], device=dev).bool()
-        if self.index.ntotal > 0:
-            _, _, n_nb = self.find_neighbors_faiss(
-                pts_gt, step='add', is_pts_grad=is_pts_grad,
-                dynamic_radius=dynamic_radius)
-            keep = n_nb == 0
-        self._input_pos = torch.cat([self._input_pos, pts_gt[keep]], 0)
-        self._input_rgb = torch.cat([self._input_rgb, color[keep].to(dev)], 0)
-        d = depth.unsqueeze(-1).repeat(1, self.N_add)
-        if self.fix_interval_when_add_along_ray:
-            z_vals = d + torch.linspace(-0.04, 0.04, steps=self.N_add,
-                                        device=dev).unsqueeze(0)
+        if torch.device(dev).type == 'cuda' and self.device_insert:
+            new_pos, new_rgb, pts, n_kept = self._select_and_place_kernels(
+                batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color,
+                is_pts_grad, dynamic_radius)
         else:
-            t = torch.linspace(0.0, 1.0, steps=self.N_add, device=dev)
-            z_vals = self.near_end_surface * d * (1. - t) + \
-                self.far_end_surface * d * t
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-        pts = pts[keep].reshape(-1, 3)
+            new_pos, new_rgb, pts, n_kept = self._select_and_place_torch(
+                batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color,
+                is_pts_grad, dynamic_radius)
+        self._input_pos = torch.cat([self._input_pos, new_pos], 0)
+        self._input_rgb = torch.cat([self._input_rgb, new_rgb], 0)
         self._cloud = torch.cat([self._cloud, pts.detach().float()], 0)
         self._pts_num += pts.shape[0]
         n = pts.shape[0]
@@ -154,7 +141,74 @@ class NeuralPointCloud(nn.Module):
             requires_grad=False)
         with self.lock:
             self.index.add(pts.detach())
-        return torch.sum(keep)
+        return n_kept
+
+    def _linspace_table(self):
+        """the N_add offsets (fixed interval) or interpolation weights along
+        the ray, from torch.linspace on the device like the reference"""
+        key = (self.fix_interval_when_add_along_ray, self.N_add)
+        tab = getattr(self, '_lin_tab', None)
+        if tab is None or tab[0] != key:
+            lo, hi = (-0.04, 0.04) if self.fix_interval_when_add_along_ray \
+                else (0.0, 1.0)
+            tab = (key, torch.linspace(lo, hi, steps=self.N_add,
+                                       device=self.device))
+            self._lin_tab = tab
+        return tab[1]
+
+    def _select_and_place_kernels(self, rays_o, rays_d, gt_depth, gt_color,
+                                  is_pts_grad, dynamic_radius):
+        """selection (depth > 0, no neural point within the add radius) and
+        placement as two launches around the neighbour count
+        (xrd_point_sensor_points, xrd_knn_search_count, xrd_point_insert); one
+        size read-back.  Rays without depth take part in the search and are
+        dropped by the insertion kernel, which keeps ray order: the same rows
+        as compacting by ``valid`` first."""
+        from ...engine import map_ops
+        dev = self.device
+        o, d = rays_o.to(dev), rays_d.to(dev)
+        depth, color = gt_depth.to(dev), gt_color.to(dev)
+        pts_gt = map_ops.point_sensor_points(o, d, depth)
+        n_nb = None
+        if self.index.ntotal > 0:
+            _, _, n_nb = self.find_neighbors_faiss(
+                pts_gt, step='add', is_pts_grad=is_pts_grad,
+                dynamic_radius=dynamic_radius)
+        return map_ops.point_insert(
+            o, d, depth, color, pts_gt, n_nb, self._linspace_table(),
+            self.fix_interval_when_add_along_ray, self.near_end_surface,
+            self.far_end_surface)
+
+    def _select_and_place_torch(self, batch_rays_o, batch_rays_d,
+                                batch_gt_depth, batch_gt_color, is_pts_grad,
+                                dynamic_radius):
+        """the same in torch ops, statement by statement like the reference
+        (:113-176)"""
+        dev = self.device
+        valid = batch_gt_depth > 0
+        color = (batch_gt_color * 255)[valid]
+        rays_o, rays_d = batch_rays_o[valid].to(dev), batch_rays_d[valid].to(dev)
+        depth = batch_gt_depth[valid].to(dev)
+        pts_gt = (rays_o[..., None, :] + rays_d[..., None, :] *
+                  depth[..., None, None]).reshape(-1, 3)
+        keep = torch.ones(pts_gt.shape[0], device=dev).bool()
+        if self.index.ntotal > 0:
+            _, _, n_nb = self.find_neighbors_faiss(
+                pts_gt, step='add', is_pts_grad=is_pts_grad,
+                dynamic_radius=dynamic_radius)
+            keep = n_nb == 0
+        d = depth.unsqueeze(-1).repeat(1, self.N_add)
+        if self.fix_interval_when_add_along_ray:
+            z_vals = d + torch.linspace(-0.04, 0.04, steps=self.N_add,
+                                        device=dev).unsqueeze(0)
+        else:
+            t = torch.linspace(0.0, 1.0, steps=self.N_add, device=dev)
+            z_vals = self.near_end_surface * d * (1. - t) + \
+                self.far_end_surface * d * t
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        pts = pts[keep].reshape(-1, 3)
+        return pts_gt[keep], color[keep].to(dev), pts.detach().float(), \
+            int(torch.sum(keep))
 
     # -- queries ------------------------------------------------------------------
     def find_neighbors_faiss(self, pos, step='add', retrain=False,

@@ -252,22 +252,32 @@ class SparseVoxel(Model):
         return w / (torch.sum(w, axis=-1, keepdims=True) + 1e-8), z_min
 
     # -- map maintenance ----------------------------------------------------------
+    @staticmethod
+    def distinct_voxels_torch(voxels):
+        """distinct rows in first-occurrence order with torch ops"""
+        uniq, inv = torch.unique(voxels, dim=0, return_inverse=True)
+        first = torch.full((uniq.shape[0], ), voxels.shape[0],
+                           dtype=torch.int64, device=voxels.device)
+        first.scatter_reduce_(0, inv, torch.arange(
+            voxels.shape[0], device=voxels.device), reduce='amin')
+        return voxels[torch.sort(first).values]
+
     def insert_points(self, points, dedup=True):
         """world points -> voxel coordinates -> octree (:333-340).  With
         ``dedup`` the distinct voxels are extracted on the device in
         first-occurrence order before the (host-side) insertion: the octree
         only ever creates a node for the first occurrence, so node and vertex
         ids are identical while the device->host copy shrinks from one row per
-        depth pixel to one per voxel."""
+        depth pixel to one per voxel.  (``distinct_voxels_torch`` is the same
+        selection in torch ops: the parity check of the kernels.)"""
         voxels = torch.div(points, self.config.voxel_size,
                            rounding_mode='floor').int()
         if dedup and voxels.is_cuda and voxels.shape[0] > 0:
-            uniq, inv = torch.unique(voxels, dim=0, return_inverse=True)
-            first = torch.full((uniq.shape[0], ), voxels.shape[0],
-                               dtype=torch.int64, device=voxels.device)
-            first.scatter_reduce_(0, inv, torch.arange(
-                voxels.shape[0], device=voxels.device), reduce='amin')
-            voxels = voxels[torch.sort(first).values]
+            # first occurrences through a device hash table + one compaction
+            # (xrd_voxel_first_flags / xrd_compact_rows) in place of
+            # torch.unique(dim=0)'s lexicographic sort of one row per pixel
+            from ...engine.map_ops import distinct_voxels
+            voxels = distinct_voxels(voxels)
         self.svo.insert(voxels.cpu().int())
         self.update_map_states()
 
