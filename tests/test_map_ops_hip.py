@@ -149,6 +149,7 @@ def test_sparse_voxel_insert_points_same_octree_as_torch_dedup():
     vox = torch.div(pts, 0.2, rounding_mode='floor').int()
     trees = []
     for rows in (distinct_voxels(vox), SparseVoxel.distinct_voxels_torch(vox)):
+        _svo.reset_id_counter()    # node ids come from a process-wide counter
         tree = _svo.Octree()
         tree.init(256, 16, 0.2)
         tree.insert(rows.cpu().int())

@@ -682,8 +682,9 @@ def test_pointslam_mapping_graph_equals_eager_on_recorded_draws(monkeypatch):
     decoder) eager and as captured / replayed graphs on the SAME recorded
     draws, from the same map state.  The feature-gradient scatter uses float
     atomics, so two EAGER runs already differ (measured: 1.3e-3 of the max
-    norm on single geometry features, 6e-5 colour features, 1.4e-5 decoder):
-    graph-vs-eager must stay at that floor."""
+    norm on single geometry features, 6e-5 colour features, 1.4e-5 decoder,
+    with a tail: 3e-4 on the decoder was seen once): graph-vs-eager must stay
+    at that floor, which the test measures itself with a second eager call."""
     algo, slam, data, _ = _pointslam_loop(False, 3)
     dev = torch.device('cuda:0')
     pools, ctrs = {}, {}
@@ -731,7 +732,7 @@ def test_pointslam_mapping_graph_equals_eager_on_recorded_draws(monkeypatch):
     frames = algo.select_optimize_frames(
         frame, algo.config.keyframe_selection_method)
     res = {}
-    for graphs in (False, True):
+    for run, graphs in (('eager', False), ('eager2', False), ('graph', True)):
         restore(base)
         for c in ctrs.values():
             c.zero_()
@@ -739,7 +740,7 @@ def test_pointslam_mapping_graph_equals_eager_on_recorded_draws(monkeypatch):
         algo.use_graphs = graphs
         algo.eager_fixed_shapes = True
         algo.optimize_update(20, frames, is_mapping=True)
-        res[graphs] = snapshot()
+        res[run] = snapshot()
 
     def gap(a, b):
         out = {k: float((a[k] - b[k]).abs().max() / b[k].abs().max())
@@ -747,7 +748,18 @@ def test_pointslam_mapping_graph_equals_eager_on_recorded_draws(monkeypatch):
         out['dec'] = max(float((x - y).abs().max() / y.abs().max())
                          for x, y in zip(a['dec'], b['dec']))
         return out
-    moved = gap(res[False], base)
+    moved = gap(res['eager'], base)
     assert min(moved.values()) > 0.05          # the call did train the map
-    g = gap(res[True], res[False])
-    assert g['col'] < 2e-4 and g['dec'] < 2e-4 and g['geo'] < 5e-3, g
+    # the floor of THIS process: the same eager call twice
+    floor = gap(res['eager2'], res['eager'])
+    g = gap(res['graph'], res['eager'])
+    rep = os.environ.get('XRD_PARITY_REPORT')
+    if rep:
+        with open(rep, 'a') as fh:
+            fh.write(f'pointslam/mapping_graph_vs_eager\tgap={g}\t'
+                     f'eager_vs_eager={floor}\tmoved={moved}\n')
+    # a wrong selection / loss / step would show at the scale of ``moved``
+    # (> 5e-2); the bars sit 50x below it and above the atomics' tail
+    bars = {'col': 5e-4, 'dec': 1e-3, 'geo': 5e-3}
+    for k, bar in bars.items():
+        assert g[k] < max(bar, 4 * floor[k]), (g, floor)

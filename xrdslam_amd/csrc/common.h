@@ -88,6 +88,30 @@ __device__ __forceinline__ float row16_sum(float v) {
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// LDS fragment reads of an MFMA contraction as volatile asm: left to itself
+// the compiler sinks every fragment read next to the MFMAs that consume it
+// (read - wait - MFMAs: one exposed LDS latency per group); pinned, the reads
+// of K-step s+1 are in flight while the MFMAs of step s issue.  lds_landed()
+// is the matching wait; lds_tie() makes a value's consumers depend on it.
+template <int OFF>
+__device__ __forceinline__ float lds_async(uint32_t addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// LDS reads return in order: PENDING = reads issued after the ones waited for
+template <int PENDING>
+__device__ __forceinline__ void lds_landed() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory");
+}
+__device__ __forceinline__ void lds_tie(float& v) {
+  asm volatile("" : "+v"(v));
+}
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+  return (uint32_t)(uintptr_t)(
+      const __attribute__((address_space(3))) float*)p;
+}
+
 // make LDS writes of this wave visible to its own later LDS reads
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -19,7 +19,7 @@
 // relative-position features, neighbour distances), scatters the colour
 // feature gradients with atomics (tiles transposed through LDS: 128-byte rows
 // per instruction), and leaves the operands of the weight gradients in HBM for
-// pc_dw_kernel (all 13 products in one launch over a job table).
+// pc_dw_kernel (all 14 products in one launch over a job table).
 //
 // Reference behaviour restated, never copied; parity: tests/test_pointslam_hip.py.
 #include <hip/hip_runtime.h>
@@ -659,17 +659,22 @@ __global__ __launch_bounds__(PW * 64, 2) void point_color_bwd_kernel(
 }
 
 // ---- weight gradients: out[128][N] = G^T A over the rows ---------------------------
-// G [rows][128], A = [A1 | A2] [rows][w1 + w2] (N = w1 + w2 <= 16 NT).  A block of
-// 8 waves owns chunks of 64 rows and keeps its share of the product in MFMA
-// accumulators (wave w: output rows 16w .. 16w+15, NT column tiles); the
-// chunk's rows are staged in LDS (row strides 144 / 176 floats: the four row
-// groups of a fragment read fall on distinct banks).  Column sums of G and of
-// A ride along (bias gradients).  All 13 products of a backward run as ONE
-// launch over a job table (blocks of different jobs share the CUs), their
-// per-block partials [128 * 16 NT + 128 + 16 NT] are summed into the flat
-// gradient by one launch of pc_dw_reduce_kernel.
-constexpr int DW_WAVES = 8, DW_CHUNK = 64, DW_GS = 144, DW_AS = 176;
-constexpr int DW_JOBS = 13;
+// G [rows][128], A [rows][N] (N <= 128).  A block of 4 waves owns chunks of 64
+// rows and keeps its share of the product in MFMA accumulators (wave w: output
+// rows 32w .. 32w+31 = two G tiles x NT column tiles, so that a fragment of A
+// feeds two MFMAs); the chunk's rows are staged in LDS (row stride 144 floats:
+// the four row groups of a fragment read fall on distinct banks).  The rows
+// travel global -> registers -> LDS with the NEXT chunk's loads issued before
+// this chunk's contraction, and inside the contraction the fragments of
+// K-step s+1 are read before the MFMAs of step s (pinned asm reads,
+// common.h); 74 KB of LDS and <= 256 registers: two blocks share a CU.
+// Column sums of G and of A ride along (bias gradients).  All 14 products of a
+// backward run as ONE launch over a job table (blocks of different jobs share
+// the CUs), their per-block partials [128 * 16 NT + 128 + 16 NT] are summed
+// into the flat gradient by one launch of pc_dw_reduce_kernel.
+constexpr int DW_WAVES = 4, DW_THREADS = DW_WAVES * 64, DW_CHUNK = 64,
+              DW_GS = 144, DW_AS = 144;
+constexpr int DW_JOBS = 14;
 constexpr int kDwLds = DW_CHUNK * (DW_GS + DW_AS) * (int)sizeof(float);
 __host__ __device__ constexpr int dw_plen(int nt) {
   return 128 * 16 * nt + 128 + 16 * nt;
@@ -689,10 +694,46 @@ struct DwJobs {
   DwJob j[DW_JOBS];
 };
 
+// fragments of one K-step: the wave's two G tiles and the NT column tiles
+template <int NT>
+struct DwFrag {
+  float g[2], a[NT];
+  template <int KOFF, int I>
+  __device__ __forceinline__ void load_a(uint32_t aaddr) {
+    if constexpr (I < NT) {
+      a[I] = lds_async<KOFF + 64 * I>(aaddr);
+      load_a<KOFF, I + 1>(aaddr);
+    }
+  }
+  template <int KOFF>
+  __device__ __forceinline__ void load(uint32_t gaddr, uint32_t aaddr) {
+    g[0] = lds_async<KOFF>(gaddr);
+    g[1] = lds_async<KOFF + 64>(gaddr);
+    load_a<KOFF, 0>(aaddr);
+  }
+  template <int PENDING>
+  __device__ __forceinline__ void landed() {
+    lds_landed<PENDING>();
+    lds_tie(g[0]);
+    lds_tie(g[1]);
+#pragma unroll
+    for (int it = 0; it < NT; ++it) lds_tie(a[it]);
+  }
+  __device__ __forceinline__ void mma(f32x4 (*acc)[NT]) const {
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      acc[0][it] = XRD_MFMA4(g[0], a[it], acc[0][it]);
+      acc[1][it] = XRD_MFMA4(g[1], a[it], acc[1][it]);
+    }
+  }
+};
+
 template <int NT>
 __device__ __forceinline__ void dw_block(const DwJob& job, int blk,
                                          float* __restrict__ ws, float* Gs,
                                          float* As) {
+  static_assert(DW_GS == DW_AS, "one K-step stride for both operands");
+  constexpr int KSTEP = 4 * DW_GS * 4;          // bytes between K-steps
   const float* __restrict__ G = job.G;
   const float* __restrict__ A1 = job.A1;
   const float* __restrict__ A2 = job.A2;
@@ -701,95 +742,118 @@ __device__ __forceinline__ void dw_block(const DwJob& job, int blk,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < DW_CHUNK * DW_AS; i += DW_WAVES * 64)
+  for (int i = threadIdx.x; i < DW_CHUNK * DW_AS; i += DW_THREADS)
     As[i] = 0.f;                                     // padding columns stay 0
-  f32x4 acc[NT];
+  f32x4 acc[2][NT];
 #pragma unroll
-  for (int it = 0; it < NT; ++it) acc[it] = z4;
-  float gsum = 0.f, asum0 = 0.f, asum1 = 0.f;
+  for (int it = 0; it < NT; ++it) acc[0][it] = acc[1][it] = z4;
+  float gsum = 0.f, asum = 0.f;
   const int64_t nchunks = (rows + DW_CHUNK - 1) / DW_CHUNK;
   const int k = lane >> 4, j = lane & 15;
   const int q1 = w1 >> 2, qq = q1 + (w2 >> 2);
+  // (unconditional loads on clamped rows — no branch per load; rows beyond
+  // the job's count become zeros when they are stored to LDS)
+  constexpr int GQ = 8;               // G quads per thread: 64 x 32 / 256
+  constexpr int AQ = NT;              // A quads per thread: 64 x 4 NT / 256
+  f32x4 vg[GQ], va[AQ];
+  const int nq = DW_CHUNK * qq;
+  const int64_t last = rows - 1;
+  auto fetch = [&](int64_t ch) {
+    const int64_t r0 = ch * DW_CHUNK;
+#pragma unroll
+    for (int u = 0; u < GQ; ++u) {
+      const int i = threadIdx.x + u * DW_THREADS;
+      int64_t row = r0 + (i >> 5);
+      row = row < last ? row : last;
+      vg[u] = *reinterpret_cast<const f32x4*>(G + row * 128 + ((i & 31) << 2));
+    }
+#pragma unroll
+    for (int u = 0; u < AQ; ++u) {
+      int i = threadIdx.x + u * DW_THREADS;
+      i = i < nq ? i : nq - 1;
+      const int r = i / qq, c = i - r * qq;
+      int64_t row = r0 + r;
+      row = row < last ? row : last;
+      const float* __restrict__ src =
+          c < q1 ? A1 + row * w1 + 4 * c : A2 + row * w2 + 4 * (c - q1);
+      va[u] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  if (blk < nchunks) fetch(blk);
   for (int64_t ch = blk; ch < nchunks; ch += job.nblk) {
     const int64_t r0 = ch * DW_CHUNK;
     __syncthreads();
-    {
-      // G: 64 x 32 float4 = 4 per thread, all loads in flight before the stores
-      f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * DW_WAVES * 64;
-        const int r = i >> 5, c4 = (i & 31) << 2;
-        v[u] = r0 + r < rows
-                   ? *reinterpret_cast<const f32x4*>(G + (r0 + r) * 128 + c4)
-                   : z4;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * DW_WAVES * 64;
-        *reinterpret_cast<f32x4*>(Gs + (i >> 5) * DW_GS + ((i & 31) << 2)) =
-            v[u];
-      }
+    for (int u = 0; u < GQ; ++u) {
+      const int i = threadIdx.x + u * DW_THREADS;
+      *reinterpret_cast<f32x4*>(Gs + (i >> 5) * DW_GS + ((i & 31) << 2)) =
+          r0 + (i >> 5) < rows ? vg[u] : z4;
     }
-#pragma unroll 2
-    for (int i = threadIdx.x; i < DW_CHUNK * qq; i += DW_WAVES * 64) {
+#pragma unroll
+    for (int u = 0; u < AQ; ++u) {
+      const int i = threadIdx.x + u * DW_THREADS;
       const int r = i / qq, c = i - r * qq;
-      f32x4 v = z4;
-      if (r0 + r < rows)
-        v = c < q1
-                ? *reinterpret_cast<const f32x4*>(A1 + (r0 + r) * w1 + 4 * c)
-                : *reinterpret_cast<const f32x4*>(A2 + (r0 + r) * w2 +
-                                                  4 * (c - q1));
-      *reinterpret_cast<f32x4*>(As + r * DW_AS + 4 * c) = v;
+      if (i < nq)
+        *reinterpret_cast<f32x4*>(As + r * DW_AS + 4 * c) =
+            r0 + r < rows ? va[u] : z4;
     }
     __syncthreads();
-#pragma unroll 2
-    for (int ks = 0; ks < DW_CHUNK / 4; ++ks) {
-      const int r = 4 * ks + k;
-      const float ga = Gs[r * DW_GS + 16 * wave + j];
-#pragma unroll
-      for (int it = 0; it < NT; ++it)
-        acc[it] = XRD_MFMA4(ga, As[r * DW_AS + 16 * it + j], acc[it]);
+    if (ch + job.nblk < nchunks) fetch(ch + job.nblk);
+    {
+      uint32_t gaddr = lds_addr(Gs + k * DW_GS + 32 * wave + j);
+      uint32_t aaddr = lds_addr(As + k * DW_AS + j);
+      DwFrag<NT> f0, f1;
+      f0.template load<0>(gaddr, aaddr);
+#pragma unroll 1
+      for (int ks = 0; ks < DW_CHUNK / 4 - 2; ks += 2) {
+        f1.template load<KSTEP>(gaddr, aaddr);
+        f0.template landed<NT + 2>();     // f1's reads stay in flight
+        f0.mma(acc);
+        f0.template load<2 * KSTEP>(gaddr, aaddr);
+        f1.template landed<NT + 2>();
+        f1.mma(acc);
+        gaddr += 2 * KSTEP;
+        aaddr += 2 * KSTEP;
+      }
+      f1.template load<KSTEP>(gaddr, aaddr);
+      f0.template landed<NT + 2>();
+      f0.mma(acc);
+      f1.template landed<0>();
+      f1.mma(acc);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      gsum += Gs[(grp * 16 + r) * DW_GS + col];
-      asum0 += As[(grp * 16 + r) * DW_AS + col];
-      if (NT > 8 && col < 16 * NT - 128)
-        asum1 += As[(grp * 16 + r) * DW_AS + 128 + col];
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      gsum += Gs[(grp * 32 + r) * DW_GS + col];
+      asum += As[(grp * 32 + r) * DW_AS + col];
     }
   }
   float* out = ws + job.ws_off + (int64_t)blk * dw_plen(NT);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = 16 * wave + 4 * k + r;
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int it = 0; it < NT; ++it) out[o * (16 * NT) + 16 * it + j] = acc[it][r];
-  }
+    for (int r = 0; r < 4; ++r) {
+      const int o = 32 * wave + 16 * t + 4 * k + r;
+#pragma unroll
+      for (int it = 0; it < NT; ++it)
+        out[o * (16 * NT) + 16 * it + j] = acc[t][it][r];
+    }
   __syncthreads();
-  float* R = Gs;   // [3][4][128]
-  R[(0 * 4 + grp) * 128 + col] = gsum;
-  R[(1 * 4 + grp) * 128 + col] = asum0;
-  R[(2 * 4 + grp) * 128 + col] = asum1;
+  float* R = Gs;   // [2][2][128]
+  R[(0 * 2 + grp) * 128 + col] = gsum;
+  R[(1 * 2 + grp) * 128 + col] = asum;
   __syncthreads();
   if (threadIdx.x < 128) {
-    float t[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-      t[m] = (R[(m * 4 + 0) * 128 + col] + R[(m * 4 + 1) * 128 + col]) +
-             (R[(m * 4 + 2) * 128 + col] + R[(m * 4 + 3) * 128 + col]);
-    out[128 * 16 * NT + col] = t[0];
-    if (col < 16 * NT) out[128 * 16 * NT + 128 + col] = t[1];
-    if (NT > 8 && col < 16 * NT - 128)
-      out[128 * 16 * NT + 256 + col] = t[2];
+    out[128 * 16 * NT + col] = R[0 * 128 + col] + R[1 * 128 + col];
+    if (col < 16 * NT)
+      out[128 * 16 * NT + 128 + col] = R[2 * 128 + col] + R[3 * 128 + col];
   }
 }
 
-__global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
+__global__ __launch_bounds__(DW_THREADS, 2) void pc_dw_kernel(
     const DwJobs jobs, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Gs = reinterpret_cast<float*>(smem_raw);   // [64][144]
-  float* As = Gs + DW_CHUNK * DW_GS;                 // [64][176]
+  float* As = Gs + DW_CHUNK * DW_GS;                 // [64][144]
   int ji = 0;
 #pragma unroll 1
   for (int t = 1; t < DW_JOBS; ++t)
@@ -801,8 +865,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void pc_dw_kernel(
     case 2: dw_block<2>(job, blk, ws, Gs, As); break;
     case 3: dw_block<3>(job, blk, ws, Gs, As); break;
     case 4: dw_block<4>(job, blk, ws, Gs, As); break;
-    case 8: dw_block<8>(job, blk, ws, Gs, As); break;
-    default: dw_block<11>(job, blk, ws, Gs, As); break;
+    default: dw_block<8>(job, blk, ws, Gs, As); break;
   }
 }
 
@@ -840,7 +903,7 @@ __global__ __launch_bounds__(256) void pc_dw_reduce_kernel(
       flat[job.transposed ? job.w_off + cc * job.ldo + o
                           : job.w_off + o * job.ldo + cc] = v;
   } else if (i < wl + 128) {
-    if (!job.b_from_a) flat[job.b_off + (i - wl)] = v;
+    if (!job.b_from_a && job.b_off >= 0) flat[job.b_off + (i - wl)] = v;
   } else {
     if (job.b_from_a && i - wl - 128 < N) flat[job.b_off + (i - wl - 128)] = v;
   }
@@ -1009,9 +1072,14 @@ static void dw_plan(int64_t n, const float* save_c, const float* save_h,
     if (i == 0)
       p.add(n, c1, gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(0), 40, 0, F::pb(0),
             0);
-    else if (i == 3)
-      p.add(n, c1, gz, op.e40, 40, hp, 128, 168, 11, F::pw(3), 168, 0,
+    else if (i == 3) {
+      // [e40 | h] -> 168 columns as two products (columns 0..39 with the bias,
+      // columns 40..167 without: b_off -1)
+      p.add(n, c1, gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(3), 168, 0,
             F::pb(3), 0);
+      p.add(n, c1, gz, hp, 128, nullptr, 0, 128, 8, F::pw(3) + 40, 168, 0, -1,
+            0);
+    }
     else
       p.add(n, c1, gz, hp, 128, nullptr, 0, 128, 8, F::pw(i), 128, 0, F::pb(i),
             0);
@@ -1137,7 +1205,7 @@ int xrd_point_color_bwd(int64_t n_points, const float* points,
   }
   DwPlan plan;
   dw_plan(n, save_c, save_h, ops, plan);
-  hipLaunchKernelGGL(pc_dw_kernel, dim3(plan.blocks), dim3(DW_WAVES * 64),
+  hipLaunchKernelGGL(pc_dw_kernel, dim3(plan.blocks), dim3(DW_THREADS),
                      kDwLds, st, plan.jobs, workspace);
   hipLaunchKernelGGL(pc_dw_reduce_kernel, dim3(plan.red_blocks), dim3(256), 0,
                      st, plan.jobs, workspace, g_flat);

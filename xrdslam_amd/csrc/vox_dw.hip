@@ -9,24 +9,31 @@
 // handle badly (rocBLAS: 4.8 ms for the five at 590 000 capacity rows, plus
 // ~1 ms per column sum), and the LIVE point count is only known on the device.
 //
-// A block of 8 waves owns chunks of 64 points (persistent, stride = grid) and
+// A block of 4 waves owns chunks of 64 points (persistent, stride = grid) and
 // keeps its share of all five products in MFMA accumulators across its chunks
 // (v_mfma_f32_16x16x4_f32: A = 16 output features x 4 points of G^T, B = 4
-// points x 16 input features): wave w owns output rows 16w..16w+15 of every
-// 128-row product (1 + 8 + 8 + 9 accumulator tiles).  Per layer the chunk's G
-// and A rows are staged in LDS (row stride 144 floats: the four point groups
-// of a fragment read fall on distinct banks).  The one-row products (gs, the
-// three colour rows) and the bias sums run on the VALU from the same staged
-// rows.  Rows beyond the live count are staged as zeros.  Each block writes
-// its partial to a [blocks, 54276] workspace; vox_dw_reduce sums the live
-// blocks into the flat gradient (state_dict order).
+// points x 16 input features): wave w owns output rows 32w..32w+31 of every
+// 128-row product (2 x (1 + 8 + 8 + 9) accumulator tiles = 208 registers: one
+// wave per SIMD with the whole register file; with 8 thinner waves the
+// compiler ran out of registers at 256 and serialised every LDS read with the
+// two MFMAs that consume it).  Per layer the chunk's G and A rows are staged
+// in LDS (row stride 144 floats: the four point groups of a fragment read fall
+// on distinct banks); the stage's rows travel global -> registers -> LDS with
+// the loads of the NEXT stage issued before the current contraction, and
+// inside a contraction the fragments of K-step s+1 are read before the MFMAs
+// of step s.  The one-row products (gs, the three colour rows) and the bias
+// sums run on the VALU from the same staged rows.  Rows beyond the live count
+// are staged as zeros.  Each block writes its partial to a [blocks, 54276]
+// workspace; vox_dw_reduce sums the live blocks into the flat gradient
+// (state_dict order).
 #include "common.h"
 #include "vox_layout.h"
 
 namespace xrd {
 namespace {
 
-constexpr int DW_WAVES = 8;
+constexpr int DW_WAVES = 4;
+constexpr int DW_THREADS = DW_WAVES * 64;
 constexpr int DW_CHUNK = 64;      // points per stage
 constexpr int DW_STRIDE = 144;    // LDS row stride (floats)
 constexpr int DW_BLOCKS = 256;    // persistent blocks: one per CU
@@ -37,48 +44,80 @@ constexpr int F_W0 = 0, F_B0 = 2048, F_W1 = 2176, F_B1 = 18560,
               F_W4 = 53889, F_B4 = 54273;
 static_assert(F_B4 + 3 == DW_LEN, "flat layout");
 
-// rows [p0, p0+64) x width floats of src ([P, width] row-major) -> LDS rows of
-// stride DW_STRIDE at column col0; rows >= n are zeros
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int col0,
-                                           const float* __restrict__ src,
-                                           int width, int64_t p0, int64_t n) {
-  const int w4 = width >> 2;
-  for (int i = threadIdx.x; i < DW_CHUNK * w4; i += DW_WAVES * 64) {
-    const int r = i / w4, c = (i - r * w4) << 2;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p0 + r < n)
-      v = *reinterpret_cast<const f32x4*>(src + (p0 + r) * width + c);
-    *reinterpret_cast<f32x4*>(dst + r * DW_STRIDE + col0 + c) = v;
+// fragments of one K-step: the wave's two G tiles and the NT input tiles
+template <int NT>
+struct Frag {
+  float g[2], a[NT];
+  template <int KOFF, int I>
+  __device__ __forceinline__ void load_a(uint32_t aaddr) {
+    if constexpr (I < NT) {
+      a[I] = lds_async<KOFF + 64 * I>(aaddr);
+      load_a<KOFF, I + 1>(aaddr);
+    }
   }
-}
-
-// acc[it] += G^T(tile of this wave) x A(input tile it) over the 64 staged rows
+  // KOFF: byte offset of the K-step relative to the address registers
+  template <int KOFF>
+  __device__ __forceinline__ void load(uint32_t gaddr, uint32_t aaddr) {
+    g[0] = lds_async<KOFF>(gaddr);
+    g[1] = lds_async<KOFF + 64>(gaddr);
+    load_a<KOFF, 0>(aaddr);
+  }
+  template <int PENDING>
+  __device__ __forceinline__ void landed() {
+    lds_landed<PENDING>();
+    lds_tie(g[0]);
+    lds_tie(g[1]);
+#pragma unroll
+    for (int it = 0; it < NT; ++it) lds_tie(a[it]);
+  }
+  __device__ __forceinline__ void mma(f32x4 (*acc)[NT]) const {
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      acc[0][it] = XRD_MFMA4(g[0], a[it], acc[0][it]);
+      acc[1][it] = XRD_MFMA4(g[1], a[it], acc[1][it]);
+    }
+  }
+};
+// acc[t][it] += G^T(tile 2 wave + t) x A(input tile it) over the 64 staged rows
 template <int NT>
 __device__ __forceinline__ void contract(const float* __restrict__ g,
                                          const float* __restrict__ a, int wave,
-                                         int lane, f32x4* acc) {
+                                         int lane, f32x4 (*acc)[NT]) {
+  constexpr int KSTEP = 4 * DW_STRIDE * 4;      // bytes between K-steps
   const int k = lane >> 4, j = lane & 15;
-#pragma unroll 2
-  for (int ks = 0; ks < DW_CHUNK / 4; ++ks) {
-    const int row = (4 * ks + k) * DW_STRIDE;
-    const float ga = g[row + 16 * wave + j];
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-      acc[it] = XRD_MFMA4(ga, a[row + 16 * it + j], acc[it]);
+  uint32_t gaddr = lds_addr(g + k * DW_STRIDE + 32 * wave + j);
+  uint32_t aaddr = lds_addr(a + k * DW_STRIDE + j);
+  Frag<NT> f0, f1;
+  f0.template load<0>(gaddr, aaddr);
+#pragma unroll 1
+  for (int ks = 0; ks < DW_CHUNK / 4 - 2; ks += 2) {
+    f1.template load<KSTEP>(gaddr, aaddr);
+    f0.template landed<NT + 2>();     // f1's reads stay in flight
+    f0.mma(acc);
+    f0.template load<2 * KSTEP>(gaddr, aaddr);
+    f1.template landed<NT + 2>();
+    f1.mma(acc);
+    gaddr += 2 * KSTEP;
+    aaddr += 2 * KSTEP;
   }
+  f1.template load<KSTEP>(gaddr, aaddr);
+  f0.template landed<NT + 2>();
+  f0.mma(acc);
+  f1.template landed<0>();
+  f1.mma(acc);
 }
 
 // column sums of the staged G rows: thread (col = t & 127, grp = t >> 7) adds
-// its 16 rows
-__device__ __forceinline__ float colsum16(const float* __restrict__ g) {
+// its 32 rows
+__device__ __forceinline__ float colsum32(const float* __restrict__ g) {
   const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
   float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s += g[(grp * 16 + r) * DW_STRIDE + col];
+#pragma unroll 8
+  for (int r = 0; r < 32; ++r) s += g[(grp * 32 + r) * DW_STRIDE + col];
   return s;
 }
 
-__global__ __launch_bounds__(DW_WAVES * 64) void vox_dw_kernel(
+__global__ __launch_bounds__(DW_THREADS, 1) void vox_dw_kernel(
     int64_t p_cap, const int* __restrict__ n_dev,
     const float* __restrict__ sx, const float* __restrict__ sh1,
     const float* __restrict__ sh2, const float* __restrict__ sf,
@@ -97,99 +136,159 @@ __global__ __launch_bounds__(DW_WAVES * 64) void vox_dw_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 a0[1] = {z4}, a1[8], ao[8], ac[9];
+  f32x4 a0[2][1], a1[2][8], ao[2][8], ac[2][9];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a1[i] = ao[i] = z4;
+  for (int t = 0; t < 2; ++t) {
+    a0[t][0] = z4;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) ac[i] = z4;
+    for (int i = 0; i < 8; ++i) a1[t][i] = ao[t][i] = z4;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ac[t][i] = z4;
+  }
   float b0 = 0.f, b1 = 0.f, bo = 0.f, bc = 0.f;     // bias column sums
   float r_gs = 0.f, r4[3] = {0.f, 0.f, 0.f};       // one-row products
-  float bs = 0.f;                                   // sums of gc3 columns
+  f32x4 bsv = {0.f, 0.f, 0.f, 0.f};   // gc3 column sums: row t of every chunk
+  // (loads are unconditional on a clamped row — no branch per load — and rows
+  // beyond the live count become zeros when they are stored to LDS)
+  f32x4 vg[8], va[8], vx, vs;     // G rows, A rows (128 wide), x / gc3 rows
+  const int64_t last = n - 1;     // n > 0 here
+  auto fetch128 = [&](f32x4* v, const float* __restrict__ src, int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = threadIdx.x + u * DW_THREADS;
+      const int c = (i & 31) << 2;
+      int64_t row = p0 + (i >> 5);
+      row = row < last ? row : last;
+      v[u] = *reinterpret_cast<const f32x4*>(src + row * 128 + c);
+    }
+  };
+  auto store128 = [&](float* __restrict__ dst, const f32x4* v, int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = threadIdx.x + u * DW_THREADS;
+      *reinterpret_cast<f32x4*>(dst + (i >> 5) * DW_STRIDE + ((i & 31) << 2)) =
+          p0 + (i >> 5) < n ? v[u] : z4;
+    }
+  };
+  // x rows (16 wide): one quad per thread
+  auto fetch_x = [&](int64_t p0) {
+    const int c = (threadIdx.x & 3) << 2;
+    int64_t row = p0 + (threadIdx.x >> 2);
+    row = row < last ? row : last;
+    vx = *reinterpret_cast<const f32x4*>(sx + row * 16 + c);
+  };
+  auto store_x = [&](int col0, int64_t p0) {
+    const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) << 2;
+    *reinterpret_cast<f32x4*>(A + r * DW_STRIDE + col0 + c) =
+        p0 + r < n ? vx : z4;
+  };
+  auto fetch_l0 = [&](int64_t p0) {
+    fetch128(vg, gh1, p0);
+    fetch_x(p0);
+    int64_t row = p0 + (threadIdx.x & (DW_CHUNK - 1));
+    row = row < last ? row : last;
+    vs = *reinterpret_cast<const f32x4*>(gc3 + row * 4);
+  };
+  fetch_l0((int64_t)blockIdx.x * DW_CHUNK);
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t p0 = ch * DW_CHUNK;
     // ---- layer 0: gh1^T x ------------------------------------------------
     __syncthreads();
-    stage_rows(G, 0, gh1, 128, p0, n);
-    stage_rows(A, 0, sx, 16, p0, n);
+    store128(G, vg, p0);
+    store_x(0, p0);
     if (threadIdx.x < DW_CHUNK) {
-      f32x4 v = z4;
-      if (p0 + threadIdx.x < n)
-        v = *reinterpret_cast<const f32x4*>(gc3 + (p0 + threadIdx.x) * 4);
-      *reinterpret_cast<f32x4*>(S + threadIdx.x * 4) = v;
+      const f32x4 row = p0 + threadIdx.x < n ? vs : z4;
+      *reinterpret_cast<f32x4*>(S + threadIdx.x * 4) = row;
+      bsv += row;
     }
     __syncthreads();
+    fetch128(vg, gh2, p0);
+    fetch128(va, sh1, p0);
     contract<1>(G, A, wave, lane, a0);
-    b0 += colsum16(G);
-    if (threadIdx.x < 4)
-      for (int r = 0; r < DW_CHUNK; ++r) bs += S[r * 4 + threadIdx.x];
+    b0 += colsum32(G);
     // ---- layer 1: gh2^T h1 -------------------------------------------------
     __syncthreads();
-    stage_rows(G, 0, gh2, 128, p0, n);
-    stage_rows(A, 0, sh1, 128, p0, n);
+    store128(G, vg, p0);
+    store128(A, va, p0);
     __syncthreads();
+    fetch128(vg, gf, p0);
+    fetch128(va, sh2, p0);
     contract<8>(G, A, wave, lane, a1);
-    b1 += colsum16(G);
+    b1 += colsum32(G);
     // ---- sdf_out: [gs | gf]^T h2 ---------------------------------------------
     __syncthreads();
-    stage_rows(G, 0, gf, 128, p0, n);
-    stage_rows(A, 0, sh2, 128, p0, n);
+    store128(G, vg, p0);
+    store128(A, va, p0);
     __syncthreads();
+    fetch128(vg, ghc, p0);
+    fetch128(va, sf, p0);
+    fetch_x(p0);
     contract<8>(G, A, wave, lane, ao);
-    bo += colsum16(G);
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      r_gs = fmaf(S[(grp * 16 + r) * 4 + 3],
-                  A[(grp * 16 + r) * DW_STRIDE + col], r_gs);
+    bo += colsum32(G);
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r)
+      r_gs = fmaf(S[(grp * 32 + r) * 4 + 3],
+                  A[(grp * 32 + r) * DW_STRIDE + col], r_gs);
     // ---- colour layer 0: ghc^T [f | x] ------------------------------------------
     __syncthreads();
-    stage_rows(G, 0, ghc, 128, p0, n);
-    stage_rows(A, 0, sf, 128, p0, n);
-    stage_rows(A, 128, sx, 16, p0, n);
+    store128(G, vg, p0);
+    store128(A, va, p0);
+    store_x(128, p0);
     __syncthreads();
+    fetch128(va, shc, p0);
     contract<9>(G, A, wave, lane, ac);
-    bc += colsum16(G);
+    bc += colsum32(G);
     // ---- colour layer 1: g3^T hc (three rows, VALU) ---------------------------
     __syncthreads();
-    stage_rows(A, 0, shc, 128, p0, n);
+    store128(A, va, p0);
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float h = A[(grp * 16 + r) * DW_STRIDE + col];
+    if (ch + gridDim.x < nchunks) fetch_l0((ch + gridDim.x) * DW_CHUNK);
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const float h = A[(grp * 32 + r) * DW_STRIDE + col];
 #pragma unroll
       for (int o = 0; o < 3; ++o)
-        r4[o] = fmaf(S[(grp * 16 + r) * 4 + o], h, r4[o]);
+        r4[o] = fmaf(S[(grp * 32 + r) * 4 + o], h, r4[o]);
     }
   }
   // ---- this block's partial ------------------------------------------------------
   float* out = partial + (int64_t)blockIdx.x * DW_LEN;
   const int q = lane >> 4, j = lane & 15;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = 16 * wave + 4 * q + r;
-    out[F_W0 + o * 16 + j] = a0[0][r];
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      out[F_W1 + o * 128 + 16 * it + j] = a1[it][r];
-      out[F_WO + (1 + o) * 128 + 16 * it + j] = ao[it][r];
+    for (int r = 0; r < 4; ++r) {
+      const int o = 32 * wave + 16 * t + 4 * q + r;
+      out[F_W0 + o * 16 + j] = a0[t][0][r];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        out[F_W1 + o * 128 + 16 * it + j] = a1[t][it][r];
+        out[F_WO + (1 + o) * 128 + 16 * it + j] = ao[t][it][r];
+      }
+#pragma unroll
+      for (int it = 0; it < 9; ++it)
+        out[F_WC + o * 144 + 16 * it + j] = ac[t][it][r];
     }
-#pragma unroll
-    for (int it = 0; it < 9; ++it)
-      out[F_WC + o * 144 + 16 * it + j] = ac[it][r];
   }
-  // VALU sums: 4 row groups -> one value per column, through LDS
+  // VALU sums: 2 row groups -> one value per column, through LDS
   __syncthreads();
-  float* R = G;   // [8 quantities][4 groups][128]
+  float* R = G;   // [8 quantities][2 groups][128]
   const float vals[8] = {b0, b1, bo, bc, r_gs, r4[0], r4[1], r4[2]};
 #pragma unroll
-  for (int k = 0; k < 8; ++k) R[(k * 4 + grp) * 128 + col] = vals[k];
-  if (threadIdx.x < 4) S[threadIdx.x] = bs;
+  for (int k = 0; k < 8; ++k) R[(k * 2 + grp) * 128 + col] = vals[k];
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float t = wave_sum(bsv[c]);
+      if (lane == 0) S[c] = t;
+    }
+  }
   __syncthreads();
   if (threadIdx.x < 128) {
     float t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      t[k] = R[(k * 4 + 0) * 128 + col] + R[(k * 4 + 1) * 128 + col] +
-             R[(k * 4 + 2) * 128 + col] + R[(k * 4 + 3) * 128 + col];
+      t[k] = R[(k * 2 + 0) * 128 + col] + R[(k * 2 + 1) * 128 + col];
     out[F_B0 + col] = t[0];
     out[F_B1 + col] = t[1];
     out[F_BO + 1 + col] = t[2];
@@ -268,7 +367,7 @@ int xrd_vox_dw(int64_t n_points, const int32_t* n_points_dev,
   if (n_points > 0) {
     const int64_t nchunks = (n_points + DW_CHUNK - 1) / DW_CHUNK;
     if (nchunks < nb) nb = (int)nchunks;
-    hipLaunchKernelGGL(vox_dw_kernel, dim3(nb), dim3(DW_WAVES * 64), lds, st,
+    hipLaunchKernelGGL(vox_dw_kernel, dim3(nb), dim3(DW_THREADS), lds, st,
                        n_points, n_points_dev, save_x, save_h1, save_h2,
                        save_f, save_hc, g_c3, g_hc, g_f, g_h2, g_h1,
                        workspace);

@@ -381,7 +381,7 @@ class PointSLAM(Algorithm):
                 frame.rgb.dtype == np.float32:
             cached = getattr(frame, '_dynamic_radius', None)
             if cached is None:
-                from ..engine.map_ops import point_dynamic_radius
+                from ...engine.map_ops import point_dynamic_radius
                 _, rgb = frame.device_images(self._dev)
                 cached = frame._dynamic_radius = point_dynamic_radius(
                     rgb.reshape(frame.h, frame.w, 3),
@@ -414,7 +414,7 @@ class PointSLAM(Algorithm):
         (xrd_point_frustum_mask), else ``get_mask_from_c2w_torch``."""
         cam, dev = self.camera, self._dev
         if torch.device(dev).type == 'cuda':
-            from ..engine.map_ops import point_frustum_mask
+            from ...engine.map_ops import point_frustum_mask
             w2c = torch.linalg.inv(c2w.detach().to(dev).double())
             return point_frustum_mask(
                 self.model.neural_point_cloud.cloud_tensor(dev), w2c,
