@@ -742,8 +742,6 @@ __device__ __forceinline__ void dw_block(const DwJob& job, int blk,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < DW_CHUNK * DW_AS; i += DW_THREADS)
-    As[i] = 0.f;                                     // padding columns stay 0
   f32x4 acc[2][NT];
 #pragma unroll
   for (int it = 0; it < NT; ++it) acc[0][it] = acc[1][it] = z4;
@@ -756,7 +754,10 @@ __device__ __forceinline__ void dw_block(const DwJob& job, int blk,
   constexpr int GQ = 8;               // G quads per thread: 64 x 32 / 256
   constexpr int AQ = NT;              // A quads per thread: 64 x 4 NT / 256
   f32x4 vg[GQ], va[AQ];
-  const int nq = DW_CHUNK * qq;
+  // thread -> A quad: row i / (4 NT), quad i % (4 NT) of the 16 NT staged
+  // columns; quads beyond the job's qq are staged as zeros (padding columns of
+  // the last tile), so the tile needs no separate clearing pass
+  constexpr int RQ = 4 * NT;
   const int64_t last = rows - 1;
   auto fetch = [&](int64_t ch) {
     const int64_t r0 = ch * DW_CHUNK;
@@ -769,9 +770,10 @@ __device__ __forceinline__ void dw_block(const DwJob& job, int blk,
     }
 #pragma unroll
     for (int u = 0; u < AQ; ++u) {
-      int i = threadIdx.x + u * DW_THREADS;
-      i = i < nq ? i : nq - 1;
-      const int r = i / qq, c = i - r * qq;
+      const int i = threadIdx.x + u * DW_THREADS;
+      const int r = i / RQ;
+      int c = i - r * RQ;
+      c = c < qq ? c : qq - 1;
       int64_t row = r0 + r;
       row = row < last ? row : last;
       const float* __restrict__ src =
@@ -792,10 +794,9 @@ __device__ __forceinline__ void dw_block(const DwJob& job, int blk,
 #pragma unroll
     for (int u = 0; u < AQ; ++u) {
       const int i = threadIdx.x + u * DW_THREADS;
-      const int r = i / qq, c = i - r * qq;
-      if (i < nq)
-        *reinterpret_cast<f32x4*>(As + r * DW_AS + 4 * c) =
-            r0 + r < rows ? va[u] : z4;
+      const int r = i / RQ, c = i - r * RQ;
+      *reinterpret_cast<f32x4*>(As + r * DW_AS + 4 * c) =
+          c < qq && r0 + r < rows ? va[u] : z4;
     }
     __syncthreads();
     if (ch + job.nblk < nchunks) fetch(ch + job.nblk);
@@ -854,10 +855,10 @@ __global__ __launch_bounds__(DW_THREADS, 2) void pc_dw_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Gs = reinterpret_cast<float*>(smem_raw);   // [64][144]
   float* As = Gs + DW_CHUNK * DW_GS;                 // [64][144]
+  // (the 13 thresholds as independent scalar loads: one latency, not 13)
   int ji = 0;
-#pragma unroll 1
-  for (int t = 1; t < DW_JOBS; ++t)
-    if ((int)blockIdx.x >= jobs.j[t].blk0) ji = t;
+#pragma unroll
+  for (int t = 1; t < DW_JOBS; ++t) ji += (int)blockIdx.x >= jobs.j[t].blk0;
   const DwJob& job = jobs.j[ji];
   const int blk = blockIdx.x - job.blk0;
   switch (job.nt) {
@@ -1036,9 +1037,16 @@ static int pc_fwd(int64_t n, const float* points, const int64_t* neighbors,
   return check_launch("xrd_point_color_fwd");
 }
 
-// blocks a job may use: its partials cost 128 x 16 NT floats per block, so the
-// short products (n rows) take fewer blocks than F_theta's (8 n rows)
-static int dw_cap(int64_t rows_per_point) { return rows_per_point > 1 ? 256 : 128; }
+// Blocks a job may use.  A block pays ~9 us before its first MFMA (dispatch,
+// job record, first rows from HBM) and a partial of 128 x 16 NT floats at the
+// end, so jobs get FEW, long blocks: the 12 products over n rows share one
+// round of the 512 resident blocks (2 a CU), F_theta's two over 8 n rows the
+// next, each in proportion to its cost per chunk (16 x 2 NT MFMAs + ~1.5 us of
+// staging ~ NT + 4).
+static int dw_cap(int nt, int64_t rows_per_point) {
+  if (rows_per_point > 1) return nt == 2 ? 219 : 293;    // weights 6 : 8
+  return nt == 8 ? 62 : nt == 3 ? 36 : nt == 2 ? 31 : 26;  // 12 : 7 : 6 : 5
+}
 
 struct DwPlan {
   DwJobs jobs;
@@ -1065,35 +1073,34 @@ static void dw_plan(int64_t n, const float* save_c, const float* save_h,
                     float* ops, DwPlan& p) {
   using F = PcFlat;
   const PcOps op(ops, n);
-  const int c1 = dw_cap(1), c8 = dw_cap(8);
   for (int i = 0; i < 5; ++i) {
     const float* gz = op.gz + (int64_t)i * n * 128;
     const float* hp = save_h + (int64_t)(i - 1) * n * 128;
-    if (i == 0)
-      p.add(n, c1, gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(0), 40, 0, F::pb(0),
-            0);
-    else if (i == 3) {
+    if (i == 0) {
+      p.add(n, dw_cap(3, 1), gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(0), 40, 0,
+            F::pb(0), 0);
+    } else if (i == 3) {
       // [e40 | h] -> 168 columns as two products (columns 0..39 with the bias,
       // columns 40..167 without: b_off -1)
-      p.add(n, c1, gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(3), 168, 0,
-            F::pb(3), 0);
-      p.add(n, c1, gz, hp, 128, nullptr, 0, 128, 8, F::pw(3) + 40, 168, 0, -1,
-            0);
+      p.add(n, dw_cap(3, 1), gz, op.e40, 40, nullptr, 0, 40, 3, F::pw(3), 168,
+            0, F::pb(3), 0);
+      p.add(n, dw_cap(8, 1), gz, hp, 128, nullptr, 0, 128, 8, F::pw(3) + 40,
+            168, 0, -1, 0);
+    } else {
+      p.add(n, dw_cap(8, 1), gz, hp, 128, nullptr, 0, 128, 8, F::pw(i), 128, 0,
+            F::pb(i), 0);
     }
-    else
-      p.add(n, c1, gz, hp, 128, nullptr, 0, 128, 8, F::pw(i), 128, 0, F::pb(i),
-            0);
-    p.add(n, c1, op.gh + (int64_t)i * n * 128, save_c, 32, nullptr, 0, 32, 2,
-          F::fcw(i), 32, 0, F::fcb(i), 0);
+    p.add(n, dw_cap(2, 1), op.gh + (int64_t)i * n * 128, save_c, 32, nullptr, 0,
+          32, 2, F::fcw(i), 32, 0, F::fcb(i), 0);
   }
   // output layer and F_theta's second layer: the 128-wide operand is G, the
   // product comes out transposed
-  p.add(n, c1, save_h + 4 * n * 128, op.go, 4, nullptr, 0, 3, 1, F::OW, 128, 1,
-        F::OB, 1);
-  p.add(8 * n, c8, op.fh, op.fgy, 32, nullptr, 0, 32, 2, F::W2, 128, 1, F::B2,
-        1);
-  p.add(8 * n, c8, op.fga, op.fx, 52, nullptr, 0, 52, 4, F::W1, 52, 0, F::B1,
-        0);
+  p.add(n, dw_cap(1, 1), save_h + 4 * n * 128, op.go, 4, nullptr, 0, 3, 1,
+        F::OW, 128, 1, F::OB, 1);
+  p.add(8 * n, dw_cap(2, 8), op.fh, op.fgy, 32, nullptr, 0, 32, 2, F::W2, 128,
+        1, F::B2, 1);
+  p.add(8 * n, dw_cap(4, 8), op.fga, op.fx, 52, nullptr, 0, 52, 4, F::W1, 52, 0,
+        F::B1, 0);
 }
 
 template <int PW>
