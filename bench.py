@@ -1407,14 +1407,23 @@ def main():
             # not a product path)
             'torch_gpu_baseline': torch_gpu,
         }
+        # (secondary legs: a failure is recorded, it must not lose the line)
         if world == 1 and args.ingest == 'resident' and not args.no_others:
-            out['config']['ingest_files_fps'] = _ingest_files_leg(
-                cfg, cam, dev, cad)
+            try:
+                out['config']['ingest_files_fps'] = _ingest_files_leg(
+                    cfg, cam, dev, cad)
+            except Exception as e:
+                out['config']['ingest_files_fps'] = None
+                out['config']['ingest_files_error'] = \
+                    f'{type(e).__name__}: {str(e)[:200]}'
         if world == 1 and not args.no_coslam:
             # the second algorithm the north star names, same frame loop
             co_args = argparse.Namespace(**vars(args))
             co_args.first_iters = None
-            co = run_coslam(co_args, dev, not args.no_cpu_baseline)
+            try:
+                co = run_coslam(co_args, dev, not args.no_cpu_baseline)
+            except Exception as e:
+                co = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
             out['co_slam'] = co
         if world == 1 and not args.no_others:
             # BASELINE configs[2..4] in the same (driver-run) line, each on a
@@ -1432,7 +1441,7 @@ def main():
                 try:
                     res = fn(a2, dev)
                 except Exception as e:   # one leg must not lose the line
-                    res = {'error': f'{type(e).__name__}: {e}'}
+                    res = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
                 res.update({'steps': steps, 'warmup': warm,
                             'leg_wall_s': time.perf_counter() - t_leg})
                 if first is not None:

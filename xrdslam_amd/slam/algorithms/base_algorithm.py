@@ -35,6 +35,16 @@ from ..engine.optimizers import OptimizerConfig, Optimizers
 from ..models.base_model import ModelConfig
 
 
+def _capture(graph):
+    """hipGraph capture that other host threads cannot invalidate: the frame
+    prefetcher (data/datasets.Prefetcher) allocates pinned memory and issues
+    copies on its own stream while the tracker / mapper captures — legal, but
+    in torch's default 'global' capture mode any such call from ANY thread
+    ends the capture with hipErrorStreamCaptureInvalidated (seen in the
+    --ingest files leg of bench.py)."""
+    return torch.cuda.graph(graph, capture_error_mode='thread_local')
+
+
 @dataclass
 class AlgorithmConfig(InstantiateConfig):
     _target: Type = field(default_factory=lambda: Algorithm)
@@ -368,7 +378,7 @@ class Algorithm:
                 self._iteration(opt, [sf], False, step, n_iters, False, track)
             elif slot['graph'] is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     self._iteration(opt, [sf], False, step, n_iters, False,
                                     track)
                 slot['graph'] = g
@@ -478,7 +488,7 @@ class Algorithm:
                     if gen is not None and hasattr(
                             ga, 'register_generator_state'):
                         ga.register_generator_state(gen)
-                    with torch.cuda.graph(ga):
+                    with _capture(ga):
                         self._iteration(opt, sfs, True, step, n_iters, coarse,
                                         None, part='grad')
                     ga.replay()
@@ -486,7 +496,7 @@ class Algorithm:
                         opt.stepping_parameters(step))
                     _dist.run_grad_jobs(jobs)
                     gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb):
+                    with _capture(gb):
                         self._iteration(opt, sfs, True, step, n_iters, coarse,
                                         None, part='step')
                     gb.replay()
@@ -526,7 +536,7 @@ class Algorithm:
                                     None)
                 else:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with _capture(g):
                         self._iteration(opt, sfs, True, step, n_iters, coarse,
                                         None)
                     graphs[k] = g
@@ -633,7 +643,7 @@ class Algorithm:
                         if gen is not None and hasattr(
                                 graph, 'register_generator_state'):
                             graph.register_generator_state(gen)
-                        with torch.cuda.graph(graph):
+                        with _capture(graph):
                             self._iteration(*args, step, n_iters, coarse,
                                             track, part='grad')
                         graph.replay()
@@ -641,7 +651,7 @@ class Algorithm:
                             optimizers.stepping_parameters(step))
                         _dist.run_grad_jobs(jobs)
                         graph_b = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph_b):
+                        with _capture(graph_b):
                             self._iteration(*args, step, n_iters, coarse,
                                             track, part='step')
                         graph_b.replay()
@@ -663,7 +673,7 @@ class Algorithm:
                                         track)
                     elif graph is None:
                         graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph):
+                        with _capture(graph):
                             self._iteration(optimizers, optimize_frames,
                                             is_mapping, step, n_iters, coarse,
                                             track)

@@ -23,7 +23,7 @@ from ...engine import dist as _dist
 from ..common.common import get_rays, get_samples
 from ..engine.optimizers import Optimizers
 from ..models.joint_encoding import JointEncodingConfig
-from .base_algorithm import Algorithm, AlgorithmConfig
+from .base_algorithm import Algorithm, AlgorithmConfig, _capture
 
 
 @dataclass
@@ -446,7 +446,7 @@ class CoSLAM(Algorithm):
                                     None)
                 else:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with _capture(g):
                         self._iteration(opt, frames, True, step, n_iters,
                                         False, None)
                     graphs[k] = g
