@@ -35,14 +35,32 @@ from ..engine.optimizers import OptimizerConfig, Optimizers
 from ..models.base_model import ModelConfig
 
 
-def _capture(graph):
-    """hipGraph capture that other host threads cannot invalidate: the frame
-    prefetcher (data/datasets.Prefetcher) allocates pinned memory and issues
-    copies on its own stream while the tracker / mapper captures — legal, but
-    in torch's default 'global' capture mode any such call from ANY thread
-    ends the capture with hipErrorStreamCaptureInvalidated (seen in the
-    --ingest files leg of bench.py)."""
-    return torch.cuda.graph(graph, capture_error_mode='thread_local')
+class _capture(torch.cuda.graph):
+    """hipGraph capture context of the frame loops: ``torch.cuda.graph`` with
+    two changes.
+
+    * capture mode 'thread_local': the frame prefetcher
+      (data/datasets.Prefetcher) allocates pinned memory and issues copies on
+      its own stream while the tracker / mapper captures — legal, but in the
+      default 'global' mode any such call from ANY thread ends the capture
+      with hipErrorStreamCaptureInvalidated (seen in the --ingest files leg of
+      bench.py).
+    * no ``torch.cuda.empty_cache()`` in front of the capture.  The stock
+      context returns every cached block to the driver "to free memory for the
+      graph"; SplaTAM and Point-SLAM capture three times per FRAME, and every
+      tensor of the next phase then went through hipMalloc again (measured:
+      the 1600-point keyframe selection right after the tracking capture
+      took 10-27 ms, of which the arithmetic is < 1 ms).  The capture's own
+      allocations come from the graph's private pool either way."""
+
+    def __init__(self, graph):
+        super().__init__(graph, capture_error_mode='thread_local')
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self.stream_ctx.__enter__()
+        self.cuda_graph.capture_begin(
+            *self.pool, capture_error_mode=self.capture_error_mode)
 
 
 @dataclass

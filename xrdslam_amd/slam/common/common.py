@@ -187,22 +187,37 @@ def get_rays(camera, c2w, device):
     return rays_o, rays_d
 
 
-def get_pointcloud(depth, camera, c2w, sampled_indices):
-    """world points of the pixels ``sampled_indices`` [n,2] = (row, col),
-    camera looking down +z; points that coincide with the camera origin
-    (rounded to 1e-4) are dropped (common.py:313-339)"""
+def _pointcloud_rows(depth, camera, c2w, sampled_indices):
+    """-> (world points [n,3] of the pixels ``sampled_indices`` [n,2] =
+    (row, col), camera looking down +z; keep [n]: False for the rows the
+    reference drops).  The reference appends the origin to
+    |round(points, 4)|, takes ``unique(dim=0)`` with counts and drops every row
+    whose rounded value occurs more than once (common.py:313-339): i.e. rows
+    that coincide with the camera origin or with ANOTHER sampled row.  The same
+    set comes out of an all-pairs comparison of the n <= 1600 rows — three
+    elementwise launches; ``unique(dim=0)`` (a lexicographic device sort),
+    ``round(decimals=)`` and ``isin`` cost ~20 ms EACH per call on the GPU
+    (measured: 44 ms of a 95 ms SplaTAM frame went into this selection)."""
     xx = (sampled_indices[:, 1] - camera.cx) / camera.fx
     yy = (sampled_indices[:, 0] - camera.cy) / camera.fy
     z = depth[sampled_indices[:, 0], sampled_indices[:, 1]]
     pts_cam = torch.stack((xx * z, yy * z, z), -1)
     pts4 = torch.cat([pts_cam, torch.ones_like(pts_cam[:, :1])], 1)
     pts = (c2w.to(pts4) @ pts4.T).T[:, :3]
-    rounded = torch.abs(torch.round(pts, decimals=4))
-    origin = torch.zeros(1, 3, device=pts.device, dtype=pts.dtype)
-    _, idx, counts = torch.cat([rounded, origin], 0).unique(
-        dim=0, return_inverse=True, return_counts=True)
-    dup = torch.isin(idx, torch.where(counts.gt(1))[0])[:len(rounded)]
-    return pts[~dup]
+    # torch.round(pts, decimals=4) = nearbyint(x * 1e4) / 1e4
+    rounded = torch.abs(torch.round(pts * 1e4) / 1e4)
+    same = (rounded[:, None, :] == rounded[None, :, :]).all(-1)
+    dup = (same.sum(1) > 1) | (rounded == 0).all(1)
+    return pts, ~dup
+
+
+def get_pointcloud(depth, camera, c2w, sampled_indices):
+    """world points of the pixels ``sampled_indices`` [n,2] = (row, col),
+    camera looking down +z; points that coincide with the camera origin or
+    with another sampled point (rounded to 1e-4) are dropped
+    (common.py:313-339)"""
+    pts, keep = _pointcloud_rows(depth, camera, c2w, sampled_indices)
+    return pts[keep]
 
 
 def setup_camera(camera, w2c, near=0.01, far=100, device='cuda'):
@@ -240,6 +255,7 @@ def keyframe_selection_overlap(camera, cur_frame, keyframes_graph, k,
     if len(keyframes_graph) == 0:
         return []
     H, W = camera.height, camera.width
+    keep = None
     if use_ray_sample:
         rays_o, rays_d, gd, _ = get_samples(camera, pixs_per_image,
                                             cur_frame.get_pose(),
@@ -254,15 +270,33 @@ def keyframe_selection_overlap(camera, cur_frame, keyframes_graph, k,
     else:
         # SplaTAM branch (:373-387): back-projected valid-depth pixels, camera
         # looking down +z, no x flip
-        depth = torch.as_tensor(cur_frame.depth).to(device)
+        # (the frame's device-resident depth; the dropped rows travel as a
+        # mask: no compaction, no size read-back)
+        if torch.device(device).type == 'cuda':
+            depth = cur_frame.device_images(device)[0].reshape(H, W)
+        else:
+            depth = torch.as_tensor(cur_frame.depth).to(device)
         valid = torch.stack(torch.where(depth > 0), 1)
         pick = valid[torch.randint(valid.shape[0],
                                    (pixs_per_image * N_samples, )).to(device)]
-        pts = get_pointcloud(depth, camera, cur_frame.get_pose().to(device),
-                             pick)
+        pts, keep = _pointcloud_rows(depth, camera,
+                                     cur_frame.get_pose().to(device), pick)
     c2ws = torch.stack([kf.get_pose().detach().to(device)
                         for kf in keyframes_graph])
-    w2c = torch.linalg.inv(c2ws.double())
+    if c2ws.is_cuda:
+        # rigid inverse [R^T | -R^T t] in f64 (three elementwise launches): the
+        # poses come out of OptimizablePose (unit quaternion / axis-angle), so
+        # it equals the LU inverse to ~1e-7 — far inside the 20 px margin of
+        # the test below — while torch.linalg.inv on the device is a batched
+        # LU with a status read-back (several ms per mapping call)
+        c64 = c2ws.double()
+        Rt = c64[:, :3, :3].transpose(1, 2)
+        w2c = torch.zeros_like(c64)
+        w2c[:, :3, :3] = Rt
+        w2c[:, :3, 3] = -(Rt @ c64[:, :3, 3:4]).squeeze(-1)
+        w2c[:, 3, 3] = 1.0
+    else:
+        w2c = torch.linalg.inv(c2ws.double())
     homo = torch.cat([pts.double(), torch.ones_like(pts[:, :1]).double()], 1)
     cam = torch.einsum('kij,nj->kni', w2c, homo)[..., :3]
     if use_ray_sample:
@@ -274,7 +308,11 @@ def keyframe_selection_overlap(camera, cur_frame, keyframes_graph, k,
     edge = 20
     inside = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge) & \
         ((zc < 0) if use_ray_sample else (zc > 0))
-    percent = inside.float().mean(1).cpu().numpy()
+    if keep is None:
+        percent = inside.float().mean(1)
+    else:   # the mean over the kept rows
+        percent = (inside & keep).float().sum(1) / keep.float().sum()
+    percent = percent.cpu().numpy()
     order = np.argsort(-percent, kind='stable')
     selected = [keyframes_graph[a] for a in order if percent[a] > 0.0]
     perm = np.random.permutation(len(selected))[:k]
