@@ -260,10 +260,18 @@ def test_point_cloud_and_camera_frame_helpers_match_reference():
     idx = torch.stack([torch.randint(0, 48, (200,), generator=g),
                        torch.randint(0, 64, (200,), generator=g)], 1)
     c2w = torch.eye(4)                  # origin at 0 so the filter triggers
+    # rows the reference's unique(dim=0)-with-counts drops BOTH copies of: the
+    # same pixel drawn twice, and two pixels mirrored about the optical axis
+    # with equal depth (it compares |round(p, 4)|)
+    idx[0] = idx[1] = torch.tensor([20, 30])
+    idx[2], idx[3] = torch.tensor([25, 10]), torch.tensor([25, 53])
+    depth[25, 10] = depth[25, 53] = 1.25
     ref = rc.get_pointcloud(depth, rcam, c2w, idx)
     mine = mc.get_pointcloud(depth, cam, c2w, idx)
-    assert ref.shape == mine.shape and ref.shape[0] < 200
+    assert ref.shape == mine.shape and ref.shape[0] < 200 - 4
     assert torch.allclose(ref, mine)
+    _, keep = mc._pointcloud_rows(depth, cam, c2w, idx)
+    assert not keep[:4].any() and int(keep.sum()) == ref.shape[0]
     w2c = torch.linalg.inv(_pose(3))
     pts = torch.randn(50, 3, generator=g)
     a = rh.get_depth_and_silhouette(pts, w2c)
