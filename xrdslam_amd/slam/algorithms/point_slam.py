@@ -121,6 +121,10 @@ class PointSLAM(Algorithm):
         self.model.model_update(inp)
         if cfg.mapping_frustum_feature_selection:
             self.model.masked_indices = self.get_mask_from_c2w(c2w, depth)
+        # the per-frame radius cache served the tracking and the mapping call
+        # of this frame; the query radii live on in dynamic_r_query_allkeyframe
+        # (a keyframe must not pin 2.4 MB of add radii for the whole run)
+        cur_frame._dynamic_radius = None
 
     def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
         pass
