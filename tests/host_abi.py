@@ -1,0 +1,168 @@
+"""TEST INFRASTRUCTURE ONLY — never imported by the product path.
+
+A host-side stand-in for the C-ABI library object: the entry points the
+``compat`` shims call are evaluated on HOST pointers by the oracles
+(oracle/tcnn_oracle.py; oracle/svo_oracle.c through tests/svo_util.py), every
+other symbol (level tables, sizes, the host C++ octree) goes to the real
+``libxrdslam_hip.so``.  With it the shims run unchanged on CPU tensors, so the
+REFERENCE's own model code can be executed end to end on top of
+``xrdslam_amd.compat`` in the build container: what is exercised is the shim
+modules and the call protocol of the boundary (argument order, dtypes, who
+allocates what, accumulate-or-overwrite) — the kernels behind the same entry
+points are what the ``-m gpu`` suites check against the same goldens.
+
+    with host_abi.installed():   # patches xrdslam_amd._lib.lib / stream_ptr
+        ...
+"""
+import contextlib
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(os.path.dirname(HERE), 'oracle'), HERE]
+import svo_util  # noqa: E402
+import tcnn_oracle as to  # noqa: E402
+
+
+def _addr(p):
+    if p is None:
+        return 0
+    if isinstance(p, int):
+        return p
+    return int(p.value or 0)
+
+
+def _view(p, shape, ctype=C.c_float):
+    """numpy view of host memory at pointer ``p`` (0 elements: empty array)"""
+    n = int(np.prod(shape))
+    dt = np.dtype(ctype)
+    if n == 0:
+        return np.zeros(shape, dt)
+    a = _addr(p)
+    assert a, 'null pointer for a non-empty array'
+    return np.ctypeslib.as_array(C.cast(a, C.POINTER(ctype)),
+                                 shape=(n, )).reshape(shape)
+
+
+def _levels(n_levels, scales, res, sizes, offsets):
+    sc = _view(scales, (n_levels, ))
+    rs, sz, of = (_view(p, (n_levels, ), C.c_uint32)
+                  for p in (res, sizes, offsets))
+    lv = [(float(a), int(b), int(c), int(d))
+          for a, b, c, d in zip(sc, rs, sz, of)]
+    return lv, int(of[-1]) + int(sz[-1])
+
+
+class HostAbi:
+    """proxy of the ctypes library: oracle-backed compute entry points"""
+
+    def __init__(self, real):
+        self._real = real
+        self.calls = []          # names of the compute entry points used
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    # -- tiny-cuda-nn encodings ------------------------------------------------
+    def xrd_hashgrid_fwd(self, n_levels, scales, res, sizes, offsets, n, x,
+                         params, y, stream):
+        self.calls.append('xrd_hashgrid_fwd')
+        lv, total = _levels(n_levels, scales, res, sizes, offsets)
+        xt = torch.from_numpy(_view(x, (n, 3)))
+        pt = torch.from_numpy(_view(params, (total * 2, )))
+        _view(y, (n, 2 * n_levels))[...] = \
+            to.hashgrid_forward(xt, pt, lv).numpy()
+        return 0
+
+    def xrd_hashgrid_bwd(self, n_levels, scales, res, sizes, offsets, n, x,
+                         params, dy, dparams, dx, stream):
+        self.calls.append('xrd_hashgrid_bwd')
+        lv, total = _levels(n_levels, scales, res, sizes, offsets)
+        want_p, want_x = bool(_addr(dparams)), bool(_addr(dx))
+        xt = torch.from_numpy(_view(x, (n, 3)).copy()).requires_grad_(want_x)
+        pt = torch.from_numpy(_view(params, (total * 2, )).copy()) \
+            .requires_grad_(want_p)
+        g = torch.from_numpy(_view(dy, (n, 2 * n_levels)).copy())
+        with torch.enable_grad():
+            to.hashgrid_forward(xt, pt, lv).backward(g)
+        if want_p:      # the header: dparams is ACCUMULATED into
+            _view(dparams, (total * 2, ))[...] += pt.grad.numpy()
+        if want_x:
+            _view(dx, (n, 3))[...] = xt.grad.numpy()
+        return 0
+
+    def xrd_oneblob_fwd(self, n, dims, n_bins, x, y, stream):
+        self.calls.append('xrd_oneblob_fwd')
+        xt = torch.from_numpy(_view(x, (n, dims)))
+        _view(y, (n, dims * n_bins))[...] = \
+            to.oneblob_forward(xt, n_bins).numpy()
+        return 0
+
+    def xrd_oneblob_bwd(self, n, dims, n_bins, x, dy, dx, stream):
+        self.calls.append('xrd_oneblob_bwd')
+        xt = torch.from_numpy(_view(x, (n, dims)).copy()).requires_grad_(True)
+        g = torch.from_numpy(_view(dy, (n, dims * n_bins)).copy())
+        with torch.enable_grad():
+            to.oneblob_forward(xt, n_bins).backward(g)
+        _view(dx, (n, dims))[...] = xt.grad.numpy()
+        return 0
+
+    # -- sparse_voxels `grid` kernels ------------------------------------------
+    def xrd_svo_intersect(self, B, N, M, voxelsize, n_max, shared, ray_start,
+                          ray_dir, points, children, idx, mn, mx, hits,
+                          stream):
+        self.calls.append('xrd_svo_intersect')
+        pshape = (N, 3) if shared else (B, N, 3)
+        cshape = (N, 9) if shared else (B, N, 9)
+        pts = _view(points, pshape)
+        ch = _view(children, cshape, C.c_int32)
+        if shared:      # one octree for every batch row
+            pts = np.repeat(pts[None], B, axis=0)
+            ch = np.repeat(ch[None], B, axis=0)
+        o_idx, o_mn, o_mx, _ = svo_util.svo_intersect_oracle(
+            np.ascontiguousarray(_view(ray_start, (B, M, 3))),
+            np.ascontiguousarray(_view(ray_dir, (B, M, 3))),
+            np.ascontiguousarray(pts), np.ascontiguousarray(ch),
+            float(voxelsize), int(n_max))
+        _view(idx, (B, M, n_max), C.c_int32)[...] = o_idx
+        _view(mn, (B, M, n_max))[...] = o_mn
+        _view(mx, (B, M, n_max))[...] = o_mx
+        return 0
+
+    def xrd_inverse_cdf_sampling(self, G, R, P, S, fixed_step, pts_idx,
+                                 min_depth, max_depth, noise, probs, steps,
+                                 sidx, sdep, sdis, stream):
+        self.calls.append('xrd_inverse_cdf_sampling')
+        a = [np.ascontiguousarray(_view(pts_idx, (G, R, P), C.c_int32)),
+             np.ascontiguousarray(_view(min_depth, (G, R, P))),
+             np.ascontiguousarray(_view(max_depth, (G, R, P))),
+             np.ascontiguousarray(_view(noise, (G, R, S))),
+             np.ascontiguousarray(_view(probs, (G, R, P))),
+             np.ascontiguousarray(_view(steps, (G, R)))]
+        o_idx, o_dep, o_dis = svo_util.inverse_cdf_oracle(*a,
+                                                          float(fixed_step))
+        _view(sidx, (G, R, S), C.c_int32)[...] = o_idx
+        _view(sdep, (G, R, S))[...] = o_dep
+        _view(sdis, (G, R, S))[...] = o_dis
+        return 0
+
+
+@contextlib.contextmanager
+def installed():
+    """route xrdslam_amd._lib through the host backend (and drop the stream
+    argument: there is no HIP stream on this box)"""
+    from xrdslam_amd import _lib
+    real_lib, real_stream = _lib.lib, _lib.stream_ptr
+    proxy = HostAbi(real_lib())
+    _lib.lib = lambda: proxy
+    _lib.stream_ptr = lambda device=None: None
+    _lib.host_backend = proxy
+    try:
+        yield proxy
+    finally:
+        _lib.lib, _lib.stream_ptr = real_lib, real_stream
+        _lib.host_backend = None

@@ -142,3 +142,34 @@ def test_every_entry_point_survives_null_arguments():
             assert r == 0, (name, r)
         else:
             assert r in (1, 3), (name, r)
+
+
+def test_shims_refuse_host_tensors_without_the_test_backend():
+    """the package never sets the test seam (_lib.host_backend), and without
+    it the shims fail loudly on host tensors: no CPU path in the product"""
+    import pytest
+    import torch
+    assert _lib.host_backend is None
+    from xrdslam_amd.compat import grid
+    from xrdslam_amd.compat import tinycudann as tcnn
+    enc = tcnn.Encoding(3, {'otype': 'OneBlob', 'n_bins': 16})
+    with pytest.raises(_lib.XrdError):
+        enc(torch.rand(4, 3))
+    z = torch.zeros(1, 4, 3)
+    with pytest.raises(RuntimeError):
+        grid.svo_intersect(z, z, torch.zeros(1, 8, 3),
+                           torch.zeros(1, 8, 9, dtype=torch.int32), 0.2, 10)
+    import subprocess
+    import sys
+    r = subprocess.run(['grep', '-rn', 'host_backend', '--include=*.py',
+                        os.path.join(ROOT, 'xrdslam_amd'),
+                        os.path.join(ROOT, 'bench.py'),
+                        os.path.join(ROOT, '__graft_entry__.py')],
+                       capture_output=True, text=True)
+    users = sorted({l.split(':')[0][len(ROOT) + 1:]
+                    for l in r.stdout.splitlines()})
+    # defined in _lib.py, read by the two shims, assigned nowhere
+    assert users == ['xrdslam_amd/_lib.py', 'xrdslam_amd/compat/grid.py',
+                     'xrdslam_amd/compat/tinycudann.py']
+    assert not [l for l in r.stdout.splitlines()
+                if 'host_backend =' in l and '_lib.py' not in l]

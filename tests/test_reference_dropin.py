@@ -5,7 +5,15 @@ TorchScript seam, csrc_torch/svo_class.cpp), the ``grid`` and ``tinycudann``
 import names.  Runs in a subprocess (the compiled reference octree of
 tests/test_octree.py registers the same ``svo`` class name in its process).
 No kernel runs here (CPU container); the GPU suites exercise the kernels
-behind the same shims."""
+behind the same shims.
+
+``test_reference_models_execute_on_the_shims`` goes one step further: the
+reference's ``JointEncoding`` and ``SparseVoxel`` run forward, losses and
+backward THROUGH the shims, with the C-ABI's compute entry points served by a
+host backend (tests/host_abi.py: the oracles on host pointers), and reproduce
+the committed goldens — the ones the HIP kernels are checked against on the
+GPU.  Reference code -> shim -> boundary protocol is executed here; boundary
+-> kernels there."""
 import json
 import os
 import subprocess
@@ -38,6 +46,30 @@ def test_reference_models_run_on_the_shims():
     assert out['co_n_decoder'] == 5184
     assert out['co_n_table'] == 1640944
     assert out['tcnn_module'] == 'xrdslam_amd.compat.tinycudann'
+
+
+def test_reference_models_execute_on_the_shims():
+    r = subprocess.run([sys.executable,
+                        os.path.join(HERE, 'dropin_exec_probe.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines()
+            if l.startswith('DROPIN_EXEC ')][-1]
+    out = json.loads(line[12:])
+    # Co-SLAM: tracking, mapping and first-frame mapping calls of the
+    # reference's JointEncoding on compat.tinycudann; every output, loss term
+    # and gradient equals the golden the reference produced on the oracle
+    # encodings (same arithmetic behind the boundary: exact)
+    assert out['coslam_calls'] == ['xrd_hashgrid_bwd', 'xrd_hashgrid_fwd',
+                                   'xrd_oneblob_bwd', 'xrd_oneblob_fwd']
+    for tag, (name, err) in out['coslam_worst'].items():
+        assert err < 1e-6, (tag, name, err)
+    # Vox-Fusion: the reference's SparseVoxel on torch.classes.svo (octree
+    # arrays equal the compiled reference's) and compat.grid
+    assert out['vox_calls'] == ['xrd_inverse_cdf_sampling',
+                                'xrd_svo_intersect']
+    assert out['vox_rays_hit'] == 280
+    assert out['vox_worst'][1] < 1e-5, out['vox_worst']
 
 
 def test_svo_class_matches_python_shim():

@@ -15,7 +15,7 @@ from .. import _lib
 
 
 def _check(t, name, dtype):
-    if not t.is_cuda:
+    if not t.is_cuda and _lib.host_backend is None:
         raise RuntimeError(f'{name} must be a CUDA tensor')
     if not t.is_contiguous():
         raise RuntimeError(f'{name} must be a contiguous tensor')

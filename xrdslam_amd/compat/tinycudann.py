@@ -136,7 +136,7 @@ class Encoding(nn.Module):
         return [int(r) for r in self._res]
 
     def forward(self, x):
-        if not x.is_cuda:
+        if not x.is_cuda and _lib.host_backend is None:
             raise _lib.XrdError('tinycudann shim: CUDA tensors only '
                                 '(no CPU fallback)')
         if self.otype == 'OneBlob':
