@@ -155,4 +155,40 @@ with host_abi.installed() as abi:
     out['vox_worst'] = [k, verr[k]]
     out['vox_rays_hit'] = int(res['ray_mask'].sum())
     out['vox_calls'] = sorted(set(abi.calls))
+    abi.calls.clear()
+
+    # ---- Point-SLAM: slam/models/conv_onet_pointslam.py + neural_point_cloud
+    # on compat.faiss — the golden's own generation procedure
+    # (oracle/make_golden_pointslam.py: two frames of point insertion, renders
+    # in both stages, tracking and mapping losses, all gradients), with the
+    # faiss stand-in swapped for the shim; everything it would have written is
+    # compared with the committed file
+    import faiss as faiss_mod
+    assert faiss_mod.__name__ == 'xrdslam_amd.compat.faiss'
+    import make_golden_pointslam as mg
+    import pointslam_golden_util as pgu
+    mg.faiss_standin.module = lambda: faiss_mod
+    captured = {}
+    real_save = np.savez_compressed
+    np.savez_compressed = lambda path, **kw: captured.update(kw)
+    try:
+        mg.main()
+    finally:
+        np.savez_compressed = real_save
+    g = np.load(pgu.GOLDEN)
+    assert sorted(captured) == sorted(g.files)
+    perr = {}
+    for k in g.files:
+        a, b = np.asarray(captured[k]), g[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if b.dtype == bool or np.issubdtype(b.dtype, np.integer):
+            perr[k] = float((a != b).sum())
+        else:
+            perr[k] = rel(a, b)
+    k = max(perr, key=perr.get)
+    out['point_worst'] = [k, perr[k]]
+    out['point_keys'] = len(perr)
+    out['point_cloud'] = [int(captured['add0/cloud'].shape[0]),
+                          int(captured['add1/cloud'].shape[0])]
+    out['point_calls'] = sorted(set(abi.calls))
 print('DROPIN_EXEC ' + json.dumps(out))

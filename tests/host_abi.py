@@ -151,6 +151,72 @@ class HostAbi:
         return 0
 
 
+    # -- Point-SLAM neighbour search (exact, brute force behind the grid API) ---
+    def xrd_knn_cell_ids(self, n, points, origin, cell, dims, cell_ids,
+                         stream):
+        self.calls.append('xrd_knn_cell_ids')
+        p = _view(points, (n, 3))
+        o = _view(origin, (3, ))
+        d = _view(dims, (3, ), C.c_int32)
+        inv = np.float32(1.0) / np.float32(cell)
+        c = np.floor((p - o[None]) * inv).astype(np.int64)
+        c = np.clip(c, 0, d[None].astype(np.int64) - 1)
+        _view(cell_ids, (n, ), C.c_int64)[...] = \
+            (c[:, 2] * d[1] + c[:, 1]) * d[0] + c[:, 0]
+        return 0
+
+    def xrd_knn_cell_ranges(self, n, sorted_ids, start, end, stream):
+        self.calls.append('xrd_knn_cell_ranges')
+        ids = _view(sorted_ids, (n, ), C.c_int64)
+        # (the caller's arrays are pre-zeroed and sized by the grid: only the
+        # occupied cells are written, like the kernel)
+        first = np.flatnonzero(np.r_[True, ids[1:] != ids[:-1]])
+        last = np.r_[first[1:], n]
+        for c, a, b in zip(ids[first], first, last):
+            C.cast(_addr(start), C.POINTER(C.c_int32))[int(c)] = int(a)
+            C.cast(_addr(end), C.POINTER(C.c_int32))[int(c)] = int(b)
+        return 0
+
+    def xrd_knn_search_count(self, m, queries, sorted_points, sorted_ids,
+                             origin, cell, dims, cell_start, cell_end, k,
+                             max_radius, out_d2, out_idx, radius_q, radius_all,
+                             n_within, stream):
+        self.calls.append('xrd_knn_search_count')
+        d = _view(dims, (3, ), C.c_int32)
+        ncell = int(d[0]) * int(d[1]) * int(d[2])
+        n = int(_view(cell_end, (ncell, ), C.c_int32).max())
+        q = _view(queries, (m, 3))
+        pts = _view(sorted_points, (n, 3))
+        ids = _view(sorted_ids, (n, ), C.c_int32).astype(np.int64)
+        D = np.full((m, k), np.finfo(np.float32).max, np.float32)
+        I = np.full((m, k), -1, np.int64)
+        diff = q[:, None, :] - pts[None, :, :]
+        d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + \
+            diff[..., 2] * diff[..., 2]
+        lim = np.float32(max_radius) * np.float32(max_radius)
+        for r in range(m):
+            ok = np.flatnonzero(d2[r] <= lim)
+            order = ok[np.lexsort((ids[ok], d2[r][ok]))][:k]
+            D[r, :order.size] = d2[r][order]
+            I[r, :order.size] = ids[order]
+        _view(out_d2, (m, k))[...] = D
+        _view(out_idx, (m, k), C.c_int64)[...] = I
+        if _addr(n_within):
+            rq = _view(radius_q, (m, )) if _addr(radius_q) else \
+                np.full(m, np.float32(radius_all), np.float32)
+            _view(n_within, (m, ), C.c_int32)[...] = \
+                ((D < (rq * rq)[:, None]) & (I >= 0)).sum(1)
+        return 0
+
+    def xrd_knn_search(self, m, queries, sorted_points, sorted_ids, origin,
+                       cell, dims, cell_start, cell_end, k, max_radius, out_d2,
+                       out_idx, stream):
+        return self.xrd_knn_search_count(
+            m, queries, sorted_points, sorted_ids, origin, cell, dims,
+            cell_start, cell_end, k, max_radius, out_d2, out_idx, None, 0.0,
+            None, stream)
+
+
 @contextlib.contextmanager
 def installed():
     """route xrdslam_amd._lib through the host backend (and drop the stream

@@ -168,8 +168,9 @@ def test_shims_refuse_host_tensors_without_the_test_backend():
                        capture_output=True, text=True)
     users = sorted({l.split(':')[0][len(ROOT) + 1:]
                     for l in r.stdout.splitlines()})
-    # defined in _lib.py, read by the two shims, assigned nowhere
-    assert users == ['xrdslam_amd/_lib.py', 'xrdslam_amd/compat/grid.py',
+    # defined in _lib.py, read by the three shims, assigned nowhere
+    assert users == ['xrdslam_amd/_lib.py', 'xrdslam_amd/compat/faiss.py',
+                     'xrdslam_amd/compat/grid.py',
                      'xrdslam_amd/compat/tinycudann.py']
     assert not [l for l in r.stdout.splitlines()
                 if 'host_backend =' in l and '_lib.py' not in l]

@@ -8,8 +8,8 @@ No kernel runs here (CPU container); the GPU suites exercise the kernels
 behind the same shims.
 
 ``test_reference_models_execute_on_the_shims`` goes one step further: the
-reference's ``JointEncoding`` and ``SparseVoxel`` run forward, losses and
-backward THROUGH the shims, with the C-ABI's compute entry points served by a
+reference's ``JointEncoding``, ``SparseVoxel`` and Point-SLAM ``ConvOnet2`` run
+forward, losses and backward THROUGH the shims, with the C-ABI's compute entry points served by a
 host backend (tests/host_abi.py: the oracles on host pointers), and reproduce
 the committed goldens — the ones the HIP kernels are checked against on the
 GPU.  Reference code -> shim -> boundary protocol is executed here; boundary
@@ -70,6 +70,14 @@ def test_reference_models_execute_on_the_shims():
                                 'xrd_svo_intersect']
     assert out['vox_rays_hit'] == 280
     assert out['vox_worst'][1] < 1e-5, out['vox_worst']
+    # Point-SLAM: the golden's whole generation procedure (the reference's
+    # ConvOnet2 / NeuralPointCloud / decoders: two frames of point insertion,
+    # renders in both stages, tracking and mapping losses, all gradients) on
+    # compat.faiss; all 256 arrays of the committed file
+    assert out['point_calls'] == ['xrd_knn_cell_ids', 'xrd_knn_cell_ranges',
+                                  'xrd_knn_search_count']
+    assert out['point_keys'] == 256 and out['point_cloud'] == [519, 858]
+    assert out['point_worst'][1] < 1e-5, out['point_worst']
 
 
 def test_svo_class_matches_python_shim():

@@ -16,6 +16,7 @@ import os
 import numpy as np
 import torch
 
+from .. import _lib
 from ..engine.knn import GridKNN
 
 METRIC_L2 = 1
@@ -43,8 +44,10 @@ class IndexIVFFlat:
 
     def _index(self):
         if self._knn is None:
+            # (host tensors only under the test seam of _lib, see there)
+            dev = self._device if _lib.host_backend is None else 'cpu'
             self._knn = GridKNN(float(os.environ.get('XRD_KNN_RADIUS', 0.16)),
-                                self._device)
+                                dev)
         return self._knn
 
     @property

@@ -100,13 +100,16 @@ class GridKNN:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
+        # (the count output is not optional in the kernel; the scratch keeps a
+        # name so that it outlives the call)
+        within = cnt if cnt is not None else torch.empty(
+            m, dtype=torch.int32, device=self.device)
         _lib.check(lib.xrd_knn_search_count(
             m, _lib.ptr(q), _lib.ptr(self._sorted_pts),
             _lib.ptr(self._sorted_ids), self._origin.ctypes.data,
             self.max_radius, self._dims.ctypes.data, _lib.ptr(self._start),
             _lib.ptr(self._end), k, self.max_radius, _lib.ptr(D), _lib.ptr(I),
-            _lib.ptr(rq), r_all, _lib.ptr(cnt) if cnt is not None else
-            _lib.ptr(torch.empty(m, dtype=torch.int32, device=self.device)),
+            _lib.ptr(rq), r_all, _lib.ptr(within),
             _lib.stream_ptr(self.device)), 'xrd_knn_search_count')
         if PROFILE is not None:
             e1.record()
