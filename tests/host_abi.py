@@ -220,15 +220,30 @@ class HostAbi:
 @contextlib.contextmanager
 def installed():
     """route xrdslam_amd._lib through the host backend (and drop the stream
-    argument: there is no HIP stream on this box)"""
+    argument: there is no HIP stream on this box).  The product shims refuse
+    host tensors unconditionally; every switch that lets the reference's model
+    code reach this backend with host tensors is patched HERE, for the
+    duration of the block, and nowhere inside ``xrdslam_amd/``."""
     from xrdslam_amd import _lib
+    from xrdslam_amd.compat import faiss as c_faiss
+    from xrdslam_amd.compat import grid as c_grid
+    from xrdslam_amd.compat import tinycudann as c_tcnn
     real_lib, real_stream = _lib.lib, _lib.stream_ptr
+    real = (c_grid._require_device, c_tcnn._require_device,
+            c_faiss.index_cpu_to_gpu)
     proxy = HostAbi(real_lib())
     _lib.lib = lambda: proxy
     _lib.stream_ptr = lambda device=None: None
-    _lib.host_backend = proxy
+    c_grid._require_device = lambda t, name: None
+    c_tcnn._require_device = lambda x: None
+
+    def host_index(resource, device_id, index):
+        index._device = 'cpu'
+        return index
+    c_faiss.index_cpu_to_gpu = host_index
     try:
         yield proxy
     finally:
         _lib.lib, _lib.stream_ptr = real_lib, real_stream
-        _lib.host_backend = None
+        (c_grid._require_device, c_tcnn._require_device,
+         c_faiss.index_cpu_to_gpu) = real

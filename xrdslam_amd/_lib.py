@@ -11,11 +11,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxrdslam_hip.so')
 
 _lib = None
-# TEST SEAM, never set by the package: tests/host_abi.py installs an
-# oracle-backed proxy of the library here (and as ``lib()``) to execute the
-# reference's model code on the shims in the GPU-less build container.  The
-# shims refuse host tensors unless it is set.
-host_backend = None
 
 c_float_p = C.c_void_p  # raw device pointers are passed as integers
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p

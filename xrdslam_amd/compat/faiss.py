@@ -44,10 +44,8 @@ class IndexIVFFlat:
 
     def _index(self):
         if self._knn is None:
-            # (host tensors only under the test seam of _lib, see there)
-            dev = self._device if _lib.host_backend is None else 'cpu'
             self._knn = GridKNN(float(os.environ.get('XRD_KNN_RADIUS', 0.16)),
-                                dev)
+                                self._device)
         return self._knn
 
     @property

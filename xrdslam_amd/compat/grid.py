@@ -14,9 +14,13 @@ import torch
 from .. import _lib
 
 
-def _check(t, name, dtype):
-    if not t.is_cuda and _lib.host_backend is None:
+def _require_device(t, name):
+    if not t.is_cuda:
         raise RuntimeError(f'{name} must be a CUDA tensor')
+
+
+def _check(t, name, dtype):
+    _require_device(t, name)
     if not t.is_contiguous():
         raise RuntimeError(f'{name} must be a contiguous tensor')
     if t.dtype != dtype:

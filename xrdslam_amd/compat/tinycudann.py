@@ -136,12 +136,16 @@ class Encoding(nn.Module):
         return [int(r) for r in self._res]
 
     def forward(self, x):
-        if not x.is_cuda and _lib.host_backend is None:
-            raise _lib.XrdError('tinycudann shim: CUDA tensors only '
-                                '(no CPU fallback)')
+        _require_device(x)
         if self.otype == 'OneBlob':
             return _OneBlobFn.apply(x, self.n_bins)
         return _HashGridFn.apply(x, self.params, self)
+
+
+def _require_device(x):
+    if not x.is_cuda:
+        raise _lib.XrdError('tinycudann shim: CUDA tensors only '
+                            '(no CPU fallback)')
 
 
 class Network(nn.Module):
