@@ -76,9 +76,12 @@ def test_rasterizer_matches_oracle(N, H, W, iso):
     assert m2d.grad[:, 2].abs().max() == 0
 
 
-def _big_scene(N, seed):
+def _big_scene(N, seed, aniso_every=0):
     """640x480 SplaTAM-shaped view (BASELINE configs[3]): N isotropic
-    Gaussians of a few pixels radius spread over the frustum in depth 1-4 m"""
+    Gaussians of a few pixels radius spread over the frustum in depth 1-4 m;
+    ``aniso_every`` = k > 0 turns every k-th Gaussian into an anisotropic one
+    with a random orientation (the rotation gradient of an isotropic Gaussian
+    is identically zero)"""
     H, W, fx = 480, 640, 320.0
     g = torch.Generator().manual_seed(seed)
     z = 1.0 + 3.0 * torch.rand(N, generator=g)
@@ -90,6 +93,12 @@ def _big_scene(N, seed):
     sc = (0.004 + 0.012 * torch.rand(N, 1, generator=g)).repeat(1, 3) * \
         z[:, None] / 2.0
     rot = torch.tensor([[1.0, 0, 0, 0]]).repeat(N, 1)
+    if aniso_every:
+        k = aniso_every
+        sc[::k] = sc[::k] * (0.5 + 1.5 * torch.rand(sc[::k].shape,
+                                                   generator=g))
+        q = torch.randn(rot[::k].shape, generator=g)
+        rot[::k] = q / q.norm(dim=-1, keepdim=True)
     w2c = torch.eye(4)
     near, far = 0.01, 100.0
     cx, cy = 319.5, 239.5
@@ -105,12 +114,15 @@ def test_rasterizer_at_baseline_shape_vs_oracle_crops():
     """640x480, 120 000 Gaussians (BASELINE configs[3]: SplaTAM renders the
     whole image of ~4e5 Gaussians per pass; the dense oracle is O(N H W), so
     it evaluates six 32x32 crops): colour, depth and — with a loss that weights
-    only the crops' pixels — every gradient.  A fifth of the Gaussians have
-    opacity 0.999, so alpha saturates at 0.99 near their centres: the
-    published backward passes the gradient through that clamp."""
+    only the crops' pixels — every gradient, the rotations' included (a third
+    of the Gaussians are anisotropic with random orientations so that it is
+    not identically zero).  A fifth of the Gaussians have opacity 0.999, so
+    alpha saturates at 0.99 near their centres: the published backward passes
+    the gradient through that clamp."""
     from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
     N = 120000
-    means, cols, op, sc, rot, view, full, tfx, tfy, H, W = _big_scene(N, 3)
+    means, cols, op, sc, rot, view, full, tfx, tfy, H, W = _big_scene(
+        N, 3, aniso_every=3)
     op[::5] = 0.999
     crops = [(0, 0), (304, 224), (608, 448), (96, 400), (512, 64), (320, 16)]
     gw = torch.Generator().manual_seed(9)
@@ -143,7 +155,8 @@ def test_rasterizer_at_baseline_shape_vs_oracle_crops():
         assert rel_err(got_c, C_ref.detach()) < 1e-4, (x0, y0)
         assert rel_err(got_d, D_ref.detach()) < 1e-4, (x0, y0)
     assert torch.equal(radii.cpu(), radii_ref)
-    names = ['means3D', 'colors', 'opacities', 'scales']
+    names = ['means3D', 'colors', 'opacities', 'scales', 'rotations']
+    assert len(names) == len(gl) == len(leaves)
     for name, a, b in zip(names, gl, leaves):
         assert float(b.grad.abs().max()) > 0, name
         assert rel_err(a.grad.cpu(), b.grad) < 1e-4, name

@@ -421,6 +421,16 @@ def test_fused_dense_adam_matches_torch_incl_skipped_parameters():
             a.grad, b.grad = g.clone(), g.clone()
         o_ref.step()
         o_mine.step()
+        if step in (1, 4):
+            # state_dict() in the middle of a run must leave the live state
+            # alone (torch returns the live per-parameter dicts; advisor
+            # finding, round 3): step, state_dict, step, state_dict again
+            mid = o_mine.state_dict()['state']
+            assert all(v['step'].dim() == 0 for v in mid.values())
+            for p in mine:
+                if o_mine.state[p]:
+                    assert o_mine.state[p]['step'].shape == (2, )
+                    assert o_mine.state[p]['step'].is_cuda
     torch.cuda.synchronize()
     for a, b in zip(ref, mine):
         assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a - b).abs().max()

@@ -168,6 +168,12 @@ class _Binning:
             total = int(tiles.sum().item()) if n > 0 else 0   # host sync
             if st is not None:
                 st['high'] = max(st.get('high', 0), total)
+        if st is not None and st.get('floor') is not None:
+            fn, ftotal = st['floor']
+            if abs(n - fn) <= 0.02 * max(fn, 1):
+                total = max(total, ftotal)       # see reserve()
+            else:
+                st['floor'] = None
         need = max(int(total * self.HEADROOM) + 1024, 1 << 16)
         if st is None:
             st = self.state[key] = {
@@ -178,6 +184,26 @@ class _Binning:
         if need > st['cap'] or need < st['cap'] // 3:
             st['cap'] = need
         return st['cap']
+
+    def reserve(self, dev, n, total):
+        """the caller KNOWS a view of these ``n`` Gaussians produces ``total``
+        pairs (SplaTAM sizes the list from the largest count over ALL frames
+        of the mapping window before any iteration is captured: a captured
+        iteration renders a different keyframe on every replay through the
+        same frozen list).  Holds as a floor while n stays within 2 %."""
+        need = max(int(total * self.HEADROOM) + 1024, 1 << 16)
+        key = str(dev)
+        st = self.state.get(key)
+        if st is None:
+            st = self.state[key] = {
+                'cap': need, 'n': n, 'event': None, 'last': None,
+                'last_cap': need, 'ws': None, 'high': total,
+                'peak': torch.zeros(1, dtype=torch.int64, device=dev),
+                'host': torch.zeros(1, dtype=torch.int64).pin_memory()}
+        st['floor'] = (n, total)
+        st['high'] = max(st.get('high', 0), total)
+        if need > st['cap']:
+            st['cap'] = need
 
     def workspace(self, dev, nbytes):
         st = self.state[str(dev)]
@@ -270,6 +296,30 @@ def _geometry(lib, cam, dev, st, m3, sc, rt, op):
     _BIN.report(dev, n, cap, n_keys)
     return depths, xy, conic_o, radii, ranges, plist, n_keys, \
         (cap, key_pos, offsets)
+
+
+def count_pairs(raster_settings, means3D, scales, rotations, opacities):
+    """number of (Gaussian, tile) pairs a render of this view would bin, as a
+    0-d int64 device tensor: the preprocess launch alone, no binning, no
+    blend, no host sync"""
+    lib = _lib.lib()
+    cam = _camera(raster_settings)
+    dev = means3D.device
+    st = _lib.stream_ptr(dev)
+    n = means3D.shape[0]
+    f = dict(dtype=torch.float32, device=dev)
+    i = dict(dtype=torch.int32, device=dev)
+    depths, xy = torch.empty(n, **f), torch.empty(n, 2, **f)
+    conic_o, radii = torch.empty(n, 4, **f), torch.empty(n, **i)
+    rect, tiles = torch.empty(n, 4, **i), torch.empty(n, **i)
+    _lib.check(lib.xrd_gs_preprocess(
+        C.byref(cam), n, _lib.ptr(means3D.detach().float().contiguous()),
+        _lib.ptr(scales.detach().float().contiguous()),
+        _lib.ptr(rotations.detach().float().contiguous()),
+        _lib.ptr(opacities.detach().float().contiguous()), _lib.ptr(depths),
+        _lib.ptr(xy), _lib.ptr(conic_o), _lib.ptr(radii), _lib.ptr(rect),
+        _lib.ptr(tiles), st), 'xrd_gs_preprocess')
+    return tiles.sum(dtype=torch.int64)
 
 
 # the blend: True = forward with per-bucket checkpoints + lane-per-Gaussian

@@ -296,6 +296,9 @@ class FusedDenseAdam(torch.optim.Optimizer):
         ``step`` as a 0-d float tensor (the shared device counters are
         expanded)"""
         sd = super().state_dict()
+        # torch hands back the LIVE per-parameter dicts (sd['state'][i] is
+        # self.state[p]): edit copies, never the running state
+        sd['state'] = {k: dict(v) for k, v in sd['state'].items()}
         for st in sd['state'].values():
             if 'step' in st:
                 st['step'] = st['step'].detach()[0].float().cpu()

@@ -53,10 +53,28 @@ class _capture(torch.cuda.graph):
       took 10-27 ms, of which the arithmetic is < 1 ms).  The capture's own
       allocations come from the graph's private pool either way."""
 
+    # the attributes of torch.cuda.graph this override touches (checked once
+    # per process; a torch that renamed them gets the stock context, which is
+    # slower here but correct)
+    _PRIVATE = ('stream_ctx', 'pool', 'cuda_graph', 'capture_error_mode')
+    _checked = None
+
     def __init__(self, graph):
         super().__init__(graph, capture_error_mode='thread_local')
+        if _capture._checked is None:
+            _capture._checked = all(hasattr(self, a) for a in self._PRIVATE)
+            if not _capture._checked:
+                import warnings
+                warnings.warn('torch.cuda.graph internals changed: graph '
+                              'captures use the stock context (empties the '
+                              'allocator cache before every capture)')
+            else:
+                import gc
+                gc.collect()    # once, like the stock context does per entry
 
     def __enter__(self):
+        if not _capture._checked:
+            return super().__enter__()
         torch.cuda.synchronize()
         self.stream_ctx.__enter__()
         self.cuda_graph.capture_begin(
@@ -316,11 +334,16 @@ class Algorithm:
                 track['c2w'].copy_(torch.where(better, cur, track['c2w']))
                 track['loss'].copy_(torch.where(better, lval, track['loss']))
                 track['valid'].logical_or_(better)
-        if loss.requires_grad:
+        if getattr(self, '_grads_assigned', False):
+            # a fused iteration computed the loss AND assigned every .grad
+            # (NiceSLAM._fused_map_step / _fused_track_step say so
+            # explicitly): nothing to back-propagate
+            self._grads_assigned = False
+        else:
+            # a loss that arrives detached by accident raises here, as in the
+            # reference loop
             loss.backward(retain_graph=(self.config.retain_graph and
                                         is_mapping))
-        # else: a fused iteration computed the loss AND assigned every .grad
-        # (NiceSLAM._fused_map_step): nothing to back-propagate
         self.post_processing(step, is_mapping, optimizers.optimizers,
                              coarse=coarse)
         if part == 'grad':

@@ -408,6 +408,7 @@ class NiceSLAM(Algorithm):
             for p, g in zip(params, slam_ops.pose_param_grads(g7, layout)):
                 if p.requires_grad:
                     p.grad = g
+        self._grads_assigned = True     # _iteration: no backward to run
         return loss
 
     def _fused_track_step(self, idx, imgs, quat, bound6, crop):
@@ -428,6 +429,7 @@ class NiceSLAM(Algorithm):
         g7 = slam_ops.sample_rays_poses_bwd(sctx, g_o, g_d)
         for p, g in zip(params, slam_ops.pose_param_grads(g7, layout)):
             p.grad = g
+        self._grads_assigned = True     # _iteration: no backward to run
         return loss
 
     fused_iteration = True  # use the fused launches when the batch shape is fixed

@@ -134,10 +134,38 @@ class SplaTAM(Algorithm):
             inp['w2c'] = torch.inverse(pose)
         return inp
 
+    def _graphs_ok(self, optimizers, is_mapping):
+        # bundle adjustment optimises the pose of the frame an iteration
+        # draws: a captured iteration would bake ONE frame's pose parameters
+        # in (the static frame slot carries images and a detached pose only)
+        if is_mapping and self.model.config.mapping_do_ba:
+            return False
+        return super()._graphs_ok(optimizers, is_mapping)
+
+    def _reserve_pair_list(self, frames):
+        """size the rasteriser's static (Gaussian, tile) pair list from the
+        LARGEST count over every frame of the window (one preparation +
+        preprocess launch per frame, one read-back) before the iterations are
+        captured: a replay renders a different keyframe through the frozen
+        list, and the eager iteration in front of the capture saw only one of
+        them.  The reference sizes every pass exactly (num_rendered)."""
+        cloud = self.model.gaussian_cloud
+        if cloud is None or not frames:
+            return
+        from ...compat import diff_gaussian_rasterization as dgr
+        dev = torch.device(self.device)
+        with torch.no_grad():
+            counts = [cloud.pair_count(f.get_pose().detach().to(dev))
+                      for f in frames]
+            total = int(torch.stack(counts).max().item())
+        dgr._BIN.reserve(dev, cloud.params['means3D'].shape[0], total)
+
     def optimize_update(self, n_iters, optimize_frames, is_mapping,
                         coarse=False):
+        self._window = optimize_frames if is_mapping else None
         out = super().optimize_update(n_iters, optimize_frames, is_mapping,
                                       coarse=coarse)
+        self._window = None
         if self.use_graphs and torch.device(self.device).type == 'cuda':
             from ...compat import diff_gaussian_rasterization as dgr
             dgr._BIN.check_replays(torch.device(self.device))
@@ -153,6 +181,9 @@ class SplaTAM(Algorithm):
     def pre_precessing(self, cur_frame, is_mapping):
         if is_mapping:
             self.model.model_update(cur_frame)
+            if self.use_graphs and torch.device(self.device).type == 'cuda' \
+                    and not self.model.config.mapping_do_ba:
+                self._reserve_pair_list(getattr(self, '_window', None))
 
     def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
         if is_mapping:

@@ -95,6 +95,17 @@ class GaussianCloud(nn.Module):
         self.variables.pop('seen', None)
         return {'rgb': im, 'depth_sil': depth_sil, 'depth': depth}
 
+    def pair_count(self, c2w):
+        """(Gaussian, tile) pairs a render from ``c2w`` would bin (0-d device
+        tensor; preparation + preprocess launches only)"""
+        from ...engine.gs import GsPrepareFn
+        p = self.params
+        with torch.no_grad():
+            pts, rot, opac, scales, _ = GsPrepareFn.apply(
+                p['means3D'], p['unnorm_rotations'], p['logit_opacities'],
+                p['log_scales'], c2w, self.first_frame_w2c, True, False, False)
+            return _dgr.count_pairs(self.gaussian_cam, pts, scales, rot, opac)
+
     # -- optimiser surgery -------------------------------------------------------
     def _reset_stats(self, n):
         for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius'):
