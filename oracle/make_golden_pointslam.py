@@ -8,6 +8,8 @@ tests/golden/pointslam_render.npz.
 
     python oracle/make_golden_pointslam.py          # the small case
     python oracle/make_golden_pointslam.py tum      # BASELINE configs[4]
+    python oracle/make_golden_pointslam.py tum64    # its f64 referee
+    python oracle/make_golden_pointslam.py small64  # f64 referee, small case
 
 ``tum``: the shapes of the reference's point-slam configuration
 (slam/configs/input_config.py:297-340: 1500 tracking rays, 5000 mapping rays,
@@ -16,6 +18,20 @@ neural points grown over two frames.  Inputs and feature draws are regenerated
 from seeds on both sides (tests/pointslam_golden_util.tum_inputs); the file
 holds the reference's outputs (gradients of the point features as the rows of
 a seeded subset + column sums) -> tests/golden/pointslam_tum.npz.
+
+``tum64``: the f64 REFEREE of the ``tum`` case.  The same reference classes,
+the same cloud (grown in f32, draw for draw), the same feature draws — but the
+three queries (geometry mapping, colour mapping, tracking) are evaluated in
+float64: parameters and features promoted, ``torch.set_default_dtype(float64)``
+and the reference's hard-coded ``.float()`` / ``dtype=torch.float`` casts
+redirected to float64 FOR THE DURATION OF THE QUERIES (patched here, in the
+harness; the reference tree is untouched), exact kNN on the f64 sample
+positions.  Two f32 evaluations of this path (torch on the CPU = the golden,
+the HIP kernels) differ from each other on the rays whose samples sit on a
+ReLU kink of the 32-wide decoder or on the query-radius cut; the referee tells
+which of the two is closer to the exact value and bounds the kernels' distance
+by the reference's own (tests/test_pointslam_hip.py) ->
+tests/golden/pointslam_tum_f64.npz (+ the f32 reference's distance to it).
 """
 import os
 import sys
@@ -240,8 +256,233 @@ def main_tum():
           {k2: float(v.detach()) for k2, v in ld.items()})
 
 
+class _Index64(faiss_standin.IndexIVFFlat):
+    """exact kNN on f64 queries, squared distances returned in f64"""
+
+    def search(self, x, k):
+        x = np.asarray(x, np.float64).reshape(-1, 3)
+        pts = self.pts.astype(np.float64)
+        m = x.shape[0]
+        D = np.full((m, k), 3.4028235e38, np.float64)
+        ids = np.full((m, k), -1, np.int64)
+        for a in range(0, m, 2048):
+            d2 = ((x[a:a + 2048, None, :] - pts[None, :, :])**2).sum(-1)
+            order = np.argsort(d2, axis=1, kind='stable')[:, :k]
+            D[a:a + 2048, :order.shape[1]] = np.take_along_axis(d2, order, 1)
+            ids[a:a + 2048, :order.shape[1]] = order
+        return D, ids
+
+
+def main_tum64():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import pointslam_golden_util as pg
+    ref_harness.install()
+    sys.modules['faiss'] = faiss_standin.module()
+    import slam.model_components.neural_point_cloud as npc_mod
+    npc_mod.faiss = sys.modules['faiss']
+    from slam.common.camera import Camera
+    from slam.models.conv_onet_pointslam import ConvOnet2, ConvOnet2Config
+    ConvOnet2.load_pretrain = lambda self: None  # LFS pointer only
+    torch.manual_seed(0)
+    model = ConvOnet2(ConvOnet2Config(), Camera(*pg.TUM_CAM))
+    gen = torch.Generator().manual_seed(pg.TUM_DRAW_SEED)
+    real_normal = torch.Tensor.normal_
+
+    def rec_normal(self, mean=0, std=1, **k):
+        # the SAME f32 draw whatever the tensor's dtype
+        t = torch.empty(self.shape, dtype=torch.float32)
+        real_normal(t, mean=mean, std=std, generator=gen)
+        self.copy_(t)
+        return self
+
+    g32 = np.load(os.path.join(GOLD, 'pointslam_tum.npz'))
+    out = {}
+    undo = None
+    torch.Tensor.normal_ = rec_normal
+    try:
+        for k in range(2):          # the cloud: f32, exactly the golden's
+            model.model_update(pg.tum_add_inputs(k))
+        npc = model.neural_point_cloud
+        assert len(npc._cloud_pos) == int(g32['add1/n_cloud'])
+        model.masked_indices = pg.tum_frustum_mask(npc.pts_num())
+        model.get_param_groups()
+        # the queries are drawn under the f32 default dtype (torch.rand under
+        # a float64 default draws different numbers)
+        queries = {m: pg.tum_query(m) for m in (True, False)}
+        # ---- from here on: float64 ------------------------------------
+        undo = _enter_f64(model, npc)
+        for tag, stage, is_mapping in (('map_geo', 'geometry', True),
+                                       ('map_col', 'color', True),
+                                       ('track', 'color', False)):
+            q = queries[is_mapping]
+            for p in model.parameters():
+                p.grad = None
+            npc.geo_feats.grad = npc.col_feats.grad = None
+            ro = q['o'].double().requires_grad_(True)
+            rd = q['d'].double().requires_grad_(True)
+            inp = {'rays_o': ro, 'rays_d': rd, 'target_s': q['color'].double(),
+                   'target_d': q['depth'].double().reshape(-1, 1),
+                   'stage': stage, 'batch_dynamic_r': q['r'].double()}
+            res = model.get_outputs(inp)
+            ld = model.get_loss_dict(res, inp, is_mapping, stage)
+            sum(ld.values()).backward()
+            assert res['depth'].dtype == torch.float64
+            assert ro.grad.dtype == torch.float64
+            vm = res['valid_ray_mask'].numpy()
+            out[f'{tag}/valid_ray_mask'] = vm
+            for k2 in ('rgb', 'depth', 'uncertainty'):
+                out[f'{tag}/{k2}'] = res[k2].detach().numpy()
+            for k2, v in ld.items():
+                out[f'{tag}/loss_{k2}'] = v.detach().numpy()
+            out[f'{tag}/g_rays_o'] = ro.grad.numpy()
+            out[f'{tag}/g_rays_d'] = rd.grad.numpy()
+            for name, t in (('g_geo', npc.geo_feats.grad),
+                            ('g_col', npc.col_feats.grad)):
+                if t is None or f'{tag}/{name}/rows' not in g32.files:
+                    continue
+                a = t.numpy()
+                assert a.dtype == np.float64
+                out[f'{tag}/{name}/rows'] = a[pg.subset(a.shape[0])].copy()
+                out[f'{tag}/{name}/colsum'] = a.sum(0)
+                out[f'{tag}/{name}/abssum'] = np.abs(a).sum(1)[
+                    pg.subset(a.shape[0], 7, 4000)]
+            for k2, p in model.decoder.named_parameters():
+                if p.grad is not None and f'{tag}/g_dec/{k2}' in g32.files:
+                    out[f'{tag}/g_dec/{k2}'] = p.grad.numpy().copy()
+    finally:
+        torch.Tensor.normal_ = real_normal
+        if undo is not None:
+            undo()
+    # the f32 reference's own distance to the referee, for the record
+    for k in sorted(out):
+        if k in g32.files and out[k].dtype == np.float64 and out[k].size:
+            a, b = np.asarray(g32[k], np.float64), out[k]
+            print(f'  f32 reference vs f64: {k:50s} '
+                  f'{np.abs(a - b).max() / max(np.abs(b).max(), 1e-30):.3e}')
+        elif k in g32.files:
+            print(f'  {k}: equal = {bool(np.array_equal(g32[k], out[k]))}')
+    path = os.path.join(GOLD, 'pointslam_tum_f64.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def _enter_f64(model, npc):
+    """promote the reference model to float64 and redirect its hard-coded
+    float32 casts; returns the undo function"""
+    real_float, real_f = torch.Tensor.float, torch.float
+    torch.set_default_dtype(torch.float64)
+    torch.Tensor.float = lambda self: self.double()
+    torch.float = torch.float64
+    model.double()
+    cd = model.decoder.color_decoder
+    cd.embedder._B = cd.embedder._B.double()
+    npc.double()                # geo_feats / col_feats are Parameters
+    assert npc.geo_feats.dtype == torch.float64
+    idx64 = _Index64(None, 3, 1)
+    idx64.pts, idx64.is_trained = npc.index.pts, True
+    npc.index = idx64
+
+    def undo():
+        torch.Tensor.float, torch.float = real_float, real_f
+        torch.set_default_dtype(torch.float32)
+    return undo
+
+
+def main_small64():
+    """f64 referee of the small case (pointslam_render.npz): inputs and draws
+    are read back from that file -> tests/golden/pointslam_render_f64.npz"""
+    ref_harness.install()
+    sys.modules['faiss'] = faiss_standin.module()
+    import slam.model_components.neural_point_cloud as npc_mod
+    npc_mod.faiss = sys.modules['faiss']
+    from slam.common.camera import Camera
+    from slam.models.conv_onet_pointslam import ConvOnet2, ConvOnet2Config
+    ConvOnet2.load_pretrain = lambda self: None  # LFS pointer only
+    g32 = np.load(os.path.join(GOLD, 'pointslam_render.npz'))
+    T = lambda k: torch.from_numpy(g32[k])  # noqa: E731
+    torch.manual_seed(0)
+    model = ConvOnet2(ConvOnet2Config(mapping_pixels_based_on_color_grad=40),
+                      Camera(40., 40., 31.5, 23.5, 64, 48))
+    for k, v in model.decoder.state_dict().items():
+        assert np.array_equal(v.numpy(), g32[f'dec/{k}']), k
+    draws = iter([T(f'draw{i}') for i in range(int(g32['n_draws']))])
+    real_normal = torch.Tensor.normal_
+
+    def replay_normal(self, mean=0, std=1, **k):
+        self.copy_(next(draws))     # the golden's own draws, in call order
+        return self
+
+    out = {}
+    undo = None
+    torch.Tensor.normal_ = replay_normal
+    try:
+        for k in range(2):
+            model.model_update({
+                'batch_rays_o': T(f'add{k}/o'), 'batch_rays_d': T(f'add{k}/d'),
+                'batch_gt_depth': T(f'add{k}/depth'),
+                'batch_gt_color': T(f'add{k}/color'),
+                'batch_dynamic_r': T(f'add{k}/r'),
+                'batch_rays_o_grad': T(f'add{k}/o2'),
+                'batch_rays_d_grad': T(f'add{k}/d2'),
+                'batch_gt_depth_grad': T(f'add{k}/depth2'),
+                'batch_gt_color_grad': T(f'add{k}/color2'),
+                'batch_dynamic_r_grad': T(f'add{k}/r2')})
+        npc = model.neural_point_cloud
+        assert np.array_equal(np.array(npc._cloud_pos, np.float32),
+                              g32['add1/cloud'])
+        model.masked_indices = T('frustum_mask')
+        model.get_param_groups()
+        undo = _enter_f64(model, npc)
+        for tag, stage, is_mapping in (('map_geo', 'geometry', True),
+                                       ('map_col', 'color', True),
+                                       ('track', 'color', False)):
+            for p in model.parameters():
+                p.grad = None
+            npc.geo_feats.grad = npc.col_feats.grad = None
+            ro = T('q/o').double().requires_grad_(True)
+            rd = T('q/d').double().requires_grad_(True)
+            inp = {'rays_o': ro, 'rays_d': rd,
+                   'target_s': T('q/color').double(),
+                   'target_d': T('q/depth').double().reshape(-1, 1),
+                   'stage': stage, 'batch_dynamic_r': T('q/r').double()}
+            res = model.get_outputs(inp)
+            ld = model.get_loss_dict(res, inp, is_mapping, stage)
+            sum(ld.values()).backward()
+            assert res['depth'].dtype == torch.float64
+            for k2 in ('rgb', 'depth', 'uncertainty', 'valid_ray_mask'):
+                out[f'{tag}/{k2}'] = res[k2].detach().numpy()
+            for k2, v in ld.items():
+                out[f'{tag}/loss_{k2}'] = v.detach().numpy()
+            out[f'{tag}/g_rays_o'] = ro.grad.numpy()
+            out[f'{tag}/g_rays_d'] = rd.grad.numpy()
+            out[f'{tag}/g_geo'] = npc.geo_feats.grad.numpy().copy()
+            if npc.col_feats.grad is not None:
+                out[f'{tag}/g_col'] = npc.col_feats.grad.numpy().copy()
+            for k2, p in model.decoder.named_parameters():
+                if p.grad is not None:
+                    out[f'{tag}/g_dec/{k2}'] = p.grad.numpy().copy()
+    finally:
+        torch.Tensor.normal_ = real_normal
+        if undo is not None:
+            undo()
+    worst = {}
+    for k in sorted(out):
+        if k in g32.files and out[k].dtype == np.float64 and out[k].size:
+            a, b = np.asarray(g32[k], np.float64), out[k]
+            worst[k] = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    for k in sorted(worst, key=worst.get)[-8:]:
+        print(f'  f32 reference vs f64: {k:55s} {worst[k]:.3e}')
+    path = os.path.join(GOLD, 'pointslam_render_f64.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'tum':
+    if len(sys.argv) > 1 and sys.argv[1] == 'small64':
+        main_small64()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'tum64':
+        main_tum64()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'tum':
         main_tum()
     else:
         main()

@@ -12,6 +12,11 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden',
 
 GOLDEN_TUM = os.path.join(os.path.dirname(__file__), 'golden',
                           'pointslam_tum.npz')
+GOLDEN_F64 = os.path.join(os.path.dirname(__file__), 'golden',
+                          'pointslam_render_f64.npz')
+# the same case evaluated in float64 by the reference's classes (the referee)
+GOLDEN_TUM_F64 = os.path.join(os.path.dirname(__file__), 'golden',
+                              'pointslam_tum_f64.npz')
 # TUM fr1 intrinsics, 640x480
 TUM_CAM = (517.3, 516.5, 318.6, 255.3, 640, 480)
 TUM_DRAW_SEED = 21
@@ -80,7 +85,8 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def run(g, device, knn_factory=None, freeze_fixed_decoders=False):
+def run(g, device, knn_factory=None, freeze_fixed_decoders=False,
+        outputs=None):
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.models.conv_onet_pointslam import (ConvOnet2,
                                                              ConvOnet2Config)
@@ -168,29 +174,32 @@ def run(g, device, knn_factory=None, freeze_fixed_decoders=False):
         res = model.get_outputs(inp)
         ld = model.get_loss_dict(res, inp, is_mapping, stage)
         sum(ld.values()).backward()
-        errs[f'{tag}/valid_ray_mask'] = float(np.any(
-            res['valid_ray_mask'].cpu().numpy() != g[f'{tag}/valid_ray_mask']))
+        got = {f'{tag}/valid_ray_mask': res['valid_ray_mask'].cpu().numpy()}
         for k2 in ('rgb', 'depth', 'uncertainty'):
-            errs[f'{tag}/{k2}'] = rel_err(res[k2].detach().cpu(),
-                                          g[f'{tag}/{k2}'])
+            got[f'{tag}/{k2}'] = res[k2].detach().cpu().numpy()
         for k2, v in ld.items():
-            errs[f'{tag}/loss_{k2}'] = rel_err(v.detach().cpu(),
-                                               g[f'{tag}/loss_{k2}'])
-        errs[f'{tag}/g_rays_o'] = rel_err(ro.grad.cpu(), g[f'{tag}/g_rays_o'])
-        errs[f'{tag}/g_rays_d'] = rel_err(rd.grad.cpu(), g[f'{tag}/g_rays_d'])
-        errs[f'{tag}/g_geo'] = rel_err(npc.geo_feats.grad.cpu(),
-                                       g[f'{tag}/g_geo'])
+            got[f'{tag}/loss_{k2}'] = v.detach().cpu().numpy()
+        got[f'{tag}/g_rays_o'] = ro.grad.cpu().numpy()
+        got[f'{tag}/g_rays_d'] = rd.grad.cpu().numpy()
+        got[f'{tag}/g_geo'] = npc.geo_feats.grad.cpu().numpy()
         if f'{tag}/g_col' in g.files:
-            errs[f'{tag}/g_col'] = rel_err(npc.col_feats.grad.cpu(),
-                                           g[f'{tag}/g_col'])
+            got[f'{tag}/g_col'] = npc.col_feats.grad.cpu().numpy()
         for k2, p in model.decoder.named_parameters():
             key = f'{tag}/g_dec/{k2}'
             if key in g.files and (p.grad is not None or p.requires_grad):
-                errs[key] = rel_err(p.grad.cpu(), g[key])
+                got[key] = p.grad.cpu().numpy()
+        if outputs is not None:
+            outputs.update(got)
+        for key, v in got.items():
+            if key.endswith('valid_ray_mask'):
+                errs[key] = float(np.any(v != g[key]))
+            else:
+                errs[key] = rel_err(v, g[key])
     return errs
 
 
-def run_tum(g, device, knn_factory=None, freeze_fixed_decoders=False):
+def run_tum(g, device, knn_factory=None, freeze_fixed_decoders=False,
+            outputs=None):
     """the TUM-shaped golden (BASELINE configs[4] shapes: 19 389 neural
     points, 5000 x 5 mapping / 1500 x 5 tracking samples): inputs and feature
     draws regenerated from seeds, outputs compared with the reference's"""
@@ -251,6 +260,7 @@ def run_tum(g, device, knn_factory=None, freeze_fixed_decoders=False):
                                     g['cloud_sum'])
     model.masked_indices = tum_frustum_mask(npc.pts_num()).to(device)
     model.get_param_groups()
+    got = {}
     for tag, stage, is_mapping in (('map_geo', 'geometry', True),
                                    ('map_col', 'color', True),
                                    ('track', 'color', False)):
@@ -266,42 +276,75 @@ def run_tum(g, device, knn_factory=None, freeze_fixed_decoders=False):
         res = model.get_outputs(inp)
         ld = model.get_loss_dict(res, inp, is_mapping, stage)
         sum(ld.values()).backward()
-        errs[f'{tag}/valid_ray_mask'] = float(np.any(
-            res['valid_ray_mask'].cpu().numpy() != g[f'{tag}/valid_ray_mask']))
+        got[f'{tag}/valid_ray_mask'] = res['valid_ray_mask'].cpu().numpy()
         for k2 in ('rgb', 'depth', 'uncertainty'):
-            errs[f'{tag}/{k2}'] = rel_err(res[k2].detach().cpu(),
-                                          g[f'{tag}/{k2}'])
+            got[f'{tag}/{k2}'] = res[k2].detach().cpu().numpy()
         for k2, v in ld.items():
-            errs[f'{tag}/loss_{k2}'] = rel_err(v.detach().cpu(),
-                                               g[f'{tag}/loss_{k2}'])
-        errs[f'{tag}/g_rays_o'] = rel_err(ro.grad.cpu(), g[f'{tag}/g_rays_o'])
-        errs[f'{tag}/g_rays_d'] = rel_err(rd.grad.cpu(), g[f'{tag}/g_rays_d'])
-        # '#frac': share of rows (rays / points) deviating by more than 1e-4
-        # of the largest entry (tests/parity.row_outliers)
-        for nm, got in (('g_rays_o', ro.grad), ('g_rays_d', rd.grad)):
-            want = np.asarray(g[f'{tag}/{nm}'], np.float64)
-            dev_ = np.abs(got.cpu().numpy() - want).max(1) / \
-                max(np.abs(want).max(), 1e-30)
-            errs[f'{tag}/{nm}#frac'] = float((dev_ > 1e-4).mean())
+            got[f'{tag}/loss_{k2}'] = v.detach().cpu().numpy()
+        got[f'{tag}/g_rays_o'] = ro.grad.cpu().numpy()
+        got[f'{tag}/g_rays_d'] = rd.grad.cpu().numpy()
         for name, t in (('g_geo', npc.geo_feats.grad),
                         ('g_col', npc.col_feats.grad)):
-            if f'{tag}/{name}/rows' not in g.files:
+            if t is None or f'{tag}/{name}/rows' not in g.files:
                 continue
             a = t.detach().cpu().numpy()
-            # scale of the whole gradient: the stored rows are a subset
-            big = float(np.abs(g[f'{tag}/{name}/rows']).max())
-            drow = np.abs(a[subset(a.shape[0])] -
-                          g[f'{tag}/{name}/rows']).max(1) / max(big, 1e-30)
-            errs[f'{tag}/{name}/rows'] = float(drow.max())
-            errs[f'{tag}/{name}/rows#frac'] = float((drow > 1e-4).mean())
-            errs[f'{tag}/{name}/colsum'] = rel_err(
-                a.astype(np.float64).sum(0), g[f'{tag}/{name}/colsum'])
-            errs[f'{tag}/{name}/abssum'] = rel_err(
-                np.abs(a.astype(np.float64)).sum(1)[subset(a.shape[0], 7,
-                                                            4000)],
-                g[f'{tag}/{name}/abssum'])
+            got[f'{tag}/{name}/rows'] = a[subset(a.shape[0])]
+            got[f'{tag}/{name}/colsum'] = a.astype(np.float64).sum(0)
+            got[f'{tag}/{name}/abssum'] = np.abs(a.astype(np.float64)).sum(
+                1)[subset(a.shape[0], 7, 4000)]
         for k2, p in model.decoder.named_parameters():
             key = f'{tag}/g_dec/{k2}'
             if key in g.files and (p.grad is not None or p.requires_grad):
-                errs[key] = rel_err(p.grad.cpu(), g[key])
+                got[key] = p.grad.cpu().numpy()
+    if outputs is not None:
+        outputs.update(got)
+    for tag in ('map_geo', 'map_col', 'track'):
+        errs[f'{tag}/valid_ray_mask'] = float(np.any(
+            got[f'{tag}/valid_ray_mask'] != g[f'{tag}/valid_ray_mask']))
+        for key in sorted(got):
+            if not key.startswith(tag + '/') or key.endswith('valid_ray_mask'):
+                continue
+            if key.endswith('/rows'):
+                # scale of the whole gradient: the stored rows are a subset
+                big = float(np.abs(g[key]).max())
+                drow = np.abs(got[key] - g[key]).max(1) / max(big, 1e-30)
+                errs[key] = float(drow.max())
+                errs[key + '#frac'] = float((drow > 1e-4).mean())
+                continue
+            errs[key] = rel_err(got[key], g[key])
+            if key.endswith('g_rays_o') or key.endswith('g_rays_d'):
+                # '#frac': share of rows (rays / points) deviating by more
+                # than 1e-4 of the largest entry (tests/parity.row_outliers)
+                want = np.asarray(g[key], np.float64)
+                dev_ = np.abs(got[key] - want).max(1) / \
+                    max(np.abs(want).max(), 1e-30)
+                errs[key + '#frac'] = float((dev_ > 1e-4).mean())
     return errs
+
+
+def referee(got, ref32, ref64, tol=1e-4):
+    """kernel outputs ``got`` judged against the f64 evaluation ``ref64`` of
+    the reference (oracle/make_golden_pointslam.py tum64), with the f32
+    reference ``ref32``'s own distance to it as the yardstick.  Returns
+    {key: (kernel_vs_f64, ref32_vs_f64[, frac_kernel, frac_ref32, rows])}:
+    max-norm relative deviations; for per-row arrays (ray gradients, point
+    feature gradient rows, per-ray renders) also the share of rows further
+    than ``tol`` of the largest entry from the f64 value."""
+    out = {}
+    for key in sorted(got):
+        if key not in ref64.files or key.endswith('valid_ray_mask'):
+            continue
+        t = np.asarray(ref64[key], np.float64)
+        a = np.asarray(got[key], np.float64)
+        b = np.asarray(ref32[key], np.float64)
+        scale = max(np.abs(t).max(), 1e-30)
+        if t.ndim >= 1 and t.shape[0] >= 1000:
+            da = np.abs(a - t).reshape(t.shape[0], -1).max(1) / scale
+            db = np.abs(b - t).reshape(t.shape[0], -1).max(1) / scale
+            out[key] = (float(da.max()), float(db.max()),
+                        float((da > tol).mean()), float((db > tol).mean()),
+                        t.shape[0])
+        else:
+            out[key] = (float(np.abs(a - t).max() / scale),
+                        float(np.abs(b - t).max() / scale))
+    return out

@@ -18,25 +18,49 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def referee_verdict(ref, tol=TOL):
+    """the bar of pg.referee()'s numbers: the kernels may be as far from the
+    f64 value as 2 x the f32 reference itself is (and never need to be closer
+    than 1e-4); of per-row arrays at most 1.5 x the reference's share of rows
+    (+ 2 rows) may sit further than 1e-4 from it — rows where an f32
+    evaluation falls on the other side of a ReLU kink / the radius cut"""
+    bad = {}
+    for k, v in ref.items():
+        if not v[0] <= max(tol, 2.0 * v[1]):
+            bad[k] = v
+        elif len(v) > 2 and not v[2] <= 1.5 * v[3] + 2.0 / v[4]:
+            bad[k + '#frac'] = v
+    return bad
+
+
 @pytest.mark.parametrize('freeze', [False, True])
 def test_point_slam_model_vs_reference(freeze):
     """freeze=False: the modular operators, every gradient of the reference;
     freeze=True (the engine's default): the geometry path on its fused
-    kernels (xrd_point_geo_*), the fixed geometry decoder without gradients"""
-    g = np.load(pg.GOLDEN)
-    errs = pg.run(g, 'cuda:0', freeze_fixed_decoders=freeze)
+    kernels (xrd_point_geo_*), the fixed geometry decoder without gradients.
 
-    def tol(k):
-        if k.startswith('track/') and ('g_dec' in k or 'loss' in k):
-            # the tracking loss divides by sqrt(rendered variance), a sum of
-            # w (z - depth)^2 over 5 samples within 2 % of the depth: its
-            # rounding (torch on the CPU for the golden, torch on the GPU
-            # here) is amplified into the loss (1.2e-4 measured) and the
-            # geometry-decoder gradients (up to 4.8e-4).  Everything else, the ray
-            # gradients through the 1/d^2 weights included, holds 1e-4.
-            return 5e-4
-        return TOL
-    bad = {k: v for k, v in errs.items() if not v < tol(k)}
+    Everything holds 1e-4 against the f32 golden except the quantities behind
+    the tracking loss's division by sqrt(rendered variance) — those are judged
+    by the f64 referee (oracle/make_golden_pointslam.py small64: the
+    reference's classes in float64 on the same cloud and draws):
+    |kernel - f64| <= max(1e-4, 2 |reference_f32 - f64|)."""
+    g = np.load(pg.GOLDEN)
+    g64 = np.load(pg.GOLDEN_F64)
+    got = {}
+    errs = pg.run(g, 'cuda:0', freeze_fixed_decoders=freeze, outputs=got)
+    ref = pg.referee(got, g, g64)
+    report = os.environ.get('XRD_PARITY_REPORT')
+    if report:
+        with open(report, 'a') as f:
+            for k, v in sorted(ref.items()):
+                f.write(f'pointslam_small_f64/freeze={int(freeze)}/{k} '
+                        f'kernel-vs-f64 {v[0]:.3e} reference_f32-vs-f64 '
+                        f'{v[1]:.3e} kernel-vs-reference_f32 '
+                        f'{errs.get(k, float("nan")):.3e}\n')
+    bad = {k: (v, ref.get(k)) for k, v in errs.items()
+           if not v < TOL and k not in ref}
+    assert not bad, bad
+    bad = referee_verdict(ref)
     assert not bad, bad
 
 
@@ -48,35 +72,42 @@ def test_point_slam_model_vs_reference_tum_shapes(freeze):
     ConvOnet2 / NeuralPointCloud / POINT decoders
     (oracle/make_golden_pointslam.py tum): cloud growth, renders, losses and
     every gradient (point-feature gradients: 2000 seeded rows + column sums +
-    4000 row norms)."""
+    4000 row norms).
+
+    Two f32 evaluations of this path differ on the rays / points whose samples
+    sit on a ReLU kink of the 32-wide geometry decoder or on the query-radius
+    cut (the reference's own f32 result is 3.8e-2 of the largest ray gradient
+    away from its f64 evaluation on such a ray).  So every quantity is judged
+    by a REFEREE: the reference's classes evaluated in float64 on the same
+    cloud, draws and queries (``tum64``, tests/golden/pointslam_tum_f64.npz).
+    Bar: |kernel - f64| <= max(1e-4, 2 |reference_f32 - f64|) for every
+    array, and the share of rows further than 1e-4 from the f64 value at most
+    1.5 x the f32 reference's share.  Everything that is NOT such a row holds
+    1e-4 against the f32 golden as before (``#frac`` = 0 on the modular path;
+    on the fused geometry kernels the rows counted by the referee)."""
     g = np.load(pg.GOLDEN_TUM)
-    errs = pg.run_tum(g, 'cuda:0', freeze_fixed_decoders=freeze)
+    g64 = np.load(pg.GOLDEN_TUM_F64)
+    got = {}
+    errs = pg.run_tum(g, 'cuda:0', freeze_fixed_decoders=freeze, outputs=got)
+    ref = pg.referee(got, g, g64)
     report = os.environ.get('XRD_PARITY_REPORT')
     if report:
         with open(report, 'a') as f:
             for k, v in sorted(errs.items()):
                 f.write(f'pointslam_tum/freeze={int(freeze)}/{k} {v:.3e}\n')
-
-    def tol(k):
-        if k.endswith('#frac'):
-            # share of rays / points off by more than 1e-4: none on the
-            # modular operators; <= 1 % on the fused geometry kernels, whose
-            # MFMA chain rounds the 32-wide ReLU decoder's pre-activations
-            # differently from torch's GEMMs — measured: 0.13 % of the 25 000
-            # samples land on the other side of a ReLU kink (their occupancy
-            # agrees to 4e-5, their gradient jumps by one unit's share), the
-            # same phenomenon the NICE-SLAM decoders show (DESIGN.md 2)
-            return 0.01 if freeze else 1e-9
-        if freeze and ('g_rays' in k or '/rows' in k or 'abssum' in k or
-                       'colsum' in k):
-            # ... and those rows / the sums that contain them: bounded by a
-            # flipped unit's share of the largest gradient
-            return 0.15 if ('g_rays' in k or '/rows' in k) else 1e-2
-        if k.startswith('track/') and ('g_dec' in k or 'loss' in k):
-            return 5e-4   # see test_point_slam_model_vs_reference
-        return TOL
-    bad = {k: v for k, v in errs.items() if not v < tol(k)}
+            for k, v in sorted(ref.items()):
+                f.write(f'pointslam_tum_f64/freeze={int(freeze)}/{k} '
+                        f'kernel-vs-f64 {v[0]:.3e} reference_f32-vs-f64 '
+                        f'{v[1]:.3e}' + (f' rows>1e-4: kernel {v[2]:.4%} '
+                                         f'reference {v[3]:.4%}'
+                                         if len(v) > 2 else '') + '\n')
+    assert not any(errs[k] for k in errs if k.endswith('valid_ray_mask') or
+                   k.endswith('/count') or k.endswith('/n_input')), errs
+    bad = referee_verdict(ref)
     assert not bad, bad
+    # the exact-arithmetic parts (cloud growth) against the f32 golden
+    for k in ('cloud_rows', 'cloud_sum'):
+        assert errs[k] < TOL, (k, errs[k])
 
 
 def _pointslam_loop(use_graphs, frames):
