@@ -27,69 +27,75 @@ __global__ __launch_bounds__(256) void point_map_loss_kernel(
     const uint8_t* __restrict__ ray_valid, float coef, float w_color,
     int min_valid, float* __restrict__ loss, float* __restrict__ g_raw) {
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  // The per-ray arithmetic runs in f64 (S <= 16 samples a ray: free): behind
+  // a saturated sample 1 - alpha is a difference of nearly equal numbers and
+  // its f32 rounding (relative ~1e-3) lands in every later weight; the f64
+  // evaluation of the reference is the value two f32 evaluations scatter
+  // around (tests/test_pointslam_hip.py judges against it).
   float l_geo = 0.f, l_rgb = 0.f;
   if (ray < n) {
-    float alpha[kMaxS], T[kMaxS], w[kMaxS], z[kMaxS];
+    double alpha[kMaxS], T[kMaxS], w[kMaxS], z[kMaxS];
     int cnt = 0;
-    float run = 1.f, wsum = 0.f;
+    double run = 1.0, wsum = 0.0;
     for (int s = 0; s < S; ++s) {
       const bool has = point_mask[ray * S + s] != 0;
       cnt += has;
-      const float occ = has ? raw[(ray * S + s) * 4 + 3] : -100.f;
-      alpha[s] = 1.f / (1.f + expf(-(coef * occ)));
+      const double occ = has ? (double)raw[(ray * S + s) * 4 + 3] : -100.0;
+      alpha[s] = 1.0 / (1.0 + exp(-((double)coef * occ)));
       T[s] = run;
       w[s] = alpha[s] * run;
-      run = run * (1.f - alpha[s] + 1e-10f);
+      run = run * (1.0 - alpha[s] + 1e-10);
       wsum += w[s];
-      z[s] = z_vals[ray * S + s];
+      z[s] = (double)z_vals[ray * S + s];
     }
-    const float W = wsum + 1e-10f;
-    float A = 0.f;
+    const double W = wsum + 1e-10;
+    double A = 0.0;
     for (int s = 0; s < S; ++s) A += w[s] * z[s];
-    const float depth = A / W;
-    const float td = target_d[ray];
-    bool m = td > 0.f && cnt >= min_valid && !(depth != depth);
+    const double depth = A / W;
+    const double td = (double)target_d[ray];
+    bool m = td > 0.0 && cnt >= min_valid && !(depth != depth);
     if (ray_valid != nullptr) m = m && ray_valid[ray] != 0;
-    float col[3] = {0.f, 0.f, 0.f}, g_col[3] = {0.f, 0.f, 0.f};
+    double col[3] = {0.0, 0.0, 0.0}, g_col[3] = {0.0, 0.0, 0.0};
     const bool color = target_rgb != nullptr;
     if (color) {
       for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) col[c] += w[s] * raw[(ray * S + s) * 4 + c];
+        for (int c = 0; c < 3; ++c)
+          col[c] += w[s] * (double)raw[(ray * S + s) * 4 + c];
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[c] /= W;
     }
-    float g_depth = 0.f;
+    double g_depth = 0.0;
     if (m) {
-      const float e = td - depth;
-      l_geo = fabsf(e);
-      g_depth = e > 0.f ? -1.f : (e < 0.f ? 1.f : 0.f);
+      const double e = td - depth;
+      l_geo = (float)fabs(e);
+      g_depth = e > 0.0 ? -1.0 : (e < 0.0 ? 1.0 : 0.0);
       if (color) {
+        double lr = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float ec = target_rgb[ray * 3 + c] - col[c];
-          l_rgb += fabsf(ec);
-          g_col[c] = w_color * (ec > 0.f ? -1.f : (ec < 0.f ? 1.f : 0.f));
+          const double ec = (double)target_rgb[ray * 3 + c] - col[c];
+          lr += fabs(ec);
+          g_col[c] = (double)w_color * (ec > 0.0 ? -1.0 : (ec < 0.0 ? 1.0 : 0.0));
         }
-        l_rgb *= w_color;
+        l_rgb = (float)(lr * (double)w_color);
       }
     }
     // backward: g_w_s, then the transmittance chain from the last sample
-    float tail = 0.f;   // sum_{k > s} g_w_k w_k
+    double tail = 0.0;   // sum_{k > s} g_w_k w_k
     for (int s = S - 1; s >= 0; --s) {
-      float g_w = g_depth * (z[s] - depth) / W;
+      double g_w = g_depth * (z[s] - depth) / W;
       f32x4 out = {0.f, 0.f, 0.f, 0.f};
       if (color) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          g_w += g_col[c] * (raw[(ray * S + s) * 4 + c] - col[c]) / W;
-          out[c] = g_col[c] * w[s] / W;
+          g_w += g_col[c] * ((double)raw[(ray * S + s) * 4 + c] - col[c]) / W;
+          out[c] = (float)(g_col[c] * w[s] / W);
         }
       }
-      const float g_alpha =
-          g_w * T[s] - tail / (1.f - alpha[s] + 1e-10f);
+      const double g_alpha = g_w * T[s] - tail / (1.0 - alpha[s] + 1e-10);
       tail += g_w * w[s];
-      out[3] = g_alpha * coef * alpha[s] * (1.f - alpha[s]);
+      out[3] = (float)(g_alpha * (double)coef * alpha[s] * (1.0 - alpha[s]));
       *reinterpret_cast<f32x4*>(g_raw + (ray * S + s) * 4) = out;
     }
   }
@@ -449,9 +455,10 @@ extern "C" int xrd_point_track_loss(
 namespace xrd {
 namespace {
 
+// f64 per-ray arithmetic, see point_map_loss_kernel
 struct RayW {
-  float alpha[kMaxS], T[kMaxS], w[kMaxS], z[kMaxS];
-  float W, depth;
+  double alpha[kMaxS], T[kMaxS], w[kMaxS], z[kMaxS];
+  double W, depth;
 };
 
 __device__ __forceinline__ void ray_weights(int ray, int S,
@@ -460,18 +467,19 @@ __device__ __forceinline__ void ray_weights(int ray, int S,
                                             const uint8_t* __restrict__ pm,
                                             const float* __restrict__ z_vals,
                                             float coef, RayW& r) {
-  float run = 1.f, wsum = 0.f, A = 0.f;
+  double run = 1.0, wsum = 0.0, A = 0.0;
   for (int s = 0; s < S; ++s) {
     const bool has = pm == nullptr || pm[ray * S + s] != 0;
-    const float o = has ? occ[(int64_t)(ray * S + s) * occ_stride] : -100.f;
-    r.alpha[s] = 1.f / (1.f + expf(-(coef * o)));
+    const double o =
+        has ? (double)occ[(int64_t)(ray * S + s) * occ_stride] : -100.0;
+    r.alpha[s] = 1.0 / (1.0 + exp(-((double)coef * o)));
     r.T[s] = run;
     r.w[s] = r.alpha[s] * run;
-    run = run * (1.f - r.alpha[s] + 1e-10f);
+    run = run * (1.0 - r.alpha[s] + 1e-10);
     wsum += r.w[s];
-    r.z[s] = z_vals[ray * S + s];
+    r.z[s] = (double)z_vals[ray * S + s];
   }
-  r.W = wsum + 1e-10f;
+  r.W = wsum + 1e-10;
   for (int s = 0; s < S; ++s) A += r.w[s] * r.z[s];
   r.depth = A / r.W;
 }
@@ -486,20 +494,21 @@ __global__ __launch_bounds__(256) void point_composite_fwd_kernel(
   if (ray >= n) return;
   RayW r;
   ray_weights(ray, S, occ, occ_stride, pm, z_vals, coef, r);
-  depth[ray] = r.depth;
-  float v = 0.f, col[3] = {0.f, 0.f, 0.f};
+  depth[ray] = (float)r.depth;
+  double v = 0.0, col[3] = {0.0, 0.0, 0.0};
   for (int s = 0; s < S; ++s) {
-    const float t = r.z[s] - r.depth;
+    const double t = r.z[s] - r.depth;
     v += r.w[s] * t * t;
     if (rgb != nullptr) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        col[c] += r.w[s] * rgb[(int64_t)(ray * S + s) * rgb_stride + c];
+        col[c] +=
+            r.w[s] * (double)rgb[(int64_t)(ray * S + s) * rgb_stride + c];
     }
   }
-  var[ray] = v;
+  var[ray] = (float)v;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) color[ray * 3 + c] = col[c] / r.W;
+  for (int c = 0; c < 3; ++c) color[ray * 3 + c] = (float)(col[c] / r.W);
 }
 
 __global__ __launch_bounds__(256) void point_composite_bwd_kernel(
@@ -514,49 +523,51 @@ __global__ __launch_bounds__(256) void point_composite_bwd_kernel(
   if (ray >= n) return;
   RayW r;
   ray_weights(ray, S, occ, occ_stride, pm, z_vals, coef, r);
-  const float gd = g_depth ? g_depth[ray] : 0.f;
-  const float gv = g_var ? g_var[ray] : 0.f;
-  float gc[3] = {0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
+  const double gd = g_depth ? (double)g_depth[ray] : 0.0;
+  const double gv = g_var ? (double)g_var[ray] : 0.0;
+  double gc[3] = {0.0, 0.0, 0.0}, col[3] = {0.0, 0.0, 0.0};
   const bool color = rgb != nullptr && g_color != nullptr;
-  float S1 = 0.f;   // sum w (z - depth): d var / d depth = -2 S1
+  double S1 = 0.0;   // sum w (z - depth): d var / d depth = -2 S1
   for (int s = 0; s < S; ++s) {
     S1 += r.w[s] * (r.z[s] - r.depth);
     if (color) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        col[c] += r.w[s] * rgb[(int64_t)(ray * S + s) * rgb_stride + c];
+        col[c] +=
+            r.w[s] * (double)rgb[(int64_t)(ray * S + s) * rgb_stride + c];
     }
   }
   if (color) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       col[c] /= r.W;
-      gc[c] = g_color[ray * 3 + c];
+      gc[c] = (double)g_color[ray * 3 + c];
     }
   }
-  const float gdep = gd - 2.f * gv * S1;   // total gradient reaching depth
-  float tail = 0.f;
+  const double gdep = gd - 2.0 * gv * S1;   // total gradient reaching depth
+  double tail = 0.0;
   for (int s = S - 1; s >= 0; --s) {
-    const float t = r.z[s] - r.depth;
-    float g_w = gdep * t / r.W + gv * t * t;
+    const double t = r.z[s] - r.depth;
+    double g_w = gdep * t / r.W + gv * t * t;
     if (color) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float v = rgb[(int64_t)(ray * S + s) * rgb_stride + c];
+        const double v =
+            (double)rgb[(int64_t)(ray * S + s) * rgb_stride + c];
         g_w += gc[c] * (v - col[c]) / r.W;
         if (g_rgb != nullptr)
           g_rgb[(int64_t)(ray * S + s) * g_rgb_stride + c] =
-              gc[c] * r.w[s] / r.W;
+              (float)(gc[c] * r.w[s] / r.W);
       }
     } else if (g_rgb != nullptr) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         g_rgb[(int64_t)(ray * S + s) * g_rgb_stride + c] = 0.f;
     }
-    const float g_alpha = g_w * r.T[s] - tail / (1.f - r.alpha[s] + 1e-10f);
+    const double g_alpha = g_w * r.T[s] - tail / (1.0 - r.alpha[s] + 1e-10);
     tail += g_w * r.w[s];
     g_occ[(int64_t)(ray * S + s) * g_occ_stride] =
-        g_alpha * coef * r.alpha[s] * (1.f - r.alpha[s]);
+        (float)(g_alpha * (double)coef * r.alpha[s] * (1.0 - r.alpha[s]));
   }
 }
 
