@@ -71,6 +71,34 @@ FWD_FLOPS = {'coarse': 12.4e3, 'middle': 31.0e3, 'fine': 72.0e3,
              'color': 103.0e3}
 
 
+def calibrated(cpu, algo):
+    """attach the port-vs-reference calibration of the build container
+    (tools/cpu_reference_calibration.py -> profiles/
+    r04_cpu_reference_calibration.json: seconds of this ``kind: port`` code
+    over seconds of the REFERENCE's own PyTorch code on the same host, shapes
+    and thread count) to a cpu_baseline object, plus the reference rate it
+    implies on THIS host"""
+    if not cpu:
+        return cpu
+    try:
+        with open(os.path.join(ROOT, 'profiles',
+                               'r04_cpu_reference_calibration.json')) as f:
+            cal = json.load(f).get(algo)
+        ratio = float(cal['port_over_reference'])
+    except Exception:
+        cpu['port_over_reference'] = None
+        return cpu
+    cpu['port_over_reference'] = ratio
+    cpu['reference_estimate'] = {
+        'value': cpu['value'] * ratio, 'unit': cpu.get('unit', 'frames/s'),
+        'how': 'port rate x (port seconds / reference seconds) measured '
+               'once in the build container on the same shapes '
+               f'({cal["threads"]} threads there; profiles/'
+               'r04_cpu_reference_calibration.json): the reference tree '
+               'does not exist on the GPU box'}
+    return cpu
+
+
 def pmc_traffic(kernels, which='r03_pmc.json'):
     """bytes per launch of a launch group from the committed PMC pass
     (profiles/r02_pmc*.json, made by tools/run_pmc.sh on this same workload):
@@ -392,7 +420,8 @@ def run_coslam(args, dev, with_cpu, world=1):
             'ate_rmse_aligned_m': slam.trajectory_stats()[
                 'absolute_translational_error.rmse']},
         'roofline': roofline,
-        'cpu_baseline': co_cpu_baseline(min(16, os.cpu_count() or 1))
+        'cpu_baseline': calibrated(
+            co_cpu_baseline(min(16, os.cpu_count() or 1)), 'co-slam')
         if with_cpu else None}
 
 
@@ -661,7 +690,8 @@ def run_voxfusion(args, dev, world=1):
                              'timed region replays captured graphs)'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = vox_cpu_baseline(min(os.cpu_count() or 1, 16))
+        cpu = calibrated(vox_cpu_baseline(min(os.cpu_count() or 1, 16)),
+                         'vox-fusion')
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -823,46 +853,20 @@ def run_splatam(args, dev):
 
 
 def splatam_cpu_baseline(threads, n_gaussians, n_pixels):
-    """the torch oracle of the rasteriser (oracle/gs_oracle.py: a DENSE
-    per-pixel evaluation of every Gaussian, O(N H W) — the reference's
-    rasteriser is a CUDA-only dependency with no CPU path) forward+backward on
-    a bounded sample, scaled by N H W to the workload and by the 200 raster
-    passes of a frame"""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import gs_oracle as go
-    torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(0)
-    N, H, W, fx = 1500, 48, 64, 40.0
-    means = (torch.randn(N, 3, generator=g) * torch.tensor([0.8, 0.6, 0.5]) +
-             torch.tensor([0.0, 0.0, 2.5])).requires_grad_()
-    cols = torch.rand(N, 3, generator=g).requires_grad_()
-    op = (torch.rand(N, 1, generator=g) * 0.9 + 0.05).requires_grad_()
-    sc = (torch.rand(N, 1, generator=g) * 0.1 + 0.02).repeat(1, 3) \
-        .requires_grad_()
-    rot = torch.tensor([[1.0, 0, 0, 0]]).repeat(N, 1).requires_grad_()
-    near, far = 0.01, 100.0
-    proj = torch.tensor([[2 * fx / W, 0, 0, 0], [0, 2 * fx / H, 0, 0],
-                         [0, 0, far / (far - near),
-                          -(far * near) / (far - near)], [0, 0, 1, 0]])
-    view = torch.eye(4)
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 10.0 or reps < 2:
-        color, _, depth, _ = go.rasterize(means, cols, op, sc, rot, view,
-                                          proj.t().contiguous(), H, W,
-                                          W / (2 * fx), H / (2 * fx))
-        color.sum().backward()
-        reps += 1
-    t_pass = (time.perf_counter() - t0) / reps
-    scale = (n_gaussians * n_pixels) / float(N * H * W)
-    return {'value': 1.0 / (t_pass * scale * 200), 'unit': 'frames/s',
-            'cores': threads, 'kind': 'port',
-            'sample': f'{reps} forward+backward passes of the dense torch '
-                      f'oracle, {N} Gaussians x {W}x{H} pixels '
-                      f'({t_pass:.3f} s each); scaled by N*H*W to '
-                      f'{int(n_gaussians)} Gaussians x 640x480 and 200 '
-                      'passes per frame (the oracle evaluates every Gaussian '
-                      'at every pixel: it is a checker, not a rasteriser)'}
+    """no CPU baseline for SplaTAM: the reference's rasteriser
+    (diff-gaussian-rasterization-w-depth) is a CUDA-only dependency with no
+    CPU path, and the only CPU rasteriser in this repo is the parity checker
+    (oracle/gs_oracle.py: every Gaussian at every pixel, O(N H W)) — scaling
+    it by N H W (round 3: 3.7e-7 frames/s) measures the checker, not a
+    rasteriser.  The object keeps the contract's keys with value null."""
+    return {'value': None, 'unit': 'frames/s', 'cores': threads,
+            'kind': 'none',
+            'sample': 'not measured: the reference rasteriser is CUDA-only '
+                      '(no CPU path to time) and the dense parity checker '
+                      'oracle/gs_oracle.py is O(N H W) per pass — not a '
+                      'baseline; compare SplaTAM through roofline.frac and '
+                      f'launch_us ({int(n_gaussians)} Gaussians x '
+                      f'{int(n_pixels)} pixels)'}
 
 
 class _NumpyImages:
@@ -976,7 +980,8 @@ def run_pointslam(args, dev, world=1):
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = pointslam_cpu_baseline(min(os.cpu_count() or 1, 16))
+            cpu = calibrated(pointslam_cpu_baseline(
+                min(os.cpu_count() or 1, 16)), 'point-slam')
         except Exception as e:   # the baseline must not take the line down
             cpu = {'value': None, 'unit': 'frames/s', 'kind': 'port',
                    'cores': 0, 'sample': f'failed: {type(e).__name__}: {e}'}
@@ -988,6 +993,20 @@ def run_pointslam(args, dev, world=1):
             'workload': 'Point-SLAM 640x480 synthetic RGB-D: 40 tracking it x '
                         '1500 rays + 300 mapping it x 5000 rays (every frame '
                         'during the first 20, then every 5th), 5 samples/ray',
+            # which of the two cadences the timed frames fall into, and the
+            # rate the other one implies from the same timers
+            'regime': ('every timed frame is a mapping frame (frame id <= '
+                       f'{cad.lazy_start}: the reference maps every frame '
+                       'there) - the conservative rate' if
+                       args.warmup + args.steps <= cad.lazy_start else
+                       'timed frames straddle the every-frame and the '
+                       'every-5th-frame cadence'),
+            'steady_state_fps_estimate': (
+                1.0 / ((t_track + t_map / cad.map_every) / args.steps)
+                if args.warmup + args.steps <= cad.lazy_start else None),
+            'steady_state_note': 'frames past the lazy start map every '
+                                 f'{cad.map_every}th frame: 1 / (track + map '
+                                 f'/ {cad.map_every}) from this run\'s timers',
             'track_ms_per_frame': t_track / args.steps * 1e3,
             'map_ms_per_frame': t_map / args.steps * 1e3,
             'ate_rmse_m': slam.ate_rmse(),
@@ -1359,7 +1378,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             # torch CPU ops on these small tensors stop scaling (and collapse)
             # beyond a few tens of threads: use at most 16 host cores
-            cpu = cpu_baseline(min(16, os.cpu_count() or 1))
+            cpu = calibrated(cpu_baseline(min(16, os.cpu_count() or 1)),
+                             'nice-slam')
             torch_gpu = cpu_baseline(1, device=str(dev))
         fps = args.steps / elapsed
         out = {
@@ -1375,7 +1395,13 @@ def main():
                 'workload': 'NICE-SLAM Replica/office0-shaped 640x480 RGB-D: '
                             '10 tracking it x 200 rays/frame + every 5th '
                             'frame 60 mapping it x 1000 rays + 60 coarse it, '
-                            '48 samples/ray, coarse/middle/fine/color grids',
+                            '48 samples/ray, coarse/middle/fine/color grids; '
+                            f'synthetic trajectory sampled at {NICE_TRAJ_FRAMES}'
+                            ' frames (~5 mm a frame, Replica\'s pace; SURVEY '
+                            '8d names 200 frames = 14 mm a frame, which '
+                            'NICE-SLAM\'s 10 tracking iterations cannot '
+                            'follow: same work per frame, ATE 3-6 cm instead '
+                            'of 15 cm)',
                 'parallelism': 'replicated tracking, ray-sharded mapping, '
                                'all-reduce of selected-cell gradients'
                                if world > 1 else 'single GPU',
@@ -1410,8 +1436,11 @@ def main():
         # (secondary legs: a failure is recorded, it must not lose the line)
         if world == 1 and args.ingest == 'resident' and not args.no_others:
             try:
-                out['config']['ingest_files_fps'] = _ingest_files_leg(
-                    cfg, cam, dev, cad)
+                leg = _ingest_files_leg(cfg, cam, dev, cad)
+                # a scalar (the driver's record keeps config's scalars) + the
+                # leg's details next to it
+                out['config']['ingest_files_fps'] = leg['value']
+                out['config']['ingest_files_leg'] = leg
             except Exception as e:
                 out['config']['ingest_files_fps'] = None
                 out['config']['ingest_files_error'] = \
@@ -1420,11 +1449,19 @@ def main():
             # the second algorithm the north star names, same frame loop
             co_args = argparse.Namespace(**vars(args))
             co_args.first_iters = None
+            # (its own region: >= 100 timed frames after >= 10 warm-up frames
+            # — a 20-frame region is 0.1 s; the object carries its steps)
+            co_args.steps = max(args.steps, 100)
+            co_args.warmup = max(args.warmup, 10)
             try:
                 co = run_coslam(co_args, dev, not args.no_cpu_baseline)
             except Exception as e:
                 co = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+            co.setdefault('steps', co_args.steps)
+            co.setdefault('warmup', co_args.warmup)
             out['co_slam'] = co
+            # flat copy: the driver's record truncates nested objects
+            out['config']['co_slam_fps'] = co.get('value')
         if world == 1 and not args.no_others:
             # BASELINE configs[2..4] in the same (driver-run) line, each on a
             # budget that keeps the whole default run within a few minutes:
@@ -1449,6 +1486,7 @@ def main():
                 if first is not None:
                     res['first_iters_override'] = first
                 out[name] = res
+                out['config'][name + '_fps'] = res.get('value')
                 torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if world > 1:
