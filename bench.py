@@ -733,7 +733,7 @@ class _CvPoses:
         return d
 
 
-def run_splatam(args, dev):
+def run_splatam(args, dev, world=1):
     """SplaTAM frame loop: 40 tracking + 60 mapping iterations per frame, two
     full-image raster passes (colour; depth/silhouette) per iteration over
     ~4e5 Gaussians, on the HIP rasteriser (tile binning on the device)."""
@@ -747,6 +747,9 @@ def run_splatam(args, dev):
     cam = Camera(**CAM)
     algo = splatam_config().setup(camera=cam, device=str(dev))
     algo.use_graphs = not args.no_graphs
+    # N > 1: tracking replicated, every mapping iteration's image split into
+    # tile-row bands over the ranks, Gaussian gradients all-reduced
+    _setup_dist(dev, world)
     data = _CvPoses(SyntheticRoom(
         CO_BOUND, H=cam.height, W=cam.width, fx=cam.fx, fy=cam.fy, cx=cam.cx,
         cy=cam.cy, n_frames=max(args.warmup + args.steps + 1, 200),
@@ -758,17 +761,7 @@ def run_splatam(args, dev):
                           keyframe_every=cad.keyframe_every,
                           pose_device=str(dev),
                           use_relative_pose=cad.use_relative_pose)
-    for k in range(1 + args.warmup):
-        slam.step(k)
-    slam.t_track = slam.t_map = 0.0
-    torch.cuda.synchronize()
-    gc_was = _gc_pause()
-    t0 = time.perf_counter()
-    for k in range(1 + args.warmup, 1 + args.warmup + args.steps):
-        slam.step(k)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    _gc_resume(gc_was)
+    elapsed = _timed_frames(slam, args, dev, world)
     t_track, t_map = slam.t_track, slam.t_map
     # per-launch HIP-event timing of one more frame (100 iterations, 200
     # raster passes each way) right after the timed region
@@ -1199,12 +1192,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.algo in ('co-slam', 'vox-fusion', 'splaTAM', 'point-slam'):
-        if world > 1 and args.algo == 'splaTAM':
-            raise SystemExit('--algo splaTAM runs on one GPU this round')
         res = run_coslam(args, dev, not args.no_cpu_baseline and world == 1,
                          world) \
             if args.algo == 'co-slam' else run_voxfusion(args, dev, world) \
-            if args.algo == 'vox-fusion' else run_splatam(args, dev) \
+            if args.algo == 'vox-fusion' else run_splatam(args, dev, world) \
             if args.algo == 'splaTAM' else run_pointslam(args, dev, world)
         res.update({'n_gpus': world, 'steps': args.steps,
                     'warmup': args.warmup, 'higher_is_better': True,

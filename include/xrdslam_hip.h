@@ -701,6 +701,14 @@ int xrd_gs_preprocess(const xrd_gs_camera* cam, int n, const float* means3D,
                       const float* opacities, float* depths, float* xy,
                       float* conic_opacity, int32_t* radii, int32_t* rect,
                       int32_t* tiles_touched, xrd_stream_t stream);
+/* Tile-band sharding of one image over ranks (the reference
+ * rasterises the whole image in one process,
+ * slam/model_components/gaussian_cloud_splatam.py:47-78): clip rect to the tile
+ * rows [tile_row0, tile_row1) and recount tiles_touched, in place, after
+ * xrd_gs_preprocess.  Binning / blend / backward then cover the band only
+ * (tiles outside it composite nothing: background). */
+int xrd_gs_band_clip(int n, int tile_row0, int tile_row1, int32_t* rect,
+                     int32_t* tiles_touched, xrd_stream_t stream);
 /* keys[i] = (tile_id << 32) | float_bits(depth), values[i] = Gaussian id, at
  * the offsets given by the INCLUSIVE scan of tiles_touched */
 int xrd_gs_duplicate_keys(int n, int image_width, const int32_t* rect,

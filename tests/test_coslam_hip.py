@@ -319,6 +319,48 @@ def test_sample_distinct_dev_equals_host_sized_call():
         assert torch.equal(a, b)
 
 
+def test_coslam_slot_prewarm_leaves_the_run_unchanged():
+    """pre-warming the capacity slots (two eager + two captured iterations per
+    bucket on the call's data) restores the model, its optimiser state and
+    the random streams: the mapping call that follows starts from the same
+    state and draws the same batches as without the warm-up — same map after
+    the call up to the float-atomic order of the table gradient"""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import cadence, coslam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    bound = [[-3, 3], [-4, 2.5], [-2, 2.5]]
+    cam = Camera(fx=150., fy=150., cx=79.5, cy=59.5, width=160, height=120)
+    tables = []
+    for prewarm in (False, True):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = coslam_config(bound)
+        cfg.mapping_first_n_iters = 60
+        cfg.tracking_Wedge = cfg.tracking_Hedge = 5
+        cfg.mapping_sample = 768
+        algo = cfg.setup(camera=cam, device='cuda:0')
+        algo.use_graphs = True
+        algo.prewarm_slots = prewarm
+        data = SyntheticRoom(bound, H=120, W=160, fx=150., fy=150., cx=79.5,
+                             cy=59.5, n_frames=200, device='cuda:0')
+        cad = cadence['co-slam']
+        slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                              keyframe_every=cad.keyframe_every,
+                              pose_device='cuda:0')
+        for k in range(6):          # frame 5: the first slot call
+            slam.step(k)
+        assert len(algo._pslots) == (5 if prewarm else 1)
+        tables.append(algo.model.embed_fn.params.detach().clone())
+    a, b = tables
+    # Adam turns a last-bit difference of a near-zero gradient into a step of
+    # ~lr on that entry: compare the bulk, not the worst entry
+    diff = (a - b).abs()
+    assert float(diff.mean()) < 1e-5 * float(a.abs().mean()) + 1e-7, \
+        (float(diff.mean()), float(a.abs().mean()))
+    assert float((diff > 1e-3).float().mean()) < 1e-3
+
+
 @pytest.mark.parametrize('persistent', [False, True])
 def test_coslam_mapping_graph_slot(persistent):
     """Co-SLAM with mapping through the persistent capacity slot (pose stacks,
@@ -352,9 +394,10 @@ def test_coslam_mapping_graph_slot(persistent):
     assert len(algo.keyframe_graph) == 9
     if persistent:
         slots = algo._pslots
-        # 768 // K rays of the current frame: buckets 1024, 512, 256, 128
-        assert set(slots) <= {128, 256, 512, 1024}
-        assert any(len(s['graphs']) == 2 for s in slots.values())
+        # every bucket is built and captured when the first slot is needed
+        # (prewarm_slots): both iteration kinds of all five
+        assert set(slots) == {128, 256, 512, 1024, 2048}
+        assert all(len(s['graphs']) == 2 for s in slots.values())
     ate = slam.ate_rmse()
     assert ate < 0.02, ate
     # bundle adjustment wrote the keyframe poses back

@@ -4,6 +4,7 @@ selected-cell gradient exchange for grid parameters."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -110,3 +111,27 @@ def test_refreshed_grad_jobs_follow_the_static_selection():
             assert torch.equal(cells[m], torch.full((len(sel), 32), 3.0))
             assert torch.equal(cells[~m],
                                torch.full((12 - len(sel), 32), float(r + 1)))
+
+
+def test_tile_band_partition_covers_the_image_once():
+    """SplaTAM's tile-row bands (engine/dist.tile_band): every pixel row is
+    owned by exactly one rank, the rendered tile rows cover the owned rows
+    plus the 5-row SSIM halo, for image heights that are and are not
+    multiples of the 16-pixel tile and for more ranks than tile rows"""
+    from xrdslam_amd.engine.dist import tile_band
+    for height in (480, 120, 100, 33):
+        gy = (height + 15) // 16
+        for world in (1, 2, 3, 4, 8):
+            owned = np.zeros(height, np.int64)
+            for r in range(world):
+                b = tile_band(r, world, height)
+                r0, r1 = b['own']
+                owned[r0:r1] += 1
+                t0, t1 = b['render_tiles']
+                if r1 > r0:
+                    assert t0 * 16 <= max(0, r0 - 5)
+                    assert min(t1 * 16, height) >= min(height, r1 + 5)
+                    assert 0 <= t0 < t1 <= gy
+                else:
+                    assert (t0, t1) == (0, 0)
+            assert (owned == 1).all(), (height, world)

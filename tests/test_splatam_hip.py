@@ -118,6 +118,80 @@ def test_splatam_loop_tracks_synthetic_room(graphs):
     assert np.abs(rgb - data[6]['rgb'])[gt > 0].mean() < 0.1
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_tile_band_shards_add_up_to_the_full_image_iteration(world):
+    """multi-GPU SplaTAM mapping (one full frame per iteration ->
+    tile-row bands over the ranks): every rank rasterises its band + the SSIM
+    halo (xrd_gs_band_clip) and owns the loss terms of its rows; the ranks'
+    gradients of all five Gaussian tensors must add up to the single-process
+    iteration (depth L1 with the full image's normaliser, colour L1, SSIM
+    windows across the band borders).  The ranks are played one after the
+    other on this GPU — the sum taken here is what the mapping all-reduce
+    delivers.  (160 x 120 = 8 tile rows: bands of 4+4 / 2+3+3 rows.)"""
+    from xrdslam_amd.compat import diff_gaussian_rasterization as dgr
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.engine import dist as xd
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import cadence, splatam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    torch.manual_seed(0)
+    np.random.seed(0)
+    bound = [[-3, 3], [-4, 2.5], [-2, 2.5]]
+    cam = Camera(fx=150., fy=150., cx=79.5, cy=59.5, width=160, height=120)
+    cfg = splatam_config()
+    cfg.mapping_n_iters = 10
+    cfg.tracking_n_iters = 10
+    algo = cfg.setup(camera=cam, device='cuda:0')
+    algo.use_graphs = False
+    data = _CvPoses(SyntheticRoom(bound, H=120, W=160, fx=150., fy=150.,
+                                  cx=79.5, cy=59.5, n_frames=200,
+                                  device='cuda:0'))
+    cad = cadence['splaTAM']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every,
+                          pose_device='cuda:0',
+                          use_relative_pose=cad.use_relative_pose)
+    for k in range(3):
+        slam.step(k)
+    frames = list(algo.keyframe_graph)[-1:]
+    params = algo.model.gaussian_cloud.params
+    names = list(params)
+
+    def grads():
+        for p in params.values():
+            p.grad = None
+        np.random.seed(5)                  # the frame an iteration draws
+        algo.host_pre_iteration(frames, True, 0)
+        algo.get_loss(frames, True).backward()
+        torch.cuda.synchronize()
+        return {k: params[k].grad.detach().clone() for k in names}
+
+    st = xd.state
+    saved = (st.enabled, st.rank, st.world)
+    try:
+        st.enabled, st.rank, st.world = False, 0, 1
+        full = grads()
+        assert dgr.BAND is None and algo.model.own_rows is None
+        total, rows = None, []
+        for r in range(world):
+            st.enabled, st.rank, st.world = True, r, world
+            g = grads()
+            assert dgr.BAND == xd.tile_band(r, world, 120)['render_tiles']
+            rows.append(algo.model.own_rows)
+            total = g if total is None else {k: total[k] + g[k]
+                                             for k in names}
+    finally:
+        st.enabled, st.rank, st.world = saved
+        algo._set_band(False)
+    # the bands own every row exactly once
+    assert rows[0][0] == 0 and rows[-1][1] == 120
+    assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    for k in names:
+        assert float(full[k].abs().max()) > 0, k
+        err = float((total[k] - full[k]).abs().max() / full[k].abs().max())
+        assert err < 1e-4, (k, err)
+
+
 def _rand_rigid(gen):
     q = torch.randn(4, generator=gen, dtype=torch.float64)
     q = q / q.norm()

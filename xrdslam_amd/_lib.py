@@ -154,6 +154,7 @@ _SIGS = {
     'xrd_allreduce_max_i32': (C.c_int, [vp, vp, i64, vp]),
     'xrd_comm_destroy': (None, [vp]),
     'xrd_gs_preprocess': (C.c_int, [vp, C.c_int] + [vp] * 11),
+    'xrd_gs_band_clip': (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'xrd_gs_duplicate_keys': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         vp]),
     'xrd_gs_tile_ranges': (C.c_int, [i64, vp, vp, vp]),

@@ -88,6 +88,10 @@ def _build_camera(rs: GaussianRasterizationSettings) -> _lib.GsCamera:
     return cam
 
 
+# tile-band sharding (engine/dist.py, SplaTAM mapping over ranks): (first tile
+# row, one past the last) this process rasterises, or None = the whole image
+BAND = None
+
 # bench.py: per-launch HIP-event timing, key -> [(start, end)], plus the
 # (pixel, contributing Gaussian) pair count of every forward pass
 PROFILE = None
@@ -271,6 +275,11 @@ def _geometry(lib, cam, dev, st, m3, sc, rt, op):
             _lib.ptr(op), _lib.ptr(depths), _lib.ptr(xy),
             _lib.ptr(conic_o), _lib.ptr(radii), _lib.ptr(rect),
             _lib.ptr(tiles), st), 'xrd_gs_preprocess')
+    if BAND is not None:
+        # multi-GPU mapping: this rank rasterises tile rows [BAND[0], BAND[1])
+        _lib.check(lib.xrd_gs_band_clip(
+            n, int(BAND[0]), int(BAND[1]), _lib.ptr(rect), _lib.ptr(tiles),
+            st), 'xrd_gs_band_clip')
     gx, gy = (W + 15) // 16, (H + 15) // 16
     ranges = torch.empty(gx * gy, 2, **i)
     # tile binning on the stream (scan, key duplication, radix sort,

@@ -162,6 +162,23 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(
   tiles[i] = (x1 - x0) * (y1 - y0);
 }
 
+// tile-band sharding (multi-GPU mapping, SURVEY 8e: each rank rasterises a band
+// of tile rows): clip every Gaussian's tile rectangle to rows [ty0, ty1) and
+// recount its tiles; everything after (binning, blend, backward) sees only the
+// band's pairs.  radii keep the full-image value (visibility statistics).
+__global__ __launch_bounds__(256) void gs_band_clip_kernel(
+    int n, int ty0, int ty1, int* __restrict__ rect, int* __restrict__ tiles) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x0 = rect[i * 4], x1 = rect[i * 4 + 2];
+  const int y0 = max(rect[i * 4 + 1], ty0), y1 = min(rect[i * 4 + 3], ty1);
+  const int cnt = y1 > y0 ? (x1 - x0) * (y1 - y0) : 0;
+  rect[i * 4 + 1] = cnt ? y0 : 0;
+  rect[i * 4 + 3] = cnt ? y1 : 0;
+  if (!cnt) rect[i * 4] = rect[i * 4 + 2] = 0;
+  tiles[i] = cnt;
+}
+
 __global__ __launch_bounds__(256) void gs_duplicate_kernel(
     int n, const int* __restrict__ rect, const int64_t* __restrict__ offsets,
     const float* __restrict__ depths, int grid_x, int64_t* __restrict__ keys,
@@ -576,6 +593,17 @@ int xrd_gs_preprocess(const xrd_gs_camera* c, int n, const float* means3D,
                      opacities, depths, xy, conic_opacity, radii, rect,
                      tiles_touched);
   return check_launch("xrd_gs_preprocess");
+}
+
+int xrd_gs_band_clip(int n, int tile_row0, int tile_row1, int32_t* rect,
+                     int32_t* tiles_touched, xrd_stream_t stream) {
+  if (n < 0 || tile_row0 < 0 || tile_row1 < tile_row0) return XRD_ERR_ARG;
+  if (!rect || !tiles_touched) return XRD_ERR_ARG;
+  if (n == 0) return XRD_OK;
+  hipLaunchKernelGGL(gs_band_clip_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, n, tile_row0, tile_row1, rect,
+                     tiles_touched);
+  return check_launch("xrd_gs_band_clip");
 }
 
 int xrd_gs_duplicate_keys(int n, int image_width, const int32_t* rect,

@@ -81,6 +81,24 @@ class RcclComm:
             self.handle = None
 
 
+def tile_band(rank: int, world: int, height: int, tile: int = 16,
+              halo_px: int = 5):
+    """Tile-band partition of one image over ranks (SplaTAM mapping, SURVEY
+    8e): rank r OWNS the pixel rows [row0, row1) = tile rows [t0, t1) of an
+    even split of the ceil(height / tile) tile rows, and RENDERS the tile rows
+    [r0, r1) that cover its rows plus ``halo_px`` rows on either side (the
+    11 x 11 SSIM window of a pixel it owns reaches 5 rows into its neighbours'
+    bands).  -> dict(own=(row0, row1), render_tiles=(r0, r1))"""
+    gy = (height + tile - 1) // tile
+    t0, t1 = (gy * rank) // world, (gy * (rank + 1)) // world
+    row0, row1 = t0 * tile, min(t1 * tile, height)
+    if t1 <= t0:
+        return {'own': (0, 0), 'render_tiles': (0, 0)}
+    r0 = max(0, (row0 - halo_px) // tile)
+    r1 = min(gy, (row1 + halo_px + tile - 1) // tile)
+    return {'own': (row0, row1), 'render_tiles': (r0, r1)}
+
+
 class DistState:
     def __init__(self):
         self.enabled = False

@@ -325,6 +325,8 @@ class CoSLAM(Algorithm):
     # current-frame ray count falls in its bucket; from the 21st keyframe on
     # that count is constant (min_sample_pixels).
     persistent_map = True
+    # capture the graphs of every bucket when the first slot is needed
+    prewarm_slots = True
     _BUCKETS = (128, 256, 512, 1024, 2048)
 
     def graph_segment_key(self, is_mapping, step, n_iters, coarse=False):
@@ -366,52 +368,36 @@ class CoSLAM(Algorithm):
                 'target_d': rows[:, 6:7], 'first': False, 'sharded': False,
                 'n_live': slot['n_live']}
 
-    def _persistent_map(self, n_iters, frames):
-        """one mapping call through a capacity slot; False = not usable
-        (the caller takes the per-call path)"""
+    def _new_slot(self, bucket, K, d_img, c_img):
+        cfg = self.config
+        dev = torch.device(self.model.device)
+        kcap = max(64, 2 * (K + 1))
+        r = torch.nn.Parameter(torch.zeros(kcap, 3, device=dev))
+        t = torch.nn.Parameter(torch.zeros(kcap, 3, device=dev))
+        r.grad, t.grad = torch.zeros_like(r), torch.zeros_like(t)
+        fixed = torch.zeros(kcap, 1, 1, dtype=torch.bool, device=dev)
+        fixed[0] = True
+        pose_opt = Optimizers(dict(cfg.optimizers),
+                              {'mapping_pose_r': [r],
+                               'mapping_pose_t': [t]})
+        opt = pose_opt + self.model_optimizers
+        opt.parameters = {**pose_opt.parameters,
+                          **self.model_optimizers.parameters}
+        opt.static_grads = True
+        return {
+            'bucket': bucket, 'r': r, 't': t, 'fixed': fixed,
+            'pose_opt': pose_opt, 'opt': opt, 'graphs': {},
+            'bank_version': self._bank_version,
+            'depth': torch.empty_like(d_img),
+            'rgb': torch.empty_like(c_img),
+            'n_bank': torch.zeros(1, dtype=torch.int64, device=dev),
+            'cur_id': torch.zeros(1, dtype=torch.int64, device=dev),
+            'n_live': torch.zeros(1, dtype=torch.int32, device=dev)}
+
+    def _load_slot(self, slot, frames, K, d_img, c_img, n_cur):
         from ..engine.optimizers import reset_optimizer_state
         cfg = self.config
         dev = torch.device(self.model.device)
-        K = len(self.keyframe_graph)
-        cur = frames[-1]
-        n_cur = max(cfg.mapping_sample // K, cfg.min_sample_pixels)
-        bucket = next((b for b in self._BUCKETS if b >= n_cur), None)
-        if bucket is None:
-            return False
-        slots = self.__dict__.setdefault('_pslots', {})
-        slot = slots.get(bucket)
-        d_img, c_img = cur.device_images(dev)
-        if slot is not None and (
-                K + 1 > slot['r'].shape[0] or
-                slot['bank_version'] != self._bank_version or
-                slot['depth'].shape != d_img.shape):
-            slot = None                      # capacities outgrown
-        if self.model_optimizers is None:
-            self.model_optimizers = Optimizers(
-                dict(cfg.optimizers), {**self.model.get_param_groups()})
-        if slot is None:
-            kcap = max(64, 2 * (K + 1))
-            r = torch.nn.Parameter(torch.zeros(kcap, 3, device=dev))
-            t = torch.nn.Parameter(torch.zeros(kcap, 3, device=dev))
-            r.grad, t.grad = torch.zeros_like(r), torch.zeros_like(t)
-            fixed = torch.zeros(kcap, 1, 1, dtype=torch.bool, device=dev)
-            fixed[0] = True
-            pose_opt = Optimizers(dict(cfg.optimizers),
-                                  {'mapping_pose_r': [r],
-                                   'mapping_pose_t': [t]})
-            opt = pose_opt + self.model_optimizers
-            opt.parameters = {**pose_opt.parameters,
-                              **self.model_optimizers.parameters}
-            opt.static_grads = True
-            slot = slots[bucket] = {
-                'bucket': bucket, 'r': r, 't': t, 'fixed': fixed,
-                'pose_opt': pose_opt, 'opt': opt, 'graphs': {},
-                'bank_version': self._bank_version,
-                'depth': torch.empty_like(d_img),
-                'rgb': torch.empty_like(c_img),
-                'n_bank': torch.zeros(1, dtype=torch.int64, device=dev),
-                'cur_id': torch.zeros(1, dtype=torch.int64, device=dev),
-                'n_live': torch.zeros(1, dtype=torch.int32, device=dev)}
         with torch.no_grad():
             slot['r'].zero_()
             slot['t'].zero_()
@@ -429,6 +415,103 @@ class CoSLAM(Algorithm):
         # the reference builds the pose optimisers per call: fresh Adam state
         for o in slot['pose_opt'].optimizers.values():
             reset_optimizer_state(o)
+
+    def _prewarm_slots(self, frames, K, d_img, c_img):
+        """Build and capture the graphs of EVERY bucket the first time a
+        capacity slot is needed (and again after the bank was re-allocated):
+        the current-frame ray count runs through 2048, 1024, 512, 256, 128
+        while the first 20 keyframes arrive, and each new bucket used to pay
+        two eager iterations + two captures inside whatever frame needed it
+        first (a 20-frame timed region right after start-up held four of
+        them: 150 frames/s where the steady state is 214).  The warm-up
+        iterations run on the call's real data; the model, its optimiser
+        state and the random stream are restored afterwards, so the
+        trajectory of the run is unchanged."""
+        cfg = self.config
+        dev = torch.device(self.model.device)
+        slots = self.__dict__.setdefault('_pslots', {})
+        todo = [b for b in self._BUCKETS
+                if b not in slots or len(slots[b]['graphs']) < 2 or
+                slots[b]['bank_version'] != self._bank_version or
+                K + 1 > slots[b]['r'].shape[0]]
+        if not todo:
+            return
+        tensors = [p for ps in self.model_optimizers.parameters.values()
+                   for p in ps]
+
+        def opt_state():
+            return [v for o in self.model_optimizers.optimizers.values()
+                    for stt in o.state.values() for v in stt.values()
+                    if torch.is_tensor(v)]
+        rng = torch.cuda.get_rng_state(dev)
+        cpu_rng = torch.get_rng_state()
+        saved_p = [p.detach().clone() for p in tensors]
+        saved_s = [(v, v.detach().clone()) for v in opt_state()]
+        n_iters = cfg.mapping_n_iters
+        acc = cfg.optimizers['mapping_pose_r']['optimizer'].accum_step
+        steps = (0, (acc or 1) - 1)      # an iteration of each kind
+        for b in todo:
+            slot = slots[b] = self._new_slot(b, K, d_img, c_img)
+            self._load_slot(slot, frames, K, d_img, c_img,
+                            min(b, self.camera.height * self.camera.width))
+            self._pslot = slot
+            self.fixed_shape_batches = True
+            try:
+                for st in steps:
+                    k = self.graph_segment_key(True, st, n_iters)
+                    if k in slot['graphs']:
+                        continue
+                    self._iteration(slot['opt'], frames, True, st, n_iters,
+                                    False, None)
+                    g = torch.cuda.CUDAGraph()
+                    with _capture(g):
+                        self._iteration(slot['opt'], frames, True, st,
+                                        n_iters, False, None)
+                    slot['graphs'][k] = g
+                slot['seen'] = set(slot['graphs'])
+            finally:
+                self._pslot = None
+                self.fixed_shape_batches = False
+        with torch.no_grad():
+            for p, v in zip(tensors, saved_p):
+                p.copy_(v)
+            known = {id(v) for v, _ in saved_s}
+            for v, c in saved_s:
+                v.copy_(c)
+            for v in opt_state():
+                if id(v) not in known:
+                    v.zero_()       # created by the warm-up: back to fresh
+        torch.cuda.set_rng_state(rng, dev)
+        torch.set_rng_state(cpu_rng)
+
+    def _persistent_map(self, n_iters, frames):
+        """one mapping call through a capacity slot; False = not usable
+        (the caller takes the per-call path)"""
+        cfg = self.config
+        dev = torch.device(self.model.device)
+        K = len(self.keyframe_graph)
+        cur = frames[-1]
+        n_cur = max(cfg.mapping_sample // K, cfg.min_sample_pixels)
+        bucket = next((b for b in self._BUCKETS if b >= n_cur), None)
+        if bucket is None:
+            return False
+        slots = self.__dict__.setdefault('_pslots', {})
+        d_img, c_img = cur.device_images(dev)
+        if self.model_optimizers is None:
+            self.model_optimizers = Optimizers(
+                dict(cfg.optimizers), {**self.model.get_param_groups()})
+        slot = slots.get(bucket)
+        if slot is not None and (
+                K + 1 > slot['r'].shape[0] or
+                slot['bank_version'] != self._bank_version or
+                slot['depth'].shape != d_img.shape):
+            slot = None                      # capacities outgrown
+        if slot is None and self.prewarm_slots:
+            self._prewarm_slots(frames, K, d_img, c_img)
+            slot = slots.get(bucket)
+        if slot is None:
+            slot = slots[bucket] = self._new_slot(bucket, K, d_img, c_img)
+        self._load_slot(slot, frames, K, d_img, c_img, n_cur)
         opt, graphs = slot['opt'], slot['graphs']
         self._pslot = slot
         self.fixed_shape_batches = True

@@ -96,6 +96,7 @@ class SplaTAM(Algorithm):
         buffers the captured iteration reads."""
         f = optimize_frames[np.random.randint(0, len(optimize_frames))]
         self._chosen = f
+        self._set_band(is_mapping)
         if not (getattr(self, 'fixed_shape_batches', False) and is_mapping):
             self._slot_live = False
             return
@@ -160,11 +161,31 @@ class SplaTAM(Algorithm):
             total = int(torch.stack(counts).max().item())
         dgr._BIN.reserve(dev, cloud.params['means3D'].shape[0], total)
 
+    def _set_band(self, on):
+        """multi-GPU mapping: one full frame per iteration ->
+        every rank rasterises a band of tile rows (plus the SSIM halo) and
+        owns the loss terms of its rows; the Gaussian gradients are summed by
+        the mapping all-reduce (Optimizers.optimizer_step_all).  Tracking,
+        growth and pruning stay replicated on the whole image."""
+        from ...compat import diff_gaussian_rasterization as dgr
+        from ...engine import dist as xdist
+        st = xdist.state
+        if on and st.enabled and st.world > 1:
+            band = xdist.tile_band(st.rank, st.world, self.camera.height)
+            dgr.BAND = band['render_tiles']
+            self.model.own_rows = band['own']
+        else:
+            dgr.BAND = None
+            self.model.own_rows = None
+
     def optimize_update(self, n_iters, optimize_frames, is_mapping,
                         coarse=False):
         self._window = optimize_frames if is_mapping else None
-        out = super().optimize_update(n_iters, optimize_frames, is_mapping,
-                                      coarse=coarse)
+        try:
+            out = super().optimize_update(n_iters, optimize_frames,
+                                          is_mapping, coarse=coarse)
+        finally:
+            self._set_band(False)
         self._window = None
         if self.use_graphs and torch.device(self.device).type == 'cuda':
             from ...compat import diff_gaussian_rasterization as dgr

@@ -162,6 +162,15 @@ class GaussianSplatting(Model):
             target_d = torch.as_tensor(inputs['target_d']).to(dev).float()
             target_rgb = torch.as_tensor(inputs['target_s']).to(dev).float()
         rgb, depth_sil = outputs['rgb'], outputs['depth_sil']
+        own = self._own_rows_mask(rgb) if is_mapping else None
+        if own is not None:
+            # tile-band sharding: this rank rendered its band (+ halo); only
+            # the pixels it OWNS feed the L1 terms, the other ranks add theirs
+            # (the normalisers stay the full image's: depth count from the
+            # target, 3 H W for the colour mean).  Rows outside the rendered
+            # band composite nothing, so their terms reach no Gaussian.
+            rgb = rgb * own + rgb.detach() * (1.0 - own)
+            depth_sil = depth_sil * own + depth_sil.detach() * (1.0 - own)
         ld, lc = GsLossFn.apply(
             rgb, depth_sil, target_d, target_rgb, is_mapping,
             (not is_mapping) and use_sil, sil_thres, weights['depth'],
@@ -170,9 +179,31 @@ class GaussianSplatting(Model):
             chw = frame.device_rgb_chw(dev) if frame is not None else \
                 target_rgb.reshape(rgb.shape[1], rgb.shape[2], 3) \
                 .permute(2, 0, 1).contiguous()
-            ssim = slam_ops.SsimMapFn.apply(rgb, chw).mean()
+            ssim_map = slam_ops.SsimMapFn.apply(outputs['rgb'], chw)
+            if own is not None:
+                # the windows CENTRED on this rank's rows (they read up to 5
+                # rendered rows of the neighbouring bands: the halo)
+                ssim = (ssim_map * own).sum() / ssim_map.numel()
+            else:
+                ssim = ssim_map.mean()
             lc = lc + (0.2 * weights['rgb']) * (1.0 - ssim)
         return {'depth': ld, 'rgb': lc}
+
+    # tile-band sharding of the mapping image (set by the algorithm when the
+    # mapping work is spread over ranks): (row0, row1) this rank owns
+    own_rows = None
+
+    def _own_rows_mask(self, like):
+        if self.own_rows is None:
+            return None
+        key = (tuple(self.own_rows), tuple(like.shape[-2:]), like.device)
+        hit = getattr(self, '_own_mask', None)
+        if hit is None or hit[0] != key:
+            m = torch.zeros(1, like.shape[-2], like.shape[-1],
+                            device=like.device)
+            m[:, self.own_rows[0]:self.own_rows[1]] = 1.0
+            hit = self._own_mask = (key, m)
+        return hit[1]
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         return {k: [v.to(self.device)]
