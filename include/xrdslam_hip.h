@@ -624,6 +624,24 @@ int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
                         int32_t* s_idx, float* s_depth, int32_t* cnt,
                         int32_t* offs, float* xyz, int32_t* vox, int32_t* meta,
                         double* loss_acc, xrd_stream_t stream);
+/* Sharded mapping (exact against the single-process iteration): every
+ * rank passes the WHOLE batch (same draws) and ray_keep [n_rays] u8 marking
+ * its slice.  All rays are intersected, sorted, regrouped ([200, R, P]) and
+ * sampled — so the sampler's rows and the size record (hit rays, longest row,
+ * free-space / band sample counts, usable depths: the loss normalisers) are
+ * those of the whole batch on every rank, no exchange needed — but only kept
+ * rays leave points; the others read as rays without a hit afterwards (hit =
+ * 0, cnt = 0).  ray_keep NULL = xrd_vox_sample_rays. */
+int xrd_vox_sample_rays_shard(
+    int n_rays, int n_max, int s_cap, int64_t p_cap, int n_nodes,
+    const float* centres, const int32_t* children, float voxel_size,
+    float max_distance, float step_size, float trunc, float max_depth,
+    const float* rays_o, const float* rays_d, const float* target_d,
+    const float* noise, const uint8_t* ray_keep, int32_t* hit_idx,
+    float* hit_min, float* hit_max, float* probs, float* steps, int32_t* hit,
+    int32_t* rank, int32_t* hit_rays, int32_t* s_idx, float* s_depth,
+    int32_t* cnt, int32_t* offs, float* xyz, int32_t* vox, int32_t* meta,
+    double* loss_acc, xrd_stream_t stream);
 int xrd_vox_render_fwd(int n_rays, int s_cap, int64_t p_cap, float trunc,
                        float max_depth, const int32_t* hit,
                        const int32_t* cnt, const int32_t* offs,

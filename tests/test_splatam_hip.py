@@ -187,6 +187,13 @@ def test_tile_band_shards_add_up_to_the_full_image_iteration(world):
     assert rows[0][0] == 0 and rows[-1][1] == 120
     assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
     for k in names:
+        if k == 'unnorm_rotations':
+            # isotropic Gaussians: the rotation gradient is identically zero
+            # (what arrives is the rounding noise of the covariance chain)
+            ref = float(full['means3D'].abs().max())
+            assert float(full[k].abs().max()) < 1e-4 * ref
+            assert float(total[k].abs().max()) < 1e-4 * ref
+            continue
         assert float(full[k].abs().max()) > 0, k
         err = float((total[k] - full[k]).abs().max() / full[k].abs().max())
         assert err < 1e-4, (k, err)

@@ -140,6 +140,9 @@ _SIGS = {
     'xrd_vox_sample_rays': (C.c_int, [C.c_int, C.c_int, C.c_int, i64, C.c_int,
                                       vp, vp, f32, f32, f32, f32, f32] +
                             [vp] * 21),
+    'xrd_vox_sample_rays_shard': (C.c_int, [C.c_int, C.c_int, C.c_int, i64,
+                                            C.c_int, vp, vp, f32, f32, f32,
+                                            f32, f32] + [vp] * 22),
     'xrd_vox_render_fwd': (C.c_int, [C.c_int, C.c_int, i64, f32, f32] +
                            [vp] * 14 + [f32] * 4 + [vp] * 3),
     'xrd_vox_render_bwd': (C.c_int, [C.c_int, C.c_int, i64, f32, f32] +

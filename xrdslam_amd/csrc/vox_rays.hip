@@ -293,9 +293,14 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
 
 __global__ __launch_bounds__(1024) void vox_point_scan_kernel(
     int n_rays, int64_t p_cap, const int* __restrict__ cnt,
-    int* __restrict__ offs, int* __restrict__ meta) {
+    const uint8_t* __restrict__ ray_keep, int* __restrict__ offs,
+    int* __restrict__ meta) {
+  // (sharded mapping: rays of other ranks are sampled — they shape the
+  // regrouping and the size record — but get no points here)
   const int total = block_scan_1024(
-      n_rays, [&](int i) { return cnt[i]; }, offs);
+      n_rays,
+      [&](int i) { return ray_keep != nullptr && !ray_keep[i] ? 0 : cnt[i]; },
+      offs);
   if (threadIdx.x == 0) {
     offs[n_rays] = total;
     if ((int64_t)total > p_cap) atomicOr(meta + M_OVERFLOW, 2);
@@ -308,8 +313,9 @@ __global__ __launch_bounds__(1024) void vox_point_scan_kernel(
 __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
     int n_rays, int s_cap, int64_t p_cap, float trunc, float max_depth,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-    const float* __restrict__ target_d, const int* __restrict__ hit,
-    const int* __restrict__ cnt, const int* __restrict__ offs,
+    const float* __restrict__ target_d, int* __restrict__ hit,
+    int* __restrict__ cnt, const int* __restrict__ offs,
+    const uint8_t* __restrict__ ray_keep,
     const int* __restrict__ s_idx, const float* __restrict__ s_depth,
     float* __restrict__ xyz, int* __restrict__ vox, int* __restrict__ meta) {
   __shared__ int red[3];   // front, band, usable-depth counts
@@ -318,6 +324,10 @@ __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
   if (threadIdx.x < 3) red[threadIdx.x] = 0;
   __syncthreads();
   if (ray < n_rays && hit[ray]) {
+  // a ray of another rank's shard counts towards the batch-global sample
+  // counts below (they are the loss normalisers) but leaves no points and is
+  // a ray without a hit for everything after this kernel
+  const bool keep = ray_keep == nullptr || ray_keep[ray] != 0;
   const int s_max = meta[M_SMAX] < s_cap ? meta[M_SMAX] : s_cap;
   const int n = cnt[ray];
   const int64_t p0 = offs[ray];
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
     const bool in = s < s_max;
     const bool valid = s < n;
     const float z = valid ? s_depth[(int64_t)ray * s_cap + s] : kPadDepth;
-    if (valid && p0 + s < p_cap) {
+    if (keep && valid && p0 + s < p_cap) {
       const int64_t p = p0 + s;
 #pragma unroll
       for (int k = 0; k < 3; ++k) xyz[p * 3 + k] = o[k] + d[k] * z;
@@ -348,6 +358,10 @@ __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
     if (n_front) atomicAdd(&red[0], n_front);
     if (n_mid) atomicAdd(&red[1], n_mid);
     if (td > 0.01f && td < max_depth) atomicAdd(&red[2], 1);
+    if (!keep) {
+      cnt[ray] = 0;
+      hit[ray] = 0;
+    }
   }
   }
   __syncthreads();
@@ -692,6 +706,23 @@ int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
                         int32_t* s_idx, float* s_depth, int32_t* cnt,
                         int32_t* offs, float* xyz, int32_t* vox, int32_t* meta,
                         double* loss_acc, xrd_stream_t stream) {
+  return xrd_vox_sample_rays_shard(
+      n_rays, n_max, s_cap, p_cap, n_nodes, centres, children, voxel_size,
+      max_distance, step_size, trunc, max_depth, rays_o, rays_d, target_d,
+      noise, nullptr, hit_idx, hit_min, hit_max, probs, steps, hit, rank,
+      hit_rays, s_idx, s_depth, cnt, offs, xyz, vox, meta, loss_acc, stream);
+}
+
+int xrd_vox_sample_rays_shard(
+    int n_rays, int n_max, int s_cap, int64_t p_cap, int n_nodes,
+    const float* centres, const int32_t* children, float voxel_size,
+    float max_distance, float step_size, float trunc, float max_depth,
+    const float* rays_o, const float* rays_d, const float* target_d,
+    const float* noise, const uint8_t* ray_keep, int32_t* hit_idx,
+    float* hit_min, float* hit_max, float* probs, float* steps, int32_t* hit,
+    int32_t* rank, int32_t* hit_rays, int32_t* s_idx, float* s_depth,
+    int32_t* cnt, int32_t* offs, float* xyz, int32_t* vox, int32_t* meta,
+    double* loss_acc, xrd_stream_t stream) {
   if (n_rays < 0 || n_max < 1 || n_max > 64 || s_cap < 1 || p_cap < 1 ||
       !(step_size > 0.f))
     return XRD_ERR_ARG;
@@ -723,10 +754,10 @@ int xrd_vox_sample_rays(int n_rays, int n_max, int s_cap, int64_t p_cap,
                      s_cap, hit_idx, hit_min, hit_max, probs, steps, noise,
                      hit, rank, hit_rays, meta, s_idx, s_depth, cnt);
   hipLaunchKernelGGL(vox_point_scan_kernel, dim3(1), dim3(1024), 0, st,
-                     n_rays, p_cap, cnt, offs, meta);
+                     n_rays, p_cap, cnt, ray_keep, offs, meta);
   hipLaunchKernelGGL(vox_compact_kernel, grid, block, 0, st, n_rays, s_cap,
                      p_cap, trunc, max_depth, rays_o, rays_d, target_d, hit,
-                     cnt, offs, s_idx, s_depth, xyz, vox, meta);
+                     cnt, offs, ray_keep, s_idx, s_depth, xyz, vox, meta);
   return check_launch("xrd_vox_sample_rays");
 }
 

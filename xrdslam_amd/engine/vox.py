@@ -322,26 +322,29 @@ def _pack(params, like):
     return flatten_decoder(params)[pack_index(like.device)]
 
 
-def sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise):
-    """hits, samples and points of a ray batch into ``ws``"""
+def sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise, keep=None):
+    """hits, samples and points of a ray batch into ``ws``.  ``keep`` [n] u8
+    (sharded mapping): the rays this rank renders — the others are sampled
+    too (whole-batch regrouping and loss normalisers) but leave no points"""
     lib = _lib.lib()
     dev = rays_o.device
     centres = ms['voxel_center_xyz']
     children = ms['voxel_structure']
     with _Timed(('vox_sample_rays', ws.n)):
-        _lib.check(lib.xrd_vox_sample_rays(
+        _lib.check(lib.xrd_vox_sample_rays_shard(
             ws.n, N_MAX_HITS, ws.s_cap, ws.p_cap, centres.shape[0],
             _lib.ptr(centres), _lib.ptr(children), float(cfg.voxel_size),
             float(cfg.max_distance), float(cfg.step_size),
             float(cfg.training_trunc * cfg.data_sc_factor),
             float(cfg.max_dpeth), _lib.ptr(rays_o), _lib.ptr(rays_d),
-            _lib.ptr(target_d), _lib.ptr(noise), _lib.ptr(ws.hit_idx),
+            _lib.ptr(target_d), _lib.ptr(noise), _lib.ptr(keep),
+            _lib.ptr(ws.hit_idx),
             _lib.ptr(ws.hit_min), _lib.ptr(ws.hit_max), _lib.ptr(ws.probs),
             _lib.ptr(ws.steps), _lib.ptr(ws.hit), _lib.ptr(ws.rank),
             _lib.ptr(ws.hit_rays), _lib.ptr(ws.s_idx), _lib.ptr(ws.s_depth),
             _lib.ptr(ws.cnt), _lib.ptr(ws.offs), _lib.ptr(ws.xyz),
             _lib.ptr(ws.vox), _lib.ptr(ws.meta), _lib.ptr(ws.acc),
-            _lib.stream_ptr(dev)), 'xrd_vox_sample_rays')
+            _lib.stream_ptr(dev)), 'xrd_vox_sample_rays_shard')
 
 
 def _points_fwd(ws, ms, cfg, packed, save):
@@ -395,7 +398,8 @@ class _VoxRenderLossFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[10:])
         assert not need_w or ws.need_w
         packed = flat.detach()[pack_index(rays_o.device)]
-        sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise)
+        sample_rays(ws, ms, cfg, rays_o, rays_d, target_d, noise,
+                    getattr(ws, 'keep', None))
         if ws.meta_sync is not None:
             ws.meta_sync(ws.meta)
         _points_fwd(ws, ms, cfg, packed, need_w)

@@ -74,7 +74,14 @@ class VoxFusion(Algorithm):
         # the modular path syncs the host (hit counts, ragged lengths);
         # sharded (multi-GPU) mapping exchanges its batch-global loss
         # normalisers in the middle of the iteration: eager
-        if not self.fused_iteration or (is_mapping and _dist.state.enabled):
+        if not self.fused_iteration:
+            return False
+        if is_mapping and _dist.state.enabled and \
+                not _dist.state.deterministic:
+            # independent draws per rank: the loss normalisers are exchanged
+            # in the middle of the iteration (deterministic sharding has no
+            # collective before the gradient all-reduce: [gradient graph]
+            # all-reduce [step graph], base class)
             return False
         return super()._graphs_ok(optimizers, is_mapping)
 
@@ -133,17 +140,19 @@ class VoxFusion(Algorithm):
         ro, rd, td, tc, _, _ = SampleRaysFn.apply(
             c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
             (0, 0, cam.width), (-big, big, -big, big, -big, big))
+        out = {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
+               'sharded': sharded}
         if sharded and _dist.state.deterministic:
-            # every rank drew the SAME batch (shared RNG stream); this rank
-            # keeps a contiguous slice of every frame's rays
+            # every rank drew the SAME batch (shared RNG stream) and passes
+            # all of it: the ray pipeline (intersection, the sampler's
+            # [200, R, P] regrouping of the hit rays, the size record) runs on
+            # the whole batch everywhere, this rank evaluates the points of a
+            # contiguous slice of every frame's rays (ray_keep)
             lo, hi = _dist.state.shard_slice(n)
-            sel = (torch.arange(lo, hi, device=dev).unsqueeze(0) +
-                   n * torch.arange(len(frames), device=dev).unsqueeze(1)
-                   ).reshape(-1)
-            ro, rd = ro.index_select(0, sel), rd.index_select(0, sel)
-            td, tc = td[sel], tc[sel]
-        return {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
-                'sharded': sharded}
+            keep = torch.zeros(len(frames), n, dtype=torch.uint8, device=dev)
+            keep[:, lo:hi] = 1
+            out['ray_keep'] = keep.reshape(-1)
+        return out
 
     def create_voxels(self, frame):
         """allocate the voxels seen by this frame (:96-107); the back
@@ -176,6 +185,14 @@ class VoxFusion(Algorithm):
             if fused is not None:
                 self.last_loss_terms = fused[1]
                 return fused[0]
+        keep = inp.pop('ray_keep', None)
+        if keep is not None:
+            # the modular path renders a shard of the rays (normalisers
+            # exchanged in the loss): this rank's slice of the batch
+            sel = keep.bool()
+            inp = {k: (v[sel] if torch.is_tensor(v) and v.dim() > 0 and
+                       v.shape[0] == sel.shape[0] else v)
+                   for k, v in inp.items()}
         out = self.model(inp)
         losses = self.model.get_loss_dict(out, inp, is_mapping, step)
         return functools.reduce(torch.add, losses.values())

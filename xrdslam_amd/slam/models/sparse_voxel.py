@@ -346,9 +346,17 @@ class SparseVoxel(Model):
             return None
         need_w = is_mapping and torch.is_grad_enabled()
         ws = self.ray_workspace(inputs['rays_o'].shape[0], need_w)
-        # a shard of the mapping rays (multi-GPU): batch-global normalisers
+        # multi-GPU mapping.  Deterministic sharding: the WHOLE batch arrives
+        # with a mask of this rank's rays (ray_keep) — every rank samples all
+        # rays, so the regrouping and the loss normalisers are the batch's own
+        # and the ranks' losses / gradients add up exactly; only the points of
+        # the kept rays are evaluated.  Independent draws per rank: a shard of
+        # rays, the normalisers are exchanged (meta_sync).
+        keep = inputs.get('ray_keep')
+        ws.keep = None if keep is None else \
+            keep.to(torch.uint8).contiguous()
         ws.meta_sync = (self.meta_sync or _vox.allreduce_meta) \
-            if inputs.get('sharded', False) else None
+            if inputs.get('sharded', False) and keep is None else None
         out = _vox.render_loss(
             self.decoder, ws, self.map_states, self.config, inputs['rays_o'],
             inputs['rays_d'], inputs['target_d'], inputs['target_s'],
