@@ -339,6 +339,27 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
  * 48 samples a ray (32 + 16) only: other sampling configs ->
  * XRD_ERR_UNSUPPORTED (use xrd_nice_render_fwd / xrd_nice_loss /
  * xrd_nice_render_bwd). */
+/* One NICE-SLAM TRACKING iteration (colour stage, 48 samples a ray) as one
+ * launch + one finishing launch: forward render, the robust tracking loss of
+ * slam/models/conv_onet.py:145-176 (residual |d - depth| / sqrt(var), rays
+ * below 10 x the batch's lower median when handle_dynamic, + w_color x L1
+ * colour on the same rays when use_color; the variance is detached) and the
+ * backward to the rays.  The batch median sits between forward and backward:
+ * the blocks meet at one grid barrier, so every block must be resident —
+ * n_rays <= 1024 (4 rays a block, one block a CU), else XRD_ERR_UNSUPPORTED
+ * (use xrd_nice_render_fwd / xrd_nice_loss / xrd_nice_render_bwd).  Same
+ * arithmetic as that chain (tests/test_nice_hip.py).  ws:
+ * xrd_nice_track_ws_floats(n_rays) floats, 16-byte aligned, ZERO before its
+ * first use and handed back usable (the barrier counter is re-zeroed).
+ * -> g_rays_o / g_rays_d [n,3] (overwritten), loss [1] f64. */
+int64_t xrd_nice_track_ws_floats(int n_rays);
+int xrd_nice_track_iter(const xrd_nice_scene* scene, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        const float* tgt_rgb, const uint8_t* keep,
+                        int use_color, int handle_dynamic, float w_color,
+                        float* g_rays_o, float* g_rays_d, float* ws,
+                        double* loss, xrd_stream_t stream);
 int64_t xrd_nice_map_ws_floats(const xrd_nice_scene* scene, int stage,
                                int n_rays);
 int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,

@@ -297,6 +297,63 @@ def test_render_at_baseline_config_vs_oracle(tag, n_rays):
     parity.assert_all([(f'nice_office0/{tag}/{n}', a, b) for n, a, b in pairs])
 
 
+@pytest.mark.parametrize('n,use_color,handle_dynamic,masked', [
+    (200, True, True, False), (200, True, True, True), (333, False, True, False),
+    (200, True, False, True), (1024, True, True, False)])
+def test_one_launch_tracking_iteration(n, use_color, handle_dynamic, masked):
+    """xrd_nice_track_iter (forward + robust tracking loss + backward as ONE
+    launch: the batch median is taken at a grid barrier) against the CPU
+    oracle (loss_dict's tracking branch, pinned to conv_onet.py:145-176 by
+    tests/test_oracle_nice.py) AND against the three-launch chain it replaces
+    (xrd_nice_render_fwd / xrd_nice_loss / xrd_nice_render_bwd), at
+    BASELINE configs[1] (office0 grids, 200 tracking rays) and at the largest
+    batch the barrier admits; twice in a row on the same workspace."""
+    import parity
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n, 12)
+    keep = None
+    if masked:
+        keep = (torch.rand(n, generator=torch.Generator().manual_seed(4))
+                > 0.1)
+    scene, gl, flats = build_scene(bound, grids, decs, dev)
+    args = (scene, rays_o.to(dev), rays_d.to(dev), depth.to(dev), None,
+            color.to(dev), None if keep is None else
+            keep.to(dev).to(torch.uint8), use_color, handle_dynamic, 0.5)
+    got = []
+    for one in (True, True, False):
+        en.TRACK_ONE_LAUNCH = one
+        try:
+            loss, g_o, g_d = en.nice_track_iter(*args)
+        finally:
+            en.TRACK_ONE_LAUNCH = True
+        torch.cuda.synchronize()
+        got.append((float(loss), g_o.cpu(), g_d.cpu()))
+    (l1, o1, d1), (l2, o2, d2), (l3, o3, d3) = got
+    # same workspace twice: identical (no atomics on this path)
+    assert l1 == l2 and torch.equal(o1, o2) and torch.equal(d1, d2)
+    # the chain it replaces: the same arithmetic
+    assert abs(l1 - l3) <= 1e-6 * abs(l3)
+    assert parity.rel_max(o1, o3) < 1e-5 and parity.rel_max(d1, d3) < 1e-5
+    if n > 400 or not (use_color and handle_dynamic):
+        # (the oracle leg: seconds per 100 rays on the CPU; its loss_dict is
+        # the reference's default tracking loss — colour term and dynamic
+        # mask on)
+        return
+    sel = slice(None) if keep is None else keep
+    ro = rays_o.clone().requires_grad_(True)
+    rd = rays_d.clone().requires_grad_(True)
+    ref = no.render_batch_ray(ro[sel], rd[sel], depth[sel], grids, decs,
+                              bound, 'color')
+    ld = no.loss_dict(ref, depth[sel], color[sel], False, 'color')
+    ref_loss = sum(ld.values())
+    ref_loss.backward()
+    assert abs(l1 - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    parity.assert_all([('track/g_rays_o', o1, ro.grad),
+                       ('track/g_rays_d', d1, rd.grad)])
+
+
 @pytest.mark.parametrize('stage,need_rays,need_dec', [
     ('middle', True, False), ('fine', True, False), ('color', True, True),
     ('color', False, True), ('middle', False, False), ('fine', False, False),

@@ -449,26 +449,29 @@ def _run_sequence(render, n_frames, seed=0, pretrained=True, traj_frames=600):
 
 def test_ate_engine_equals_reference_arithmetic_loop():
     n = int(os.environ.get('XRD_ATE_FRAMES', '11'))
-    ate_e, tr_e = _run_sequence('engine', n)
-    ate_o, tr_o = _run_sequence('oracle', n)
-    gaps = np.abs(tr_e - tr_o).max(1)
-    gap = float(gaps.max())
+    seeds = (0, 1, 2)
+    runs = [(_run_sequence('engine', n, seed=sd)[0],
+             _run_sequence('oracle', n, seed=sd)[0]) for sd in seeds]
+    ate_e = float(np.mean([r[0] for r in runs]))
+    ate_o = float(np.mean([r[1] for r in runs]))
     line = (f'NICE-SLAM 160x120, {n} frames at 5 mm a frame, decoders with '
-            f'the occupancy prior: ATE engine {ate_e * 100:.2f} cm, ATE oracle '
-            f'loop {ate_o * 100:.2f} cm, max position gap between the two '
-            f'trajectories {gap * 100:.3f} cm; per frame (mm): ' +
-            ' '.join(f'{g * 1e3:.2f}' for g in gaps))
+            f'the occupancy prior, mean over seeds {seeds}: ATE engine '
+            f'{ate_e * 100:.2f} cm, ATE oracle loop {ate_o * 100:.2f} cm; '
+            'per seed (engine / oracle, cm): ' +
+            ' '.join(f'{a * 100:.2f}/{b * 100:.2f}' for a, b in runs))
     rep = os.environ.get('XRD_PARITY_REPORT')
     if rep:
         with open(rep, 'a') as f:
             f.write(line + '\n')
     print(line)
     # The two loops see the same draws and differ by f32 rounding of the
-    # render and the order of the gradient atomics; Adam turns a sign flip of
-    # a near-zero pose gradient into a step of ~lr, so the trajectories are
-    # not bit-equal (measured: they separate by up to 3 cm and come back) —
-    # but both must track, with the same error against ground truth to 1 cm
-    # (measured 1.62 / 2.07 cm, profiles/r04_parity_margins.txt).
+    # render and the order of the gradient atomics (in BOTH loops: torch's
+    # index_add_ is atomic too); Adam turns a sign flip of a near-zero pose
+    # gradient into a step of ~lr, so single trajectories separate by up to
+    # 3 cm and two runs of the SAME loop differ by ~0.3 cm of ATE.  What must
+    # agree is the error against ground truth: 1 cm on the mean of three
+    # seeds (a single pair was 1.62 / 2.07 cm, profiles/
+    # r04_parity_margins.txt), and both loops must track.
     assert abs(ate_e - ate_o) < 0.01, line
     assert max(ate_e, ate_o) < 0.04, line
 

@@ -112,6 +112,140 @@ __device__ __forceinline__ void map_composite(
   gocc_s = galpha * 10.f * alpha * oma;
 }
 
+// ---- tracking iteration in the same launch (round 4) ------------------------
+// The tracking loss (slam/models/conv_onet.py:145-176) puts a BATCH statistic
+// between the forward and the backward: the residual |d - depth| / sqrt(var)
+// of a ray counts only while it is below 10 x the batch's (lower) median.
+// Round 3 therefore ran forward launch, loss launch (one block: sort), and a
+// backward launch that recomputed the whole forward (43 + 14 + 79 us for 200
+// rays).  Here a block still owns whole rays and keeps the forward's state in
+// registers; the blocks meet at ONE grid barrier: every ray publishes its
+// residual, every block selects the median from the n residuals itself, and
+// the backward continues from the registers.  All blocks must be resident
+// (n <= 4 x 256 rays: one block a CU) — the caller checks.
+struct TrackArgs {
+  double* res;             // [n] residuals (1e300: ray not kept)
+  double* ray_lossc;       // [n] sum |d colour| of the rays that count
+  unsigned* bar;           // grid barrier counter (zero on entry, re-zeroed
+                           // by the finishing launch)
+  int use_color, handle_dynamic;
+};
+
+// forward half of the compositing (lane l = sample l): weights, depth, the
+// depth variance and the colour of the ray
+template <int S>
+__device__ __forceinline__ void track_forward(
+    const float* __restrict__ rawray, int lane, double zl, f32x4& rw,
+    float& alpha, float& oma, double& T, double& wd, double& dep,
+    double& var, float (&c)[3]) {
+  const bool valid = lane < S;
+  rw = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (valid) rw = *reinterpret_cast<const f32x4*>(rawray + lane * 4);
+  alpha = 0.f;
+  oma = 1.f;
+  if (valid) {
+    const float e = expf(-10.f * fabsf(rw[3]));  // <= 1
+    const float hi = 1.f / (1.f + e), lo = e / (1.f + e);
+    alpha = rw[3] >= 0.f ? hi : lo;
+    oma = rw[3] >= 0.f ? lo : hi;
+  }
+  const double f = (double)oma + 1e-10;
+  double incl = valid ? f : 1.0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_up(incl, o);
+    if (lane >= o) incl *= u;
+  }
+  T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.0;
+  wd = (double)alpha * T;
+  // the rendered values the loss sees: the arithmetic of the forward launch
+  // this replaces (nice_fwd_kernel: f32 sigmoid, f32 product scan like the
+  // reference's cumprod, f64 depth / variance sums) — the f64 weights above
+  // serve the backward (composite_bwd)
+  {
+    const float a32 = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
+    const float f32f = valid ? (1.f - a32 + 1e-10f) : 1.f;
+    float inc = f32f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float u = __shfl_up(inc, o);
+      if (lane >= o) inc *= u;
+    }
+    float T32 = __shfl_up(inc, 1);
+    if (lane == 0) T32 = 1.f;
+    const float w = a32 * T32;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = wave_sum(w * rw[a]);
+    dep = wave_sum(valid ? (double)w * zl : 0.0);
+    const double dz = zl - dep;
+    var = wave_sum(valid ? (double)w * dz * dz : 0.0);
+  }
+}
+// backward half: d loss / d occupancy logit of the lane's sample from
+// d loss / d depth (the variance is detached, conv_onet.py:157) and d colour
+template <int S>
+__device__ __forceinline__ float track_backward(
+    int lane, double zl, const f32x4 rw, float alpha, float oma, double T,
+    double wd, double gdep, const float (&grgb)[3]) {
+  const bool valid = lane < S;
+  const double f = (double)oma + 1e-10;
+  double gw = 0.0;
+  if (valid)
+    gw = gdep * zl +
+         (double)(grgb[0] * rw[0] + grgb[1] * rw[1] + grgb[2] * rw[2]);
+  double suf = valid ? gw * wd : 0.0;  // inclusive suffix sum
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_down(suf, o);
+    if (lane + o < 64) suf += u;
+  }
+  double sexc = __shfl_down(suf, 1);
+  if (lane == 63) sexc = 0.0;
+  const float galpha = valid ? (float)(gw * T - sexc / f) : 0.f;
+  return galpha * 10.f * alpha * oma;
+}
+// all blocks of the launch (every one resident) meet once
+__device__ __forceinline__ void grid_barrier_once(unsigned* bar) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <
+           gridDim.x)
+      __builtin_amdgcn_s_sleep(2);
+    __threadfence();
+  }
+  __syncthreads();
+}
+// 10 x the lower median of the kept rays' residuals (torch.median), selected by
+// rank counting over the n residuals by the whole block; R: n doubles of LDS
+__device__ __forceinline__ double track_threshold(const double* __restrict__ res,
+                                                  int n, double* R,
+                                                  double* s_thr) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    R[i] = __hip_atomic_load(res + i, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) *s_thr = 1e300;
+  __syncthreads();
+  int cnt = 0;
+  for (int j = 0; j < n; ++j) cnt += R[j] < 1e300;   // (uniform: broadcasts)
+  if (cnt > 0) {
+    const int k = (cnt - 1) / 2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const double v = R[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const double u = R[j];
+        rank += (u < v) || (u == v && j < i);
+      }
+      if (rank == k) *s_thr = 10.0 * v;
+    }
+  }
+  __syncthreads();
+  return *s_thr;
+}
+
 // per-tile operand scratch of the deferred weight-gradient contraction
 // (floats): feature-major matrices M[f][pt] = 512 floats
 constexpr int SC_C = 0;                 // grid features c
@@ -473,7 +607,7 @@ struct MapGeom {
 static_assert(MapGeom<3>::LDS * 4 <= 163840, "LDS per CU");
 static_assert(MapGeom<3>::NW == 12, "the contraction's unit table: 12 waves");
 
-template <int STAGE, int NT, bool NEED_DP, bool NEED_DW>
+template <int STAGE, int NT, bool NEED_DP, bool NEED_DW, bool TRACK = false>
 __global__ __launch_bounds__((MapGeom<NT>::NW * 64),
                              ((MapGeom<NT>::NW + 3) / 4)) void
 nice_map_fused_kernel(
@@ -483,8 +617,10 @@ nice_map_fused_kernel(
     const uint8_t* __restrict__ keep, float w_color, float* gg_middle,
     float* gg_fine, float* gg_color, double* __restrict__ part,
     float* __restrict__ dw_rep, float* __restrict__ dw_scr,
-    double* __restrict__ ray_loss) {
+    double* __restrict__ ray_loss, TrackArgs trk) {
   static_assert(!NEED_DW || STAGE == XRD_STAGE_COLOR, "dW: colour stage");
+  static_assert(!TRACK || (STAGE == XRD_STAGE_COLOR && NEED_DP && !NEED_DW),
+                "tracking: colour stage, ray gradients only");
   using G = MapGeom<NT>;
   constexpr int S = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -593,7 +729,59 @@ nice_map_fused_kernel(
     __syncthreads();
     // ---- compositing, loss, compositing backward (every wave: its ray) ----
     float gocc = 0.f, gcol[3] = {0.f, 0.f, 0.f};
-    if (active) {
+    if constexpr (TRACK) {
+      // forward half of every ray, the residuals meet at the grid barrier,
+      // the block selects the batch median, the backward half follows
+      f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+      float alpha = 0.f, oma = 1.f, crgb[3] = {0.f, 0.f, 0.f};
+      double T = 1.0, wd = 0.0, dep = 0.0, var = 0.0;
+      const bool kept = active && (keep == nullptr || keep[ray] != 0);
+      if (active)
+        track_forward<S>(rawbuf + slot * 256, lane, zl, rw, alpha, oma, T, wd,
+                         dep, var, crgb);
+      const double inv = 1.0 / sqrt(var + 1e-10);
+      const double diff = (double)gd - dep;
+      const double res = fabs(diff) * inv;
+      if (active && tile == 0 && lane == 0)
+        __hip_atomic_store(trk.res + ray, kept ? res : 1e300,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      grid_barrier_once(trk.bar);
+      // (the forward's staged colour-decoder fragments are dead: their LDS
+      // holds the residuals until the backward stages its own)
+      const double thr =
+          trk.handle_dynamic
+              ? track_threshold(trk.res, n, reinterpret_cast<double*>(wl),
+                                reinterpret_cast<double*>(embB))
+              : 1e300;
+      if (active) {
+        const bool m = kept && gd > 0.f &&
+                       (!trk.handle_dynamic || res < thr);
+        const double gdep =
+            m ? (diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0)) * inv : 0.0;
+        float grgb[3] = {0.f, 0.f, 0.f};
+        float lc = 0.f;
+        if (m && trk.use_color) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float dc = tgt_rgb[ray * 3 + a] - crgb[a];
+            lc += fabsf(dc);
+            grgb[a] = w_color * (dc > 0.f ? -1.f : (dc < 0.f ? 1.f : 0.f));
+          }
+        }
+        const float gocc_s =
+            track_backward<S>(lane, zl, rw, alpha, oma, T, wd, gdep, grgb);
+        const int src = 16 * tile + li;
+        gocc = __shfl(gocc_s, src);
+        if (!tg.inb) gocc = 0.f;  // occupancy was overridden to 100
+        const float wsrc = __shfl((float)wd, src);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gcol[a] = grgb[a] * wsrc;
+        if (tile == 0 && lane == 0) {
+          ray_loss[ray] = m ? res : 0.0;
+          trk.ray_lossc[ray] = (double)lc;
+        }
+      }
+    } else if (active) {
       float gocc_s, w, grgb[3];
       double loss;
       const bool kept = keep == nullptr || keep[ray] != 0;
@@ -629,7 +817,8 @@ nice_map_fused_kernel(
       if (active) {
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
-        grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
+        if constexpr (!TRACK)
+          grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
       }
     }
     if (STAGE >= XRD_STAGE_FINE) {
@@ -644,7 +833,8 @@ nice_map_fused_kernel(
         const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
-        grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
+        if constexpr (!TRACK)
+          grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
       }
     }
     {
@@ -658,7 +848,8 @@ nice_map_fused_kernel(
                                             mask_m, gc, gp32);
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
-        grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
+        if constexpr (!TRACK)
+          grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);
       }
     }
     if (NEED_DW) {
@@ -860,8 +1051,48 @@ int launch_map(const xrd_nice_scene* scene, int n, const float* rays_o,
   const int nb = ngroups < kMapBlocks ? ngroups : kMapBlocks;
   hipLaunchKernelGGL(kern, dim3(nb), dim3(G::NW * 64), lds, st, *scene, n,
                      rays_o, rays_d, gt_depth, dmax, tgt_rgb, keep, w_color,
-                     gg[1], gg[2], gg[3], part, dw_rep, dw_scr, ray_loss);
+                     gg[1], gg[2], gg[3], part, dw_rep, dw_scr, ray_loss,
+                     TrackArgs{});
   return check_launch("xrd_nice_map_iter");
+}
+
+// tracking: ray gradients = sum of the ray's tile partials, loss = depth term
+// + (float) w_color x (float) colour term like xrd_nice_loss; the grid barrier
+// counter is left zeroed for the next call
+__global__ __launch_bounds__(256) void nice_track_finish_kernel(
+    const double* __restrict__ part, int n, float* __restrict__ g_rays_o,
+    float* __restrict__ g_rays_d, const double* __restrict__ ray_loss,
+    const double* __restrict__ ray_lossc, float w_color, unsigned* bar,
+    double* __restrict__ loss) {
+  __shared__ double sh[2][4];
+  if (blockIdx.x == gridDim.x - 1) {
+    double sd = 0.0, sc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      sd += ray_loss[i];
+      sc += ray_lossc[i];
+    }
+    sd = wave_sum(sd);
+    sc = wave_sum(sc);
+    if ((threadIdx.x & 63) == 0) {
+      sh[0][threadIdx.x >> 6] = sd;
+      sh[1][threadIdx.x >> 6] = sc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double d = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+      const double c = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+      if (loss != nullptr) loss[0] = d + (double)(w_color * (float)c);
+      *bar = 0u;
+    }
+    return;
+  }
+  const int j = (int)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n * 6) return;
+  const int ray = j / 6, a = j % 6;
+  double s = 0.0;
+  for (int t = 0; t < 3; ++t) s += part[((size_t)ray * 3 + t) * 6 + a];
+  float* dst = a < 3 ? g_rays_o + ray * 3 + a : g_rays_d + ray * 3 + a - 3;
+  *dst = (float)s;
 }
 
 #define MAP_ARGS                                                             \
@@ -986,6 +1217,69 @@ int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
                      dp ? n_rays : 0, 3, g_rays_o, g_rays_d, ray_loss, n_rays,
                      loss);
   return check_launch("xrd_nice_map_iter/finish");
+}
+
+int64_t xrd_nice_track_ws_floats(int n_rays) {
+  if (n_rays < 0) return -1;
+  // [n*3][6] f64 tile partials | [n] f64 depth terms | [n] f64 colour terms |
+  // [n] f64 residuals | barrier counter
+  return (int64_t)n_rays * 3 * 6 * 2 + 6 * (int64_t)n_rays + 4;
+}
+
+int xrd_nice_track_iter(const xrd_nice_scene* scene, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        const float* tgt_rgb, const uint8_t* keep,
+                        int use_color, int handle_dynamic, float w_color,
+                        float* g_rays_o, float* g_rays_d, float* ws,
+                        double* loss, xrd_stream_t stream) {
+  using G = MapGeom<3>;
+  if (scene == nullptr || n_rays < 0) return XRD_ERR_ARG;
+  if (!rays_o || !rays_d || !gt_depth || !dmax || !tgt_rgb || !g_rays_o ||
+      !g_rays_d || !ws)
+    return XRD_ERR_ARG;
+  if (scene->t_uniform == nullptr || scene->t_surface == nullptr)
+    return XRD_ERR_ARG;
+  for (int g = 1; g < 4; ++g)
+    if (scene->grid[g] == nullptr || scene->dec[g] == nullptr)
+      return XRD_ERR_ARG;
+  if (scene->n_samples != 32 || scene->n_surface != 16)
+    return XRD_ERR_UNSUPPORTED;  // 48 samples a ray = 3 tiles
+  // the grid barrier needs every block resident: one block (4 rays) a CU
+  if (n_rays > G::RPBM * kMapBlocks) return XRD_ERR_UNSUPPORTED;
+  if (n_rays == 0) return XRD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  auto kern = nice_map_fused_kernel<XRD_STAGE_COLOR, 3, true, false, true>;
+  const size_t lds = G::LDS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr_set = true;
+  }
+  double* part = reinterpret_cast<double*>(ws);
+  double* ray_loss = part + (size_t)n_rays * 3 * 6;
+  TrackArgs trk;
+  trk.ray_lossc = ray_loss + n_rays;
+  trk.res = trk.ray_lossc + n_rays;
+  trk.bar = reinterpret_cast<unsigned*>(trk.res + n_rays);
+  trk.use_color = use_color;
+  trk.handle_dynamic = handle_dynamic;
+  const int ngroups = (n_rays + G::RPBM - 1) / G::RPBM;
+  hipLaunchKernelGGL(kern, dim3(ngroups), dim3(G::NW * 64), lds, st, *scene,
+                     n_rays, rays_o, rays_d, gt_depth, dmax, tgt_rgb, keep,
+                     w_color, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, part, (float*)nullptr, (float*)nullptr,
+                     ray_loss, trk);
+  int rc = check_launch("xrd_nice_track_iter");
+  if (rc != XRD_OK) return rc;
+  hipLaunchKernelGGL(nice_track_finish_kernel,
+                     dim3((n_rays * 6 + 255) / 256 + 1), dim3(256), 0, st,
+                     part, n_rays, g_rays_o, g_rays_d, ray_loss,
+                     trk.ray_lossc, w_color, trk.bar, loss);
+  return check_launch("xrd_nice_track_iter/finish");
 }
 
 int xrd_nice_map_warmup(void) {
