@@ -327,7 +327,7 @@ def test_one_launch_tracking_iteration(n, use_color, handle_dynamic, masked):
         try:
             loss, g_o, g_d = en.nice_track_iter(*args)
         finally:
-            en.TRACK_ONE_LAUNCH = True
+            en.TRACK_ONE_LAUNCH = False
         torch.cuda.synchronize()
         got.append((float(loss), g_o.cpu(), g_d.cpu()))
     (l1, o1, d1), (l2, o2, d2), (l3, o3, d3) = got

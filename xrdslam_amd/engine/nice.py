@@ -410,8 +410,17 @@ def nice_map_iter(scene: NiceScene, stage: str, rays_o: torch.Tensor,
     return loss, g_o, g_d, g_flat
 
 
-# tracking iterations as one launch (False: forward / loss / backward launches)
-TRACK_ONE_LAUNCH = True
+# Tracking iterations as one launch (xrd_nice_track_iter) instead of the
+# forward / loss / backward launches.  OFF by default — measured on MI355X at
+# the reference's 200 tracking rays (profiles/r04_nice_track_one_launch.txt):
+# the one-launch kernel runs 147 us against 43 + 14 + 79 us for the chain (the
+# iteration 176 vs 166 us).  200 rays are 50 blocks of 4 rays: the launch is
+# bound by ONE block's dependent chain (three decoders forward, three
+# backward, six staging barriers), not by throughput, and dropping the
+# backward's forward recompute saves less than the grid barrier and the
+# 12-wave blocks cost.  The lever for this batch size is depth, not launches:
+# the three decoders of a tile on three waves at once.
+TRACK_ONE_LAUNCH = False
 
 
 @torch.no_grad()
