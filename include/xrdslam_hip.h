@@ -339,6 +339,22 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
  * 48 samples a ray (32 + 16) only: other sampling configs ->
  * XRD_ERR_UNSUPPORTED (use xrd_nice_render_fwd / xrd_nice_loss /
  * xrd_nice_render_bwd). */
+/* xrd_nice_map_iter that also hands out, per sample (48 a ray, ray-major),
+ * the sample point [n*48,3] and d loss / d occupancy logit [n*48] (0 for
+ * samples outside the bound and rays with keep == 0) — what a caller needs to
+ * form the weight gradient of the fine / middle decoder outside the launch
+ * (mapping_fix_fine = False, slam/models/conv_onet.py:62,190-195: the fused
+ * launch contracts the colour decoder's weight gradient only).  Both NULL =
+ * xrd_nice_map_iter; coarse stage -> XRD_ERR_UNSUPPORTED. */
+int xrd_nice_map_iter_export(const xrd_nice_scene* scene, int stage,
+                             int n_rays, const float* rays_o,
+                             const float* rays_d, const float* gt_depth,
+                             const float* dmax, const float* tgt_rgb,
+                             const uint8_t* keep, float w_color,
+                             float* g_rays_o, float* g_rays_d,
+                             float* const g_grid[4], float* g_dec_color,
+                             float* sample_points, float* g_occ, float* ws,
+                             double* loss, xrd_stream_t stream);
 /* One NICE-SLAM TRACKING iteration (colour stage, 48 samples a ray) as one
  * launch + one finishing launch: forward render, the robust tracking loss of
  * slam/models/conv_onet.py:145-176 (residual |d - depth| / sqrt(var), rays

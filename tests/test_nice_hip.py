@@ -297,6 +297,52 @@ def test_render_at_baseline_config_vs_oracle(tag, n_rays):
     parity.assert_all([(f'nice_office0/{tag}/{n}', a, b) for n, a, b in pairs])
 
 
+@pytest.mark.parametrize('stage', ['fine', 'color'])
+def test_fine_decoder_weight_gradient_from_the_export(stage):
+    """mapping_fix_fine = False (conv_onet.py:62,190-195): the one-launch
+    mapping iteration hands out the sample points and d loss / d occupancy
+    logit of every sample (xrd_nice_map_iter_export); the fine decoder's weight
+    gradient formed from them (engine/nice.decoder_weight_grad: the decoder
+    re-evaluated with torch ops on the device) against the CPU oracle's
+    autograd, every parameter of the fine decoder, at BASELINE configs[1]
+    shapes (office0 grids, 1000 rays, 6 % masked); the exported points are the
+    kernel's own sample positions (checked through the gradient) and the other
+    outputs are those of the plain call."""
+    import parity
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    n = 1000
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n, 11)
+    keep = torch.rand(n, generator=torch.Generator().manual_seed(4)) > 0.06
+    od = {kind: {m: v.clone().requires_grad_(kind == 'fine')
+                 for m, v in sd.items()} for kind, sd in decs.items()}
+    ref = no.render_batch_ray(rays_o[keep], rays_d[keep], depth[keep], grids,
+                              od, bound, stage)
+    sum(no.loss_dict(ref, depth[keep], color[keep], True,
+                     stage).values()).backward()
+    want = en.flatten_state_dict(
+        {m: v.grad for m, v in od['fine'].items()}, 'fine')
+    scene, gl, flats = build_scene(bound, grids, decs, dev,
+                                   grid_requires_grad=True)
+    args = (scene, stage, rays_o.to(dev), rays_d.to(dev), depth.to(dev), None,
+            color.to(dev), keep.to(dev).to(torch.uint8), 0.2, True, False)
+    plain = en.nice_map_iter(*args)
+    export = {}
+    got = en.nice_map_iter(*args, export=export)
+    torch.cuda.synchronize()
+    assert abs(float(got[0]) - float(plain[0])) <= 1e-9 * abs(float(plain[0]))
+    assert torch.equal(got[1], plain[1]) and torch.equal(got[2], plain[2])
+    assert export['points'].shape == (n * 48, 3)
+    # rays that were masked out carry no gradient
+    g = export['g_occ'].reshape(n, 48)
+    assert float(g[~keep.to(dev)].abs().max()) == 0.0
+    g_fine = en.decoder_weight_grad(scene, 'fine', flats['fine'],
+                                    export['points'], export['g_occ'])
+    assert float(want.abs().max()) > 0
+    parity.assert_all([(f'fine_dw/{stage}', g_fine.cpu(), want)])
+
+
 @pytest.mark.parametrize('n,use_color,handle_dynamic,masked', [
     (200, True, True, False), (200, True, True, True), (333, False, True, False),
     (200, True, False, True), (1024, True, True, False)])

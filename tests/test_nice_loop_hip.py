@@ -124,6 +124,50 @@ def test_fused_iteration_equals_generic_hooks(is_mapping, step, ba, coarse):
                 assert close(other['dec'], a['dec'], 1e-4)
 
 
+@pytest.mark.parametrize('graphs', [False, True])
+def test_loop_with_a_trainable_fine_decoder(graphs):
+    """mapping_fix_fine = False (conv_onet.py:62,190-195; the reference's
+    non-default switch): the frame loop runs on the one-launch mapping
+    iteration, the fine decoder is in the 'decoder' group next to the colour
+    decoder, gets its gradient in the fine and colour stages and moves; the
+    middle decoder (never optimised) does not."""
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.configs.input_config import cadence, nice_slam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    dev = 'cuda:0'
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cam = Camera(80., 80., 79.5, 59.5, 160, 120)
+    cfg = nice_slam_config(BOUND)
+    cfg.tracking_Hedge = cfg.tracking_Wedge = 10
+    cfg.mapping_first_n_iters, cfg.mapping_n_iters = 60, 20
+    cfg.model.mapping_fix_fine = False
+    cfg.model.pretrained_decoders_xrd = PRETRAINED
+    algo = cfg.setup(camera=cam, device=dev)
+    algo.use_graphs = graphs
+    fine0 = algo.model.decoder.fine_decoder.flat.detach().clone()
+    mid0 = algo.model.decoder.middle_decoder.flat.detach().clone()
+    col0 = algo.model.decoder.color_decoder.flat.detach().clone()
+    data = SyntheticRoom(BOUND, H=120, W=160, fx=80., fy=80., cx=79.5, cy=59.5,
+                         n_frames=600, shrink=0.3, device=dev)
+    cad = cadence['nice-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every, pose_device=dev)
+    for k in range(7):
+        slam.step(k)
+    groups = algo.model.get_param_groups()
+    assert any(p is algo.model.decoder.fine_decoder.flat
+               for p in groups['decoder'])
+    fine = algo.model.decoder.fine_decoder.flat.detach()
+    assert float((fine - fine0).abs().max()) > 1e-5
+    assert float((algo.model.decoder.color_decoder.flat.detach() -
+                  col0).abs().max()) > 1e-5
+    assert torch.equal(algo.model.decoder.middle_decoder.flat.detach(), mid0)
+    assert torch.isfinite(fine).all()
+    assert slam.ate_rmse() < 0.05
+
+
 def test_frustum_selection_kernel_matches_the_reference_pinned_mask():
     """xrd_nice_frustum_cells (two launches for all grids) against
     frustum_cell_mask, the torch restatement that

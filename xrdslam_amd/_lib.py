@@ -98,6 +98,10 @@ _SIGS = {
     'xrd_nice_map_iter': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
                                     vp, vp, vp, vp, vp, vp, f32, vp, vp,
                                     C.POINTER(vp * 4), vp, vp, vp, vp]),
+    'xrd_nice_map_iter_export': (C.c_int, [C.POINTER(NiceScene), C.c_int,
+                                           C.c_int, vp, vp, vp, vp, vp, vp,
+                                           f32, vp, vp, C.POINTER(vp * 4),
+                                           vp, vp, vp, vp, vp, vp]),
     'xrd_nice_track_ws_floats': (i64, [C.c_int]),
     'xrd_nice_track_iter': (C.c_int, [C.POINTER(NiceScene), C.c_int, vp, vp,
                                       vp, vp, vp, vp, C.c_int, C.c_int, f32,

@@ -129,6 +129,10 @@ struct TrackArgs {
   unsigned* bar;           // grid barrier counter (zero on entry, re-zeroed
                            // by the finishing launch)
   int use_color, handle_dynamic;
+  // mapping, optional: the sample points [n*S,3] and d loss / d occupancy
+  // logit [n*S] of every sample (xrd_nice_map_iter_export)
+  float* exp_p;
+  float* exp_g;
 };
 
 // forward half of the compositing (lane l = sample l): weights, depth, the
@@ -796,6 +800,12 @@ nice_map_fused_kernel(
       for (int a = 0; a < 3; ++a) gcol[a] = grgb[a] * wsrc;
       if (tile == 0 && lane == 0 && ray_loss != nullptr) ray_loss[ray] = loss;
     }
+    if (!TRACK && trk.exp_g != nullptr && active && q == 0) {
+      const size_t sidx = (size_t)ray * S + 16 * tile + li;
+      trk.exp_g[sidx] = gocc;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) trk.exp_p[sidx * 3 + a] = p32[0][a];
+    }
     // ---- backward: colour -> fine -> middle --------------------------------
     asm volatile("" : "+v"(lane));
     double gp64[3] = {0.0, 0.0, 0.0};
@@ -1034,7 +1044,8 @@ int launch_map(const xrd_nice_scene* scene, int n, const float* rays_o,
                const float* rays_d, const float* gt_depth, const float* dmax,
                const float* tgt_rgb, const uint8_t* keep, float w_color,
                float* const gg[4], double* part, float* dw_rep,
-               float* dw_scr, double* ray_loss, hipStream_t st) {
+               float* dw_scr, double* ray_loss, float* exp_p, float* exp_g,
+               hipStream_t st) {
   using G = MapGeom<3>;
   auto kern = nice_map_fused_kernel<ST, 3, DP, DW>;
   const size_t lds = G::LDS * sizeof(float);
@@ -1052,7 +1063,7 @@ int launch_map(const xrd_nice_scene* scene, int n, const float* rays_o,
   hipLaunchKernelGGL(kern, dim3(nb), dim3(G::NW * 64), lds, st, *scene, n,
                      rays_o, rays_d, gt_depth, dmax, tgt_rgb, keep, w_color,
                      gg[1], gg[2], gg[3], part, dw_rep, dw_scr, ray_loss,
-                     TrackArgs{});
+                     TrackArgs{nullptr, nullptr, nullptr, 0, 0, exp_p, exp_g});
   return check_launch("xrd_nice_map_iter");
 }
 
@@ -1097,14 +1108,15 @@ __global__ __launch_bounds__(256) void nice_track_finish_kernel(
 
 #define MAP_ARGS                                                             \
   scene, n_rays, rays_o, rays_d, gt_depth, dmax, tgt_rgb, keep, w_color, gg, \
-      part, dw_rep, dw_scr, ray_loss, st
+      part, dw_rep, dw_scr, ray_loss, exp_p, exp_g, st
 
 int map_dispatch(int stage, bool dp, bool dw, const xrd_nice_scene* scene,
                  int n_rays, const float* rays_o, const float* rays_d,
                  const float* gt_depth, const float* dmax,
                  const float* tgt_rgb, const uint8_t* keep, float w_color,
                  float* const gg[4], double* part, float* dw_rep,
-                 float* dw_scr, double* ray_loss, hipStream_t st) {
+                 float* dw_scr, double* ray_loss, float* exp_p, float* exp_g,
+                 hipStream_t st) {
   switch (stage) {
     case XRD_STAGE_MIDDLE:
       if (dp) return launch_map<XRD_STAGE_MIDDLE, true, false>(MAP_ARGS);
@@ -1154,8 +1166,28 @@ int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
                       float w_color, float* g_rays_o, float* g_rays_d,
                       float* const g_grid[4], float* g_dec_color, float* ws,
                       double* loss, xrd_stream_t stream) {
+  return xrd_nice_map_iter_export(scene, stage, n_rays, rays_o, rays_d,
+                                  gt_depth, dmax, tgt_rgb, keep, w_color,
+                                  g_rays_o, g_rays_d, g_grid, g_dec_color,
+                                  nullptr, nullptr, ws, loss, stream);
+}
+
+int xrd_nice_map_iter_export(const xrd_nice_scene* scene, int stage,
+                             int n_rays, const float* rays_o,
+                             const float* rays_d, const float* gt_depth,
+                             const float* dmax, const float* tgt_rgb,
+                             const uint8_t* keep, float w_color,
+                             float* g_rays_o, float* g_rays_d,
+                             float* const g_grid[4], float* g_dec_color,
+                             float* sample_points, float* g_occ, float* ws,
+                             double* loss, xrd_stream_t stream) {
   if (scene == nullptr || n_rays < 0 || stage < 0 || stage > 3)
     return XRD_ERR_ARG;
+  if ((sample_points == nullptr) != (g_occ == nullptr)) return XRD_ERR_ARG;
+  if (g_occ != nullptr && stage == XRD_STAGE_COARSE)
+    return XRD_ERR_UNSUPPORTED;
+  float* exp_p = sample_points;
+  float* exp_g = g_occ;
   if (!rays_o || !rays_d || !gt_depth || !ws) return XRD_ERR_ARG;
   if ((g_rays_o == nullptr) != (g_rays_d == nullptr)) return XRD_ERR_ARG;
   if (scene->t_uniform == nullptr) return XRD_ERR_ARG;
@@ -1204,7 +1236,7 @@ int xrd_nice_map_iter(const xrd_nice_scene* scene, int stage, int n_rays,
       ws + (rep_off + (size_t)kMapBlocks * kColorFlat + 3) / 4 * 4;
   int rc = map_dispatch(stage, dp, dw, scene, n_rays, rays_o, rays_d, gt_depth,
                         dmax, tgt_rgb, keep, w_color, gg, part, dw_rep, dw_scr,
-                        ray_loss, st);
+                        ray_loss, exp_p, exp_g, st);
   if (rc != XRD_OK) return rc;
   const int len = dw ? kColorFlat : 0;
   const int ngroups_map = (n_rays + 3) / 4;   // MapGeom::RPBM rays a group
@@ -1261,7 +1293,7 @@ int xrd_nice_track_iter(const xrd_nice_scene* scene, int n_rays,
   }
   double* part = reinterpret_cast<double*>(ws);
   double* ray_loss = part + (size_t)n_rays * 3 * 6;
-  TrackArgs trk;
+  TrackArgs trk = {};
   trk.ray_lossc = ray_loss + n_rays;
   trk.res = trk.ray_lossc + n_rays;
   trk.bar = reinterpret_cast<unsigned*>(trk.res + n_rays);
@@ -1291,7 +1323,8 @@ int xrd_nice_map_warmup(void) {
         if (dw && stage != XRD_STAGE_COLOR) continue;
         int rc = map_dispatch(stage, dp, dw, &sc, 0, nullptr, nullptr, nullptr,
                               nullptr, nullptr, nullptr, 0.f, gg, nullptr,
-                              nullptr, nullptr, nullptr, nullptr);
+                              nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr);
         if (rc != XRD_OK) return rc;
       }
   return XRD_OK;

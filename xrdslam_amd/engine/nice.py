@@ -347,8 +347,12 @@ def nice_map_iter(scene: NiceScene, stage: str, rays_o: torch.Tensor,
                   rays_d: torch.Tensor, gt_depth: torch.Tensor,
                   dmax: Optional[torch.Tensor], tgt_rgb: torch.Tensor,
                   keep: Optional[torch.Tensor], w_color: float,
-                  need_rays: bool, need_dec: bool):
-    """One mapping iteration of ``stage`` as one launch (+ one finishing
+                  need_rays: bool, need_dec: bool, export=None):
+    """``export``: a dict that receives 'points' [n*48,3] and 'g_occ' [n*48]
+    (the sample points and d loss / d occupancy logit of every sample,
+    xrd_nice_map_iter_export) — what decoder_weight_grad needs.
+
+    One mapping iteration of ``stage`` as one launch (+ one finishing
     launch): render, the mapping loss of conv_onet.py:178-184 and every
     gradient (``xrd_nice_map_iter``).  Grid gradients are accumulated into
     ``grid.grad`` of the stage's grids that require grad; returns
@@ -400,14 +404,76 @@ def nice_map_iter(scene: NiceScene, stage: str, rays_o: torch.Tensor,
             gg[gi] = _grid_grad_buffer(g).data_ptr()
             g._xrd_grad_fresh = True  # torch.Adam skips grad=None
             grid_grads = True
+    exp_p = exp_g = None
+    if export is not None and stage != 'coarse':
+        S = scene.n_total(stage, True)
+        exp_p = torch.empty(n * S, 3, dtype=torch.float32, device=dev)
+        exp_g = torch.empty(n * S, dtype=torch.float32, device=dev)
+        export['points'], export['g_occ'] = exp_p, exp_g
     with _Timed(('nice_map', stage, n, need_rays, need_dec, grid_grads)):
-        _lib.check(lib.xrd_nice_map_iter(
+        _lib.check(lib.xrd_nice_map_iter_export(
             C.byref(cs), STAGES[stage], n, _lib.ptr(rays_o), _lib.ptr(rays_d),
             _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(tc), _lib.ptr(keep),
             float(w_color), _lib.ptr(g_o), _lib.ptr(g_d), C.byref(gg),
-            _lib.ptr(g_flat), _lib.ptr(ws), _lib.ptr(loss),
-            _lib.stream_ptr(dev)), 'xrd_nice_map_iter')
+            _lib.ptr(g_flat), _lib.ptr(exp_p), _lib.ptr(exp_g), _lib.ptr(ws),
+            _lib.ptr(loss), _lib.stream_ptr(dev)), 'xrd_nice_map_iter_export')
     return loss, g_o, g_d, g_flat
+
+
+def _grid_features(grid, p, bound):
+    """MLP.sample_grid_feature (decoder_nice.py:195-205): f64 normalisation of
+    the points to [-1, 1] per axis, then F.grid_sample(bilinear, border,
+    align_corners=True) on the [1,32,Z,Y,X] grid -> [P,32]"""
+    b = bound
+    pn = ((p.double() - b[:, 0]) / (b[:, 1] - b[:, 0]) * 2 - 1).float()
+    c = torch.nn.functional.grid_sample(
+        grid, pn[None, :, None, None], padding_mode='border',
+        align_corners=True, mode='bilinear')
+    return c.reshape(grid.shape[1], -1).t()
+
+
+def decoder_weight_grad(scene: NiceScene, kind: str, flat: torch.Tensor,
+                        points: torch.Tensor, g_out: torch.Tensor):
+    """d loss / d parameters of the MIDDLE or FINE decoder from the exported
+    per-sample upstream gradient (mapping_fix_fine = False, conv_onet.py:62,
+    190-195; the fused launch contracts the colour decoder's weight gradient
+    only): the decoder of decoder_nice.py:207-234 is re-evaluated on the
+    sample points with torch ops ON THE DEVICE (grid features detached: the
+    grids' own gradient comes out of the launch) and sum(g_out * occupancy) is
+    back-propagated to its flat parameter.  Returns the flat gradient."""
+    assert kind in ('middle', 'fine')
+    F = torch.nn.functional
+    with torch.enable_grad():
+        w = flat.detach().requires_grad_(True)
+        sd, off = {}, 0
+        for name, shape in param_shapes(kind):
+            k = 1
+            for d in shape:
+                k *= d
+            sd[name] = w[off:off + k].view(shape)
+            off += k
+        # (the bound lives on the host; its device copy is made once, outside
+        # any graph capture: the first iteration of a segment runs eagerly)
+        bound = scene.__dict__.get('_bound_dev')
+        if bound is None or bound.device != points.device:
+            bound = scene._bound_dev = scene.bound.to(points.device)
+        with torch.no_grad():
+            c = _grid_features(scene.grids['grid_' + kind], points, bound)
+            if kind == 'fine':      # c = [c_fine, c_middle] (:215-217)
+                c = torch.cat([c, _grid_features(scene.grids['grid_middle'],
+                                                 points, bound)], 1)
+        emb = torch.sin(points.float() @ sd['embedder._B'])
+        h = emb
+        for i in range(5):
+            h = F.relu(F.linear(h, sd[f'pts_linears.{i}.weight'],
+                                sd[f'pts_linears.{i}.bias']))
+            h = h + F.linear(c, sd[f'fc_c.{i}.weight'], sd[f'fc_c.{i}.bias'])
+            if i == 2:
+                h = torch.cat([emb, h], -1)
+        out = F.linear(h, sd['output_linear.weight'],
+                       sd['output_linear.bias']).squeeze(-1)
+        (out * g_out).sum().backward()
+    return w.grad
 
 
 # Tracking iterations as one launch (xrd_nice_track_iter) instead of the

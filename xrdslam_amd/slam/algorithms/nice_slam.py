@@ -325,6 +325,12 @@ class NiceSLAM(Algorithm):
                 mcfg.rendering_n_surface == 16:
             return self._fused_map_step(idx, imgs, quat, bound6, det, n_pix,
                                         (Hedge, Wedge, wcrop), detach)
+        if is_mapping and not mcfg.mapping_fix_fine:
+            raise NotImplementedError(
+                'mapping_fix_fine=False needs the one-launch mapping iteration '
+                '(quaternion poses on the device, 32 + 16 samples a ray): the '
+                'fine decoder\'s weight gradient is formed from its exported '
+                'per-sample gradients')
         if quat is not None and not is_mapping and self.fused_map_launch \
                 and not det and all(p.requires_grad for p in quat[1]):
             return self._fused_track_step(idx, imgs, quat, bound6,
@@ -395,11 +401,21 @@ class NiceSLAM(Algorithm):
             getattr(scene, 'decoder_trainable', True) and \
             scene.dec_flat.get('color') is not None and \
             scene.dec_flat['color'].requires_grad
+        # mapping_fix_fine = False: the fine decoder trains in the stages that
+        # evaluate it (its weight gradient from the exported per-sample
+        # gradients, engine/nice.decoder_weight_grad)
+        fine = self.model.decoder.fine_decoder.flat
+        need_fine = (not mcfg.mapping_fix_fine) and \
+            stage in ('fine', 'color') and fine.requires_grad
+        export = {} if need_fine else None
         loss, g_o, g_d, g_flat = _en.nice_map_iter(
             scene, stage, ro_s, rd_s, td_s, dmax, tc_s, keep_s,
-            mcfg.mapping_w_color_loss, need_rays, need_dec)
+            mcfg.mapping_w_color_loss, need_rays, need_dec, export=export)
         if need_dec:
             scene.dec_flat['color'].grad = g_flat
+        if need_fine:
+            fine.grad = _en.decoder_weight_grad(
+                scene, 'fine', fine, export['points'], export['g_occ'])
         if need_rays:
             if sel is not None:
                 g_o = torch.zeros_like(ro).index_copy_(0, sel, g_o)
@@ -462,10 +478,20 @@ class NiceSLAM(Algorithm):
         self.set_stage(is_mapping, step, n_iters, coarse=coarse)
         if is_mapping:
             self.model.grid_processing(coarse=coarse)
-        if self.fused_iteration and getattr(self, 'fixed_shape_batches',
-                                            False) and \
-                torch.device(self.model.device).type == 'cuda':
+        on_gpu = torch.device(self.model.device).type == 'cuda'
+        # mapping_fix_fine = False: the fine decoder's weight gradient comes
+        # out of the one-launch iteration's export -> that path, captured or
+        # not (un-compacted batch + keep mask)
+        train_fine = is_mapping and not coarse and \
+            not self.model.config.mapping_fix_fine
+        if self.fused_iteration and on_gpu and \
+                (getattr(self, 'fixed_shape_batches', False) or train_fine):
             return self._fused_loss(optimize_frames, is_mapping)
+        if train_fine:
+            raise NotImplementedError(
+                'mapping_fix_fine=False runs on the fused mapping iteration '
+                '(CUDA device, fused_iteration): the generic hooks do not '
+                'produce the fine decoder\'s weight gradient')
         model_input = self.get_model_input(optimize_frames, is_mapping)
         outputs = self.model(model_input)
         losses = self.model.get_loss_dict(outputs, model_input, is_mapping,

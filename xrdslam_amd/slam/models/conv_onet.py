@@ -321,9 +321,11 @@ class ConvOnet(Model):
         groups: Dict[str, List[Parameter]] = {}
         dec_params = []
         if not self.config.mapping_fix_fine:
-            raise NotImplementedError(
-                'mapping_fix_fine=False: fine-decoder weight gradients are '
-                'not built yet (xrd_nice_render_bwd: XRD_ERR_UNSUPPORTED)')
+            # (conv_onet.py:190-195) the fine decoder trains too: its weight
+            # gradient is formed from the fused iteration's exported
+            # per-sample gradients (NiceSLAM._fused_map_step,
+            # engine/nice.decoder_weight_grad); the generic hooks refuse
+            dec_params.append(self.decoder.fine_decoder.flat)
         if not self.config.mapping_fix_color:
             dec_params.append(self.decoder.color_decoder.flat)
         if dec_params:
