@@ -486,6 +486,22 @@ int xrd_hashgrid_bwd(int n_levels, const float* scales, const uint32_t* res,
                      int64_t n_points, const float* x, const float* params,
                      const float* dy, float* dparams, float* dx,
                      xrd_stream_t stream);
+/* Co-SLAM's smoothness term (slam/models/joint_encoding.py:165-197) on the
+ * hash grid: total variation of the 2*L features on a random lattice of
+ * side^3 points voxel_size apart inside bound6 (xmin,xmax,ymin,ymax,zmin,zmax;
+ * HOST doubles).  rand_offset / rand_shift: the reference's two torch.rand
+ * draws (DEVICE doubles [3] each: lattice origin inside the volume, sub-voxel
+ * shift).  points [side^3,3] (normalised to the unit cube, f64 arithmetic like
+ * the reference's bbox), feat / dfeat [side^3, 2L]: the features and
+ * d loss / d features, loss [1] f64 = scale * sum of squared neighbour
+ * differences along the three axes / (side + 1)^3.  Three launches. */
+int xrd_hashgrid_tv(int n_levels, const float* scales, const uint32_t* res,
+                    const uint32_t* sizes, const uint32_t* offsets,
+                    const float* params, int side, const double* bound6,
+                    double voxel_size, double margin,
+                    const double* rand_offset, const double* rand_shift,
+                    float scale, float* points, float* feat, float* dfeat,
+                    double* loss, xrd_stream_t stream);
 /* OneBlob: y[n,dims*n_bins] (dimension-major), quartic kernel, periodic */
 int xrd_oneblob_fwd(int64_t n_points, int dims, int n_bins, const float* x,
                     float* y, xrd_stream_t stream);
@@ -1121,6 +1137,18 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                           const float* g_maps, const float* g_raw,
                           float* g_rays_o, float* g_rays_d, float* g_table,
                           float* g_dw, float* workspace, xrd_stream_t stream);
+/* ... with n_extra further points (extra_x [n_extra,3] normalised like the
+ * samples, extra_dfeat [n_extra, 32] = d loss / d their hash features, e.g.
+ * xrd_hashgrid_tv's lattice) whose table gradient joins the samples' in the
+ * SAME scatter launch (a second scatter costs as much as the first).
+ * workspace: xrd_coslam_bwd_ws_floats_extra(n_rays, n_extra) floats. */
+int64_t xrd_coslam_bwd_ws_floats_extra(int n_rays, int64_t n_extra);
+int xrd_coslam_render_bwd_extra(
+    const xrd_coslam_scene* scene, int n_rays, const float* rays_o,
+    const float* rays_d, const float* z_vals, const float* raw,
+    const float* g_maps, const float* g_raw, float* g_rays_o, float* g_rays_d,
+    float* g_table, float* g_dw, int64_t n_extra, const float* extra_x,
+    const float* extra_dfeat, float* workspace, xrd_stream_t stream);
 
 /* Co-SLAM mapping batch (slam/algorithms/coslam.py:139-150 sample_global_rays,
  * :152-210 get_model_input).

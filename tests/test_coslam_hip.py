@@ -73,6 +73,74 @@ def test_fused_loss_vs_reference(tag, is_mapping, first):
     assert not bad, bad
 
 
+def test_fused_smoothness_equals_the_torch_formulation():
+    """the smoothness term on xrd_hashgrid_tv (lattice points, hash features,
+    TV loss and feature gradient as three launches; its table gradient either
+    scattered on its own or handed to a pending render backward, whose ONE
+    scatter launch then carries both) against the torch formulation
+    (JointEncoding.smoothness, pinned to the reference by the goldens): same
+    draws, loss and table gradient, alone and next to the render."""
+    from xrdslam_amd.engine import coslam as ec
+    model = cg.build_office0_model('cuda:0')
+    cfg = model.config
+    w = cfg.trainging_smooth_weight * 1e4     # well above f32 noise
+    dev = 'cuda:0'
+    tab = model.embed_fn.params
+
+    def draws():
+        gen = torch.Generator(device=dev).manual_seed(5)
+        return lambda shape, like: torch.rand(shape, device=like.device,
+                                              dtype=like.dtype, generator=gen)
+
+    # --- alone -------------------------------------------------------------
+    tab.grad = None
+    model._rand = draws()
+    ref = model.smoothness(cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
+                           cfg.trainging_smooth_margin) * w
+    ref.backward()
+    g_ref = tab.grad.clone()
+    tab.grad = None
+    model._rand = draws()
+    model._render_bwd_pending = False
+    got = ec.smoothness(model, cfg.trainging_smooth_pts - 1,
+                        cfg.trainging_smooth_vox, cfg.trainging_smooth_margin,
+                        w)
+    got.backward()
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(ref)) < 1e-5 * abs(float(ref))
+    assert float(g_ref.abs().max()) > 0
+    err = float((tab.grad - g_ref).abs().max() / g_ref.abs().max())
+    assert err < 1e-4, err
+    # --- next to the fused render: one scatter for both ---------------------
+    n = 512
+    ro, rd, depth, color = [t.to(dev) for t in cg.office0_inputs(n, 3)]
+    inp = {'rays_o': ro, 'rays_d': rd, 'target_d': depth, 'target_s': color,
+           'first': False}
+    res = {}
+    for fused in (False, True):
+        model.fused_smoothness = fused
+        model.fused_losses = True
+        for p_ in model.parameters():
+            p_.grad = None
+        tab.grad = None
+        model._rand = draws()
+        out = model.get_outputs(inp)
+        ld = model.get_loss_dict(out, inp, True, 0)
+        assert 'smooth_loss' in ld
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        res[fused] = (float(ld['smooth_loss']), tab.grad.clone())
+        if fused:       # the lattice left with the render's scatter
+            assert model._smooth_stash is None
+            assert not model._render_bwd_pending
+    del model._rand
+    model.fused_smoothness = True
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    err = float((res[True][1] - res[False][1]).abs().max() /
+                res[False][1].abs().max())
+    assert err < 1e-4, err
+
+
 def test_fused_tracking_iteration_matches_generic_hooks():
     """CoSLAM.get_loss through the fused launches (sampling, render, loss)
     equals the generic get_model_input -> model -> get_loss_dict path on the

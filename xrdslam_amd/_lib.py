@@ -116,6 +116,8 @@ _SIGS = {
                                    vp]),
     'xrd_hashgrid_bwd': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, vp, vp,
                                    vp, vp, vp]),
+    'xrd_hashgrid_tv': (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, vp,
+                                  f64, f64, vp, vp, f32, vp, vp, vp, vp, vp]),
     'xrd_oneblob_fwd': (C.c_int, [i64, C.c_int, C.c_int, vp, vp, vp]),
     'xrd_oneblob_bwd': (C.c_int, [i64, C.c_int, C.c_int, vp, vp, vp, vp]),
     'xrd_octree_create': (vp, [C.c_int, C.c_int, f64]),
@@ -220,6 +222,9 @@ _SIGS = {
     'xrd_coslam_bwd_ws_floats': (i64, [C.c_int]),
     'xrd_coslam_render_bwd': (C.c_int, [C.POINTER(CoslamScene), C.c_int] +
                               [vp] * 12),
+    'xrd_coslam_bwd_ws_floats_extra': (i64, [C.c_int, i64]),
+    'xrd_coslam_render_bwd_extra': (C.c_int, [C.POINTER(CoslamScene), C.c_int]
+                                    + [vp] * 10 + [i64] + [vp] * 4),
     'xrd_sample_distinct': (C.c_int, [i64, C.c_int, vp, vp, vp]),
     'xrd_sample_distinct_dev': (C.c_int, [vp, C.c_int, vp, vp, vp]),
     'xrd_pose_rays_fwd': (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),

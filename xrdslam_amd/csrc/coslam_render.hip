@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
     const float* __restrict__ raw, const float* __restrict__ g_maps,
     const float* __restrict__ g_raw, float* __restrict__ g_o,
     float* __restrict__ g_d, float* __restrict__ partials,
-    float* __restrict__ xs, float* __restrict__ dfeat) {
+    float* __restrict__ xs, float* __restrict__ dfeat, int64_t n_extra) {
   __shared__ __attribute__((aligned(16))) float lds[kBwdWaves * kStage];
   __shared__ LevelTab lt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -486,7 +486,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
   const int S = sc.n_range_d + sc.n_sample_d;
   const int NT = (S + 15) >> 4;
   const int tiles = n_rays * NT;
-  const size_t n_samples = (size_t)n_rays * S;
+  // (level stride of dfeat: the samples + the extra points appended behind
+  // them for the merged table scatter)
+  const size_t n_samples = (size_t)n_rays * S + (size_t)n_extra;
 #ifdef XRD_CS_NO_DW  // experiment switch
   constexpr bool DW = false;
 #else
@@ -963,9 +965,12 @@ int xrd_coslam_render_fwd(const xrd_coslam_scene* scene, int n_rays,
 // workspace: [block partials of dW][normalised sample positions N*3]
 // [hash-feature gradients 16*N*2], N = n_rays * kMaxS
 int64_t xrd_coslam_bwd_ws_floats(int n_rays) {
-  if (n_rays < 0) return -1;
+  return xrd_coslam_bwd_ws_floats_extra(n_rays, 0);
+}
+int64_t xrd_coslam_bwd_ws_floats_extra(int n_rays, int64_t n_extra) {
+  if (n_rays < 0 || n_extra < 0) return -1;
   return (int64_t)kBwdMaxBlocks * cs::kDwLen +
-         (int64_t)n_rays * kMaxS * (3 + 2 * XRD_COSLAM_LEVELS);
+         ((int64_t)n_rays * kMaxS + n_extra) * (3 + 2 * XRD_COSLAM_LEVELS);
 }
 
 int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
@@ -974,8 +979,44 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                           const float* g_maps, const float* g_raw,
                           float* g_rays_o, float* g_rays_d, float* g_table,
                           float* g_dw, float* workspace, xrd_stream_t stream) {
+  return xrd_coslam_render_bwd_extra(scene, n_rays, rays_o, rays_d, z_vals,
+                                     raw, g_maps, g_raw, g_rays_o, g_rays_d,
+                                     g_table, g_dw, 0, nullptr, nullptr,
+                                     workspace, stream);
+}
+
+// extra points [n_extra,3] (normalised like the samples) with feature
+// gradients [n_extra, 32] (point-major) -> behind the samples in the
+// level-major staging of the table scatter
+namespace xrd {
+namespace {
+__global__ __launch_bounds__(256) void coslam_extra_stage_kernel(
+    int64_t n_extra, int64_t n_own, const float* __restrict__ ex,
+    const float* __restrict__ edf, float* __restrict__ xs,
+    float* __restrict__ dfeat) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = threadIdx.x & 15;
+  const int64_t p = gid >> 4;
+  if (p >= n_extra) return;
+  const int64_t stride = n_own + n_extra;
+  *reinterpret_cast<float2*>(dfeat + ((size_t)l * stride + n_own + p) * 2) =
+      *reinterpret_cast<const float2*>(edf + p * 2 * XRD_COSLAM_LEVELS +
+                                       2 * l);
+  if (l < 3) xs[(n_own + p) * 3 + l] = ex[p * 3 + l];
+}
+}  // namespace
+}  // namespace xrd
+
+int xrd_coslam_render_bwd_extra(
+    const xrd_coslam_scene* scene, int n_rays, const float* rays_o,
+    const float* rays_d, const float* z_vals, const float* raw,
+    const float* g_maps, const float* g_raw, float* g_rays_o, float* g_rays_d,
+    float* g_table, float* g_dw, int64_t n_extra, const float* extra_x,
+    const float* extra_dfeat, float* workspace, xrd_stream_t stream) {
   int rc = check_scene(scene, n_rays);
   if (rc != XRD_OK) return rc;
+  if (n_extra < 0 || (n_extra > 0 && (!extra_x || !extra_dfeat || !g_table)))
+    return XRD_ERR_ARG;
   if (!rays_o || !rays_d || !z_vals || !raw || !g_maps) return XRD_ERR_ARG;
   const bool dp = g_rays_o != nullptr || g_rays_d != nullptr;
   const bool dg = g_table != nullptr || g_dw != nullptr;
@@ -996,12 +1037,12 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
   if (dg && blocks > kBwdMaxBlocks) blocks = kBwdMaxBlocks;
   const int64_t n_samples = (int64_t)n_rays * S;
   float* xs = dg ? workspace + (size_t)kBwdMaxBlocks * cs::kDwLen : nullptr;
-  float* dfeat = dg ? xs + n_samples * 3 : nullptr;
+  float* dfeat = dg ? xs + (n_samples + n_extra) * 3 : nullptr;
 #define BWD_CASE(DPV, DGV)                                                    \
   hipLaunchKernelGGL((coslam_bwd_kernel<DPV, DGV>), dim3(blocks),             \
                      dim3(kBwdWaves * 64), 0, st, *scene, n_rays, rays_o,     \
                      rays_d, z_vals, raw, g_maps, g_raw, g_rays_o, g_rays_d,  \
-                     workspace, xs, dfeat)
+                     workspace, xs, dfeat, n_extra)
   // map + pose gradients: two launches (each recomputes the tile's forward)
   // beat the combined variant, which needs all 512 registers and runs at one
   // wave per SIMD: 2.8 + 3.3 ms vs 9.1 ms at 1e5 rays, 0.23 vs 0.36 ms at
@@ -1024,11 +1065,21 @@ int xrd_coslam_render_bwd(const xrd_coslam_scene* scene, int n_rays,
                        dim3(256), 0, st, workspace, blocks, chunk, g_dw);
     rc = check_launch("coslam_reduce_kernel");
     if (rc != XRD_OK) return rc;
+    if (n_extra > 0) {
+      hipLaunchKernelGGL(coslam_extra_stage_kernel,
+                         dim3((unsigned)((n_extra * 16 + 255) / 256)), dim3(256),
+                         0, st, n_extra, n_samples, extra_x, extra_dfeat, xs,
+                         dfeat);
+      rc = check_launch("coslam_extra_stage_kernel");
+      if (rc != XRD_OK) return rc;
+    }
+    // ONE scatter for the samples and the extra points (the smoothness
+    // lattice): a second launch costs as much as the first (~140 us)
     rc = launch_hash_chunk_scatter(XRD_COSLAM_LEVELS, scene->lv_scale,
                                    scene->lv_res, scene->lv_size,
-                                   scene->lv_offset, n_samples, xs, dfeat, 2,
-                                   2 * n_samples, g_table,
-                                   /*accumulate=*/false, stream);
+                                   scene->lv_offset, n_samples + n_extra, xs,
+                                   dfeat, 2, 2 * (n_samples + n_extra),
+                                   g_table, /*accumulate=*/false, stream);
   }
   return rc;
 }

@@ -121,6 +121,79 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(
   }
 }
 
+// ---- Co-SLAM smoothness term (joint_encoding.py:165-197) as kernels ---------------
+// total variation of the hash features on a random R^3 lattice (R = 31 points
+// a side, 0.1 m apart): the lattice points (f64 like the reference's bbox
+// arithmetic), then — after a hashgrid forward over them — the loss and
+// d loss / d features in one launch.  ~35 torch launches (coordinates, the
+// arithmetic around them, three slice-subtract-square-sum chains and their
+// autograd backward) become three.
+__global__ __launch_bounds__(256) void tv_points_kernel(
+    int R, double vs, double margin, double b0x, double b0y, double b0z,
+    double vx, double vy, double vz, const double* __restrict__ r_off,
+    const double* __restrict__ r_shift, float* __restrict__ pts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= R * R * R) return;
+  const int c[3] = {p / (R * R), (p / R) % R, p % R};
+  const double b0[3] = {b0x, b0y, b0z}, vol[3] = {vx, vy, vz};
+  const double grid_size = (double)R * vs;   // (sample_points - 1) * voxel
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double omax = vol[a] - grid_size - 2.0 * margin;
+    const double off = r_off[a] * omax + margin;
+    // pts = (coords + rand) * voxel + bb0 + offset;  (pts - bb0) / volume
+    const double x = (((double)c[a] + r_shift[a]) * vs + b0[a]) + off;
+    pts[p * 3 + a] = (float)((x - b0[a]) / vol[a]);
+  }
+}
+
+// one 16-lane group per lattice point, lane = level (float2 per level)
+__global__ __launch_bounds__(256) void tv_loss_kernel(
+    int R, int L, float gscale, const float* __restrict__ feat,
+    float* __restrict__ dfeat, double* __restrict__ loss) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lvl_lane = threadIdx.x & 15;
+  const int p = (int)(gid >> 4);
+  const int P = R * R * R;
+  float part = 0.f;
+  if (p < P) {
+    const int c[3] = {p / (R * R), (p / R) % R, p % R};
+    const int st[3] = {R * R, R, 1};
+    for (int l = lvl_lane; l < L; l += 16) {
+      const float2 f0 =
+          *reinterpret_cast<const float2*>(feat + (size_t)p * 2 * L + 2 * l);
+      float2 g = {0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (c[a] + 1 < R) {
+          const float2 f1 = *reinterpret_cast<const float2*>(
+              feat + (size_t)(p + st[a]) * 2 * L + 2 * l);
+          const float dx = f1.x - f0.x, dy = f1.y - f0.y;
+          part += dx * dx + dy * dy;
+          g.x -= 2.f * dx;
+          g.y -= 2.f * dy;
+        }
+        if (c[a] > 0) {
+          const float2 f1 = *reinterpret_cast<const float2*>(
+              feat + (size_t)(p - st[a]) * 2 * L + 2 * l);
+          g.x += 2.f * (f0.x - f1.x);
+          g.y += 2.f * (f0.y - f1.y);
+        }
+      }
+      *reinterpret_cast<float2*>(dfeat + (size_t)p * 2 * L + 2 * l) =
+          make_float2(g.x * gscale, g.y * gscale);
+    }
+  }
+  __shared__ double sh[4];
+  const double s = wave_sum((double)part);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (t != 0.0) atomicAdd(loss, t * (double)gscale);
+  }
+}
+
 // ---- gradient scatter, LDS-privatised per (level, chunk, point slice) --------
 // Random f32 global atomics run at ~5-10 G transactions/s on MI355X (measured:
 // 1.3 ms for the 7 M corner updates of one Co-SLAM mapping batch).  The tables
@@ -386,6 +459,42 @@ int xrd_hashgrid_bwd(int n_levels, const float* scales, const uint32_t* res,
     rc = check_launch("xrd_hashgrid_bwd");
   }
   return rc;
+}
+
+int xrd_hashgrid_tv(int n_levels, const float* scales, const uint32_t* res,
+                    const uint32_t* sizes, const uint32_t* offsets,
+                    const float* params, int side, const double* bound6,
+                    double voxel_size, double margin,
+                    const double* rand_offset, const double* rand_shift,
+                    float scale, float* points, float* feat, float* dfeat,
+                    double* loss, xrd_stream_t stream) {
+  HashMeta M;
+  int rc = fill_meta(M, n_levels, scales, res, sizes, offsets);
+  if (rc != XRD_OK) return rc;
+  if (side < 2 || side > 128 || !bound6 || !(voxel_size > 0.0))
+    return XRD_ERR_ARG;
+  if (!params || !rand_offset || !rand_shift || !points || !feat || !dfeat ||
+      !loss)
+    return XRD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = side * side * side;
+  rc = zero_floats(reinterpret_cast<float*>(loss), 2, stream);
+  if (rc != XRD_OK) return rc;
+  hipLaunchKernelGGL(tv_points_kernel, dim3((P + 255) / 256), dim3(256), 0, st,
+                     side, voxel_size, margin, bound6[0], bound6[2], bound6[4],
+                     bound6[1] - bound6[0], bound6[3] - bound6[2],
+                     bound6[5] - bound6[4], rand_offset, rand_shift, points);
+  const int64_t threads = (int64_t)P * 16;
+  hipLaunchKernelGGL((hashgrid_kernel<false>),
+                     dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                     M, (int64_t)P, points, params, feat, nullptr, nullptr,
+                     nullptr);
+  // loss = scale * tv / (side + 1)^3 (joint_encoding.py:197: sample_points^3)
+  const double n3 = (double)(side + 1) * (side + 1) * (side + 1);
+  hipLaunchKernelGGL(tv_loss_kernel, dim3((unsigned)((threads + 255) / 256)),
+                     dim3(256), 0, st, side, n_levels, (float)(scale / n3),
+                     feat, dfeat, loss);
+  return check_launch("xrd_hashgrid_tv");
 }
 
 int xrd_oneblob_fwd(int64_t n_points, int dims, int n_bins, const float* x,

@@ -99,8 +99,8 @@ class SceneTables:
         self.device = torch.device(device)
         self._ws = None
 
-    def workspace(self, n_rays):
-        need = _lib.lib().xrd_coslam_bwd_ws_floats(n_rays)
+    def workspace(self, n_rays, n_extra=0):
+        need = _lib.lib().xrd_coslam_bwd_ws_floats_extra(n_rays, n_extra)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.float32,
                                    device=self.device)
@@ -158,7 +158,11 @@ class _CoslamRenderFn(torch.autograd.Function):
                 C.byref(sc), n, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(td),
                 _lib.ptr(rn), _lib.ptr(z_vals), _lib.ptr(raw), _lib.ptr(maps),
                 _lib.stream_ptr(dev)), 'xrd_coslam_render_fwd')
-        ctx.sc, ctx.tables = sc, tables
+        ctx.sc, ctx.tables, ctx.model = sc, tables, model
+        # (the smoothness term's lattice joins THIS backward's table scatter
+        # when it runs first, see _SmoothFn)
+        model._render_bwd_pending = bool(table.requires_grad)
+        model._smooth_stash = None
         ctx.save_for_backward(ro, rd, z_vals, raw, table, pack)
         ctx.mark_non_differentiable(z_vals)
         # gradients of the non-differentiable outputs arrive as None instead
@@ -185,18 +189,99 @@ class _CoslamRenderFn(torch.autograd.Function):
             if g_maps is None else g_maps.float().contiguous()
         if g_raw is not None:
             g_raw = g_raw.float().contiguous()
-        ws = _lib.ptr(ctx.tables.workspace(n)) if need_map else None
+        model = ctx.model
+        model._render_bwd_pending = False
+        stash, model._smooth_stash = getattr(model, '_smooth_stash', None), \
+            None
+        ex = ed = None
+        n_extra = 0
+        if need_map and stash is not None:
+            ex, ed = stash
+            n_extra = ex.shape[0]
+        ws = _lib.ptr(ctx.tables.workspace(n, n_extra)) if need_map else None
         with _Timed(('coslam_bwd', n, bool(need_rays), bool(need_map))):
-            _lib.check(lib.xrd_coslam_render_bwd(
+            _lib.check(lib.xrd_coslam_render_bwd_extra(
                 C.byref(ctx.sc), n, _lib.ptr(ro), _lib.ptr(rd),
                 _lib.ptr(z_vals), _lib.ptr(raw), _lib.ptr(g_maps),
                 _lib.ptr(g_raw), _lib.ptr(g_o), _lib.ptr(g_d),
-                _lib.ptr(g_table), _lib.ptr(g_dw), ws,
-                _lib.stream_ptr(dev)), 'xrd_coslam_render_bwd')
+                _lib.ptr(g_table), _lib.ptr(g_dw), n_extra, _lib.ptr(ex),
+                _lib.ptr(ed), ws, _lib.stream_ptr(dev)),
+                'xrd_coslam_render_bwd_extra')
         g_flat = None
         if need_map:
             g_flat = g_dw[_index(dev)[1]]
         return g_o, g_d, None, None, g_table, g_flat, None, None
+
+
+class _SmoothFn(torch.autograd.Function):
+    """JointEncoding.smoothness (joint_encoding.py:165-197) x ``scale`` on the
+    kernels of xrd_hashgrid_tv: lattice points, hash features, TV loss and
+    d loss / d features in three launches.  The backward does NOT scatter into
+    the table itself when a fused render backward of the same iteration is
+    still to come: it leaves (points, d features) for it, and the table
+    gradient of both leaves in ONE scatter launch.  If no render backward is
+    pending it scatters on its own (xrd_hashgrid_bwd)."""
+
+    @staticmethod
+    def forward(ctx, table, model, side, voxel, margin, scale, r_off,
+                r_shift):
+        lib = _lib.lib()
+        enc = model.embed_fn
+        dev = table.device
+        L = enc.n_output_dims // 2
+        P = side**3
+        f = dict(dtype=torch.float32, device=dev)
+        pts, feat = torch.empty(P, 3, **f), torch.empty(P, 2 * L, **f)
+        dfeat = torch.empty(P, 2 * L, **f)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        bb = np.ascontiguousarray(
+            model.bounding_box.detach().cpu().double().numpy().reshape(-1))
+        t = table.detach()
+        _lib.check(lib.xrd_hashgrid_tv(
+            L, enc._scales.ctypes.data, enc._res.ctypes.data,
+            enc._sizes.ctypes.data, enc._offsets.ctypes.data, _lib.ptr(t),
+            int(side), bb.ctypes.data, float(voxel), float(margin),
+            _lib.ptr(r_off), _lib.ptr(r_shift), float(scale), _lib.ptr(pts),
+            _lib.ptr(feat), _lib.ptr(dfeat), _lib.ptr(loss),
+            _lib.stream_ptr(dev)), 'xrd_hashgrid_tv')
+        ctx.model, ctx.L = model, L
+        ctx.save_for_backward(pts, dfeat, t)
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, dfeat, t = ctx.saved_tensors
+        model = ctx.model
+        d = dfeat * g.float()
+        if getattr(model, '_render_bwd_pending', False):
+            model._smooth_stash = (pts, d)
+            return (None, ) * 8
+        lib = _lib.lib()
+        enc = model.embed_fn
+        g_table = torch.zeros_like(t)
+        _lib.check(lib.xrd_hashgrid_bwd(
+            ctx.L, enc._scales.ctypes.data, enc._res.ctypes.data,
+            enc._sizes.ctypes.data, enc._offsets.ctypes.data, pts.shape[0],
+            _lib.ptr(pts), _lib.ptr(t), _lib.ptr(d.contiguous()),
+            _lib.ptr(g_table), None, _lib.stream_ptr(t.device)),
+            'xrd_hashgrid_bwd')
+        return (g_table, ) + (None, ) * 7
+
+
+def smoothness(model, side, voxel, margin, scale):
+    """the smoothness term of the mapping loss, already multiplied by
+    ``scale`` (= its weight); draws the reference's two random vectors with
+    the model's generator hook (same RNG consumption as the torch path)"""
+    dev = model.embed_fn.params.device
+    bb = model._bbox(dev)
+    volume = bb[:, 1] - bb[:, 0]
+    offset_max = volume - (side * voxel) - 2 * margin
+    r_off = model._rand((3, ), offset_max).double().contiguous()
+    r_shift = model._rand((1, 1, 1, 3), volume).double().reshape(3) \
+        .contiguous()
+    return _SmoothFn.apply(model.embed_fn.params, model, int(side),
+                           float(voxel), float(margin), float(scale), r_off,
+                           r_shift)
 
 
 def render(model, tables, rays_o, rays_d, target_d, rnd, train_map=True):

@@ -131,10 +131,19 @@ class JointEncoding(Model):
             self.last_loss_terms = l5
             losses = {'data_loss': total}
             if is_mapping and not inputs['first']:
-                losses['smooth_loss'] = self.smoothness(
-                    cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
-                    cfg.trainging_smooth_margin) * \
-                    (cfg.trainging_smooth_weight * smooth_scale)
+                if self.fused_smoothness and cfg.tcnn_encoding:
+                    # lattice points, hash features, TV loss and its feature
+                    # gradient as three launches; the table gradient leaves
+                    # with the render backward's scatter (engine/coslam.py)
+                    losses['smooth_loss'] = ec.smoothness(
+                        self, cfg.trainging_smooth_pts - 1,
+                        cfg.trainging_smooth_vox, cfg.trainging_smooth_margin,
+                        cfg.trainging_smooth_weight * smooth_scale)
+                else:
+                    losses['smooth_loss'] = self.smoothness(
+                        cfg.trainging_smooth_pts, cfg.trainging_smooth_vox,
+                        cfg.trainging_smooth_margin) * \
+                        (cfg.trainging_smooth_weight * smooth_scale)
             return losses
         if sharded:
             losses = self._sharded_data_losses(outputs, inputs)
@@ -211,6 +220,8 @@ class JointEncoding(Model):
             cfg.trainging_depth_weight,
             'sdf_loss': sdf_sum / (n * S) * sdf_w * cfg.trainging_sdf_weight,
             'fs_loss': fs_sum / (n * S) * fs_w * cfg.trainging_fs_weight}
+
+    fused_smoothness = True   # the smoothness term on xrd_hashgrid_tv (CUDA)
 
     def smoothness(self, sample_points=256, voxel_size=0.1, margin=0.05):
         """total variation of the hash features on a random lattice"""
