@@ -1169,6 +1169,18 @@ int xrd_sample_distinct_dev(const int64_t* n_total, int n_out,
                             xrd_stream_t stream);
 int xrd_sample_distinct(int64_t n_total, int n_out, const int64_t* keys4,
                         int64_t* out_idx, xrd_stream_t stream);
+/* The mapping batch in one launch: bank rows at bank_idx [n_bank] (int64) of
+ * the keyframe ray bank [*,7] + the current frame's pixels pix [n_cur] (int64,
+ * flat) gathered from ray_dirs [H*W,3], rgb [H*W,3], depth [H*W] -> rows
+ * [n_bank+n_cur,7] = (direction, rgb, depth), ids [n_bank+n_cur] int64 = pose
+ * row of every ray (bank row / rays_per_keyframe; *cur_id, a device scalar,
+ * for the current frame's) — coslam.py:139-150 (sample_global_rays) and the
+ * concatenations of :152-210. */
+int xrd_coslam_map_rows(int n_bank, const int64_t* bank_idx, const float* bank,
+                        int rays_per_keyframe, int n_cur, const int64_t* pix,
+                        const float* ray_dirs, const float* rgb,
+                        const float* depth, const int64_t* cur_id, float* rows,
+                        int64_t* ids, xrd_stream_t stream);
 int xrd_pose_rays_fwd(int n, const float* dirs, int dir_stride,
                       const int64_t* pose_ids, const float* c2w, float* rays_o,
                       float* rays_d, xrd_stream_t stream);

@@ -73,6 +73,29 @@ def test_fused_loss_vs_reference(tag, is_mapping, first):
     assert not bad, bad
 
 
+def test_map_rows_kernel_equals_the_torch_gathers():
+    """xrd_coslam_map_rows against the index / floor-divide / gather / cat
+    chain it replaces (coslam.py:139-150,152-210), bit for bit"""
+    from xrdslam_amd.engine import slam_ops
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(1)
+    HW, per_kf, K = 640 * 480, 15360, 7
+    bank = torch.rand(2 * K * per_kf, 7, generator=g).to(dev)
+    dirs = torch.randn(HW, 3, generator=g).to(dev)
+    rgb = torch.rand(HW, 3, generator=g).to(dev)
+    depth = torch.rand(HW, 1, generator=g).to(dev)
+    idx = torch.randint(0, K * per_kf, (2048, ), generator=g).to(dev)
+    pix = torch.randint(0, HW, (341, ), generator=g).to(dev)
+    cur = torch.tensor([K], dtype=torch.int64, device=dev)
+    rows, ids = slam_ops.coslam_map_rows(bank, idx, per_kf, pix, dirs, rgb,
+                                         depth, cur)
+    want = torch.cat([bank[idx], torch.cat([dirs[pix], rgb[pix],
+                                            depth[pix]], -1)], 0)
+    want_ids = torch.cat([torch.div(idx, per_kf, rounding_mode='floor'),
+                          cur.expand(341)], 0)
+    assert torch.equal(rows, want) and torch.equal(ids, want_ids)
+
+
 def test_fused_smoothness_equals_the_torch_formulation():
     """the smoothness term on xrd_hashgrid_tv (lattice points, hash features,
     TV loss and feature gradient as three launches; its table gradient either

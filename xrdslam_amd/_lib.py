@@ -227,6 +227,8 @@ _SIGS = {
                                     + [vp] * 10 + [i64] + [vp] * 4),
     'xrd_sample_distinct': (C.c_int, [i64, C.c_int, vp, vp, vp]),
     'xrd_sample_distinct_dev': (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    'xrd_coslam_map_rows': (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int] +
+                            [vp] * 8),
     'xrd_pose_rays_fwd': (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
     'xrd_pose_rays_bwd': (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp,
                                     vp, vp]),

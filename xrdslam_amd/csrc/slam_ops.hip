@@ -908,6 +908,66 @@ int xrd_sample_distinct_dev(const int64_t* n_total, int n_out,
   return check_launch("xrd_sample_distinct_dev");
 }
 
+// Co-SLAM mapping batch (slam/algorithms/coslam.py:139-150,152-210): rows of
+// the keyframe ray bank at bank_idx + the current frame's pixels pix ->
+// rows [n_bank + n_cur, 7] = (camera-frame direction, rgb, depth) and the pose
+// id of every row (bank row / rays per keyframe; *cur_id for the current
+// frame).  One launch for two index gathers, a floor division, three image
+// gathers and four concatenations.
+namespace xrd {
+namespace {
+__global__ __launch_bounds__(256) void coslam_map_rows_kernel(
+    int n_bank, const int64_t* __restrict__ bank_idx,
+    const float* __restrict__ bank, int rays_per_kf, int n_cur,
+    const int64_t* __restrict__ pix, const float* __restrict__ dirs,
+    const float* __restrict__ rgb, const float* __restrict__ depth,
+    const int64_t* __restrict__ cur_id, float* __restrict__ rows,
+    int64_t* __restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_bank + n_cur) return;
+  float v[7];
+  int64_t id;
+  if (i < n_bank) {
+    const int64_t r = bank_idx[i];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) v[c] = bank[r * 7 + c];
+    id = r / rays_per_kf;
+  } else {
+    const int64_t p = pix[i - n_bank];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v[c] = dirs[p * 3 + c];
+      v[3 + c] = rgb[p * 3 + c];
+    }
+    v[6] = depth[p];
+    id = cur_id[0];
+  }
+#pragma unroll
+  for (int c = 0; c < 7; ++c) rows[(size_t)i * 7 + c] = v[c];
+  ids[i] = id;
+}
+}  // namespace
+}  // namespace xrd
+
+int xrd_coslam_map_rows(int n_bank, const int64_t* bank_idx, const float* bank,
+                        int rays_per_keyframe, int n_cur, const int64_t* pix,
+                        const float* ray_dirs, const float* rgb,
+                        const float* depth, const int64_t* cur_id, float* rows,
+                        int64_t* ids, xrd_stream_t stream) {
+  if (n_bank < 0 || n_cur < 0 || rays_per_keyframe < 1) return XRD_ERR_ARG;
+  if (!rows || !ids) return XRD_ERR_ARG;
+  if (n_bank > 0 && (!bank_idx || !bank)) return XRD_ERR_ARG;
+  if (n_cur > 0 && (!pix || !ray_dirs || !rgb || !depth || !cur_id))
+    return XRD_ERR_ARG;
+  const int n = n_bank + n_cur;
+  if (n == 0) return XRD_OK;
+  hipLaunchKernelGGL(xrd::coslam_map_rows_kernel, dim3((n + 255) / 256),
+                     dim3(256), 0, (hipStream_t)stream, n_bank, bank_idx, bank,
+                     rays_per_keyframe, n_cur, pix, ray_dirs, rgb, depth,
+                     cur_id, rows, ids);
+  return xrd::check_launch("xrd_coslam_map_rows");
+}
+
 int xrd_pose_rays_fwd(int n, const float* dirs, int dir_stride,
                       const int64_t* pose_ids, const float* c2w, float* rays_o,
                       float* rays_d, xrd_stream_t stream) {

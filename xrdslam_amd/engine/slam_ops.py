@@ -466,6 +466,25 @@ def sample_distinct_dev(n_total_dev, n_out: int, device, generator=None):
     return out
 
 
+def coslam_map_rows(bank, bank_idx, rays_per_keyframe, pix, ray_dirs, rgb,
+                    depth, cur_id):
+    """-> (rows [n,7], ids [n] int64) of a Co-SLAM mapping batch: bank rows at
+    ``bank_idx`` + the current frame's pixels ``pix`` (xrd_coslam_map_rows)"""
+    dev = bank.device
+    nb = 0 if bank_idx is None else bank_idx.shape[0]
+    nc = pix.shape[0]
+    rows = torch.empty(nb + nc, 7, dtype=torch.float32, device=dev)
+    ids = torch.empty(nb + nc, dtype=torch.int64, device=dev)
+    assert bank.dtype == torch.float32 and bank.is_contiguous()
+    _lib.check(_lib.lib().xrd_coslam_map_rows(
+        nb, _lib.ptr(bank_idx), _lib.ptr(bank), int(rays_per_keyframe), nc,
+        _lib.ptr(pix), _lib.ptr(ray_dirs.contiguous()),
+        _lib.ptr(rgb.contiguous()), _lib.ptr(depth.contiguous()),
+        _lib.ptr(cur_id), _lib.ptr(rows), _lib.ptr(ids),
+        _lib.stream_ptr(dev)), 'xrd_coslam_map_rows')
+    return rows, ids
+
+
 class PoseRaysFn(torch.autograd.Function):
     """rays_o, rays_d of rays with per-ray pose ids: rays_d = R[id] dir,
     rays_o = t[id]; differentiable w.r.t. c2w [n_pose,4,4].  ``rows`` [n,>=3]

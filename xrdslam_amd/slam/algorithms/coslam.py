@@ -355,14 +355,12 @@ class CoSLAM(Algorithm):
         c2w = torch.where(slot['fixed'], c2w.detach(), c2w)
         idx = slam_ops.sample_distinct_dev(slot['n_bank'],
                                            cfg.mapping_sample, dev)
-        bank = self._bank[idx]
-        fid = torch.div(idx, self.num_rays_to_save, rounding_mode='floor')
         n = self.camera.height * self.camera.width
         pix = self._distinct(n, slot['bucket'], dev)
-        cur = torch.cat([self._ray_dirs()[pix], slot['rgb'][pix],
-                         slot['depth'][pix]], -1)
-        rows = torch.cat([bank, cur], 0)
-        ids = torch.cat([fid, slot['cur_id'].expand(slot['bucket'])], 0)
+        # bank rows + the current frame's pixels + their pose ids: one launch
+        rows, ids = slam_ops.coslam_map_rows(
+            self._bank, idx, self.num_rays_to_save, pix, self._ray_dirs(),
+            slot['rgb'], slot['depth'], slot['cur_id'])
         rays_o, rays_d = slam_ops.PoseRaysFn.apply(c2w, rows, ids)
         return {'rays_o': rays_o, 'rays_d': rays_d, 'target_s': rows[:, 3:6],
                 'target_d': rows[:, 6:7], 'first': False, 'sharded': False,
