@@ -99,7 +99,7 @@ def calibrated(cpu, algo):
     return cpu
 
 
-def pmc_traffic(kernels, which='r03_pmc.json'):
+def pmc_traffic(kernels, which='r04_pmc.json'):
     """bytes per launch of a launch group from the committed PMC pass
     (profiles/r02_pmc*.json, made by tools/run_pmc.sh on this same workload):
     sum over the group's kernels of 2 x FETCH_SIZE (gfx950 correction) +
@@ -389,7 +389,7 @@ def run_coslam(args, dev, with_cpu, world=1):
             (['coslam_reduce_kernel', 'hash_chunk_scatter_kernel']
              if map_grads else [])) if kernel == 'coslam_bwd'
         else pmc_traffic(['coslam_fwd_kernel']),
-        'traffic_source': 'profiles/r03_pmc.json (see NICE line)',
+        'traffic_source': 'profiles/r04_pmc.json (see NICE line)',
         'intensity_flop_per_byte': aflops / abytes,
         'kernel': f'{kernel}[rays={n_rays},ray_grad={int(ray_grads)},'
                   f'map_grad={int(map_grads)}] (launch group: zero-fill, '
@@ -668,8 +668,8 @@ def run_voxfusion(args, dev, world=1):
                 {'vox_dw': ['vox_dw_kernel', 'vox_dw_reduce_kernel'],
                  'vox_points_fwd': ['vox_points_fwd_kernel'],
                  'vox_points_bwd': ['vox_points_bwd_kernel']}[kern],
-                'r03_pmc_vox.json'),
-            'traffic_source': 'profiles/r03_pmc_vox.json (rocprofv3 --pmc '
+                'r04_pmc_vox.json'),
+            'traffic_source': 'profiles/r04_pmc_vox.json (rocprofv3 --pmc '
                               'FETCH_SIZE / WRITE_SIZE passes of this '
                               'workload, FETCH x2 on gfx950)',
             'kernel': f'{kern}[decoder_grad={int(need_w)}]' + (
@@ -794,8 +794,8 @@ def run_splatam(args, dev, world=1):
         'frac': bwd_flops / (us['gs_render_bwd'] * 1e-6) / MFMA_F32_PEAK,
         'traffic': pmc_traffic(['gs_blend_bwd_kernel',
                                 'gs_key_reduce_kernel'],
-                               'r03_pmc_splatam.json'),
-        'traffic_source': 'profiles/r03_pmc_splatam.json (rocprofv3 --pmc '
+                               'r04_pmc_splatam.json'),
+        'traffic_source': 'profiles/r04_pmc_splatam.json (rocprofv3 --pmc '
                           'FETCH_SIZE / WRITE_SIZE passes of this workload, '
                           'FETCH x2 on gfx950)',
         'kernel': 'xrd_gs_blend_bwd<dual> = gs_blend_bwd_kernel + '
@@ -953,8 +953,8 @@ def run_pointslam(args, dev, world=1):
             'frac': flop / (us * 1e-6) / MFMA_F32_PEAK,
             'traffic': pmc_traffic(['point_color_bwd_kernel', 'pc_dw_kernel',
                                     'pc_dw_reduce_kernel'],
-                                   'r03_pmc_pointslam.json'),
-            'traffic_source': 'profiles/r03_pmc_pointslam.json (rocprofv3 '
+                                   'r04_pmc_pointslam.json'),
+            'traffic_source': 'profiles/r04_pmc_pointslam.json (rocprofv3 '
                               '--pmc FETCH_SIZE / WRITE_SIZE passes of this '
                               'workload, FETCH x2 on gfx950; mean over the '
                               "passes' launches)",
@@ -1341,7 +1341,7 @@ def main():
                                                        need_pose, need_dec))
                         if nice_group_kernels(kernel, stage, need_pose,
                                               need_dec) else None),
-            'traffic_source': 'profiles/r03_pmc.json (rocprofv3 --pmc '
+            'traffic_source': 'profiles/r04_pmc.json (rocprofv3 --pmc '
                               'FETCH_SIZE, WRITE_SIZE passes of this workload;'
                               ' bytes per launch group, FETCH x2 on gfx950)',
             'intensity_flop_per_byte': aflops / abytes,
