@@ -205,3 +205,84 @@ def office0_pairs(got, gold, tag):
             continue  # fused loss path reports one data term (see run_case)
         pairs.append((f'coslam_office0/{key}', v, gold[key]))
     return pairs
+
+
+# ---------------------------------------------------------------------------
+# non-default model options (tests/golden/coslam_variants.npz, made by
+# ``oracle/make_golden_coslam.py variants`` from the reference's own model)
+# ---------------------------------------------------------------------------
+VARIANT_GOLDEN = os.path.join(os.path.dirname(__file__), 'golden',
+                              'coslam_variants.npz')
+VARIANTS = {
+    'twogrid': dict(oneGrid=False),
+    'importance': dict(training_n_importance=8),
+    'twogrid_importance': dict(oneGrid=False, training_n_importance=8),
+    'importance_det': dict(training_n_importance=8, training_perturb=0),
+}
+VARIANT_TAGS = (('track', False), ('map', True))
+
+
+def variant_state(model, grids):
+    """seeded tables and decoder weights, identical on the generator and the
+    test side"""
+    for i, (_, grid) in enumerate(sorted(grids.items())):
+        with torch.no_grad():
+            grid.params.copy_(torch.from_numpy(
+                office0_table(grid.params.numel(), seed=31 + i)))
+    model.decoder.load_state_dict(office0_decoder_state(model, seed=33))
+
+
+def build_variant(g, name, device):
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.models.joint_encoding import (JointEncoding,
+                                                        JointEncodingConfig)
+    cfg = JointEncodingConfig(cam_depth_trunc=100.0, tcnn_encoding=True,
+                              hashsize=10, trainging_smooth_pts=8,
+                              **VARIANTS[name])
+    model = JointEncoding(cfg, Camera(40., 40., 31.5, 23.5, 64, 48),
+                          torch.from_numpy(g['bound']))
+    grids = {'embed_fn': model.embed_fn}
+    if not cfg.oneGrid:
+        grids['embed_fn_color'] = model.embed_fn_color
+    variant_state(model, grids)
+    return model.to(device), grids
+
+
+def run_variant(model, grids, g, name, tag, is_mapping, device):
+    """(label, got, gold) triples for tests/parity.py"""
+    pre = f'{name}/{tag}'
+    draws = iter([torch.from_numpy(g[f'{pre}/rand{i}'])
+                  for i in range(int(g[f'{pre}/n_rand']))])
+
+    def fed(shape, like):
+        t = next(draws)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.to(like)
+
+    model._rand = fed
+    for p in model.parameters():
+        p.grad = None
+    ro = torch.from_numpy(g['rays_o']).to(device).requires_grad_(True)
+    rd = torch.from_numpy(g['rays_d']).to(device).requires_grad_(True)
+    inp = {'rays_o': ro, 'rays_d': rd, 'first': False,
+           'target_s': torch.from_numpy(g['target_s']).to(device),
+           'target_d': torch.from_numpy(g['target_d']).to(device)}
+    res = model.get_outputs(inp)
+    ld = model.get_loss_dict(res, inp, is_mapping, 0)
+    sum(ld.values()).backward()
+    assert next(draws, None) is None, 'unused recorded draws'
+    lab = f'coslam_variants/{pre}'
+    pairs = [(f'{lab}/{k}', res[k].detach().cpu().numpy(), g[f'{pre}/{k}'])
+             for k in ('rgb', 'depth', 'depth_var', 'acc_map', 'z_vals',
+                       'raw')]
+    gold_losses = [k for k in g.files if k.startswith(f'{pre}/loss_')]
+    assert len(gold_losses) == len(ld)
+    pairs += [(f'{lab}/loss_{k}', v.detach().cpu().numpy(),
+               g[f'{pre}/loss_{k}']) for k, v in ld.items()]
+    pairs += [(f'{lab}/g_rays_o', ro.grad.cpu().numpy(), g[f'{pre}/g_rays_o']),
+              (f'{lab}/g_rays_d', rd.grad.cpu().numpy(), g[f'{pre}/g_rays_d'])]
+    pairs += [(f'{lab}/g_{n_}', grid.params.grad.cpu().numpy(),
+               g[f'{pre}/g_{n_}']) for n_, grid in grids.items()]
+    pairs += [(f'{lab}/g_dec/{k}', p.grad.cpu().numpy(), g[f'{pre}/g_dec/{k}'])
+              for k, p in model.decoder.named_parameters()]
+    return pairs

@@ -57,6 +57,21 @@ def test_baseline_config_vs_reference(tag, is_mapping, first, n, mode):
     parity.assert_all([(f'{mode}:{n_}', a, b) for n_, a, b in pairs])
 
 
+@pytest.mark.parametrize('tag,is_mapping', cg.VARIANT_TAGS)
+@pytest.mark.parametrize('name', list(cg.VARIANTS))
+def test_non_default_model_options_vs_reference(name, tag, is_mapping):
+    """the configurations the fused renderer declines (a separate colour
+    grid; the importance-sampling pass) run on the modular HIP encodings:
+    both hash grids through xrd_hashgrid_*, OneBlob through xrd_oneblob_*;
+    against tests/golden/coslam_variants.npz, element-wise 1e-4"""
+    import parity
+    g = np.load(cg.VARIANT_GOLDEN)
+    model, grids = cg.build_variant(g, name, 'cuda:0')
+    assert model._fused_tables('cuda:0') is None
+    parity.assert_all(cg.run_variant(model, grids, g, name, tag, is_mapping,
+                                     'cuda:0'))
+
+
 @pytest.mark.parametrize('tag,is_mapping,first', cg.TAGS)
 def test_fused_loss_vs_reference(tag, is_mapping, first):
     """xrd_coslam_loss (loss terms + their gradients through the fused

@@ -47,6 +47,20 @@ def test_joint_encoding_at_baseline_config(oracle_encodings, tag, is_mapping,
     parity.assert_all(cg.office0_pairs(got, gold, tag))
 
 
+@pytest.mark.parametrize('tag,is_mapping', cg.VARIANT_TAGS)
+@pytest.mark.parametrize('name', list(cg.VARIANTS))
+def test_non_default_model_options_vs_reference(oracle_encodings, name, tag,
+                                                is_mapping):
+    """oneGrid=False (second, colour-only grid + ColorSDFNet) and
+    training_n_importance>0 (inverse-CDF second pass; perturbed and
+    deterministic) against the reference's own model, element-wise"""
+    import parity
+    g = np.load(cg.VARIANT_GOLDEN)
+    model, grids = cg.build_variant(g, name, 'cpu')
+    parity.assert_all(cg.run_variant(model, grids, g, name, tag, is_mapping,
+                                     'cpu'))
+
+
 def test_fixed_shape_depth_loss_equals_compacted(oracle_encodings):
     g = np.load(cg.GOLDEN)
     model = cg.build_model(g, 'cpu')

@@ -11,7 +11,7 @@ acc = collections.defaultdict(list)
 
 
 def short_name(name):
-    m = re.search(r'nice_map_fused_kernel<(\d+), (\d+), (\w+), (\w+)>', name)
+    m = re.search(r'nice_map_fused_kernel<(\d+), (\d+), (\w+), (\w+)(?:, \w+)?>', name)
     if m:
         return (f'nice_map_fused<stage={m.group(1)},NT={m.group(2)},'
                 f'dp={m.group(3)},dw={m.group(4)}>')
@@ -47,7 +47,8 @@ def short_name(name):
               'gs_key_reduce_kernel', 'gs_pack_kernel',
               'gs_prepare_fwd_kernel', 'gs_prepare_bwd_kernel',
               'gs_loss_stats_kernel', 'gs_loss_grad_kernel',
-              'frustum_select_kernel',
+              'frustum_select_kernel', 'tv_points_kernel', 'tv_loss_kernel',
+              'coslam_extra_stage_kernel', 'coslam_map_rows_kernel',
               'frustum_depth_kernel'):
         if k in name:
             return k

@@ -170,6 +170,13 @@ class JointEncoding(Model):
         else:
             depth_loss = compute_loss(outputs['depth'].squeeze()[valid],
                                       td[valid])
+        if 'rgb0' in outputs:
+            # importance sampling: the first pass's maps are supervised too
+            # (reference joint_encoding.py:115-119)
+            rgb_loss = rgb_loss + compute_loss(outputs['rgb0'] * rgb_w,
+                                               target_rgb * rgb_w)
+            depth_loss = depth_loss + compute_loss(outputs['depth0'][valid],
+                                                   td[valid])
         truncation = cfg.training_trunc * cfg.data_sc_factor
         fs_loss, sdf_loss = get_sdf_loss(outputs['z_vals'], target_d,
                                          outputs['raw'][..., -1], truncation,
@@ -299,10 +306,52 @@ class JointEncoding(Model):
         rgb, disp, acc, weights, depth, depth_var = self.raw2outputs(
             raw, z_vals, cfg.training_white_bkgd)
         if cfg.training_n_importance > 0:
-            raise NotImplementedError('importance sampling is off in the '
-                                      'reference defaults and not built')
-        return {'rgb': rgb, 'depth': depth, 'disp_map': disp, 'acc_map': acc,
-                'depth_var': depth_var, 'z_vals': z_vals, 'raw': raw}
+            # second pass (reference joint_encoding.py:303-325): inverse-CDF
+            # draws from the first pass's interior weights, merged and sorted
+            # with the first samples; the first pass's maps stay in the
+            # outputs (suffix 0) and are supervised by get_loss_dict
+            first_pass = {'rgb0': rgb, 'disp0': disp, 'acc0': acc,
+                          'depth0': depth, 'depth_var0': depth_var}
+            z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            z_new = self._importance_samples(
+                z_mid, weights[..., 1:-1], cfg.training_n_importance,
+                cfg.training_perturb == 0.).detach()
+            z_vals, _ = torch.sort(torch.cat([z_vals, z_new], -1), -1)
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * \
+                z_vals[..., :, None]
+            raw = self.run_network(pts)
+            rgb, disp, acc, weights, depth, depth_var = self.raw2outputs(
+                raw, z_vals, cfg.training_white_bkgd)
+        ret = {'rgb': rgb, 'depth': depth, 'disp_map': disp, 'acc_map': acc,
+               'depth_var': depth_var, 'z_vals': z_vals, 'raw': raw}
+        if cfg.training_n_importance > 0:
+            ret.update(first_pass)
+            ret['z_std'] = torch.std(z_new, dim=-1, unbiased=False)
+        return ret
+
+    def _importance_samples(self, bins, weights, n_new, deterministic):
+        """n_new depths per ray from the piecewise-linear inverse of the CDF
+        of ``weights`` (one weight per interval of ``bins``); reference
+        model_components/utils.py:31 (sample_pdf)"""
+        pdf = weights + 1e-5
+        pdf = pdf / pdf.sum(-1, keepdim=True)
+        cdf = torch.nn.functional.pad(torch.cumsum(pdf, -1), (1, 0))
+        lead = list(cdf.shape[:-1])
+        if deterministic:
+            half = 0.5 / n_new
+            u = torch.linspace(half, 1. - half, steps=n_new,
+                               device=cdf.device).expand(lead + [n_new])
+        else:
+            u = self._rand(tuple(lead + [n_new]), cdf)
+        u = u.contiguous()
+        hi = torch.searchsorted(cdf, u, right=True)
+        lo = (hi - 1).clamp_min(0)
+        hi = hi.clamp_max(cdf.shape[-1] - 1)
+        c_lo, c_hi = cdf.gather(-1, lo), cdf.gather(-1, hi)
+        b_lo, b_hi = bins.gather(-1, lo), bins.gather(-1, hi)
+        width = c_hi - c_lo
+        width = torch.where(width < 1e-5, torch.ones_like(width), width)
+        return b_lo + (u - c_lo) / width * (b_hi - b_lo)
 
     def sdf2weights(self, sdf, z_vals):
         """bell-shaped weights sigma(s/tr) sigma(-s/tr), cut tr behind the
