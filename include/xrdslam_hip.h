@@ -1057,6 +1057,18 @@ int xrd_pose_aa_fwd(int n, const float* r3, const float* t3, float* c2w16,
                     xrd_stream_t stream);
 int xrd_pose_aa_bwd(int n, const float* r3, const float* g_c2w16, float* g_r3,
                     float* g_t3, xrd_stream_t stream);
+/* Pose hand-over between frames on the device (no host round trip between the
+ * last tracking iteration of a frame and the first of the next).
+ * xrd_pose_from_matrix: OptimizablePose.from_matrix (slam/utils/opt_pose.py:
+ * 97-110; frame.py:24-36): c2w16 -> vec = [t(3), rot], rot = unit quaternion
+ * (r,i,j,k), r >= 0 (XRD_ROT_QUAT, 7 floats) or axis-angle (XRD_ROT_AXIS_ANGLE,
+ * 6 floats).  xrd_pose_predict: the tracker's constant-velocity start
+ * (slam/pipeline/tracker.py:185-199): next = (prev @ inv(prev2)) @ prev. */
+enum { XRD_ROT_AXIS_ANGLE = 0, XRD_ROT_QUAT = 1 };
+int xrd_pose_from_matrix(int rot_rep, const float* c2w16, float* vec,
+                         xrd_stream_t stream);
+int xrd_pose_predict(const float* prev16, const float* prev2_16,
+                     float* next16, xrd_stream_t stream);
 /* torch.optim.Adam step on a small dense tensor, step count on the device */
 int xrd_adam_dense(float* param, const float* grad, float* m, float* v,
                    int64_t n, float lr, float beta1, float beta2, float eps,

@@ -96,6 +96,9 @@ def test_argument_checks_of_the_iteration_kernels():
                              None) == 3               # one-block loss: <= 8192
     assert lib.xrd_pose_quat_fwd(None, p, p, None) == 1
     assert lib.xrd_pose_quat_bwd(p, None, p, p, None) == 1
+    assert lib.xrd_pose_from_matrix(1, None, p, None) == 1
+    assert lib.xrd_pose_from_matrix(2, p, p, None) == 1   # unknown rot_rep
+    assert lib.xrd_pose_predict(p, None, p, None) == 1
 
 
 def test_backward_workspace_contract():

@@ -208,6 +208,8 @@ _SIGS = {
     'xrd_pose_quat_bwd': (C.c_int, [vp] * 5),
     'xrd_pose_aa_fwd': (C.c_int, [C.c_int, vp, vp, vp, vp]),
     'xrd_pose_aa_bwd': (C.c_int, [C.c_int, vp, vp, vp, vp, vp]),
+    'xrd_pose_from_matrix': (C.c_int, [C.c_int, vp, vp, vp]),
+    'xrd_pose_predict': (C.c_int, [vp, vp, vp, vp]),
     'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
                                  vp, vp]),
     'xrd_adam_dense_tick': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32,

@@ -681,6 +681,127 @@ __global__ __launch_bounds__(256) void pose_rays_bwd_kernel(
   }
 }
 
+// ---- pose hand-over between frames without a host round trip ---------------
+// A tracking call ends with "the best pose of the frame" on the device; the
+// reference turns it into the frame's pose parameters and the next frame's
+// constant-velocity start on the host (slam/common/frame.py:24-36,
+// slam/utils/opt_pose.py:97-110, slam/pipeline/tracker.py:185-199).  With the
+// tracking iterations inside one hipGraph that host hop (device -> numpy ->
+// pytorch3d-style conversions -> upload) is the GPU's idle time between two
+// frames; these two single-thread kernels keep the chain on the device.
+//
+// pose_from_matrix: OptimizablePose.from_matrix — rotation matrix -> unit
+// quaternion (r,i,j,k) through the best conditioned of the four candidates
+// (largest of 1 +- m00 +- m11 +- m22), sign r >= 0, optionally -> axis-angle
+// (theta = 2 atan2(|v|, r)); out = [t(3), rot(3 or 4)], float32 arithmetic in
+// the order of the host formulas.
+__global__ void pose_from_matrix_kernel(const float* __restrict__ c2w,
+                                        int quat_rep,
+                                        float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float m[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m[i][j] = c2w[i * 4 + j];
+  const float t[4] = {1.f + m[0][0] + m[1][1] + m[2][2],
+                      1.f + m[0][0] - m[1][1] - m[2][2],
+                      1.f - m[0][0] + m[1][1] - m[2][2],
+                      1.f - m[0][0] - m[1][1] + m[2][2]};
+  int best = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (t[k] > t[best]) best = k;
+  const float d = 2.0f * sqrtf(fmaxf(t[best], 1e-12f));
+  float q[4];
+  if (best == 0) {
+    q[0] = d / 4;
+    q[1] = (m[2][1] - m[1][2]) / d;
+    q[2] = (m[0][2] - m[2][0]) / d;
+    q[3] = (m[1][0] - m[0][1]) / d;
+  } else if (best == 1) {
+    q[0] = (m[2][1] - m[1][2]) / d;
+    q[1] = d / 4;
+    q[2] = (m[0][1] + m[1][0]) / d;
+    q[3] = (m[0][2] + m[2][0]) / d;
+  } else if (best == 2) {
+    q[0] = (m[0][2] - m[2][0]) / d;
+    q[1] = (m[0][1] + m[1][0]) / d;
+    q[2] = d / 4;
+    q[3] = (m[1][2] + m[2][1]) / d;
+  } else {
+    q[0] = (m[1][0] - m[0][1]) / d;
+    q[1] = (m[0][2] + m[2][0]) / d;
+    q[2] = (m[1][2] + m[2][1]) / d;
+    q[3] = d / 4;
+  }
+  if (q[0] < 0.f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = -q[k];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) out[a] = c2w[a * 4 + 3];
+  if (quat_rep) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[3 + k] = q[k];
+  } else {
+    const float n = sqrtf(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float theta = 2.0f * atan2f(n, q[0]);
+    const float scale = n < 1e-8f ? 2.0f : theta / n;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[3 + k] = q[1 + k] * scale;
+  }
+}
+
+// pose_predict: constant-velocity start of the next frame,
+// (prev @ inv(prev2)) @ prev.  The inverse is a general 4x4 one (Gauss-Jordan
+// with partial pivoting, in double, rounded to float like numpy's float32
+// LAPACK result to ~1 ulp); the two products are float32.
+__global__ void pose_predict_kernel(const float* __restrict__ prev,
+                                    const float* __restrict__ prev2,
+                                    float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      a[i][j] = (double)prev2[i * 4 + j];
+      a[i][4 + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r)
+      if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 8; ++j) {
+        const double tmp = a[c][j];
+        a[c][j] = a[piv][j];
+        a[piv][j] = tmp;
+      }
+    const double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  float inv2[4][4], delta[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) inv2[i][j] = (float)a[i][4 + j];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) acc += prev[i * 4 + k] * inv2[k][j];
+      delta[i][j] = acc;
+    }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) acc += delta[i][k] * prev[k * 4 + j];
+      out[i * 4 + j] = acc;
+    }
+}
+
 }  // namespace
 }  // namespace xrd
 
@@ -807,6 +928,24 @@ int xrd_nice_loss(int n, int is_mapping, int use_color, int handle_dynamic,
                      handle_dynamic, w_color, depth, var, rgb, tgt_d, tgt_rgb,
                      keep, loss, g_depth, g_rgb);
   return check_launch("xrd_nice_loss");
+}
+
+int xrd_pose_from_matrix(int rot_rep, const float* c2w16, float* vec,
+                         xrd_stream_t stream) {
+  if (!c2w16 || !vec) return XRD_ERR_ARG;
+  if (rot_rep != XRD_ROT_AXIS_ANGLE && rot_rep != XRD_ROT_QUAT)
+    return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_from_matrix_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, c2w16, rot_rep == XRD_ROT_QUAT, vec);
+  return check_launch("xrd_pose_from_matrix");
+}
+
+int xrd_pose_predict(const float* prev16, const float* prev2_16,
+                     float* next16, xrd_stream_t stream) {
+  if (!prev16 || !prev2_16 || !next16) return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_predict_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, prev16, prev2_16, next16);
+  return check_launch("xrd_pose_predict");
 }
 
 int xrd_pose_quat_fwd(const float* t3, const float* q4, float* c2w16,

@@ -431,6 +431,33 @@ class FusedDenseAdam(torch.optim.Optimizer):
                 p._xrd_steps = getattr(p, '_xrd_steps', 0) + 1
 
 
+@torch.no_grad()
+def pose_from_matrix(c2w: torch.Tensor, rot_rep: str) -> torch.Tensor:
+    """OptimizablePose.from_matrix on the device: c2w[4,4] f32 -> [t, rot]
+    (7 floats for 'quat', 6 for 'axis_angle'), one launch, no host sync"""
+    quat = rot_rep == 'quat'
+    c2w = c2w.detach().float().contiguous()
+    vec = torch.empty(7 if quat else 6, dtype=torch.float32,
+                      device=c2w.device)
+    _lib.check(_lib.lib().xrd_pose_from_matrix(
+        1 if quat else 0, _lib.ptr(c2w), _lib.ptr(vec),
+        _lib.stream_ptr(c2w.device)), 'xrd_pose_from_matrix')
+    return vec
+
+
+@torch.no_grad()
+def pose_predict(prev: torch.Tensor, prev2: torch.Tensor) -> torch.Tensor:
+    """constant-velocity start of the next frame on the device:
+    (prev @ inv(prev2)) @ prev (tracker.py:185-199)"""
+    prev = prev.detach().float().contiguous()
+    prev2 = prev2.detach().float().contiguous()
+    out = torch.empty(4, 4, dtype=torch.float32, device=prev.device)
+    _lib.check(_lib.lib().xrd_pose_predict(
+        _lib.ptr(prev), _lib.ptr(prev2), _lib.ptr(out),
+        _lib.stream_ptr(prev.device)), 'xrd_pose_predict')
+    return out
+
+
 def track_best(loss, c2w, track):
     """track: dict(loss f64 [], c2w [4,4] f32, valid uint8 [])"""
     _lib.check(_lib.lib().xrd_track_best(

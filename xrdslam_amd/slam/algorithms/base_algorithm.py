@@ -261,6 +261,10 @@ class Algorithm:
     # ---- the optimiser loop ------------------------------------------------
     use_graphs = False  # capture each stage segment into a hipGraph (MI355X)
     persistent_track_graph = True  # one tracking graph reused across frames
+    # the persistent tracking graph hands its best pose back as a device
+    # tensor instead of numpy (set by a driver that keeps the pose chain on
+    # the device, slam/pipeline.py: SequentialSLAM(device_poses=True))
+    device_track_result = False
     # mapping graphs kept from one mapping call to the next (algorithms whose
     # mapping work has call-independent shapes opt in, see _map_slot_run)
     persistent_map_graph = False
@@ -427,6 +431,10 @@ class Algorithm:
             else:
                 slot['graph'].replay()
         self.fixed_shape_batches = False
+        if self.device_track_result:
+            # no host sync: the caller keeps the pose on the device (a frame
+            # whose loss never improved keeps its start, like `return None`)
+            return torch.where(track['valid'], track['c2w'], init)
         if not bool(track['valid'].item()):
             return None
         return track['c2w'].cpu().numpy()

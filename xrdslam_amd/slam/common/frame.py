@@ -34,6 +34,18 @@ class Frame(nn.Module):
         pose, checked: frame.py:24-29) on the host, then moved to the pose
         device with one upload per parameter — on the device the conversion
         costs two host syncs and ~15 tiny launches per frame."""
+        if torch.is_tensor(pose_np) and pose_np.is_cuda and \
+                torch.device(self.pose_device).type == 'cuda':
+            # a pose that is already on the device (the tracking graph's best
+            # pose, the device-side constant-velocity start) stays there: one
+            # conversion launch instead of a host round trip that would drain
+            # the queue between two frames
+            from ...engine import slam_ops
+            vec = slam_ops.pose_from_matrix(pose_np.to(self.pose_device),
+                                            rot_rep)
+            self.pose = OptimizablePose(vec, separate_LR=separate_LR,
+                                        rot_rep=rot_rep)
+            return
         Rt = torch.as_tensor(pose_np, dtype=torch.float32).cpu()
         pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,
                                            rot_rep=rot_rep)

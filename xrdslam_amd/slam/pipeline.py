@@ -34,11 +34,34 @@ def predict_current_pose(frame_id, gt_c2w_np, estimate_c2w_list):
     return (prev @ np.linalg.inv(prev2)) @ prev
 
 
+def predict_current_pose_device(frame_id, estimate_c2w_list):
+    """the same on the device (frame_id >= 1, estimates on the GPU): one
+    launch, no host copy of the previous poses"""
+    from ..engine import slam_ops
+    prev = estimate_c2w_list[frame_id - 1].detach()
+    if frame_id == 1:
+        return prev.clone()
+    return slam_ops.pose_predict(prev,
+                                 estimate_c2w_list[frame_id - 2].detach())
+
+
 class SequentialSLAM:
     def __init__(self, algorithm, dataset, map_every=5, keyframe_every=50,
                  lazy_start=-1, pose_device='cpu', use_relative_pose=False,
-                 init_pose_offset=0):
+                 init_pose_offset=0, device_poses=None):
         self.algorithm, self.dataset = algorithm, dataset
+        # MI355X: keep the pose chain of consecutive frames on the device —
+        # best pose of the tracking graph -> pose parameters -> constant-
+        # velocity start of the next frame — so that the host never waits for
+        # a frame's result and the queue does not drain between frames
+        # (tracking-only frames were ~35 % GPU idle: 1.7 ms of graph replays,
+        # then ~1 ms of host pose bookkeeping behind a device->host read).
+        # Needs the poses on the GPU and the persistent tracking graph;
+        # None = on exactly then.  Multi-GPU runs keep the host hop (rank 0's
+        # result is broadcast through the host).
+        if device_poses is None:
+            device_poses = torch.device(pose_device).type == 'cuda'
+        self.device_poses = bool(device_poses)
         self.map_every, self.keyframe_every = map_every, keyframe_every
         self.lazy_start = lazy_start
         self.pose_device = pose_device
@@ -71,7 +94,14 @@ class SequentialSLAM:
                 gt_c2w = self._first_new @ (np.linalg.inv(self._first_old) @
                                             gt_c2w)
         gt_c2w = gt_c2w.astype(np.float32)
-        init = predict_current_pose(idx, gt_c2w, alg.get_estimate_c2w_list())
+        est = alg.get_estimate_c2w_list()
+        on_device = self._device_chain()
+        alg.device_track_result = on_device
+        if on_device and idx >= 1 and est[idx - 1].is_cuda and \
+                (idx < 2 or est[idx - 2].is_cuda):
+            init = predict_current_pose_device(idx, est)
+        else:
+            init = predict_current_pose(idx, gt_c2w, est)
         frame = Frame(fid=idx, rgb=data['rgb'], depth=data['depth'],
                       gt_pose=gt_c2w, init_pose=init,
                       separate_LR=alg.is_separate_LR(),
@@ -102,6 +132,15 @@ class SequentialSLAM:
         self.t_track += t1 - t0
         self.t_map += t2 - t1
         return frame
+
+    def _device_chain(self):
+        from ..engine import dist as _dist
+        alg = self.algorithm
+        return self.device_poses and not _dist.state.enabled and \
+            bool(getattr(alg, 'use_graphs', False)) and \
+            bool(getattr(alg, 'persistent_track_graph', False)) and \
+            torch.device(alg.device).type == 'cuda' and \
+            torch.device(self.pose_device).type == 'cuda'
 
     def _sync_pose(self, cand):
         """multi-GPU: tracking is replicated; rank 0's result is broadcast so
