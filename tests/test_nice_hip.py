@@ -629,3 +629,48 @@ def test_point_queries_match_oracle_and_mesher_runs():
     if mesh is not None:    # random-init decoders may have no zero crossing
         assert mesh.faces.max() < mesh.vertices.shape[0]
         assert mesh.vertex_colors.shape[0] == mesh.vertices.shape[0]
+
+
+@pytest.mark.parametrize('n', [1, 7, 200, 1024, 1025, 3000])
+@pytest.mark.parametrize('masked', [False, True])
+def test_tracking_loss_median_both_selection_paths(n, masked):
+    """xrd_nice_loss, tracking branch with the dynamic-object mask
+    (conv_onet.py:152-166: residual < 10 x torch.median of the kept rays):
+    the order statistic comes from rank counting up to 1024 rays and from the
+    bitonic network above; against the torch formulation in f64, with ties"""
+    from xrdslam_amd.engine import slam_ops
+    dev = _cuda()
+    g = torch.Generator().manual_seed(n)
+    depth = (1.0 + torch.rand(n, generator=g, dtype=torch.float64)).to(dev)
+    var = (0.01 + torch.rand(n, generator=g, dtype=torch.float64)).to(dev)
+    td = (1.0 + torch.rand(n, generator=g)).to(dev)
+    td[torch.rand(n, generator=g) < 0.1] = 0.0
+    if n > 8:
+        # exact ties around the median and a few dynamic outliers
+        depth[: n // 4] = 1.5
+        var[: n // 4] = 0.04
+        td[: n // 4] = 1.75
+        td[-max(n // 20, 1):] += 50.0
+    rgb = torch.rand(n, 3, generator=g).to(dev).requires_grad_(True)
+    tc = torch.rand(n, 3, generator=g).to(dev)
+    keep = None
+    if masked:
+        keep = (torch.rand(n, generator=g) > 0.2).to(dev)
+        if not bool(keep.any()):
+            keep[0] = True
+    d = depth.clone().requires_grad_(True)
+    loss = slam_ops.NiceLossFn.apply(
+        d, var, rgb, td, tc, None if keep is None else keep.to(torch.uint8),
+        False, True, True, 0.5)
+    loss.backward()
+    d2 = depth.clone().requires_grad_(True)
+    rgb2 = rgb.detach().clone().requires_grad_(True)
+    kp = torch.ones(n, dtype=torch.bool, device=dev) if keep is None else keep
+    res = (td.double() - d2).abs() / torch.sqrt(var + 1e-10)
+    med = res[kp].median() if bool(kp.any()) else res.new_tensor(1e300)
+    m = kp & (td > 0) & (res < 10 * med)
+    want = res[m].sum() + 0.5 * (tc[m] - rgb2[m]).abs().sum().double()
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-6 * max(abs(float(want)), 1)
+    assert torch.allclose(d.grad, d2.grad, rtol=1e-12, atol=0)
+    assert torch.equal(rgb.grad, rgb2.grad)
