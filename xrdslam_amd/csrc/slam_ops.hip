@@ -140,26 +140,42 @@ __global__ __launch_bounds__(1024) void nice_loss_kernel(
       }
       sorted[i] = v;
     }
-    atomicAdd(&s_cnt, local);
+    // one LDS atomic per wave: 1024 same-address atomics serialise (measured:
+    // 7 of this launch's 14 us at n = 200)
+    const int wave_local = (int)wave_sum((float)local);
+    if ((tid & 63) == 0 && wave_local) atomicAdd(&s_cnt, wave_local);
     __syncthreads();
     const int cnt = s_cnt;
-    if (np2 <= T) {
+    if (np2 <= 256) {
       // a tracking batch (200 rays): the order statistic by rank counting —
       // thread i counts the residuals that sort before its own (ties by
-      // index), every read an LDS broadcast; 2 barriers instead of the 36+
-      // of the bitonic network below (11 of this launch's 14 us at n = 200)
+      // index), every read an LDS broadcast; 3 barriers instead of the 36
+      // of the bitonic network below.  Larger batches sort (measured: rank
+      // counting is slower than the network from ~1000 rays on)
       __shared__ double s_med;
+      __shared__ int s_rank[256];
+      // np2 <= T are both powers of two: T / np2 threads share an element,
+      // each counting over its part of the batch (n = 200: 64 compares a
+      // thread instead of 200 in a quarter of the waves)
+      const int groups = min(T / np2, np2);
+      const int i = tid & (np2 - 1), part = tid / np2, span = np2 / groups;
       if (tid == 0) s_med = 1e300;
+      if (tid < np2) s_rank[tid] = 0;
       __syncthreads();
-      if (tid < n && cnt > 0) {
-        const double v = sorted[tid];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
+      if (i < n && part < groups && cnt > 0) {
+        const double v = sorted[i];
+        const int j0 = part * span, j1 = min(n, j0 + span);
+        int r = 0;
+#pragma unroll 4
+        for (int j = j0; j < j1; ++j) {
           const double u = sorted[j];
-          rank += (u < v || (u == v && j < tid)) ? 1 : 0;
+          r += (u < v || (u == v && j < i)) ? 1 : 0;
         }
-        if (rank == (cnt - 1) / 2) s_med = v;
+        if (r) atomicAdd(&s_rank[i], r);
       }
+      __syncthreads();
+      if (tid < n && cnt > 0 && s_rank[tid] == (cnt - 1) / 2)
+        s_med = sorted[tid];
       __syncthreads();
       thr = cnt > 0 ? 10.0 * s_med : 1e300;
     } else {
