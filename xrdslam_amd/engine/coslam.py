@@ -133,16 +133,46 @@ def make_scene(model, tables, table_params, pack):
     return sc
 
 
+def track_pack(model, dev, refresh=False):
+    """the decoder's packed MFMA fragments for calls that do not train it
+    (tracking): a static buffer, re-packed only when ``refresh`` finds the
+    weights changed (or the owner invalidated ``model._track_pack_key`` after
+    a mapping call whose captured optimiser steps torch's version counters do
+    not see).  Inside the tracking iteration (eager or captured) the buffer is
+    just read: the per-call concatenate / fill / gather launches are gone."""
+    dev = torch.device(dev)
+    buf = model.__dict__.get('_track_pack')
+    ws = [model.decoder.color_net.model[0].weight,
+          model.decoder.color_net.model[2].weight,
+          model.decoder.sdf_net.model[0].weight,
+          model.decoder.sdf_net.model[2].weight]
+    if buf is None or buf.device != dev:
+        buf = model._track_pack = torch.empty(
+            _lib.lib().xrd_coslam_pack_len(), dtype=torch.float32, device=dev)
+        model._track_pack_key = None
+        refresh = True
+    if refresh:
+        key = tuple((w._version, w.data_ptr()) for w in ws)
+        if key != model.__dict__.get('_track_pack_key'):
+            pack_idx, _ = _index(dev)
+            with torch.no_grad():
+                flat = torch.cat([w.detach().reshape(-1).float() for w in ws])
+                buf.copy_(torch.cat([flat, flat.new_zeros(1)])[pack_idx])
+            model._track_pack_key = key
+    return buf
+
+
 class _CoslamRenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, target_d, rnd, table, flat, model,
-                tables):
+                tables, pack=None):
         lib = _lib.lib()
         dev = rays_o.device
-        pack_idx, _ = _index(dev)
-        with torch.no_grad():
-            pack = torch.cat([flat.detach().float(),
-                              flat.new_zeros(1)])[pack_idx].contiguous()
+        if pack is None:
+            pack_idx, _ = _index(dev)
+            with torch.no_grad():
+                pack = torch.cat([flat.detach().float(),
+                                  flat.new_zeros(1)])[pack_idx].contiguous()
         ro = rays_o.detach().float().contiguous()
         rd = rays_d.detach().float().contiguous()
         td = target_d.detach().float().reshape(-1).contiguous()
@@ -210,7 +240,7 @@ class _CoslamRenderFn(torch.autograd.Function):
         g_flat = None
         if need_map:
             g_flat = g_dw[_index(dev)[1]]
-        return g_o, g_d, None, None, g_table, g_flat, None, None
+        return g_o, g_d, None, None, g_table, g_flat, None, None, None
 
 
 class _SmoothFn(torch.autograd.Function):
@@ -288,11 +318,19 @@ def render(model, tables, rays_o, rays_d, target_d, rnd, train_map=True):
     """-> dict like JointEncoding.render_rays (joint_encoding.py:250-344).
     ``train_map=False`` (tracking: only the pose is stepped) skips the hash
     table / decoder gradients, which nobody consumes."""
-    table, flat = model.embed_fn.params, flat_decoder(model.decoder)
-    if not train_map:
-        table, flat = table.detach(), flat.detach()
-    maps, z_vals, raw = _CoslamRenderFn.apply(
-        rays_o, rays_d, target_d, rnd, table, flat, model, tables)
+    if train_map:
+        maps, z_vals, raw = _CoslamRenderFn.apply(
+            rays_o, rays_d, target_d, rnd, model.embed_fn.params,
+            flat_decoder(model.decoder), model, tables)
+    else:
+        # the first call after the weights changed re-packs (a caller that
+        # replays captured tracking iterations refreshes before the replays:
+        # CoSLAM.pre_precessing)
+        pack = track_pack(model, rays_o.device,
+                          refresh=not torch.cuda.is_current_stream_capturing())
+        maps, z_vals, raw = _CoslamRenderFn.apply(
+            rays_o, rays_d, target_d, rnd, model.embed_fn.params.detach(),
+            None, model, tables, pack)
     return {'rgb': maps[:, 0:3], 'depth': maps[:, 3], 'disp_map': maps[:, 6],
             'acc_map': maps[:, 5], 'depth_var': maps[:, 4], 'z_vals': z_vals,
             'raw': raw, '_maps': maps}

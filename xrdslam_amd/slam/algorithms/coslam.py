@@ -77,7 +77,19 @@ class CoSLAM(Algorithm):
 
     # -- hooks that are no-ops for Co-SLAM --------------------------------------
     def pre_precessing(self, cur_frame, is_mapping):
-        pass
+        if not is_mapping and getattr(self.model, 'use_fused', True) and \
+                torch.device(self.model.device).type == 'cuda' and \
+                self.model._fused_tables(self.model.device) is not None:
+            # tracking reads the decoder through a static packed buffer:
+            # bring it up to date BEFORE the (possibly replayed) iterations
+            from ...engine import coslam as ec
+            ec.track_pack(self.model, self.model.device, refresh=True)
+
+    def after_mapping_update(self):
+        # the decoder was stepped (possibly by replayed graphs, which torch's
+        # version counters do not see): tracking re-packs it before its next
+        # iterations
+        self.model._track_pack_key = None
 
     def post_processing(self, step, is_mapping, optimizer=None, coarse=False):
         pass
