@@ -187,13 +187,14 @@ def sample_rays_poses(idx, depth_imgs, rgb_imgs, cam, crop, bound6, layout,
         b6, _lib.ptr(idx), dp, cp, tp, qp, _lib.ptr(c2ws), _lib.ptr(ro),
         _lib.ptr(rd), _lib.ptr(td), _lib.ptr(tc), _lib.ptr(keep),
         _lib.ptr(dmax), _lib.stream_ptr(dev)), 'xrd_sample_rays_multi')
+    # (ctx[8]: the F camera matrices the launch built on the way)
     return (ro, rd, td, tc, keep, dmax), (cam, crop, F, n, layout, tp, qp,
-                                          idx)
+                                          idx, c2ws)
 
 
 def sample_rays_poses_bwd(ctx, g_ro, g_rd):
     """[F,7] gradient of the frames' (t, q) pose parameters"""
-    cam, (H0, W0, wcrop), F, n, layout, tp, qp, idx = ctx
+    cam, (H0, W0, wcrop), F, n, layout, tp, qp, idx = ctx[:8]
     dev = idx.device
     g7 = torch.empty(F, 7, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().xrd_sample_rays_multi_bwd(

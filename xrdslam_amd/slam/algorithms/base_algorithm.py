@@ -327,7 +327,9 @@ class Algorithm:
         if not is_mapping:
             # keep the pose that produced the lowest loss (evaluated before
             # its Adam step, base_algorithm.py:262-265), on the device
-            cur = optimize_frames[-1].get_pose().detach()
+            cur = self.__dict__.pop('_iter_c2w', None)
+            if cur is None:
+                cur = optimize_frames[-1].get_pose().detach()
             if cur.is_cuda and loss.is_cuda and \
                     track['loss'].device == loss.device:
                 from ...engine import slam_ops

@@ -446,6 +446,9 @@ class NiceSLAM(Algorithm):
         for p, g in zip(params, slam_ops.pose_param_grads(g7, layout)):
             p.grad = g
         self._grads_assigned = True     # _iteration: no backward to run
+        # the pose this loss was evaluated at (for the keep-the-best-pose
+        # step): the sampling launch built the matrix already
+        self._iter_c2w = sctx[8][-1]
         return loss
 
     fused_iteration = True  # use the fused launches when the batch shape is fixed
