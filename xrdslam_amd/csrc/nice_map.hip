@@ -903,60 +903,89 @@ nice_map_fused_kernel(
 }
 
 // Coarse stage (grid_coarse is its only parameter, conv_onet.py:187-195; 32
-// uniform samples, no depth guidance): a block = one ray = two tile waves, the
-// decoder read from L2 (it is 6 KB a pass), the gradient scattered into one of
-// kCoarseRep replicas (coarse_rep_reduce).
-__global__ __launch_bounds__(2 * 64, 2) void nice_map_coarse_kernel(
+// uniform samples, no depth guidance).  A block = 4 rays = 8 tile waves with
+// the decoder's fragments (forward + transposed, 50 KB) staged in LDS once per
+// block; the gradient is scattered into one of kCoarseRep replicas
+// (nice_map_coarse_finish_kernel).  Round 3 ran one ray per block with the
+// fragments read from L2: a ray's forward + backward is a chain of ten layer
+// passes, each behind an L2 round trip — 47 us a launch whether 200 or 1000
+// rays were in it.  The coarse mapper runs next to the mapper on a side
+// stream (NiceSLAM._coarse_on_side_stream); measured, it still cost 2.9 ms
+// per mapping call + the 4 tracking frames after it (13 % of the frame time).
+constexpr int kCoarseRPB = 4;                       // rays per block
+constexpr int kCoarseWaves = 2 * kCoarseRPB;        // 2 tiles a ray
+constexpr int kCoarseWaveLds = 256 + kScatterFloats;
+constexpr size_t kCoarseLds =
+    ((size_t)NoXyzPack::LEN + kCoarseWaves * kCoarseWaveLds +
+     kCoarseRPB * 256) * sizeof(float);
+static_assert(NoXyzPack::LEN % 4 == 0, "16-byte staging");
+static_assert(kCoarseLds <= 163840, "LDS per CU");
+
+__global__ __launch_bounds__(kCoarseWaves * 64, 2) void nice_map_coarse_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const uint8_t* __restrict__ keep, float* gg_coarse,
     float* __restrict__ rep, double* __restrict__ ray_loss) {
-  constexpr int NT = 2, S = 32;
-  __shared__ __attribute__((aligned(16))) float
-      smem[NT * (256 + kScatterFloats) + 256];
+  constexpr int S = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // staged fragments
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = wave >> 1, tile = wave & 1;
   const int q = lane >> 4, li = lane & 15;
-  float* R = smem + wave * (256 + kScatterFloats);
-  float* rawbuf = smem + NT * (256 + kScatterFloats);
+  float* R = wl + NoXyzPack::LEN + wave * kCoarseWaveLds;
+  float* rawbuf =
+      wl + NoXyzPack::LEN + kCoarseWaves * kCoarseWaveLds + slot * 256;
   double* zbuf = reinterpret_cast<double*>(R);
   ScatterLds SL;
   SL.gt = R + 256;
   SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
   SL.w = SL.gt + 16 * 33 + 16 * 8;
-  for (int ray = blockIdx.x; ray < n; ray += gridDim.x) {
-    RayCtx rc;
-    load_ray(rays_o, rays_d, nullptr, ray, false, rc);
-    const double zl = sample_z<S>(sc, rc, 0.f, lane, zbuf, zbuf + 64);
-    TileGeom tg;
-    tile_geom(rc, zbuf[64 + 16 * wave + li], sc.bound, tg);
+  for (int i = threadIdx.x * 4; i < NoXyzPack::LEN; i += blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(wl + i) =
+        *reinterpret_cast<const f32x4*>(sc.dec[0] + i);
+  __syncthreads();
+  const int ngroups = (n + kCoarseRPB - 1) / kCoarseRPB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * kCoarseRPB + slot);
+    const bool active = ray < n;
+    double zl = 0.0;
+    TileGeom tg = {};
     f32x4 c_a[1][2], gc[1][2];
-    float o1[1];
-    uint64_t mask[1];
+    float o1[1] = {0.f};
+    uint64_t mask[1] = {0};
     Tri tr;
-    tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
-    tri_gather(sc.grid[0], tr, q, c_a[0]);
-    noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
-    if (q == 0)
-      *reinterpret_cast<f32x4*>(rawbuf + (16 * wave + li) * 4) =
-          f32x4{0.f, 0.f, 0.f, tg.inb ? o1[0] : 100.f};
+    if (active) {
+      RayCtx rc;
+      load_ray(rays_o, rays_d, nullptr, ray, false, rc);
+      zl = sample_z<S>(sc, rc, 0.f, lane, zbuf, zbuf + 64);
+      tile_geom(rc, zbuf[64 + 16 * tile + li], sc.bound, tg);
+      tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+      tri_gather(sc.grid[0], tr, q, c_a[0]);
+      noxyz_fwd<1, true>(wl, lane, c_a, o1, mask);
+      if (q == 0)
+        *reinterpret_cast<f32x4*>(rawbuf + (16 * tile + li) * 4) =
+            f32x4{0.f, 0.f, 0.f, tg.inb ? o1[0] : 100.f};
+    }
     __syncthreads();
-    float gocc_s, w, grgb[3];
-    double loss;
-    const bool kept = keep == nullptr || keep[ray] != 0;
-    map_composite<S>(rawbuf, lane, zl, gt_depth[ray], nullptr, kept, false,
-                     0.f, gocc_s, w, grgb, loss);
-    if (wave == 0 && lane == 0 && ray_loss != nullptr) ray_loss[ray] = loss;
-    float gocc = __shfl(gocc_s, 16 * wave + li);
-    if (!tg.inb) gocc = 0.f;
-    const float go[1] = {gocc};
-    noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
-    tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
-    float* ggc = gg_coarse;
-    if (rep != nullptr && gg_coarse != nullptr)
-      ggc = rep + (size_t)(blockIdx.x & (kCoarseRep - 1)) *
-                      ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
-    grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
-    __syncthreads();  // rawbuf is rewritten by the next ray
+    if (active) {
+      float gocc_s, w, grgb[3];
+      double loss;
+      const bool kept = keep == nullptr || keep[ray] != 0;
+      map_composite<S>(rawbuf, lane, zl, gt_depth[ray], nullptr, kept, false,
+                       0.f, gocc_s, w, grgb, loss);
+      if (tile == 0 && lane == 0 && ray_loss != nullptr) ray_loss[ray] = loss;
+      float gocc = __shfl(gocc_s, 16 * tile + li);
+      if (!tg.inb) gocc = 0.f;
+      const float go[1] = {gocc};
+      noxyz_bwd<1>(wl, lane, go, mask, gc);
+      tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
+      float* ggc = gg_coarse;
+      if (rep != nullptr && gg_coarse != nullptr)
+        ggc = rep + (size_t)(ray & (kCoarseRep - 1)) *
+                        ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
+      grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
+    }
+    __syncthreads();  // rawbuf is rewritten by the next group
   }
 }
 
@@ -1209,8 +1238,20 @@ int xrd_nice_map_iter_export(const xrd_nice_scene* scene, int stage,
     float* rep = ws + 2 * (size_t)n_rays + 4;
     const int64_t ne =
         (int64_t)scene->gdim[0] * scene->gdim[1] * scene->gdim[2] * 32;
-    hipLaunchKernelGGL(nice_map_coarse_kernel, dim3(n_rays), dim3(128), 0, st,
-                       *scene, n_rays, rays_o, rays_d, gt_depth, keep, gg[0],
+    static bool coarse_attr = false;
+    if (!coarse_attr) {
+      if (hipFuncSetAttribute(
+              reinterpret_cast<const void*>(nice_map_coarse_kernel),
+              hipFuncAttributeMaxDynamicSharedMemorySize,
+              (int)kCoarseLds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute");
+      coarse_attr = true;
+    }
+    const int cgroups = (n_rays + kCoarseRPB - 1) / kCoarseRPB;
+    hipLaunchKernelGGL(nice_map_coarse_kernel,
+                       dim3(cgroups < 2 * kMapBlocks ? cgroups : 2 * kMapBlocks),
+                       dim3(kCoarseWaves * 64), kCoarseLds, st, *scene, n_rays,
+                       rays_o, rays_d, gt_depth, keep, gg[0],
                        gg[0] ? rep : nullptr, ray_loss);
     int rc = check_launch("xrd_nice_map_iter/coarse");
     if (rc != XRD_OK) return rc;
