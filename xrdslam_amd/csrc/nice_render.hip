@@ -283,6 +283,165 @@ nice_bwd_fused_kernel(
              A);
 }
 
+// ---- tracking batches: the three decoders of a tile in three blocks ---------
+// A tracking batch (200 rays) is 600 tiles; the fused backward above gives a
+// tile wave a chain of six decoder passes (three recomputed forwards, three
+// backwards), each behind a staging barrier, on 150 of the 256 CUs.  Here
+// grid.y = the decoder (0 middle, 1 fine, 2 colour): a block = 4 rays = 12
+// tile waves stages ONE decoder's fragments and runs ONE forward + ONE
+// backward pass; 200 rays = 150 blocks; the three roles' d loss / d point meet
+// behind the kernel boundary in the finishing launch (9 partial rows a ray).
+// Measured at 200 rays (tools: HIP events over 20 captured calls): 76.1 ->
+// 59.5 us incl. the finishing launch; 3 rays a block 59.0, 2: 71.7, 1: 89.5.
+// Not adopted for the forward: one pass + a compositing launch is 40.8 us
+// against 39.6 us for the three-pass kernel (the passes of a one-ray block
+// have a SIMD to themselves).  Roles inside ONE block would need the three
+// decoders' fragments at once (197 KB forward); with the fragments read from
+// L2 instead the forward measured 66 us, the backward 149 us.
+constexpr int kRoleRPB = 4;
+// one round of blocks on the 256 CUs, and the 9 part rows of a ray must fit
+// the workspace xrd_nice_bwd_ws_floats(n) promises (n*36 + replicas + 64)
+constexpr int kRoleMaxRays = 340;
+static_assert((kRoleMaxRays + kRoleRPB - 1) / kRoleRPB * 3 <= 256, "one round");
+static_assert((size_t)kRoleMaxRays * 9 * 6 * 2 <=
+                  (size_t)kRoleMaxRays * 36 + (size_t)kDwRep * kColorFlat,
+              "part rows fit the workspace");
+template <int ROLE> struct RolePack;
+template <> struct RolePack<0> { using P = MlpPack<32, 1>; };
+template <> struct RolePack<1> { using P = MlpPack<64, 1>; };
+template <> struct RolePack<2> { using P = MlpPack<32, 4>; };
+constexpr int kRoleFwdMax = MlpPack<64, 1>::WHT;
+constexpr int kRoleBwdMax = MlpPack<64, 1>::LEN - MlpPack<64, 1>::EMB;
+constexpr int kRoleWl = kRoleFwdMax > kRoleBwdMax ? kRoleFwdMax : kRoleBwdMax;
+template <int NT>
+constexpr size_t role_lds_floats() {
+  return (size_t)kRoleWl + kRoleRPB * NT * 256;
+}
+
+// backward to the rays (no grid / decoder gradients): part row
+// (ray * NT + tile) * 3 + role
+template <int NT>
+__global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ dmax_p, const float* __restrict__ raw,
+    const double* __restrict__ g_depth, const double* __restrict__ g_var,
+    const float* __restrict__ g_rgb, double* __restrict__ part) {
+  constexpr int S = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = wave / NT, tile = wave % NT;
+  const int q = lane >> 4, li = lane & 15;
+  const int role = blockIdx.y;
+  double* zbuf = reinterpret_cast<double*>(wl + kRoleWl) + wave * 128;
+  using PM = MlpPack<32, 1>;
+  using PF = MlpPack<64, 1>;
+  using PC = MlpPack<32, 4>;
+  const int ngroups = (n + kRoleRPB - 1) / kRoleRPB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * kRoleRPB + slot);
+    const bool active = ray < n;
+    TileGeom tg = {};
+    float gocc = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+    double gp64[3] = {0.0, 0.0, 0.0};
+    float gp32[1][3] = {{0.f, 0.f, 0.f}};
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    uint64_t mask[1] = {0};
+    Tri tr;
+    f32x4 c_a[1][4];
+    if (active) {
+      RayCtx rc;
+      load_ray(rays_o, rays_d, gt_depth, ray, true, rc);
+      const double zl = sample_z<S>(sc, rc, dmax_p[0], lane, zbuf, zbuf + 64);
+      float gocc_s, w, grgb[3];
+      composite_bwd<S>(raw, ray, lane, zl, g_depth, g_var, g_rgb, gocc_s, w,
+                       grgb);
+      const int src = 16 * tile + li;
+      tile_geom(rc, zbuf[64 + src], sc.bound, tg);
+      gocc = __shfl(gocc_s, src);
+      if (!tg.inb) gocc = 0.f;  // occupancy was overridden to 100
+      const float wsrc = __shfl(w, src);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gcol[a] = grgb[a] * wsrc;
+        p32[0][a] = tg.p32[a];
+      }
+      f32x4 c2[2];
+      if (role == 1) {
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+        tri_gather(sc.grid[1], tr, q, c2);
+        c_a[0][2] = c2[0];
+        c_a[0][3] = c2[1];
+      }
+      const int g = role == 0 ? 1 : role == 1 ? 2 : 3;
+      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3 * g, tr);
+      tri_gather(sc.grid[g], tr, q, c2);
+      c_a[0][0] = c2[0];
+      c_a[0][1] = c2[1];
+    }
+    if (role == 0) {
+      const f32x4 c_m[1][2] = {{c_a[0][0], c_a[0][1]}};
+      const float go[1][1] = {{gocc}};
+      f32x4 gc[1][2];
+      stage_weights(wl, sc.dec[1], PM::WHT);
+      if (active) {
+        float om[1][1];
+        mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask, nullptr);
+      }
+      stage_weights(wl, sc.dec[1] + PM::EMB, PM::LEN - PM::EMB);
+      if (active) {
+        mlp_bwd<1, 32, 1, true, true>(wl - PM::EMB, lane, p32, c_m, go, mask,
+                                      gc, gp32);
+        tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
+      }
+    } else if (role == 1) {
+      const float go[1][1] = {{gocc}};
+      f32x4 gc[1][4];
+      stage_weights(wl, sc.dec[2], PF::WHT);
+      if (active) {
+        float of[1][1];
+        mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_a, of, mask, nullptr);
+      }
+      stage_weights(wl, sc.dec[2] + PF::EMB, PF::LEN - PF::EMB);
+      if (active) {
+        mlp_bwd<1, 64, 1, true, true>(wl - PF::EMB, lane, p32, c_a, go, mask,
+                                      gc, gp32);
+        const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
+        tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
+      }
+    } else {
+      const f32x4 c_c[1][2] = {{c_a[0][0], c_a[0][1]}};
+      // channel 3 is overwritten by fine+middle occupancy -> no gradient
+      const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
+      f32x4 gc[1][2];
+      stage_weights(wl, sc.dec[3], PC::WHT);
+      if (active) {
+        float oc[1][4];
+        mlp_fwd<1, 32, 4, true, false>(wl, lane, p32, c_c, oc, mask, nullptr);
+      }
+      stage_weights(wl, sc.dec[3] + PC::EMB, PC::LEN - PC::EMB);
+      if (active) {
+        mlp_bwd<1, 32, 4, true, true>(wl - PC::EMB, lane, p32, c_c, go, mask,
+                                      gc, gp32);
+        tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
+      }
+    }
+    if (active) {
+      const size_t row = ((size_t)ray * NT + tile) * 3 + role;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double g = gp64[a] + (double)gp32[0][a];
+        const double so = wave_sum(g), sd = wave_sum(g * tg.z);
+        if (lane == 0) {
+          part[row * 6 + a] = so;
+          part[row * 6 + 3 + a] = sd;
+        }
+      }
+    }
+  }
+}
+
 // Forward render.  A block = RPB rays (15 / 16 waves, one 16-sample tile
 // each); like the backward it stages one decoder's forward fragments at a time
 // in LDS and loops over groups of rays (persistent blocks, one per CU).
@@ -1084,6 +1243,19 @@ static int fused_dispatch(const xrd_nice_scene* scene, int stage, int nt,
 #undef FUSED_ST
 }
 
+static int roles_attr() {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(
+            reinterpret_cast<const void*>(nice_bwd_roles_kernel<3>),
+            hipFuncAttributeMaxDynamicSharedMemorySize,
+            (int)(role_lds_floats<3>() * sizeof(float))) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr = true;
+  }
+  return XRD_OK;
+}
+
 extern "C" {
 
 int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
@@ -1140,9 +1312,27 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
     rc = zero_floats(dw_rep, (size_t)kDwRep * kColorFlat, stream);
     if (rc != XRD_OK) return rc;
   }
-  rc = fused_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d,
-                      gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg, part,
-                      dw_rep, st);
+  int nt_rows = nt;
+  if (stage == XRD_STAGE_COLOR && nt == 3 && dp && !dw &&
+      n_rays <= kRoleMaxRays && gt_depth != nullptr && !gg[1] && !gg[2] &&
+      !gg[3]) {
+    // tracking: one decoder per block (the part rows of the three roles
+    // extend into the — unused — replica region of the workspace)
+    const size_t lds = role_lds_floats<3>() * sizeof(float);
+    rc = roles_attr();
+    if (rc != XRD_OK) return rc;
+    const int ngroups = (n_rays + kRoleRPB - 1) / kRoleRPB;
+    hipLaunchKernelGGL(nice_bwd_roles_kernel<3>, dim3(ngroups, 3),
+                       dim3(kRoleRPB * 3 * 64), lds, st, *scene, n_rays,
+                       rays_o, rays_d, gt_depth, dmax, raw, g_depth, g_var,
+                       g_rgb, part);
+    rc = check_launch("xrd_nice_render_bwd/roles");
+    nt_rows = 9;
+  } else {
+    rc = fused_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d,
+                        gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg, part,
+                        dw_rep, st);
+  }
   if (rc != XRD_OK) return rc;
   if (dw || dp) {
     const int len = dw ? kColorFlat : 0;
@@ -1150,7 +1340,7 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
     hipLaunchKernelGGL(nice_bwd_finish_kernel, dim3((total + 255) / 256),
                        dim3(256), 0, st, dw_rep, len,
                        dw ? g_dec[XRD_DEC_COLOR] : nullptr, part,
-                       dp ? n_rays : 0, nt, g_rays_o, g_rays_d);
+                       dp ? n_rays : 0, nt_rows, g_rays_o, g_rays_d);
     return check_launch("xrd_nice_render_bwd/finish");
   }
   return XRD_OK;
@@ -1158,6 +1348,7 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
 
 int xrd_nice_warmup(void) {
   float* gg[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (int rc = roles_attr(); rc != XRD_OK) return rc;
   xrd_nice_scene sc = {};
   for (int stage = XRD_STAGE_COARSE; stage <= XRD_STAGE_COLOR; ++stage)
     for (int nt = 2; nt <= 3; ++nt) {
