@@ -30,7 +30,8 @@ def short_name(name):
               'nice_map_finish_kernel',
               'nice_bwd_coarse_kernel', 'nice_bwd_finish_kernel',
               'coarse_rep_reduce_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
-              'hash_chunk_scatter_kernel', 'coslam_reduce_kernel',
+              'hash_chunk_scatter_kernel', 'hash_chunk_scatter_runs_kernel',
+              'coslam_reduce_kernel',
               'coslam_loss_grad_kernel', 'adam_dense_kernel',
               'reduce_partials_kernel', 'hashgrid_kernel',
               'vox_points_fwd_kernel', 'vox_points_bwd_kernel', 'vox_dw_kernel',

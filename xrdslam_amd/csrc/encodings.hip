@@ -213,10 +213,25 @@ struct ChunkMeta {
   int n_levels;
 };
 
-__global__ __launch_bounds__(1024) void hash_chunk_scatter_kernel(
-    ChunkMeta M, int64_t n, const float* __restrict__ x,
+// Round 4: the scatter with RUN MERGING (round 3 visited the points in a
+// strided permutation, one point a thread: half of its 233 us were the
+// permutation's 64-line gathers, half the LDS atomics).  The points of a Co-SLAM batch
+// are consecutive samples of rays (and the lines of the smoothness lattice):
+// neighbours in memory are neighbours in space.  A thread walks a run of
+// ``run_len`` consecutive points, keeps the 8 corners of the current cell and
+// their sums in registers, and touches LDS only when the run leaves the cell:
+// fewer ds_add_f32 lane-operations (the half of the round-3 kernel that is
+// bound by the ~0.4 lane-op / clock / CU this chip retires) and consecutive
+// addresses per lane instead of the 64-line gathers of the permutation (the
+// other half; profiles/r04_coslam_scatter_experiments.txt).  Correct for any
+// run length and any point order (a run that crosses into another ray just
+// flushes).  Measured at the mapping batch (102 727 points): 233 us -> 166 us
+// with runs of 8 (4: 181, 16: 199, 43 = one thread a ray: 309 — too few
+// threads); at 44 032 points runs of 4: 111 -> 91 us.
+__global__ __launch_bounds__(1024) void hash_chunk_scatter_runs_kernel(
+    ChunkMeta M, int64_t n, int run_len, const float* __restrict__ x,
     const float* __restrict__ dy, int64_t point_stride, int64_t level_stride,
-    float* __restrict__ dparams, int64_t p_mul) {
+    float* __restrict__ dparams) {
   __shared__ float acc[2 * kChunk];
   int lvl = 0;
   while (lvl + 1 < M.n_levels && blockIdx.x >= M.first_block[lvl + 1]) ++lvl;
@@ -229,44 +244,68 @@ __global__ __launch_bounds__(1024) void hash_chunk_scatter_kernel(
   for (int i = threadIdx.x; i < 2 * (int)cnt; i += blockDim.x) acc[i] = 0.f;
   __syncthreads();
   const float* gy = dy + (int64_t)lvl * level_stride;
-  // Points are visited in a strided permutation p = (i * P) mod n (P prime,
-  // not dividing n): neighbouring lanes then work on points of different
-  // rays/depths instead of one ray's consecutive samples, which all fall
-  // into the same cell at the coarse levels (same-address LDS conflicts).
-  const int64_t stride = (int64_t)blockDim.x * n_slices;
-  const int64_t i0 = (int64_t)slice * blockDim.x + threadIdx.x;
-  const int64_t p_step = n > 0 ? (stride * p_mul) % n : 0;
-  int64_t p = n > 0 ? (i0 * p_mul) % n : 0;
-  // dense level <=> res^3 fits the level (tcnn grid_index); hashed levels
-  // have power-of-two sizes (checked on the host)
   const bool dense = (uint64_t)lv.res * lv.res * lv.res <= (uint64_t)lv.size;
   const uint32_t hmask = lv.size - 1;
-  for (int64_t i = i0; i < n;
-       i += stride, p = (p + p_step >= n ? p + p_step - n : p + p_step)) {
-    const float2 g = *reinterpret_cast<const float2*>(gy + p * point_stride);
-    if (g.x == 0.f && g.y == 0.f) continue;
-    const float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
-    const float fx = fmaf(lv.scale, px, 0.5f), fy = fmaf(lv.scale, py, 0.5f),
-                fz = fmaf(lv.scale, pz, 0.5f);
-    const float ffx = floorf(fx), ffy = floorf(fy), ffz = floorf(fz);
-    const uint32_t cx = (uint32_t)(int)ffx, cy = (uint32_t)(int)ffy,
-                   cz = (uint32_t)(int)ffz;
-    const float wx = fx - ffx, wy = fy - ffy, wz = fz - ffz;
+  const int64_t n_runs = (n + run_len - 1) / run_len;
+  for (int64_t r = (int64_t)slice * blockDim.x + threadIdx.x; r < n_runs;
+       r += (int64_t)blockDim.x * n_slices) {
+    const int64_t p0 = r * run_len;
+    const int len = (int)min((int64_t)run_len, n - p0);
+    uint32_t ccx = 0xffffffffu, ccy = 0, ccz = 0;
+    uint32_t idx[8];
+    float ax[8], ay[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
-      const uint32_t ux = cx + bx, uy = cy + by, uz = cz + bz;
-      const uint32_t full = dense
-          ? (ux + uy * lv.res + uz * lv.res * lv.res) % lv.size
-          : ((ux * 1u) ^ (uy * 2654435761u) ^ (uz * 805459861u)) & hmask;
-      const uint32_t idx = full - lo;
-      if (idx < cnt) {
+      idx[c] = 0xffffffffu;
+      ax[c] = 0.f;
+      ay[c] = 0.f;
+    }
+    for (int s = 0; s < len; ++s) {
+      const int64_t p = p0 + s;
+      const float2 g = *reinterpret_cast<const float2*>(gy + p * point_stride);
+      if (g.x == 0.f && g.y == 0.f) continue;
+      const float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
+      const float fx = fmaf(lv.scale, px, 0.5f), fy = fmaf(lv.scale, py, 0.5f),
+                  fz = fmaf(lv.scale, pz, 0.5f);
+      const float ffx = floorf(fx), ffy = floorf(fy), ffz = floorf(fz);
+      const uint32_t cx = (uint32_t)(int)ffx, cy = (uint32_t)(int)ffy,
+                     cz = (uint32_t)(int)ffz;
+      const float wx = fx - ffx, wy = fy - ffy, wz = fz - ffz;
+      if (cx != ccx || cy != ccy || cz != ccz) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (idx[c] < cnt && (ax[c] != 0.f || ay[c] != 0.f)) {
+            atomicAdd(&acc[2 * idx[c]], ax[c]);
+            atomicAdd(&acc[2 * idx[c] + 1], ay[c]);
+          }
+          const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
+          const uint32_t ux = cx + bx, uy = cy + by, uz = cz + bz;
+          const uint32_t full = dense
+              ? (ux + uy * lv.res + uz * lv.res * lv.res) % lv.size
+              : ((ux * 1u) ^ (uy * 2654435761u) ^ (uz * 805459861u)) & hmask;
+          idx[c] = full - lo;
+          ax[c] = 0.f;
+          ay[c] = 0.f;
+        }
+        ccx = cx;
+        ccy = cy;
+        ccz = cz;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t bx = c & 1, by = (c >> 1) & 1, bz = (c >> 2) & 1;
         const float w = (bx ? wx : 1.f - wx) * (by ? wy : 1.f - wy) *
                         (bz ? wz : 1.f - wz);
-        atomicAdd(&acc[2 * idx], w * g.x);
-        atomicAdd(&acc[2 * idx + 1], w * g.y);
+        ax[c] = fmaf(w, g.x, ax[c]);
+        ay[c] = fmaf(w, g.y, ay[c]);
       }
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (idx[c] < cnt && (ax[c] != 0.f || ay[c] != 0.f)) {
+        atomicAdd(&acc[2 * idx[c]], ax[c]);
+        atomicAdd(&acc[2 * idx[c] + 1], ay[c]);
+      }
   }
   __syncthreads();
   float* out = dparams + 2 * ((size_t)lv.offset + lo);
@@ -374,14 +413,11 @@ int launch_hash_chunk_scatter(int n_levels, const float* scales,
     blocks += chunks * M.slices[l];
   }
   M.first_block[n_levels] = blocks;
-  static const int64_t primes[] = {7919, 7927, 7933, 7937, 7949, 7951, 7963};
-  int64_t P = 1;
-  for (int64_t c : primes)
-    if (n_points > c && n_points % c != 0) { P = c; break; }
-  hipLaunchKernelGGL(hash_chunk_scatter_kernel, dim3(blocks), dim3(1024), 0, st,
-                     M, n_points, x, dy, point_stride, level_stride, dparams,
-                     P);
-  return check_launch("hash_chunk_scatter_kernel");
+  const int run_len = n_points >= 65536 ? 8 : 4;
+  hipLaunchKernelGGL(hash_chunk_scatter_runs_kernel, dim3(blocks), dim3(1024),
+                     0, st, M, n_points, run_len, x, dy, point_stride,
+                     level_stride, dparams);
+  return check_launch("hash_chunk_scatter_runs_kernel");
 }
 
 }  // namespace xrd
