@@ -225,9 +225,11 @@ struct ChunkMeta {
 // addresses per lane instead of the 64-line gathers of the permutation (the
 // other half; profiles/r04_coslam_scatter_experiments.txt).  Correct for any
 // run length and any point order (a run that crosses into another ray just
-// flushes).  Measured at the mapping batch (102 727 points): 233 us -> 166 us
-// with runs of 8 (4: 181, 16: 199, 43 = one thread a ray: 309 — too few
-// threads); at 44 032 points runs of 4: 111 -> 91 us.
+// flushes).  Measured, synthetic rays (102 727 points): 233 us -> 166 us with
+// runs of 8 (4: 181, 16: 199, 43 = one thread a ray: 309 — too few threads),
+// at 44 032 points runs of 4: 111 -> 91 us; in the Co-SLAM mapping iteration
+// (sorted near-surface + uniform samples, + the smoothness lattice: 135 k
+// points) 267 us -> 204 us with runs of 6 (4: 221, 5: 202, 8: 211, 12: 267).
 __global__ __launch_bounds__(1024) void hash_chunk_scatter_runs_kernel(
     ChunkMeta M, int64_t n, int run_len, const float* __restrict__ x,
     const float* __restrict__ dy, int64_t point_stride, int64_t level_stride,
@@ -413,7 +415,7 @@ int launch_hash_chunk_scatter(int n_levels, const float* scales,
     blocks += chunks * M.slices[l];
   }
   M.first_block[n_levels] = blocks;
-  const int run_len = n_points >= 65536 ? 8 : 4;
+  const int run_len = n_points >= 65536 ? 6 : 4;
   hipLaunchKernelGGL(hash_chunk_scatter_runs_kernel, dim3(blocks), dim3(1024),
                      0, st, M, n_points, run_len, x, dy, point_stride,
                      level_stride, dparams);
