@@ -1,6 +1,8 @@
 """GPU idle time of a rocprofv3 --kernel-trace run: union of the kernel
 intervals over the LAST ``frac`` of the trace (the timed region of bench.py),
-and which kernels the queue waited in front of.
+and which kernels the queue waited in front of.  CAVEAT: rocprofv3's kernel
+tracing serialises dispatches (concurrent streams show 0 % overlap) and adds
+~10 us in front of every graph launch: read the idle time as an upper bound.
 usage: trace_gaps.py <kernel_trace.csv> [frac=0.5]"""
 import collections
 import csv
