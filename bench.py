@@ -386,7 +386,7 @@ def run_coslam(args, dev, with_cpu, world=1):
         'traffic': pmc_traffic(
             (['coslam_bwd<dp=false,dg=true>'] if map_grads else []) +
             (['coslam_bwd<dp=true,dg=false>'] if ray_grads else []) +
-            (['coslam_reduce_kernel', 'hash_chunk_scatter_kernel']
+            (['coslam_reduce_kernel', 'hash_chunk_scatter_runs_kernel']
              if map_grads else [])) if kernel == 'coslam_bwd'
         else pmc_traffic(['coslam_fwd_kernel']),
         'traffic_source': 'profiles/r04_pmc.json (see NICE line)',
