@@ -253,7 +253,9 @@ __global__ __launch_bounds__(1024) void hash_chunk_scatter_runs_kernel(
        r += (int64_t)blockDim.x * n_slices) {
     const int64_t p0 = r * run_len;
     const int len = (int)min((int64_t)run_len, n - p0);
-    uint32_t ccx = 0xffffffffu, ccy = 0, ccz = 0;
+    uint32_t ccx = 0, ccy = 0, ccz = 0;
+    bool have = false;  // (no sentinel cell: points left of the unit cube
+                        // wrap to 0xffffffff like in the forward)
     uint32_t idx[8];
     float ax[8], ay[8];
 #pragma unroll
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(1024) void hash_chunk_scatter_runs_kernel(
       const uint32_t cx = (uint32_t)(int)ffx, cy = (uint32_t)(int)ffy,
                      cz = (uint32_t)(int)ffz;
       const float wx = fx - ffx, wy = fy - ffy, wz = fz - ffz;
-      if (cx != ccx || cy != ccy || cz != ccz) {
+      if (!have || cx != ccx || cy != ccy || cz != ccz) {
+        have = true;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           if (idx[c] < cnt && (ax[c] != 0.f || ay[c] != 0.f)) {
