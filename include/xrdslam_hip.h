@@ -315,6 +315,32 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
                         float* g_rays_o, float* g_rays_d,
                         float* const g_grid[4], float* const g_dec[4],
                         float* ws, xrd_stream_t stream);
+/* Tracking (colour stage, 48 samples a ray, <= 340 rays, ray gradients only):
+ * the forward keeps the ReLU masks of the three decoders — masks:
+ * xrd_nice_fwd_masks_words(n_rays) 64-bit words, [(ray*3 + tile)*3 + decoder]
+ * [64 lanes] — and the backward that receives them skips its forward
+ * recompute (one decoder per block, csrc/nice_render.hip).  Same results as
+ * xrd_nice_render_fwd / xrd_nice_render_bwd (the forward bit for bit, the ray
+ * gradients up to the summation order of the three decoders' parts).  Other
+ * shapes -> XRD_ERR_UNSUPPORTED (use the pair above).  Replaces the same
+ * reference lines: the renderer (conv_onet.py:339-524) under autograd in
+ * Algorithm.optimize_update's tracking loop (base_algorithm.py:243-275). */
+int64_t xrd_nice_fwd_masks_words(int n_rays);
+int xrd_nice_render_fwd_masks(const xrd_nice_scene* scene, int stage,
+                              int n_rays, const float* rays_o,
+                              const float* rays_d, const float* gt_depth,
+                              const float* dmax, double* depth, double* var,
+                              float* rgb, float* raw_out, uint64_t* masks,
+                              xrd_stream_t stream);
+int xrd_nice_render_bwd_masks(const xrd_nice_scene* scene, int stage,
+                              int n_rays, const float* rays_o,
+                              const float* rays_d, const float* gt_depth,
+                              const float* dmax, const float* raw,
+                              const double* g_depth, const double* g_var,
+                              const float* g_rgb, const uint64_t* masks,
+                              float* g_rays_o, float* g_rays_d, float* ws,
+                              xrd_stream_t stream);
+
 
 /* One NICE-SLAM MAPPING iteration of a stage as one launch (+ one finishing
  * launch): forward render, the mapping loss and the backward of everything it

@@ -674,3 +674,46 @@ def test_tracking_loss_median_both_selection_paths(n, masked):
     assert abs(float(loss) - float(want)) <= 1e-6 * max(abs(float(want)), 1)
     assert torch.allclose(d.grad, d2.grad, rtol=1e-12, atol=0)
     assert torch.equal(rgb.grad, rgb2.grad)
+
+
+@pytest.mark.parametrize('n,masked', [(200, False), (333, True), (340, False)])
+def test_tracking_backward_from_the_forwards_masks(n, masked):
+    """xrd_nice_render_fwd_masks / _bwd_masks (the forward keeps the decoders'
+    ReLU masks, the decoder-per-block backward skips its forward recompute)
+    against the plain pair on the same batch: same loss and — the masks being
+    the ones the recompute would produce — the same ray gradients bit for
+    bit; above the path's ray limit the call is refused"""
+    from xrdslam_amd import _lib
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n, 21)
+    keep = None
+    if masked:
+        keep = (torch.rand(n, generator=torch.Generator().manual_seed(2))
+                > 0.1).to(dev).to(torch.uint8)
+    scene, gl, flats = build_scene(bound, grids, decs, dev)
+    args = (scene, rays_o.to(dev), rays_d.to(dev), depth.to(dev), None,
+            color.to(dev), keep, True, True, 0.5)
+    out = {}
+    for flag in (True, False):
+        en.TRACK_KEEP_MASKS = flag
+        try:
+            loss, g_o, g_d = en.nice_track_iter(*args)
+        finally:
+            en.TRACK_KEEP_MASKS = True
+        torch.cuda.synchronize()
+        out[flag] = (float(loss), g_o.cpu(), g_d.cpu())
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1])
+    assert torch.equal(out[True][2], out[False][2])
+    assert float(out[True][1].abs().max()) > 0
+    lib = _lib.lib()
+    assert lib.xrd_nice_fwd_masks_words(n) == n * 9 * 64
+    import ctypes as C
+    cs = scene.c_struct()
+    p = C.c_void_p(16)
+    assert lib.xrd_nice_render_fwd_masks(C.byref(cs), 3, 341, p, p, p, p, p,
+                                         p, p, p, p, None) == 3   # unsupported
+    assert lib.xrd_nice_render_fwd_masks(C.byref(cs), 3, 8, p, p, p, p, p, p,
+                                         p, p, None, None) == 1   # no masks

@@ -79,6 +79,11 @@ _SIGS = {
     'xrd_point_render_bwd': (C.c_int, [C.c_int, C.c_int] + [vp] * 8 +
                              [f32, C.c_int] + [vp] * 4 + [f32] + [vp] * 18),
     'xrd_nice_bwd_ws_floats': (i64, [C.c_int]),
+    'xrd_nice_fwd_masks_words': (i64, [C.c_int]),
+    'xrd_nice_render_fwd_masks': (C.c_int, [C.POINTER(NiceScene), C.c_int,
+                                            C.c_int] + [vp] * 10),
+    'xrd_nice_render_bwd_masks': (C.c_int, [C.POINTER(NiceScene), C.c_int,
+                                            C.c_int] + [vp] * 13),
     'xrd_nice_coarse_ws_floats': (i64, [C.POINTER(NiceScene)]),
     'xrd_nice_render_bwd': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,

@@ -280,14 +280,18 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
       if ((s & 7) == 7) XRD_SB();
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      // the layer's 8 ReLU bits are collected in a 32-bit word with constant
+      // shifts; ONE 64-bit shift a layer places them (the layer index is a
+      // run-time value: 8 variable 64-bit shifts a layer were measurable in
+      // the one-wave-a-SIMD tracking kernels)
+      uint32_t m8 = 0;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a = acc[t][jt][r];
-          if (SAVE_MASK && a > 0.f)
-            mask[t] |= (uint64_t)1 << (i * 8 + jt * 4 + r);
+          if (SAVE_MASK && a > 0.f) m8 |= 1u << (jt * 4 + r);
           h[t][jt][r] = fmaxf(a, 0.f) + cc[t][jt][r];
         }
         if (SAVE_H) hs[i][jt] = h[t][jt];
@@ -298,6 +302,8 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
                 h[t][jt][r];
         }
       }
+      if (SAVE_MASK) mask[t] |= (uint64_t)m8 << (i * 8);
+    }
     if (i < 4) {
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {

@@ -326,7 +326,10 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const float* __restrict__ dmax_p, const float* __restrict__ raw,
     const double* __restrict__ g_depth, const double* __restrict__ g_var,
-    const float* __restrict__ g_rgb, double* __restrict__ part) {
+    const float* __restrict__ g_rgb, double* __restrict__ part,
+    const uint64_t* __restrict__ masks) {
+  // masks != nullptr: the forward kept the ReLU masks (nice_fwd_kernel
+  // KEEP_MASK) — no forward fragments are staged, no forward pass is run
   constexpr int S = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
   const int slot = wave / NT, tile = wave % NT;
   const int q = lane >> 4, li = lane & 15;
   const int role = blockIdx.y;
+  const bool have = masks != nullptr;
   double* zbuf = reinterpret_cast<double*>(wl + kRoleWl) + wave * 128;
   using PM = MlpPack<32, 1>;
   using PF = MlpPack<64, 1>;
@@ -379,15 +383,20 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
       tri_gather(sc.grid[g], tr, q, c2);
       c_a[0][0] = c2[0];
       c_a[0][1] = c2[1];
+      if (have)
+        mask[0] = masks[((size_t)(ray * NT + tile) * 3 + role) * 64 + lane];
     }
     if (role == 0) {
       const f32x4 c_m[1][2] = {{c_a[0][0], c_a[0][1]}};
       const float go[1][1] = {{gocc}};
       f32x4 gc[1][2];
-      stage_weights(wl, sc.dec[1], PM::WHT);
-      if (active) {
-        float om[1][1];
-        mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask, nullptr);
+      if (!have) {
+        stage_weights(wl, sc.dec[1], PM::WHT);
+        if (active) {
+          float om[1][1];
+          mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask,
+                                         nullptr);
+        }
       }
       stage_weights(wl, sc.dec[1] + PM::EMB, PM::LEN - PM::EMB);
       if (active) {
@@ -398,10 +407,13 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
     } else if (role == 1) {
       const float go[1][1] = {{gocc}};
       f32x4 gc[1][4];
-      stage_weights(wl, sc.dec[2], PF::WHT);
-      if (active) {
-        float of[1][1];
-        mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_a, of, mask, nullptr);
+      if (!have) {
+        stage_weights(wl, sc.dec[2], PF::WHT);
+        if (active) {
+          float of[1][1];
+          mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_a, of, mask,
+                                         nullptr);
+        }
       }
       stage_weights(wl, sc.dec[2] + PF::EMB, PF::LEN - PF::EMB);
       if (active) {
@@ -415,10 +427,13 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
       // channel 3 is overwritten by fine+middle occupancy -> no gradient
       const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
       f32x4 gc[1][2];
-      stage_weights(wl, sc.dec[3], PC::WHT);
-      if (active) {
-        float oc[1][4];
-        mlp_fwd<1, 32, 4, true, false>(wl, lane, p32, c_c, oc, mask, nullptr);
+      if (!have) {
+        stage_weights(wl, sc.dec[3], PC::WHT);
+        if (active) {
+          float oc[1][4];
+          mlp_fwd<1, 32, 4, true, false>(wl, lane, p32, c_c, oc, mask,
+                                         nullptr);
+        }
       }
       stage_weights(wl, sc.dec[3] + PC::EMB, PC::LEN - PC::EMB);
       if (active) {
@@ -454,14 +469,19 @@ constexpr size_t fwd_lds_floats() {
   return (size_t)kWMax + RPB * 256 + RPB * NT * 256;
 }
 
-template <int STAGE, int NT, int RPB>
+// KEEP_MASK: the ReLU masks of the three decoders go to ``masks``
+// [(ray * NT + tile) * 3 + decoder][64 lanes] (uint64: 40 bits a lane) — a
+// backward that gets them skips its forward recompute (tracking,
+// xrd_nice_render_fwd_masks / xrd_nice_render_bwd_masks)
+template <int STAGE, int NT, int RPB, bool KEEP_MASK = false>
 __global__ __launch_bounds__(RPB * NT * 64, (RPB * NT + 3) / 4) void
 nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
                 const float* __restrict__ rays_d,
                 const float* __restrict__ gt_depth,
                 const float* __restrict__ dmax_p, double* __restrict__ depth,
                 double* __restrict__ var, float* __restrict__ rgb,
-                float* __restrict__ raw_out) {
+                float* __restrict__ raw_out,
+                uint64_t* __restrict__ masks = nullptr) {
   constexpr int S = NT * 16;
   constexpr int NW = RPB * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -508,9 +528,11 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
       stage_weights(wl, sc.dec[1], MlpPack<32, 1>::WHT);
       if (active) {
         float om[1][1];
-        mlp_fwd<1, 32, 1, false, false>(wl, lane, p32, c_m, om, mdummy,
-                                        nullptr);
+        mlp_fwd<1, 32, 1, KEEP_MASK, false>(wl, lane, p32, c_m, om, mdummy,
+                                            nullptr);
         occ = om[0][0];
+        if (KEEP_MASK)
+          masks[((size_t)(ray * NT + tile) * 3 + 0) * 64 + lane] = mdummy[0];
       }
       if (STAGE >= XRD_STAGE_FINE) {
         f32x4 c_f[1][4];
@@ -526,9 +548,11 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
         stage_weights(wl, sc.dec[2], MlpPack<64, 1>::WHT);
         if (active) {
           float of[1][1];
-          mlp_fwd<1, 64, 1, false, false>(wl, lane, p32, c_f, of, mdummy,
-                                          nullptr);
+          mlp_fwd<1, 64, 1, KEEP_MASK, false>(wl, lane, p32, c_f, of, mdummy,
+                                              nullptr);
           occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
+          if (KEEP_MASK)
+            masks[((size_t)(ray * NT + tile) * 3 + 1) * 64 + lane] = mdummy[0];
         }
       }
       if (STAGE == XRD_STAGE_COLOR) {
@@ -540,8 +564,10 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
         stage_weights(wl, sc.dec[3], MlpPack<32, 4>::WHT);
         if (active) {
           float oc[1][4];
-          mlp_fwd<1, 32, 4, false, false>(wl, lane, p32, c_c, oc, mdummy,
-                                          nullptr);
+          mlp_fwd<1, 32, 4, KEEP_MASK, false>(wl, lane, p32, c_c, oc, mdummy,
+                                              nullptr);
+          if (KEEP_MASK)
+            masks[((size_t)(ray * NT + tile) * 3 + 2) * 64 + lane] = mdummy[0];
           col[0] = oc[0][0];
           col[1] = oc[0][1];
           col[2] = oc[0][2];
@@ -971,7 +997,8 @@ static int launch_fwd(const xrd_nice_scene* scene, int n, const float* rays_o,
   const int ngroups = (n + rpb - 1) / rpb;
   const int nb = ngroups < kFusedBlocks ? ngroups : kFusedBlocks;
   hipLaunchKernelGGL(kern, dim3(nb), dim3(rpb * NTV * 64), lds, st, *scene, n,
-                     rays_o, rays_d, gt_depth, dmax, depth, var, rgb, raw_out);
+                     rays_o, rays_d, gt_depth, dmax, depth, var, rgb, raw_out,
+                     (uint64_t*)nullptr);
   return check_launch("xrd_nice_render_fwd");
 }
 
@@ -1258,14 +1285,56 @@ static int roles_attr() {
 
 extern "C" {
 
-int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
-                        const float* rays_o, const float* rays_d,
-                        const float* gt_depth, const float* dmax,
-                        const float* raw, const double* g_depth,
-                        const double* g_var, const float* g_rgb,
-                        float* g_rays_o, float* g_rays_d,
-                        float* const g_grid[4], float* const g_dec[4],
-                        float* ws, xrd_stream_t stream) {
+static bool masks_supported(int stage, int nt, int n_rays,
+                            const float* gt_depth) {
+  return stage == XRD_STAGE_COLOR && nt == 3 && n_rays <= kRoleMaxRays &&
+         gt_depth != nullptr;
+}
+
+int64_t xrd_nice_fwd_masks_words(int n_rays) {
+  return n_rays < 0 ? -1 : (int64_t)n_rays * 3 * 3 * 64;
+}
+
+int xrd_nice_render_fwd_masks(const xrd_nice_scene* scene, int stage,
+                              int n_rays, const float* rays_o,
+                              const float* rays_d, const float* gt_depth,
+                              const float* dmax, double* depth, double* var,
+                              float* rgb, float* raw_out, uint64_t* masks,
+                              xrd_stream_t stream) {
+  int nt = 0;
+  int rc = nice_check(scene, stage, n_rays, gt_depth, &nt);
+  if (rc != XRD_OK) return rc;
+  if (!rays_o || !rays_d || !depth || !var || !rgb || !masks)
+    return XRD_ERR_ARG;
+  if (!masks_supported(stage, nt, n_rays, gt_depth))
+    return XRD_ERR_UNSUPPORTED;
+  if (!dmax) return XRD_ERR_ARG;
+  auto kern = nice_fwd_kernel<XRD_STAGE_COLOR, 3, 1, true>;
+  const size_t lds = fwd_lds_floats<3, 1>() * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    attr_set = true;
+  }
+  if (n_rays == 0) return XRD_OK;
+  hipLaunchKernelGGL(kern, dim3(n_rays), dim3(3 * 64), lds,
+                     (hipStream_t)stream, *scene, n_rays, rays_o, rays_d,
+                     gt_depth, dmax, depth, var, rgb, raw_out, masks);
+  return check_launch("xrd_nice_render_fwd_masks");
+}
+
+static int render_bwd_impl(const xrd_nice_scene* scene, int stage, int n_rays,
+                           const float* rays_o, const float* rays_d,
+                           const float* gt_depth, const float* dmax,
+                           const float* raw, const double* g_depth,
+                           const double* g_var, const float* g_rgb,
+                           const uint64_t* masks, float* g_rays_o,
+                           float* g_rays_d, float* const g_grid[4],
+                           float* const g_dec[4], float* ws,
+                           xrd_stream_t stream) {
   int nt = 0;
   int rc = nice_check(scene, stage, n_rays, gt_depth, &nt);
   if (rc != XRD_OK) return rc;
@@ -1325,9 +1394,11 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
     hipLaunchKernelGGL(nice_bwd_roles_kernel<3>, dim3(ngroups, 3),
                        dim3(kRoleRPB * 3 * 64), lds, st, *scene, n_rays,
                        rays_o, rays_d, gt_depth, dmax, raw, g_depth, g_var,
-                       g_rgb, part);
+                       g_rgb, part, masks);
     rc = check_launch("xrd_nice_render_bwd/roles");
     nt_rows = 9;
+  } else if (masks != nullptr) {
+    return XRD_ERR_UNSUPPORTED;  // masks: the ray-gradient-only tracking path
   } else {
     rc = fused_dispatch(scene, stage, nt, dp, dw, n_rays, rays_o, rays_d,
                         gt_depth, dmax, raw, g_depth, g_var, g_rgb, gg, part,
@@ -1344,6 +1415,33 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
     return check_launch("xrd_nice_render_bwd/finish");
   }
   return XRD_OK;
+}
+
+int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
+                        const float* rays_o, const float* rays_d,
+                        const float* gt_depth, const float* dmax,
+                        const float* raw, const double* g_depth,
+                        const double* g_var, const float* g_rgb,
+                        float* g_rays_o, float* g_rays_d,
+                        float* const g_grid[4], float* const g_dec[4],
+                        float* ws, xrd_stream_t stream) {
+  return render_bwd_impl(scene, stage, n_rays, rays_o, rays_d, gt_depth, dmax,
+                         raw, g_depth, g_var, g_rgb, nullptr, g_rays_o,
+                         g_rays_d, g_grid, g_dec, ws, stream);
+}
+
+int xrd_nice_render_bwd_masks(const xrd_nice_scene* scene, int stage,
+                              int n_rays, const float* rays_o,
+                              const float* rays_d, const float* gt_depth,
+                              const float* dmax, const float* raw,
+                              const double* g_depth, const double* g_var,
+                              const float* g_rgb, const uint64_t* masks,
+                              float* g_rays_o, float* g_rays_d, float* ws,
+                              xrd_stream_t stream) {
+  if (!masks || !g_rays_o || !g_rays_d) return XRD_ERR_ARG;
+  return render_bwd_impl(scene, stage, n_rays, rays_o, rays_d, gt_depth, dmax,
+                         raw, g_depth, g_var, g_rgb, masks, g_rays_o,
+                         g_rays_d, nullptr, nullptr, ws, stream);
 }
 
 int xrd_nice_warmup(void) {

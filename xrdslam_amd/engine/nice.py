@@ -487,6 +487,10 @@ def decoder_weight_grad(scene: NiceScene, kind: str, flat: torch.Tensor,
 # 12-wave blocks cost.  The lever for this batch size is depth, not launches:
 # the three decoders of a tile on three waves at once.
 TRACK_ONE_LAUNCH = False
+# the tracking forward keeps the decoders' ReLU masks for the backward
+# (xrd_nice_render_fwd_masks / _bwd_masks: colour stage, <= 340 rays)
+TRACK_KEEP_MASKS = True
+TRACK_MASKS_MAX_RAYS = 340
 
 
 @torch.no_grad()
@@ -543,12 +547,25 @@ def nice_track_iter(scene: NiceScene, rays_o: torch.Tensor,
     g_rgb = torch.empty(n, 3, **f32)
     g_o, g_d = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
     ws = torch.empty(lib.xrd_nice_bwd_ws_floats(n), **f32)
+    # tracking-sized batches: the forward hands its ReLU masks to the backward
+    # (no forward recompute there); larger ones take the plain pair
+    masks = None
+    if TRACK_KEEP_MASKS and S == 48 and n <= TRACK_MASKS_MAX_RAYS:
+        masks = torch.empty(lib.xrd_nice_fwd_masks_words(n),
+                            dtype=torch.int64, device=dev)
     with _Timed(('nice_fwd', 'color', n, False, False, False)):
-        _lib.check(lib.xrd_nice_render_fwd(
-            C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
-            _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(depth),
-            _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(raw), st),
-            'xrd_nice_render_fwd')
+        if masks is not None:
+            _lib.check(lib.xrd_nice_render_fwd_masks(
+                C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
+                _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(depth),
+                _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(raw), _lib.ptr(masks),
+                st), 'xrd_nice_render_fwd_masks')
+        else:
+            _lib.check(lib.xrd_nice_render_fwd(
+                C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
+                _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(depth),
+                _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(raw), st),
+                'xrd_nice_render_fwd')
     _lib.check(lib.xrd_nice_loss(
         n, 0, int(use_color), int(handle_dynamic), float(w_color),
         _lib.ptr(depth), _lib.ptr(var), _lib.ptr(rgb), _lib.ptr(gd),
@@ -556,12 +573,20 @@ def nice_track_iter(scene: NiceScene, rays_o: torch.Tensor,
         _lib.ptr(g_rgb), st), 'xrd_nice_loss')
     gg, gdec = (C.c_void_p * 4)(), (C.c_void_p * 4)()
     with _Timed(('nice_bwd', 'color', n, True, False, False)):
-        _lib.check(lib.xrd_nice_render_bwd(
-            C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
-            _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(raw),
-            _lib.ptr(g_dep), None, _lib.ptr(g_rgb), _lib.ptr(g_o),
-            _lib.ptr(g_d), C.byref(gg), C.byref(gdec), _lib.ptr(ws), st),
-            'xrd_nice_render_bwd')
+        if masks is not None:
+            _lib.check(lib.xrd_nice_render_bwd_masks(
+                C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
+                _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(raw),
+                _lib.ptr(g_dep), None, _lib.ptr(g_rgb), _lib.ptr(masks),
+                _lib.ptr(g_o), _lib.ptr(g_d), _lib.ptr(ws), st),
+                'xrd_nice_render_bwd_masks')
+        else:
+            _lib.check(lib.xrd_nice_render_bwd(
+                C.byref(cs), STAGES['color'], n, _lib.ptr(rays_o),
+                _lib.ptr(rays_d), _lib.ptr(gd), _lib.ptr(dm), _lib.ptr(raw),
+                _lib.ptr(g_dep), None, _lib.ptr(g_rgb), _lib.ptr(g_o),
+                _lib.ptr(g_d), C.byref(gg), C.byref(gdec), _lib.ptr(ws), st),
+                'xrd_nice_render_bwd')
     return loss, g_o, g_d
 
 
