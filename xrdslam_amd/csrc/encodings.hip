@@ -201,9 +201,9 @@ __global__ __launch_bounds__(256) void tv_loss_kernel(
 // chunk of one level into LDS, re-derives the corner indices of the points of
 // its slice for that level (a few integer ops) and keeps only the hits; the
 // chunk is then added to the table with coalesced atomics (non-zero entries
-// only).  LDS f32 atomics retire ~1 lane-op per clock per CU (measured), so
-// the work is balanced over >= 16 blocks per level: levels with few chunks are
-// split into more point slices.
+// only).  LDS f32 atomics retire well under one lane-op per clock per CU
+// (~0.4 measured in round 4), so the work is balanced over >= 32 blocks per
+// level: levels with few chunks are split into more point slices.
 constexpr int kChunk = 8192;       // entries (x2 floats = 64 KB of LDS)
 constexpr int kBlocksPerLevel = 32;
 struct ChunkMeta {
