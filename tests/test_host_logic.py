@@ -143,6 +143,20 @@ def test_convonet_bound_and_grid_shapes_cpu():
     assert m.decoder.color_decoder.flat.numel() == 15899
 
 
+def test_unbuilt_model_options_are_refused_loudly():
+    """options of the reference models the kernels are not built for fail at
+    construction instead of being ignored (NICE-SLAM: the second,
+    inverse-CDF sampling pass of conv_onet.py:498-512)"""
+    import pytest
+    from xrdslam_amd.slam.configs.input_config import nice_slam_config
+    from xrdslam_amd.slam.models.conv_onet import ConvOnet
+    cfg = nice_slam_config()
+    cfg.model.rendering_n_importance = 8
+    bb = torch.from_numpy(np.array(cfg.mapping_bound))
+    with pytest.raises(NotImplementedError, match='n_importance'):
+        ConvOnet(cfg.model, Camera(320., 320., 319.5, 239.5, 640, 480), bb)
+
+
 def test_synthetic_room_preload_is_transparent():
     """preloaded frames are the frames generated on demand; items are copies
     (callers may edit the dict), and on the CPU no device images are added"""

@@ -114,6 +114,13 @@ class ConvOnet(Model):
 
     def populate_modules(self):
         super().populate_modules()
+        if self.config.rendering_n_importance > 0:
+            # conv_onet.py:498-512 (a second, inverse-CDF pass of N_importance
+            # samples, off in every reference configuration): the render
+            # kernels are built for 32 (+16 depth-guided) samples a ray
+            raise NotImplementedError(
+                'rendering_n_importance > 0 is not built for the NICE-SLAM '
+                'kernels (reference default: 0)')
         self.decoder = NICE(coarse=self.config.coarse)
         self.load_bound()
         self.load_pretrain()
