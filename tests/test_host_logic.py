@@ -155,6 +155,11 @@ def test_unbuilt_model_options_are_refused_loudly():
     bb = torch.from_numpy(np.array(cfg.mapping_bound))
     with pytest.raises(NotImplementedError, match='n_importance'):
         ConvOnet(cfg.model, Camera(320., 320., 319.5, 239.5, 640, 480), bb)
+    cfg = nice_slam_config()
+    cfg.model.rendering_perturb = 1.0
+    cfg.model.rendering_lindisp = True
+    with pytest.raises(NotImplementedError, match='lindisp.*perturb'):
+        ConvOnet(cfg.model, Camera(320., 320., 319.5, 239.5, 640, 480), bb)
 
 
 def test_synthetic_room_preload_is_transparent():

@@ -114,13 +114,29 @@ class ConvOnet(Model):
 
     def populate_modules(self):
         super().populate_modules()
-        if self.config.rendering_n_importance > 0:
+        cfg = self.config
+        if cfg.rendering_n_importance > 0:
             # conv_onet.py:498-512 (a second, inverse-CDF pass of N_importance
             # samples, off in every reference configuration): the render
             # kernels are built for 32 (+16 depth-guided) samples a ray
             raise NotImplementedError(
                 'rendering_n_importance > 0 is not built for the NICE-SLAM '
                 'kernels (reference default: 0)')
+        # the other switches the kernels do not implement are refused too
+        # instead of being ignored (reference defaults in brackets)
+        unbuilt = []
+        if cfg.rendering_lindisp:
+            unbuilt.append('rendering_lindisp=True (False)')
+        if cfg.rendering_perturb > 0:
+            unbuilt.append('rendering_perturb>0 (0.0)')
+        if cfg.model_pos_embedding_method != 'fourier':
+            unbuilt.append("model_pos_embedding_method!='fourier'")
+        if cfg.model_c_dim != 32 or cfg.data_dim != 3:
+            unbuilt.append('model_c_dim!=32 / data_dim!=3')
+        if unbuilt:
+            raise NotImplementedError(
+                'NICE-SLAM options not built for the HIP kernels: ' +
+                ', '.join(unbuilt))
         self.decoder = NICE(coarse=self.config.coarse)
         self.load_bound()
         self.load_pretrain()
