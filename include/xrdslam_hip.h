@@ -159,9 +159,12 @@ int xrd_point_geo_bwd(int64_t n_points, const float* points,
  *   features and the recomputed neighbour distances; NULL = not wanted),
  *   g_col_feats [N,32] (ACCUMULATED with atomics; NULL = not wanted), g_flat
  *   [xrd_point_color_grad_len] (overwritten; NULL = no parameter gradients).
- *   With g_flat: ops = xrd_point_color_ops_floats(n) floats of scratch (the
- *   operands of the weight gradients), workspace = xrd_point_color_ws_floats()
- *   floats (per-block partial products). */
+ *   With g_flat: the weight gradients are contracted inside the backward's
+ *   blocks (MFMA accumulators over the block's 128 points);
+ *   ops = xrd_point_color_ops_floats(n) floats of scratch (the narrow operands
+ *   read back as B fragments: 492 floats a point), workspace =
+ *   xrd_point_color_ws_floats() floats (one partial per block, summed by a
+ *   second launch). */
 int xrd_point_color_flat_len(void);
 int xrd_point_color_grad_len(void);
 int xrd_point_color_pack_len(void);

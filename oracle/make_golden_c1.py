@@ -1,0 +1,529 @@
+"""TEST INFRASTRUCTURE ONLY (build container: needs /root/reference).
+
+Trajectory-level goldens: the REFERENCE's own Algorithm classes — imported
+unmodified from /root/reference through ref_harness — run their whole
+tracking/mapping loop on the CPU over a short synthetic RGB-D sequence, in the
+per-frame order of the reference's Tracker.spin / Mapper.spin
+(slam/pipeline/tracker.py:52-167, slam/pipeline/mapper.py:20-37: the two
+processes alternate strictly through two events, so one loop reproduces the
+sequence).  Per seed the estimated trajectory, the ground truth and the ATE
+are stored; the GPU tests run the engine on the SAME sequence and hold its
+ATE statistics to the reference's.
+
+    python oracle/make_golden_c1.py coslam      # BASELINE.json configs[0]
+    python oracle/make_golden_c1.py voxfusion
+    python oracle/make_golden_c1.py pointslam
+    python oracle/make_golden_c1.py nice
+    -> tests/golden/c1_<algo>.npz
+
+co-slam = BASELINE config 1: 64 frames, 320x240, hash grid + 2x32 MLPs, the
+reference's input_config.py:203-295 hyper-parameters (10 tracking iterations
+x 1024 rays, every 5th frame 10 mapping iterations (first 200), keyframe every
+5th frame).  tiny-cuda-nn is served by oracle/tcnn_standin (unvendored
+dependency: see oracle/tcnn_oracle.py), the other native extensions by the
+stand-ins the kernel goldens use.  A single run of these loops is chaotic
+(random pixel draws, Adam on a few thousand rays): the fixture holds
+N_SEEDS runs and the tests compare means, with the reference's own spread as
+the yardstick.
+"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [HERE, ROOT, os.path.join(ROOT, 'tests')]
+import ref_harness  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+N_SEEDS = int(os.environ.get('C1_SEEDS', '3'))
+# plumbing check: C1_FRAMES=2 C1_SEEDS=1 runs two frames and writes nothing
+SMOKE_FRAMES = int(os.environ.get('C1_FRAMES', '0'))
+
+# the sequence every c1_* fixture is run on; tests rebuild it from these
+SEQ = {
+    'coslam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=240,
+                   W=320, fx=160.0, fy=160.0, cx=159.5, cy=119.5,
+                   n_frames=64),
+    # shorter sequences for the other algorithms (reference hyper-parameters
+    # of input_config.py unless the generator says otherwise)
+    'voxfusion': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=240,
+                      W=320, fx=160.0, fy=160.0, cx=159.5, cy=119.5,
+                      n_frames=24),
+    # 160x120, ~5 mm a frame (the pace NICE-SLAM's 10 tracking iterations at
+    # lr 1e-3 follow), office0 bounds of the reference's nice-slam config
+    'nice': dict(bound=[[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]], H=120, W=160,
+                 fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=600, shrink=0.3,
+                 run_frames=11),
+    'pointslam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=120,
+                      W=160, fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=200,
+                      run_frames=8),
+    'splatam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=48,
+                    W=64, fx=32.0, fy=32.0, cx=31.5, cy=23.5, n_frames=200,
+                    run_frames=6),
+}
+
+
+def sequence(name):
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    s = SEQ[name]
+    kw = {'shrink': s['shrink']} if 'shrink' in s else {}
+    room = SyntheticRoom(s['bound'], H=s['H'], W=s['W'], fx=s['fx'],
+                         fy=s['fy'], cx=s['cx'], cy=s['cy'],
+                         n_frames=s['n_frames'], device='cpu', **kw)
+    return room, s
+
+
+def run_loop(algorithm, frames, Frame, map_every, keyframe_every,
+             use_relative_pose=False, init_pose_offset=0, log=None,
+             lazy_start=-1, n_total=None):
+    """tracker.py:52-167 + mapper.py:20-37 in one loop.  ``n_total`` = length
+    of the dataset the frames are the head of (the last frame of the DATASET
+    is always mapped, tracker.py:176-180)"""
+    first_old = first_new = None
+    n = n_total or len(frames)
+    for idx in range(len(frames)):
+        d = frames[idx]
+        gt = d['c2w'].astype(np.float64)
+        if use_relative_pose:                         # tracker.py:76-89
+            if idx == 0:
+                first_old, gt = gt, np.eye(4)
+                gt[:3, 3] += init_pose_offset
+                first_new = gt
+            else:
+                gt = first_new @ (np.linalg.inv(first_old) @ gt)
+        gt = gt.astype(np.float32)
+        est = algorithm.get_estimate_c2w_list()
+        if idx < 1:                                   # tracker.py:185-199
+            init = gt
+        elif idx == 1:
+            init = est[0].detach().cpu().numpy()
+        else:
+            p1 = est[idx - 1].detach().cpu().numpy()
+            p2 = est[idx - 2].detach().cpu().numpy()
+            init = (p1 @ np.linalg.inv(p2)) @ p1
+        # (fid as the 0-d array the reference's DataLoader hands over)
+        frame = Frame(fid=np.asarray(idx), rgb=d['rgb'], depth=d['depth'], gt_pose=gt,
+                      init_pose=init, separate_LR=algorithm.is_separate_LR(),
+                      rot_rep=algorithm.get_rot_rep())
+        cand = algorithm.do_tracking(frame)
+        if algorithm.is_initialized() and cand is not None:
+            frame.set_pose(cand, separate_LR=algorithm.is_separate_LR(),
+                           rot_rep=algorithm.get_rot_rep())
+        g = torch.from_numpy(gt)
+        algorithm.add_framepose(frame.get_pose().detach(), g, g.clone())
+        every = 1 if idx <= lazy_start else map_every     # tracker.py:172-175
+        if every != -1 and (idx % every == 0 or idx == n - 1):
+            frame.is_final_frame = idx == n - 1
+            algorithm.do_mapping(frame)
+            algorithm.update_framepose(idx, frame.get_pose().detach())
+            if idx % keyframe_every == 0:
+                algorithm.add_keyframe(frame)
+        if log and idx % 8 == 0:
+            log(idx)
+    est = torch.stack([p.detach().cpu() for p in
+                       algorithm.get_estimate_c2w_list()]).numpy()
+    gt = torch.stack([p.cpu() for p in algorithm.get_gt_c2w_list()]).numpy()
+    return est, gt
+
+
+def pose_conversions():
+    """pytorch3d is not installed here: the reference's opt_pose.py gets the
+    three conversions it imports from the repo's restatement of pytorch3d's
+    formulas (xrdslam_amd/slam/utils/opt_pose.py, pinned to the code the
+    reference tree vendors in tests/test_reference_host_parity.py)"""
+    import slam.utils.opt_pose as rp
+    from xrdslam_amd.slam.utils import opt_pose as mp
+    rp.matrix_to_quaternion = mp.matrix_to_quaternion
+    rp.quaternion_to_axis_angle = mp.quaternion_to_axis_angle
+    rp.quaternion_to_matrix = mp.quaternion_to_matrix
+
+
+def ate(est, gt):
+    return float(np.sqrt(((est[:, :3, 3] - gt[:, :3, 3])**2).sum(1).mean()))
+
+
+def _frames(room, n, cv=False):
+    """cv: OpenCV-convention poses (camera looks down +z: what SplaTAM's
+    back-projection assumes) instead of the room's OpenGL ones"""
+    out = []
+    for k in range(n):
+        d = room[k]
+        c2w = np.array(d['c2w'], dtype=np.float64)
+        if cv:
+            c2w[:3, 1] *= -1
+            c2w[:3, 2] *= -1
+        out.append({'rgb': np.asarray(d['rgb'], np.float32),
+                    'depth': np.asarray(d['depth'], np.float32),
+                    'c2w': c2w})
+    return out
+
+
+def coslam():
+    """BASELINE.json configs[0]: the reference's own co-slam config object
+    (input_config.py:203-295: 10 tracking iterations x 1024 rays, every 5th
+    frame 10 mapping iterations (first 200) over the keyframe ray bank, BA of
+    all keyframes) with the scene bounds of the synthetic room"""
+    import copy
+    ref_harness.install()
+    import tcnn_standin
+    tcnn_mod = tcnn_standin.module()
+    sys.modules['tinycudann'] = tcnn_mod
+    import slam.model_components.encodings_coslam as enc
+    enc.tcnn = tcnn_mod
+    x = reference_configs()['co-slam'].xrdslam
+    from slam.common.camera import Camera
+    from slam.common.frame import Frame
+    pose_conversions()
+    room, s = sequence('coslam')
+    frames = _frames(room, s['n_frames'])
+    cam = Camera(s['fx'], s['fy'], s['cx'], s['cy'], s['W'], s['H'])
+    out = _header(s)
+    cfg0 = copy.deepcopy(x.algorithm)
+    cfg0.mapping_bound = cfg0.marching_cubes_bound = s['bound']
+
+    def make():
+        return copy.deepcopy(cfg0).setup(camera=cam, device='cpu')
+    return _run_seeds('co-slam', make, Frame, _cadence(x), out, s['n_frames'],
+                      frames)
+
+
+def _seed(seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def _target():
+    which = sys.argv[1] if len(sys.argv) > 1 else 'coslam'
+    return os.path.join(GOLD, f'c1_{which}.npz')
+
+
+def _header(s):
+    h = {'seq/bound': np.array(s['bound']),
+         'seq/intrinsics': np.array([s['fx'], s['fy'], s['cx'], s['cy'],
+                                     s['W'], s['H']]),
+         'seq/n_frames': np.array(s['n_frames']),
+         'seq/run_frames': np.array(s.get('run_frames', s['n_frames']))}
+    if 'shrink' in s:
+        h['seq/shrink'] = np.array(s['shrink'])
+    return h
+
+
+def reference_configs():
+    """the reference's OWN ``algorithm_configs`` (slam/configs/input_config.py).
+    That module imports every algorithm of the reference (DPVO, NeuralRecon:
+    altcorr, fastba, torchvision, torchsparse ...): while it is imported, any
+    module that cannot be found resolves to a MagicMock"""
+    import importlib.abc
+    import importlib.machinery
+    from unittest import mock
+
+    class Loader(importlib.abc.Loader):
+        def create_module(self, spec):
+            m = mock.MagicMock(name=spec.name)
+            m.__path__, m.__spec__, m.__name__ = [], spec, spec.name
+            return m
+
+        def exec_module(self, module):
+            pass
+
+    class Finder(importlib.abc.MetaPathFinder):
+        def find_spec(self, name, path, target=None):
+            # only imports issued BY reference files (or by a mock package
+            # made here): optional imports of installed packages must keep
+            # failing the way their authors expect
+            f = sys._getframe(1)
+            while f is not None and 'importlib' in f.f_code.co_filename:
+                f = f.f_back
+            by_ref = f is not None and f.f_code.co_filename.startswith(
+                ref_harness.REF_ROOT)
+            parent = name.rpartition('.')[0]
+            if not by_ref and not isinstance(sys.modules.get(parent),
+                                             mock.MagicMock):
+                return None
+            return importlib.machinery.ModuleSpec(name, Loader(),
+                                                  is_package=True)
+    f = Finder()
+    sys.meta_path.append(f)
+    try:
+        from slam.configs.input_config import algorithm_configs
+    finally:
+        sys.meta_path.remove(f)
+    return algorithm_configs
+
+
+def _run_seeds(name, make_algo, Frame, cad, out, n_run, frames, **loop_kw):
+    for seed in range(N_SEEDS):
+        _seed(seed)
+        algo = make_algo()
+        t0 = time.time()
+        if SMOKE_FRAMES:
+            n_run = SMOKE_FRAMES
+        est, gt = run_loop(
+            algo, frames[:n_run], Frame, map_every=cad['map_every'],
+            keyframe_every=cad['keyframe_every'],
+            log=lambda i: print(f'  {name} seed {seed} frame {i} '
+                                f'{time.time() - t0:.0f}s', flush=True),
+            **loop_kw)
+        out[f'est/{seed}'], out['gt'] = est, gt
+        out[f'ate/{seed}'] = np.array(ate(est, gt))
+        out[f'seconds/{seed}'] = np.array(time.time() - t0)
+        print(f'{name} seed {seed}: ATE {ate(est, gt) * 100:.3f} cm '
+              f'({time.time() - t0:.0f} s)', flush=True)
+        if not SMOKE_FRAMES:       # keep what is done if the run is cut
+            np.savez_compressed(_target(), **out)
+    return out
+
+
+def _zeros_on_cpu():
+    """the reference allocates with device='cuda' in places"""
+    real = {n: getattr(torch, n) for n in ('zeros', 'ones', 'empty', 'tensor',
+                                           'arange', 'linspace', 'full',
+                                           'rand', 'randn', 'eye', 'randint',
+                                           'zeros_like', 'ones_like',
+                                           'as_tensor', 'meshgrid')}
+
+    def wrap(fn):
+        def f(*a, **k):
+            if str(k.get('device', '')).startswith('cuda'):
+                k['device'] = 'cpu'
+            return fn(*a, **k)
+        return f
+    for n, fn in real.items():
+        setattr(torch, n, wrap(fn))
+    real_to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple('cpu' if isinstance(x, str) and x.startswith('cuda') else x
+                  for x in a)
+        if str(k.get('device', '')).startswith('cuda'):
+            k['device'] = 'cpu'
+        return real_to(self, *a, **k)
+    torch.Tensor.to = to
+
+
+def _reduced(out, cfg, **fields):
+    """iteration / ray counts a fixture runs with instead of the reference's
+    input_config values (CPU budget); stored as cfg/<field>, applied to the
+    engine's config by tests/c1_util.overrides"""
+    for k, v in fields.items():
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, v)
+        out[f'cfg/{k}'] = np.array(v)
+
+
+def _cadence(x):
+    return {'map_every': x.tracker.map_every,
+            'keyframe_every': x.mapper.keyframe_every}
+
+
+def voxfusion():
+    """input_config.py:159-201 (the reference's own config object): 30
+    tracking iterations x 1024 rays, every frame 15 mapping iterations (first
+    30) x 1024 rays x <= 5 frames, relative poses + 10 m offset, 0.2 m voxels.
+    Octree = the reference's sparse_octree sources compiled by
+    oracle/build_ref_octree.py, ``grid`` = oracle/grid_standin.py (the C
+    oracle of the two CUDA kernels)"""
+    import copy
+
+    import build_ref_octree
+    import grid_standin
+    ref_harness.install()
+    sys.modules['grid'] = grid_standin.module()
+    build_ref_octree.load()
+    _zeros_on_cpu()
+    import slam.model_components.voxel_helpers_voxfusion as vh
+    vh._ext = sys.modules['grid']
+    x = reference_configs()['vox-fusion'].xrdslam
+    from slam.common.camera import Camera
+    from slam.common.frame import Frame
+    pose_conversions()
+    room, s = sequence('voxfusion')
+    frames = _frames(room, s['n_frames'])
+    cam = Camera(s['fx'], s['fy'], s['cx'], s['cy'], s['W'], s['H'])
+    out = _header(s)
+
+    def make():
+        return copy.deepcopy(x.algorithm).setup(camera=cam, device='cpu')
+    return _run_seeds('vox-fusion', make, Frame, _cadence(x), out,
+                      s['n_frames'], frames,
+                      use_relative_pose=x.tracker.use_relative_pose,
+                      init_pose_offset=x.tracker.init_pose_offset)
+
+
+def nice():
+    """input_config.py:45-157 on a 160x120 camera: the reference's NiceSLAM +
+    ConvOnet with decoders carrying an occupancy prior (the shipped
+    pretrained/*.pt are git-LFS pointers: ``load_pretrain`` reads the
+    checkpoint tools/pretrain_nice_decoders.py made), 10 tracking iterations
+    x 200 rays, every 5th frame 30 mapping (+30 coarse) iterations, first 150"""
+    import copy
+    ref_harness.install()
+    _zeros_on_cpu()
+    x = reference_configs()['nice-slam'].xrdslam
+    from slam.common.camera import Camera
+    from slam.common.frame import Frame
+    from slam.models.conv_onet import ConvOnet
+    import slam.model_components.utils as ru
+    ru.cv2 = _image_libs()[2]          # frustum mask: cv2.remap
+    pose_conversions()
+    ckpt = torch.load(os.path.join(ROOT, 'xrdslam_amd', 'data', 'pretrained',
+                                   'nice_decoders_synth.pt'),
+                      map_location='cpu')
+
+    def load_pretrain(self):
+        for kind, sd in ckpt.items():
+            getattr(self.decoder, kind + '_decoder').load_state_dict(sd)
+    ConvOnet.load_pretrain = load_pretrain
+    room, s = sequence('nice')
+    n_run = s['run_frames']
+    frames = _frames(room, n_run)
+    cam = Camera(s['fx'], s['fy'], s['cx'], s['cy'], s['W'], s['H'])
+    out = _header(s)
+    cfg0 = copy.deepcopy(x.algorithm)
+    cfg0.mapping_bound = cfg0.marching_cubes_bound = s['bound']
+    _reduced(out, cfg0, tracking_Hedge=10, tracking_Wedge=10,
+             mapping_first_n_iters=150, mapping_n_iters=30)
+
+    def make():
+        return copy.deepcopy(cfg0).setup(camera=cam, device='cpu')
+    return _run_seeds('nice-slam', make, Frame, _cadence(x), out, n_run,
+                      frames, n_total=s['n_frames'])
+
+
+def _image_libs():
+    """skimage / cv2 are not installed: the three functions the reference's
+    Point-SLAM calls, restated from their published definitions
+    (skimage.color.rgb2gray luma weights; skimage.filters.sobel_h / sobel_v =
+    [1,2,1]/4 smoothing x [1,0,-1] difference, reflected borders;
+    cv2.remap(INTER_LINEAR, constant zero border)).  They steer which pixels
+    are sampled, the per-pixel radii and the frustum mask — not the render."""
+    import types
+
+    def rgb2gray(im):
+        im = np.asarray(im)
+        return im[..., 0] * 0.2125 + im[..., 1] * 0.7154 + im[..., 2] * 0.0721
+
+    def sobel(a, axis):
+        p = np.pad(np.asarray(a, np.float64), 1, mode='symmetric')
+        if axis == 0:
+            d = p[:-2, :] - p[2:, :]
+            return (d[:, :-2] + 2 * d[:, 1:-1] + d[:, 2:]) / 4.0
+        d = p[:, :-2] - p[:, 2:]
+        return (d[:-2, :] + 2 * d[1:-1, :] + d[2:, :]) / 4.0
+
+    def remap(img, mx, my, interpolation=None):
+        img = np.asarray(img)
+        H, W = img.shape[:2]
+        mx, my = np.asarray(mx, np.float32), np.asarray(my, np.float32)
+        x0, y0 = np.floor(mx), np.floor(my)
+        fx, fy = mx - x0, my - y0
+
+        def tap(xx, yy):
+            ok = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+            v = img[np.clip(yy, 0, H - 1).astype(np.int64),
+                    np.clip(xx, 0, W - 1).astype(np.int64)]
+            return np.where(ok, v, 0).astype(np.float32)
+        r = tap(x0, y0) * (1 - fx) * (1 - fy) + tap(x0 + 1, y0) * fx * \
+            (1 - fy) + tap(x0, y0 + 1) * (1 - fx) * fy + \
+            tap(x0 + 1, y0 + 1) * fx * fy
+        return r.astype(np.float32).reshape(-1, 1) if r.ndim == 1 else r
+    filters = types.SimpleNamespace(sobel_h=lambda a: sobel(a, 0),
+                                    sobel_v=lambda a: sobel(a, 1))
+    cv2 = types.SimpleNamespace(remap=remap, INTER_LINEAR=1)
+    return rgb2gray, filters, cv2
+
+
+def pointslam():
+    """input_config.py:297-375 on a 160x120 camera with reduced counts (the
+    reference's 1500 / 5000 rays x 40 / 300 iterations take hours on the
+    CPU): 20 tracking iterations x 300 rays, every frame (lazy_start 20) 40
+    mapping iterations x 1000 rays, first 150; 1500 + 200 pixels added per
+    frame.  kNN = oracle/faiss_standin.py (exact)"""
+    import copy
+
+    import faiss_standin
+    ref_harness.install()
+    sys.modules['faiss'] = faiss_standin.module()
+    _zeros_on_cpu()
+    import slam.model_components.neural_point_cloud as npc_mod
+    npc_mod.faiss = sys.modules['faiss']
+    x = reference_configs()['point-slam'].xrdslam
+    import slam.algorithms.point_slam as ps
+    import slam.common.common as rc
+    rgb2gray, filters, cv2 = _image_libs()
+    ps.rgb2gray = rc.rgb2gray = rgb2gray
+    ps.filters = rc.filters = filters
+    ps.cv2 = cv2
+    from slam.common.camera import Camera
+    from slam.common.frame import Frame
+    from slam.models.conv_onet_pointslam import ConvOnet2
+    ConvOnet2.load_pretrain = lambda self: None      # LFS pointer only
+    pose_conversions()
+    room, s = sequence('pointslam')
+    n_run = s['run_frames']
+    frames = _frames(room, n_run)
+    cam = Camera(s['fx'], s['fy'], s['cx'], s['cy'], s['W'], s['H'])
+    out = _header(s)
+    cfg0 = copy.deepcopy(x.algorithm)
+    _reduced(out, cfg0, tracking_Hedge=10, tracking_Wedge=10,
+             tracking_n_iters=20, tracking_sample=300, mapping_n_iters=40,
+             mapping_first_n_iters=150, mapping_sample=1000,
+             pixels_adding=1500, mapping_pixels_based_on_color_grad=200)
+    out['cad/lazy_start'] = np.array(x.tracker.lazy_start)
+
+    def make():
+        return copy.deepcopy(cfg0).setup(camera=cam, device='cpu')
+    return _run_seeds('point-slam', make, Frame, _cadence(x), out, n_run,
+                      frames, n_total=s['n_frames'],
+                      lazy_start=x.tracker.lazy_start)
+
+
+def splatam():
+    """input_config.py:377-431 on a 64x48 camera: 40 tracking iterations and
+    60 mapping iterations a frame, every frame, the reference's SplaTAM /
+    GaussianSplatting / GaussianCloud on oracle/gs_standin.py (dense
+    O(N H W) rasteriser, "parity unpinned": see oracle/gs_oracle.py)"""
+    import copy
+
+    import gs_standin
+    ref_harness.install()
+    sys.modules['diff_gaussian_rasterization'] = gs_standin.module()
+    _zeros_on_cpu()
+    x = reference_configs()['splaTAM'].xrdslam
+    import slam.common.common as rc
+    rc.GaussianRasterizer = gs_standin.GaussianRasterizer
+    rc.Camera_gs = getattr(rc, 'Camera_gs', None)
+    from slam.common.camera import Camera
+    from slam.common.frame import Frame
+    pose_conversions()
+    room, s = sequence('splatam')
+    n_run = s['run_frames']
+    frames = _frames(room, n_run, cv=True)
+    cam = Camera(s['fx'], s['fy'], s['cx'], s['cy'], s['W'], s['H'])
+    out = _header(s)
+    out['seq/cv_poses'] = np.array(1)
+    cfg0 = copy.deepcopy(x.algorithm)
+
+    def make():
+        return copy.deepcopy(cfg0).setup(camera=cam, device='cpu')
+    return _run_seeds('splaTAM', make, Frame, _cadence(x), out, n_run, frames,
+                      n_total=s['n_frames'],
+                      use_relative_pose=x.tracker.use_relative_pose,
+                      init_pose_offset=x.tracker.init_pose_offset)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1] if len(sys.argv) > 1 else 'coslam'
+    torch.set_num_threads(int(os.environ.get('C1_THREADS', min(16, os.cpu_count() or 1))))
+    res = globals()[which]()
+    if SMOKE_FRAMES:
+        sys.exit(0)
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(_target(), **res)
+    print('wrote', _target())

@@ -655,7 +655,10 @@ class Algorithm:
             optimizers = self.setup_optimizers(n_iters, optimize_frames,
                                                is_mapping, coarse=coarse)
             # multi-GPU: mapping gradients are summed over ranks (engine/dist)
-            optimizers.allreduce = bool(is_mapping)
+            # (an algorithm whose mapping cannot be sharded under its current
+            # options runs it replicated: identical gradients on every rank)
+            optimizers.allreduce = bool(is_mapping) and \
+                not getattr(self, 'replicated_mapping', False)
             track = None
             if not is_mapping:
                 pdev = optimize_frames[-1].get_pose().device

@@ -161,6 +161,19 @@ class SplaTAM(Algorithm):
             total = int(torch.stack(counts).max().item())
         dgr._BIN.reserve(dev, cloud.params['means3D'].shape[0], total)
 
+    @property
+    def replicated_mapping(self):
+        """Only the fused loss applies the own-rows mask, and the 3D-GS
+        densification statistics (means2D gradients) are per-rank partial in
+        band mode: with either option set every rank renders and scores the
+        WHOLE image and the mapping all-reduce is off (replicated mapping:
+        correct, not sharded)"""
+        cfg = self.model.config
+        return not (cfg.mapping_use_l1 and
+                    not cfg.mapping_ignore_outlier_depth_loss and
+                    not cfg.mapping_use_gaussian_splatting_densification and
+                    torch.device(self.device).type == 'cuda')
+
     def _set_band(self, on):
         """multi-GPU mapping: one full frame per iteration ->
         every rank rasterises a band of tile rows (plus the SSIM halo) and
@@ -170,7 +183,8 @@ class SplaTAM(Algorithm):
         from ...compat import diff_gaussian_rasterization as dgr
         from ...engine import dist as xdist
         st = xdist.state
-        if on and st.enabled and st.world > 1:
+        shardable = not self.replicated_mapping
+        if on and st.enabled and st.world > 1 and shardable:
             band = xdist.tile_band(st.rank, st.world, self.camera.height)
             dgr.BAND = band['render_tiles']
             self.model.own_rows = band['own']
