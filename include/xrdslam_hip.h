@@ -671,6 +671,12 @@ int xrd_vox_dw(int64_t n_points, const int32_t* n_points_dev,
  * i32 on the device.  meta[5] = overflow bits (1: a sample row needed more
  * than s_cap slots, 2: more than p_cap points, 4: a sample row with a hole),
  * meta[10] = traversal stack overflow; a caller checks them once per frame.
+ * meta must be ZERO before its first use and stay with its pipeline: beyond
+ * the record it holds the blocks' partial counts.
+ *
+ * xrd_vox_sample_rays is THREE launches (intersection + hit sort; hit-ray
+ * ranks + sampling; point offsets + compaction): the batch-wide prefixes are
+ * sums over per-block partial counts taken by the next launch's blocks.
  *
  * xrd_vox_sample_rays: rays [n_rays,3] (+ target_d [n_rays]) -> hits (octree
  *   traversal when centres != NULL, n_max <= 64 hits a ray; else hit_idx /

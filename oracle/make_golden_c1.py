@@ -199,6 +199,8 @@ def _seed(seed):
 
 
 def _target():
+    if os.environ.get('C1_OUT'):
+        return os.environ['C1_OUT']
     which = sys.argv[1] if len(sys.argv) > 1 else 'coslam'
     return os.path.join(GOLD, f'c1_{which}.npz')
 
@@ -257,8 +259,15 @@ def reference_configs():
     return algorithm_configs
 
 
+ONLY_SEED = os.environ.get('C1_ONLY_SEED')
+
+
 def _run_seeds(name, make_algo, Frame, cad, out, n_run, frames, **loop_kw):
-    for seed in range(N_SEEDS):
+    # every seed in a process of its own (run by main() below): the
+    # reference keeps state between runs of a process (its octree extension's
+    # node tables outlived a model: an index error in the second run)
+    for seed in ([int(ONLY_SEED)] if ONLY_SEED is not None else
+                 range(N_SEEDS)):
         _seed(seed)
         algo = make_algo()
         t0 = time.time()
@@ -449,6 +458,7 @@ def pointslam():
 
     import faiss_standin
     ref_harness.install()
+    faiss_standin.FAST = True      # k-d tree: exact neighbours, fast
     sys.modules['faiss'] = faiss_standin.module()
     _zeros_on_cpu()
     import slam.model_components.neural_point_cloud as npc_mod
@@ -518,8 +528,26 @@ def splatam():
                       init_pose_offset=x.tracker.init_pose_offset)
 
 
+def _per_seed_processes(which):
+    """run every seed in its own process, merge the per-seed files"""
+    import subprocess
+    merged = None
+    for seed in range(N_SEEDS):
+        tmp = os.path.join('/tmp', f'c1_{which}_{seed}.npz')
+        env = dict(os.environ, C1_ONLY_SEED=str(seed), C1_OUT=tmp)
+        subprocess.run([sys.executable, os.path.abspath(__file__), which],
+                       env=env, check=True)
+        g = dict(np.load(tmp))
+        merged = g if merged is None else {**merged, **g}
+        np.savez_compressed(_target(), **merged)   # keep what is done
+    print('wrote', _target())
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'coslam'
+    if ONLY_SEED is None and not SMOKE_FRAMES:
+        _per_seed_processes(which)
+        sys.exit(0)
     torch.set_num_threads(int(os.environ.get('C1_THREADS', min(16, os.cpu_count() or 1))))
     res = globals()[which]()
     if SMOKE_FRAMES:

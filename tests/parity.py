@@ -86,3 +86,14 @@ def row_outliers(a, b, tol=RTOL):
     scale = max(np.abs(b).max(), 1e-30)
     dev = np.abs(a - b).reshape(a.shape[0], -1).max(1) / scale
     return float((dev > tol).mean()), float(dev.max())
+
+
+def row_stats(a, b):
+    """per-row max deviation relative to max|b| -> (mean, median, p99, max,
+    p90)"""
+    a, b = _np(a), _np(b)
+    scale = max(np.abs(b).max(), 1e-30)
+    dev = np.abs(a - b).reshape(a.shape[0], -1).max(1) / scale
+    return (float(dev.mean()), float(np.median(dev)),
+            float(np.percentile(dev, 99)), float(dev.max()),
+            float(np.percentile(dev, 90)))

@@ -326,10 +326,14 @@ def referee(got, ref32, ref64, tol=1e-4):
     """kernel outputs ``got`` judged against the f64 evaluation ``ref64`` of
     the reference (oracle/make_golden_pointslam.py tum64), with the f32
     reference ``ref32``'s own distance to it as the yardstick.  Returns
-    {key: (kernel_vs_f64, ref32_vs_f64[, frac_kernel, frac_ref32, rows])}:
-    max-norm relative deviations; for per-row arrays (ray gradients, point
-    feature gradient rows, per-ray renders) also the share of rows further
-    than ``tol`` of the largest entry from the f64 value."""
+    {key: (kernel_vs_f64, ref32_vs_f64[, frac_kernel, frac_ref32, rows,
+    frac_direct])}: max-norm relative deviations; for per-row arrays (ray
+    gradients, point feature gradient rows, per-ray renders) also the share of
+    rows further than ``tol`` of the largest entry from the f64 value, and
+    ``frac_direct`` = of the rows where the f32 reference AGREES with its f64
+    value (within ``tol``: no kink / radius-cut row of the reference), the
+    share on which the kernel is further than ``tol`` from the f32 golden —
+    the direct kernel-vs-golden comparison where the yardstick is not noisy."""
     out = {}
     for key in sorted(got):
         if key not in ref64.files or key.endswith('valid_ray_mask'):
@@ -341,9 +345,13 @@ def referee(got, ref32, ref64, tol=1e-4):
         if t.ndim >= 1 and t.shape[0] >= 1000:
             da = np.abs(a - t).reshape(t.shape[0], -1).max(1) / scale
             db = np.abs(b - t).reshape(t.shape[0], -1).max(1) / scale
+            dab = np.abs(a - b).reshape(t.shape[0], -1).max(1) / scale
+            agree = db <= tol
             out[key] = (float(da.max()), float(db.max()),
                         float((da > tol).mean()), float((db > tol).mean()),
-                        t.shape[0])
+                        t.shape[0],
+                        float((dab[agree] > tol).mean()) if agree.any()
+                        else 0.0)
         else:
             out[key] = (float(np.abs(a - t).max() / scale),
                         float(np.abs(b - t).max() / scale))

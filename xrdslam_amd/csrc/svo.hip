@@ -15,6 +15,7 @@
 //     LDS and holds only nodes the ray is known to enter, with their slab
 //     depths.
 #include "common.h"
+#include "svo_intersect.h"
 #include "svo_sample.h"
 
 #pragma clang fp contract(off)  // keep the float expressions as written
@@ -22,50 +23,18 @@
 namespace xrd {
 namespace {
 
-constexpr int kStack = 128;   // >= 1 + 7 * levels; 256^3 trees need 57
 constexpr int kRaysPerBlock = 64;
 
-__device__ __forceinline__ void ray_aabb(const float (&o)[3],
-                                         const float (&d)[3], const float* c,
-                                         float half, float& lo, float& hi) {
-  float f_low = 0.f, f_high = 100000.f;
-  lo = hi = -1.f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float inv = 1.0f / d[k];
-    float a = (c[k] - half - o[k]) * inv;
-    float b = (c[k] + half - o[k]) * inv;
-    if (b < a) {
-      const float t = a;
-      a = b;
-      b = t;
-    }
-    if (b < f_low) return;
-    if (a > f_high) return;
-    f_low = (a > f_low) ? a : f_low;
-    f_high = (b < f_high) ? b : f_high;
-    if (f_low > f_high) return;
-  }
-  lo = f_low;
-  hi = f_high;
-}
-
-// One WAVE per ray.  The reference pops a node, tests its box and pushes all
-// of its children; here the 8 children of a popped node are tested at once on
-// lanes 0-7 and only the ones the ray enters are pushed, in child order — the
-// nodes whose boxes are hit are therefore visited in the same LIFO order, and
-// leaves are recorded in the same order with the same (lo, hi), while a ray
-// takes one serial step per HIT internal node instead of one per node looked
-// at (8x fewer dependent loads).
+// One WAVE per ray (body: svo_intersect.h).
 __global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
     int n, int m, float voxelsize, int n_max, int64_t tree_stride,
     const float* __restrict__ ray_start, const float* __restrict__ ray_dir,
     const float* __restrict__ points, const int* __restrict__ children,
     int* __restrict__ idx, float* __restrict__ min_depth,
     float* __restrict__ max_depth, int* __restrict__ overflow) {
-  __shared__ int s_node[4][kStack];
-  __shared__ int s_side[4][kStack];
-  __shared__ float s_lo[4][kStack], s_hi[4][kStack];
+  __shared__ int s_node[4][kSvoStack];
+  __shared__ int s_side[4][kSvoStack];
+  __shared__ float s_lo[4][kSvoStack], s_hi[4][kSvoStack];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.y;
   const int j = blockIdx.x * 4 + wave;
@@ -82,63 +51,17 @@ __global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
   int* I = idx + rbase * n_max;
   float* MN = min_depth + rbase * n_max;
   float* MX = max_depth + rbase * n_max;
-  const float half_voxel = voxelsize * 0.5;
-  int ptr = -1, cnt = 0;
-  {  // root is node 0
-    const int side = C[8];
-    float lo, hi;
-    ray_aabb(o, d, P, half_voxel * (float)side, lo, hi);
-    if (lo > -1.0f) {
-      ptr = 0;
-      if (lane == 0) {
-        s_node[wave][0] = 0;
-        s_side[wave][0] = side;
-        s_lo[wave][0] = lo;
-        s_hi[wave][0] = hi;
-      }
-    }
-  }
-  wave_lds_sync();
-  while (ptr > -1 && cnt < n_max) {
-    const int k = s_node[wave][ptr];
-    const int side = s_side[wave][ptr];
-    if (side == 1) {  // terminal node
-      if (lane == 0) {
-        I[cnt] = k;
-        MN[cnt] = s_lo[wave][ptr];
-        MX[cnt] = s_hi[wave][ptr];
-      }
-      ++cnt;
-      --ptr;
-      continue;
-    }
-    --ptr;
-    int c = -1, cs = 0;
-    float lo = -1.f, hi = -1.f;
-    if (lane < 8) {
-      c = C[k * 9 + lane];
-      if (c > -1) {
-        cs = C[c * 9 + 8];
-        ray_aabb(o, d, P + c * 3, half_voxel * (float)cs, lo, hi);
-      }
-    }
-    const uint64_t mask = __ballot(c > -1 && lo > -1.0f);
-    const int n_push = __popcll(mask);
-    if (ptr + 1 + n_push > kStack) {
-      if (overflow && lane == 0) *overflow = 1;
-      break;
-    }
-    wave_lds_sync();  // every lane has read the popped entry
-    if ((mask >> lane) & 1) {
-      const int at = ptr + 1 + __popcll(mask & ((1ull << lane) - 1));
-      s_node[wave][at] = c;
-      s_side[wave][at] = cs;
-      s_lo[wave][at] = lo;
-      s_hi[wave][at] = hi;
-    }
-    ptr += n_push;
-    wave_lds_sync();
-  }
+  bool ovf;
+  const int cnt = svo_intersect_ray(
+      lane, s_node[wave], s_side[wave], s_lo[wave], s_hi[wave], o, d, P, C,
+      voxelsize, n_max, ovf, [&](int slot, int node, float lo, float hi) {
+        if (lane == 0) {
+          I[slot] = node;
+          MN[slot] = lo;
+          MX[slot] = hi;
+        }
+      });
+  if (ovf && overflow && lane == 0) *overflow = 1;
   for (int l = cnt + lane; l < n_max; l += 64) I[l] = -1;  // unused slots
   (void)n;
 }

@@ -32,6 +32,7 @@
 // Reference behaviour restated, never copied.  Parity: tests/test_vox_rays_hip.py
 // (against the modular path, itself pinned to the reference-made golden).
 #include "common.h"
+#include "svo_intersect.h"
 #include "svo_sample.h"  // also switches fp contraction off for this file
 
 namespace xrd {
@@ -57,114 +58,251 @@ enum Meta {
   M_STICKY_OVF = 11,   // OR of M_OVERFLOW (| 8 for M_STACKOVF)
   M_STICKY_ROW = 12,   // max of M_MAXSTEPS
   M_STICKY_PTS = 13,   // max number of valid samples a launch wanted
-  M_WANT_PTS = 14,     // valid samples before clamping to the capacity
-  M_LEN = 16
+  M_WANT_PTS = 14      // valid samples before clamping to the capacity
 };
 
 constexpr int kWaves = 8;          // rays per block
 constexpr float kPadDepth = 10.f;  // MAX_DEPTH of the padded samples
 constexpr int kGroups = 200;       // G of InverseCDFRaySampling.forward
 
-// Per-ray contributions to the size record go through LDS first: one global
-// atomic per block and counter instead of one per ray (thousands of atomics
-// on ONE address serialise in L2 — measured 35-65 us a kernel at 6144 rays).
-__global__ void vox_meta_reset_kernel(int* meta, double* acc) {
-  if (threadIdx.x == 0) {
-    // the previous launch's record -> sticky slots
+// ---------------------------------------------------------------- ray pipeline
+// intersect -> hit sort -> hit-ray ranks -> sampling -> point offsets ->
+// compaction as THREE launches (round 5; six launches + the reset before:
+// ~11 us of launch / drain each for a few microseconds of work, 77 us x 45
+// iterations a frame).  The steps need three batch-wide results — the number
+// of hit rays and the two maxima the sampler's [200, R, P] regrouping is
+// built from, the compacted list of hit rays (a ray's group reads OTHER rays'
+// hit rows), the point offsets.  A block owns a CONTIGUOUS range of rays and
+// leaves its partial counts in meta[M_PART]; the NEXT launch's blocks each sum
+// the partials they need (a prefix over <= 1024 block counts) and rebuild the
+// compacted hit-ray list in LDS from the hit flags: the two single-block scan
+// launches and the reset launch are gone, and nothing is an atomic on one
+// address.
+// (Tried first: ONE launch whose resident blocks meet at three grid barriers
+// — 121 us: an agent-scope release / acquire per block and barrier writes
+// back / invalidates the XCDs' L2s, and bulk data crosses blocks at every
+// barrier.)  The per-ray arithmetic is the code of the former kernels:
+// bit-identical results (tests/test_vox_rays_hip.py).
+constexpr int kPipeBlocks = 1024;
+enum MetaExt {
+  M_PART = 16,                         // [kPipeBlocks][8] per-block partials
+  M_LEN = M_PART + 8 * kPipeBlocks
+};
+enum Part { PT_HITS = 0, PT_MAXCOL, PT_MAXCEIL, PT_STACK, PT_CNT, PT_SMAX,
+            PT_OVF, PT_WANT };
+
+struct PipeArgs {
+  int n_rays, n_max, s_cap, n_nodes;
+  int64_t p_cap;
+  float voxel_size, max_distance, inv_step, trunc, max_depth;
+  const float *centres, *rays_o, *rays_d, *target_d, *noise;
+  const int* children;
+  const uint8_t* ray_keep;
+  int *hit_idx, *hit, *rank, *hit_rays, *s_idx, *cnt, *offs, *vox, *meta;
+  float *hit_min, *hit_max, *probs, *steps, *s_depth, *xyz;
+  double* loss_acc;
+};
+
+// sum / max of the blocks' partials (slot `what`) over blocks [0, upto) and
+// over all blocks: every wave computes them redundantly (<= 768 values)
+__device__ __forceinline__ void part_sums(const int* __restrict__ part,
+                                          int what, int upto, int lane,
+                                          int& before, int& total) {
+  int b = 0, s = 0;
+  for (int i = lane; i < (int)gridDim.x; i += 64) {
+    const int v = part[i * 8 + what];
+    s += v;
+    if (i < upto) b += v;
+  }
+  before = __reduce_add_sync(0xffffffffffffffffull, b);
+  total = __reduce_add_sync(0xffffffffffffffffull, s);
+}
+__device__ __forceinline__ int part_max(const int* __restrict__ part, int what,
+                                        int lane) {
+  int m = 0;
+  for (int i = lane; i < (int)gridDim.x; i += 64) {
+    const int v = part[i * 8 + what];
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int u = __shfl_xor(m, o);
+    m = u > m ? u : m;
+  }
+  return m;
+}
+__device__ __forceinline__ int part_or(const int* __restrict__ part, int what,
+                                       int lane) {
+  int m = 0;
+  for (int i = lane; i < (int)gridDim.x; i += 64) m |= part[i * 8 + what];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+  return m;
+}
+
+// ---- 1: intersection (or the caller's hits) and the sort by entry depth ------
+__global__ __launch_bounds__(kWaves * 64) void vox_hits_kernel(const PipeArgs A) {
+  // LDS per wave: the DFS stack of the intersection (4 x kSvoStack words) and
+  // the hit row (3 x 64)
+  __shared__ int stack_s[kWaves][4 * kSvoStack];
+  __shared__ int row_s[kWaves][3 * 64];
+  __shared__ int red[8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* const meta = A.meta;
+  int* const part = meta + M_PART;
+  const int n_rays = A.n_rays, n_max = A.n_max, s_cap = A.s_cap;
+  // contiguous rays of this block (multiples of the 8 waves); the three
+  // launches use the same grid
+  const int rpb = ((n_rays + (int)gridDim.x - 1) / (int)gridDim.x + kWaves - 1) /
+                  kWaves * kWaves;
+  const int r_lo = blockIdx.x * rpb;
+  const int r_hi = r_lo + rpb < n_rays ? r_lo + rpb : n_rays;
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+  __syncthreads();
+  int* s_node = stack_s[wave];
+  int* s_side = s_node + kSvoStack;
+  float* s_lo = reinterpret_cast<float*>(s_side + kSvoStack);
+  float* s_hi = s_lo + kSvoStack;
+  int* s_id = row_s[wave];
+  float* s_a = reinterpret_cast<float*>(s_id + 64);
+  float* s_b = s_a + 64;
+  for (int ray = r_lo + wave; ray < r_hi; ray += kWaves) {
+    const int64_t row = (int64_t)ray * n_max;
+    int id = -1;
+    float a = 0.f, b = 0.f;
+    if (A.centres != nullptr) {
+      const float o[3] = {A.rays_o[ray * 3], A.rays_o[ray * 3 + 1],
+                          A.rays_o[ray * 3 + 2]};
+      const float d[3] = {A.rays_d[ray * 3], A.rays_d[ray * 3 + 1],
+                          A.rays_d[ray * 3 + 2]};
+      bool ovf;
+      const int cnt = svo_intersect_ray(
+          lane, s_node, s_side, s_lo, s_hi, o, d, A.centres, A.children,
+          A.voxel_size, n_max, ovf, [&](int slot, int node, float lo, float hi) {
+            if (lane == slot) {
+              id = node;
+              a = lo;
+              b = hi;
+            }
+          });
+      if (ovf && lane == 0) atomicOr(&red[PT_STACK], 1);
+      if (lane >= cnt) id = -1;
+    } else if (lane < n_max) {
+      id = A.hit_idx[row + lane];
+      a = A.hit_min[row + lane];
+      b = A.hit_max[row + lane];
+    }
+    const bool in = lane < n_max;
+    if (id == -1) a = b = A.max_distance;
+    // stable rank by entry depth
+    int rank = 0;
+    for (int j = 0; j < n_max; ++j) {
+      const float aj = __shfl(a, j);
+      rank += (aj < a || (aj == a && j < lane)) ? 1 : 0;
+    }
+    if (in) {
+      s_id[rank] = id;
+      s_a[rank] = a;
+      s_b[rank] = b;
+    }
+    wave_lds_sync();
+    if (in) {
+      id = s_id[lane];
+      a = s_a[lane];
+      b = s_b[lane];
+      if (a > A.max_distance) id = -1;
+      if (id == -1) a = b = A.max_distance;
+    }
+    wave_lds_sync();
+    const int count = __popcll(__ballot(in && id != -1));
+    const float len = (in && id != -1) ? b - a : 0.f;
+    if (in) s_a[lane] = len;
+    wave_lds_sync();
+    float sum = 0.f;
+    for (int j = 0; j < n_max; ++j) sum = sum + s_a[j];
+    if (in) {
+      A.hit_idx[row + lane] = id;
+      A.hit_min[row + lane] = a;
+      A.hit_max[row + lane] = b;
+      A.probs[row + lane] = len / sum;
+    }
+    wave_lds_sync();
+    if (lane == 0) {
+      // torch divides by a python scalar as a multiplication with its reciprocal
+      const float st = sum * A.inv_step;
+      A.steps[ray] = st;
+      A.hit[ray] = count > 0 ? 1 : 0;
+      if (count > 0) {
+        atomicAdd(&red[PT_HITS], 1);
+        atomicMax(&red[PT_MAXCOL], count);
+        atomicMax(&red[PT_MAXCEIL], (int)ceilf(st));
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) part[blockIdx.x * 8 + threadIdx.x] = red[threadIdx.x];
+}
+
+// ---- 2: the batch's size record, hit-ray ranks, sampling ------------------------
+__global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(const PipeArgs A) {
+  // dynamic LDS: the compacted hit-ray list [n_rays], then per wave the
+  // cumulative probabilities (64) and the sample row (2 x s_cap)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int red[8];
+  __shared__ int wsum[kWaves];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* const meta = A.meta;
+  int* const part = meta + M_PART;
+  const int n_rays = A.n_rays, n_max = A.n_max, s_cap = A.s_cap;
+  // contiguous rays of this block (multiples of the 8 waves); the three
+  // launches use the same grid
+  const int rpb = ((n_rays + (int)gridDim.x - 1) / (int)gridDim.x + kWaves - 1) /
+                  kWaves * kWaves;
+  const int r_lo = blockIdx.x * rpb;
+  const int r_hi = r_lo + rpb < n_rays ? r_lo + rpb : n_rays;
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+  __syncthreads();
+  int* hit_rays_s = reinterpret_cast<int*>(smem_raw);
+  int* wbase = hit_rays_s + (n_rays + 3) / 4 * 4 + wave * (64 + 2 * s_cap);
+  float* cum_s = reinterpret_cast<float*>(wbase);
+  int* LI = wbase + 64;
+  float* LD = reinterpret_cast<float*>(LI + s_cap);
+  // ---- 2: the batch's size record, hit-ray ranks ---------------------------
+  int hits_before, n_hit_rays;
+  part_sums(part, PT_HITS, blockIdx.x, lane, hits_before, n_hit_rays);
+  (void)hits_before;
+  const int P = part_max(part, PT_MAXCOL, lane);
+  const int max_ceil = part_max(part, PT_MAXCEIL, lane);
+  const int stack_ovf = part_or(part, PT_STACK, lane);
+  const int max_steps_all = max_ceil + P;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the previous launch's record -> sticky slots, then this launch's
     meta[M_STICKY_OVF] |= meta[M_OVERFLOW] | (meta[M_STACKOVF] ? 8 : 0);
     if (meta[M_MAXSTEPS] > meta[M_STICKY_ROW])
       meta[M_STICKY_ROW] = meta[M_MAXSTEPS];
     if (meta[M_WANT_PTS] > meta[M_STICKY_PTS])
       meta[M_STICKY_PTS] = meta[M_WANT_PTS];
+    for (int i = 0; i < M_STICKY_OVF; ++i) meta[i] = 0;
+    meta[M_WANT_PTS] = 0;
+    meta[15] = 0;
+    meta[M_NHITCOL] = P;
+    meta[M_NHITRAYS] = n_hit_rays;
+    meta[M_MAXCEIL] = max_ceil;
+    meta[M_MAXSTEPS] = max_steps_all;
+    meta[M_STACKOVF] = stack_ovf;
+    for (int i = 0; i < 4; ++i) A.loss_acc[i] = 0.0;
   }
-  __syncthreads();
-  if (threadIdx.x < M_LEN &&
-      (threadIdx.x < M_STICKY_OVF || threadIdx.x > M_STICKY_PTS))
-    meta[threadIdx.x] = 0;
-  if (threadIdx.x < 4) acc[threadIdx.x] = 0.0;
-}
-
-// ---------------------------------------------------------------- hit sort
-// in place on idx / min_depth / max_depth [N, n_max]; probs [N, n_max],
-// steps [N], hit [N]
-__global__ __launch_bounds__(kWaves * 64) void vox_hit_sort_kernel(
-    int n_rays, int n_max, float max_distance, float inv_step,
-    int* __restrict__ idx, float* __restrict__ mn, float* __restrict__ mx,
-    float* __restrict__ probs, float* __restrict__ steps,
-    int* __restrict__ hit, int* __restrict__ meta) {
-  __shared__ int s_id[kWaves][64];
-  __shared__ float s_a[kWaves][64], s_b[kWaves][64];
-  __shared__ int red[2];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * kWaves + wave;
-  if (threadIdx.x < 2) red[threadIdx.x] = 0;
-  __syncthreads();
-  const bool live = ray < n_rays;
-  const int64_t row = (int64_t)(live ? ray : 0) * n_max;
-  const bool in = live && lane < n_max;
-  int id = in ? idx[row + lane] : -1;
-  float a = in ? mn[row + lane] : 0.f, b = in ? mx[row + lane] : 0.f;
-  if (id == -1) a = b = max_distance;
-  // stable rank by entry depth
-  int rank = 0;
-  for (int j = 0; j < n_max; ++j) {
-    const float aj = __shfl(a, j);
-    rank += (aj < a || (aj == a && j < lane)) ? 1 : 0;
-  }
-  if (in) {
-    s_id[wave][rank] = id;
-    s_a[wave][rank] = a;
-    s_b[wave][rank] = b;
-  }
-  wave_lds_sync();
-  if (in) {
-    id = s_id[wave][lane];
-    a = s_a[wave][lane];
-    b = s_b[wave][lane];
-    if (a > max_distance) id = -1;
-    if (id == -1) a = b = max_distance;
-  }
-  wave_lds_sync();
-  const int count = __popcll(__ballot(in && id != -1));
-  const float len = (in && id != -1) ? b - a : 0.f;
-  if (in) s_a[wave][lane] = len;
-  wave_lds_sync();
-  float sum = 0.f;
-  for (int j = 0; j < n_max; ++j) sum = sum + s_a[wave][j];
-  if (in) {
-    idx[row + lane] = id;
-    mn[row + lane] = a;
-    mx[row + lane] = b;
-    probs[row + lane] = len / sum;
-  }
-  if (live && lane == 0) {
-    // torch divides by a python scalar as a multiplication with its reciprocal
-    const float st = sum * inv_step;
-    steps[ray] = st;
-    hit[ray] = count > 0 ? 1 : 0;
-    if (count > 0) {
-      atomicMax(&red[0], count);
-      atomicMax(&red[1], (int)ceilf(st));
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && red[0] > 0) atomicMax(meta + M_NHITCOL, red[0]);
-  if (threadIdx.x == 1 && red[1] > 0) atomicMax(meta + M_MAXCEIL, red[1]);
-}
-
-// exclusive scan of v[0..n) by ONE block of 1024 threads; out[n] = total
-template <class Load>
-__device__ __forceinline__ int block_scan_1024(int n, Load load,
-                                               int* __restrict__ out) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n ? load(i) : 0;
-    int inc = v;
+  // the compacted list of hit rays, rebuilt by EVERY block in LDS (a ray's
+  // group reads other rays' rows): thread t scans a contiguous slice of the
+  // hit flags, the block scans the slices' counts.  Ranks and the global list
+  // are written by the block that owns the ray.
+  {
+    const int per = (n_rays + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int i0 = threadIdx.x * per < n_rays ? threadIdx.x * per : n_rays;
+    const int i1 = i0 + per < n_rays ? i0 + per : n_rays;
+    int c = 0;
+    for (int i = i0; i < i1; ++i) c += A.hit[i] != 0;
+    int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int u = __shfl_up(inc, o);
@@ -172,63 +310,32 @@ __device__ __forceinline__ int block_scan_1024(int n, Load load,
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    const int carry = carry_s;
-    if (i < n) out[i] = carry + woff + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-    __syncthreads();
+    int at = inc - c;
+    for (int w = 0; w < wave; ++w) at += wsum[w];
+    for (int i = i0; i < i1; ++i) {
+      const bool h = A.hit[i] != 0;
+      if (i >= r_lo && i < r_hi) {
+        A.rank[i] = at;
+        if (h) A.hit_rays[at] = i;
+      }
+      if (h) hit_rays_s[at++] = i;
+    }
   }
-  return carry_s;
-}
-
-__global__ __launch_bounds__(1024) void vox_ray_scan_kernel(
-    int n_rays, const int* __restrict__ hit, int* __restrict__ rank,
-    int* __restrict__ hit_rays, int* __restrict__ meta) {
-  const int total = block_scan_1024(
-      n_rays, [&](int i) { return hit[i]; }, rank);
-  for (int i = threadIdx.x; i < n_rays; i += 1024)
-    if (hit[i]) hit_rays[rank[i]] = i;
-  if (threadIdx.x == 0) {
-    meta[M_NHITRAYS] = total;
-    meta[M_MAXSTEPS] = meta[M_MAXCEIL] + meta[M_NHITCOL];
-  }
-}
-
-// ---------------------------------------------------------------- sampling
-__global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
-    int n_rays, int n_max, int s_cap, const int* __restrict__ idx,
-    const float* __restrict__ mn, const float* __restrict__ mx,
-    const float* __restrict__ probs, const float* __restrict__ steps,
-    const float* __restrict__ noise, const int* __restrict__ hit,
-    const int* __restrict__ rank, const int* __restrict__ hit_rays,
-    int* __restrict__ meta, int* __restrict__ s_idx,
-    float* __restrict__ s_depth, int* __restrict__ cnt) {
-  // the ray's sample row is assembled in LDS (scattered slot writes, then
-  // the count) and written out once, coalesced
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ float cum_s[kWaves][64];
-  __shared__ int red[2];   // longest row, overflow bits
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * kWaves + wave;
-  int* LI = reinterpret_cast<int*>(smem_raw) + wave * s_cap;
-  float* LD = reinterpret_cast<float*>(smem_raw) + (kWaves + wave) * s_cap;
-  if (threadIdx.x < 2) red[threadIdx.x] = 0;
   __syncthreads();
-  const bool live = ray < n_rays;
-  const bool work = live && hit[ray] != 0;
-  if (live && !work && lane == 0) cnt[ray] = 0;
-  if (work) {
-    const int n_hit_rays = meta[M_NHITRAYS];
-    const int P = meta[M_NHITCOL];
+  // ---- 3: sampling -------------------------------------------------------------
+  for (int ray = r_lo + wave; ray < r_hi; ray += kWaves) {
+    const bool work = A.hit[ray] != 0;
+    if (!work) {
+      if (lane == 0) A.cnt[ray] = 0;
+      continue;
+    }
     const int R = (n_hit_rays + kGroups - 1) / kGroups;  // rays per group
-    const int r = rank[ray];
+    const int r = A.rank[ray];
     const int g = r / R, j = r - g * R;
     const int H = j * P;
-    int max_steps = meta[M_MAXSTEPS];
+    int max_steps = max_steps_all;
     if (max_steps > s_cap) {
-      if (lane == 0) atomicOr(&red[1], 1);
+      if (lane == 0) atomicOr(&red[PT_OVF], 1);
       max_steps = s_cap;
     }
     for (int s = lane; s < max_steps; s += 64) {
@@ -236,13 +343,13 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
       LD[s] = kPadDepth;
     }
     wave_lds_sync();
-    const int* own = idx + (int64_t)ray * n_max;
+    const int* own = A.hit_idx + (int64_t)ray * n_max;
     const int64_t goff = (int64_t)g * R * P, total = (int64_t)kGroups * R * P;
-    const float* UN = noise ? noise + (int64_t)ray * s_cap : nullptr;
+    const float* UN = A.noise ? A.noise + (int64_t)ray * s_cap : nullptr;
     inverse_cdf_ray(
-        lane, cum_s[wave], P, R, H, mn + (int64_t)ray * n_max,
-        mx + (int64_t)ray * n_max, probs + (int64_t)ray * n_max, steps[ray],
-        -1.f,
+        lane, cum_s, P, R, H, A.hit_min + (int64_t)ray * n_max,
+        A.hit_max + (int64_t)ray * n_max, A.probs + (int64_t)ray * n_max,
+        A.steps[ray], -1.f,
         [&](int i) -> int {
           // flat index i of the group's [R, P] hit array
           if (i >= H && i < H + P) return own[i - H];
@@ -250,8 +357,8 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
           const int rr = i / P, col = i - rr * P;
           // rows past the last hit ray are copies of the first one
           const int q = g * R + rr;
-          const int src = hit_rays[q < n_hit_rays ? q : 0];
-          return idx[(int64_t)src * n_max + col];
+          const int src = hit_rays_s[q < n_hit_rays ? q : 0];
+          return A.hit_idx[(int64_t)src * n_max + col];
         },
         [&](int c) -> float {
           if (UN == nullptr || c >= s_cap) return 0.5f;
@@ -266,8 +373,8 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
     wave_lds_sync();
     // valid samples of the row (they form a prefix; anything else is
     // reported); padded samples carry depth = MAX_DEPTH (ray_sample :709-711)
-    int* SI = s_idx + (int64_t)ray * s_cap;
-    float* SD = s_depth + (int64_t)ray * s_cap;
+    int* SI = A.s_idx + (int64_t)ray * s_cap;
+    float* SD = A.s_depth + (int64_t)ray * s_cap;
     int count = 0, last = -1;
     for (int s0 = 0; s0 < max_steps; s0 += 64) {
       const int s = s0 + lane;
@@ -280,91 +387,112 @@ __global__ __launch_bounds__(kWaves * 64) void vox_sample_kernel(
         SD[s] = id == -1 ? kPadDepth : LD[s];
       }
     }
+    wave_lds_sync();
     if (lane == 0) {
-      cnt[ray] = count;
-      atomicMax(&red[0], count);
-      if (last + 1 != count) atomicOr(&red[1], 4);
+      A.cnt[ray] = count;
+      atomicMax(&red[PT_SMAX], count);
+      if (last + 1 != count) atomicOr(&red[PT_OVF], 4);
+      // (sharded mapping: rays of other ranks are sampled — they shape the
+      // regrouping and the size record — but get no points)
+      if (A.ray_keep == nullptr || A.ray_keep[ray]) atomicAdd(&red[PT_CNT], count);
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && red[0] > 0) atomicMax(meta + M_SMAX, red[0]);
-  if (threadIdx.x == 1 && red[1] != 0) atomicOr(meta + M_OVERFLOW, red[1]);
+  if (threadIdx.x >= 4 && threadIdx.x < 8)
+    part[blockIdx.x * 8 + threadIdx.x] = red[threadIdx.x];
 }
 
-__global__ __launch_bounds__(1024) void vox_point_scan_kernel(
-    int n_rays, int64_t p_cap, const int* __restrict__ cnt,
-    const uint8_t* __restrict__ ray_keep, int* __restrict__ offs,
-    int* __restrict__ meta) {
-  // (sharded mapping: rays of other ranks are sampled — they shape the
-  // regrouping and the size record — but get no points here)
-  const int total = block_scan_1024(
-      n_rays,
-      [&](int i) { return ray_keep != nullptr && !ray_keep[i] ? 0 : cnt[i]; },
-      offs);
-  if (threadIdx.x == 0) {
-    offs[n_rays] = total;
-    if ((int64_t)total > p_cap) atomicOr(meta + M_OVERFLOW, 2);
-    meta[M_NPTS] = (int64_t)total > p_cap ? (int)p_cap : total;
-    meta[M_WANT_PTS] = total;
-  }
-}
-
-// xyz / voxel id of every valid sample + the sample counts of the loss weights
-__global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(
-    int n_rays, int s_cap, int64_t p_cap, float trunc, float max_depth,
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-    const float* __restrict__ target_d, int* __restrict__ hit,
-    int* __restrict__ cnt, const int* __restrict__ offs,
-    const uint8_t* __restrict__ ray_keep,
-    const int* __restrict__ s_idx, const float* __restrict__ s_depth,
-    float* __restrict__ xyz, int* __restrict__ vox, int* __restrict__ meta) {
-  __shared__ int red[3];   // front, band, usable-depth counts
+// ---- 3: point offsets, compaction, the loss weights' sample counts -----------
+__global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(const PipeArgs A) {
+  __shared__ int red[8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * kWaves + wave;
-  if (threadIdx.x < 3) red[threadIdx.x] = 0;
+  int* const meta = A.meta;
+  int* const part = meta + M_PART;
+  const int n_rays = A.n_rays, n_max = A.n_max, s_cap = A.s_cap;
+  // contiguous rays of this block (multiples of the 8 waves); the three
+  // launches use the same grid
+  const int rpb = ((n_rays + (int)gridDim.x - 1) / (int)gridDim.x + kWaves - 1) /
+                  kWaves * kWaves;
+  const int r_lo = blockIdx.x * rpb;
+  const int r_hi = r_lo + rpb < n_rays ? r_lo + rpb : n_rays;
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
   __syncthreads();
-  if (ray < n_rays && hit[ray]) {
-  // a ray of another rank's shard counts towards the batch-global sample
-  // counts below (they are the loss normalisers) but leaves no points and is
-  // a ray without a hit for everything after this kernel
-  const bool keep = ray_keep == nullptr || ray_keep[ray] != 0;
-  const int s_max = meta[M_SMAX] < s_cap ? meta[M_SMAX] : s_cap;
-  const int n = cnt[ray];
-  const int64_t p0 = offs[ray];
-  const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1],
-                      rays_o[ray * 3 + 2]};
-  const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1],
-                      rays_d[ray * 3 + 2]};
-  const float td = target_d[ray];
-  const float lo = td - trunc, hi = td + trunc;
-  int n_front = 0, n_mid = 0;
-  for (int s0 = 0; s0 < s_max; s0 += 64) {
-    const int s = s0 + lane;
-    const bool in = s < s_max;
-    const bool valid = s < n;
-    const float z = valid ? s_depth[(int64_t)ray * s_cap + s] : kPadDepth;
-    if (keep && valid && p0 + s < p_cap) {
-      const int64_t p = p0 + s;
+  // ---- 4: point offsets, compaction -------------------------------------------
+  int pts_before, pts_total;
+  part_sums(part, PT_CNT, blockIdx.x, lane, pts_before, pts_total);
+  const int s_longest = part_max(part, PT_SMAX, lane);
+  const int ovf_bits = part_or(part, PT_OVF, lane);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.offs[n_rays] = pts_total;
+    meta[M_SMAX] = s_longest;
+    meta[M_OVERFLOW] = ovf_bits | ((int64_t)pts_total > A.p_cap ? 2 : 0);
+    meta[M_NPTS] = (int64_t)pts_total > A.p_cap ? (int)A.p_cap : pts_total;
+    meta[M_WANT_PTS] = pts_total;
+  }
+  if (wave == 0) {   // exclusive offsets of this block's rays, in ray order
+    int base = pts_before;
+    for (int r0 = r_lo; r0 < r_hi; r0 += 64) {
+      const int ray = r0 + lane;
+      int v = 0;
+      if (ray < r_hi && (A.ray_keep == nullptr || A.ray_keep[ray]))
+        v = A.cnt[ray];
+      int inc = v;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) xyz[p * 3 + k] = o[k] + d[k] * z;
-      vox[p] = s_idx[(int64_t)ray * s_cap + s];
-    }
-    const bool front = in && z < lo;
-    const bool back = in && z > hi;
-    n_front += __popcll(__ballot(front));
-    n_mid += __popcll(__ballot(in && !front && !back && td > 0.f));
-  }
-  if (lane == 0) {
-    if (n_front) atomicAdd(&red[0], n_front);
-    if (n_mid) atomicAdd(&red[1], n_mid);
-    if (td > 0.01f && td < max_depth) atomicAdd(&red[2], 1);
-    if (!keep) {
-      cnt[ray] = 0;
-      hit[ray] = 0;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+      }
+      if (ray < r_hi) A.offs[ray] = base + inc - v;
+      base += __shfl(inc, 63);
     }
   }
+  if (threadIdx.x < 8) red[threadIdx.x] = 0;
+  __syncthreads();   // (offs of this block's rays are written; LDS counters)
+  __threadfence_block();
+  for (int ray = r_lo + wave; ray < r_hi; ray += kWaves) {
+    if (!A.hit[ray]) continue;
+    // a ray of another rank's shard counts towards the batch-global sample
+    // counts below (they are the loss normalisers) but leaves no points and
+    // is a ray without a hit for everything after this kernel
+    const bool keep = A.ray_keep == nullptr || A.ray_keep[ray] != 0;
+    const int s_max = s_longest < s_cap ? s_longest : s_cap;
+    const int n = A.cnt[ray];
+    const int64_t p0 = A.offs[ray];
+    const float o[3] = {A.rays_o[ray * 3], A.rays_o[ray * 3 + 1],
+                        A.rays_o[ray * 3 + 2]};
+    const float d[3] = {A.rays_d[ray * 3], A.rays_d[ray * 3 + 1],
+                        A.rays_d[ray * 3 + 2]};
+    const float td = A.target_d[ray];
+    const float lo = td - A.trunc, hi = td + A.trunc;
+    int n_front = 0, n_mid = 0;
+    for (int s0 = 0; s0 < s_max; s0 += 64) {
+      const int s = s0 + lane;
+      const bool in = s < s_max;
+      const bool valid = s < n;
+      const float z = valid ? A.s_depth[(int64_t)ray * s_cap + s] : kPadDepth;
+      if (keep && valid && p0 + s < A.p_cap) {
+        const int64_t p = p0 + s;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) A.xyz[p * 3 + k] = o[k] + d[k] * z;
+        A.vox[p] = A.s_idx[(int64_t)ray * s_cap + s];
+      }
+      const bool front = in && z < lo;
+      const bool back = in && z > hi;
+      n_front += __popcll(__ballot(front));
+      n_mid += __popcll(__ballot(in && !front && !back && td > 0.f));
+    }
+    if (lane == 0) {
+      if (n_front) atomicAdd(&red[0], n_front);
+      if (n_mid) atomicAdd(&red[1], n_mid);
+      if (td > 0.01f && td < A.max_depth) atomicAdd(&red[2], 1);
+      if (!keep) {
+        A.cnt[ray] = 0;
+        A.hit[ray] = 0;
+      }
+    }
   }
   __syncthreads();
+  // (block 0 zeroed the counters before barrier 1: these adds come after it)
   if (threadIdx.x < 3 && red[threadIdx.x] != 0)
     atomicAdd(meta + M_NFRONT + threadIdx.x, red[threadIdx.x]);
 }
@@ -729,35 +857,40 @@ int xrd_vox_sample_rays_shard(
   if (s_cap > 1024) return XRD_ERR_UNSUPPORTED;  // sample rows live in LDS
   if (!meta || !loss_acc) return XRD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(vox_meta_reset_kernel, dim3(1), dim3(64), 0, st, meta,
-                     loss_acc);
-  if (n_rays == 0) return check_launch("xrd_vox_sample_rays");
-  if (!rays_o || !rays_d || !target_d || !hit_idx || !hit_min || !hit_max ||
-      !probs || !steps || !hit || !rank || !hit_rays || !s_idx || !s_depth ||
-      !cnt || !offs || !xyz || !vox)
+  if (n_rays > 0 &&
+      (!rays_o || !rays_d || !target_d || !hit_idx || !hit_min || !hit_max ||
+       !probs || !steps || !hit || !rank || !hit_rays || !s_idx || !s_depth ||
+       !cnt || !offs || !xyz || !vox))
     return XRD_ERR_ARG;
-  if (centres != nullptr) {  // NULL: hit_idx / hit_min / hit_max are given
-    const int rc = xrd_svo_intersect(1, n_nodes, n_rays, voxel_size, n_max, 1,
-                                     rays_o, rays_d, centres, children,
-                                     hit_idx, hit_min, hit_max,
-                                     meta + M_STACKOVF, stream);
-    if (rc != XRD_OK) return rc;
+  if (centres != nullptr && (n_nodes < 1 || !children)) return XRD_ERR_ARG;
+  PipeArgs A;
+  A.n_rays = n_rays; A.n_max = n_max; A.s_cap = s_cap; A.n_nodes = n_nodes;
+  A.p_cap = p_cap; A.voxel_size = voxel_size; A.max_distance = max_distance;
+  A.inv_step = 1.0f / step_size; A.trunc = trunc; A.max_depth = max_depth;
+  A.centres = centres; A.rays_o = rays_o; A.rays_d = rays_d;
+  A.target_d = target_d; A.noise = noise; A.children = children;
+  A.ray_keep = ray_keep; A.hit_idx = hit_idx; A.hit = hit; A.rank = rank;
+  A.hit_rays = hit_rays; A.s_idx = s_idx; A.cnt = cnt; A.offs = offs;
+  A.vox = vox; A.meta = meta; A.hit_min = hit_min; A.hit_max = hit_max;
+  A.probs = probs; A.steps = steps; A.s_depth = s_depth; A.xyz = xyz;
+  A.loss_acc = loss_acc;
+  const size_t lds =
+      ((size_t)(n_rays + 3) / 4 * 4 + (size_t)kWaves * (64 + 2 * s_cap)) * 4;
+  if (lds > 150 * 1024) return XRD_ERR_UNSUPPORTED;   // > ~30 k rays a batch
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vox_sample_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    lds_set = lds;
   }
-  const dim3 grid((n_rays + kWaves - 1) / kWaves), block(kWaves * 64);
-  hipLaunchKernelGGL(vox_hit_sort_kernel, grid, block, 0, st, n_rays, n_max,
-                     max_distance, 1.0f / step_size, hit_idx, hit_min, hit_max,
-                     probs, steps, hit, meta);
-  hipLaunchKernelGGL(vox_ray_scan_kernel, dim3(1), dim3(1024), 0, st, n_rays,
-                     hit, rank, hit_rays, meta);
-  hipLaunchKernelGGL(vox_sample_kernel, grid, block,
-                     (size_t)kWaves * s_cap * 8, st, n_rays, n_max,
-                     s_cap, hit_idx, hit_min, hit_max, probs, steps, noise,
-                     hit, rank, hit_rays, meta, s_idx, s_depth, cnt);
-  hipLaunchKernelGGL(vox_point_scan_kernel, dim3(1), dim3(1024), 0, st,
-                     n_rays, p_cap, cnt, ray_keep, offs, meta);
-  hipLaunchKernelGGL(vox_compact_kernel, grid, block, 0, st, n_rays, s_cap,
-                     p_cap, trunc, max_depth, rays_o, rays_d, target_d, hit,
-                     cnt, offs, ray_keep, s_idx, s_depth, xyz, vox, meta);
+  int nb = (n_rays + kWaves - 1) / kWaves;
+  nb = nb < 1 ? 1 : nb > kPipeBlocks ? kPipeBlocks : nb;
+  const dim3 grid(nb), block(kWaves * 64);
+  hipLaunchKernelGGL(vox_hits_kernel, grid, block, 0, st, A);
+  hipLaunchKernelGGL(vox_sample_kernel, grid, block, lds, st, A);
+  hipLaunchKernelGGL(vox_compact_kernel, grid, block, 0, st, A);
   return check_launch("xrd_vox_sample_rays");
 }
 
