@@ -1168,12 +1168,16 @@ def _ingest_files_leg(cfg, cam, dev, cad, n_timed=30, n_warm=5):
 
 def nice_side_run(args, dev, seed, host_pose):
     """one more NICE-SLAM run of the headline workload (own model, own seed):
-    -> frames/s and ATE.  host_pose=True: the contract of the reference's
-    Tracker — pose parameters are CPU tensors (slam/common/frame.py:33-38), the
-    next frame's initial pose is predicted in numpy from host copies of the
-    last two estimates (slam/pipeline/tracker.py:185-199) — i.e. what ds-run
-    would see with this engine under its own Tracker; the headline keeps the
-    pose chain on the device (SequentialSLAM(pose_device='cuda'))."""
+    -> frames/s and ATE.  host_pose=True: the per-frame contract of the
+    reference's Tracker — the tracking result is read back to the host as a
+    numpy matrix every frame and the next frame's initial pose is predicted in
+    numpy from host copies of the last two estimates
+    (slam/pipeline/tracker.py:107-112,185-199): one device->host sync a frame,
+    i.e. what ds-run would see with this engine under its own Tracker.  (The
+    Frame's pose PARAMETERS stay device tensors: the captured iterations read
+    them; the reference's CPU shared-memory parameters, frame.py:33-38, would
+    be one more 28-byte upload per frame.)  The headline keeps the whole pose
+    chain on the device (SequentialSLAM(device_poses=True))."""
     from xrdslam_amd.data.synthetic import SyntheticRoom
     from xrdslam_amd.slam.common.camera import Camera
     from xrdslam_amd.slam.configs.input_config import (cadence,
@@ -1200,7 +1204,7 @@ def nice_side_run(args, dev, seed, host_pose):
     cad = cadence['nice-slam']
     slam = SequentialSLAM(algo, data, map_every=cad.map_every,
                           keyframe_every=cad.keyframe_every,
-                          pose_device='cpu' if host_pose else str(dev),
+                          pose_device=str(dev),
                           device_poses=False if host_pose else None)
     for k in range(1 + args.warmup):
         slam.step(k)
@@ -1574,10 +1578,10 @@ def main():
                 host = nice_side_run(args, dev, 0, True)
                 out['config']['fps_host_pose_contract'] = host['fps']
                 out['config']['host_pose_contract'] = dict(
-                    host, what='same workload with pose parameters on the '
-                    'host and the numpy constant-velocity prediction of the '
-                    'reference Tracker (tracker.py:185-199, frame.py:33-38): '
-                    'the rate ds-run would see')
+                    host, what='same workload with the tracking result read '
+                    'back to the host every frame and the numpy constant-'
+                    'velocity prediction of the reference Tracker '
+                    '(tracker.py:107-112,185-199): the rate ds-run would see')
             except Exception as e:
                 out['config']['side_runs_error'] = \
                     f'{type(e).__name__}: {str(e)[:200]}'

@@ -6,6 +6,11 @@
 // kernels per convolution at 3x480x640); here one launch computes the five
 // windowed moments from an LDS tile and the SSIM value, and keeps the three
 // partial derivatives the backward needs; one more launch blurs them back.
+// The window is an outer product: a block filters its tile's rows once
+// (26 x 16 row sums per quantity, kept in LDS) and every pixel then sums 11
+// of them down its column — 22 instead of 121 taps a pixel and quantity, in
+// the SAME association (row sums first, then the column) as the direct form,
+// so the maps are bit-identical to round 4's.
 #include "common.h"
 
 namespace xrd {
@@ -31,6 +36,7 @@ __global__ __launch_bounds__(kT* kT) void ssim_fwd_kernel(
     float* __restrict__ d_mu1, float* __restrict__ d_e11,
     float* __restrict__ d_e12) {
   __shared__ float s1[kE][kE + 1], s2[kE][kE + 1];
+  __shared__ float hs[5][kE][kT + 1];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const float* a = img1 + plane;
   const float* b = img2 + plane;
@@ -41,16 +47,14 @@ __global__ __launch_bounds__(kT* kT) void ssim_fwd_kernel(
     s2[ty][tx] = load0(b, H, W, y0 + ty, x0 + tx);
   }
   __syncthreads();
-  const int x = blockIdx.x * kT + threadIdx.x, y = blockIdx.y * kT + threadIdx.y;
-  if (x >= W || y >= H) return;
-  float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-  for (int dy = 0; dy < 11; ++dy) {
+  // row sums of the five quantities for the tile's 26 rows x 16 columns
+  for (int i = threadIdx.y * kT + threadIdx.x; i < kE * kT; i += kT * kT) {
+    const int ty = i / kT, tx = i - ty * kT;
     float r1 = 0.f, r2 = 0.f, r11 = 0.f, r22 = 0.f, r12 = 0.f;
 #pragma unroll
     for (int dx = 0; dx < 11; ++dx) {
-      const float u = s1[threadIdx.y + dy][threadIdx.x + dx];
-      const float v = s2[threadIdx.y + dy][threadIdx.x + dx];
+      const float u = s1[ty][tx + dx];
+      const float v = s2[ty][tx + dx];
       const float w = win.g[dx];
       r1 = fmaf(w, u, r1);
       r2 = fmaf(w, v, r2);
@@ -58,12 +62,24 @@ __global__ __launch_bounds__(kT* kT) void ssim_fwd_kernel(
       r22 = fmaf(w, v * v, r22);
       r12 = fmaf(w, u * v, r12);
     }
+    hs[0][ty][tx] = r1;
+    hs[1][ty][tx] = r2;
+    hs[2][ty][tx] = r11;
+    hs[3][ty][tx] = r22;
+    hs[4][ty][tx] = r12;
+  }
+  __syncthreads();
+  const int x = blockIdx.x * kT + threadIdx.x, y = blockIdx.y * kT + threadIdx.y;
+  if (x >= W || y >= H) return;
+  float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 11; ++dy) {
     const float wy = win.g[dy];
-    mu1 = fmaf(wy, r1, mu1);
-    mu2 = fmaf(wy, r2, mu2);
-    e11 = fmaf(wy, r11, e11);
-    e22 = fmaf(wy, r22, e22);
-    e12 = fmaf(wy, r12, e12);
+    mu1 = fmaf(wy, hs[0][threadIdx.y + dy][threadIdx.x], mu1);
+    mu2 = fmaf(wy, hs[1][threadIdx.y + dy][threadIdx.x], mu2);
+    e11 = fmaf(wy, hs[2][threadIdx.y + dy][threadIdx.x], e11);
+    e22 = fmaf(wy, hs[3][threadIdx.y + dy][threadIdx.x], e22);
+    e12 = fmaf(wy, hs[4][threadIdx.y + dy][threadIdx.x], e12);
   }
   const float s1sq = e11 - mu1 * mu1, s2sq = e22 - mu2 * mu2;
   const float s12 = e12 - mu1 * mu2;
@@ -89,6 +105,7 @@ __global__ __launch_bounds__(kT* kT) void ssim_bwd_kernel(
     const float* __restrict__ d_mu1, const float* __restrict__ d_e11,
     const float* __restrict__ d_e12, float* __restrict__ g_img1) {
   __shared__ float t0[kE][kE + 1], t1[kE][kE + 1], t2[kE][kE + 1];
+  __shared__ float hs[3][kE][kT + 1];
   const size_t plane = (size_t)blockIdx.z * H * W;
   const int x0 = blockIdx.x * kT - kR, y0 = blockIdx.y * kT - kR;
   for (int i = threadIdx.y * kT + threadIdx.x; i < kE * kE; i += kT * kT) {
@@ -107,23 +124,30 @@ __global__ __launch_bounds__(kT* kT) void ssim_bwd_kernel(
     t2[ty][tx] = g * c;
   }
   __syncthreads();
+  for (int i = threadIdx.y * kT + threadIdx.x; i < kE * kT; i += kT * kT) {
+    const int ty = i / kT, tx = i - ty * kT;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int dx = 0; dx < 11; ++dx) {
+      const float w = win.g[dx];
+      r0 = fmaf(w, t0[ty][tx + dx], r0);
+      r1 = fmaf(w, t1[ty][tx + dx], r1);
+      r2 = fmaf(w, t2[ty][tx + dx], r2);
+    }
+    hs[0][ty][tx] = r0;
+    hs[1][ty][tx] = r1;
+    hs[2][ty][tx] = r2;
+  }
+  __syncthreads();
   const int x = blockIdx.x * kT + threadIdx.x, y = blockIdx.y * kT + threadIdx.y;
   if (x >= W || y >= H) return;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
   for (int dy = 0; dy < 11; ++dy) {
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-#pragma unroll
-    for (int dx = 0; dx < 11; ++dx) {
-      const float w = win.g[dx];
-      r0 = fmaf(w, t0[threadIdx.y + dy][threadIdx.x + dx], r0);
-      r1 = fmaf(w, t1[threadIdx.y + dy][threadIdx.x + dx], r1);
-      r2 = fmaf(w, t2[threadIdx.y + dy][threadIdx.x + dx], r2);
-    }
     const float wy = win.g[dy];
-    b0 = fmaf(wy, r0, b0);
-    b1 = fmaf(wy, r1, b1);
-    b2 = fmaf(wy, r2, b2);
+    b0 = fmaf(wy, hs[0][threadIdx.y + dy][threadIdx.x], b0);
+    b1 = fmaf(wy, hs[1][threadIdx.y + dy][threadIdx.x], b1);
+    b2 = fmaf(wy, hs[2][threadIdx.y + dy][threadIdx.x], b2);
   }
   const size_t o = plane + (size_t)y * W + x;
   g_img1[o] = b0 + 2.f * img1[o] * b1 + img2[o] * b2;
