@@ -1289,6 +1289,10 @@ def main():
     ap.add_argument('--no-side-runs', action='store_true',
                     help='NICE-SLAM: skip the two extra seeds (ATE mean / '
                          'spread) and the host-pose-contract run')
+    ap.add_argument('--no-steady-state', dest='steady_state',
+                    action='store_false',
+                    help='Point-SLAM: skip the run of the every-5th-frame '
+                         'regime past the lazy start (21 more frames)')
     ap.add_argument('--no-graphs', action='store_true',
                     help='run every iteration eagerly (no hipGraph capture)')
     ap.add_argument('--first-iters', type=int, default=None,

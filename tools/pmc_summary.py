@@ -41,6 +41,7 @@ def short_name(name):
               'vox_render_bwd_kernel', 'vox_ray_grad_kernel',
               'gs_render_fwd_kernel', 'gs_render_bwd_kernel',
               'gs_preprocess_kernel', 'knn_search_kernel',
+              'point_color_bwd_w_kernel', 'vox_hits_kernel',
               'point_color_bwd_kernel', 'point_color_fwd_kernel',
               'pc_dw_reduce_kernel', 'pc_dw_kernel', 'point_geo_bwd_kernel',
               'point_geo_fwd_kernel', 'point_map_loss_kernel',
