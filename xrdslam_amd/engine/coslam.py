@@ -191,7 +191,11 @@ class _CoslamRenderFn(torch.autograd.Function):
         ctx.sc, ctx.tables, ctx.model = sc, tables, model
         # (the smoothness term's lattice joins THIS backward's table scatter
         # when it runs first, see _SmoothFn)
-        model._render_bwd_pending = bool(table.requires_grad)
+        # (only a forward that CAN be followed by a backward arms the
+        # hand-over: a render under no_grad left the flag set, and the next
+        # smoothness backward parked a table gradient nobody picked up)
+        model._render_bwd_pending = bool(table.requires_grad and
+                                         torch.is_grad_enabled())
         model._smooth_stash = None
         ctx.save_for_backward(ro, rd, z_vals, raw, table, pack)
         ctx.mark_non_differentiable(z_vals)

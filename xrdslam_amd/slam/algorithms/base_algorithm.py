@@ -322,6 +322,11 @@ class Algorithm:
             optimizers.optimizer_step_all(step=step, exchange=False)
             return
         optimizers.zero_grad_all()
+        # the fused steps' hand-over fields live for ONE iteration: a
+        # get_loss call outside this method (tests, evaluation, an exception)
+        # must not make the next iteration skip its backward
+        self._grads_assigned = False
+        self.__dict__.pop('_iter_c2w', None)
         loss = self.get_loss(optimize_frames, is_mapping, step, n_iters,
                              coarse=coarse)
         if not is_mapping:

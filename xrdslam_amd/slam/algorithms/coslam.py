@@ -426,7 +426,7 @@ class CoSLAM(Algorithm):
         for o in slot['pose_opt'].optimizers.values():
             reset_optimizer_state(o)
 
-    def _prewarm_slots(self, frames, K, d_img, c_img):
+    def _prewarm_slots(self, frames, K, d_img, c_img, bucket=None):
         """Build and capture the graphs of EVERY bucket the first time a
         capacity slot is needed (and again after the bank was re-allocated):
         the current-frame ray count runs through 2048, 1024, 512, 256, 128
@@ -444,6 +444,14 @@ class CoSLAM(Algorithm):
                 if b not in slots or len(slots[b]['graphs']) < 2 or
                 slots[b]['bank_version'] != self._bank_version or
                 K + 1 > slots[b]['r'].shape[0]]
+        if slots and bucket is not None:
+            # REGROWTH (a slot was outgrown, the bank re-allocated): the ray
+            # count only shrinks with the keyframe count, so the buckets above
+            # the one in use are never needed again — re-capturing all five
+            # cost ~20 iterations + 10 captures inside one frame, a latency
+            # spike that grew with the run length.  Only the first call warms
+            # every bucket.
+            todo = [b for b in todo if b <= bucket]
         if not todo:
             return
         tensors = [p for ps in self.model_optimizers.parameters.values()
@@ -517,7 +525,7 @@ class CoSLAM(Algorithm):
                 slot['depth'].shape != d_img.shape):
             slot = None                      # capacities outgrown
         if slot is None and self.prewarm_slots:
-            self._prewarm_slots(frames, K, d_img, c_img)
+            self._prewarm_slots(frames, K, d_img, c_img, bucket)
             slot = slots.get(bucket)
         if slot is None:
             slot = slots[bucket] = self._new_slot(bucket, K, d_img, c_img)

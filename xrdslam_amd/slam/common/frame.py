@@ -45,6 +45,14 @@ class Frame(nn.Module):
                                             rot_rep)
             self.pose = OptimizablePose(vec, separate_LR=separate_LR,
                                         rot_rep=rot_rep)
+            if check:
+                # the initial pose's consistency check of the reference
+                # (frame.py:24-29); costs a host sync, so only where the
+                # caller asks for it (frame 0)
+                if not torch.allclose(pose_np.to(self.pose_device).float(),
+                                      self.pose.matrix().detach(), atol=1e-3):
+                    raise ValueError('Transformation inconsistency detected!',
+                                     pose_np, self.pose.matrix())
             return
         Rt = torch.as_tensor(pose_np, dtype=torch.float32).cpu()
         pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,

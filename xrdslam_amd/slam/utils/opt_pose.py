@@ -98,8 +98,13 @@ class OptimizablePose(nn.Module):
             print('Not support rotation represion: ', rot_rep)
         if separate_LR:
             rname = 'data_r' if rot_rep == 'axis_angle' else 'data_q'
-            self.register_parameter(rname, nn.Parameter(init_pose[3:]))
-            self.register_parameter('data_t', nn.Parameter(init_pose[:3]))
+            # (clones: two parameters must not be views of one 7-float
+            # storage — torch.save would write it whole, and the rotation
+            # parameter would sit at a 12-byte offset)
+            self.register_parameter(rname,
+                                    nn.Parameter(init_pose[3:].clone()))
+            self.register_parameter('data_t',
+                                    nn.Parameter(init_pose[:3].clone()))
         else:
             self.register_parameter('data', nn.Parameter(init_pose))
 
