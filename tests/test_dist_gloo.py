@@ -135,3 +135,38 @@ def test_tile_band_partition_covers_the_image_once():
                 else:
                     assert (t0, t1) == (0, 0)
             assert (owned == 1).all(), (height, world)
+
+
+def _pose_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xrdslam_amd.engine import dist as xd
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    xd.state.setup('cpu', seed=3)
+
+    class _Alg:
+        device = 'cpu'
+    slam = SequentialSLAM(_Alg(), [], pose_device='cpu')
+    mine = torch.eye(4) * float(rank + 1)
+    as_tensor = slam._sync_pose(mine.clone())          # device pose chain
+    as_numpy = slam._sync_pose(mine.numpy().copy())    # host hand-over
+    out[rank] = (torch.is_tensor(as_tensor), as_tensor.clone(),
+                 isinstance(as_numpy, np.ndarray), torch.from_numpy(as_numpy))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tracking_result_is_broadcast_where_it_lives():
+    """multi-GPU frame loop: tracking is replicated, rank 0's result continues
+    on every rank.  A tensor result (the device pose chain) is broadcast as a
+    tensor and stays one — no host hop —, a numpy result stays numpy."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pose_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    for r in range(world):
+        is_t, t, is_n, n = out[r]
+        assert is_t and is_n
+        assert torch.equal(t, torch.eye(4)) and torch.equal(n, torch.eye(4))

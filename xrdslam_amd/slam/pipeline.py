@@ -57,8 +57,8 @@ class SequentialSLAM:
         # (tracking-only frames were ~35 % GPU idle: 1.7 ms of graph replays,
         # then ~1 ms of host pose bookkeeping behind a device->host read).
         # Needs the poses on the GPU and the persistent tracking graph;
-        # None = on exactly then.  Multi-GPU runs keep the host hop (rank 0's
-        # result is broadcast through the host).
+        # None = on exactly then.  Multi-GPU runs broadcast rank 0's result as
+        # a device tensor (_sync_pose).
         if device_poses is None:
             device_poses = torch.device(pose_device).type == 'cuda'
         self.device_poses = bool(device_poses)
@@ -134,9 +134,10 @@ class SequentialSLAM:
         return frame
 
     def _device_chain(self):
-        from ..engine import dist as _dist
         alg = self.algorithm
-        return self.device_poses and not _dist.state.enabled and \
+        # (multi-GPU: the chain stays on the device too — rank 0's result is
+        # broadcast as a device tensor, _sync_pose)
+        return self.device_poses and \
             bool(getattr(alg, 'use_graphs', False)) and \
             bool(getattr(alg, 'persistent_track_graph', False)) and \
             torch.device(alg.device).type == 'cuda' and \
@@ -150,6 +151,12 @@ class SequentialSLAM:
         if not _dist.state.enabled or cand is None:
             return cand
         import torch.distributed as dist
+        if torch.is_tensor(cand):
+            # the device pose chain: the 4x4 is broadcast where it lives (one
+            # RCCL broadcast of 64 bytes over xGMI), no host hop
+            t = cand.detach().to(torch.float32).contiguous()
+            dist.broadcast(t, src=0)
+            return t
         dev = self.algorithm.device
         t = torch.as_tensor(cand, dtype=torch.float32).to(dev).contiguous()
         dist.broadcast(t, src=0)
