@@ -495,7 +495,7 @@ def _run_sequence(render, n_frames, seed=0, pretrained=True, traj_frames=600):
 
 def test_ate_engine_equals_reference_arithmetic_loop():
     n = int(os.environ.get('XRD_ATE_FRAMES', '11'))
-    seeds = (0, 1, 2)
+    seeds = (0, 1, 2, 3, 4)
     runs = [(_run_sequence('engine', n, seed=sd)[0],
              _run_sequence('oracle', n, seed=sd)[0]) for sd in seeds]
     ate_e = float(np.mean([r[0] for r in runs]))
@@ -515,9 +515,11 @@ def test_ate_engine_equals_reference_arithmetic_loop():
     # index_add_ is atomic too); Adam turns a sign flip of a near-zero pose
     # gradient into a step of ~lr, so single trajectories separate by up to
     # 3 cm and two runs of the SAME loop differ by ~0.3 cm of ATE.  What must
-    # agree is the error against ground truth: 1 cm on the mean of three
+    # agree is the error against ground truth: 1 cm on the mean of FIVE
     # seeds (a single pair was 1.62 / 2.07 cm, profiles/
-    # r04_parity_margins.txt), and both loops must track.
+    # r04_parity_margins.txt; with three seeds one run of round 5 came out at
+    # 1.25 / 2.56 cm — single-seed sigma ~0.45 cm in both loops — and the two
+    # reruns passed), and both loops must track.
     assert abs(ate_e - ate_o) < 0.01, line
     assert max(ate_e, ate_o) < 0.04, line
 
