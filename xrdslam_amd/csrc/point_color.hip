@@ -835,10 +835,21 @@ __device__ __forceinline__ void c1xn_step(uint32_t g0, uint32_t g1,
     c1xn_step<NB, BIAS, CH, S + 1>(g0, g1, cur, acc, accb, a);
 }
 
-template <int NB, bool BIAS, int CH, class Rows>
+// the B fragments of the first CH K-steps (issued by a caller that knows them
+// to be written earlier than the A operand is published)
+template <int NB, int CH, class Rows>
+__device__ __forceinline__ void load_b(const Rows& B, float (*cur)[NB]) {
+#pragma unroll
+  for (int s = 0; s < CH; ++s)
+#pragma unroll
+    for (int it = 0; it < NB; ++it) cur[s][it] = B.at(s, it);
+}
+
+template <int NB, bool BIAS, int CH, class Rows, bool PRELOADED = false>
 __device__ __forceinline__ void contract_1xn(const float* __restrict__ gs,
                                              const Rows& B, f32x4* acc,
-                                             f32x4& accb) {
+                                             f32x4& accb,
+                                             float (*pre)[NB] = nullptr) {
   // A fragments: LDS, pinned reads 4 K-steps ahead; B fragments: global, CH
   // K-steps per batch of loads (one exposed L2 / HBM round trip per batch:
   // CH = 32 where the registers allow), the next batch in flight while this
@@ -849,7 +860,8 @@ __device__ __forceinline__ void contract_1xn(const float* __restrict__ gs,
 #pragma unroll
   for (int s = 0; s < CH; ++s)
 #pragma unroll
-    for (int it = 0; it < NB; ++it) cur[s][it] = B.at(s, it);
+    for (int it = 0; it < NB; ++it)
+      cur[s][it] = PRELOADED ? pre[s][it] : B.at(s, it);
 #pragma unroll 1
   for (int c = 0; c < NCH; ++c) {
     if constexpr (NCH > 1) {
@@ -1054,6 +1066,10 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
       // of it, it is spilled)
       int64_t pti = pt;
       asm volatile("" : "+v"(pti));
+      // the layer's saved output (softplus' comes from it): issued in front
+      // of the staging copy, it lands behind it
+      f32x4 h[8];
+      load_rows<8>(save_h + (int64_t)i * n * 128, 128, pti, q, valid, h);
       __syncthreads();      // the contraction of layer i + 1 has read its operands
       pc_copy(wl, pk + K::rw(i), K::rlen(i));
       pc_copy(wl + kBwdFcOff, pk + K::tfc(i), 8 * 8 * 64 + 128);
@@ -1066,8 +1082,7 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
       dense_hp<2, 32, 32>(FCT, lane, 0, g_h, g_c);
       f32x4 g_z[8];
       {
-        f32x4 h[8], cc[8];
-        load_rows<8>(save_h + (int64_t)i * n * 128, 128, pti, q, valid, h);
+        f32x4 cc[8];
         if (i == 4) {
           // output layer (3 rows): d OW = sum_points go (x) h_4 as lane
           // products summed over the wave's 16 points on DPP (an MFMA product
@@ -1196,14 +1211,16 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
     float gD[8], wsum = 0.f;
     {
       float gw[8], sum = 0.f;
+      f32x4 y[8][2];   // (all eight rows in flight before the first product)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        load_rows<2>(save_y, 32, pt * 8 + k, q, valid, y[k]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        f32x4 y[2];
-        load_rows<2>(save_y, 32, pt * 8 + k, q, valid, y);
         float d = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          d += g_c[0][t] * y[0][t] + g_c[1][t] * y[1][t];
+          d += g_c[0][t] * y[k][0][t] + g_c[1][t] * y[k][1][t];
         gw[k] = group4_sum(d);
         sum += gw[k] * (nb.u[k] / nb.den);
         if (nb.has && nb.u[k] != 0.f) wsum += nb.u[k] / nb.den;
@@ -1239,6 +1256,22 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
     const float* W1 = wl;
     const float* brel = wl + WB_F_BREL;
     f32x4 hbar[8], w1_acc[4] = {z4, z4, z4, z4}, b1_acc = z4;
+    // gathers of a neighbour's position / colour feature row, one neighbour
+    // ahead (an exposed L2 / HBM round trip per neighbour otherwise)
+    float nbx[3] = {0.f, 0.f, 0.f};
+    f32x4 nbf[2] = {z4, z4};
+    auto gather_nb = [&](int k2) {
+      const int id2 = pick8(nb.id, k2);
+      if (nb.has && pick8(nb.u, k2) != 0.f) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nbx[a] = cloud[(int64_t)id2 * 3 + a];
+        nbf[0] = *reinterpret_cast<const f32x4*>(feats + (int64_t)id2 * 32 +
+                                                 4 * q);
+        nbf[1] = *reinterpret_cast<const f32x4*>(feats + (int64_t)id2 * 32 +
+                                                 16 + 4 * q);
+      }
+    };
+    gather_nb(0);
     // d loss / d B_rel: lane (q, .) owns columns fidx(4s + q), s < 5
     float brel_acc[5][3];
 #pragma unroll
@@ -1254,15 +1287,12 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
       const float uk = pick8(nb.u, k);
       const bool live = nb.has && uk != 0.f;
       const int id = pick8(nb.id, k);
-      float raw[3] = {0.f, 0.f, 0.f}, rel[3];
-      f32x4 f[2] = {z4, z4};
-      if (live) {
+      // (this neighbour's position and feature row were gathered before the
+      // previous neighbour's contraction: nbx / nbf)
+      float raw[3], rel[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) raw[a] = cloud[(int64_t)id * 3 + a] - p[a];
-        f[0] = *reinterpret_cast<const f32x4*>(feats + (int64_t)id * 32 + 4 * q);
-        f[1] = *reinterpret_cast<const f32x4*>(feats + (int64_t)id * 32 + 16 +
-                                               4 * q);
-      }
+      for (int a = 0; a < 3; ++a) raw[a] = live ? nbx[a] - p[a] : 0.f;
+      const f32x4 f[2] = {live ? nbf[0] : z4, live ? nbf[1] : z4};
 #pragma unroll
       for (int a = 0; a < 3; ++a) rel[a] = kTwoPi * raw[a];
       float e5[5], d5[5];
@@ -1341,14 +1371,20 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
       for (int a = 0; a < 3; ++a)
         gp[a] -= group4_sum(grel[a]) * kTwoPi + 2.f * raw[a] * gDk;
       // ---- d W1 += g_a (x) x over the block's points -------------------------------
-      __syncthreads();      // neighbour k - 1's contraction is done
-      publish_rows<8>(wl + WB_GSF, lp, q, g_a);
-      __syncthreads();      // (also: every wave's x rows are written)
+      __syncthreads();      // neighbour k - 1's contraction is done; every
+                            // wave's x rows of this neighbour are written
       {
         const OpsRows B(ops.fx + (int64_t)k * n * 52, 52, row0, n, first, q, li);
+        // the first pass's B fragments land behind the publish + barrier, the
+        // next neighbour's gathers behind the contraction
+        float b01[32][2];
+        load_b<2, 32>(B, b01);
+        if (k + 1 < 8) gather_nb(k + 1);
+        publish_rows<8>(wl + WB_GSF, lp, q, g_a);
+        __syncthreads();
         const float* ga_s = wl + WB_GSF + q * WB_S + li + 16 * wave;
         f32x4 none = z4;
-        contract_1xn<2, true, 32>(ga_s, B, w1_acc, b1_acc);
+        contract_1xn<2, true, 32, OpsRows, true>(ga_s, B, w1_acc, b1_acc, b01);
         contract_1xn<2, false, 32>(ga_s, B.tiles_from(2), w1_acc + 2, none);
       }
     }
@@ -1358,13 +1394,15 @@ __global__ __launch_bounds__(WB_PW * 64, 1) void point_color_bwd_w_kernel(
     put_record(part, R::B1 + wave, lane, b1_acc);
     // ---- d W2^T = hbar (x) g_c ------------------------------------------------------
     __syncthreads();
-    publish_rows<8>(wl + WB_GSF, lp, q, hbar);
-    __syncthreads();
     {
       const OpsRows B(ops.gc, 32, row0, n, first, q, li);
+      float bg[32][2];
+      load_b<2, 32>(B, bg);
+      publish_rows<8>(wl + WB_GSF, lp, q, hbar);
+      __syncthreads();
       f32x4 acc[2] = {z4, z4}, none = z4;
-      contract_1xn<2, false, 32>(wl + WB_GSF + q * WB_S + li + 16 * wave, B,
-                                 acc, none);
+      contract_1xn<2, false, 32, OpsRows, true>(
+          wl + WB_GSF + q * WB_S + li + 16 * wave, B, acc, none, bg);
       put_record(part, R::W2 + wave * 2, lane, acc[0]);
       put_record(part, R::W2 + wave * 2 + 1, lane, acc[1]);
     }
