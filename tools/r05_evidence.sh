@@ -23,14 +23,15 @@ for a in $pmc; do
   echo "pmc $a done $((SECONDS-t0))s"
 done
 export XRD_PARITY_REPORT=$out/parity_margins.txt
-timeout 400 python -m pytest tests -m gpu -q > $out/gpu_tests.txt 2>&1
+timeout 600 python -m pytest tests -m gpu -q > $out/gpu_tests.txt 2>&1
 tail -3 $out/gpu_tests.txt; echo "tests done $((SECONDS-t0))s"
-timeout 400 python bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
+timeout 600 python bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
 tail -1 $out/bench_stdout.txt > $out/bench_line.json
 echo "bench done $((SECONDS-t0))s"; cut -c1-200 $out/bench_line.json
 XRD_PROF_SCRIPT=bench.py timeout 500 bash tools/run_profile.sh $tag/prof --no-cpu-baseline --no-side-runs > $out/prof_tail.txt 2>&1
 echo "prof done $((SECONDS-t0))s"; head -3 $out/prof/kernel_summary.txt
 timeout 100 python tools/nice_bwd_timing.py 1000 200 > $out/nice_map_timing.txt 2>&1
+timeout 100 python tools/pc_graph_timing.py 24508 > $out/pointslam_group_timing.txt 2>&1
 timeout 400 python tools/kernel_counts.py > $out/kernel_counts.txt 2> $out/kernel_counts_err.txt
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
 tail -1 $out/smoke.txt
