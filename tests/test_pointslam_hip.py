@@ -304,15 +304,20 @@ def _color_case(dev, seed=7, N=6000, n=5 * 1237):
 
 
 @pytest.mark.gpu
-def test_fused_color_path_matches_modular():
+@pytest.mark.parametrize('n', [5 * 1237, 100, 128, 129, 257 * 128 + 5])
+def test_fused_color_path_matches_modular(n):
     """xrd_point_color_fwd / _bwd (F_theta per neighbour, interpolation and
-    the colour decoder in one kernel each way, weight gradients as
-    contractions over the saved operands) against MLP_color's torch path on
+    the colour decoder in one kernel each way, the weight gradients contracted
+    inside the backward's 128-point blocks) against MLP_color's torch path on
     the same neighbours: colours, d/d positions, d/d colour features, d/d
-    every decoder parameter (incl. the learnable relative-position matrix)"""
+    every decoder parameter (incl. the learnable relative-position matrix).
+    Sizes: a partial last group (shifted back over the previous one), fewer
+    points than one group (row-clamped variant), exactly one group, one group
+    + 1 point, and more groups than one launch holds partials for (the later
+    reductions accumulate)"""
     from xrdslam_amd.engine import point as ep
     dev = 'cuda:0'
-    dec, npc, q, radius, w_out = _color_case(dev)
+    dec, npc, q, radius, w_out = _color_case(dev, n=n)
     assert ep.color_supported(dec)
 
     def run(fused):
