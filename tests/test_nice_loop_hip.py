@@ -562,3 +562,84 @@ def test_deterministic_shards_add_up_to_the_single_gpu_iteration(world,
         assert close(total['grids'][k], single['grids'][k]), k
     if single['dec'] is not None:
         assert close(total['dec'], single['dec'])
+
+
+def test_render_img_equals_the_oracle_image():
+    """NiceSLAM.render_img (nice_slam.py:234-279: every pixel's ray through
+    the colour-stage render in ray_batch_size chunks) after a short mapping
+    run, IMAGE level: depth and colour of every pixel against
+    oracle/nice_oracle.py evaluated on the same grids / decoders / rays,
+    element-wise 1e-4 of the image's range (pixels whose ray has a sample on a
+    ReLU kink / cell border may differ by more: at most 0.2 % of them, none by
+    more than 1e-2)."""
+    import nice_oracle as no
+    from xrdslam_amd.data.synthetic import SyntheticRoom
+    from xrdslam_amd.slam.common.camera import Camera
+    from xrdslam_amd.slam.common.common import get_rays
+    from xrdslam_amd.slam.configs.input_config import cadence, nice_slam_config
+    from xrdslam_amd.slam.pipeline import SequentialSLAM
+    dev = 'cuda:0'
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cam = Camera(40., 40., 39.5, 29.5, 80, 60)
+    cfg = nice_slam_config(BOUND)
+    cfg.tracking_Hedge = cfg.tracking_Wedge = 5
+    cfg.mapping_first_n_iters, cfg.mapping_n_iters = 60, 20
+    cfg.ray_batch_size = 1700          # three chunks, the last one ragged
+    cfg.model.pretrained_decoders_xrd = PRETRAINED
+    algo = cfg.setup(camera=cam, device=dev)
+    data = SyntheticRoom(BOUND, H=60, W=80, fx=40., fy=40., cx=39.5, cy=29.5,
+                         n_frames=600, shrink=0.3, device=dev)
+    cad = cadence['nice-slam']
+    slam = SequentialSLAM(algo, data, map_every=cad.map_every,
+                          keyframe_every=cad.keyframe_every, pose_device=dev)
+    for k in range(3):
+        slam.step(k)
+    model = algo.model
+    c2w = algo.get_estimate_c2w_list()[2].to(dev)
+    gt_depth = np.asarray(data[2]['depth'].cpu() if torch.is_tensor(
+        data[2]['depth']) else data[2]['depth'], np.float32)
+    color, depth = algo.render_img(c2w, gt_depth)
+    # the oracle on the same rays
+    model.sync_decoders(force=True) if hasattr(model, 'sync_decoders') else None
+
+    def views(dec):
+        out, off = {}, 0
+        for name, shape in dec.shapes:
+            n = int(np.prod(shape))
+            out[name] = dec.flat[off:off + n].view(shape)
+            off += n
+        return out
+    decs = {k: views(d) for k, d in model.decoder.decoders().items()}
+    grids = {k: g.detach() for k, g in model.grid_c.items()}
+    with torch.no_grad():
+        ro, rd = get_rays(cam, c2w, device=dev)
+        ro = ro.reshape(-1, 3).float()
+        rd = rd.reshape(-1, 3).float()
+        td = torch.from_numpy(gt_depth).to(dev).reshape(-1, 1)
+        # chunk by chunk like render_img: the far bound and the no-depth
+        # rays' surface samples use the CHUNK's largest depth
+        # (conv_onet.py:391-484)
+        outs = [no.render_batch_ray(ro[i:i + 1700], rd[i:i + 1700],
+                                    td[i:i + 1700], grids, decs,
+                                    model.bounding_box.to(dev), 'color')
+                for i in range(0, ro.shape[0], 1700)]
+    want_d = torch.cat([o['depth'] for o in outs]).reshape(60, 80).double() \
+        .cpu().numpy()
+    want_c = torch.cat([o['rgb'] for o in outs]).reshape(60, 80, 3).cpu() \
+        .numpy()
+    for name, got, want in (('depth', depth, want_d), ('color', color, want_c)):
+        scale = max(float(np.abs(want).max()), 1e-30)
+        dev_px = np.abs(got - want).reshape(60 * 80, -1).max(1) / scale
+        frac = float((dev_px > 1e-4).mean())
+        bad = dev_px > 1e-4
+        line = (f'nice render_img 80x60 {name}: max {dev_px.max():.2e}, '
+                f'pixels > 1e-4: {frac:.3%} (of them without sensor depth: '
+                f'{int((bad & (gt_depth.reshape(-1) <= 0)).sum())} of '
+                f'{int(bad.sum())}; pixels without sensor depth: '
+                f'{int((gt_depth <= 0).sum())})')
+        rep = os.environ.get('XRD_PARITY_REPORT')
+        if rep:
+            with open(rep, 'a') as f:
+                f.write(line + '\n')
+        assert frac <= 0.002 and dev_px.max() < 1e-2, line
