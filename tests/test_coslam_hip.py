@@ -370,6 +370,30 @@ def test_coslam_loop_tracks_synthetic_room():
         data[10]['depth']) else data[10]['depth'])
     err = np.abs(depth - gt)[gt > 0].mean()
     assert err < 0.1, err
+    # IMAGE level: the fused renderer against the modular path (the mirror of
+    # JointEncoding.render_rays on the HIP encodings + torch MLPs, itself held
+    # to goldens made by the reference's model), same pose, same draws
+    pose = algo.get_estimate_c2w_list()[10].to('cuda:0')
+    imgs = {}
+    for fused in (True, False):
+        algo.model.use_fused = fused
+        algo.model._fused_ok = None
+        torch.manual_seed(123)
+        with torch.no_grad():
+            imgs[fused] = algo.render_img(pose, gt_depth=data[10]['depth'])
+    algo.model.use_fused = True
+    for name, a, b in (('color', imgs[True][0], imgs[False][0]),
+                       ('depth', imgs[True][1], imgs[False][1])):
+        scale = max(float(np.abs(b).max()), 1e-30)
+        dev_px = np.abs(a - b).reshape(120 * 160, -1).max(1) / scale
+        line = (f'co-slam render_img 160x120 {name}: fused vs modular max '
+                f'{dev_px.max():.2e}, pixels > 1e-4: '
+                f'{float((dev_px > 1e-4).mean()):.3%}')
+        rep = os.environ.get('XRD_PARITY_REPORT')
+        if rep:
+            with open(rep, 'a') as f:
+                f.write(line + '\n')
+        assert (dev_px > 1e-4).mean() <= 0.002 and dev_px.max() < 1e-2, line
 
 
 def test_live_count_loss_equals_the_trimmed_batch():
