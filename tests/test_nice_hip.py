@@ -743,7 +743,7 @@ def test_tracking_backward_from_the_forwards_masks(n, masked):
     assert torch.equal(out[True][2], out[False][2])
     assert float(out[True][1].abs().max()) > 0
     lib = _lib.lib()
-    assert lib.xrd_nice_fwd_masks_words(n) == n * 9 * 64
+    assert lib.xrd_nice_fwd_masks_words(n) == n * (9 * 64 + 32)
     import ctypes as C
     cs = scene.c_struct()
     p = C.c_void_p(16)

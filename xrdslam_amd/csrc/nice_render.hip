@@ -616,6 +616,166 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
   }
 }
 
+// Tracking-sized forward (colour stage, <= kRoleMaxRays rays, masks kept): the
+// three decoders of a tile run on three BLOCKS at once (blockIdx.y = decoder,
+// like nice_bwd_roles_kernel) instead of one after the other on one wave —
+// at 200 rays x 3 tiles the plain forward is 600 waves each walking three
+// staging barriers and three dependent decoder chains; here 1800 waves walk
+// one.  The decoders of a sample meet in nice_fwd_roles_finish_kernel: the
+// colour block writes raw[..][0:3], the fine block raw[..][3], the middle block
+// ``occ_m`` [ray][64]; the finishing launch adds the two occupancies in the
+// forward's order (fine + middle, conv_onet.py:370 override after it), writes
+// the final raw row and composites the ray (same code, same values, bit for
+// bit: tests/test_nice_hip.py::test_tracking_backward_from_the_forwards_masks).
+#ifndef XRD_ROLE_FWD_RPB
+#define XRD_ROLE_FWD_RPB 4
+#endif
+constexpr int kRoleFwdRPB = XRD_ROLE_FWD_RPB;
+template <int NT>
+constexpr size_t role_fwd_lds_floats() {
+  return (size_t)kRoleFwdMax + kRoleFwdRPB * NT * 256;
+}
+
+template <int NT>
+__global__ __launch_bounds__(kRoleFwdRPB * NT * 64, 1) void
+nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
+                      const float* __restrict__ rays_o,
+                      const float* __restrict__ rays_d,
+                      const float* __restrict__ gt_depth,
+                      const float* __restrict__ dmax_p,
+                      float* __restrict__ raw_out,
+                      uint64_t* __restrict__ masks,
+                      float* __restrict__ occ_m) {
+  constexpr int S = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = wave / NT, tile = wave % NT;
+  const int q = lane >> 4, li = lane & 15;
+  const int role = blockIdx.y;
+  double* zbuf = reinterpret_cast<double*>(wl + kRoleFwdMax) + wave * 128;
+  using PM = MlpPack<32, 1>;
+  using PF = MlpPack<64, 1>;
+  using PC = MlpPack<32, 4>;
+  const int ngroups = (n + kRoleFwdRPB - 1) / kRoleFwdRPB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * kRoleFwdRPB + slot);
+    const bool active = ray < n;
+    float p32[1][3] = {{0.f, 0.f, 0.f}};
+    uint64_t mask[1] = {0};
+    f32x4 c_a[1][4];
+    if (active) {
+      RayCtx rc;
+      TileGeom tg;
+      Tri tr;
+      load_ray(rays_o, rays_d, gt_depth, ray, true, rc);
+      sample_z<S>(sc, rc, dmax_p[0], lane, zbuf, zbuf + 64);
+      tile_geom(rc, zbuf[64 + 16 * tile + li], sc.bound, tg);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) p32[0][a] = tg.p32[a];
+      f32x4 c2[2];
+      if (role == 1) {
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+        tri_gather(sc.grid[1], tr, q, c2);
+        c_a[0][2] = c2[0];
+        c_a[0][3] = c2[1];
+      }
+      const int g = role + 1;
+      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3 * g, tr);
+      tri_gather(sc.grid[g], tr, q, c2);
+      c_a[0][0] = c2[0];
+      c_a[0][1] = c2[1];
+    }
+    const size_t mrow = ((size_t)(ray * NT + tile) * 3 + role) * 64 + lane;
+    const size_t srow = (size_t)ray * S + 16 * tile + li;
+    if (role == 0) {
+      stage_weights(wl, sc.dec[1], PM::WHT);
+      if (active) {
+        const f32x4 c_m[1][2] = {{c_a[0][0], c_a[0][1]}};
+        float om[1][1];
+        mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask, nullptr);
+        masks[mrow] = mask[0];
+        if (q == 0) occ_m[(size_t)ray * 64 + 16 * tile + li] = om[0][0];
+      }
+    } else if (role == 1) {
+      stage_weights(wl, sc.dec[2], PF::WHT);
+      if (active) {
+        float of[1][1];
+        mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_a, of, mask, nullptr);
+        masks[mrow] = mask[0];
+        if (q == 0) raw_out[srow * 4 + 3] = of[0][0];
+      }
+    } else {
+      stage_weights(wl, sc.dec[3], PC::WHT);
+      if (active) {
+        const f32x4 c_c[1][2] = {{c_a[0][0], c_a[0][1]}};
+        float oc[1][4];
+        mlp_fwd<1, 32, 4, true, false>(wl, lane, p32, c_c, oc, mask, nullptr);
+        masks[mrow] = mask[0];
+        if (q == 0) {
+          raw_out[srow * 4 + 0] = oc[0][0];
+          raw_out[srow * 4 + 1] = oc[0][1];
+          raw_out[srow * 4 + 2] = oc[0][2];
+        }
+      }
+    }
+  }
+}
+
+// one wave = one ray: occupancy = fine + middle (100 outside the bound),
+// final raw row, compositing (the tail of nice_fwd_kernel)
+template <int NT>
+__global__ __launch_bounds__(256) void nice_fwd_roles_finish_kernel(
+    xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ dmax_p, const float* __restrict__ occ_m,
+    float* __restrict__ raw_out, double* __restrict__ depth,
+    double* __restrict__ var, float* __restrict__ rgb) {
+  constexpr int S = NT * 16;
+  __shared__ double zsh[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (ray >= n) return;
+  RayCtx rc;
+  TileGeom tg;
+  load_ray(rays_o, rays_d, gt_depth, ray, true, rc);
+  const double zl = sample_z<S>(sc, rc, dmax_p[0], lane, zsh[wave],
+                                zsh[wave] + 64);
+  tile_geom(rc, zl, sc.bound, tg);
+  const bool valid = lane < S;
+  f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    rw = *reinterpret_cast<const f32x4*>(raw_out + ((size_t)ray * S + lane) * 4);
+    float occ = rw[3] + occ_m[(size_t)ray * 64 + lane];  // fine + middle
+    if (!tg.inb) occ = 100.f;  // conv_onet.py:370
+    rw[3] = occ;
+    *reinterpret_cast<f32x4*>(raw_out + ((size_t)ray * S + lane) * 4) = rw;
+  }
+  const float alpha = valid ? 1.f / (1.f + expf(-10.f * rw[3])) : 0.f;
+  const float f = valid ? (1.f - alpha + 1e-10f) : 1.f;
+  float incl = f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float u = __shfl_up(incl, o);
+    if (lane >= o) incl *= u;
+  }
+  float T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.f;
+  const float w = alpha * T;
+  const float R = wave_sum(w * rw[0]), G = wave_sum(w * rw[1]),
+              B = wave_sum(w * rw[2]);
+  const double dep = wave_sum(valid ? (double)w * zl : 0.0);
+  const double tmp = zl - dep;
+  const double vr = wave_sum(valid ? (double)w * tmp * tmp : 0.0);
+  if (lane == 0) {
+    depth[ray] = dep;
+    var[ray] = vr;
+    rgb[ray * 3 + 0] = R;
+    rgb[ray * 3 + 1] = G;
+    rgb[ray * 3 + 2] = B;
+  }
+}
+
 // Point queries (the mesher's query_fn / color_func, conv_onet.py:213-240 ->
 // NICE.forward with stage 'fine' / 'color', and ConvOnet.eval_points'
 // out-of-bound override conv_onet.py:358-370): raw [n,4] = (rgb raw or 0,
@@ -1292,7 +1452,10 @@ static bool masks_supported(int stage, int nt, int n_rays,
 }
 
 int64_t xrd_nice_fwd_masks_words(int n_rays) {
-  return n_rays < 0 ? -1 : (int64_t)n_rays * 3 * 3 * 64;
+  // ReLU masks [(ray * 3 + tile) * 3 + decoder][64], then the middle
+  // decoder's occupancy [ray][64] f32 (the hand-over between the decoder
+  // blocks of the forward and its finishing launch)
+  return n_rays < 0 ? -1 : (int64_t)n_rays * (3 * 3 * 64 + 32);
 }
 
 int xrd_nice_render_fwd_masks(const xrd_nice_scene* scene, int stage,
@@ -1309,8 +1472,9 @@ int xrd_nice_render_fwd_masks(const xrd_nice_scene* scene, int stage,
   if (!masks_supported(stage, nt, n_rays, gt_depth))
     return XRD_ERR_UNSUPPORTED;
   if (!dmax) return XRD_ERR_ARG;
-  auto kern = nice_fwd_kernel<XRD_STAGE_COLOR, 3, 1, true>;
-  const size_t lds = fwd_lds_floats<3, 1>() * sizeof(float);
+  if (!raw_out) return XRD_ERR_ARG;  // the decoder blocks meet in it
+  auto kern = nice_fwd_roles_kernel<3>;
+  const size_t lds = role_fwd_lds_floats<3>() * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1320,9 +1484,17 @@ int xrd_nice_render_fwd_masks(const xrd_nice_scene* scene, int stage,
     attr_set = true;
   }
   if (n_rays == 0) return XRD_OK;
-  hipLaunchKernelGGL(kern, dim3(n_rays), dim3(3 * 64), lds,
-                     (hipStream_t)stream, *scene, n_rays, rays_o, rays_d,
-                     gt_depth, dmax, depth, var, rgb, raw_out, masks);
+  hipStream_t st = (hipStream_t)stream;
+  float* occ_m = reinterpret_cast<float*>(masks + (size_t)n_rays * 3 * 3 * 64);
+  const int ngroups = (n_rays + kRoleFwdRPB - 1) / kRoleFwdRPB;
+  hipLaunchKernelGGL(kern, dim3(ngroups, 3), dim3(kRoleFwdRPB * 3 * 64), lds,
+                     st, *scene, n_rays, rays_o, rays_d, gt_depth, dmax,
+                     raw_out, masks, occ_m);
+  rc = check_launch("xrd_nice_render_fwd_masks");
+  if (rc != XRD_OK) return rc;
+  hipLaunchKernelGGL(nice_fwd_roles_finish_kernel<3>, dim3((n_rays + 3) / 4),
+                     dim3(256), 0, st, *scene, n_rays, rays_o, rays_d,
+                     gt_depth, dmax, occ_m, raw_out, depth, var, rgb);
   return check_launch("xrd_nice_render_fwd_masks");
 }
 
