@@ -320,9 +320,12 @@ int xrd_nice_render_bwd(const xrd_nice_scene* scene, int stage, int n_rays,
                         float* ws, xrd_stream_t stream);
 /* Tracking (colour stage, 48 samples a ray, <= 340 rays, ray gradients only):
  * the forward keeps the ReLU masks of the three decoders — masks:
- * xrd_nice_fwd_masks_words(n_rays) 64-bit words, [(ray*3 + tile)*3 + decoder]
- * [64 lanes] — and the backward that receives them skips its forward
- * recompute (one decoder per block, csrc/nice_render.hip).  Same results as
+ * xrd_nice_fwd_masks_words(n_rays) 64-bit words: [(ray*3 + tile)*3 + decoder]
+ * [64 lanes], then n_rays * 32 words the forward's launches hand over in —
+ * and the backward that receives them skips its forward recompute.  Both run
+ * one decoder per block (three blocks a group of tiles, csrc/nice_render.hip)
+ * and a finishing launch; raw_out is required (the decoder blocks meet in it).
+ * Same results as
  * xrd_nice_render_fwd / xrd_nice_render_bwd (the forward bit for bit, the ray
  * gradients up to the summation order of the three decoders' parts).  Other
  * shapes -> XRD_ERR_UNSUPPORTED (use the pair above).  Replaces the same

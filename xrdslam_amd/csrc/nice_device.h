@@ -953,6 +953,30 @@ __device__ __forceinline__ void stage_weights(float* __restrict__ wl,
   __syncthreads();
 }
 
+// stage_weights in two halves for a block's FIRST pass: the loads are issued
+// into registers (stage_issue), the caller runs its ray set-up and grid
+// gathers under their latency, then the LDS stores and the barrier
+// (stage_commit).  T = threads of the block, NV = ceil(n / (4 T)).
+template <int T, int NV>
+__device__ __forceinline__ void stage_issue(const float* __restrict__ src,
+                                            int n, f32x4 (&r)[NV]) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = ((int)threadIdx.x + k * T) * 4;
+    if (i < n) r[k] = *reinterpret_cast<const f32x4*>(src + i);
+  }
+}
+template <int T, int NV>
+__device__ __forceinline__ void stage_commit(float* __restrict__ wl, int n,
+                                             const f32x4 (&r)[NV]) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = ((int)threadIdx.x + k * T) * 4;
+    if (i < n) *reinterpret_cast<f32x4*>(wl + i) = r[k];
+  }
+  __syncthreads();
+}
+
 // The 68 16x16 blocks of the colour decoder's flat gradient over the FWD = 8
 // waves of a block (w = wave, jt = (w >> 1) & 1, kt = w & 1):
 //   layer i:  w < 4  fc_c.i.weight block (jt, kt)        [A = gh_i, B = c]

@@ -287,22 +287,32 @@ nice_bwd_fused_kernel(
 // A tracking batch (200 rays) is 600 tiles; the fused backward above gives a
 // tile wave a chain of six decoder passes (three recomputed forwards, three
 // backwards), each behind a staging barrier, on 150 of the 256 CUs.  Here
-// grid.y = the decoder (0 middle, 1 fine, 2 colour): a block = 4 rays = 12
-// tile waves stages ONE decoder's fragments and runs ONE forward + ONE
-// backward pass; 200 rays = 150 blocks; the three roles' d loss / d point meet
-// behind the kernel boundary in the finishing launch (9 partial rows a ray).
-// Measured at 200 rays (tools: HIP events over 20 captured calls): 76.1 ->
-// 59.5 us incl. the finishing launch; 3 rays a block 59.0, 2: 71.7, 1: 89.5.
-// Not adopted for the forward: one pass + a compositing launch is 40.8 us
-// against 39.6 us for the three-pass kernel (the passes of a one-ray block
-// have a SIMD to themselves).  Roles inside ONE block would need the three
+// grid.y = the decoder (0 middle, 1 fine, 2 colour): a block stages ONE
+// decoder's fragments and runs ONE pass over W tiles (tiles numbered
+// ray * NT + tile across the batch, whatever ray they belong to); the three
+// roles' d loss / d point meet behind the kernel boundary in the finishing
+// launch (9 partial rows a ray).  Roles inside ONE block would need the three
 // decoders' fragments at once (197 KB forward); with the fragments read from
 // L2 instead the forward measured 66 us, the backward 149 us.
-constexpr int kRoleRPB = 4;
-// one round of blocks on the 256 CUs, and the 9 part rows of a ray must fit
-// the workspace xrd_nice_bwd_ws_floats(n) promises (n*36 + replicas + 64)
+// The decoder pass of a wave is MFMA-issue bound (240 / 336 / 240 16x16x4
+// steps forward), so what a launch costs is the number of waves that share a
+// SIMD: 12-wave blocks (rounds 3-4: four rays a block) put three on each SIMD
+// of 150 CUs and leave 106 CUs idle — in that shape a role-split forward
+// bought nothing over the three-pass kernel (40.8 vs 39.6 us, round 3);
+// 8-wave blocks put two on each SIMD of 225 CUs.  Measured at 200 rays (HIP
+// events over 20 captured calls behind a 10 ms matmul, tools/_exp/
+// fwdmask_time.py): forward 35.7 -> 29.3 us incl. its finishing launch (the
+// three-pass kernel: 39.3), backward from the masks 43.4 -> 33.1 us; 4- and
+// 6-wave blocks 36.7 / 39.6 and 43.3 / 47.2 us (more blocks than CUs, every
+// block stages its decoder); with the first staging's loads issued before
+// the ray set-up and the gathers (stage_issue / stage_commit) 28.7 / 30.5 us.
+// Batches whose 8-wave blocks would not fit one round of the 256 CUs take 12.
+constexpr int role_waves(int n_rays) {
+  return (n_rays * 3 + 7) / 8 * 3 <= 256 ? 8 : 12;
+}
+// the 9 part rows of a ray must fit the workspace xrd_nice_bwd_ws_floats(n)
+// promises (n*36 + replicas + 64)
 constexpr int kRoleMaxRays = 340;
-static_assert((kRoleMaxRays + kRoleRPB - 1) / kRoleRPB * 3 <= 256, "one round");
 static_assert((size_t)kRoleMaxRays * 9 * 6 * 2 <=
                   (size_t)kRoleMaxRays * 36 + (size_t)kDwRep * kColorFlat,
               "part rows fit the workspace");
@@ -313,28 +323,27 @@ template <> struct RolePack<2> { using P = MlpPack<32, 4>; };
 constexpr int kRoleFwdMax = MlpPack<64, 1>::WHT;
 constexpr int kRoleBwdMax = MlpPack<64, 1>::LEN - MlpPack<64, 1>::EMB;
 constexpr int kRoleWl = kRoleFwdMax > kRoleBwdMax ? kRoleFwdMax : kRoleBwdMax;
-template <int NT>
+template <int W>
 constexpr size_t role_lds_floats() {
-  return (size_t)kRoleWl + kRoleRPB * NT * 256;
+  return (size_t)kRoleWl + W * 256;
 }
 
 // backward to the rays (no grid / decoder gradients): part row
 // (ray * NT + tile) * 3 + role
-template <int NT>
-__global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
+template <int NT, int W>
+__global__ __launch_bounds__(W * 64, 1) void nice_bwd_roles_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const float* __restrict__ dmax_p, const float* __restrict__ raw,
     const double* __restrict__ g_depth, const double* __restrict__ g_var,
     const float* __restrict__ g_rgb, double* __restrict__ part,
     const uint64_t* __restrict__ masks) {
-  // masks != nullptr: the forward kept the ReLU masks (nice_fwd_kernel
-  // KEEP_MASK) — no forward fragments are staged, no forward pass is run
+  // masks != nullptr: the forward kept the ReLU masks (nice_fwd_roles_kernel)
+  // — no forward fragments are staged, no forward pass is run
   constexpr int S = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = wave / NT, tile = wave % NT;
   const int q = lane >> 4, li = lane & 15;
   const int role = blockIdx.y;
   const bool have = masks != nullptr;
@@ -342,10 +351,32 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
   using PM = MlpPack<32, 1>;
   using PF = MlpPack<64, 1>;
   using PC = MlpPack<32, 4>;
-  const int ngroups = (n + kRoleRPB - 1) / kRoleRPB;
+  // the fragments of the block's first pass are on their way to LDS under the
+  // ray set-up, the compositing backward and the gathers of the first group
+  constexpr int T = W * 64;
+  constexpr int NV = (kRoleWl / 4 + T - 1) / T;
+  const float* wfirst = sc.dec[role + 1] +
+                        (have ? (role == 1 ? PF::EMB : PM::EMB) : 0);
+  const int wlen = have ? (role == 1 ? PF::LEN - PF::EMB : PM::LEN - PM::EMB)
+                        : (role == 1 ? PF::WHT : PM::WHT);
+  static_assert(PM::EMB == PC::EMB && PM::LEN == PC::LEN && PM::WHT == PC::WHT,
+                "middle and colour packs share their layout");
+  f32x4 wreg[NV];
+  stage_issue<T, NV>(wfirst, wlen, wreg);
+  bool first = true;
+  auto stage_first = [&]() {
+    if (first)
+      stage_commit<T, NV>(wl, wlen, wreg);
+    else
+      stage_weights(wl, wfirst, wlen);
+    first = false;
+  };
+  const int ntiles = n * NT;
+  const int ngroups = (ntiles + W - 1) / W;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int ray = __builtin_amdgcn_readfirstlane(grp * kRoleRPB + slot);
-    const bool active = ray < n;
+    const int t = __builtin_amdgcn_readfirstlane(grp * W + wave);
+    const bool active = t < ntiles;
+    const int ray = t / NT, tile = t - ray * NT;
     TileGeom tg = {};
     float gocc = 0.f, gcol[3] = {0.f, 0.f, 0.f};
     double gp64[3] = {0.0, 0.0, 0.0};
@@ -390,15 +421,15 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
       const f32x4 c_m[1][2] = {{c_a[0][0], c_a[0][1]}};
       const float go[1][1] = {{gocc}};
       f32x4 gc[1][2];
+      stage_first();
       if (!have) {
-        stage_weights(wl, sc.dec[1], PM::WHT);
         if (active) {
           float om[1][1];
           mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask,
                                          nullptr);
         }
+        stage_weights(wl, sc.dec[1] + PM::EMB, PM::LEN - PM::EMB);
       }
-      stage_weights(wl, sc.dec[1] + PM::EMB, PM::LEN - PM::EMB);
       if (active) {
         mlp_bwd<1, 32, 1, true, true>(wl - PM::EMB, lane, p32, c_m, go, mask,
                                       gc, gp32);
@@ -407,15 +438,15 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
     } else if (role == 1) {
       const float go[1][1] = {{gocc}};
       f32x4 gc[1][4];
+      stage_first();
       if (!have) {
-        stage_weights(wl, sc.dec[2], PF::WHT);
         if (active) {
           float of[1][1];
           mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_a, of, mask,
                                          nullptr);
         }
+        stage_weights(wl, sc.dec[2] + PF::EMB, PF::LEN - PF::EMB);
       }
-      stage_weights(wl, sc.dec[2] + PF::EMB, PF::LEN - PF::EMB);
       if (active) {
         mlp_bwd<1, 64, 1, true, true>(wl - PF::EMB, lane, p32, c_a, go, mask,
                                       gc, gp32);
@@ -427,15 +458,15 @@ __global__ __launch_bounds__(kRoleRPB * NT * 64, 1) void nice_bwd_roles_kernel(
       // channel 3 is overwritten by fine+middle occupancy -> no gradient
       const float go[1][4] = {{gcol[0], gcol[1], gcol[2], 0.f}};
       f32x4 gc[1][2];
+      stage_first();
       if (!have) {
-        stage_weights(wl, sc.dec[3], PC::WHT);
         if (active) {
           float oc[1][4];
           mlp_fwd<1, 32, 4, true, false>(wl, lane, p32, c_c, oc, mask,
                                          nullptr);
         }
+        stage_weights(wl, sc.dec[3] + PC::EMB, PC::LEN - PC::EMB);
       }
-      stage_weights(wl, sc.dec[3] + PC::EMB, PC::LEN - PC::EMB);
       if (active) {
         mlp_bwd<1, 32, 4, true, true>(wl - PC::EMB, lane, p32, c_c, go, mask,
                                       gc, gp32);
@@ -469,19 +500,14 @@ constexpr size_t fwd_lds_floats() {
   return (size_t)kWMax + RPB * 256 + RPB * NT * 256;
 }
 
-// KEEP_MASK: the ReLU masks of the three decoders go to ``masks``
-// [(ray * NT + tile) * 3 + decoder][64 lanes] (uint64: 40 bits a lane) — a
-// backward that gets them skips its forward recompute (tracking,
-// xrd_nice_render_fwd_masks / xrd_nice_render_bwd_masks)
-template <int STAGE, int NT, int RPB, bool KEEP_MASK = false>
+template <int STAGE, int NT, int RPB>
 __global__ __launch_bounds__(RPB * NT * 64, (RPB * NT + 3) / 4) void
 nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
                 const float* __restrict__ rays_d,
                 const float* __restrict__ gt_depth,
                 const float* __restrict__ dmax_p, double* __restrict__ depth,
                 double* __restrict__ var, float* __restrict__ rgb,
-                float* __restrict__ raw_out,
-                uint64_t* __restrict__ masks = nullptr) {
+                float* __restrict__ raw_out) {
   constexpr int S = NT * 16;
   constexpr int NW = RPB * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -528,11 +554,9 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
       stage_weights(wl, sc.dec[1], MlpPack<32, 1>::WHT);
       if (active) {
         float om[1][1];
-        mlp_fwd<1, 32, 1, KEEP_MASK, false>(wl, lane, p32, c_m, om, mdummy,
+        mlp_fwd<1, 32, 1, false, false>(wl, lane, p32, c_m, om, mdummy,
                                             nullptr);
         occ = om[0][0];
-        if (KEEP_MASK)
-          masks[((size_t)(ray * NT + tile) * 3 + 0) * 64 + lane] = mdummy[0];
       }
       if (STAGE >= XRD_STAGE_FINE) {
         f32x4 c_f[1][4];
@@ -548,11 +572,9 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
         stage_weights(wl, sc.dec[2], MlpPack<64, 1>::WHT);
         if (active) {
           float of[1][1];
-          mlp_fwd<1, 64, 1, KEEP_MASK, false>(wl, lane, p32, c_f, of, mdummy,
+          mlp_fwd<1, 64, 1, false, false>(wl, lane, p32, c_f, of, mdummy,
                                               nullptr);
           occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
-          if (KEEP_MASK)
-            masks[((size_t)(ray * NT + tile) * 3 + 1) * 64 + lane] = mdummy[0];
         }
       }
       if (STAGE == XRD_STAGE_COLOR) {
@@ -564,10 +586,8 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
         stage_weights(wl, sc.dec[3], MlpPack<32, 4>::WHT);
         if (active) {
           float oc[1][4];
-          mlp_fwd<1, 32, 4, KEEP_MASK, false>(wl, lane, p32, c_c, oc, mdummy,
+          mlp_fwd<1, 32, 4, false, false>(wl, lane, p32, c_c, oc, mdummy,
                                               nullptr);
-          if (KEEP_MASK)
-            masks[((size_t)(ray * NT + tile) * 3 + 2) * 64 + lane] = mdummy[0];
           col[0] = oc[0][0];
           col[1] = oc[0][1];
           col[2] = oc[0][2];
@@ -627,17 +647,13 @@ nice_fwd_kernel(xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
 // forward's order (fine + middle, conv_onet.py:370 override after it), writes
 // the final raw row and composites the ray (same code, same values, bit for
 // bit: tests/test_nice_hip.py::test_tracking_backward_from_the_forwards_masks).
-#ifndef XRD_ROLE_FWD_RPB
-#define XRD_ROLE_FWD_RPB 4
-#endif
-constexpr int kRoleFwdRPB = XRD_ROLE_FWD_RPB;
-template <int NT>
+template <int W>  // waves of a block: role_waves()
 constexpr size_t role_fwd_lds_floats() {
-  return (size_t)kRoleFwdMax + kRoleFwdRPB * NT * 256;
+  return (size_t)kRoleFwdMax + W * 256;
 }
 
-template <int NT>
-__global__ __launch_bounds__(kRoleFwdRPB * NT * 64, 1) void
+template <int NT, int W>
+__global__ __launch_bounds__(W * 64, 1) void
 nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
                       const float* __restrict__ rays_o,
                       const float* __restrict__ rays_d,
@@ -650,17 +666,27 @@ nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = wave / NT, tile = wave % NT;
   const int q = lane >> 4, li = lane & 15;
   const int role = blockIdx.y;
   double* zbuf = reinterpret_cast<double*>(wl + kRoleFwdMax) + wave * 128;
   using PM = MlpPack<32, 1>;
   using PF = MlpPack<64, 1>;
   using PC = MlpPack<32, 4>;
-  const int ngroups = (n + kRoleFwdRPB - 1) / kRoleFwdRPB;
+  // the block's decoder: fragments on their way to LDS under the ray set-up
+  // and the gathers of the first group
+  constexpr int T = W * 64;
+  constexpr int NV = (kRoleFwdMax / 4 + T - 1) / T;
+  const float* wsrc = sc.dec[role + 1];
+  const int wlen = role == 0 ? PM::WHT : role == 1 ? PF::WHT : PC::WHT;
+  f32x4 wreg[NV];
+  stage_issue<T, NV>(wsrc, wlen, wreg);
+  bool first = true;
+  const int ntiles = n * NT;
+  const int ngroups = (ntiles + W - 1) / W;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int ray = __builtin_amdgcn_readfirstlane(grp * kRoleFwdRPB + slot);
-    const bool active = ray < n;
+    const int t = __builtin_amdgcn_readfirstlane(grp * W + wave);
+    const bool active = t < ntiles;
+    const int ray = t / NT, tile = t - ray * NT;
     float p32[1][3] = {{0.f, 0.f, 0.f}};
     uint64_t mask[1] = {0};
     f32x4 c_a[1][4];
@@ -688,8 +714,12 @@ nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
     }
     const size_t mrow = ((size_t)(ray * NT + tile) * 3 + role) * 64 + lane;
     const size_t srow = (size_t)ray * S + 16 * tile + li;
+    if (first)
+      stage_commit<T, NV>(wl, wlen, wreg);
+    else
+      stage_weights(wl, wsrc, wlen);
+    first = false;
     if (role == 0) {
-      stage_weights(wl, sc.dec[1], PM::WHT);
       if (active) {
         const f32x4 c_m[1][2] = {{c_a[0][0], c_a[0][1]}};
         float om[1][1];
@@ -698,7 +728,6 @@ nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
         if (q == 0) occ_m[(size_t)ray * 64 + 16 * tile + li] = om[0][0];
       }
     } else if (role == 1) {
-      stage_weights(wl, sc.dec[2], PF::WHT);
       if (active) {
         float of[1][1];
         mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_a, of, mask, nullptr);
@@ -706,7 +735,6 @@ nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
         if (q == 0) raw_out[srow * 4 + 3] = of[0][0];
       }
     } else {
-      stage_weights(wl, sc.dec[3], PC::WHT);
       if (active) {
         const f32x4 c_c[1][2] = {{c_a[0][0], c_a[0][1]}};
         float oc[1][4];
@@ -1157,8 +1185,7 @@ static int launch_fwd(const xrd_nice_scene* scene, int n, const float* rays_o,
   const int ngroups = (n + rpb - 1) / rpb;
   const int nb = ngroups < kFusedBlocks ? ngroups : kFusedBlocks;
   hipLaunchKernelGGL(kern, dim3(nb), dim3(rpb * NTV * 64), lds, st, *scene, n,
-                     rays_o, rays_d, gt_depth, dmax, depth, var, rgb, raw_out,
-                     (uint64_t*)nullptr);
+                     rays_o, rays_d, gt_depth, dmax, depth, var, rgb, raw_out);
   return check_launch("xrd_nice_render_fwd");
 }
 
@@ -1430,17 +1457,56 @@ static int fused_dispatch(const xrd_nice_scene* scene, int stage, int nt,
 #undef FUSED_ST
 }
 
+template <int W>
+static int roles_attr_w() {
+  if (hipFuncSetAttribute(
+          reinterpret_cast<const void*>(nice_bwd_roles_kernel<3, W>),
+          hipFuncAttributeMaxDynamicSharedMemorySize,
+          (int)(role_lds_floats<W>() * sizeof(float))) != hipSuccess ||
+      hipFuncSetAttribute(
+          reinterpret_cast<const void*>(nice_fwd_roles_kernel<3, W>),
+          hipFuncAttributeMaxDynamicSharedMemorySize,
+          (int)(role_fwd_lds_floats<W>() * sizeof(float))) != hipSuccess)
+    return check_launch("hipFuncSetAttribute");
+  return XRD_OK;
+}
+
 static int roles_attr() {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(
-            reinterpret_cast<const void*>(nice_bwd_roles_kernel<3>),
-            hipFuncAttributeMaxDynamicSharedMemorySize,
-            (int)(role_lds_floats<3>() * sizeof(float))) != hipSuccess)
-      return check_launch("hipFuncSetAttribute");
+    if (int rc = roles_attr_w<8>(); rc != XRD_OK) return rc;
+    if (int rc = roles_attr_w<12>(); rc != XRD_OK) return rc;
     attr = true;
   }
   return XRD_OK;
+}
+
+template <int W>
+static void launch_fwd_roles(const xrd_nice_scene* scene, int n_rays,
+                             const float* rays_o, const float* rays_d,
+                             const float* gt_depth, const float* dmax,
+                             float* raw_out, uint64_t* masks, float* occ_m,
+                             hipStream_t st) {
+  hipLaunchKernelGGL((nice_fwd_roles_kernel<3, W>),
+                     dim3((n_rays * 3 + W - 1) / W, 3), dim3(W * 64),
+                     role_fwd_lds_floats<W>() * sizeof(float), st, *scene,
+                     n_rays, rays_o, rays_d, gt_depth, dmax, raw_out, masks,
+                     occ_m);
+}
+
+template <int W>
+static void launch_bwd_roles(const xrd_nice_scene* scene, int n_rays,
+                             const float* rays_o, const float* rays_d,
+                             const float* gt_depth, const float* dmax,
+                             const float* raw, const double* g_depth,
+                             const double* g_var, const float* g_rgb,
+                             double* part, const uint64_t* masks,
+                             hipStream_t st) {
+  hipLaunchKernelGGL((nice_bwd_roles_kernel<3, W>),
+                     dim3((n_rays * 3 + W - 1) / W, 3), dim3(W * 64),
+                     role_lds_floats<W>() * sizeof(float), st, *scene, n_rays,
+                     rays_o, rays_d, gt_depth, dmax, raw, g_depth, g_var,
+                     g_rgb, part, masks);
 }
 
 extern "C" {
@@ -1473,23 +1539,17 @@ int xrd_nice_render_fwd_masks(const xrd_nice_scene* scene, int stage,
     return XRD_ERR_UNSUPPORTED;
   if (!dmax) return XRD_ERR_ARG;
   if (!raw_out) return XRD_ERR_ARG;  // the decoder blocks meet in it
-  auto kern = nice_fwd_roles_kernel<3>;
-  const size_t lds = role_fwd_lds_floats<3>() * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return check_launch("hipFuncSetAttribute");
-    attr_set = true;
-  }
+  rc = roles_attr();
+  if (rc != XRD_OK) return rc;
   if (n_rays == 0) return XRD_OK;
   hipStream_t st = (hipStream_t)stream;
   float* occ_m = reinterpret_cast<float*>(masks + (size_t)n_rays * 3 * 3 * 64);
-  const int ngroups = (n_rays + kRoleFwdRPB - 1) / kRoleFwdRPB;
-  hipLaunchKernelGGL(kern, dim3(ngroups, 3), dim3(kRoleFwdRPB * 3 * 64), lds,
-                     st, *scene, n_rays, rays_o, rays_d, gt_depth, dmax,
-                     raw_out, masks, occ_m);
+  if (role_waves(n_rays) == 8)
+    launch_fwd_roles<8>(scene, n_rays, rays_o, rays_d, gt_depth, dmax, raw_out,
+                        masks, occ_m, st);
+  else
+    launch_fwd_roles<12>(scene, n_rays, rays_o, rays_d, gt_depth, dmax,
+                         raw_out, masks, occ_m, st);
   rc = check_launch("xrd_nice_render_fwd_masks");
   if (rc != XRD_OK) return rc;
   hipLaunchKernelGGL(nice_fwd_roles_finish_kernel<3>, dim3((n_rays + 3) / 4),
@@ -1559,14 +1619,14 @@ static int render_bwd_impl(const xrd_nice_scene* scene, int stage, int n_rays,
       !gg[3]) {
     // tracking: one decoder per block (the part rows of the three roles
     // extend into the — unused — replica region of the workspace)
-    const size_t lds = role_lds_floats<3>() * sizeof(float);
     rc = roles_attr();
     if (rc != XRD_OK) return rc;
-    const int ngroups = (n_rays + kRoleRPB - 1) / kRoleRPB;
-    hipLaunchKernelGGL(nice_bwd_roles_kernel<3>, dim3(ngroups, 3),
-                       dim3(kRoleRPB * 3 * 64), lds, st, *scene, n_rays,
-                       rays_o, rays_d, gt_depth, dmax, raw, g_depth, g_var,
-                       g_rgb, part, masks);
+    if (role_waves(n_rays) == 8)
+      launch_bwd_roles<8>(scene, n_rays, rays_o, rays_d, gt_depth, dmax, raw,
+                          g_depth, g_var, g_rgb, part, masks, st);
+    else
+      launch_bwd_roles<12>(scene, n_rays, rays_o, rays_d, gt_depth, dmax, raw,
+                           g_depth, g_var, g_rgb, part, masks, st);
     rc = check_launch("xrd_nice_render_bwd/roles");
     nt_rows = 9;
   } else if (masks != nullptr) {
