@@ -32,6 +32,7 @@ XRD_PROF_SCRIPT=bench.py timeout 500 bash tools/run_profile.sh $tag/prof --no-cp
 echo "prof done $((SECONDS-t0))s"; head -3 $out/prof/kernel_summary.txt
 timeout 100 python tools/nice_bwd_timing.py 1000 200 > $out/nice_map_timing.txt 2>&1
 timeout 100 python tools/pc_graph_timing.py 24508 > $out/pointslam_group_timing.txt 2>&1
+timeout 100 python tools/nice_track_timing.py 200 > $out/nice_track_timing.txt 2>&1
 timeout 400 python tools/kernel_counts.py > $out/kernel_counts.txt 2> $out/kernel_counts_err.txt
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
 tail -1 $out/smoke.txt

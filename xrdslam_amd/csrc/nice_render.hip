@@ -300,8 +300,8 @@ nice_bwd_fused_kernel(
 // of 150 CUs and leave 106 CUs idle — in that shape a role-split forward
 // bought nothing over the three-pass kernel (40.8 vs 39.6 us, round 3);
 // 8-wave blocks put two on each SIMD of 225 CUs.  Measured at 200 rays (HIP
-// events over 20 captured calls behind a 10 ms matmul, tools/_exp/
-// fwdmask_time.py): forward 35.7 -> 29.3 us incl. its finishing launch (the
+// events over 20 captured calls behind a 10 ms matmul,
+// tools/nice_track_timing.py): forward 35.7 -> 29.3 us incl. its finishing launch (the
 // three-pass kernel: 39.3), backward from the masks 43.4 -> 33.1 us; 4- and
 // 6-wave blocks 36.7 / 39.6 and 43.3 / 47.2 us (more blocks than CUs, every
 // block stages its decoder); with the first staging's loads issued before
@@ -403,13 +403,16 @@ __global__ __launch_bounds__(W * 64, 1) void nice_bwd_roles_kernel(
         p32[0][a] = tg.p32[a];
       }
       f32x4 c2[2];
+      // (the two lookups of the fine decoder one after the other: issued
+      // together — as the forward does — the backward measured 32.8 instead
+      // of 30.5 us, its 240 registers leave no room for a second corner set)
       if (role == 1) {
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
         tri_gather(sc.grid[1], tr, q, c2);
         c_a[0][2] = c2[0];
         c_a[0][3] = c2[1];
       }
-      const int g = role == 0 ? 1 : role == 1 ? 2 : 3;
+      const int g = role + 1;
       tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3 * g, tr);
       tri_gather(sc.grid[g], tr, q, c2);
       c_a[0][0] = c2[0];
@@ -701,14 +704,21 @@ nice_fwd_roles_kernel(xrd_nice_scene sc, int n,
       for (int a = 0; a < 3; ++a) p32[0][a] = tg.p32[a];
       f32x4 c2[2];
       if (role == 1) {
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
-        tri_gather(sc.grid[1], tr, q, c2);
-        c_a[0][2] = c2[0];
-        c_a[0][3] = c2[1];
+        // both lookups of the fine decoder in one basic block: the 32 loads
+        // go out together (28.7 -> 28.0 us)
+        Tri trm;
+        f32x4 cm[2];
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, trm);
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        tri_gather(sc.grid[1], trm, q, cm);
+        tri_gather(sc.grid[2], tr, q, c2);
+        c_a[0][2] = cm[0];
+        c_a[0][3] = cm[1];
+      } else {
+        const int g = role + 1;
+        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3 * g, tr);
+        tri_gather(sc.grid[g], tr, q, c2);
       }
-      const int g = role + 1;
-      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3 * g, tr);
-      tri_gather(sc.grid[g], tr, q, c2);
       c_a[0][0] = c2[0];
       c_a[0][1] = c2[1];
     }
