@@ -1,6 +1,10 @@
 """HIP-event timing of xrd_nice_render_fwd / xrd_nice_render_bwd (the launch
 group of one call) per stage and gradient set at the office0 config.
-Run on the GPU box:  python tools/nice_bwd_timing.py [n_rays ...]"""
+Run on the GPU box:  python tools/nice_bwd_timing.py [--cameras K] [n_rays ...]
+(--cameras K: the rays leave K camera centres through random pixels, like a
+mapping window of K frames — their first samples share grid cells, which is
+what the gradient scatters see in a frame loop; default: rays scattered over
+the room)"""
 import ctypes as C
 import os
 import sys
@@ -34,6 +38,34 @@ st = _lib.stream_ptr(dev)
 P = _lib.ptr
 
 
+CAMERAS = 0
+if '--cameras' in sys.argv:
+    k = sys.argv.index('--cameras')
+    CAMERAS = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
+
+
+def make_rays(n):
+    if not CAMERAS:
+        o = ((torch.rand(n, 3, device=dev) - 0.5) * 2.0).contiguous()
+        d = torch.randn(n, 3, device=dev)
+        return o, (d / d.norm(dim=1, keepdim=True)).contiguous()
+    cam = torch.randint(0, CAMERAS, (n, ), device=dev)
+    centres = (torch.rand(CAMERAS, 3, device=dev) - 0.5) * 2.0
+    # 640x480, 90 degrees across: pixel directions around a per-camera axis
+    u = (torch.rand(n, device=dev) - 0.5) * 2.0
+    v = (torch.rand(n, device=dev) - 0.5) * 1.5
+    axis = torch.randn(CAMERAS, 3, device=dev)
+    axis = axis / axis.norm(dim=1, keepdim=True)
+    up = torch.tensor([0., 0., 1.], device=dev).expand(CAMERAS, 3)
+    right = torch.linalg.cross(axis, up)
+    right = right / right.norm(dim=1, keepdim=True)
+    up2 = torch.linalg.cross(right, axis)
+    d = axis[cam] + u[:, None] * right[cam] + v[:, None] * up2[cam]
+    return centres[cam].contiguous(), \
+        (d / d.norm(dim=1, keepdim=True)).contiguous()
+
+
 def timeit(fn, iters=30, warm=5):
     for _ in range(warm):
         fn()
@@ -51,9 +83,7 @@ for n in [int(a) for a in sys.argv[1:]] or [200, 1000]:
     if True:
         # coarse stage: old chain (fwd + bwd incl. replica reduce) vs one launch
         cs = scene.c_struct()
-        o = ((torch.rand(n, 3, device=dev) - 0.5) * 2.0).contiguous()
-        d = torch.randn(n, 3, device=dev)
-        d = (d / d.norm(dim=1, keepdim=True)).contiguous()
+        o, d = make_rays(n)
         depth = (1.0 + 2.0 * torch.rand(n, device=dev)).contiguous()
         dep = torch.empty(n, dtype=torch.float64, device=dev)
         var = torch.empty_like(dep)
@@ -88,9 +118,7 @@ for n in [int(a) for a in sys.argv[1:]] or [200, 1000]:
         print(f'n={n:5d} coarse fwd {timeit(cf):7.1f} us | bwd+reduce '
               f'{timeit(cb):7.1f} | map_iter (2 launches) {timeit(cm):7.1f}',
               flush=True)
-    o = ((torch.rand(n, 3, device=dev) - 0.5) * 2.0).contiguous()
-    d = torch.randn(n, 3, device=dev)
-    d = (d / d.norm(dim=1, keepdim=True)).contiguous()
+    o, d = make_rays(n)
     depth = (1.0 + 2.0 * torch.rand(n, device=dev)).contiguous()
     dmax = depth.max().reshape(1)
     for stage, si in (('middle', 1), ('fine', 2), ('color', 3)):
