@@ -26,7 +26,9 @@ def short_name(name):
     m = re.search(r'coslam_bwd_kernel<(\w+), (\w+)>', name)
     if m:
         return f'coslam_bwd<dp={m.group(1)},dg={m.group(2)}>'
-    for k in ('nice_map_coarse_finish_kernel', 'nice_map_coarse_kernel',
+    for k in ('nice_fwd_roles_finish_kernel', 'nice_fwd_roles_kernel',
+              'nice_bwd_roles_kernel',
+              'nice_map_coarse_finish_kernel', 'nice_map_coarse_kernel',
               'nice_map_finish_kernel',
               'nice_bwd_coarse_kernel', 'nice_bwd_finish_kernel',
               'coarse_rep_reduce_kernel', 'adam_cells_kernel', 'coslam_fwd_kernel',
