@@ -128,3 +128,27 @@ def test_device_pose_chain_tracks_like_the_host_chain():
     assert abs(sa.ate_rmse() - sb.ate_rmse()) < 2e-3
     assert sa.ate_rmse() < 0.03
     assert a.device_track_result and not b.device_track_result
+
+
+def test_initial_pose_check_of_device_poses_is_deferred_not_dropped():
+    """frame.py:24-29 checks every frame's initial pose against its
+    parameterisation; for a pose that is already on the device the comparison
+    stays there (no host read per frame) and is raised by the next trajectory
+    reader (Frame.raise_if_inconsistent)"""
+    from xrdslam_amd.slam.common.frame import Frame
+    d = np.ones((4, 6), np.float32)
+    c = np.zeros((4, 6, 3), np.float32)
+    Frame.raise_if_inconsistent()          # start clean
+    good = torch.from_numpy(_rigid(np.random.default_rng(3))).to(DEV)
+    Frame(0, c, d, init_pose=good, separate_LR=True, rot_rep='quat',
+          device=DEV)
+    Frame.raise_if_inconsistent()          # consistent: nothing raised
+    bad = good.clone()
+    bad[:3, :3] *= 2.0                     # not a rotation
+    Frame(1, c, d, init_pose=bad, separate_LR=True, rot_rep='quat',
+          device=DEV)                      # no host read here ...
+    Frame(2, c, d, init_pose=good, separate_LR=True, rot_rep='quat',
+          device=DEV)
+    with pytest.raises(ValueError):
+        Frame.raise_if_inconsistent()      # ... raised here
+    Frame.raise_if_inconsistent()          # and cleared

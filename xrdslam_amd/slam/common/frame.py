@@ -13,6 +13,21 @@ from ..utils.opt_pose import OptimizablePose
 
 
 class Frame(nn.Module):
+    # device -> largest |initial pose - its parameterisation| since the last
+    # raise_if_inconsistent() (device tensors: see set_pose)
+    _pose_check = {}
+
+    @staticmethod
+    def raise_if_inconsistent(atol=1e-3):
+        """the deferred half of the initial-pose check of device-resident
+        poses (one host read for all frames since the last call)"""
+        pending, Frame._pose_check = Frame._pose_check, {}
+        for dev, err in pending.items():
+            e = float(err)
+            if not e <= atol:   # also catches NaN
+                raise ValueError('Transformation inconsistency detected! '
+                                 f'(largest deviation {e:g} on {dev})')
+
     def __init__(self, fid, rgb, depth, init_pose=None, gt_pose=None,
                  separate_LR=False, rot_rep='axis_angle',
                  device='cpu') -> None:
@@ -47,12 +62,18 @@ class Frame(nn.Module):
                                         rot_rep=rot_rep)
             if check:
                 # the initial pose's consistency check of the reference
-                # (frame.py:24-29); costs a host sync, so only where the
-                # caller asks for it (frame 0)
-                if not torch.allclose(pose_np.to(self.pose_device).float(),
-                                      self.pose.matrix().detach(), atol=1e-3):
-                    raise ValueError('Transformation inconsistency detected!',
-                                     pose_np, self.pose.matrix())
+                # (frame.py:24-29) WITHOUT its host read: the largest
+                # deviation seen so far stays on the device and is raised at
+                # the next point that reads poses back anyway
+                # (Frame.raise_if_inconsistent: the trajectory readers of the
+                # pipeline) — a read here would drain the queue once a frame
+                # (measured: Co-SLAM 333 -> 306 frames/s)
+                err = (pose_np.to(self.pose_device).float() -
+                       self.pose.matrix().detach()).abs().amax()
+                key = torch.device(self.pose_device)
+                worst = Frame._pose_check.get(key)
+                Frame._pose_check[key] = err if worst is None else \
+                    torch.maximum(worst, err)
             return
         Rt = torch.as_tensor(pose_np, dtype=torch.float32).cpu()
         pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,

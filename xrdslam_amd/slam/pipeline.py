@@ -166,6 +166,7 @@ class SequentialSLAM:
         """ATE statistics of the frames processed so far, like ds-eval prints
         them (utils/eval_traj.py); ``align=False`` = ate_rmse()"""
         from .utils.eval_traj import evaluate_trajectory
+        Frame.raise_if_inconsistent()
         alg = self.algorithm
         n = len(alg.get_estimate_c2w_list())
         return evaluate_trajectory(alg.get_gt_c2w_list(),
@@ -176,12 +177,14 @@ class SequentialSLAM:
         """the trajectory file the reference's tracker leaves in its output
         directory (tracker.py:411-420)"""
         from .utils.eval_traj import save_eval_tar
+        Frame.raise_if_inconsistent()
         save_eval_tar(self.algorithm,
                       len(self.algorithm.get_estimate_c2w_list()), path)
 
     def ate_rmse(self):
         """translation RMSE between estimated and GT poses (no alignment: the
         synthetic runs start from the GT pose of frame 0)"""
+        Frame.raise_if_inconsistent()
         est = torch.stack([p[:3, 3].cpu() for p in
                            self.algorithm.get_estimate_c2w_list()])
         gt = torch.stack([p[:3, 3] for p in self.algorithm.get_gt_c2w_list()])
