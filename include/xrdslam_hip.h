@@ -1100,11 +1100,18 @@ int xrd_pose_aa_bwd(int n, const float* r3, const float* g_c2w16, float* g_r3,
  * xrd_pose_from_matrix: OptimizablePose.from_matrix (slam/utils/opt_pose.py:
  * 97-110; frame.py:24-36): c2w16 -> vec = [t(3), rot], rot = unit quaternion
  * (r,i,j,k), r >= 0 (XRD_ROT_QUAT, 7 floats) or axis-angle (XRD_ROT_AXIS_ANGLE,
- * 6 floats).  xrd_pose_predict: the tracker's constant-velocity start
+ * 6 floats).  xrd_pose_from_matrix_checked: the same + Frame's consistency
+ * check of an initial pose (slam/common/frame.py:24-29, |c2w - matrix of the
+ * parameters| <= 1e-3) without its host read: the largest deviation of the
+ * rotation rebuilt from the quaternion is folded into dev_max[0] (a device
+ * float the caller zeroes and reads when it reads poses back anyway; NaN
+ * sticks).  xrd_pose_predict: the tracker's constant-velocity start
  * (slam/pipeline/tracker.py:185-199): next = (prev @ inv(prev2)) @ prev. */
 enum { XRD_ROT_AXIS_ANGLE = 0, XRD_ROT_QUAT = 1 };
 int xrd_pose_from_matrix(int rot_rep, const float* c2w16, float* vec,
                          xrd_stream_t stream);
+int xrd_pose_from_matrix_checked(int rot_rep, const float* c2w16, float* vec,
+                                 float* dev_max, xrd_stream_t stream);
 int xrd_pose_predict(const float* prev16, const float* prev2_16,
                      float* next16, xrd_stream_t stream);
 /* torch.optim.Adam step on a small dense tensor, step count on the device */

@@ -214,6 +214,7 @@ _SIGS = {
     'xrd_pose_aa_fwd': (C.c_int, [C.c_int, vp, vp, vp, vp]),
     'xrd_pose_aa_bwd': (C.c_int, [C.c_int, vp, vp, vp, vp, vp]),
     'xrd_pose_from_matrix': (C.c_int, [C.c_int, vp, vp, vp]),
+    'xrd_pose_from_matrix_checked': (C.c_int, [C.c_int, vp, vp, vp, vp]),
     'xrd_pose_predict': (C.c_int, [vp, vp, vp, vp]),
     'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
                                  vp, vp]),

@@ -731,10 +731,14 @@ __global__ __launch_bounds__(256) void pose_rays_bwd_kernel(
 // quaternion (r,i,j,k) through the best conditioned of the four candidates
 // (largest of 1 +- m00 +- m11 +- m22), sign r >= 0, optionally -> axis-angle
 // (theta = 2 atan2(|v|, r)); out = [t(3), rot(3 or 4)], float32 arithmetic in
-// the order of the host formulas.
+// the order of the host formulas.  ``dev_max`` (optional): the reference's
+// consistency check of an initial pose (frame.py:24-29: |c2w - matrix of the
+// parameters| <= 1e-3) without its host read — the largest deviation of the
+// rotation rebuilt from the quaternion is folded into dev_max[0] (NaN sticks).
 __global__ void pose_from_matrix_kernel(const float* __restrict__ c2w,
                                         int quat_rep,
-                                        float* __restrict__ out) {
+                                        float* __restrict__ out,
+                                        float* __restrict__ dev_max) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float m[3][3];
 #pragma unroll
@@ -775,6 +779,30 @@ __global__ void pose_from_matrix_kernel(const float* __restrict__ c2w,
   if (q[0] < 0.f) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = -q[k];
+  }
+  if (dev_max != nullptr) {
+    // quaternion_to_matrix (opt_pose.py: two_s = 2 / |q|^2)
+    const float two_s =
+        2.0f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float r[3][3] = {
+        {1 - two_s * (q[2] * q[2] + q[3] * q[3]),
+         two_s * (q[1] * q[2] - q[3] * q[0]),
+         two_s * (q[1] * q[3] + q[2] * q[0])},
+        {two_s * (q[1] * q[2] + q[3] * q[0]),
+         1 - two_s * (q[1] * q[1] + q[3] * q[3]),
+         two_s * (q[2] * q[3] - q[1] * q[0])},
+        {two_s * (q[1] * q[3] - q[2] * q[0]),
+         two_s * (q[2] * q[3] + q[1] * q[0]),
+         1 - two_s * (q[1] * q[1] + q[2] * q[2])}};
+    float err = dev_max[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float e = fabsf(r[i][j] - m[i][j]);
+        if (!(e <= err)) err = e;   // larger, or NaN
+      }
+    dev_max[0] = err;
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) out[a] = c2w[a * 4 + 3];
@@ -973,8 +1001,20 @@ int xrd_pose_from_matrix(int rot_rep, const float* c2w16, float* vec,
   if (rot_rep != XRD_ROT_AXIS_ANGLE && rot_rep != XRD_ROT_QUAT)
     return XRD_ERR_ARG;
   hipLaunchKernelGGL(pose_from_matrix_kernel, dim3(1), dim3(64), 0,
-                     (hipStream_t)stream, c2w16, rot_rep == XRD_ROT_QUAT, vec);
+                     (hipStream_t)stream, c2w16, rot_rep == XRD_ROT_QUAT, vec,
+                     (float*)nullptr);
   return check_launch("xrd_pose_from_matrix");
+}
+
+int xrd_pose_from_matrix_checked(int rot_rep, const float* c2w16, float* vec,
+                                 float* dev_max, xrd_stream_t stream) {
+  if (!c2w16 || !vec || !dev_max) return XRD_ERR_ARG;
+  if (rot_rep != XRD_ROT_AXIS_ANGLE && rot_rep != XRD_ROT_QUAT)
+    return XRD_ERR_ARG;
+  hipLaunchKernelGGL(pose_from_matrix_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, c2w16, rot_rep == XRD_ROT_QUAT, vec,
+                     dev_max);
+  return check_launch("xrd_pose_from_matrix_checked");
 }
 
 int xrd_pose_predict(const float* prev16, const float* prev2_16,

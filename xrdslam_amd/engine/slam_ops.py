@@ -433,13 +433,21 @@ class FusedDenseAdam(torch.optim.Optimizer):
 
 
 @torch.no_grad()
-def pose_from_matrix(c2w: torch.Tensor, rot_rep: str) -> torch.Tensor:
+def pose_from_matrix(c2w: torch.Tensor, rot_rep: str,
+                     dev_max: torch.Tensor = None) -> torch.Tensor:
     """OptimizablePose.from_matrix on the device: c2w[4,4] f32 -> [t, rot]
-    (7 floats for 'quat', 6 for 'axis_angle'), one launch, no host sync"""
+    (7 floats for 'quat', 6 for 'axis_angle'), one launch, no host sync.
+    ``dev_max`` (1 float on the device): the largest |c2w - matrix(rot)| seen
+    is folded into it (Frame's initial-pose check without its host read)"""
     quat = rot_rep == 'quat'
     c2w = c2w.detach().float().contiguous()
     vec = torch.empty(7 if quat else 6, dtype=torch.float32,
                       device=c2w.device)
+    if dev_max is not None:
+        _lib.check(_lib.lib().xrd_pose_from_matrix_checked(
+            1 if quat else 0, _lib.ptr(c2w), _lib.ptr(vec), _lib.ptr(dev_max),
+            _lib.stream_ptr(c2w.device)), 'xrd_pose_from_matrix_checked')
+        return vec
     _lib.check(_lib.lib().xrd_pose_from_matrix(
         1 if quat else 0, _lib.ptr(c2w), _lib.ptr(vec),
         _lib.stream_ptr(c2w.device)), 'xrd_pose_from_matrix')

@@ -21,9 +21,9 @@ class Frame(nn.Module):
     def raise_if_inconsistent(atol=1e-3):
         """the deferred half of the initial-pose check of device-resident
         poses (one host read for all frames since the last call)"""
-        pending, Frame._pose_check = Frame._pose_check, {}
-        for dev, err in pending.items():
+        for dev, err in Frame._pose_check.items():
             e = float(err)
+            err.zero_()
             if not e <= atol:   # also catches NaN
                 raise ValueError('Transformation inconsistency detected! '
                                  f'(largest deviation {e:g} on {dev})')
@@ -56,24 +56,24 @@ class Frame(nn.Module):
             # conversion launch instead of a host round trip that would drain
             # the queue between two frames
             from ...engine import slam_ops
-            vec = slam_ops.pose_from_matrix(pose_np.to(self.pose_device),
-                                            rot_rep)
-            self.pose = OptimizablePose(vec, separate_LR=separate_LR,
-                                        rot_rep=rot_rep)
+            worst = None
             if check:
                 # the initial pose's consistency check of the reference
-                # (frame.py:24-29) WITHOUT its host read: the largest
-                # deviation seen so far stays on the device and is raised at
-                # the next point that reads poses back anyway
+                # (frame.py:24-29) WITHOUT its host read: the conversion
+                # launch folds the deviation into a device float that is
+                # raised at the next point that reads poses back anyway
                 # (Frame.raise_if_inconsistent: the trajectory readers of the
                 # pipeline) — a read here would drain the queue once a frame
                 # (measured: Co-SLAM 333 -> 306 frames/s)
-                err = (pose_np.to(self.pose_device).float() -
-                       self.pose.matrix().detach()).abs().amax()
                 key = torch.device(self.pose_device)
                 worst = Frame._pose_check.get(key)
-                Frame._pose_check[key] = err if worst is None else \
-                    torch.maximum(worst, err)
+                if worst is None:
+                    worst = Frame._pose_check[key] = torch.zeros(
+                        1, dtype=torch.float32, device=key)
+            vec = slam_ops.pose_from_matrix(pose_np.to(self.pose_device),
+                                            rot_rep, dev_max=worst)
+            self.pose = OptimizablePose(vec, separate_LR=separate_LR,
+                                        rot_rep=rot_rep)
             return
         Rt = torch.as_tensor(pose_np, dtype=torch.float32).cpu()
         pose = OptimizablePose.from_matrix(Rt, separate_LR=separate_LR,
