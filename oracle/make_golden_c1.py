@@ -64,7 +64,7 @@ SEQ = {
                       run_frames=8),
     'splatam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=48,
                     W=64, fx=32.0, fy=32.0, cx=31.5, cy=23.5, n_frames=200,
-                    run_frames=6),
+                    run_frames=4),
 }
 
 
