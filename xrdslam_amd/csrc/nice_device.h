@@ -346,6 +346,56 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
 
 // MLP_no_xyz (coarse, decoder_nice.py:308-320): h=c; 5x(Linear+ReLU), skip
 // cat[c,h] after layer 2; Linear(32,1).
+// One layer, its index a template parameter: the layer's A fragments (16 or
+// 32 ds_read_b32) are all issued before the first MFMA.  With the layer index
+// a run-time value (rounds 1-4) every MFMA waited for its own fragment read —
+// a chain of 16-32 LDS latencies a layer: the coarse mapper's forward was
+// 11.8 k cycles for 96 MFMAs (phase stamps, profiles/r05_scatter_contention.txt).
+template <int NT, bool SAVE_MASK, int I>
+__device__ __forceinline__ void noxyz_fwd_layer(
+    const float* __restrict__ pk, int lane, const f32x4 (&c)[NT][2],
+    f32x4 (&h)[NT][2], uint64_t (&mask)[NT]) {
+  using P = NoXyzPack;
+  constexpr int KS = P::ks(I);
+  const int q = lane >> 4;
+  float a[2][KS];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      a[jt][s] = pk[P::w(I) + (jt * KS + s) * 64 + lane];
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const f32x4 b =
+        *reinterpret_cast<const f32x4*>(pk + P::B + I * 32 + 16 * jt + 4 * q);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][jt] = b;
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        // layer 3: K-steps 0..7 read c, 8..15 read h
+        const float b = (I == 3 && s < 8) ? c[t][(s & 7) >> 2][s & 3]
+                                          : h[t][(s & 7) >> 2][s & 3];
+        acc[t][jt] = XRD_MFMA4(a[jt][s], b, acc[t][jt]);
+      }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[t][jt][r];
+        if (SAVE_MASK && v > 0.f)
+          mask[t] |= (uint64_t)1 << (I * 8 + jt * 4 + r);
+        h[t][jt][r] = fmaxf(v, 0.f);
+      }
+}
+
 template <int NT, bool SAVE_MASK>
 __device__ __forceinline__ void noxyz_fwd(const float* __restrict__ pk,
                                           int lane, const f32x4 (&c)[NT][2],
@@ -360,47 +410,11 @@ __device__ __forceinline__ void noxyz_fwd(const float* __restrict__ pk,
     h[t][1] = c[t][1];
     mask[t] = 0;
   }
-#pragma unroll 1
-  for (int i = 0; i < 5; ++i) {
-    f32x4 acc[NT][2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      const f32x4 b =
-          *reinterpret_cast<const f32x4*>(pk + P::B + i * 32 + 16 * jt + 4 * q);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][jt] = b;
-    }
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int ks = P::ks(i);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      if (s < ks) {
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          const float a = pk[P::w(i) + (jt * ks + s) * 64 + lane];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            // layer 3: K-steps 0..7 read c, 8..15 read h
-            const float b = (i == 3 && s < 8) ? c[t][(s & 7) >> 2][s & 3]
-                                              : h[t][(s & 7) >> 2][s & 3];
-            acc[t][jt] = XRD_MFMA4(a, b, acc[t][jt]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = acc[t][jt][r];
-          if (SAVE_MASK && a > 0.f)
-            mask[t] |= (uint64_t)1 << (i * 8 + jt * 4 + r);
-          h[t][jt][r] = fmaxf(a, 0.f);
-        }
-  }
+  noxyz_fwd_layer<NT, SAVE_MASK, 0>(pk, lane, c, h, mask);
+  noxyz_fwd_layer<NT, SAVE_MASK, 1>(pk, lane, c, h, mask);
+  noxyz_fwd_layer<NT, SAVE_MASK, 2>(pk, lane, c, h, mask);
+  noxyz_fwd_layer<NT, SAVE_MASK, 3>(pk, lane, c, h, mask);
+  noxyz_fwd_layer<NT, SAVE_MASK, 4>(pk, lane, c, h, mask);
   const f32x4 w0 = *reinterpret_cast<const f32x4*>(pk + P::WOUT + 4 * q);
   const f32x4 w1 = *reinterpret_cast<const f32x4*>(pk + P::WOUT + 16 + 4 * q);
   const float bo = pk[P::BOUT];
@@ -541,7 +555,56 @@ __device__ __forceinline__ void mlp_bwd(
 }
 
 // coarse decoder backward: only d/d(c) is needed (grid_coarse is the only
-// parameter optimised in the coarse stage; no pose gradient, no decoder grads)
+// parameter optimised in the coarse stage; no pose gradient, no decoder grads).
+// One layer with its index a template parameter, fragments read ahead of the
+// MFMAs like noxyz_fwd_layer.
+template <int NT, int I>
+__device__ __forceinline__ void noxyz_bwd_layer(
+    const float* __restrict__ pk, int lane, const uint64_t (&mask)[NT],
+    f32x4 (&gh)[NT][2], f32x4 (&gc)[NT][2]) {
+  using P = NoXyzPack;
+  // layer 3: tiles 0,1 -> c part, tiles 2,3 -> h part
+  constexpr int KTS = (I == 3) ? 4 : 2;
+  float a[KTS][8];
+#pragma unroll
+  for (int kt = 0; kt < KTS; ++kt)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      a[kt][s] = pk[P::wt(I) + (kt * 8 + s) * 64 + lane];
+  f32x4 ga[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ga[t][jt][r] =
+            ((mask[t] >> (I * 8 + jt * 4 + r)) & 1) ? gh[t][jt][r] : 0.f;
+  f32x4 gprev[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    gprev[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gprev[t][1] = gprev[t][0];
+  }
+#pragma unroll
+  for (int kt = 0; kt < KTS; ++kt)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (I == 3 && kt < 2)
+          gc[t][kt] = XRD_MFMA4(a[kt][s], ga[t][s >> 2][s & 3], gc[t][kt]);
+        else
+          gprev[t][kt & 1] =
+              XRD_MFMA4(a[kt][s], ga[t][s >> 2][s & 3], gprev[t][kt & 1]);
+      }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    gh[t][0] = gprev[t][0];
+    gh[t][1] = gprev[t][1];
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void noxyz_bwd(const float* __restrict__ pk,
                                           int lane, const float (&gout)[NT],
@@ -559,49 +622,11 @@ __device__ __forceinline__ void noxyz_bwd(const float* __restrict__ pk,
     gc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     gc[t][1] = gc[t][0];
   }
-#pragma unroll 1
-  for (int i = 4; i >= 0; --i) {
-    f32x4 ga[NT][2];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ga[t][jt][r] = ((mask[t] >> (i * 8 + jt * 4 + r)) & 1)
-                             ? gh[t][jt][r]
-                             : 0.f;
-    f32x4 gprev[NT][2];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      gprev[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gprev[t][1] = gprev[t][0];
-    }
-    // layer 3: tiles 0,1 -> c part, tiles 2,3 -> h part
-    const int kts = (i == 3) ? 4 : 2;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt < kts) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const float a = pk[P::wt(i) + (kt * 8 + s) * 64 + lane];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (i == 3 && kt < 2)
-              gc[t][kt] = XRD_MFMA4(a, ga[t][s >> 2][s & 3], gc[t][kt]);
-            else
-              gprev[t][kt & 1] =
-                  XRD_MFMA4(a, ga[t][s >> 2][s & 3], gprev[t][kt & 1]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      gh[t][0] = gprev[t][0];
-      gh[t][1] = gprev[t][1];
-    }
-  }
+  noxyz_bwd_layer<NT, 4>(pk, lane, mask, gh, gc);
+  noxyz_bwd_layer<NT, 3>(pk, lane, mask, gh, gc);
+  noxyz_bwd_layer<NT, 2>(pk, lane, mask, gh, gc);
+  noxyz_bwd_layer<NT, 1>(pk, lane, mask, gh, gc);
+  noxyz_bwd_layer<NT, 0>(pk, lane, mask, gh, gc);
   // layer 0 consumes c directly
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -804,31 +829,49 @@ __device__ __forceinline__ void composite_bwd(
 }
 
 // Coarse stage backward (grid_coarse is its only parameter; no pose gradient,
-// conv_onet.py:187-195): one wave = one tile, a block = one ray.
-__global__ __launch_bounds__(2 * 64, 2) void nice_bwd_coarse_kernel(
+// conv_onet.py:187-195): one wave = one tile, a block = 4 rays = 8 tile waves
+// with the decoder's fragments (forward + transposed, 50 KB) staged in LDS once
+// per block, like nice_map_coarse_kernel (rounds 1-4: one ray a block, the
+// fragments read from L2 behind every MFMA).
+constexpr int kBwdCoarseRPB = 4;
+constexpr int kBwdCoarseWaves = 2 * kBwdCoarseRPB;
+constexpr size_t kBwdCoarseLds =
+    ((size_t)NoXyzPack::LEN + kBwdCoarseWaves * (256 + kScatterFloats)) *
+    sizeof(float);
+__global__ __launch_bounds__(kBwdCoarseWaves * 64, 2) void
+nice_bwd_coarse_kernel(
     xrd_nice_scene sc, int n, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ raw,
     const double* __restrict__ g_depth, const double* __restrict__ g_var,
     const float* __restrict__ g_rgb, float* gg_coarse,
     float* __restrict__ ws) {
-  constexpr int NT = 2, S = 32;
-  __shared__ __attribute__((aligned(16))) float smem[NT * (256 + kScatterFloats)];
+  constexpr int S = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // staged fragments
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = wave >> 1, tile = wave & 1;
   const int q = lane >> 4, li = lane & 15;
-  float* R = smem + wave * (256 + kScatterFloats);
+  float* R = wl + NoXyzPack::LEN + wave * (256 + kScatterFloats);
   double* zbuf = reinterpret_cast<double*>(R);
   ScatterLds SL;
   SL.gt = R + 256;
   SL.off = reinterpret_cast<int*>(SL.gt + 16 * 33);
   SL.w = SL.gt + 16 * 33 + 16 * 8;
-  for (int ray = blockIdx.x; ray < n; ray += gridDim.x) {
+  for (int i = threadIdx.x * 4; i < NoXyzPack::LEN; i += blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(wl + i) =
+        *reinterpret_cast<const f32x4*>(sc.dec[0] + i);
+  __syncthreads();
+  const int ngroups = (n + kBwdCoarseRPB - 1) / kBwdCoarseRPB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ray = __builtin_amdgcn_readfirstlane(grp * kBwdCoarseRPB + slot);
+    if (ray >= n) continue;   // (no block barrier inside the loop)
     RayCtx rc;
     load_ray(rays_o, rays_d, nullptr, ray, false, rc);
     const double zl = sample_z<S>(sc, rc, 0.f, lane, zbuf, zbuf + 64);
     float gocc_s, w, grgb[3];
     composite_bwd<S>(raw, ray, lane, zl, g_depth, g_var, g_rgb, gocc_s, w,
                      grgb);
-    const int src = 16 * wave + li;
+    const int src = 16 * tile + li;
     TileGeom tg;
     tile_geom(rc, zbuf[64 + src], sc.bound, tg);
     float gocc = __shfl(gocc_s, src);
@@ -840,15 +883,15 @@ __global__ __launch_bounds__(2 * 64, 2) void nice_bwd_coarse_kernel(
     Tri tr;
     tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
     tri_gather(sc.grid[0], tr, q, c_a[0]);
-    noxyz_fwd<1, true>(sc.dec[0], lane, c_a, o1, mask);
-    noxyz_bwd<1>(sc.dec[0], lane, go, mask, gc);
+    noxyz_fwd<1, true>(wl, lane, c_a, o1, mask);
+    noxyz_bwd<1>(wl, lane, go, mask, gc);
     tri_prepare(tg.p64, sc.bound, sc.coarse_enlarge, sc.gdim + 0, tr);
     // coarse grid: ~1.3e3 cells and every ray starts in the camera's cell, so
-    // the atomics of 1000 rays serialise on a few lines; blocks spread over
+    // the atomics of 1000 rays serialise on a few lines; rays spread over
     // kCoarseRep private replicas (ws), summed afterwards
     float* ggc = gg_coarse;
     if (ws != nullptr && gg_coarse != nullptr)
-      ggc = ws + (size_t)(blockIdx.x & (kCoarseRep - 1)) *
+      ggc = ws + (size_t)(ray & (kCoarseRep - 1)) *
                      ((size_t)sc.gdim[0] * sc.gdim[1] * sc.gdim[2] * 32);
     grid_scatter(ggc, sc.gmask[0], tr, lane, gc[0], SL);
   }

@@ -1600,10 +1600,21 @@ static int render_bwd_impl(const xrd_nice_scene* scene, int stage, int n_rays,
   hipStream_t st = (hipStream_t)stream;
   if (stage == XRD_STAGE_COARSE) {
     if (nt != 2) return XRD_ERR_UNSUPPORTED;
-    int nb = n_rays < kMaxBwdBlocks ? n_rays : kMaxBwdBlocks;
-    hipLaunchKernelGGL(nice_bwd_coarse_kernel, dim3(nb), dim3(128), 0, st,
-                       *scene, n_rays, rays_o, rays_d, raw, g_depth, g_var,
-                       g_rgb, gg[0], ws);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(
+              reinterpret_cast<const void*>(nice_bwd_coarse_kernel),
+              hipFuncAttributeMaxDynamicSharedMemorySize,
+              (int)kBwdCoarseLds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute");
+      attr_set = true;
+    }
+    const int ngroups = (n_rays + kBwdCoarseRPB - 1) / kBwdCoarseRPB;
+    const int nb = ngroups < kMaxBwdBlocks ? ngroups : kMaxBwdBlocks;
+    hipLaunchKernelGGL(nice_bwd_coarse_kernel, dim3(nb),
+                       dim3(kBwdCoarseWaves * 64), kBwdCoarseLds, st, *scene,
+                       n_rays, rays_o, rays_d, raw, g_depth, g_var, g_rgb,
+                       gg[0], ws);
     rc = check_launch("xrd_nice_render_bwd/coarse");
     if (rc != XRD_OK) return rc;
     if (ws != nullptr && gg[0] != nullptr) {
