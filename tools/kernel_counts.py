@@ -25,7 +25,8 @@ dev = 'cuda:0'
 SPEC = {
     'nice-slam': (lambda: ic.nice_slam_config(bench.BOUND), bench.BOUND, 11,
                   None, {'track': (False, 3), 'map middle': (True, 3),
-                         'map fine': (True, 33), 'map color': (True, 53)}),
+                         'map fine': (True, 33), 'map color': (True, 53),
+                         'map coarse': (True, 3, True)}),
     'co-slam': (lambda: ic.coslam_config(bench.CO_BOUND), bench.CO_BOUND, 11,
                 None, {'track': (False, 3), 'map': (True, 3)}),
     'vox-fusion': (ic.voxfusion_config, bench.CO_BOUND, 6, bench._CvPoses,
@@ -103,7 +104,10 @@ def run(name):
 
     def wrapped(optimizers, frames, is_mapping, step, *a, **kw):
         for tag, key in targets.items():
-            if state['on'] and key == (is_mapping, step) and \
+            coarse = bool(kw['coarse']) if 'coarse' in kw else \
+                bool(a[1]) if len(a) > 1 else False
+            if state['on'] and key[:2] == (is_mapping, step) and \
+                    coarse == (len(key) > 2 and key[2]) and \
                     tag not in state['seen']:
                 torch.cuda.synchronize()
                 with profile(activities=[ProfilerActivity.CUDA,

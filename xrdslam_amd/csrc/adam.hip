@@ -27,12 +27,14 @@ __global__ __launch_bounds__(512) void adam_cells_kernel(
   // t = step_dev[0] + 1 and the LAST block to finish stores t (every block
   // has read the counter by then) — no separate increment launch
   const int t_now = step_dev ? step_dev[0] + (tick ? 1 : 0) : step_host;
-  if (threadIdx.x == 0) {
-    const int t = t_now;
-    const double bc1 = 1.0 - pow((double)beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)beta2, (double)t);
-    s_coef[0] = (float)((double)lr / bc1);
-    s_coef[1] = (float)(1.0 / sqrt(bc2));
+  // (the two f64 pow() of the bias corrections on two lanes side by side: they
+  // are a serial ~2 us each in front of a launch that updates 170 KB)
+  if (threadIdx.x < 2) {
+    const bool first = threadIdx.x == 0;
+    const double bc =
+        1.0 - pow(first ? (double)beta1 : (double)beta2, (double)t_now);
+    s_coef[threadIdx.x] =
+        first ? (float)((double)lr / bc) : (float)(1.0 / sqrt(bc));
   }
   __syncthreads();
   const float step_size = s_coef[0], inv_bc2_sqrt = s_coef[1];

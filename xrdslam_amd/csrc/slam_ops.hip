@@ -418,10 +418,11 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(
   // stores it (step_dev = {steps taken, ticket}): the last launch of a group
   // of parameters that share the counter advances it
   const int t_now = step_dev[0] + (tick ? 1 : 0);
-  if (threadIdx.x == 0) {
-    const int t = t_now;
-    coef[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
-    coef[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+  if (threadIdx.x < 2) {   // the two f64 pow() side by side (adam.hip)
+    const bool first = threadIdx.x == 0;
+    const double bc = 1.0 - pow(first ? (double)b1 : (double)b2, (double)t_now);
+    coef[threadIdx.x] =
+        first ? (float)((double)lr / bc) : (float)(1.0 / sqrt(bc));
   }
   __syncthreads();
   const float c0 = coef[0], c1 = coef[1];
