@@ -676,11 +676,13 @@ def run_voxfusion(args, dev, world=1):
             'bound': 'mfma', 'achieved': flops / (us * 1e-6) / 1e12,
             'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
             'frac': flops / (us * 1e-6) / MFMA_F32_PEAK,
-            # mean over the tracking- and mapping-sized launches of the PMC run
+            # the counter pass of THIS variant (tracking: no weight-gradient
+            # operands; mapping: with them — two kernel names since round 5)
             'traffic': pmc_traffic(
                 {'vox_dw': ['vox_dw_kernel', 'vox_dw_reduce_kernel'],
                  'vox_points_fwd': ['vox_points_fwd_kernel'],
-                 'vox_points_bwd': ['vox_points_bwd_kernel']}[kern],
+                 'vox_points_bwd': ['vox_points_bwd<dw=%s>' %
+                                    ('true' if need_w else 'false')]}[kern],
                 'r04_pmc_vox.json'),
             'traffic_source': f'profiles/{PMC_FILE[0]} (rocprofv3 --pmc '
                               'FETCH_SIZE / WRITE_SIZE passes of this '

@@ -23,6 +23,9 @@ def short_name(name):
     m = re.search(r'nice_fwd_kernel<(\d+), (\d+)(?:, \d+)?>', name)
     if m:
         return f'nice_fwd<stage={m.group(1)},NT={m.group(2)}>'
+    m = re.search(r'vox_points_bwd_kernel<(\w+)>', name)
+    if m:
+        return f'vox_points_bwd<dw={m.group(1)}>'
     m = re.search(r'coslam_bwd_kernel<(\w+), (\w+)>', name)
     if m:
         return f'coslam_bwd<dp={m.group(1)},dg={m.group(2)}>'
