@@ -484,6 +484,27 @@ int xrd_adam_cells_tick(float* param, float* g, float* m, float* v,
                         const int32_t* n_cells_dev, int zero_grad,
                         xrd_stream_t stream);
 
+/* xrd_adam_cells_tick for up to XRD_ADAM_MAX_SETS grids in ONE launch (the
+ * feature grids a mapping stage optimises share betas / eps and differ in
+ * learning rate, selection and step count: slam/engine/optimizers.py:63-171
+ * steps them one torch.optim.Adam after the other).  Same arithmetic per grid
+ * as xrd_adam_cells_tick; sets with n_cells == 0 are skipped. */
+#define XRD_ADAM_MAX_SETS 4
+typedef struct {
+  float* param;
+  float* grad;
+  float* m;
+  float* v;
+  const int32_t* cell_idx;
+  int64_t n_cells;
+  float lr;
+  int32_t* step_ticket;
+  const int32_t* n_cells_dev;
+} xrd_adam_cells_set;
+int xrd_adam_cells_multi(int n_sets, const xrd_adam_cells_set* sets,
+                         int cell_floats, float beta1, float beta2, float eps,
+                         int zero_grad, xrd_stream_t stream);
+
 /* one-time set-up of kernel attributes (dynamic LDS sizes); call once per
  * process before capturing launches into a hipGraph */
 int xrd_nice_warmup(void);

@@ -608,6 +608,65 @@ def test_fused_cell_adam_self_advancing_counter_matches_torch():
     assert torch.allclose(got, p_ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_grids_stepped_in_one_launch_equal_one_launch_each():
+    """FusedCellAdam.step_together (xrd_adam_cells_multi: the feature grids of
+    a mapping stage in ONE launch) against one xrd_adam_cells_tick launch a
+    grid: same parameters, moments and step counters bit for bit, over 4
+    steps, with different learning rates / selections / sizes, a device-side
+    count, one empty selection and one grid that skips a step"""
+    from xrdslam_amd.engine import nice as en
+    from xrdslam_amd.slam.engine.optimizers import FusedCellAdam
+    dev = _cuda()
+
+    def build():
+        torch.manual_seed(4)
+        out = []
+        for k, (shape, n_sel, lr) in enumerate(
+                (((5, 6, 7), 61, 0.01), ((9, 8, 7), 200, 0.003),
+                 ((4, 4, 4), 64, 0.02), ((3, 3, 3), 0, 0.01))):
+            p = en.to_channels_last_grid(torch.randn(1, 32, *shape,
+                                                     device=dev))
+            p.requires_grad_(True)
+            ncell = shape[0] * shape[1] * shape[2]
+            idx = torch.randperm(ncell, device=dev)[:n_sel].int() \
+                .sort().values
+            p._xrd_cells, p._xrd_cells_count = idx, None
+            if k == 1:      # capacity buffer + device-side count
+                cap = torch.zeros(ncell, dtype=torch.int32, device=dev)
+                cap[:n_sel] = idx
+                p._xrd_cells = cap
+                p._xrd_cells_count = torch.tensor([n_sel], dtype=torch.int32,
+                                                  device=dev)
+            out.append((p, FusedCellAdam([p], lr=lr, betas=(0.9, 0.999),
+                                         eps=1e-8)))
+        return out
+
+    runs = []
+    for together in (False, True):
+        grids = build()
+        torch.manual_seed(9)
+        for step in range(4):
+            for k, (p, opt) in enumerate(grids):
+                p.grad = torch.randn_like(p)
+                p._xrd_grad_fresh = not (k == 2 and step == 1)
+            if together:
+                done = FusedCellAdam.step_together([o for _, o in grids])
+                assert len(done) == len(grids)
+            else:
+                for _, o in grids:
+                    o.step()
+        torch.cuda.synchronize()
+        runs.append([(p.detach().clone(), o._m, o._v, o._step_dev)
+                     for p, o in grids])
+    for (pa, ma, va, sa), (pb, mb, vb, sb) in zip(*runs):
+        assert torch.equal(pa, pb)
+        if ma is not None:
+            assert torch.equal(ma, mb) and torch.equal(va, vb)
+            assert torch.equal(sa, sb)
+    assert [int(r[3][0]) for r in runs[1][:3]] == [4, 4, 3]
+    assert runs[1][3][3] is None        # the empty selection never stepped
+
+
 def test_fused_cell_adam_empty_selection_is_noop():
     """a frustum mask that selects no cell of a grid: the reference's Adam over
     an empty ``val[mask]`` does nothing; so must the fused one (zero-sized

@@ -28,6 +28,18 @@ class NiceScene(C.Structure):
                 ('coarse_enlarge', f64)]
 
 
+ADAM_MAX_SETS = 4   # XRD_ADAM_MAX_SETS
+
+
+class AdamCellsSet(C.Structure):
+    """xrd_adam_cells_set (include/xrdslam_hip.h)"""
+    _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p),
+                ('m', C.c_void_p), ('v', C.c_void_p),
+                ('cell_idx', C.c_void_p), ('n_cells', C.c_int64),
+                ('lr', C.c_float), ('step_ticket', C.c_void_p),
+                ('n_cells_dev', C.c_void_p)]
+
+
 class CoslamScene(C.Structure):
     """mirror of ``xrd_coslam_scene``"""
     _fields_ = [('bound', f64 * 6), ('lv_scale', f32 * 16),
@@ -98,6 +110,8 @@ _SIGS = {
                                           vp]),
     'xrd_adam_cells_tick': (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_int, f32,
                                       f32, f32, f32, vp, vp, C.c_int, vp]),
+    'xrd_adam_cells_multi': (C.c_int, [C.c_int, C.POINTER(AdamCellsSet),
+                                       C.c_int, f32, f32, f32, C.c_int, vp]),
     'xrd_nice_warmup': (C.c_int, []),
     'xrd_nice_map_ws_floats': (i64, [C.POINTER(NiceScene), C.c_int, C.c_int]),
     'xrd_nice_map_iter': (C.c_int, [C.POINTER(NiceScene), C.c_int, C.c_int,

@@ -16,7 +16,7 @@
 namespace xrd {
 namespace {
 
-__global__ __launch_bounds__(512) void adam_cells_kernel(
+__device__ __forceinline__ void adam_cells_body(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, const int32_t* __restrict__ cell_idx,
     int64_t n_cells, int vec_per_cell, float lr, float beta1, float beta2,
@@ -75,6 +75,33 @@ __global__ __launch_bounds__(512) void adam_cells_kernel(
       step_dev[0] = t_now;
     }
   }
+}
+
+__global__ __launch_bounds__(512) void adam_cells_kernel(
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, const int32_t* __restrict__ cell_idx,
+    int64_t n_cells, int vec_per_cell, float lr, float beta1, float beta2,
+    float eps, int step_host, int32_t* __restrict__ step_dev, int tick,
+    const int32_t* __restrict__ n_cells_dev, int zero_grad) {
+  adam_cells_body(p, g, m, v, cell_idx, n_cells, vec_per_cell, lr, beta1,
+                  beta2, eps, step_host, step_dev, tick, n_cells_dev,
+                  zero_grad);
+}
+
+// several grids in one launch (blockIdx.y = the grid): a mapping iteration of
+// the colour stage steps three feature grids — three launches of ~9 us each,
+// every one a short dependent chain (count -> cell list -> moments), were 10 %
+// of the iteration
+struct AdamSets {
+  xrd_adam_cells_set s[XRD_ADAM_MAX_SETS];
+};
+__global__ __launch_bounds__(512) void adam_cells_multi_kernel(
+    AdamSets a, int vec_per_cell, float beta1, float beta2, float eps,
+    int zero_grad) {
+  const xrd_adam_cells_set& s = a.s[blockIdx.y];
+  adam_cells_body(s.param, s.grad, s.m, s.v, s.cell_idx, s.n_cells,
+                  vec_per_cell, s.lr, beta1, beta2, eps, 0, s.step_ticket, 2,
+                  s.n_cells_dev, zero_grad);
 }
 
 }  // namespace
@@ -152,3 +179,34 @@ extern "C" int xrd_adam_cells_tick(float* param, float* g, float* m, float* v,
                      beta2, eps, 0, step_ticket, 2, n_cells_dev, zero_grad,
                      stream);
 }
+
+extern "C" int xrd_adam_cells_multi(int n_sets, const xrd_adam_cells_set* sets,
+                                    int cell_floats, float beta1, float beta2,
+                                    float eps, int zero_grad,
+                                    xrd_stream_t stream) {
+  if (n_sets < 0 || n_sets > XRD_ADAM_MAX_SETS || (n_sets && !sets) ||
+      cell_floats <= 0 || (cell_floats & 3))
+    return XRD_ERR_ARG;
+  xrd::AdamSets a = {};
+  int n = 0;
+  int64_t most = 0;
+  for (int i = 0; i < n_sets; ++i) {
+    const xrd_adam_cells_set& s = sets[i];
+    if (s.n_cells < 0 || !s.step_ticket || (s.n_cells_dev && !s.cell_idx))
+      return XRD_ERR_ARG;
+    if (s.n_cells == 0) continue;   // empty selection: a no-op like torch's
+    if (!s.param || !s.grad || !s.m || !s.v) return XRD_ERR_ARG;
+    a.s[n++] = s;
+    most = s.n_cells > most ? s.n_cells : most;
+  }
+  if (n == 0) return XRD_OK;
+  const int vec = cell_floats / 4;
+  int64_t blocks = (most * vec + 511) / 512;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(xrd::adam_cells_multi_kernel,
+                     dim3((unsigned)blocks, (unsigned)n), dim3(512), 0,
+                     (hipStream_t)stream, a, vec, beta1, beta2, eps,
+                     zero_grad);
+  return xrd::check_launch("xrd_adam_cells_multi");
+}
+

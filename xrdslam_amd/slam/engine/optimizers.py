@@ -77,13 +77,13 @@ class FusedCellAdam(torch.optim.Optimizer):
             for p in g['params']:
                 p._xrd_grad_fresh = False
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        from ... import _lib
+    def _launch_args(self):
+        """what this step would hand to xrd_adam_cells_tick, or None when
+        there is nothing to do (no fresh gradient, empty selection)"""
         grp = self.param_groups[0]
         p = grp['params'][0]
         if not getattr(p, '_xrd_grad_fresh', False) or p.grad is None:
-            return
+            return None
         cells = p._xrd_cells
         # static selection (persistent mapping graphs): ``cells`` is a buffer
         # with room for every cell, the valid count lives on the device
@@ -95,7 +95,7 @@ class FusedCellAdam(torch.optim.Optimizer):
             # empty frustum selection: torch's Adam over an empty val[mask]
             # does nothing (and does not advance this parameter's step)
             p._xrd_grad_fresh = False
-            return
+            return None
         if self._m is None:
             self._m = torch.zeros(n * cf, dtype=torch.float32, device=p.device)
             self._v = torch.zeros_like(self._m)
@@ -104,14 +104,67 @@ class FusedCellAdam(torch.optim.Optimizer):
             self._step_dev = torch.zeros(2, dtype=torch.int32,
                                          device=p.device)
         b1, b2 = grp['betas']
+        return dict(p=p, cells=cells, count=count, n=n, cf=cf,
+                    lr=float(grp['lr']), b1=float(b1), b2=float(b2),
+                    eps=float(grp['eps']))
+
+    def _stepped(self):
+        if not torch.cuda.is_current_stream_capturing():
+            self.param_groups[0]['params'][0]._xrd_grad_fresh = False
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from ... import _lib
+        a = self._launch_args()
+        if a is None:
+            return
+        p = a['p']
         _lib.check(_lib.lib().xrd_adam_cells_tick(
             _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(self._m),
-            _lib.ptr(self._v), _lib.ptr(cells), n, cf, float(grp['lr']),
-            float(b1), float(b2), float(grp['eps']),
-            _lib.ptr(self._step_dev), _lib.ptr(count), 1,
+            _lib.ptr(self._v), _lib.ptr(a['cells']), a['n'], a['cf'],
+            a['lr'], a['b1'], a['b2'], a['eps'],
+            _lib.ptr(self._step_dev), _lib.ptr(a['count']), 1,
             _lib.stream_ptr(p.device)), 'xrd_adam_cells_tick')
-        if not torch.cuda.is_current_stream_capturing():
-            p._xrd_grad_fresh = False
+        self._stepped()
+
+    @staticmethod
+    @torch.no_grad()
+    def step_together(opts):
+        """the steps of several grids' optimisers as ONE launch
+        (xrd_adam_cells_multi) where their cell sizes / betas / eps agree;
+        -> the optimisers this call has stepped (or found nothing to do for)"""
+        from ... import _lib
+        done, ready = [], []
+        for o in opts:
+            a = o._launch_args()
+            done.append(o)
+            if a is not None:
+                ready.append((o, a))
+        while ready:
+            o0, a0 = ready[0]
+            key = (a0['cf'], a0['b1'], a0['b2'], a0['eps'], a0['p'].device)
+            group = [(o, a) for o, a in ready
+                     if (a['cf'], a['b1'], a['b2'], a['eps'],
+                         a['p'].device) == key][:_lib.ADAM_MAX_SETS]
+            ready = [x for x in ready if all(x[0] is not g[0] for g in group)]
+            if len(group) == 1:
+                o0.step()
+                continue
+            sets = (_lib.AdamCellsSet * len(group))()
+            for k, (o, a) in enumerate(group):
+                p = a['p']
+                sets[k].param, sets[k].grad = _lib.ptr(p), _lib.ptr(p.grad)
+                sets[k].m, sets[k].v = _lib.ptr(o._m), _lib.ptr(o._v)
+                sets[k].cell_idx = _lib.ptr(a['cells'])
+                sets[k].n_cells, sets[k].lr = a['n'], a['lr']
+                sets[k].step_ticket = _lib.ptr(o._step_dev)
+                sets[k].n_cells_dev = _lib.ptr(a['count'])
+            _lib.check(_lib.lib().xrd_adam_cells_multi(
+                len(group), sets, a0['cf'], a0['b1'], a0['b2'], a0['eps'], 1,
+                _lib.stream_ptr(a0['p'].device)), 'xrd_adam_cells_multi')
+            for o, _ in group:
+                o._stepped()
+        return done
 
 
 def reset_optimizer_state(opt: torch.optim.Optimizer) -> None:
@@ -186,7 +239,16 @@ class Optimizers:
                 getattr(self, 'parameters', None) and \
                 getattr(self, 'allreduce', False):
             _dist.allreduce_param_grads(self.stepping_parameters(step))
+        # the feature grids of a stage step in one launch
+        together = [opt for name, opt in self.optimizers.items()
+                    if isinstance(opt, FusedCellAdam) and
+                    self.config[name]['optimizer'].max_norm is None and
+                    self.config[name]['optimizer'].accum_step is None]
+        stepped = FusedCellAdam.step_together(together) \
+            if len(together) > 1 else []
         for name, opt in self.optimizers.items():
+            if any(opt is o for o in stepped):
+                continue
             ocfg = self.config[name]['optimizer']
             if ocfg.max_norm is not None:
                 torch.nn.utils.clip_grad_norm_(self.parameters[name],
