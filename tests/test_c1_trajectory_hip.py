@@ -24,7 +24,7 @@ import c1_util
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['coslam', 'voxfusion', 'nice', 'pointslam', 'splatam']
+CASES = ["coslam", "voxfusion", "nice", "pointslam", "splatam"]
 
 
 def _have(name):
