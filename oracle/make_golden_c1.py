@@ -14,6 +14,13 @@ ATE statistics to the reference's.
     python oracle/make_golden_c1.py voxfusion
     python oracle/make_golden_c1.py pointslam
     python oracle/make_golden_c1.py nice
+    python oracle/make_golden_c1.py splatam     # 50 min a seed (4 frames 64x48:
+                                                # the rasteriser is the dense
+                                                # checker); the committed file
+                                                # was made with the three seeds
+                                                # side by side: C1_ONLY_SEED=k
+                                                # C1_OUT=/tmp/c1_splatam_k.npz
+                                                # C1_THREADS=2, then merged
     -> tests/golden/c1_<algo>.npz
 
 co-slam = BASELINE config 1: 64 frames, 320x240, hash grid + 2x32 MLPs, the
