@@ -484,10 +484,12 @@ def decoder_weight_grad(scene: NiceScene, kind: str, flat: torch.Tensor,
 # bound by ONE block's dependent chain (three decoders forward, three
 # backward, six staging barriers), not by throughput, and dropping the
 # backward's forward recompute saves less than the grid barrier and the
-# 12-wave blocks cost.  The lever for this batch size is depth, not launches:
-# the three decoders of a tile on three waves at once.
+# 12-wave blocks cost.  The lever for this batch size was depth, not launches:
+# the three decoders of a tile on three blocks at once, 8 tile waves a block
+# (round 5, DESIGN 4.1d: the three-launch chain is 28 + 9 + 31 us now).
 TRACK_ONE_LAUNCH = False
-# the tracking forward keeps the decoders' ReLU masks for the backward
+# the tracking pair: one decoder per block, forward and backward; the forward
+# keeps the decoders' ReLU masks for the backward
 # (xrd_nice_render_fwd_masks / _bwd_masks: colour stage, <= 340 rays)
 TRACK_KEEP_MASKS = True
 TRACK_MASKS_MAX_RAYS = 340
