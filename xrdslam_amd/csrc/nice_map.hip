@@ -993,41 +993,57 @@ __global__ __launch_bounds__(kCoarseWaves * 64, 2) void nice_map_coarse_kernel(
 // (left zeroed for the next call: 64 columns a block, the rows split over its
 // four waves), ray gradients = sum of the ray's tile partials in a fixed
 // order, loss = sum of the per-ray losses (last block)
-__global__ __launch_bounds__(256) void nice_map_finish_kernel(
+constexpr int kFinishThreads = 1024;
+__global__ __launch_bounds__(kFinishThreads) void nice_map_finish_kernel(
     float* __restrict__ rep, int n_rep, int len, int dec_blocks,
     float* __restrict__ g_dec, const double* __restrict__ part, int n_dp,
     int nt, float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
     const double* __restrict__ ray_loss, int n, double* __restrict__ loss) {
   __shared__ double sh[4];
-  __shared__ float shf[4][64];
+  __shared__ float shf[kFinishThreads / 64][64];
   if (blockIdx.x == gridDim.x - 1) {
+    // (four waves, as ever: the loss keeps its summation order)
     double s = 0.0;
-    if (ray_loss != nullptr)
+    if (ray_loss != nullptr && threadIdx.x < 256)
       for (int i = threadIdx.x; i < n; i += 256) s += ray_loss[i];
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256)
+      sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0 && loss != nullptr)
       loss[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
     return;
   }
   if ((int)blockIdx.x < dec_blocks) {
+    // 64 columns a block, the blocks' partial rows split over its 16 waves
+    // (round 4: over 4 waves — a chain of 64 load / store pairs a thread,
+    // 12 us for the colour decoder's 250 x 15899 floats)
+    constexpr int W = kFinishThreads / 64;
     const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c;
     float s = 0.f;
     if (i < len) {
 #pragma unroll 4
-      for (int r = w; r < n_rep; r += 4) {
+      for (int r = w; r < n_rep; r += W) {
         s += rep[(size_t)r * len + i];
         rep[(size_t)r * len + i] = 0.f;
       }
     }
     shf[w][c] = s;
     __syncthreads();
-    if (w == 0 && i < len)
-      g_dec[i] = (shf[0][c] + shf[1][c]) + (shf[2][c] + shf[3][c]);
+    if (w == 0 && i < len) {
+      float t[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) t[k] = shf[k][c];
+#pragma unroll
+      for (int span = W / 2; span >= 1; span >>= 1)
+#pragma unroll
+        for (int k = 0; k < span; ++k) t[k] = t[2 * k] + t[2 * k + 1];
+      g_dec[i] = t[0];
+    }
     return;
   }
+  if (threadIdx.x >= 256) return;   // 256 partial-row sums a block, as before
   const int j = ((int)blockIdx.x - dec_blocks) * 256 + threadIdx.x;
   if (j >= n_dp * 6) return;
   const int ray = j / 6, a = j % 6;
@@ -1311,7 +1327,8 @@ int xrd_nice_map_iter_export(const xrd_nice_scene* scene, int stage,
   const int dec_blocks = (len + 63) / 64;
   const int ray_blocks = dp ? (n_rays * 6 + 255) / 256 : 0;
   hipLaunchKernelGGL(nice_map_finish_kernel,
-                     dim3(dec_blocks + ray_blocks + 1), dim3(256), 0, st,
+                     dim3(dec_blocks + ray_blocks + 1), dim3(kFinishThreads),
+                     0, st,
                      dw_rep, nb_map, len, dec_blocks, g_dec_color, part,
                      dp ? n_rays : 0, 3, g_rays_o, g_rays_d, ray_loss, n_rays,
                      loss);
