@@ -769,7 +769,8 @@ def test_tracking_loss_median_both_selection_paths(n, masked):
     assert torch.equal(rgb.grad, rgb2.grad)
 
 
-@pytest.mark.parametrize('n,masked', [(200, False), (333, True), (340, False)])
+@pytest.mark.parametrize('n,masked', [(200, False), (333, True), (340, False),
+                                      (5, False), (227, True), (228, False)])
 def test_tracking_backward_from_the_forwards_masks(n, masked):
     """xrd_nice_render_fwd_masks / _bwd_masks (the forward keeps the decoders'
     ReLU masks, the decoder-per-block backward skips its forward recompute)
