@@ -30,36 +30,44 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(
     float* __restrict__ tgt_rgb, uint8_t* __restrict__ keep,
     float* __restrict__ dmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const int64_t k = idx[i];
-  const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
-  const int64_t pix = (int64_t)row * a.W + col;
-  const float d = depth_img[pix];
-  const float dir[3] = {((float)col - a.cx) / a.fx, -((float)row - a.cy) / a.fy,
-                        -1.f};
-  float o[3], rd[3];
+  // the batch's largest kept depth: one atomic a WAVE (every kept ray issuing
+  // its own was ~1000 same-address atomics a launch, ~12 ns each)
+  float d_kept = 0.f;
+  if (i < a.n) {
+    const int64_t k = idx[i];
+    const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
+    const int64_t pix = (int64_t)row * a.W + col;
+    const float d = depth_img[pix];
+    const float dir[3] = {((float)col - a.cx) / a.fx, -((float)row - a.cy) / a.fy,
+                          -1.f};
+    float o[3], rd[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    rd[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] +
-            dir[2] * c2w[r * 4 + 2];
-    o[r] = c2w[r * 4 + 3];
-    rays_o[i * 3 + r] = o[r];
-    rays_d[i * 3 + r] = rd[r];
-    tgt_rgb[i * 3 + r] = rgb_img[pix * 3 + r];
-  }
-  tgt_d[i] = d;
-  // rays whose sensor depth lies beyond the bound are dropped
-  double t_exit = 1e300;
+    for (int r = 0; r < 3; ++r) {
+      rd[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] +
+              dir[2] * c2w[r * 4 + 2];
+      o[r] = c2w[r * 4 + 3];
+      rays_o[i * 3 + r] = o[r];
+      rays_d[i * 3 + r] = rd[r];
+      tgt_rgb[i * 3 + r] = rgb_img[pix * 3 + r];
+    }
+    tgt_d[i] = d;
+    // rays whose sensor depth lies beyond the bound are dropped
+    double t_exit = 1e300;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const double t0 = (a.bound[2 * r] - (double)o[r]) / (double)rd[r];
-    const double t1 = (a.bound[2 * r + 1] - (double)o[r]) / (double)rd[r];
-    t_exit = fmin(t_exit, fmax(t0, t1));
+    for (int r = 0; r < 3; ++r) {
+      const double t0 = (a.bound[2 * r] - (double)o[r]) / (double)rd[r];
+      const double t1 = (a.bound[2 * r + 1] - (double)o[r]) / (double)rd[r];
+      t_exit = fmin(t_exit, fmax(t0, t1));
+    }
+    const bool kp = t_exit >= (double)d;
+    keep[i] = kp ? 1 : 0;
+    if (kp && d > 0.f) d_kept = d;
   }
-  const bool kp = t_exit >= (double)d;
-  keep[i] = kp ? 1 : 0;
-  if (kp && d > 0.f && dmax)
-    atomicMax(reinterpret_cast<int*>(dmax), __float_as_int(d));
+  if (dmax) {
+    const float m = wave_max(d_kept);
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+      atomicMax(reinterpret_cast<int*>(dmax), __float_as_int(m));
+  }
 }
 
 // g_c2w[r][k] = sum_i g_rays_d[i][r] * dir_i[k];  g_c2w[r][3] = sum_i g_rays_o[i][r]
@@ -331,36 +339,42 @@ __global__ __launch_bounds__(256) void sample_rays_multi_kernel(
 #pragma unroll
     for (int k = 0; k < 16; ++k) c2w_out[f * 16 + k] = c2w[k];
   }
-  if (i >= a.n) return;
-  const int64_t g = (int64_t)f * a.n + i;
-  const int64_t k = idx[g];
-  const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
-  const int64_t pix = (int64_t)row * a.W + col;
-  const float d = fr.depth[f][pix];
-  const float dir[3] = {((float)col - a.cx) / a.fx, -((float)row - a.cy) / a.fy,
-                        -1.f};
-  float o[3], rd[3];
+  float d_kept = 0.f;   // one dmax atomic a wave (sample_rays_kernel)
+  if (i < a.n) {
+    const int64_t g = (int64_t)f * a.n + i;
+    const int64_t k = idx[g];
+    const int row = a.H0 + (int)(k / a.wcrop), col = a.W0 + (int)(k % a.wcrop);
+    const int64_t pix = (int64_t)row * a.W + col;
+    const float d = fr.depth[f][pix];
+    const float dir[3] = {((float)col - a.cx) / a.fx, -((float)row - a.cy) / a.fy,
+                          -1.f};
+    float o[3], rd[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    rd[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] +
-            dir[2] * c2w[r * 4 + 2];
-    o[r] = c2w[r * 4 + 3];
-    rays_o[g * 3 + r] = o[r];
-    rays_d[g * 3 + r] = rd[r];
-    tgt_rgb[g * 3 + r] = fr.rgb[f][pix * 3 + r];
-  }
-  tgt_d[g] = d;
-  double t_exit = 1e300;
+    for (int r = 0; r < 3; ++r) {
+      rd[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] +
+              dir[2] * c2w[r * 4 + 2];
+      o[r] = c2w[r * 4 + 3];
+      rays_o[g * 3 + r] = o[r];
+      rays_d[g * 3 + r] = rd[r];
+      tgt_rgb[g * 3 + r] = fr.rgb[f][pix * 3 + r];
+    }
+    tgt_d[g] = d;
+    double t_exit = 1e300;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const double t0 = (a.bound[2 * r] - (double)o[r]) / (double)rd[r];
-    const double t1 = (a.bound[2 * r + 1] - (double)o[r]) / (double)rd[r];
-    t_exit = fmin(t_exit, fmax(t0, t1));
+    for (int r = 0; r < 3; ++r) {
+      const double t0 = (a.bound[2 * r] - (double)o[r]) / (double)rd[r];
+      const double t1 = (a.bound[2 * r + 1] - (double)o[r]) / (double)rd[r];
+      t_exit = fmin(t_exit, fmax(t0, t1));
+    }
+    const bool kp = t_exit >= (double)d;
+    keep[g] = kp ? 1 : 0;
+    if (kp && d > 0.f) d_kept = d;
   }
-  const bool kp = t_exit >= (double)d;
-  keep[g] = kp ? 1 : 0;
-  if (kp && d > 0.f && dmax)
-    atomicMax(reinterpret_cast<int*>(dmax), __float_as_int(d));
+  if (dmax) {
+    const float m = wave_max(d_kept);
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+      atomicMax(reinterpret_cast<int*>(dmax), __float_as_int(m));
+  }
 }
 
 // block f: g_c2w of frame f (like sample_rays_bwd_kernel), then its pose

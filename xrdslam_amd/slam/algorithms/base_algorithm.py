@@ -37,7 +37,8 @@ from ..models.base_model import ModelConfig
 
 class _capture(torch.cuda.graph):
     """hipGraph capture context of the frame loops: ``torch.cuda.graph`` with
-    two changes.
+    three changes (the third: no cyclic garbage collection inside a capture,
+    see __enter__).
 
     * capture mode 'thread_local': the frame prefetcher
       (data/datasets.Prefetcher) allocates pinned memory and issues copies on
@@ -73,12 +74,27 @@ class _capture(torch.cuda.graph):
                 gc.collect()    # once, like the stock context does per entry
 
     def __enter__(self):
+        # no cyclic-GC pass while the stream captures: a collection that frees
+        # a graph / event of an earlier frame inside the capture aborts the
+        # process (the stock context runs gc.collect() in front of every
+        # capture instead — tens of ms with the frame objects alive here)
+        import gc
+        self._gc_was = gc.isenabled()
+        gc.disable()
         if not _capture._checked:
             return super().__enter__()
         torch.cuda.synchronize()
         self.stream_ctx.__enter__()
         self.cuda_graph.capture_begin(
             *self.pool, capture_error_mode=self.capture_error_mode)
+
+    def __exit__(self, *exc):
+        try:
+            return super().__exit__(*exc)
+        finally:
+            if self._gc_was:
+                import gc
+                gc.enable()
 
 
 @dataclass
