@@ -304,9 +304,16 @@ class SparseVoxel(Model):
                                            device=dev)}
             self._map_buf = buf
             self.capacity_version += 1
-        buf['vertex'][:T].copy_(features.to(dev), non_blocking=True)
-        buf['centres'][:T].copy_(centres.float().to(dev), non_blocking=True)
-        buf['structure'][:T].copy_(children.int().to(dev), non_blocking=True)
+        # ONE upload of the three host arrays (each pageable host->device copy
+        # is a host wait: three a frame): [T, 8 + 3 + 9] int32 with the
+        # centres' float bits, split on the device
+        packed = torch.cat([features.int(),
+                            centres.float().contiguous().view(torch.int32),
+                            children.int()], 1).to(dev)
+        buf['vertex'][:T].copy_(packed[:, :8])
+        buf['centres'][:T].copy_(packed[:, 8:11].contiguous()
+                                 .view(torch.float32))
+        buf['structure'][:T].copy_(packed[:, 11:20])
         state = {'voxel_vertex_idx': buf['vertex'][:T],
                  'voxel_center_xyz': buf['centres'][:T],
                  'voxel_structure': buf['structure'][:T],
