@@ -62,10 +62,13 @@ SEQ = {
                       W=320, fx=160.0, fy=160.0, cx=159.5, cy=119.5,
                       n_frames=24),
     # 160x120, ~5 mm a frame (the pace NICE-SLAM's 10 tracking iterations at
-    # lr 1e-3 follow), office0 bounds of the reference's nice-slam config
+    # lr 1e-3 follow), office0 bounds of the reference's nice-slam config.
+    # 60 frames = 24.7 cm of path (round 5 ran 11 frames = 4.8 cm: a pose
+    # frozen at frame 0 scored better than the tracker, i.e. the fixture
+    # could not tell tracking from standing still; tools/c1_regime.py)
     'nice': dict(bound=[[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]], H=120, W=160,
                  fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=600, shrink=0.3,
-                 run_frames=11),
+                 run_frames=60),
     'pointslam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=120,
                       W=160, fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=200,
                       run_frames=8),
@@ -403,8 +406,10 @@ def nice():
     out = _header(s)
     cfg0 = copy.deepcopy(x.algorithm)
     cfg0.mapping_bound = cfg0.marching_cubes_bound = s['bound']
-    _reduced(out, cfg0, tracking_Hedge=10, tracking_Wedge=10,
-             mapping_first_n_iters=150, mapping_n_iters=30)
+    # the reference's iteration counts (1500 first, 60 a mapping call, 10
+    # tracking iterations x 200 rays); only the pixel border the tracker
+    # avoids is scaled with the image (100 px of 480 -> 10 px of 120)
+    _reduced(out, cfg0, tracking_Hedge=10, tracking_Wedge=10)
 
     def make():
         return copy.deepcopy(cfg0).setup(camera=cam, device='cpu')
@@ -536,14 +541,22 @@ def splatam():
 
 
 def _per_seed_processes(which):
-    """run every seed in its own process, merge the per-seed files"""
+    """run every seed in its own process (C1_PARALLEL=1: side by side, each
+    with C1_THREADS threads), merge the per-seed files"""
     import subprocess
     merged = None
+    procs = []
     for seed in range(N_SEEDS):
         tmp = os.path.join('/tmp', f'c1_{which}_{seed}.npz')
         env = dict(os.environ, C1_ONLY_SEED=str(seed), C1_OUT=tmp)
-        subprocess.run([sys.executable, os.path.abspath(__file__), which],
-                       env=env, check=True)
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__),
+                              which], env=env)
+        procs.append((p, tmp))
+        if not os.environ.get('C1_PARALLEL'):
+            p.wait()
+    for p, tmp in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'{which}: a seed run failed')
         g = dict(np.load(tmp))
         merged = g if merged is None else {**merged, **g}
         np.savez_compressed(_target(), **merged)   # keep what is done

@@ -119,6 +119,8 @@ def run_engine(name, seed, dev='cuda', n_frames=None, configure=None,
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     sec = time.perf_counter() - t0
+    from xrdslam_amd.slam.common.frame import Frame
+    Frame.raise_if_inconsistent()   # the deferred initial-pose check
     est = torch.stack([p.detach().cpu().float() for p in
                        algo.get_estimate_c2w_list()[:n]]).numpy()
     gt = torch.stack([p.cpu().float() for p in

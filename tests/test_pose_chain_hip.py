@@ -152,3 +152,24 @@ def test_initial_pose_check_of_device_poses_is_deferred_not_dropped():
     with pytest.raises(ValueError):
         Frame.raise_if_inconsistent()      # ... raised here
     Frame.raise_if_inconsistent()          # and cleared
+
+
+def test_nan_initial_pose_is_not_erased_by_the_next_frame():
+    """the deviation is folded over frames into ONE device float: a NaN pose at
+    frame k must survive frame k+1's launch with a finite deviation (a plain
+    ``!(e <= err)`` update lets the finite value overwrite the NaN)"""
+    from xrdslam_amd.slam.common.frame import Frame
+    d = np.ones((4, 6), np.float32)
+    c = np.zeros((4, 6, 3), np.float32)
+    Frame.raise_if_inconsistent()
+    good = torch.from_numpy(_rigid(np.random.default_rng(5))).to(DEV)
+    bad = good.clone()
+    bad[0, 0] = float('nan')
+    for rep in ('quat', 'axis_angle'):
+        Frame(1, c, d, init_pose=bad, separate_LR=True, rot_rep=rep,
+              device=DEV)
+        Frame(2, c, d, init_pose=good, separate_LR=True, rot_rep=rep,
+              device=DEV)
+        with pytest.raises(ValueError):
+            Frame.raise_if_inconsistent()
+        Frame.raise_if_inconsistent()      # cleared

@@ -1,5 +1,10 @@
 """summarise rocprofv3 --pmc counter_collection.csv: mean counter value per
-kernel (our kernels only).  usage: pmc_summary.py <csv> <COUNTER> [json_out]"""
+kernel (our kernels only).
+usage: pmc_summary.py <csv> "<COUNTER> [<COUNTER> ...]" [json_out] [kernel_trace.csv]
+With a kernel trace of the same run the mean launch duration [ns] of every
+kernel is added under "_duration_ns" (what the SQ cycle counters of a
+profiled pass are divided by: the counters and the duration come from the SAME
+launches)."""
 import collections
 import csv
 import json
@@ -7,7 +12,6 @@ import re
 import sys
 
 path, counter = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(list)
 
 
 def short_name(name):
@@ -62,16 +66,32 @@ def short_name(name):
     return None
 
 
+counters = counter.split()
+acc = {c: collections.defaultdict(list) for c in counters}
 for r in csv.DictReader(open(path)):
-    if r.get('Counter_Name') != counter:
+    c = r.get('Counter_Name')
+    if c not in acc:
         continue
     s = short_name(r['Kernel_Name'])
     if s is not None:
-        acc[s].append(float(r['Counter_Value']))
-out = {}
-for k, v in sorted(acc.items()):
-    out[k] = {'launches': len(v), 'mean': sum(v) / len(v), 'max': max(v)}
-    print(f'{k:48s} launches={len(v):5d} mean_{counter}={sum(v)/len(v):14.1f} '
-          f'max={max(v):14.1f}')
+        acc[c][s].append(float(r['Counter_Value']))
+res = {}
+for c in counters:
+    out = {}
+    for k, v in sorted(acc[c].items()):
+        out[k] = {'launches': len(v), 'mean': sum(v) / len(v), 'max': max(v)}
+        print(f'{k:48s} launches={len(v):5d} mean_{c}={sum(v)/len(v):14.1f} '
+              f'max={max(v):14.1f}')
+    res[c] = out
+if len(sys.argv) > 4 and sys.argv[4]:
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[4])):
+        s = short_name(r['Kernel_Name'])
+        if s is not None:
+            dur[s].append(float(r['End_Timestamp']) -
+                          float(r['Start_Timestamp']))
+    res['_duration_ns_' + counters[0]] = {
+        k: {'launches': len(v), 'mean': sum(v) / len(v)}
+        for k, v in sorted(dur.items())}
 if len(sys.argv) > 3:
-    json.dump({counter: out}, open(sys.argv[3], 'w'), indent=1)
+    json.dump(res, open(sys.argv[3], 'w'), indent=1)

@@ -149,6 +149,35 @@ __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
   sn = (n & 2) ? -a : a;
   cs = ((n + 1) & 2) ? -b : b;
 }
+// sin_cw(x) in four stages of ~7 VALU instructions each (the same operations
+// in the same order as sincos_cw: bit-identical), so that a caller can place
+// one MFMA between two stages — a K-step of the Fourier embedding is one sine
+// and 4 MFMAs (nice_device.h: mlp_fwd_ra)
+struct SinStages {
+  float k, r, s, ps, pc, sr, cr;
+};
+__device__ __forceinline__ void sin_stage_a(float x, SinStages& t) {
+  t.k = rintf(x * 0.636619772367581f);
+  float r = fmaf(t.k, -1.57079601e+00f, x);
+  r = fmaf(t.k, -3.13916473e-07f, r);
+  t.r = fmaf(t.k, -5.39030253e-15f, r);
+}
+__device__ __forceinline__ void sin_stage_b(SinStages& t) {
+  t.s = t.r * t.r;
+  float ps = fmaf(t.s, -1.9515295891e-4f, 8.3321608736e-3f);
+  t.ps = fmaf(t.s, ps, -1.6666654611e-1f);
+  float pc = fmaf(t.s, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  t.pc = fmaf(t.s, pc, 4.166664568298827e-2f);
+}
+__device__ __forceinline__ void sin_stage_c(SinStages& t) {
+  t.sr = fmaf(t.r * t.s, t.ps, t.r);
+  t.cr = fmaf(t.s * t.s, t.pc, fmaf(t.s, -0.5f, 1.0f));
+}
+__device__ __forceinline__ float sin_stage_d(const SinStages& t) {
+  const int n = (int)t.k & 3;
+  const float a = (n & 1) ? t.cr : t.sr;
+  return (n & 2) ? -a : a;
+}
 __device__ __forceinline__ float sin_cw(float x) {
   float s, c;
   sincos_cw(x, s, c);

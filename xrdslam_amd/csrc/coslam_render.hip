@@ -489,11 +489,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam
   // (level stride of dfeat: the samples + the extra points appended behind
   // them for the merged table scatter)
   const size_t n_samples = (size_t)n_rays * S + (size_t)n_extra;
-#ifdef XRD_CS_NO_DW  // experiment switch
-  constexpr bool DW = false;
-#else
   constexpr bool DW = DG;
-#endif
   float* T = lds + wave * kStage;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 dw0[2][5], dw1[1][2], dw2[2][4], dw3[1][2];

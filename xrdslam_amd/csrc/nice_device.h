@@ -344,6 +344,183 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
   }
 }
 
+// mlp_fwd for one tile a wave with the A fragments READ AHEAD (round 6, the
+// mapping kernel).  mlp_fwd leaves the placement of its ds_read_b32 to the
+// compiler, which keeps each group of reads right in front of the MFMAs that
+// consume it: an exposed LDS round trip per group of 8-16 MFMAs, and after a
+// staging barrier the three waves of a SIMD run in step, so all of them wait
+// at the same time (phase stamps, tools/nice_map_stamps.py: the slowest wave
+// of a block needs 17 / 21 / 18 us for the middle / fine / colour forward
+// against 9.6 / 13.4 / 9.6 us of MFMA issue).  Here the layer loop is
+// unrolled and every batch of fragments is requested one MFMA batch early:
+// fc_c.(i+1)'s fragments before the 16 MFMAs of pts_linears.(i+1), those of
+// pts_linears.(i+2) before the MFMAs of fc_c.(i+1).  Same MFMA order per
+// accumulator as mlp_fwd: bit-identical results.
+template <int CD, int OD, bool SAVE_MASK, bool EMIT_H>
+__device__ __forceinline__ void mlp_fwd_ra(const float* __restrict__ pk,
+                                           int lane, const float (&p)[3],
+                                           const f32x4 (&c)[CD / 16],
+                                           float (&out)[OD], uint64_t& mask,
+                                           float* __restrict__ hsc) {
+  using P = MlpPack<CD, OD>;
+  constexpr int KC = P::KC;
+  const int q = lane >> 4;
+  f32x4 acc[2], acc3[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    acc[jt] =
+        *reinterpret_cast<const f32x4*>(pk + P::B + 0 * 32 + 16 * jt + 4 * q);
+    acc3[jt] =
+        *reinterpret_cast<const f32x4*>(pk + P::B + 3 * 32 + 16 * jt + 4 * q);
+  }
+  // Fourier embedding feeds layer 0 and the skip part of layer 3.  A K-step
+  // is one sine (~26 VALU instructions) and 4 MFMAs; written step by step a
+  // wave runs "26 VALU, then 4 MFMAs" and the three waves of a SIMD, in step
+  // behind the staging barrier, do not fill each other's gaps (stamps: the 96
+  // MFMAs of this loop took as long as the 144 of the layers).  So the loop
+  // is software-pipelined by hand — step s+1's sine is computed in the
+  // shadow of step s's MFMAs, fragments and B rows are requested a step
+  // ahead — with one MFMA between two stages of the sine (sin_stage_a..d).
+  // (EMB row 96 + q of the last step's look-ahead lies in the WOUT rows
+  // behind the table: a finite dummy whose sine is never used)
+  f32x4 bkn = *reinterpret_cast<const f32x4*>(pk + P::EMB + emap(1, q) * 4);
+  float e = sin_cw(embed_arg(
+      p, *reinterpret_cast<const f32x4*>(pk + P::EMB + emap(0, q) * 4)));
+  float a0[2], a3[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    a0[jt] = pk[P::W0 + (jt * kEmbS) * 64 + lane];
+    a3[jt] = pk[P::W3E + (jt * kEmbS) * 64 + lane];
+  }
+  XRD_SB();
+#pragma unroll 4
+  for (int s = 0; s < kEmbS; ++s) {
+    const int sn = s + 1 < kEmbS ? s + 1 : s;   // (last step: re-read, unused)
+    float n0[2], n3[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      n0[jt] = pk[P::W0 + (jt * kEmbS + sn) * 64 + lane];
+      n3[jt] = pk[P::W3E + (jt * kEmbS + sn) * 64 + lane];
+    }
+    const f32x4 bk2 =
+        *reinterpret_cast<const f32x4*>(pk + P::EMB + emap(s + 2, q) * 4);
+    // one MFMA of step s, one stage of step s+1's sine, ... (full scheduling
+    // fences: the order below is the issue order)
+    SinStages st;
+    XRD_SB();
+    acc[0] = XRD_MFMA4(a0[0], e, acc[0]);
+    XRD_SB();
+    sin_stage_a(embed_arg(p, bkn), st);
+    XRD_SB();
+    acc3[0] = XRD_MFMA4(a3[0], e, acc3[0]);
+    XRD_SB();
+    sin_stage_b(st);
+    XRD_SB();
+    acc[1] = XRD_MFMA4(a0[1], e, acc[1]);
+    XRD_SB();
+    sin_stage_c(st);
+    XRD_SB();
+    acc3[1] = XRD_MFMA4(a3[1], e, acc3[1]);
+    XRD_SB();
+    const float en = sin_stage_d(st);
+    XRD_SB();
+    e = en;
+    bkn = bk2;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      a0[jt] = n0[jt];
+      a3[jt] = n3[jt];
+    }
+  }
+  float ac[2][KC];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int s = 0; s < KC; ++s)
+      ac[jt][s] = pk[P::wc(0) + (jt * KC + s) * 64 + lane];
+  XRD_SB();
+  f32x4 h[2];
+  mask = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    // (accumulator start values are read BEFORE a batch of fragments is
+    // requested: LDS reads return in order, a bias read behind the batch
+    // would make its consumer wait for the whole batch)
+    f32x4 cc[2], accn[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      cc[jt] = *reinterpret_cast<const f32x4*>(pk + P::BC + i * 32 + 16 * jt +
+                                               4 * q);
+      if (i < 4 && i + 1 != 3)
+        accn[jt] = *reinterpret_cast<const f32x4*>(pk + P::B + (i + 1) * 32 +
+                                                   16 * jt + 4 * q);
+    }
+    float ah[2][8];
+    if (i < 4) {  // pts_linears.(i+1): lands under the MFMAs of fc_c.i
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          ah[jt][s] = pk[P::wh(i + 1) + (jt * 8 + s) * 64 + lane];
+    }
+    XRD_SB();
+#pragma unroll
+    for (int s = 0; s < KC; ++s)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+        cc[jt] = XRD_MFMA4(ac[jt][s], c[s >> 2][s & 3], cc[jt]);
+    XRD_SB();
+    if (i < 4) {  // fc_c.(i+1): lands under the MFMAs of pts_linears.(i+1)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int s = 0; s < KC; ++s)
+          ac[jt][s] = pk[P::wc(i + 1) + (jt * KC + s) * 64 + lane];
+    }
+    uint32_t m8 = 0;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = acc[jt][r];
+        if (SAVE_MASK && a > 0.f) m8 |= 1u << (jt * 4 + r);
+        h[jt][r] = fmaxf(a, 0.f) + cc[jt][r];
+      }
+      if (EMIT_H) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          hsc[i * 512 + (16 * jt + 4 * q + r) * 16 + (lane & 15)] = h[jt][r];
+      }
+    }
+    if (SAVE_MASK) mask |= (uint64_t)m8 << (i * 8);
+    if (i < 4) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+        acc[jt] = (i + 1 == 3) ? acc3[jt] : accn[jt];
+      XRD_SB();
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          acc[jt] = XRD_MFMA4(ah[jt][s], h[s >> 2][s & 3], acc[jt]);
+      XRD_SB();
+    }
+  }
+  // output layer on the VALU + reduction over the 4 lane groups
+#pragma unroll
+  for (int o = 0; o < OD; ++o) {
+    const f32x4 w0 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 4 * q);
+    const f32x4 w1 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 16 + 4 * q);
+    const float bo = pk[P::BOUT + o];
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v += w0[r] * h[0][r] + w1[r] * h[1][r];
+    out[o] = group4_sum(v) + bo;
+  }
+}
+
 // MLP_no_xyz (coarse, decoder_nice.py:308-320): h=c; 5x(Linear+ReLU), skip
 // cat[c,h] after layer 2; Linear(32,1).
 // One layer, its index a template parameter: the layer's A fragments (16 or
@@ -548,6 +725,141 @@ __device__ __forceinline__ void mlp_bwd(
 #pragma unroll
             for (int a = 0; a < 3; ++a) gp[t][a] += garg * bk[a];
           }
+        }
+      }
+    }
+  }
+}
+
+// mlp_bwd for one tile a wave with the A fragments read ahead (round 6, see
+// mlp_fwd_ra): the layer loop is unrolled; pts_linears.i's transposed
+// fragments are requested before the MFMAs of fc_c.i's, fc_c.(i-1)'s before
+// the MFMAs of pts_linears.i; the embedding backward requests column tile
+// kt+1 before the MFMAs of tile kt.  Same MFMA order per accumulator as
+// mlp_bwd: bit-identical results.
+template <int CD, int OD, bool NEED_E, bool NEED_DP>
+__device__ __forceinline__ void mlp_bwd_ra(
+    const float* __restrict__ pk, int lane, const float (&p)[3],
+    const float (&gout)[OD], const uint64_t mask, f32x4 (&gc)[CD / 16],
+    float (&gp)[3]) {
+  using P = MlpPack<CD, OD>;
+  constexpr int KTC = P::KTC;
+  const int q = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gh[2] = {z4, z4};
+#pragma unroll
+  for (int kt = 0; kt < KTC; ++kt) gc[kt] = z4;
+  float awc[KTC][8];
+#pragma unroll
+  for (int kt = 0; kt < KTC; ++kt)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      awc[kt][s] = pk[P::wct(4) + (kt * 8 + s) * 64 + lane];
+#pragma unroll
+  for (int o = 0; o < OD; ++o) {
+    const f32x4 w0 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 4 * q);
+    const f32x4 w1 =
+        *reinterpret_cast<const f32x4*>(pk + P::WOUT + o * 32 + 16 + 4 * q);
+    gh[0] += w0 * gout[o];
+    gh[1] += w1 * gout[o];
+  }
+  f32x4 ga3[2] = {z4, z4}, ga0[2] = {z4, z4};
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    float awh[2][8];
+    if (i >= 1) {  // lands under the MFMAs of fc_c.i
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          awh[kt][s] = pk[P::wht(i) + (kt * 8 + s) * 64 + lane];
+    }
+    f32x4 ga[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on = (mask >> (i * 8 + jt * 4 + r)) & 1;
+        ga[jt][r] = on ? gh[jt][r] : 0.f;
+      }
+    XRD_SB();
+    // g_c += Wc_i^T gh
+#pragma unroll
+    for (int kt = 0; kt < KTC; ++kt)
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        gc[kt] = XRD_MFMA4(awc[kt][s], gh[s >> 2][s & 3], gc[kt]);
+    XRD_SB();
+    if (i >= 1) {  // fc_c.(i-1): lands under the MFMAs of pts_linears.i
+#pragma unroll
+      for (int kt = 0; kt < KTC; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          awc[kt][s] = pk[P::wct(i - 1) + (kt * 8 + s) * 64 + lane];
+    }
+    if (NEED_E) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (i == 3) ga3[jt] = ga[jt];
+        if (i == 0) ga0[jt] = ga[jt];
+      }
+    }
+    if (i >= 1) {
+      f32x4 gprev[2] = {z4, z4};
+      XRD_SB();
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          gprev[kt] = XRD_MFMA4(awh[kt][s], ga[s >> 2][s & 3], gprev[kt]);
+      XRD_SB();
+      gh[0] = gprev[0];
+      gh[1] = gprev[1];
+    }
+  }
+  if (NEED_E) {
+    // d loss / d sin(p.B) = W0^T ga0 + W3e^T ga3, one 16-feature tile at a
+    // time; then through sin: lane group q owns feature k = emap(4kt+r, q)
+    float a3[8], a0[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      a3[s] = pk[P::W3ET + s * 64 + lane];
+      a0[s] = pk[P::W0T + s * 64 + lane];
+    }
+#pragma unroll 1
+    for (int kt = 0; kt < 6; ++kt) {
+      float n3[8], n0[8];
+      if (kt < 5) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          n3[s] = pk[P::W3ET + ((kt + 1) * 8 + s) * 64 + lane];
+          n0[s] = pk[P::W0T + ((kt + 1) * 8 + s) * 64 + lane];
+        }
+      }
+      XRD_SB();
+      f32x4 ge = z4;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        ge = XRD_MFMA4(a3[s], ga3[s >> 2][s & 3], ge);
+        ge = XRD_MFMA4(a0[s], ga0[s >> 2][s & 3], ge);
+      }
+      XRD_SB();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = emap(4 * kt + r, q);
+        const f32x4 bk = *reinterpret_cast<const f32x4*>(pk + P::EMB + k * 4);
+        const float garg = ge[r] * cos_cw(embed_arg(p, bk));
+        if (NEED_DP) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) gp[a] += garg * bk[a];
+        }
+      }
+      if (kt < 5) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          a3[s] = n3[s];
+          a0[s] = n0[s];
         }
       }
     }

@@ -307,8 +307,24 @@ __device__ __forceinline__ void color_bwd_emit(
     gh[1] += w1 * go[0][o];
   }
   uint32_t* mw = reinterpret_cast<uint32_t*>(tsc + SC_M);
-#pragma unroll 1
+  // fragments read ahead as in mlp_bwd_ra: pts_linears.i's before the MFMAs
+  // of fc_c.i's, fc_c.(i-1)'s before the MFMAs of pts_linears.i
+  float awc[2][8];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      awc[kt][s] = w[P::wct(4) + (kt * 8 + s) * 64 + lane];
+#pragma unroll
   for (int i = 4; i >= 0; --i) {
+    float awh[2][8];
+    if (i >= 1) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          awh[kt][s] = w[P::wht(i) + (kt * 8 + s) * 64 + lane];
+    }
     scr_put(tsc + SC_G + 512 * i, lane, gh);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -322,27 +338,32 @@ __device__ __forceinline__ void color_bwd_emit(
         if (li == 0)
           mw[i * 32 + 16 * jt + 4 * q + r] = (uint32_t)(b >> (16 * q)) & 0xffffu;
       }
+    XRD_SB();
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const float a = w[P::wct(i) + (kt * 8 + s) * 64 + lane];
-        gc[0][kt] = XRD_MFMA4(a, gh[s >> 2][s & 3], gc[0][kt]);
-      }
+      for (int s = 0; s < 8; ++s)
+        gc[0][kt] = XRD_MFMA4(awc[kt][s], gh[s >> 2][s & 3], gc[0][kt]);
     XRD_SB();
+    if (i >= 1) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          awc[kt][s] = w[P::wct(i - 1) + (kt * 8 + s) * 64 + lane];
+    }
     if (i == 3) {
       *reinterpret_cast<f32x4*>(park + lane * 8) = ga[0];
       *reinterpret_cast<f32x4*>(park + lane * 8 + 4) = ga[1];
     }
     if (i >= 1) {
       f32x4 gprev[2] = {z4, z4};
+      XRD_SB();
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const float a = w[P::wht(i) + (kt * 8 + s) * 64 + lane];
-          gprev[kt] = XRD_MFMA4(a, ga[s >> 2][s & 3], gprev[kt]);
-        }
+        for (int s = 0; s < 8; ++s)
+          gprev[kt] = XRD_MFMA4(awh[kt][s], ga[s >> 2][s & 3], gprev[kt]);
       XRD_SB();
       gh[0] = gprev[0];
       gh[1] = gprev[1];
@@ -352,16 +373,30 @@ __device__ __forceinline__ void color_bwd_emit(
   // through the sine; lane group q owns feature k = emap(4kt+r, q)
   const f32x4 ga3[2] = {*reinterpret_cast<const f32x4*>(park + lane * 8),
                         *reinterpret_cast<const f32x4*>(park + lane * 8 + 4)};
+  float a3[8], a0[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    a3[s] = w[P::W3ET + s * 64 + lane];
+    a0[s] = w[P::W0T + s * 64 + lane];
+  }
 #pragma unroll 1
   for (int kt = 0; kt < 6; ++kt) {
+    float n3[8], n0[8];
+    if (kt < 5) {   // column tile kt+1 lands under the MFMAs of tile kt
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        n3[s] = w[P::W3ET + ((kt + 1) * 8 + s) * 64 + lane];
+        n0[s] = w[P::W0T + ((kt + 1) * 8 + s) * 64 + lane];
+      }
+    }
+    XRD_SB();
     f32x4 ge = z4;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float a3 = w[P::W3ET + (kt * 8 + s) * 64 + lane];
-      const float a0 = w[P::W0T + (kt * 8 + s) * 64 + lane];
-      ge = XRD_MFMA4(a3, ga3[s >> 2][s & 3], ge);
-      ge = XRD_MFMA4(a0, ga[s >> 2][s & 3], ge);
+      ge = XRD_MFMA4(a3[s], ga3[s >> 2][s & 3], ge);
+      ge = XRD_MFMA4(a0[s], ga[s >> 2][s & 3], ge);
     }
+    XRD_SB();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = emap(4 * kt + r, q);
@@ -375,227 +410,371 @@ __device__ __forceinline__ void color_bwd_emit(
         if (li == 0 && k < kEmbK) atomicAdd(embB + a * 96 + k, v);
       }
     }
+    if (kt < 5) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        a3[s] = n3[s];
+        a0[s] = n0[s];
+      }
+    }
   }
 }
 
 // ---- deferred weight-gradient contraction ---------------------------------
 // lane (m = l & 15, q = l >> 4): an A operand row is feature 16jt+m, a B
 // operand column feature 16kt+m; K-step s of a tile = point 4q+s, i.e.
-// element s of the lane's 16-byte load from a feature-major matrix.
+// element s of the lane's 16-byte read from a feature-major matrix.
+//
+// Round 6: the operands come through LDS.  Rounds 3-5 let every unit read its
+// operands from the tile scratch with global loads, two tiles a batch: the
+// scratch was written a few microseconds earlier by this CU, but 9 MB per XCD
+// are in flight (L2: 4 MB), so a batch is a round trip to the Infinity Cache
+// (~2-3 us under the launch's own load) — six dependent round trips a unit,
+// two units a wave: 35 us of a 182 us block for 10 us of MFMA work
+// (profiles/r04_nice_map_phases.txt), and every operand was fetched 2-10
+// times (c by ten units).  The registers of a 168-VGPR wave cannot hold more
+// tiles in flight; the LDS can: after the last decoder pass the whole LDS of
+// the block is idle.  So the block copies the group's tiles into a ring of
+// two buffers of three tiles (2 x 70 KB) with LDS-DMA loads
+// (global_load_lds_dwordx4: 1 KB a wave instruction, no registers), round
+// r+1 in flight while round r is contracted, each operand fetched ONCE, and
+// every repeated read is a ds_read_b128.  One barrier a round.
+//
+// The 62 16x16 output blocks over the 12 waves so that every SIMD (waves w,
+// w+4, w+8) issues the same number of MFMAs a tile (64, 64, 64, 56):
+//   waves 0-5:  Fourier column tile kt6 = wave: pts_linears.0 / .3 Fourier
+//               parts, both row tiles (4 blocks sharing one B = sin(p.B))
+//   wave 8 / 9: fc_c.0 + fc_c.1 / fc_c.2 + fc_c.3 (8 blocks sharing B = c)
+//   wave 6:     fc_c.4 (4 blocks) + output_linear (2 blocks, B = h_4)
+//   wave 10:    pts_linears.1 hidden (4) + pts_linears.4 rows 0-15 (2)
+//   wave 7:     pts_linears.2 hidden (4) + pts_linears.4 rows 16-31 (2)
+//   wave 11:    pts_linears.3 hidden (4)
+// Every block accumulates its tiles in the order of rounds 3-5 (tile 0, 1,
+// ..., K-steps 0-3 each): the sums are bit for bit the earlier ones.
 __device__ __forceinline__ f32x4 ldm(const float* __restrict__ M, int f,
                                      int q) {
   return *reinterpret_cast<const f32x4*>(M + f * 16 + 4 * q);
 }
-__device__ __forceinline__ f32x4 mask4(f32x4 a, const float* __restrict__ T,
-                                       int layer, int f, int q) {
-  const uint32_t mw =
-      reinterpret_cast<const uint32_t*>(T + SC_M)[layer * 32 + f] >> (4 * q);
+
+constexpr int kRingTiles = 3;                      // tiles a round
+constexpr int kRingFloats = kRingTiles * SC_TILE;  // 17 760 floats = 71 040 B
+constexpr int kRingRounds = 12 / kRingTiles;       // a group = 12 tiles
+constexpr int kRingChunks = (kRingFloats + 255) / 256;  // 70 x 1 KB
+constexpr int kRingStride = kRingChunks * 256;     // floats between buffers
+static_assert(12 % kRingTiles == 0 && kRingFloats % 4 == 0, "whole rounds");
+
+// one LDS-DMA load of 1 KB: lane l's 16 bytes at base + voff(l) land at
+// lds_base + 16 l.  Inline asm on purpose: the compiler does not track the
+// load, so it puts no vmcnt(0) in front of the LDS reads of the OTHER ring
+// buffer (with the builtin every ds_read behind an outstanding LDS-DMA load
+// waits for it).  base, lds_base: wave-uniform.
+__device__ __forceinline__ void lds_dma16(const float* base, uint32_t voff,
+                                          uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_base), "v"(voff), "s"(base)
+               : "memory");
+}
+// this wave's share of one round: src[0, kRingFloats) -> LDS byte address dst.
+// Whole 1 KB chunks, chunk c by wave c % 12; the last chunk is partial: its
+// lanes beyond the round re-read the round's last 16 bytes (they land in the
+// pad between the two buffers) — no lane mask, no read beyond the scratch
+__device__ __forceinline__ void ring_issue(const float* __restrict__ src,
+                                           uint32_t dst, int wave, int lane) {
+  constexpr uint32_t kLastBytes = (kRingFloats - (kRingChunks - 1) * 256) * 4;
+  constexpr int kLast = kRingChunks - 1;
+  const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    if (!((mw >> s) & 1u)) a[s] = 0.f;
-  return a;
+  for (int k = 0; k < (kRingChunks + 11) / 12; ++k) {
+    const int c = wave + 12 * k;   // wave-uniform
+    if (k == kLast / 12 && c == kLast) {
+      uint32_t vl = voff < kLastBytes ? voff : kLastBytes - 16u;
+      lds_dma16(src + c * 256, vl, dst + (uint32_t)c * 1024u);
+    } else if (c < kRingChunks) {
+      lds_dma16(src + c * 256, voff, dst + (uint32_t)c * 1024u);
+    }
+  }
+}
+__device__ __forceinline__ void ring_landed() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// The operands were written a few microseconds earlier by this CU but 9 MB
-// per XCD are in flight (L2: 4 MB): most loads come back from the Infinity
-// Cache (~1-2 us).  Every unit therefore issues the loads of a CHUNK of tiles
-// before its first MFMA (6 tiles: 72 registers in flight) instead of one tile
-// at a time.  Measured (profiles/r03_nice_map_timing.txt): the launch time
-// follows the scratch VOLUME (~13 us per 1000 floats a tile: writing the
-// Fourier features out instead of recomputing their sines cost +19 us), not
-// the number of dependent round trips.
-//
 // A block adds its weight-gradient blocks to ITS row of a [blocks][flat]
 // partial buffer with plain loads and stores (nobody else touches the row; the
 // finishing launch sums the rows): measured, the same adds as float atomics
 // into 8 shared replicas cost 29 us a launch.
-__device__ __forceinline__ void padd(float* __restrict__ p, float v) {
-  *p += v;
+// first: the block's first group — its row is still zero (the finishing
+// launch leaves it so): a plain store, no read of a line that sits in HBM
+__device__ __forceinline__ void padd(float* __restrict__ p, float v,
+                                     bool first) {
+  if (first)
+    *p = v;
+  else
+    *p += v;
 }
 
-// unit u of the 18 layer units: u < 10: fc_c.i (i = u >> 1), rows jt = u & 1,
-// A = gh_i, B = c; else pts_linears.i hidden part (i = 1 + ((u - 10) >> 1)),
-// A = ga_i = masked gh_i, B = h_{i-1}.  Both column tiles, the bias rows.
-__device__ __forceinline__ void dwb_layer_unit(
-    const float* __restrict__ scr, int ntiles, int u, int lane,
-    float* __restrict__ rep) {
-  using F = MlpFlat<32, 4>;
-  constexpr int CH = 2;
-  const int m = lane & 15, q = lane >> 4;
-  const bool hid = u >= 10;
-  const int i = hid ? 1 + ((u - 10) >> 1) : (u >> 1), jt = u & 1;
-  const int aoff = SC_G + 512 * i, boff = hid ? SC_H + 512 * (i - 1) : SC_C;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  float bias = 0.f;
-#pragma unroll 1
-  for (int t0 = 0; t0 < ntiles; t0 += CH) {
-    f32x4 a[CH], b0[CH], b1[CH];
-    uint32_t mw[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const bool live = t0 + c < ntiles;
-      const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
-      a[c] = ldm(T + aoff, 16 * jt + m, q);
-      b0[c] = ldm(T + boff, m, q);
-      b1[c] = ldm(T + boff, 16 + m, q);
-      mw[c] = hid ? reinterpret_cast<const uint32_t*>(T + SC_M)
-                            [i * 32 + 16 * jt + m] >> (4 * q)
-                  : 0xfu;
-      if (!live) mw[c] = 0u;  // a tile beyond the group: no contribution
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float av = ((mw[c] >> s) & 1u) ? a[c][s] : 0.f;  // ga: masked gh
-        acc0 = XRD_MFMA4(av, b0[c][s], acc0);
-        acc1 = XRD_MFMA4(av, b1[c][s], acc1);
-        bias += av;
-      }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int j = 16 * jt + 4 * q + r;
-    float* dst = hid ? rep + F::pw(i) + j * F::pstride(i) + F::pcol(i)
-                     : rep + F::fcw(i) + j * 32;
-    padd(dst + m, acc0[r]);
-    padd(dst + 16 + m, acc1[r]);
-  }
-  const float b = group4_sum(bias);
-  if (q == 0) padd(rep + (hid ? F::pb(i) : F::fcb(i)) + 16 * jt + m, b);
+// Operand addresses inside a tile are (one per-lane base) + (a compile-time
+// offset): Tl = T + 16 m + 4 q (the lane's 16 bytes of row m of a feature-major
+// matrix), Tm = T + SC_M + m (mask words), Tq = T + 16 q (point rows).  The
+// blocks of a wave are template parameters: with run-time block tables the
+// compiler formed every block's address per lane ahead of the round loop and
+// spilled them — and a scratch reload inside the loop waits on vmcnt, i.e.
+// for the LDS-DMA loads in flight.
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) {
+  return *reinterpret_cast<const f32x4*>(p);
 }
 
 // Fourier parts of pts_linears.0 / .3, column tile kt6 (features 16kt6+m of
 // sin(p.B), recomputed): A = ga_0 / ga_3, both row tiles = 4 blocks sharing
 // one B.  kt6 == 0 also carries pts_linears.0.bias = sum ga_0.
-__device__ __forceinline__ void dwb_fourier_unit(
-    const float* __restrict__ scr, int ntiles, int kt6, int lane,
-    const float* __restrict__ dec, float* __restrict__ rep) {
-  using F = MlpFlat<32, 4>;
-  using P = MlpPack<32, 4>;
-  constexpr int CH = 2;
-  const int m = lane & 15, q = lane >> 4;
-  const int k = 16 * kt6 + m;
-  const f32x4 bk = *reinterpret_cast<const f32x4*>(dec + P::EMB + k * 4);
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[4] = {z4, z4, z4, z4};
-  float b0 = 0.f, b1 = 0.f;
-#pragma unroll 1
-  for (int t0 = 0; t0 < ntiles; t0 += CH) {
-    f32x4 pp[CH][4], a00[CH], a01[CH], a30[CH], a31[CH];
-    uint32_t m00[CH], m01[CH], m30[CH], m31[CH];
+__device__ __forceinline__ void dwl_fourier_tile(const float* __restrict__ Tl,
+                                                 const float* __restrict__ Tm,
+                                                 const float* __restrict__ Tq,
+                                                 int q, const f32x4 bk,
+                                                 f32x4 (&acc)[8],
+                                                 float (&bias)[4]) {
+  f32x4 pp[4];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const bool live = t0 + c < ntiles;
-      const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
+  for (int s = 0; s < 4; ++s) pp[s] = ld4(Tq + SC_P + 4 * s);
+  const f32x4 a00 = ld4(Tl + SC_G), a01 = ld4(Tl + SC_G + 256);
+  const f32x4 a30 = ld4(Tl + SC_G + 3 * 512);
+  const f32x4 a31 = ld4(Tl + SC_G + 3 * 512 + 256);
+  const uint32_t* mw = reinterpret_cast<const uint32_t*>(Tm);
+  const uint32_t m00 = mw[0] >> (4 * q), m01 = mw[16] >> (4 * q);
+  const uint32_t m30 = mw[3 * 32] >> (4 * q);
+  const uint32_t m31 = mw[3 * 32 + 16] >> (4 * q);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        pp[c][s] = *reinterpret_cast<const f32x4*>(T + SC_P + (4 * q + s) * 4);
-      a00[c] = ldm(T + SC_G, m, q);
-      a01[c] = ldm(T + SC_G, 16 + m, q);
-      a30[c] = ldm(T + SC_G + 3 * 512, m, q);
-      a31[c] = ldm(T + SC_G + 3 * 512, 16 + m, q);
-      const uint32_t* mw = reinterpret_cast<const uint32_t*>(T + SC_M);
-      const uint32_t on = live ? 0xfu : 0u;
-      m00[c] = (mw[m] >> (4 * q)) & on;
-      m01[c] = (mw[16 + m] >> (4 * q)) & on;
-      m30[c] = (mw[3 * 32 + m] >> (4 * q)) & on;
-      m31[c] = (mw[3 * 32 + 16 + m] >> (4 * q)) & on;
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float pv[3] = {pp[c][s][0], pp[c][s][1], pp[c][s][2]};
-        const float e = sin_cw(embed_arg(pv, bk));
-        const float v00 = ((m00[c] >> s) & 1u) ? a00[c][s] : 0.f;
-        const float v01 = ((m01[c] >> s) & 1u) ? a01[c][s] : 0.f;
-        const float v30 = ((m30[c] >> s) & 1u) ? a30[c][s] : 0.f;
-        const float v31 = ((m31[c] >> s) & 1u) ? a31[c][s] : 0.f;
-        acc[0] = XRD_MFMA4(v00, e, acc[0]);
-        acc[1] = XRD_MFMA4(v01, e, acc[1]);
-        acc[2] = XRD_MFMA4(v30, e, acc[2]);
-        acc[3] = XRD_MFMA4(v31, e, acc[3]);
-        b0 += v00;
-        b1 += v01;
-      }
+  for (int s = 0; s < 4; ++s) {
+    const float pv[3] = {pp[s][0], pp[s][1], pp[s][2]};
+    const float e = sin_cw(embed_arg(pv, bk));
+    const float v00 = ((m00 >> s) & 1u) ? a00[s] : 0.f;
+    const float v01 = ((m01 >> s) & 1u) ? a01[s] : 0.f;
+    const float v30 = ((m30 >> s) & 1u) ? a30[s] : 0.f;
+    const float v31 = ((m31 >> s) & 1u) ? a31[s] : 0.f;
+    acc[0] = XRD_MFMA4(v00, e, acc[0]);
+    acc[1] = XRD_MFMA4(v01, e, acc[1]);
+    acc[2] = XRD_MFMA4(v30, e, acc[2]);
+    acc[3] = XRD_MFMA4(v31, e, acc[3]);
+    bias[0] += v00;
+    bias[1] += v01;
   }
+}
+__device__ __forceinline__ void dwl_fourier_flush(int kt6, int m, int q,
+                                                  const f32x4 (&acc)[8],
+                                                  const float (&bias)[4],
+                                                  float* __restrict__ rep,
+                                                  bool first) {
+  using F = MlpFlat<32, 4>;
+  const int k = 16 * kt6 + m;
   if (k < kEmbK) {
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jt + 4 * q + r;
-        padd(rep + F::P0W + j * kEmbK + k, acc[jt][r]);
-        padd(rep + F::P3W + j * (kEmbK + 32) + k, acc[2 + jt][r]);
+        padd(rep + F::P0W + j * kEmbK + k, acc[jt][r], first);
+        padd(rep + F::P3W + j * (kEmbK + 32) + k, acc[2 + jt][r], first);
       }
   }
   if (kt6 == 0) {
-    const float s0 = group4_sum(b0), s1 = group4_sum(b1);
+    const float s0 = group4_sum(bias[0]), s1 = group4_sum(bias[1]);
     if (q == 0) {
-      padd(rep + F::P0B + m, s0);
-      padd(rep + F::P0B + 16 + m, s1);
+      padd(rep + F::P0B + m, s0, first);
+      padd(rep + F::P0B + 16 + m, s1, first);
     }
   }
 }
 
-// output_linear: rows = the 4 outputs (A = d loss / d output), B = h_4
-__device__ __forceinline__ void dwb_output_unit(
-    const float* __restrict__ scr, int ntiles, int lane,
-    float* __restrict__ rep) {
-  using F = MlpFlat<32, 4>;
-  constexpr int CH = 2;
-  const int m = lane & 15, q = lane >> 4;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  float bout = 0.f;
-#pragma unroll 1
-  for (int t0 = 0; t0 < ntiles; t0 += CH) {
-    f32x4 b0[CH], b1[CH];
-    float av[CH][4];
+// One A row tile against both column tiles of one B matrix (2 blocks):
+//   HID = false: fc_c.I rows JT,    A = gh_I,          B = c
+//   HID = true:  pts_linears.I,     A = masked gh_I,   B = h_{I-1}
+template <bool HID, int I, int JT>
+__device__ __forceinline__ void dwl_pair_tile(const float* __restrict__ Tl,
+                                              const float* __restrict__ Tm,
+                                              int q, f32x4& acc0, f32x4& acc1,
+                                              float& bias) {
+  constexpr int BOFF = HID ? SC_H + 512 * (I - 1) : SC_C;
+  const f32x4 a = ld4(Tl + SC_G + 512 * I + 256 * JT);
+  const f32x4 b0 = ld4(Tl + BOFF), b1 = ld4(Tl + BOFF + 256);
+  const uint32_t mw =
+      HID ? reinterpret_cast<const uint32_t*>(Tm)[I * 32 + 16 * JT] >> (4 * q)
+          : 0xfu;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const bool live = t0 + c < ntiles;
-      const float* T = scr + (size_t)(live ? t0 + c : t0) * SC_TILE;
-      b0[c] = ldm(T + SC_H + 4 * 512, m, q);
-      b1[c] = ldm(T + SC_H + 4 * 512, 16 + m, q);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        av[c][s] = (live && m < 4) ? T[SC_GO + (4 * q + s) * 4 + (m & 3)] : 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc0 = XRD_MFMA4(av[c][s], b0[c][s], acc0);
-        acc1 = XRD_MFMA4(av[c][s], b1[c][s], acc1);
-        bout += av[c][s];
-      }
+  for (int s = 0; s < 4; ++s) {
+    const float av = ((mw >> s) & 1u) ? a[s] : 0.f;  // ga: masked gh
+    acc0 = XRD_MFMA4(av, b0[s], acc0);
+    acc1 = XRD_MFMA4(av, b1[s], acc1);
+    bias += av;
   }
+}
+template <bool HID, int I, int JT>
+__device__ __forceinline__ void dwl_pair_flush(int m, int q, const f32x4 acc0,
+                                               const f32x4 acc1, float bias,
+                                               float* __restrict__ rep,
+                                               bool first) {
+  using F = MlpFlat<32, 4>;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 16 * JT + 4 * q + r;
+    float* dst = HID ? rep + F::pw(I) + j * F::pstride(I) + F::pcol(I)
+                     : rep + F::fcw(I) + j * 32;
+    padd(dst + m, acc0[r], first);
+    padd(dst + 16 + m, acc1[r], first);
+  }
+  const float b = group4_sum(bias);
+  if (q == 0) padd(rep + (HID ? F::pb(I) : F::fcb(I)) + 16 * JT + m, b, first);
+}
+// output_linear: rows = the 4 outputs (A = d loss / d output), B = h_4
+__device__ __forceinline__ void dwl_output_tile(const float* __restrict__ Tl,
+                                                const float* __restrict__ Tq,
+                                                int m, f32x4& acc0,
+                                                f32x4& acc1, float& bout) {
+  const f32x4 b0 = ld4(Tl + SC_H + 4 * 512);
+  const f32x4 b1 = ld4(Tl + SC_H + 4 * 512 + 256);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float av = m < 4 ? Tq[SC_GO + 4 * s + (m & 3)] : 0.f;
+    acc0 = XRD_MFMA4(av, b0[s], acc0);
+    acc1 = XRD_MFMA4(av, b1[s], acc1);
+    bout += av;
+  }
+}
+__device__ __forceinline__ void dwl_output_flush(int m, int q, const f32x4 acc0,
+                                                 const f32x4 acc1, float bout,
+                                                 float* __restrict__ rep,
+                                                 bool first) {
+  using F = MlpFlat<32, 4>;
   if (q == 0) {  // rows 0..3 of the accumulator = lane group 0
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      padd(rep + F::OW + r * 32 + m, acc0[r]);
-      padd(rep + F::OW + r * 32 + 16 + m, acc1[r]);
+      padd(rep + F::OW + r * 32 + m, acc0[r], first);
+      padd(rep + F::OW + r * 32 + 16 + m, acc1[r], first);
     }
   }
   const float b = group4_sum(bout);
-  if (q == 0 && m < 4) padd(rep + F::OB + m, b);
+  if (q == 0 && m < 4) padd(rep + F::OB + m, b, first);
 }
 
-// the 25 units over the 12 waves of a block (MFMAs per tile: layer unit 8,
-// Fourier unit 16, output unit 8): waves 0..5 one Fourier + one layer unit,
-// waves 6..11 two layer units, wave 6 also the output unit
+// the blocks of layer wave 6 + ROLE on one tile / at the end
+template <int ROLE>
+__device__ __forceinline__ void dwl_role_tile(const float* __restrict__ Tl,
+                                              const float* __restrict__ Tm,
+                                              const float* __restrict__ Tq,
+                                              int m, int q, f32x4 (&a)[8],
+                                              float (&b)[4]) {
+  if (ROLE == 0) {         // wave 6: fc_c.4 + output_linear
+    dwl_pair_tile<false, 4, 0>(Tl, Tm, q, a[0], a[1], b[0]);
+    dwl_pair_tile<false, 4, 1>(Tl, Tm, q, a[2], a[3], b[1]);
+    dwl_output_tile(Tl, Tq, m, a[4], a[5], b[2]);
+  } else if (ROLE == 1) {  // wave 7: pts_linears.2, .4 rows 16-31
+    dwl_pair_tile<true, 2, 0>(Tl, Tm, q, a[0], a[1], b[0]);
+    dwl_pair_tile<true, 2, 1>(Tl, Tm, q, a[2], a[3], b[1]);
+    dwl_pair_tile<true, 4, 1>(Tl, Tm, q, a[4], a[5], b[2]);
+  } else if (ROLE == 2) {  // wave 8: fc_c.0, fc_c.1
+    dwl_pair_tile<false, 0, 0>(Tl, Tm, q, a[0], a[1], b[0]);
+    dwl_pair_tile<false, 0, 1>(Tl, Tm, q, a[2], a[3], b[1]);
+    dwl_pair_tile<false, 1, 0>(Tl, Tm, q, a[4], a[5], b[2]);
+    dwl_pair_tile<false, 1, 1>(Tl, Tm, q, a[6], a[7], b[3]);
+  } else if (ROLE == 3) {  // wave 9: fc_c.2, fc_c.3
+    dwl_pair_tile<false, 2, 0>(Tl, Tm, q, a[0], a[1], b[0]);
+    dwl_pair_tile<false, 2, 1>(Tl, Tm, q, a[2], a[3], b[1]);
+    dwl_pair_tile<false, 3, 0>(Tl, Tm, q, a[4], a[5], b[2]);
+    dwl_pair_tile<false, 3, 1>(Tl, Tm, q, a[6], a[7], b[3]);
+  } else if (ROLE == 4) {  // wave 10: pts_linears.1, .4 rows 0-15
+    dwl_pair_tile<true, 1, 0>(Tl, Tm, q, a[0], a[1], b[0]);
+    dwl_pair_tile<true, 1, 1>(Tl, Tm, q, a[2], a[3], b[1]);
+    dwl_pair_tile<true, 4, 0>(Tl, Tm, q, a[4], a[5], b[2]);
+  } else {                 // wave 11: pts_linears.3
+    dwl_pair_tile<true, 3, 0>(Tl, Tm, q, a[0], a[1], b[0]);
+    dwl_pair_tile<true, 3, 1>(Tl, Tm, q, a[2], a[3], b[1]);
+  }
+}
+template <int ROLE>
+__device__ __forceinline__ void dwl_role_flush(int m, int q,
+                                               const f32x4 (&a)[8],
+                                               const float (&b)[4],
+                                               float* __restrict__ rep,
+                                               bool first) {
+  if (ROLE == 0) {
+    dwl_pair_flush<false, 4, 0>(m, q, a[0], a[1], b[0], rep, first);
+    dwl_pair_flush<false, 4, 1>(m, q, a[2], a[3], b[1], rep, first);
+    dwl_output_flush(m, q, a[4], a[5], b[2], rep, first);
+  } else if (ROLE == 1) {
+    dwl_pair_flush<true, 2, 0>(m, q, a[0], a[1], b[0], rep, first);
+    dwl_pair_flush<true, 2, 1>(m, q, a[2], a[3], b[1], rep, first);
+    dwl_pair_flush<true, 4, 1>(m, q, a[4], a[5], b[2], rep, first);
+  } else if (ROLE == 2) {
+    dwl_pair_flush<false, 0, 0>(m, q, a[0], a[1], b[0], rep, first);
+    dwl_pair_flush<false, 0, 1>(m, q, a[2], a[3], b[1], rep, first);
+    dwl_pair_flush<false, 1, 0>(m, q, a[4], a[5], b[2], rep, first);
+    dwl_pair_flush<false, 1, 1>(m, q, a[6], a[7], b[3], rep, first);
+  } else if (ROLE == 3) {
+    dwl_pair_flush<false, 2, 0>(m, q, a[0], a[1], b[0], rep, first);
+    dwl_pair_flush<false, 2, 1>(m, q, a[2], a[3], b[1], rep, first);
+    dwl_pair_flush<false, 3, 0>(m, q, a[4], a[5], b[2], rep, first);
+    dwl_pair_flush<false, 3, 1>(m, q, a[6], a[7], b[3], rep, first);
+  } else if (ROLE == 4) {
+    dwl_pair_flush<true, 1, 0>(m, q, a[0], a[1], b[0], rep, first);
+    dwl_pair_flush<true, 1, 1>(m, q, a[2], a[3], b[1], rep, first);
+    dwl_pair_flush<true, 4, 0>(m, q, a[4], a[5], b[2], rep, first);
+  } else {
+    dwl_pair_flush<true, 3, 0>(m, q, a[0], a[1], b[0], rep, first);
+    dwl_pair_flush<true, 3, 1>(m, q, a[2], a[3], b[1], rep, first);
+  }
+}
+
+// ring: the block's LDS from offset 0 (every other use of it is over: the
+// caller's barrier).  scr: the group's 12 tile slots, contiguous.
 __device__ __forceinline__ void dw_contract(const float* __restrict__ scr,
                                             int ntiles, int wave, int lane,
                                             const float* __restrict__ dec,
-                                            float* __restrict__ rep) {
-  if (wave < 6) {
-    dwb_fourier_unit(scr, ntiles, wave, lane, dec, rep);
-    dwb_layer_unit(scr, ntiles, wave, lane, rep);
-  } else {
-    dwb_layer_unit(scr, ntiles, 6 + 2 * (wave - 6), lane, rep);
-    dwb_layer_unit(scr, ntiles, 7 + 2 * (wave - 6), lane, rep);
-    if (wave == 6) dwb_output_unit(scr, ntiles, lane, rep);
+                                            float* __restrict__ ring,
+                                            float* __restrict__ rep,
+                                            bool first) {
+  using P = MlpPack<32, 4>;
+  const int m = lane & 15, q = lane >> 4;
+  const uint32_t ring_b = lds_addr(ring);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[8] = {z4, z4, z4, z4, z4, z4, z4, z4};
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bk = z4;
+  if (wave < 6)
+    bk = *reinterpret_cast<const f32x4*>(dec + P::EMB + (16 * wave + m) * 4);
+  ring_issue(scr, ring_b, wave, lane);
+#pragma unroll 1
+  for (int r = 0; r < kRingRounds; ++r) {
+    ring_landed();
+    __syncthreads();  // round r is in its buffer; round r-1's buffer is free
+    if (r + 1 < kRingRounds && (r + 1) * kRingTiles < ntiles)
+      ring_issue(scr + (size_t)(r + 1) * kRingFloats,
+                 ring_b + ((r + 1) & 1) * (kRingStride * 4), wave, lane);
+    const float* buf = ring + (r & 1) * kRingStride;
+#pragma unroll 1
+    for (int t = 0; t < kRingTiles; ++t) {
+      if (r * kRingTiles + t >= ntiles) break;  // tiles beyond the group
+      const float* T = buf + t * SC_TILE;
+      const float* Tl = T + 16 * m + 4 * q;
+      const float* Tm = T + SC_M + m;
+      const float* Tq = T + 16 * q;
+      switch (wave) {
+        case 6: dwl_role_tile<0>(Tl, Tm, Tq, m, q, acc, bias); break;
+        case 7: dwl_role_tile<1>(Tl, Tm, Tq, m, q, acc, bias); break;
+        case 8: dwl_role_tile<2>(Tl, Tm, Tq, m, q, acc, bias); break;
+        case 9: dwl_role_tile<3>(Tl, Tm, Tq, m, q, acc, bias); break;
+        case 10: dwl_role_tile<4>(Tl, Tm, Tq, m, q, acc, bias); break;
+        case 11: dwl_role_tile<5>(Tl, Tm, Tq, m, q, acc, bias); break;
+        default: dwl_fourier_tile(Tl, Tm, Tq, q, bk, acc, bias); break;
+      }
+    }
+  }
+  switch (wave) {
+    case 6: dwl_role_flush<0>(m, q, acc, bias, rep, first); break;
+    case 7: dwl_role_flush<1>(m, q, acc, bias, rep, first); break;
+    case 8: dwl_role_flush<2>(m, q, acc, bias, rep, first); break;
+    case 9: dwl_role_flush<3>(m, q, acc, bias, rep, first); break;
+    case 10: dwl_role_flush<4>(m, q, acc, bias, rep, first); break;
+    case 11: dwl_role_flush<5>(m, q, acc, bias, rep, first); break;
+    default: dwl_fourier_flush(wave, m, q, acc, bias, rep, first); break;
   }
 }
 
@@ -605,7 +784,11 @@ struct MapGeom {
   static constexpr int NW = RPBM * NT;       // waves = tiles of a group
   static constexpr int RAW = kWMax;          // raw [RPBM][64][4]
   static constexpr int WAVE0 = kWMax + RPBM * 256;  // per-wave scratch
-  static constexpr int EMBB = WAVE0 + NW * kScratch;  // embedder._B sums
+  // embedder._B sums: behind the per-wave scratch AND behind the weight-
+  // gradient contraction's operand ring, which takes the LDS from offset 0
+  static constexpr int EMBB = WAVE0 + NW * kScratch > 2 * kRingStride
+                                  ? WAVE0 + NW * kScratch
+                                  : 2 * kRingStride;
   static constexpr size_t LDS = (size_t)EMBB + 288;
 };
 static_assert(MapGeom<3>::LDS * 4 <= 163840, "LDS per CU");
@@ -683,9 +866,10 @@ nice_map_fused_kernel(
     stage_weights(wl, sc.dec[1], PM::WHT);
     asm volatile("" : "+v"(lane));
     if (active) {
-      float om[1][1];
-      mlp_fwd<1, 32, 1, true, false>(wl, lane, p32, c_m, om, mask_m, nullptr);
-      occ = om[0][0];
+      float om[1];
+      mlp_fwd_ra<32, 1, true, false>(wl, lane, p32[0], c_m[0], om, mask_m[0],
+                                     nullptr);
+      occ = om[0];
     }
     if (STAGE >= XRD_STAGE_FINE) {
       f32x4 c_f[1][4];
@@ -701,10 +885,10 @@ nice_map_fused_kernel(
       stage_weights(wl, sc.dec[2], PF::WHT);
       asm volatile("" : "+v"(lane));
       if (active) {
-        float of[1][1];
-        mlp_fwd<1, 64, 1, true, false>(wl, lane, p32, c_f, of, mask_f,
+        float of[1];
+        mlp_fwd_ra<64, 1, true, false>(wl, lane, p32[0], c_f[0], of, mask_f[0],
                                        nullptr);
-        occ = of[0][0] + occ;  // NICE.forward: fine_occ + middle_occ
+        occ = of[0] + occ;  // NICE.forward: fine_occ + middle_occ
       }
     }
     if (STAGE == XRD_STAGE_COLOR) {
@@ -716,12 +900,12 @@ nice_map_fused_kernel(
       stage_weights(wl, sc.dec[3], PC::WHT);
       asm volatile("" : "+v"(lane));
       if (active) {
-        float oc[1][4];
-        mlp_fwd<1, 32, 4, true, false, NEED_DW>(wl, lane, p32, c_c, oc, mask_c,
-                                                nullptr, tsc + SC_H);
-        col[0] = oc[0][0];
-        col[1] = oc[0][1];
-        col[2] = oc[0][2];
+        float oc[4];
+        mlp_fwd_ra<32, 4, true, NEED_DW>(wl, lane, p32[0], c_c[0], oc,
+                                         mask_c[0], tsc + SC_H);
+        col[0] = oc[0];
+        col[1] = oc[1];
+        col[2] = oc[2];
       }
     }
     if (active) {
@@ -821,8 +1005,8 @@ nice_map_fused_kernel(
           color_bwd_emit<NEED_DP>(wl - PC::EMB, lane, p32, go, mask_c[0], tsc,
                                   embB, SL.gt, gc, gp32);
       } else if (active) {
-        mlp_bwd<1, 32, 4, NEED_DP, NEED_DP>(wl - PC::EMB, lane, p32, c_c, go,
-                                            mask_c, gc, gp32);
+        mlp_bwd_ra<32, 4, NEED_DP, NEED_DP>(wl - PC::EMB, lane, p32[0], go[0],
+                                            mask_c[0], gc[0], gp32[0]);
       }
       if (active) {
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
@@ -838,8 +1022,8 @@ nice_map_fused_kernel(
                     (NEED_DP ? PF::LEN : PF::W0T) - PF::EMB);
       asm volatile("" : "+v"(lane));
       if (active) {
-        mlp_bwd<1, 64, 1, NEED_DP, NEED_DP>(wl - PF::EMB, lane, p32, c_f, go,
-                                            mask_f, gc, gp32);
+        mlp_bwd_ra<64, 1, NEED_DP, NEED_DP>(wl - PF::EMB, lane, p32[0], go[0],
+                                            mask_f[0], gc[0], gp32[0]);
         const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
@@ -854,8 +1038,8 @@ nice_map_fused_kernel(
                     (NEED_DP ? PM::LEN : PM::W0T) - PM::EMB);
       asm volatile("" : "+v"(lane));
       if (active) {
-        mlp_bwd<1, 32, 1, NEED_DP, NEED_DP>(wl - PM::EMB, lane, p32, c_m, go,
-                                            mask_m, gc, gp32);
+        mlp_bwd_ra<32, 1, NEED_DP, NEED_DP>(wl - PM::EMB, lane, p32[0], go[0],
+                                            mask_m[0], gc[0], gp32[0]);
         tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
         if constexpr (!TRACK)
@@ -875,9 +1059,12 @@ nice_map_fused_kernel(
       int lane_b = lane;
       asm volatile("" : "+v"(lane_b));  // keep the contraction's address
       // arithmetic inside the group loop (no hoisting into live registers)
-      dw_contract(dw_scr + (size_t)grp * G::NW * SC_TILE, rays_here * NT, wave,
-                  lane_b, sc.dec[3],
-                  dw_rep + (size_t)blockIdx.x * kColorFlat);
+      dw_contract(dw_scr + (size_t)grp * G::NW * SC_TILE, rays_here * NT,
+                  __builtin_amdgcn_readfirstlane(wave), lane_b, sc.dec[3], wl,
+                  dw_rep + (size_t)blockIdx.x * kColorFlat,
+                  grp == (int)blockIdx.x);
+      // (a further group's set-up writes the LDS the last round is read from)
+      if (grp + (int)gridDim.x < ngroups) __syncthreads();
     }
     if (NEED_DP && active) {
       const int tile_id = ray * NT + tile;

@@ -815,7 +815,8 @@ __global__ void pose_from_matrix_kernel(const float* __restrict__ c2w,
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const float e = fabsf(r[i][j] - m[i][j]);
-        if (!(e <= err)) err = e;   // larger, or NaN
+        // larger, or NaN; a NaN already held (an earlier frame's) stays
+        if (err == err && !(e <= err)) err = e;
       }
     dev_max[0] = err;
   }

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(kWaves * 64) void vox_compact_kernel(const PipeArgs
   const int s_longest = part_max(part, PT_SMAX, lane);
   const int ovf_bits = part_or(part, PT_OVF, lane);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    A.offs[n_rays] = pts_total;
+    // (n_rays == 0: the argument check lets a caller pass no buffers)
+    if (A.offs != nullptr) A.offs[n_rays] = pts_total;
     meta[M_SMAX] = s_longest;
     meta[M_OVERFLOW] = ovf_bits | ((int64_t)pts_total > A.p_cap ? 2 : 0);
     meta[M_NPTS] = (int64_t)pts_total > A.p_cap ? (int)A.p_cap : pts_total;

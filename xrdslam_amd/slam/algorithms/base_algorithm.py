@@ -81,12 +81,19 @@ class _capture(torch.cuda.graph):
         import gc
         self._gc_was = gc.isenabled()
         gc.disable()
-        if not _capture._checked:
-            return super().__enter__()
-        torch.cuda.synchronize()
-        self.stream_ctx.__enter__()
-        self.cuda_graph.capture_begin(
-            *self.pool, capture_error_mode=self.capture_error_mode)
+        try:
+            if not _capture._checked:
+                return super().__enter__()
+            torch.cuda.synchronize()
+            self.stream_ctx.__enter__()
+            self.cuda_graph.capture_begin(
+                *self.pool, capture_error_mode=self.capture_error_mode)
+        except BaseException:
+            # __exit__ is not called when __enter__ raises: the collector
+            # must not stay off for the rest of the process
+            if self._gc_was:
+                gc.enable()
+            raise
 
     def __exit__(self, *exc):
         try:

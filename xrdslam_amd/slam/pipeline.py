@@ -154,7 +154,10 @@ class SequentialSLAM:
         if torch.is_tensor(cand):
             # the device pose chain: the 4x4 is broadcast where it lives (one
             # RCCL broadcast of 64 bytes over xGMI), no host hop
-            t = cand.detach().to(torch.float32).contiguous()
+            # (a copy: ``cand`` is the tracking graph's static best-pose
+            # buffer — the broadcast must not write into graph-owned memory
+            # and the result must survive the next replay)
+            t = cand.detach().float().clone()
             dist.broadcast(t, src=0)
             return t
         dev = self.algorithm.device
