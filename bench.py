@@ -116,7 +116,7 @@ def pmc_traffic(kernels, which='r04_pmc.json'):
     # (the newest round's pass of that name that lists every kernel; its file
     # name is left in PMC_FILE[0] for the line's traffic_source)
     PMC_FILE[0] = None
-    for rnd in ('r05', 'r04'):
+    for rnd in ('r06', 'r05', 'r04'):
         path = os.path.join(ROOT, 'profiles', rnd + which[3:])
         if not os.path.exists(path):
             continue
@@ -129,6 +129,47 @@ def pmc_traffic(kernels, which='r04_pmc.json'):
         PMC_FILE[0] = rnd + which[3:]
         return total
     return None
+
+
+def add_counters(roofline, kernel, which='r06_pmc.json'):
+    """SQ counter evidence of the roofline's kernel from the committed
+    counter passes (tools/run_pmc.sh MFMA / LDS passes, merged by
+    tools/pmc_merge.py): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs
+    x 256 CUs x GRBM_GUI_ACTIVE per XCD) — the share of SIMD cycles an MFMA
+    was executing, the counter-based twin of ``frac`` (which divides
+    ALGORITHMIC flops by time) —, executed MFMA flops per launch (f32
+    16x16x4: 64 flop a busy cycle), LDS bank-conflict share and the
+    LDS-issue-stall share.  Fields stay absent when the pass is not there."""
+    if roofline is None:
+        return roofline
+    path = os.path.join(ROOT, 'profiles', which)
+    try:
+        pmc = json.load(open(path))
+        d = pmc['_derived'][kernel]
+    except (OSError, KeyError, ValueError):
+        return roofline
+    for k in ('mfma_busy_frac', 'lds_conflict_frac',
+              'wait_inst_lds_over_issue', 'wait_inst_any_over_issue',
+              'clock_ghz', 'duration_us_profiled'):
+        if k in d:
+            roofline[k] = d[k]
+    busy = pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', {}).get(kernel, {}).get('mean')
+    if busy is not None and roofline.get('dtype_flop_per_busy_cycle', 64):
+        roofline['executed_mfma_flops_per_launch'] = busy * 64.0
+        if roofline.get('algorithmic_flops_per_launch'):
+            roofline['executed_over_algorithmic_flops'] = \
+                busy * 64.0 / roofline['algorithmic_flops_per_launch']
+        if roofline.get('avg_launch_us') and roofline.get('unit') == \
+                'TFLOP/s':
+            roofline['frac_executed'] = busy * 64.0 / (
+                roofline['avg_launch_us'] * 1e-6) / MFMA_F32_PEAK
+    roofline['counters_kernel'] = kernel
+    roofline['counters_source'] = (
+        f'profiles/{which} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES '
+        'SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE | SQ_LDS_BANK_'
+        'CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY '
+        'SQ_ACTIVE_INST_ANY, separate passes with --kernel-trace only)')
+    return roofline
 
 
 def nice_group_kernels(kernel, stage, need_pose, need_dec):
@@ -432,7 +473,12 @@ def run_coslam(args, dev, with_cpu, world=1):
             'ate_rmse_m': slam.ate_rmse(),
             'ate_rmse_aligned_m': slam.trajectory_stats()[
                 'absolute_translational_error.rmse']},
-        'roofline': roofline,
+        'roofline': add_counters(
+            roofline, {'coslam_bwd': 'coslam_bwd<dp=%s,dg=%s>' % (
+                'true' if ray_grads else 'false',
+                'true' if map_grads else 'false'),
+                'coslam_fwd': 'coslam_fwd_kernel'}.get(kernel, kernel),
+            'r06_pmc.json'),
         'cpu_baseline': calibrated(
             co_cpu_baseline(min(CPU_THREADS, os.cpu_count() or 1)), 'co-slam')
         if with_cpu else None}
@@ -510,11 +556,30 @@ def _rccl_report(world):
     st = xdist.state
     nbytes = 8 << 20
     bw = st.measure_busbw(nbytes)
+    # the mapping iteration's own exchange: the flat gradient bucket the run
+    # actually sent (selected grid cells + decoder + pose gradients) and what
+    # one all-reduce of that size costs on this path
+    bucket = int(st.stats['bucket_bytes_max'])
+    ar_ms = st.measure_allreduce_ms(bucket) if bucket else None
     return {'ranks': st.comm.world if st.comm is not None else st.world,
             'exchange': st.backend_name(),
             'deterministic_shards': bool(st.deterministic),
             'allreduce_bytes': nbytes, 'busbw_GBps': bw,
-            'xgmi_link_peak_GBps': 153.0}
+            'xgmi_link_peak_GBps': 153.0,
+            'bucket_bytes': bucket, 'allreduce_ms': ar_ms,
+            'exchanges_enqueued_from_python': int(st.stats['exchanges'])}
+
+
+def _per_rank(world, **values):
+    """gather scalars of every rank on rank 0: {name: [rank 0, rank 1, ...]}
+    (what the north star's "mapping-step speed-up at 8 GPUs" is read from);
+    every rank must call it"""
+    if world <= 1:
+        return {k: [v] for k, v in values.items()}
+    import torch.distributed as dist
+    box = [None] * world
+    dist.all_gather_object(box, values)
+    return {k: [b[k] for b in box] for k in values}
 
 
 def _setup_dist(dev, world):
@@ -723,7 +788,12 @@ def run_voxfusion(args, dev, world=1):
             'leaf_voxels': int(algo.model.svo.count_leaf_nodes()),
             'last_batch': sizes,
             'graphs': bool(not args.no_graphs)},
-        'roofline': roofline, 'cpu_baseline': cpu}
+        'roofline': add_counters(
+            roofline, None if roofline is None else
+            {'vox_dw': 'vox_dw_kernel', 'vox_points_fwd':
+             'vox_points_fwd_kernel', 'vox_points_bwd':
+             'vox_points_bwd<dw=%s>' % ('true' if need_w else 'false')}[kern],
+            'r06_pmc_vox.json'), 'cpu_baseline': cpu}
 
 
 class _CvPoses:
@@ -857,7 +927,9 @@ def run_splatam(args, dev, world=1):
             'gaussians': int(algo.model.gaussian_cloud.params['means3D']
                              .shape[0]),
             'binning_overflowed_passes': dgr._BIN.overflowed},
-        'roofline': roofline, 'cpu_baseline': cpu}
+        'roofline': add_counters(roofline, 'gs_blend_bwd_kernel',
+                                 'r06_pmc_splatam.json'),
+        'cpu_baseline': cpu}
 
 
 def splatam_cpu_baseline(threads, n_gaussians, n_pixels):
@@ -1046,7 +1118,9 @@ def run_pointslam(args, dev, world=1):
             'map_ms_per_frame': t_map / args.steps * 1e3,
             'ate_rmse_m': slam.ate_rmse(),
             'neural_points': int(algo.model.neural_point_cloud.pts_num())},
-        'roofline': roofline, 'cpu_baseline': cpu}
+        'roofline': add_counters(roofline, 'point_color_bwd_w_kernel',
+                                 'r06_pmc_pointslam.json'),
+        'cpu_baseline': cpu}
 
 
 def pointslam_cpu_baseline(threads):
@@ -1436,10 +1510,24 @@ def main():
         # part: the sharded mapping calls all-reduce)
         keep = algo.persistent_map_graph
         algo.persistent_map_graph = False
+        torch.cuda.synchronize()
+        t_calls = time.perf_counter()
         for _ in range(5):
             algo.do_mapping(frame)
         torch.cuda.synchronize()
+        t_calls = (time.perf_counter() - t_calls) / 5
         algo.persistent_map_graph = keep
+    else:
+        t_calls = None
+    # per rank: one mapping call (its iterations + the coarse mapper on its
+    # side stream + the gradient exchange) and the mapping time per frame of
+    # the timed region — every rank takes part in the gather
+    per_rank = _per_rank(
+        world, mapping_call_ms=None if t_calls is None else t_calls * 1e3,
+        mapping_step_ms=None if t_calls is None else
+        t_calls * 1e3 / max(1, int(cfg.mapping_n_iters)),
+        map_ms_per_frame=slam.t_map / args.steps * 1e3,
+        track_ms_per_frame=slam.t_track / args.steps * 1e3)
     if os.environ.get('XRD_BENCH_TRACE'):   # host-side time per frame
         print('frame ms:', ' '.join(
             f'{k + 1 + args.warmup}:{(b - a) * 1e3:.1f}' for k, (a, b) in
@@ -1520,6 +1608,10 @@ def main():
             # the per-iteration ray batch is fixed by the reference's config
             # and split over the ranks: total work does not grow with N
             'scaling': 'strong', 'rccl': rccl,
+            # one entry a rank: mapping_step_ms = one mapping call / its
+            # iterations (sharded rays + the all-reduce of rccl.bucket_bytes,
+            # rccl.allreduce_ms each); DESIGN 5 holds the predicted curve
+            'per_rank': per_rank,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': 'NICE-SLAM Replica/office0-shaped 640x480 RGB-D: '
@@ -1558,7 +1650,10 @@ def main():
                              'like the reference' if
                              cfg.model.pretrained_decoders_xrd else
                              'random init (seeded)')},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': add_counters(
+                roofline, (nice_group_kernels(kernel, stage, need_pose,
+                                              need_dec) or [None])[0]),
+            'cpu_baseline': cpu,
             # the oracle's unfused torch ops on this GPU (a second baseline,
             # not a product path)
             'torch_gpu_baseline': torch_gpu,

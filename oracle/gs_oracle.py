@@ -38,12 +38,11 @@ def quat_to_rot(q):
     ], -1).reshape(q.shape[:-1] + (3, 3))
 
 
-def rasterize(means3D, colors, opacities, scales, rotations, viewmatrix,
-              projmatrix, H, W, tanfovx, tanfovy, bg=None, scale_modifier=1.0,
-              window=None):
-    """viewmatrix / projmatrix are the [4,4] TRANSPOSED matrices the reference
-    passes (common.py:599,605-606: w2c^T and (P w2c)^T).  Returns
-    color [3,H,W], radii [N] int, depth [1,H,W], ndc [N,2] (retain_grad-able)."""
+def project(means3D, scales, rotations, viewmatrix, projmatrix, H, W,
+            tanfovx, tanfovy, scale_modifier=1.0):
+    """the per-Gaussian half (preprocess): EWA projection, 3-sigma radius, tile
+    rectangle.  -> dict(pix [N,2], conic [N,3], tz [N], radii [N] int,
+    visible [N] bool, rect (rminx, rmaxx, rminy, rmaxy), ndc [N,2])"""
     N = means3D.shape[0]
     dev, dt = means3D.device, means3D.dtype
     V = viewmatrix.reshape(4, 4).t()   # w2c
@@ -100,6 +99,22 @@ def rasterize(means3D, colors, opacities, scales, rotations, viewmatrix,
     visible = (tz.detach() > 0.2) & (det.detach() != 0) & \
         ((rmaxx - rminx) * (rmaxy - rminy) > 0)
     radii = torch.where(visible, radius, torch.zeros_like(radius)).int()
+    return dict(pix=pix, conic=conic, tz=tz, radii=radii, visible=visible,
+                rect=(rminx, rmaxx, rminy, rmaxy), ndc=ndc)
+
+
+def rasterize(means3D, colors, opacities, scales, rotations, viewmatrix,
+              projmatrix, H, W, tanfovx, tanfovy, bg=None, scale_modifier=1.0,
+              window=None):
+    """viewmatrix / projmatrix are the [4,4] TRANSPOSED matrices the reference
+    passes (common.py:599,605-606: w2c^T and (P w2c)^T).  Returns
+    color [3,H,W], radii [N] int, depth [1,H,W], ndc [N,2] (retain_grad-able)."""
+    dev, dt = means3D.device, means3D.dtype
+    g = project(means3D, scales, rotations, viewmatrix, projmatrix, H, W,
+                tanfovx, tanfovy, scale_modifier)
+    pix, conic, tz, radii, visible, ndc = (g['pix'], g['conic'], g['tz'],
+                                           g['radii'], g['visible'], g['ndc'])
+    rminx, rmaxx, rminy, rmaxy = g['rect']
     order = torch.argsort(tz.detach(), stable=True)
     x0, y0, ww, wh = (0, 0, W, H) if window is None else window
     ys, xs = torch.meshgrid(torch.arange(y0, y0 + wh, device=dev, dtype=dt),

@@ -3,7 +3,10 @@
 ("parity unpinned", see that file).  Used to execute the reference's SplaTAM
 model on the CPU for tests/golden/splatam_render.npz and by the CPU test of
 the host mirror.  The dummy ``means2D`` input receives no gradient here (the
-densification statistics that read it are off in the reference's defaults)."""
+densification statistics that read it are off in the reference's defaults).
+``TILED = True`` evaluates the same rasteriser tile by tile (oracle/gs_tiled.py,
+held to the dense evaluation by tests/test_gs_tiled_oracle.py): what the
+trajectory fixture needs to run the reference loop at 160x120."""
 import types
 from typing import NamedTuple
 
@@ -11,6 +14,9 @@ import torch
 import torch.nn as nn
 
 import gs_oracle
+import gs_tiled
+
+TILED = False
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -35,7 +41,8 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, colors_precomp=None,
                 scales=None, rotations=None, shs=None, cov3D_precomp=None):
         rs = self.raster_settings
-        color, radii, depth, _ = gs_oracle.rasterize(
+        fn = gs_tiled.rasterize if TILED else gs_oracle.rasterize
+        color, radii, depth, _ = fn(
             means3D, colors_precomp, opacities, scales, rotations,
             rs.viewmatrix.reshape(4, 4), rs.projmatrix.reshape(4, 4),
             rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy,

@@ -69,12 +69,19 @@ SEQ = {
     'nice': dict(bound=[[-5.5, 5.9], [-6.7, 5.4], [-4.7, 5.3]], H=120, W=160,
                  fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=600, shrink=0.3,
                  run_frames=60),
+    # 20 frames = 10.5 cm of path (round 5: 8 frames with counts so reduced —
+    # 20 x 300 tracking — that the reference loop DIVERGED, 5.0 cm against
+    # 2.6 cm for a pose frozen at frame 0; tools/c1_regime.py)
     'pointslam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=120,
                       W=160, fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=200,
-                      run_frames=8),
-    'splatam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=48,
-                    W=64, fx=32.0, fy=32.0, cx=31.5, cy=23.5, n_frames=200,
-                    run_frames=4),
+                      run_frames=20),
+    # 160x120, 20 frames = 10.5 cm of path (round 5: 4 frames at 64x48 on the
+    # dense O(N H W) stand-in, where the reference loop scored 6.1 cm against
+    # 1.2 cm for a frozen pose: at 64x48 a Gaussian per pixel is too coarse to
+    # track on; tools/c1_regime.py)
+    'splatam': dict(bound=[[-3.0, 3.0], [-4.0, 2.5], [-2.0, 2.5]], H=120,
+                    W=160, fx=80.0, fy=80.0, cx=79.5, cy=59.5, n_frames=200,
+                    run_frames=20),
 }
 
 
@@ -461,11 +468,11 @@ def _image_libs():
 
 
 def pointslam():
-    """input_config.py:297-375 on a 160x120 camera with reduced counts (the
-    reference's 1500 / 5000 rays x 40 / 300 iterations take hours on the
-    CPU): 20 tracking iterations x 300 rays, every frame (lazy_start 20) 40
-    mapping iterations x 1000 rays, first 150; 1500 + 200 pixels added per
-    frame.  kNN = oracle/faiss_standin.py (exact)"""
+    """input_config.py:297-375 on a 160x120 camera: the reference's tracking
+    (40 iterations x 1500 rays) and point seeding, every frame (lazy_start 20)
+    100 mapping iterations x 2000 rays, first 500 (the reference's 300 x 5000
+    / 1500 take ~5 h a seed on these CPUs).  kNN = oracle/faiss_standin.py
+    (exact)"""
     import copy
 
     import faiss_standin
@@ -493,10 +500,12 @@ def pointslam():
     cam = Camera(s['fx'], s['fy'], s['cx'], s['cy'], s['W'], s['H'])
     out = _header(s)
     cfg0 = copy.deepcopy(x.algorithm)
+    # the reference's tracking (40 iterations x 1500 rays), point seeding and
+    # colour-gradient pixels; the mapping counts are cut for the CPU (100 x
+    # 2000 rays a frame instead of 300 x 5000, first 500 instead of 1500)
     _reduced(out, cfg0, tracking_Hedge=10, tracking_Wedge=10,
-             tracking_n_iters=20, tracking_sample=300, mapping_n_iters=40,
-             mapping_first_n_iters=150, mapping_sample=1000,
-             pixels_adding=1500, mapping_pixels_based_on_color_grad=200)
+             mapping_n_iters=100, mapping_first_n_iters=500,
+             mapping_sample=2000)
     out['cad/lazy_start'] = np.array(x.tracker.lazy_start)
 
     def make():
@@ -507,13 +516,15 @@ def pointslam():
 
 
 def splatam():
-    """input_config.py:377-431 on a 64x48 camera: 40 tracking iterations and
-    60 mapping iterations a frame, every frame, the reference's SplaTAM /
-    GaussianSplatting / GaussianCloud on oracle/gs_standin.py (dense
-    O(N H W) rasteriser, "parity unpinned": see oracle/gs_oracle.py)"""
+    """input_config.py:377-431 on a 160x120 camera: the reference's 40
+    tracking iterations and 60 mapping iterations a frame, every frame, the
+    reference's SplaTAM / GaussianSplatting / GaussianCloud on
+    oracle/gs_standin.py in its tile-culled form (oracle/gs_tiled.py; "parity
+    unpinned": see oracle/gs_oracle.py)"""
     import copy
 
     import gs_standin
+    gs_standin.TILED = True        # oracle/gs_tiled.py (= the dense oracle)
     ref_harness.install()
     sys.modules['diff_gaussian_rasterization'] = gs_standin.module()
     _zeros_on_cpu()

@@ -29,6 +29,15 @@ def ref_stats(g):
     return np.sqrt((err**2).mean(1)), err
 
 
+def frozen_ate(gt):
+    """ATE of a "tracker" that never moves: every estimate = the pose of frame
+    0.  The yardstick a fixture has to beat to certify TRACKING: a loop whose
+    error is not well below it (round 5's NICE-SLAM / Point-SLAM / SplaTAM
+    fixtures were above it) says nothing about the tracker."""
+    t = np.asarray(gt)[:, :3, 3]
+    return float(np.sqrt(((t - t[0])**2).sum(1).mean()))
+
+
 def room(g, dev):
     from xrdslam_amd.data.synthetic import SyntheticRoom
     fx, fy, cx, cy, W, H = (float(v) for v in g['seq/intrinsics'])

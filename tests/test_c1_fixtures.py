@@ -37,6 +37,19 @@ def test_fixture_is_self_consistent(name):
 
 
 @pytest.mark.parametrize('name', CASES)
+def test_reference_loop_tracks_in_the_fixture(name):
+    """the fixture certifies TRACKING: the reference loop's ATE (every seed)
+    is at most half of what a pose frozen at frame 0 scores on the same
+    sequence — the sequence is long enough, and the iteration counts high
+    enough, that standing still is clearly worse than tracking"""
+    g = c1_util.fixture(name)
+    ate, _ = c1_util.ref_stats(g)
+    frozen = c1_util.frozen_ate(g['gt'])
+    assert frozen > 0.02                       # > 2 cm: a path worth tracking
+    assert ate.max() <= 0.5 * frozen, (ate, frozen)
+
+
+@pytest.mark.parametrize('name', CASES)
 def test_fixture_ground_truth_is_the_room_the_engine_runs(name):
     """incl. the tracker's relative-pose convention (tracker.py:76-89: poses
     relative to the first frame, placed at identity + init_pose_offset —

@@ -45,6 +45,13 @@ def _worker(rank, world, port, out):
     stale._xrd_grad_fresh = False  # no gradient this iteration: not exchanged
     xd.allreduce_param_grads({'a': [dense], 'g': [grid], 's': [stale]})
     cells = grid.grad.permute(0, 2, 3, 4, 1).reshape(-1, 32)
+    # the exchange's bookkeeping (bench.py --gpus N: rccl.bucket_bytes /
+    # allreduce_ms): one exchange of 5 dense floats + 3 selected cells x 32
+    assert xd.state.stats['exchanges'] == 1
+    assert xd.state.stats['bucket_bytes_max'] == 4 * (5 + 3 * 32)
+    ms = xd.state.measure_allreduce_ms(xd.state.stats['bucket_bytes_max'],
+                                       iters=3)
+    assert ms is not None and 0.0 < ms < 1e4
     out[rank] = (dense.grad.clone(), cells.clone(), stale.grad.clone(),
                  draw.clone())
     dist.barrier()

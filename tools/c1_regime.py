@@ -95,24 +95,30 @@ def main():
         run('nice', '40 frames, first 400 / 60 a mapping call',
             variant('nice', base, mid, 40))
     elif which == 'pointslam':
-        red = dict(tracking_Hedge=10, tracking_Wedge=10, tracking_n_iters=20,
-                   tracking_sample=300, mapping_n_iters=40,
-                   mapping_first_n_iters=150, mapping_sample=1000,
-                   pixels_adding=1500, mapping_pixels_based_on_color_grad=200)
-        for n_run in (8, 20, 30):
-            run('pointslam', f'{n_run} frames reduced counts',
-                variant('pointslam', base, red, n_run, lazy=20))
-        more = dict(red, tracking_n_iters=40, tracking_sample=600,
-                    mapping_n_iters=80, mapping_first_n_iters=300)
-        for n_run in (20, 30):
-            run('pointslam', f'{n_run} frames, 40x600 tracking, 80 mapping',
-                variant('pointslam', base, more, n_run, lazy=20))
-        slow = dict(base, n_frames=400)
-        run('pointslam', '30 frames half pace reduced',
-            variant('pointslam', slow, red, 30, lazy=20))
-        full = dict(tracking_Hedge=10, tracking_Wedge=10)
-        run('pointslam', '20 frames reference counts',
-            variant('pointslam', base, full, 20, lazy=20), seeds=(0,))
+        hw = dict(tracking_Hedge=10, tracking_Wedge=10)
+        variants = {
+            'A track 40x1500, map 100x2500, first 500':
+                dict(hw, mapping_n_iters=100, mapping_sample=2500,
+                     mapping_first_n_iters=500),
+            'B track 40x1500, map 150x5000, first 750':
+                dict(hw, mapping_n_iters=150, mapping_first_n_iters=750),
+            'C track 40x1500, map 60x1000, first 300':
+                dict(hw, mapping_n_iters=60, mapping_sample=1000,
+                     mapping_first_n_iters=300),
+            'D track 40x1000, map 100x2000, first 500':
+                dict(hw, tracking_sample=1000, mapping_n_iters=100,
+                     mapping_sample=2000, mapping_first_n_iters=500),
+            'E track 40x600, map 100x2500, first 500':
+                dict(hw, tracking_sample=600, mapping_n_iters=100,
+                     mapping_sample=2500, mapping_first_n_iters=500),
+            'F reference counts': dict(hw),
+        }
+        only = sys.argv[2] if len(sys.argv) > 2 else ''
+        for label, cfg in variants.items():
+            if only and label[0] not in only:
+                continue
+            run('pointslam', f'20 frames {label}',
+                variant('pointslam', base, cfg, 20, lazy=20))
     elif which == 'splatam':
         for (W, H, f) in ((64, 48, 32.0), (160, 120, 80.0)):
             sq = dict(base, W=W, H=H, fx=f, fy=f, cx=W / 2 - 0.5,

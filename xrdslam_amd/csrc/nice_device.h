@@ -81,6 +81,73 @@ __device__ __forceinline__ void tri_prepare(const double (&p)[3],
   }
 }
 
+// tri_prepare in two halves.  The float64 normalisation of a point (a
+// subtraction, a DIVISION — ~40 instructions —, a multiply-add and the
+// rounding to float, per axis) depends on the bound only, and the middle,
+// fine and colour grids share it: tri_norm once per sample, tri_prepare_n per
+// lookup (float arithmetic + the eight corner offsets).  The one-launch
+// mapping iteration prepared the same point six times (three gathers, three
+// scatters): 18 float64 divisions a sample, more instructions than a
+// decoder's VALU work — and on gfx950 the f32 MFMAs run on the VALU's lanes
+// (DESIGN 4.1f), so every VALU instruction is time the MFMAs do not get.
+// Same operations in the same order as axis_prepare: identical cells/weights.
+__device__ __forceinline__ void tri_norm(const double (&p)[3], const double* bd,
+                                         float (&xn)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double b0 = bd[2 * a] * 1.0, b1 = bd[2 * a + 1] * 1.0;
+    const double ext = b1 - b0;
+    xn[a] = (float)(((p[a] - b0) / ext) * 2.0 - 1.0);
+  }
+}
+__device__ __forceinline__ void axis_cell(float xn, int N, int& i0, int& i1,
+                                          float& w0, float& w1, float& mult) {
+  float ix = ((xn + 1.f) / 2.f) * (float)(N - 1);
+  float gm = (float)(N - 1) / 2.f;
+  const float mx = (float)(N - 1);
+  if (!(ix > 0.f)) {
+    ix = 0.f;
+    gm = 0.f;
+  } else if (ix >= mx) {
+    ix = mx;
+    gm = 0.f;
+  }
+  const float f = floorf(ix);
+  i0 = (int)f;
+  i1 = i0 + 1;
+  w1 = ix - f;
+  w0 = (f + 1.f) - ix;
+  if (i1 > N - 1) {  // torch skips the out-of-range corner (its weight is 0)
+    i1 = N - 1;
+    w1 = 0.f;
+  }
+  mult = gm;
+}
+// NEED_INV: t.inv (d normalised / d world, a float64 division per axis) is
+// only read by tri_backward_dp
+template <bool NEED_INV>
+__device__ __forceinline__ void tri_prepare_n(const float (&xn)[3],
+                                              const double* bd,
+                                              const int* dim, Tri& t) {
+  const int Z = dim[0], Y = dim[1], X = dim[2];
+  int x0, x1, y0, y1, z0, z1;
+  axis_cell(xn[0], X, x0, x1, t.wa[0][0], t.wa[0][1], t.mult[0]);
+  axis_cell(xn[1], Y, y0, y1, t.wa[1][0], t.wa[1][1], t.mult[1]);
+  axis_cell(xn[2], Z, z0, z1, t.wa[2][0], t.wa[2][1], t.mult[2]);
+  if (NEED_INV) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      t.inv[a] = 2.0 / (bd[2 * a + 1] * 1.0 - bd[2 * a] * 1.0);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int xi = (c & 1) ? x1 : x0, yi = (c & 2) ? y1 : y0,
+              zi = (c & 4) ? z1 : z0;
+    t.off[c] = ((zi * Y + yi) * X + xi) * 32;
+    t.w[c] = (t.wa[0][c & 1] * t.wa[1][(c >> 1) & 1]) * t.wa[2][(c >> 2) & 1];
+  }
+}
+
 // gather the lane's 8 channels (16*kt + 4*q + r) of a 32-channel cell
 __device__ __forceinline__ void tri_gather(const float* __restrict__ grid,
                                            const Tri& t, int q,
@@ -152,11 +219,22 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) S.gt[i * 33 + 16 * kt + 4 * q + r] = gc[kt][r];
-  if (q == 0) {
+  // the frustum selection (cmask: one byte a cell, 0 = the cell's gradient is
+  // dropped) is looked up HERE, once per (point, corner) and all of them in
+  // flight together, and folded into the offset's sign: ~off (negative) for
+  // a masked cell.  Rounds 2-5 read the byte inside the run loop — a
+  // dependent global load in front of every flush (the frame loop always
+  // passes a selection; the timing tools did not, which hid it).
+  if (q < 2) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      S.off[i * 8 + k] = t.off[k];
-      S.w[i * 8 + k] = t.w[k];
+    for (int k = 0; k < 4; ++k) {
+      // (static indices + selects: a run-time index into t.off / t.w would
+      // put the Tri into scratch memory)
+      const int kk = 4 * q + k;
+      const int o = q == 0 ? t.off[k] : t.off[4 + k];
+      const bool keep = cmask == nullptr || cmask[o >> 5] != 0;
+      S.off[i * 8 + kk] = keep ? o : ~o;
+      S.w[i * 8 + kk] = q == 0 ? t.w[k] : t.w[4 + k];
     }
   }
   wave_lds_sync();
@@ -177,7 +255,7 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
       const int o = S.off[pt * 8 + k];
       const float wk = S.w[pt * 8 + k];
       if (o != cur[k]) {
-        if (cur[k] >= 0 && acc[k] != 0.f && (!cmask || cmask[cur[k] >> 5]))
+        if (cur[k] >= 0 && acc[k] != 0.f)
           atomicAdd(ggrid + cur[k] + ch, acc[k]);
         cur[k] = o;
         acc[k] = 0.f;
@@ -187,8 +265,7 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (cur[k] >= 0 && acc[k] != 0.f && (!cmask || cmask[cur[k] >> 5]))
-      atomicAdd(ggrid + cur[k] + ch, acc[k]);
+    if (cur[k] >= 0 && acc[k] != 0.f) atomicAdd(ggrid + cur[k] + ch, acc[k]);
 }
 
 // ---------------------------------------------------------------------------

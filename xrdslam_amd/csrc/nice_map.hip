@@ -847,6 +847,7 @@ nice_map_fused_kernel(
     float gd = 0.f;
     TileGeom tg = {};
     float p32[1][3] = {{0.f, 0.f, 0.f}};
+    float xn[3] = {0.f, 0.f, 0.f};   // the point in the bound's [-1, 1]^3
     float occ = 0.f, col[3] = {0.f, 0.f, 0.f};
     uint64_t mask_m[1] = {0}, mask_f[1] = {0}, mask_c[1] = {0};
     f32x4 c_m[1][2], c_c[1][2];
@@ -860,7 +861,8 @@ nice_map_fused_kernel(
       tile_geom(rc, zbuf[64 + 16 * tile + li], sc.bound, tg);
 #pragma unroll
       for (int a = 0; a < 3; ++a) p32[0][a] = tg.p32[a];
-      tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+      tri_norm(tg.p64, sc.bound, xn);   // once for all six lookups
+      tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 3, tr);
       tri_gather(sc.grid[1], tr, q, c_m[0]);
     }
     stage_weights(wl, sc.dec[1], PM::WHT);
@@ -875,7 +877,7 @@ nice_map_fused_kernel(
       f32x4 c_f[1][4];
       if (active) {
         f32x4 cf[2];
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 6, tr);
         tri_gather(sc.grid[2], tr, q, cf);
         c_f[0][0] = cf[0];
         c_f[0][1] = cf[1];
@@ -893,7 +895,7 @@ nice_map_fused_kernel(
     }
     if (STAGE == XRD_STAGE_COLOR) {
       if (active) {
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 9, tr);
         tri_gather(sc.grid[3], tr, q, c_c[0]);
         if (NEED_DW) scr_put(tsc + SC_C, lane, c_c[0]);
       }
@@ -1009,7 +1011,7 @@ nice_map_fused_kernel(
                                             mask_c[0], gc[0], gp32[0]);
       }
       if (active) {
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);
+        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 9, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[3], tr, q, gc[0], gp64);
         if constexpr (!TRACK)
           grid_scatter(gg_color, sc.gmask[3], tr, lane, gc[0], SL);
@@ -1025,7 +1027,7 @@ nice_map_fused_kernel(
         mlp_bwd_ra<64, 1, NEED_DP, NEED_DP>(wl - PF::EMB, lane, p32[0], go[0],
                                             mask_f[0], gc[0], gp32[0]);
         const f32x4 g2[2] = {gc[0][0], gc[0][1]};  // c_middle is no_grad
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);
+        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 6, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[2], tr, q, g2, gp64);
         if constexpr (!TRACK)
           grid_scatter(gg_fine, sc.gmask[2], tr, lane, g2, SL);
@@ -1040,7 +1042,7 @@ nice_map_fused_kernel(
       if (active) {
         mlp_bwd_ra<32, 1, NEED_DP, NEED_DP>(wl - PM::EMB, lane, p32[0], go[0],
                                             mask_m[0], gc[0], gp32[0]);
-        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);
+        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 3, tr);
         if (NEED_DP) tri_backward_dp(sc.grid[1], tr, q, gc[0], gp64);
         if constexpr (!TRACK)
           grid_scatter(gg_middle, sc.gmask[1], tr, lane, gc[0], SL);

@@ -113,6 +113,40 @@ class DistState:
         self.deterministic = os.environ.get('XRD_DIST_DETERMINISTIC',
                                             '1') != '0'
         self._bucket = None
+        # host-side bookkeeping of the gradient exchange (what bench.py
+        # --gpus N reports per rank): number of exchanges enqueued from Python
+        # (a captured iteration counts once, its replays do not pass here) and
+        # the size of the flat bucket
+        self.stats = {'exchanges': 0, 'bucket_bytes_last': 0,
+                      'bucket_bytes_max': 0}
+
+    def note_exchange(self, n_floats: int) -> None:
+        st = self.stats
+        st['exchanges'] += 1
+        st['bucket_bytes_last'] = 4 * int(n_floats)
+        st['bucket_bytes_max'] = max(st['bucket_bytes_max'], 4 * int(n_floats))
+
+    def measure_allreduce_ms(self, nbytes: int, iters: int = 20):
+        """mean time of ONE sum all-reduce of ``nbytes`` on the exchange path
+        (what a mapping iteration pays for its gradient bucket), in ms"""
+        if not self.enabled or nbytes <= 0:
+            return None
+        dev = self.comm.device if self.comm is not None else (
+            torch.device('cuda', torch.cuda.current_device())
+            if dist.get_backend() == 'nccl' else torch.device('cpu'))
+        flat = torch.zeros(max(1, nbytes // 4), dtype=torch.float32,
+                           device=dev)
+        for _ in range(3):
+            allreduce_flat(flat)
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            allreduce_flat(flat)
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / iters * 1e3
 
     def setup(self, device, seed=0):
         self.enabled = dist.is_available() and dist.is_initialized() and \
@@ -212,6 +246,7 @@ def allreduce_bucket(tensors: List[torch.Tensor]) -> None:
     if not state.enabled or not tensors:
         return
     total = sum(t.numel() for t in tensors)
+    state.note_exchange(total)
     flat = state.bucket(total, tensors[0].device)
     views, off = [], 0
     for t in tensors:
@@ -276,6 +311,7 @@ def run_grad_jobs(jobs) -> None:
     total = sum(t.numel() for t in dense) + sum(
         r * g.shape[1] for r, (g, _, _) in zip(rows, cell_jobs))
     ref = dense[0] if dense else cell_jobs[0][0]
+    state.note_exchange(total)
     flat = state.bucket(total, ref.device)
     off, dviews, cviews = 0, [], []
     for t in dense:
