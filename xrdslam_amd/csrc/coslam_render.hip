@@ -466,11 +466,10 @@ __device__ __forceinline__ void dw_flush(float* red, int base, int in_dim, int j
                   acc[m][n][r]);
 }
 
-#ifndef XRD_CS_DG_OCC
-#define XRD_CS_DG_OCC 1
-#endif
+// (the table-gradient variant keeps 30 weight-gradient accumulators a wave:
+// 250 VGPRs + 184 AGPRs, one wave a SIMD)
 template <bool DP, bool DG>
-__global__ __launch_bounds__(kBwdWaves * 64, DG ? XRD_CS_DG_OCC : 2) void coslam_bwd_kernel(
+__global__ __launch_bounds__(kBwdWaves * 64, DG ? 1 : 2) void coslam_bwd_kernel(
     Scene sc, int n_rays, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ z_vals,
     const float* __restrict__ raw, const float* __restrict__ g_maps,

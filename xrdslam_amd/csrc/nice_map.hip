@@ -27,12 +27,12 @@
 // ReLU masks, positions: 23 KB a tile) into a per-tile scratch as
 // feature-major matrices [32 features][16 points], and after the last decoder
 // of the group the block's 12 waves contract the group's 12 tiles — 62 16x16
-// blocks as 25 units that share their A / B operands, 4-6 accumulators a wave,
-// every operand one coalesced 16-byte load per lane and 4 MFMAs, no barrier —
-// and add their blocks to one of 8 replicas.  embedder._B (3 x 93) is reduced
-// on the VALU (row reductions + LDS adds) instead of 6 padded MFMA blocks.
-// The scratch is written and read once by the same CU a few microseconds
-// apart (L2 / Infinity-Cache traffic, 71 MB at 1000 rays).
+// output blocks, 4-8 accumulators a wave — and write the block's row of the
+// partial gradient.  Round 6: the operands come back through an LDS ring
+// filled by LDS-DMA loads (each fetched once; rounds 3-5 read them from the
+// scratch per unit, 2-10 times each, behind six dependent round trips a
+// unit), see dw_contract.  embedder._B (3 x 93) is reduced on the VALU (row
+// reductions + LDS adds) instead of 6 padded MFMA blocks.
 // Reference maths restated (never copied): conv_onet.py:339-524 (sampling,
 // eval_points, the stage's decoders), decoder_nice.py:103-234,
 // utils.py:189-244 (raw2outputs_nerf_color), conv_onet.py:145-185 (losses).
