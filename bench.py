@@ -455,7 +455,26 @@ def run_coslam(args, dev, with_cpu, world=1):
         'share_of_timed_kernel_time': total_ms / sum(s[0] for s in stats),
         'note': 'launches inside replayed hipGraphs (tracking) are not '
                 'event-timed; eager launches (mapping, first tracking '
-                'iteration of a frame) are'}
+                'iteration of a frame) are',
+        # the 6.6 MB hash table is L2-resident: HBM is not what binds this
+        # launch group.  The counters name the resource: the render backward
+        # with table gradients spends most of its issue cycles waiting to
+        # ISSUE LDS instructions (SQ_WAIT_INST_LDS: its per-layer operand
+        # transposes at one wave a SIMD), the chunk scatter is LDS-atomic
+        # bound (profiles/r04_coslam_scatter_experiments.txt)
+        'binding_resource': 'LDS issue (SQ_WAIT_INST_LDS / issue cycles of '
+                            'coslam_bwd<dp=false,dg=true>, hash_chunk_'
+                            'scatter_runs_kernel: see wait_inst_lds_over_'
+                            'issue, scatter_wait_inst_lds_over_issue)'}
+    try:
+        _d = json.load(open(os.path.join(ROOT, 'profiles', 'r06_pmc.json')))[
+            '_derived']
+        roofline['scatter_wait_inst_lds_over_issue'] = _d[
+            'hash_chunk_scatter_runs_kernel']['wait_inst_lds_over_issue']
+        roofline['bwd_map_wait_inst_lds_over_issue'] = _d[
+            'coslam_bwd<dp=false,dg=true>']['wait_inst_lds_over_issue']
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         'metric': 'tracking+mapping FPS @640x480',
         'value': args.steps / elapsed, 'unit': 'frames/s',
@@ -768,6 +787,35 @@ def run_voxfusion(args, dev, world=1):
             'timing_source': 'HIP events around the eager launches of two '
                              'frames run right after the timed region (the '
                              'timed region replays captured graphs)'}
+        # the launch group with the largest share of the FRAME: a mapping
+        # iteration's decoder trio (forward, backward with the weight-
+        # gradient operands, the weight products) — 15 iterations a frame
+        # against 30 tracking iterations of the cheaper decoder_grad=0 pair
+        # the roofline above quotes — with its OWN counter traffic
+        trio = [per_launch.get(f'{k}[decoder_grad=1]') for k in
+                ('vox_points_fwd', 'vox_points_bwd', 'vox_dw')]
+        if all(t is not None for t in trio):
+            pts_w = np.mean([s_['n_pts'] for m_, s_ in log
+                             if m_ and s_]) if log else 0.0
+            t_us = float(sum(trio))
+            fl = pts_w * VOX_FLOPS * 3.0      # forward + (input + weight) grads
+            tr = pmc_traffic(['vox_points_fwd_kernel',
+                              'vox_points_bwd<dw=true>', 'vox_dw_kernel',
+                              'vox_dw_reduce_kernel'], 'r04_pmc_vox.json')
+            roofline['mapping_group'] = {
+                'kernels': 'vox_points_fwd + vox_points_bwd<dw> + vox_dw '
+                           '(+ reduce) of one mapping iteration',
+                'launch_group_us': t_us, 'points': float(pts_w),
+                'algorithmic_flops': fl,
+                'frac': fl / (t_us * 1e-6) / MFMA_F32_PEAK if t_us else None,
+                'traffic': tr,
+                'algorithmic_bytes': pts_w * (VOX_BYTES + 1024),
+                'traffic_over_algorithmic': (
+                    tr / (pts_w * (VOX_BYTES + 1024)) if tr and pts_w else
+                    None),
+                'share_of_frame': 15.0 * t_us * 1e-3 /
+                (elapsed / args.steps * 1e3),
+                'traffic_source': f'profiles/{PMC_FILE[0]}'}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = calibrated(vox_cpu_baseline(min(os.cpu_count() or 1, CPU_THREADS)),

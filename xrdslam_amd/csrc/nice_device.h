@@ -225,16 +225,13 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
   // a masked cell.  Rounds 2-5 read the byte inside the run loop — a
   // dependent global load in front of every flush (the frame loop always
   // passes a selection; the timing tools did not, which hid it).
-  if (q < 2) {
+  if (q == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // (static indices + selects: a run-time index into t.off / t.w would
-      // put the Tri into scratch memory)
-      const int kk = 4 * q + k;
-      const int o = q == 0 ? t.off[k] : t.off[4 + k];
+    for (int k = 0; k < 8; ++k) {
+      const int o = t.off[k];
       const bool keep = cmask == nullptr || cmask[o >> 5] != 0;
-      S.off[i * 8 + kk] = keep ? o : ~o;
-      S.w[i * 8 + kk] = q == 0 ? t.w[k] : t.w[4 + k];
+      S.off[i * 8 + k] = keep ? o : ~o;
+      S.w[i * 8 + k] = t.w[k];
     }
   }
   wave_lds_sync();
