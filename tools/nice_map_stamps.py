@@ -30,20 +30,20 @@ ANCHORS = [
     ('fwdM', '    if (STAGE >= XRD_STAGE_FINE) {\n      f32x4 c_f[1][4];\n      if (active) {\n        f32x4 cf[2];', 0, 'before'),
     ('gatherF', '      stage_weights(wl, sc.dec[2], PF::WHT);\n', 0, 'before'),
     ('stageF', '      stage_weights(wl, sc.dec[2], PF::WHT);\n', 0, 'after'),
-    ('fwdF', '    if (STAGE == XRD_STAGE_COLOR) {\n      if (active) {\n        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);\n        tri_gather', 0, 'before'),
+    ('fwdF', '    if (STAGE == XRD_STAGE_COLOR) {\n      if (active) {\n        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 9, tr);\n        tri_gather', 0, 'before'),
     ('gatherC', '      stage_weights(wl, sc.dec[3], PC::WHT);\n', 0, 'before'),
     ('stageC', '      stage_weights(wl, sc.dec[3], PC::WHT);\n', 0, 'after'),
     ('fwdC', '    if (active) {\n      if (!tg.inb) occ = 100.f;', 0, 'before'),
     ('raw+barrier', '    // ---- compositing, loss, compositing backward', 0, 'before'),
     ('composite', '    // ---- backward: colour -> fine -> middle', 0, 'before'),
     ('stageCb', '      if (NEED_DW) {\n        if (active)\n          color_bwd_emit', 0, 'before'),
-    ('bwdC', '      if (active) {\n        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 9, tr);\n        if (NEED_DP) tri_backward_dp(sc.grid[3]', 0, 'before'),
+    ('bwdC', '      if (active) {\n        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 9, tr);\n        if (NEED_DP) tri_backward_dp(sc.grid[3]', 0, 'before'),
     ('scatterC', '    if (STAGE >= XRD_STAGE_FINE) {\n      f32x4 c_f[1][4], gc[1][4];', 0, 'before'),
     ('stageFb', '      asm volatile("" : "+v"(lane));\n      if (active) {\n        mlp_bwd_ra<64, 1, NEED_DP, NEED_DP>', 0, 'before'),
-    ('bwdF', '        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 6, tr);\n        if (NEED_DP) tri_backward_dp(sc.grid[2]', 0, 'before'),
+    ('bwdF', '        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 6, tr);\n        if (NEED_DP) tri_backward_dp(sc.grid[2]', 0, 'before'),
     ('scatterF', '    {\n      const float go[1][1] = {{gocc}};\n      f32x4 gc[1][2];\n      stage_weights(wl, sc.dec[1] + PM::EMB', 0, 'before'),
     ('stageMb', '      asm volatile("" : "+v"(lane));\n      if (active) {\n        mlp_bwd_ra<32, 1, NEED_DP, NEED_DP>', 0, 'before'),
-    ('bwdM', '        tri_prepare(tg.p64, sc.bound, 1.0, sc.gdim + 3, tr);\n        if (NEED_DP) tri_backward_dp(sc.grid[1]', 0, 'before'),
+    ('bwdM', '        tri_prepare_n<NEED_DP>(xn, sc.bound, sc.gdim + 3, tr);\n        if (NEED_DP) tri_backward_dp(sc.grid[1]', 0, 'before'),
     ('scatterM', '    if (NEED_DW) {\n      // every tile of the group has left its operands', 0, 'before'),
     ('dW barrier', '      const int rays_here = n - grp * G::RPBM', 0, 'before'),
     ('dW contract', '      // (a further group\'s set-up writes the LDS the last round', 0, 'before'),

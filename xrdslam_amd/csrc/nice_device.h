@@ -200,6 +200,18 @@ __device__ __forceinline__ void tri_backward_dp(const float* __restrict__ grid,
 // LDS, then each half-wave walks 8 consecutive points, merges runs that hit
 // the same cell in registers and issues one fully coalesced 128-B atomic per
 // (run, corner).
+//
+// Round 6 (the scatters were 3 x 9 us of the 175 us mapping block, and on
+// gfx950 that is instruction issue: a SIMD's VALU instructions and MFMAs add
+// up): the run structure is worked out ONCE, in parallel — the
+// 16 point lanes compare their corner offsets with the next point's, eight
+// ballots give "the run of corner k ends at point i" as wave-uniform bit
+// masks — instead of by every lane at every (point, corner) step (an offset
+// read, a compare against a tracked current cell, two conditional moves).
+// The walk is a multiply-add a step; a flush block is skipped by a scalar
+// branch when neither half-wave ends a run there; offsets and weights of a
+// point come in as four 16-byte LDS reads instead of sixteen 4-byte ones.
+// Runs, flush order and sums are those of rounds 2-5.
 struct ScatterLds {
   float* gt;   // [16][33] transposed gradients (point-major)
   int* off;    // [16][8]
@@ -234,35 +246,50 @@ __device__ __forceinline__ void grid_scatter(float* __restrict__ ggrid,
       S.w[i * 8 + k] = t.w[k];
     }
   }
-  wave_lds_sync();
-  const int half = lane >> 5, ch = lane & 31;
-  int cur[8];
-  float acc[8];
+  // ends[k]: bit i = the run of corner k ends at point i (the next point of
+  // the half-wave sits in another cell, or i is the half's last point);
+  // lanes 0..15 are the point lanes (q == 0), so the ballot's low 16 bits
+  // are the points
+  uint32_t ends[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    cur[k] = -1;
-    acc[k] = 0.f;
+    const int nxt = __shfl_down(t.off[k], 1, 16);
+    const bool e = (i & 7) == 7 || nxt != t.off[k];
+    ends[k] = (uint32_t)__ballot(q == 0 && e) & 0xffffu;
   }
-#pragma unroll 1
+  wave_lds_sync();
+  const int half = lane >> 5, ch = lane & 31;
+  // this half's byte of each mask: bit j = point 8 half + j
+  uint32_t mine[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mine[k] = (ends[k] >> (8 * half)) & 0xffu;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const float* gt = S.gt + half * 8 * 33 + ch;
+  const int* po = S.off + half * 64;
+  const float* pw = S.w + half * 64;
+#pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int pt = half * 8 + j;
-    const float v = S.gt[pt * 33 + ch];
+    const float v = gt[j * 33];
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(pw + j * 8);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(pw + j * 8 + 4);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 o0 = *reinterpret_cast<const i32x4*>(po + j * 8);
+    const i32x4 o1 = *reinterpret_cast<const i32x4*>(po + j * 8 + 4);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int o = S.off[pt * 8 + k];
-      const float wk = S.w[pt * 8 + k];
-      if (o != cur[k]) {
-        if (cur[k] >= 0 && acc[k] != 0.f)
-          atomicAdd(ggrid + cur[k] + ch, acc[k]);
-        cur[k] = o;
-        acc[k] = 0.f;
-      }
+      const float wk = k < 4 ? w0[k & 3] : w1[k & 3];
+      const int o = k < 4 ? o0[k & 3] : o1[k & 3];
       acc[k] = fmaf(wk, v, acc[k]);
+      // (wave-uniform: does either half end a run of corner k here?)
+      if ((ends[k] >> j) & 0x101u) {
+        const bool end = (mine[k] >> j) & 1u;
+        if (end && o >= 0 && acc[k] != 0.f) atomicAdd(ggrid + o + ch, acc[k]);
+        acc[k] = end ? 0.f : acc[k];
+      }
     }
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (cur[k] >= 0 && acc[k] != 0.f) atomicAdd(ggrid + cur[k] + ch, acc[k]);
 }
 
 // ---------------------------------------------------------------------------
