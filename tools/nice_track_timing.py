@@ -88,7 +88,10 @@ f_masks()
 torch.cuda.synchronize()
 print(f'{n} rays: decoder-per-block forward == three-pass forward (depth, '
       'var, rgb, raw):',
-      [bool(torch.equal(a, b)) for a, b in zip(ref, (dep, var, rgb, raw))])
+      [bool(torch.equal(a, b)) for a, b in zip(ref, (dep, var, rgb, raw))],
+      'largest |difference|:',
+      [float((a.double() - b.double()).abs().max())
+       for a, b in zip(ref, (dep, var, rgb, raw))])
 A = torch.randn(8192, 8192, device=dev)
 for name, f in (('xrd_nice_render_fwd (three passes a wave)', f_plain),
                 ('xrd_nice_render_fwd_masks (roles + finish)', f_masks),

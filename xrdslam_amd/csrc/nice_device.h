@@ -456,7 +456,8 @@ __device__ __forceinline__ void mlp_fwd(const float* __restrict__ pk, int lane,
 // unrolled and every batch of fragments is requested one MFMA batch early:
 // fc_c.(i+1)'s fragments before the 16 MFMAs of pts_linears.(i+1), those of
 // pts_linears.(i+2) before the MFMAs of fc_c.(i+1).  Same MFMA order per
-// accumulator as mlp_fwd: bit-identical results.
+// accumulator as mlp_fwd; the outputs differ from mlp_fwd's by rounding only
+// (<= 1e-6: the compiler contracts the VALU output layer differently).
 template <int CD, int OD, bool SAVE_MASK, bool EMIT_H>
 __device__ __forceinline__ void mlp_fwd_ra(const float* __restrict__ pk,
                                            int lane, const float (&p)[3],
@@ -837,7 +838,7 @@ __device__ __forceinline__ void mlp_bwd(
 // fragments are requested before the MFMAs of fc_c.i's, fc_c.(i-1)'s before
 // the MFMAs of pts_linears.i; the embedding backward requests column tile
 // kt+1 before the MFMAs of tile kt.  Same MFMA order per accumulator as
-// mlp_bwd: bit-identical results.
+// mlp_bwd (results equal to rounding).
 template <int CD, int OD, bool NEED_E, bool NEED_DP>
 __device__ __forceinline__ void mlp_bwd_ra(
     const float* __restrict__ pk, int lane, const float (&p)[3],
