@@ -811,3 +811,44 @@ def test_tracking_backward_from_the_forwards_masks(n, masked):
                                          p, p, p, p, None) == 3   # unsupported
     assert lib.xrd_nice_render_fwd_masks(C.byref(cs), 3, 8, p, p, p, p, p, p,
                                          p, p, None, None) == 1   # no masks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1000, 37])
+def test_partial_rows_need_no_zeroing(n):
+    """the blocks' partial rows of the colour decoder's gradient (the one-launch
+    mapping iteration's workspace) are written with plain stores by each
+    block's first group and NOT zeroed by the finishing launch any more: every
+    entry of a row must be stored in every launch.  The rows are poisoned with
+    NaN between two identical calls; the gradient must come out the same."""
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n, 5)
+    scene, gl, flats = build_scene(bound, grids, decs, dev,
+                                   color_requires_grad=True,
+                                   grid_requires_grad=True)
+    args = (scene, 'color', rays_o.to(dev), rays_d.to(dev), depth.to(dev),
+            depth.max().to(dev), color.to(dev), None, 0.2, False, True)
+    _, _, _, g1 = en.nice_map_iter(*args)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    ws = scene._map_ws[(False, n)]
+    rep_off = n * 3 * 6 * 2 + 2 * n + 4
+    n_rows = min((n + 3) // 4, 256)
+    flat_len = g1.numel()
+    ws[rep_off:rep_off + n_rows * flat_len] = float('nan')
+    _, _, _, g2 = en.nice_map_iter(*args)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g2).all())          # nothing poisoned is read
+    # bit for bit outside embedder._B (its sums meet in LDS float atomics:
+    # the order, hence the last bit, is the hardware's)
+    off, same = 0, torch.ones_like(g1, dtype=torch.bool)
+    for name, shape in en.param_shapes('color'):
+        m = int(np.prod(shape))
+        if name == 'embedder._B':
+            same[off:off + m] = False
+        off += m
+    assert torch.equal(g1[same], g2[same])
+    scale = float(g1[~same].abs().max())
+    assert float((g1[~same] - g2[~same]).abs().max()) <= 1e-5 * scale

@@ -503,8 +503,11 @@ __device__ __forceinline__ void ring_landed() {
 // partial buffer with plain loads and stores (nobody else touches the row; the
 // finishing launch sums the rows): measured, the same adds as float atomics
 // into 8 shared replicas cost 29 us a launch.
-// first: the block's first group — its row is still zero (the finishing
-// launch leaves it so): a plain store, no read of a line that sits in HBM
+// first: the block's first group of this launch — a plain store, no read of
+// a line that sits in HBM.  Every entry of a block's row is stored by its
+// first group (62 blocks + bias rows + the output rows; embedder._B at the end
+// of the kernel), so the rows need no zeroing between launches
+// (tests/test_nice_hip.py::test_partial_rows_need_no_zeroing poisons them)
 __device__ __forceinline__ void padd(float* __restrict__ p, float v,
                                      bool first) {
   if (first)
@@ -1086,7 +1089,8 @@ nice_map_fused_kernel(
     float* rep = dw_rep + (size_t)blockIdx.x * kColorFlat;
     for (int i = threadIdx.x; i < 288; i += blockDim.x) {
       const int a = i / 96, k = i % 96;
-      if (k < kEmbK) rep[MlpFlat<32, 4>::EB + a * kEmbK + k] += embB[i];
+      // (once a launch, by the block that owns the row: a plain store)
+      if (k < kEmbK) rep[MlpFlat<32, 4>::EB + a * kEmbK + k] = embB[i];
     }
   }
 }
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(kCoarseWaves * 64, 2) void nice_map_coarse_kernel(
 }
 
 // after the fused launch: decoder gradient = sum of the blocks' partial rows
-// (left zeroed for the next call: 64 columns a block, the rows split over its
+// (64 columns a block, the rows split over its
 // four waves), ray gradients = sum of the ray's tile partials in a fixed
 // order, loss = sum of the per-ray losses (last block)
 constexpr int kFinishThreads = 1024;
@@ -1213,10 +1217,7 @@ __global__ __launch_bounds__(kFinishThreads) void nice_map_finish_kernel(
     float s = 0.f;
     if (i < len) {
 #pragma unroll 4
-      for (int r = w; r < n_rep; r += W) {
-        s += rep[(size_t)r * len + i];
-        rep[(size_t)r * len + i] = 0.f;
-      }
+      for (int r = w; r < n_rep; r += W) s += rep[(size_t)r * len + i];
     }
     shf[w][c] = s;
     __syncthreads();
