@@ -35,6 +35,7 @@ __global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
   __shared__ int s_node[4][kSvoStack];
   __shared__ int s_side[4][kSvoStack];
   __shared__ float s_lo[4][kSvoStack], s_hi[4][kSvoStack];
+  __shared__ int s_kids[4][8 * kSvoStack];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.y;
   const int j = blockIdx.x * 4 + wave;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
   float* MX = max_depth + rbase * n_max;
   bool ovf;
   const int cnt = svo_intersect_ray(
-      lane, s_node[wave], s_side[wave], s_lo[wave], s_hi[wave], o, d, P, C,
+      lane, s_node[wave], s_side[wave], s_lo[wave], s_hi[wave], s_kids[wave],
+      o, d, P, C,
       voxelsize, n_max, ovf, [&](int slot, int node, float lo, float hi) {
         if (lane == 0) {
           I[slot] = node;

@@ -42,12 +42,20 @@ __device__ __forceinline__ void ray_aabb(const float (&o)[3],
 // boxes are hit are therefore visited in the same LIFO order, and leaves are
 // recorded in the same order with the same (lo, hi), while a ray takes one
 // serial step per HIT internal node instead of one per node looked at (8x
-// fewer dependent loads).  s_*: this wave's DFS stack in LDS [kSvoStack];
-// emit(slot, node, lo, hi) is called by EVERY lane for each recorded leaf.
-// Returns the number of leaves recorded; overflow: stack overflow.
+// fewer dependent loads).  Round 6: a step was still TWO dependent round
+// trips to L2 (the popped node's child ids, then the children's sizes and
+// centres) and a ray is one wave's chain of 10-20 such steps — 24 of the ray
+// pipeline's 52 us.  The child ids of a node now travel with its stack entry
+// (s_kids): when a child is pushed, the eight lanes 8 j .. 8 j + 7 fetch ITS
+// child ids in the same round trip that fetches its size and centre, so a
+// pop reads them from LDS and a step is ONE round trip.  Same nodes, same
+// order, same (lo, hi).  s_*: this wave's DFS stack in LDS [kSvoStack],
+// s_kids [kSvoStack][8]; emit(slot, node, lo, hi) is called by EVERY lane for
+// each recorded leaf.  Returns the number of leaves recorded; overflow: stack
+// overflow.
 template <class Emit>
 __device__ __forceinline__ int svo_intersect_ray(
-    int lane, int* s_node, int* s_side, float* s_lo, float* s_hi,
+    int lane, int* s_node, int* s_side, float* s_lo, float* s_hi, int* s_kids,
     const float (&o)[3], const float (&d)[3], const float* __restrict__ P,
     const int* __restrict__ C, float voxelsize, int n_max, bool& overflow,
     Emit emit) {
@@ -56,6 +64,7 @@ __device__ __forceinline__ int svo_intersect_ray(
   overflow = false;
   {  // root is node 0
     const int side = C[8];
+    const int kid = lane < 8 ? C[lane] : -1;
     float lo, hi;
     ray_aabb(o, d, P, half_voxel * (float)side, lo, hi);
     if (lo > -1.0f) {
@@ -66,6 +75,7 @@ __device__ __forceinline__ int svo_intersect_ray(
         s_lo[0] = lo;
         s_hi[0] = hi;
       }
+      if (lane < 8) s_kids[lane] = kid;
     }
   }
   wave_lds_sync();
@@ -78,15 +88,18 @@ __device__ __forceinline__ int svo_intersect_ray(
       --ptr;
       continue;
     }
-    --ptr;
     int c = -1, cs = 0;
     float lo = -1.f, hi = -1.f;
-    if (lane < 8) {
-      c = C[k * 9 + lane];
-      if (c > -1) {
-        cs = C[c * 9 + 8];
-        ray_aabb(o, d, P + c * 3, half_voxel * (float)cs, lo, hi);
-      }
+    if (lane < 8) c = s_kids[ptr * 8 + lane];
+    --ptr;
+    // lane 8 j + g: child j's child g (fetched next to child j's size and
+    // centre; used only if child j is pushed)
+    const int cj = __shfl(c, lane >> 3);
+    int kid = -1;
+    if (cj > -1) kid = C[cj * 9 + (lane & 7)];
+    if (c > -1) {
+      cs = C[c * 9 + 8];
+      ray_aabb(o, d, P + c * 3, half_voxel * (float)cs, lo, hi);
     }
     const uint64_t mask = __ballot(c > -1 && lo > -1.0f);
     const int n_push = __popcll(mask);
@@ -101,6 +114,11 @@ __device__ __forceinline__ int svo_intersect_ray(
       s_side[at] = cs;
       s_lo[at] = lo;
       s_hi[at] = hi;
+    }
+    if ((mask >> (lane >> 3)) & 1) {
+      const int j = lane >> 3;
+      const int at = ptr + 1 + __popcll(mask & ((1ull << j) - 1));
+      s_kids[at * 8 + (lane & 7)] = kid;
     }
     ptr += n_push;
     wave_lds_sync();

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kWaves * 64) void vox_hits_kernel(const PipeArgs A)
   // LDS per wave: the DFS stack of the intersection (4 x kSvoStack words) and
   // the hit row (3 x 64)
   __shared__ int stack_s[kWaves][4 * kSvoStack];
+  __shared__ int kids_s[kWaves][8 * kSvoStack];
   __shared__ int row_s[kWaves][3 * 64];
   __shared__ int red[8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(kWaves * 64) void vox_hits_kernel(const PipeArgs A)
                           A.rays_d[ray * 3 + 2]};
       bool ovf;
       const int cnt = svo_intersect_ray(
-          lane, s_node, s_side, s_lo, s_hi, o, d, A.centres, A.children,
+          lane, s_node, s_side, s_lo, s_hi, kids_s[wave], o, d, A.centres,
+          A.children,
           A.voxel_size, n_max, ovf, [&](int slot, int node, float lo, float hi) {
             if (lane == slot) {
               id = node;
