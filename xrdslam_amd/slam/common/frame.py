@@ -17,6 +17,44 @@ class Frame(nn.Module):
     # raise_if_inconsistent() (device tensors: see set_pose)
     _pose_check = {}
 
+    # device -> (pinned host copy, event) of an asynchronous read-out in flight
+    _pose_poll = {}
+
+    @staticmethod
+    def reset_pose_check():
+        """a new run starts with a clean slate (a pipeline calls this when it
+        is constructed: an inconsistency another run or test left unraised
+        must not surface here)"""
+        for err in Frame._pose_check.values():
+            err.zero_()
+        Frame._pose_poll.clear()
+
+    @staticmethod
+    def poll_inconsistent(atol=1e-3):
+        """the deferred check without a host wait: reads the deviation an
+        EARLIER call copied out asynchronously (raises if it was too large),
+        then starts the next copy.  A pipeline calls it at mapping frames, so
+        a bad initial pose is reported at most one mapping interval late even
+        when nobody reads the trajectory."""
+        for dev, err in Frame._pose_check.items():
+            if dev.type != 'cuda':
+                continue
+            hit = Frame._pose_poll.get(dev)      # [pinned host float, event]
+            if hit is None:
+                hit = Frame._pose_poll[dev] = [
+                    torch.empty(1, dtype=torch.float32).pin_memory(), None]
+            if hit[1] is not None:
+                if not hit[1].query():
+                    continue                     # the copy is still in flight
+                e, hit[1] = float(hit[0]), None
+                if not e <= atol:
+                    err.zero_()
+                    raise ValueError('Transformation inconsistency detected! '
+                                     f'(largest deviation {e:g} on {dev})')
+            hit[0].copy_(err, non_blocking=True)
+            hit[1] = torch.cuda.Event()
+            hit[1].record(torch.cuda.current_stream(dev))
+
     @staticmethod
     def raise_if_inconsistent(atol=1e-3):
         """the deferred half of the initial-pose check of device-resident

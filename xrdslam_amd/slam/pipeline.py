@@ -73,6 +73,7 @@ class SequentialSLAM:
         self._first_old = self._first_new = None
         self.t_track = 0.0
         self.t_map = 0.0
+        Frame.reset_pose_check()
 
     def is_mapframe(self, fid):
         every = 1 if fid <= self.lazy_start else self.map_every
@@ -123,6 +124,8 @@ class SequentialSLAM:
         if self.is_mapframe(idx):
             frame.is_final_frame = idx == len(self.dataset) - 1
             alg.do_mapping(frame)
+            # the deferred initial-pose check, without a host wait
+            Frame.poll_inconsistent()
             alg.update_framepose(idx, frame.get_pose().detach())
             if idx % self.keyframe_every == 0:
                 alg.add_keyframe(frame)
