@@ -366,8 +366,9 @@ int xrd_nice_render_bwd_masks(const xrd_nice_scene* scene, int stage,
  * stage), g_grid[4] (ACCUMULATED, cells masked by scene->gmask),
  * g_dec_color (flat colour-decoder gradient, overwritten; colour stage),
  * loss [1] f64 = the summed loss terms.  ws: xrd_nice_map_ws_floats(scene,
- * stage, n) floats, 16-byte aligned, ZERO before its first use and handed back
- * unchanged afterwards (the call leaves its replica sections zeroed).
+ * stage, n) floats, 16-byte aligned, ZERO before its first use (the coarse
+ * stage's gradient replicas are handed back zeroed; the colour stage's partial
+ * rows of the decoder gradient are rewritten in full by every call).
  * 48 samples a ray (32 + 16) only: other sampling configs ->
  * XRD_ERR_UNSUPPORTED (use xrd_nice_render_fwd / xrd_nice_loss /
  * xrd_nice_render_bwd). */
