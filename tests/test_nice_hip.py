@@ -852,3 +852,42 @@ def test_partial_rows_need_no_zeroing(n):
     assert torch.equal(g1[same], g2[same])
     scale = float(g1[~same].abs().max())
     assert float((g1[~same] - g2[~same]).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+def test_map_iter_with_more_groups_than_blocks():
+    """1500 rays = 375 groups on 256 persistent blocks: some blocks run a
+    second group, whose weight-gradient blocks are ADDED to the row the first
+    group stored (and whose operand ring is refilled behind a barrier).  The
+    mapping losses are plain sums over rays: the call must equal the sum of a
+    call on rays [0, 1024) — exactly one group a block — and one on the rest,
+    with the same dmax."""
+    from xrdslam_amd.engine import nice as en
+    dev = _cuda()
+    n = 1500
+    bound, grids, decs = _office0_case(1)
+    rays_o, rays_d, depth, color = _office0_rays(n, 21)
+    dmax = depth.max().to(dev)
+
+    def run(lo, hi):
+        scene, gl, _ = build_scene(bound, grids, decs, dev,
+                                   color_requires_grad=True,
+                                   grid_requires_grad=True)
+        loss, _, _, g = en.nice_map_iter(
+            scene, 'color', rays_o[lo:hi].to(dev), rays_d[lo:hi].to(dev),
+            depth[lo:hi].to(dev), dmax, color[lo:hi].to(dev), None, 0.2,
+            False, True)
+        torch.cuda.synchronize()
+        return float(loss), g.double(), {k: v.grad.double().clone()
+                                         for k, v in gl.items()
+                                         if v.grad is not None}
+    la, ga, gga = run(0, n)
+    lb, gb, ggb = run(0, 1024)
+    lc, gc, ggc = run(1024, n)
+    assert abs(la - (lb + lc)) <= 1e-9 * abs(la)
+    want = gb + gc
+    scale = float(want.abs().max())
+    assert float((ga - want).abs().max()) <= 2e-5 * scale
+    for k in gga:
+        w = ggb[k] + ggc[k]
+        assert float((gga[k] - w).abs().max()) <= 2e-5 * float(w.abs().max())
