@@ -202,3 +202,19 @@ def test_deferred_pose_check_is_polled_without_a_host_wait():
           device=DEV)
     Frame.reset_pose_check()               # a new run: nothing carried over
     Frame.raise_if_inconsistent()
+
+
+def test_deferred_pose_check_covers_the_bottom_row():
+    """the reference compares the full 4x4 (frame.py:24-29): a matrix whose
+    last row is not 0 0 0 1 is inconsistent even with a perfect rotation"""
+    from xrdslam_amd.slam.common.frame import Frame
+    d = np.ones((4, 6), np.float32)
+    c = np.zeros((4, 6, 3), np.float32)
+    Frame.reset_pose_check()
+    good = torch.from_numpy(_rigid(np.random.default_rng(11))).to(DEV)
+    bad = good.clone()
+    bad[3, 3] = 2.0
+    Frame(1, c, d, init_pose=bad, separate_LR=True, rot_rep='quat',
+          device=DEV)
+    with pytest.raises(ValueError):
+        Frame.raise_if_inconsistent()

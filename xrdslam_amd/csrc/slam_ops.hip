@@ -818,6 +818,13 @@ __global__ void pose_from_matrix_kernel(const float* __restrict__ c2w,
         // larger, or NaN; a NaN already held (an earlier frame's) stays
         if (err == err && !(e <= err)) err = e;
       }
+    // (the reference compares the full 4x4, frame.py:24-29: the translation
+    // column is copied through; the bottom row has to be 0 0 0 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float e = fabsf(c2w[12 + j] - (j == 3 ? 1.f : 0.f));
+      if (err == err && !(e <= err)) err = e;
+    }
     dev_max[0] = err;
   }
 #pragma unroll
