@@ -37,7 +37,17 @@ def test_trajectory_error_matches_the_reference_loop(name):
         pytest.skip(f'tests/golden/c1_{name}.npz not generated')
     g = c1_util.fixture(name)
     ref_ate, ref_err = c1_util.ref_stats(g)
-    seeds = range(len(ref_ate))
+    # Point-SLAM: five engine seeds and MEDIANS.  Its loop is the most
+    # chaotic of the five (float atomics in the point features: the same seed
+    # does not repeat) with occasional excursions — a seed that loses 2-3 cm
+    # over a few frames and finds its way back; the REFERENCE does the same
+    # (with a first-frame mapping of 500 iterations one of its three seeds
+    # went to 8 cm over frames 2-8 and ended at 0.3 cm; oracle/make_golden_
+    # c1.py).  Engine three-seed means over four runs of this test: 1.14,
+    # 1.02, 1.02, 1.56 cm (seeds 0.79 / 2.89 / 1.01) against the reference's
+    # 0.98: one excursion moves a three-seed mean by 0.6 cm, a median not.
+    robust = name == 'pointslam'
+    seeds = range(5 if robust else len(ref_ate))
     runs = [c1_util.run_engine(name, sd) for sd in seeds]
     ate = np.array([c1_util.ate(est, gt) for est, gt, _, _ in runs])
     err = np.stack([np.linalg.norm(est[:, :3, 3] - gt[:, :3, 3], axis=1)
@@ -52,7 +62,7 @@ def test_trajectory_error_matches_the_reference_loop(name):
             f'), reference loop {ref_ate.mean() * 100:.3f} cm (seeds ' +
             ' '.join(f'{a * 100:.3f}' for a in ref_ate) + '); engine '
             f'{np.mean([r[2] for r in runs]):.1f} s a sequence, reference '
-            f'{np.mean([float(g[f"seconds/{s}"]) for s in seeds]):.0f} s '
+            f'{np.mean([float(g[f"seconds/{s}"]) for s in range(len(ref_ate))]):.0f} s '
             '(CPU)')
     rep = os.environ.get('XRD_PARITY_REPORT')
     if rep:
@@ -72,11 +82,16 @@ def test_trajectory_error_matches_the_reference_loop(name):
     # the engine TRACKS: well below a pose frozen at frame 0 (like the
     # reference loop, tests/test_c1_fixtures.py)
     frozen = c1_util.frozen_ate(g['gt'][:n])
-    assert ate.mean() <= 0.5 * frozen, (line, frozen)
-    assert ate.mean() <= ref_ate.mean() + bar, line
-    assert ate.mean() >= min(0.4 * ref_ate.mean(), ref_ate.mean() - bar), line
-    # per frame: the seed-mean error of the engine inside the reference's
-    # spread at that frame
+    centre = np.median if robust else np.mean
+    assert centre(ate) <= 0.5 * frozen, (line, frozen)
+    assert centre(ate) <= centre(ref_ate) + bar, line
+    assert centre(ate) >= min(0.4 * centre(ref_ate),
+                              centre(ref_ate) - bar), line
+    if robust:   # and no seed is lost: every one beats the frozen pose
+        assert ate.max() <= frozen, (line, frozen)
+    # per frame: the seed-mean (Point-SLAM: seed-median) error of the engine
+    # inside the reference's spread at that frame
     bound = 2.0 * ref_err.max(0)[:n] + 0.005
-    worst = (err.mean(0) - bound).max()
-    assert worst <= 0, (line, float(worst), int((err.mean(0) - bound).argmax()))
+    per_frame = np.median(err, 0) if robust else err.mean(0)
+    worst = (per_frame - bound).max()
+    assert worst <= 0, (line, float(worst), int((per_frame - bound).argmax()))
