@@ -11,6 +11,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
 import splatam_golden_util as sg  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -116,6 +117,50 @@ def test_splatam_loop_tracks_synthetic_room(graphs):
     gt = data[6]['depth']
     assert np.abs(depth - gt)[gt > 0].mean() < 0.05
     assert np.abs(rgb - data[6]['rgb'])[gt > 0].mean() < 0.1
+    # ... and the image itself, every pixel of both passes, against the
+    # oracle rasteriser evaluated on the map this loop has built
+    ref_rgb, ref_ds = _oracle_image(algo.model.gaussian_cloud,
+                                    algo.get_estimate_c2w_list()[6])
+    valid = gt > 0
+    for name, got, ref in (
+            ('rgb', rgb, ref_rgb.permute(1, 2, 0).numpy() * valid[..., None]),
+            ('depth', depth, ref_ds[0].numpy() * valid)):
+        err = np.abs(got - ref)
+        # a pixel can differ by one blended Gaussian where the f32 kernel and
+        # the f64 oracle fall on different sides of a cut-off of the published
+        # algorithm (alpha < 1/255 skipped, T < 1e-4 stops): bounded by
+        # alpha_max * value, and rare
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert (err > 1e-4 * scale).mean() < 2e-3, (name, err.max())
+        assert err.max() < 0.02 * scale, (name, err.max())
+        assert np.median(err) < 1e-6 * scale, (name, np.median(err))
+
+
+def _oracle_image(cloud, c2w):
+    """rgb [3,H,W] and depth/silhouette/depth^2 [3,H,W] of the cloud seen
+    from ``c2w``: the reference's render-variable assembly
+    (slam_helpers_splatam) in float64 on the CPU and oracle/gs_tiled.py"""
+    import gs_tiled
+    from xrdslam_amd.slam.model_components import slam_helpers_splatam as sh
+    params = {k: v.detach().cpu().double() for k, v in cloud.params.items()}
+    w2c = torch.inverse(c2w.detach().cpu().double())
+    first = cloud.first_frame_w2c.detach().cpu().double()
+    cam = cloud.gaussian_cam
+    with torch.no_grad():
+        pts = sh.transform_to_frame(params['means3D'], w2c, False, False)
+        out = []
+        for rv in (sh.transformed_params2rendervar(params, pts),
+                   sh.transformed_params2depthplussilhouette(params, first,
+                                                             pts)):
+            img, _, _, _ = gs_tiled.rasterize(
+                rv['means3D'], rv['colors_precomp'].double(), rv['opacities'],
+                rv['scales'], rv['rotations'],
+                cam.viewmatrix.reshape(4, 4).cpu().double(),
+                cam.projmatrix.reshape(4, 4).cpu().double(),
+                cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy,
+                bg=cam.bg.cpu().double())
+            out.append(img)
+    return out
 
 
 @pytest.mark.parametrize('world', [2, 3])

@@ -117,6 +117,41 @@ __device__ __forceinline__ uint32_t lds_addr(const float* p) {
       const __attribute__((address_space(3))) float*)p;
 }
 
+// one LDS-DMA load of 1 KB: lane l's 16 bytes at base + voff(l) land at
+// lds_base + 16 l, no VGPR round trip.  Inline asm on purpose: the compiler
+// does not track the load, so it puts no vmcnt(0) in front of LDS reads of
+// OTHER buffers (with the builtin every ds_read behind an outstanding LDS-DMA
+// load waits for it); lds_dma_landed() is the wait.  base, lds_base:
+// wave-uniform.
+__device__ __forceinline__ void lds_dma16(const float* base, uint32_t voff,
+                                          uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_base), "v"(voff), "s"(base)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma_landed() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// this wave's share of a block-wide copy src[0, N) -> LDS byte address dst:
+// 1 KB chunks dealt over the NW waves, the partial last chunk by a lane mask.
+// Visible to the block after lds_dma_landed() + a barrier.
+template <int NW, int N>
+__device__ __forceinline__ void lds_dma_issue(const float* __restrict__ src,
+                                              uint32_t dst, int wave,
+                                              int lane) {
+  static_assert(N % 4 == 0, "16-byte lanes");
+  constexpr int FULL = N / 256, TAIL = N % 256;
+  const uint32_t voff = (uint32_t)lane * 16u;
+#pragma unroll
+  for (int k = 0; k < (FULL + NW - 1) / NW; ++k) {
+    const int c = wave + NW * k;   // wave-uniform
+    if (c < FULL) lds_dma16(src + c * 256, voff, dst + (uint32_t)c * 1024u);
+  }
+  if (TAIL != 0 && wave == FULL % NW && lane * 4 < TAIL)
+    lds_dma16(src + FULL * 256, voff, dst + (uint32_t)FULL * 1024u);
+}
+
 // make LDS writes of this wave visible to its own later LDS reads
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -463,18 +463,6 @@ constexpr int kRingChunks = (kRingFloats + 255) / 256;  // 70 x 1 KB
 constexpr int kRingStride = kRingChunks * 256;     // floats between buffers
 static_assert(12 % kRingTiles == 0 && kRingFloats % 4 == 0, "whole rounds");
 
-// one LDS-DMA load of 1 KB: lane l's 16 bytes at base + voff(l) land at
-// lds_base + 16 l.  Inline asm on purpose: the compiler does not track the
-// load, so it puts no vmcnt(0) in front of the LDS reads of the OTHER ring
-// buffer (with the builtin every ds_read behind an outstanding LDS-DMA load
-// waits for it).  base, lds_base: wave-uniform.
-__device__ __forceinline__ void lds_dma16(const float* base, uint32_t voff,
-                                          uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"
-               :
-               : "s"(lds_base), "v"(voff), "s"(base)
-               : "memory");
-}
 // this wave's share of one round: src[0, kRingFloats) -> LDS byte address dst.
 // Whole 1 KB chunks, chunk c by wave c % 12; the last chunk is partial: its
 // lanes beyond the round re-read the round's last 16 bytes (they land in the
