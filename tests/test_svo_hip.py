@@ -55,6 +55,93 @@ def test_svo_intersect_bit_exact(B, M):
     assert np.array_equal(idx3.cpu().numpy(), r3)
 
 
+def _chain_tree(levels):
+    """a root of side 2**levels over ONE chain of single children down to a
+    2x2x2 block of leaves: deeper than the level-synchronous walk's path key
+    (10 levels) when levels > 10"""
+    nodes = []          # (corner xyz in voxels, side)
+    corner = np.zeros(3, np.int64)
+    for lv in range(levels, 0, -1):
+        nodes.append((corner.copy(), 2**lv))
+        if lv > 1:      # descend into child 5 = (1, 0, 1)
+            corner = corner + np.array([1, 0, 1]) * 2**(lv - 1)
+    n_int = len(nodes)
+    children = -np.ones((n_int + 8, 9), np.int32)
+    centres = np.zeros((n_int + 8, 3), np.float32)
+    for i, (c, side) in enumerate(nodes):
+        centres[i] = (c + side / 2) * 0.2
+        children[i, 8] = side
+        if i + 1 < n_int:
+            children[i, 5] = i + 1
+    last, _ = nodes[-1]
+    for k in range(8):
+        off = np.array([(k >> 2) & 1, (k >> 1) & 1, k & 1])
+        centres[n_int + k] = (last + off + 0.5) * 0.2
+        children[n_int + k, 8] = 1
+        children[n_int - 1, k] = n_int + k
+    return centres, children, (last + 1.0) * 0.2
+
+
+@pytest.mark.parametrize('levels', [4, 10, 11, 13])
+def test_deep_chain_tree_falls_back_to_the_depth_first_walk(levels):
+    """levels <= 10: the level-synchronous walk; deeper: its path key is full
+    and the depth-first walk answers — same hits either way"""
+    from xrdslam_amd.compat import grid
+    centres, childs, target = _chain_tree(levels)
+    rng = np.random.default_rng(levels)
+    M = 200
+    o = (target + np.array([0.0, 0.0, -3.0]) +
+         rng.uniform(-0.5, 0.5, (M, 3))).astype(np.float32)
+    d = (target + rng.uniform(-0.3, 0.3, (M, 3)) - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ridx, rmn, rmx, _ = svo_intersect_oracle(o[None], d[None], centres[None],
+                                             childs[None], 0.2, 50)
+    assert (ridx >= 0).any(-1).mean() > 0.3
+    c = lambda a: torch.from_numpy(a).cuda()
+    idx, mn, mx = grid.svo_intersect(c(o[None]), c(d[None]), c(centres[None]),
+                                     c(childs[None]), 0.2, 50)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    hit = ridx >= 0
+    assert np.allclose(mn.cpu().numpy()[hit], rmn[hit], rtol=1e-6, atol=0)
+    assert np.allclose(mx.cpu().numpy()[hit], rmx[hit], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('n_max', [7, 50, 64, 200])
+def test_dense_block_many_leaves(n_max):
+    """a solid 52^3 block: rays cross 40-100+ leaves — more than one lane
+    each, more than n_max (the cut keeps the reference's FIRST n_max in ITS
+    stack order) and, along the diagonal, more than the 128 the
+    level-synchronous walk collects (depth-first fallback)"""
+    from xrdslam_amd.compat import grid, svo
+    g = np.arange(40, 92, dtype=np.int32)
+    vox = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3)
+    svo.reset_id_counter()
+    tree = svo.Octree()
+    tree.init(256, 16, 0.2)
+    tree.insert(torch.from_numpy(vox))
+    voxels, children, _ = tree.get_centres_and_children()
+    centres = ((voxels[:, :3] + voxels[:, -1:] / 2) * 0.2).numpy() \
+        .astype(np.float32)
+    childs = torch.cat([children, voxels[:, -1:]], -1).int().numpy()
+    rng = np.random.default_rng(n_max)
+    M = 256
+    o = (np.array([[7.0, 7.0, 6.0]]) + rng.uniform(-0.5, 0.5, (M, 3))) \
+        .astype(np.float32)
+    d = rng.uniform(0.2, 1.0, (M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ridx, rmn, rmx, _ = svo_intersect_oracle(o[None], d[None], centres[None],
+                                             childs[None], 0.2, n_max)
+    if n_max == 200:
+        assert (ridx >= 0).sum(-1).max() > 128
+    c = lambda a: torch.from_numpy(a).cuda()
+    idx, mn, mx = grid.svo_intersect(c(o[None]), c(d[None]), c(centres[None]),
+                                     c(childs[None]), 0.2, n_max)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    hit = ridx >= 0
+    assert np.allclose(mn.cpu().numpy()[hit], rmn[hit], rtol=1e-6, atol=0)
+    assert np.allclose(mx.cpu().numpy()[hit], rmx[hit], rtol=1e-6, atol=0)
+
+
 def test_matches_reference_vectors():
     from xrdslam_amd.compat import grid
     g = np.load(GOLD)

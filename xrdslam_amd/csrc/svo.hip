@@ -11,9 +11,12 @@
 //     owns one ray (the 8 children of a node are tested on 8 lanes), a 2-D
 //     grid covers rays x batches, and a tree may be shared by all batches
 //     (tree_batch_stride = 0);
-//   * the DFS stack (int[256] of scratch per thread in the reference) lives in
-//     LDS and holds only nodes the ray is known to enter, with their slab
-//     depths.
+//   * the walk is level-synchronous (svo_intersect.h: one or two L2 round
+//     trips a LEVEL instead of one per entered node; the reference's output
+//     order is restored from a path key); the depth-first walk — its stack
+//     (int[256] of scratch per thread in the reference) in LDS, holding only
+//     nodes the ray is known to enter — remains for what the first gives up
+//     on.
 #include "common.h"
 #include "svo_intersect.h"
 #include "svo_sample.h"
@@ -32,10 +35,7 @@ __global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
     const float* __restrict__ points, const int* __restrict__ children,
     int* __restrict__ idx, float* __restrict__ min_depth,
     float* __restrict__ max_depth, int* __restrict__ overflow) {
-  __shared__ int s_node[4][kSvoStack];
-  __shared__ int s_side[4][kSvoStack];
-  __shared__ float s_lo[4][kSvoStack], s_hi[4][kSvoStack];
-  __shared__ int s_kids[4][8 * kSvoStack];
+  __shared__ int lds[4][kSvoLds];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.y;
   const int j = blockIdx.x * 4 + wave;
@@ -52,17 +52,33 @@ __global__ __launch_bounds__(kRaysPerBlock * 4) void svo_intersect_kernel(
   int* I = idx + rbase * n_max;
   float* MN = min_depth + rbase * n_max;
   float* MX = max_depth + rbase * n_max;
-  bool ovf;
-  const int cnt = svo_intersect_ray(
-      lane, s_node[wave], s_side[wave], s_lo[wave], s_hi[wave], s_kids[wave],
-      o, d, P, C,
-      voxelsize, n_max, ovf, [&](int slot, int node, float lo, float hi) {
-        if (lane == 0) {
-          I[slot] = node;
-          MN[slot] = lo;
-          MX[slot] = hi;
+  bool ovf = false;
+  int cnt = 0;
+  // level by level; the depth-first walk only where that one gives up
+  const bool done = svo_intersect_ray_bfs(
+      lane, lds[wave], o, d, P, C, voxelsize, n_max,
+      [&](int n_hit, const int* node, const float* lo, const float* hi) {
+        cnt = n_hit;
+        for (int l = lane; l < n_hit; l += 64) {
+          I[l] = node[l];
+          MN[l] = lo[l];
+          MX[l] = hi[l];
         }
       });
+  if (!done) {
+    int* s = lds[wave];
+    cnt = svo_intersect_ray(
+        lane, s, s + kSvoStack, reinterpret_cast<float*>(s + 2 * kSvoStack),
+        reinterpret_cast<float*>(s + 3 * kSvoStack), s + 4 * kSvoStack, o, d,
+        P, C, voxelsize, n_max, ovf,
+        [&](int slot, int node, float lo, float hi) {
+          if (lane == 0) {
+            I[slot] = node;
+            MN[slot] = lo;
+            MX[slot] = hi;
+          }
+        });
+  }
   if (ovf && overflow && lane == 0) *overflow = 1;
   for (int l = cnt + lane; l < n_max; l += 64) I[l] = -1;  // unused slots
   (void)n;

@@ -144,8 +144,7 @@ __device__ __forceinline__ int part_or(const int* __restrict__ part, int what,
 __global__ __launch_bounds__(kWaves * 64) void vox_hits_kernel(const PipeArgs A) {
   // LDS per wave: the DFS stack of the intersection (4 x kSvoStack words) and
   // the hit row (3 x 64)
-  __shared__ int stack_s[kWaves][4 * kSvoStack];
-  __shared__ int kids_s[kWaves][8 * kSvoStack];
+  __shared__ int svo_s[kWaves][kSvoLds];
   __shared__ int row_s[kWaves][3 * 64];
   __shared__ int red[8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -160,10 +159,11 @@ __global__ __launch_bounds__(kWaves * 64) void vox_hits_kernel(const PipeArgs A)
   const int r_hi = r_lo + rpb < n_rays ? r_lo + rpb : n_rays;
   if (threadIdx.x < 8) red[threadIdx.x] = 0;
   __syncthreads();
-  int* s_node = stack_s[wave];
+  int* s_node = svo_s[wave];
   int* s_side = s_node + kSvoStack;
   float* s_lo = reinterpret_cast<float*>(s_side + kSvoStack);
   float* s_hi = s_lo + kSvoStack;
+  int* s_kids = s_node + 4 * kSvoStack;
   int* s_id = row_s[wave];
   float* s_a = reinterpret_cast<float*>(s_id + 64);
   float* s_b = s_a + 64;
@@ -176,17 +176,31 @@ __global__ __launch_bounds__(kWaves * 64) void vox_hits_kernel(const PipeArgs A)
                           A.rays_o[ray * 3 + 2]};
       const float d[3] = {A.rays_d[ray * 3], A.rays_d[ray * 3 + 1],
                           A.rays_d[ray * 3 + 2]};
-      bool ovf;
-      const int cnt = svo_intersect_ray(
-          lane, s_node, s_side, s_lo, s_hi, kids_s[wave], o, d, A.centres,
-          A.children,
-          A.voxel_size, n_max, ovf, [&](int slot, int node, float lo, float hi) {
-            if (lane == slot) {
-              id = node;
-              a = lo;
-              b = hi;
+      bool ovf = false;
+      int cnt = 0;
+      // level by level (svo_intersect.h); the depth-first walk only where
+      // that one gives up
+      const bool done = svo_intersect_ray_bfs(
+          lane, s_node, o, d, A.centres, A.children, A.voxel_size, n_max,
+          [&](int n_hit, const int* node, const float* lo, const float* hi) {
+            cnt = n_hit;
+            if (lane < n_hit) {
+              id = node[lane];
+              a = lo[lane];
+              b = hi[lane];
             }
           });
+      if (!done)
+        cnt = svo_intersect_ray(
+            lane, s_node, s_side, s_lo, s_hi, s_kids, o, d, A.centres,
+            A.children, A.voxel_size, n_max, ovf,
+            [&](int slot, int node, float lo, float hi) {
+              if (lane == slot) {
+                id = node;
+                a = lo;
+                b = hi;
+              }
+            });
       if (ovf && lane == 0) atomicOr(&red[PT_STACK], 1);
       if (lane >= cnt) id = -1;
     } else if (lane < n_max) {
