@@ -756,7 +756,13 @@ def run_voxfusion(args, dev, world=1):
         mlp = kern.startswith('vox_points')
         dw = kern.startswith('vox_dw')
         flops = pts * VOX_FLOPS * (2 if bwd else 1)
-        byts = pts * (VOX_BYTES + (1024 if bwd and need_w else 0))
+        # vox_dw reads the operand rows the forward / backward left in HBM:
+        # x [16] + h1, h2, f, hc [128 each] + gc3 [4] + ghc, gf, gh2, gh1
+        # [128 each] = 4176 B a point — what-if builds (tools/whatif_build.py,
+        # profiles/r06_vox_dw_whatif.txt) show the launch follows that read
+        # stream, not its MFMAs
+        byts = pts * (4176 if dw else
+                      VOX_BYTES + (1024 if bwd and need_w else 0))
         us = ms / calls * 1e3
         roofline = {
             'bound': 'mfma', 'achieved': flops / (us * 1e-6) / 1e12,
@@ -789,6 +795,17 @@ def run_voxfusion(args, dev, world=1):
             'timing_source': 'HIP events around the eager launches of two '
                              'frames run right after the timed region (the '
                              'timed region replays captured graphs)'}
+        if dw:
+            # the binding resource first: the operand read stream
+            ob = roofline['other_bound']
+            roofline['other_bound'] = {
+                'bound': 'mfma', 'unit': 'TFLOP/s',
+                'achieved': roofline['achieved'],
+                'peak': MFMA_F32_PEAK / 1e12, 'frac': roofline['frac']}
+            roofline.update(bound='hbm', achieved=ob['achieved'],
+                            peak=HBM_PEAK / 1e9, unit='GB/s',
+                            frac=ob['frac'],
+                            algorithmic_bytes_per_point=4176)
         # the launch group with the largest share of the FRAME: a mapping
         # iteration's decoder trio (forward, backward with the weight-
         # gradient operands, the weight products) — 15 iterations a frame

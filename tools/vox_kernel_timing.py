@@ -41,7 +41,13 @@ def main():
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--points', type=int, nargs='*',
                     default=[18000, 36000, 73000, 110000])
+    ap.add_argument('--lib', default=None,
+                    help='a what-if library (tools/whatif_build.py)')
     a = ap.parse_args()
+    if a.lib:
+        from xrdslam_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
+        print('# library:', a.lib)
     from xrdslam_amd.engine import vox as ev
     dev = 'cuda:0'
     print(f'{"points":>8} {"role":>9} {"fwd":>8} {"bwd":>8} {"dw+red":>8}  '
