@@ -1149,6 +1149,29 @@ int xrd_adam_dense_tick(float* param, const float* grad, float* m, float* v,
                         int64_t n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, int32_t* step_ticket,
                         int advance, xrd_stream_t stream);
+/* xrd_adam_dense_tick for up to XRD_ADAM_DENSE_MAX_SETS tensors in ONE launch:
+ * the reference steps one torch.optim.Adam per parameter group
+ * (slam/engine/optimizers.py:63-171: SplaTAM's five Gaussian tensors, a
+ * model's table / decoder / pose groups), each with its own learning rate and
+ * step count.  Same arithmetic per tensor as xrd_adam_dense_tick (this launch
+ * is step step_ticket[0] + 1 of a set; advance != 0 stores it).  Every set
+ * must have its OWN step_ticket (XRD_ERR_ARG otherwise); sets with n == 0 are
+ * skipped. */
+#define XRD_ADAM_DENSE_MAX_SETS 8
+typedef struct {
+  float* param;
+  const float* grad;
+  float* m;
+  float* v;
+  int64_t n;
+  float lr;
+  float weight_decay;
+  int32_t* step_ticket;
+  int32_t advance;
+} xrd_adam_dense_set;
+int xrd_adam_dense_multi(int n_sets, const xrd_adam_dense_set* sets,
+                         float beta1, float beta2, float eps,
+                         xrd_stream_t stream);
 /* keep the pose with the lowest loss (base_algorithm.py:262-265) on device */
 int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,
                    float* best_c2w16, uint8_t* valid, xrd_stream_t stream);

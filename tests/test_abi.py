@@ -126,7 +126,8 @@ def test_every_entry_point_survives_null_arguments():
                      'xrd_point_geo_bwd', 'xrd_point_color_fwd',
                      'xrd_point_color_bwd', 'xrd_gs_prepare_fwd',
                      'xrd_gs_prepare_bwd',
-                     'xrd_point_sensor_points'}   # n == 0: nothing to do
+                     'xrd_point_sensor_points',
+                     'xrd_adam_dense_multi'}   # n == 0: nothing to do
     for name, (ret, args) in _lib._SIGS.items():
         vals = [0.0 if a in (ctypes.c_float, ctypes.c_double) else
                 0 if a in (ctypes.c_int, ctypes.c_int64, ctypes.c_longlong)

@@ -578,6 +578,66 @@ def test_fused_dense_adam_matches_torch_incl_skipped_parameters():
                               rtol=2e-6, atol=1e-7)
 
 
+def test_dense_adam_of_several_optimisers_in_one_launch():
+    """FusedDenseAdam.step_together (xrd_adam_dense_multi: one launch for the
+    optimisers of several parameter groups — SplaTAM's five Gaussian tensors,
+    a model's table / decoder / poses) against one torch.optim.Adam a group:
+    different learning rates, sizes from 3 to 70 001 elements, a multi-
+    parameter optimiser (launched as step() would) in the mix, a group that
+    skips steps; bit-identical to stepping them one by one."""
+    from xrdslam_amd.engine.slam_ops import FusedDenseAdam
+    dev = _cuda()
+    torch.manual_seed(5)
+    shapes = [[(70001, )], [(3, )], [(4096, 3)], [(17, 4), (9, )], [(1000, )],
+              [(33, )]]
+    lrs = [1e-2, 3e-3, 2e-2, 1e-3, 5e-3, 1e-1]
+    ref = [[torch.randn(*sh, device=dev).requires_grad_(True) for sh in grp]
+           for grp in shapes]
+    tog = [[r.detach().clone().requires_grad_(True) for r in grp]
+           for grp in ref]
+    one = [[r.detach().clone().requires_grad_(True) for r in grp]
+           for grp in ref]
+    o_ref = [torch.optim.Adam(g, lr=lr) for g, lr in zip(ref, lrs)]
+    o_tog = [FusedDenseAdam(g, lr=lr) for g, lr in zip(tog, lrs)]
+    o_one = [FusedDenseAdam(g, lr=lr) for g, lr in zip(one, lrs)]
+    for step in range(6):
+        for k in range(len(shapes)):
+            skip = k == 4 and step in (1, 2)
+            for a, b, c in zip(ref[k], tog[k], one[k]):
+                if skip:
+                    a.grad = b.grad = c.grad = None
+                    continue
+                g = torch.randn_like(a)
+                a.grad, b.grad, c.grad = g.clone(), g.clone(), g.clone()
+        for o in o_ref + o_one:
+            o.step()
+        FusedDenseAdam.step_together(o_tog)
+    torch.cuda.synchronize()
+    for k in range(len(shapes)):
+        for a, b, c in zip(ref[k], tog[k], one[k]):
+            assert torch.equal(b, c), (k, (b - c).abs().max())
+            assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), \
+                (k, (a - b).abs().max())
+        sd_r = o_ref[k].state_dict()['state']
+        sd_t = o_tog[k].state_dict()['state']
+        for i in sd_r:
+            assert float(sd_t[i]['step']) == float(sd_r[i]['step']), (k, i)
+    # two sets on ONE counter in a launch would race: refused by the C-ABI
+    from xrdslam_amd import _lib
+    sets = (_lib.AdamDenseSet * 2)()
+    st = o_tog[0].state[tog[0][0]]
+    for k in range(2):
+        sets[k].param = _lib.ptr(tog[0][0])
+        sets[k].grad = _lib.ptr(tog[0][0].grad)
+        sets[k].m, sets[k].v = _lib.ptr(st['exp_avg']), \
+            _lib.ptr(st['exp_avg_sq'])
+        sets[k].n, sets[k].lr = 4, 1e-3
+        sets[k].step_ticket, sets[k].advance = _lib.ptr(st['step']), 1
+    rc = _lib.lib().xrd_adam_dense_multi(2, sets, 0.9, 0.999, 1e-8,
+                                         _lib.stream_ptr(dev))
+    assert rc != 0
+
+
 def test_fused_cell_adam_self_advancing_counter_matches_torch():
     """FusedCellAdam through xrd_adam_cells_tick (the kernel advances its own
     step counter): 5 steps against torch.optim.Adam over val[mask]"""

@@ -40,6 +40,17 @@ class AdamCellsSet(C.Structure):
                 ('n_cells_dev', C.c_void_p)]
 
 
+ADAM_DENSE_MAX_SETS = 8   # XRD_ADAM_DENSE_MAX_SETS
+
+
+class AdamDenseSet(C.Structure):
+    """xrd_adam_dense_set (include/xrdslam_hip.h)"""
+    _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p),
+                ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64),
+                ('lr', C.c_float), ('weight_decay', C.c_float),
+                ('step_ticket', C.c_void_p), ('advance', C.c_int32)]
+
+
 class CoslamScene(C.Structure):
     """mirror of ``xrd_coslam_scene``"""
     _fields_ = [('bound', f64 * 6), ('lv_scale', f32 * 16),
@@ -232,6 +243,8 @@ _SIGS = {
     'xrd_pose_predict': (C.c_int, [vp, vp, vp, vp]),
     'xrd_adam_dense': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32,
                                  vp, vp]),
+    'xrd_adam_dense_multi': (C.c_int, [C.c_int, C.POINTER(AdamDenseSet), f32,
+                                       f32, f32, vp]),
     'xrd_adam_dense_tick': (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32,
                                       f32, vp, C.c_int, vp]),
     'xrd_track_best': (C.c_int, [vp] * 6),

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void sample_rays_multi_bwd_kernel(
 }
 
 // -------------------------------------------------------------------- adam
-__global__ __launch_bounds__(256) void adam_dense_kernel(
+__device__ __forceinline__ void adam_dense_body(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
     float wd, int32_t* __restrict__ step_dev, int tick) {
@@ -487,6 +487,26 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(
       step_dev[0] = t_now;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void adam_dense_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+    float wd, int32_t* __restrict__ step_dev, int tick) {
+  adam_dense_body(p, g, m, v, n, lr, b1, b2, eps, wd, step_dev, tick);
+}
+
+// several tensors in one launch (blockIdx.y = the tensor): the Gaussian
+// cloud's five tensors, a model's table + decoder + poses each have their own
+// optimiser (learning rate, step count) and were one 4-8 us launch each
+struct AdamDenseSets {
+  xrd_adam_dense_set s[XRD_ADAM_DENSE_MAX_SETS];
+};
+__global__ __launch_bounds__(256) void adam_dense_multi_kernel(
+    AdamDenseSets a, float b1, float b2, float eps) {
+  const xrd_adam_dense_set& s = a.s[blockIdx.y];
+  adam_dense_body(s.param, s.grad, s.m, s.v, s.n, s.lr, b1, b2, eps,
+                  s.weight_decay, s.step_ticket, s.advance ? 2 : 1);
 }
 
 __global__ void track_best_kernel(const double* __restrict__ loss,
@@ -1094,6 +1114,35 @@ int xrd_adam_dense_tick(float* param, const float* grad, float* m, float* v,
                      (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, step_ticket, advance ? 2 : 1);
   return check_launch("xrd_adam_dense_tick");
+}
+
+int xrd_adam_dense_multi(int n_sets, const xrd_adam_dense_set* sets,
+                         float beta1, float beta2, float eps,
+                         xrd_stream_t stream) {
+  if (n_sets < 0 || n_sets > XRD_ADAM_DENSE_MAX_SETS || (n_sets && !sets))
+    return XRD_ERR_ARG;
+  AdamDenseSets a = {};
+  int n = 0;
+  int64_t most = 0;
+  for (int i = 0; i < n_sets; ++i) {
+    const xrd_adam_dense_set& s = sets[i];
+    if (s.n < 0 || !s.step_ticket) return XRD_ERR_ARG;
+    // every set must own its counter: a set that advances a counter another
+    // set of the same launch still reads would race
+    for (int j = 0; j < i; ++j)
+      if (sets[j].step_ticket == s.step_ticket) return XRD_ERR_ARG;
+    if (s.n == 0) continue;
+    if (!s.param || !s.grad || !s.m || !s.v) return XRD_ERR_ARG;
+    a.s[n++] = s;
+    most = s.n > most ? s.n : most;
+  }
+  if (n == 0) return XRD_OK;
+  int64_t blocks = (most + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(adam_dense_multi_kernel,
+                     dim3((unsigned)blocks, (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, a, beta1, beta2, eps);
+  return check_launch("xrd_adam_dense_multi");
 }
 
 int xrd_track_best(const double* loss, const float* c2w16, double* best_loss,

@@ -336,7 +336,61 @@ class FusedDenseAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        lib = _lib.lib()
+        for launch in self._plan():
+            self._launch(launch)
+
+    @staticmethod
+    def _launch(a):
+        p, g, m, v, n, (lr, b1, b2, eps, wd), step, advance = a
+        _lib.check(_lib.lib().xrd_adam_dense_tick(
+            _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, lr, b1,
+            b2, eps, wd, _lib.ptr(step), advance, _lib.stream_ptr(p.device)),
+            'xrd_adam_dense_tick')
+
+    @staticmethod
+    @torch.no_grad()
+    def step_together(opts):
+        """the steps of several optimisers as ONE launch
+        (xrd_adam_dense_multi) where each contributes a single launch with a
+        step counter of its own and betas / eps / device agree; everything
+        else is launched as step() would"""
+        plans = [o._plan() for o in opts]
+        single = [pl[0] for pl in plans if len(pl) == 1]
+        for pl in plans:
+            if len(pl) != 1:
+                for a in pl:
+                    FusedDenseAdam._launch(a)
+        while single:
+            a0 = single[0]
+            key = (a0[5][1:4], a0[0].device)
+            grp, rest, seen = [], [], set()
+            for a in single:
+                if (a[5][1:4], a[0].device) == key and \
+                        id(a[6]) not in seen and \
+                        len(grp) < _lib.ADAM_DENSE_MAX_SETS:
+                    grp.append(a)
+                    seen.add(id(a[6]))
+                else:
+                    rest.append(a)
+            single = rest
+            if len(grp) == 1:
+                FusedDenseAdam._launch(grp[0])
+                continue
+            sets = (_lib.AdamDenseSet * len(grp))()
+            for k, (p, g, m, v, n, (lr, b1, b2, eps, wd), step, adv) in \
+                    enumerate(grp):
+                sets[k].param, sets[k].grad = _lib.ptr(p), _lib.ptr(g)
+                sets[k].m, sets[k].v = _lib.ptr(m), _lib.ptr(v)
+                sets[k].n, sets[k].lr, sets[k].weight_decay = n, lr, wd
+                sets[k].step_ticket, sets[k].advance = _lib.ptr(step), adv
+            _lib.check(_lib.lib().xrd_adam_dense_multi(
+                len(grp), sets, key[0][0], key[0][1], key[0][2],
+                _lib.stream_ptr(key[1])), 'xrd_adam_dense_multi')
+
+    def _plan(self):
+        """-> the launches of this step: (param, grad, m, v, n, (lr, b1, b2,
+        eps, wd), step counter, advance) each; sets up fresh state"""
+        out = []
         for grp in self.param_groups:
             b1, b2 = grp['betas']
             live = [p for p in grp['params'] if p.grad is not None]
@@ -406,12 +460,9 @@ class FusedDenseAdam(torch.optim.Optimizer):
                                        for p in live]))
             if grp['_flat_ok'] and self._consecutive(grads):
                 st = self.state[live[0]]
-                _lib.check(lib.xrd_adam_dense_tick(
-                    _lib.ptr(live[0]), _lib.ptr(grads[0]),
-                    _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
-                    sum(p.numel() for p in live), *args, _lib.ptr(st['step']),
-                    1, _lib.stream_ptr(live[0].device)),
-                    'xrd_adam_dense_tick')
+                out.append((live[0], grads[0], st['exp_avg'],
+                            st['exp_avg_sq'], sum(p.numel() for p in live),
+                            args, st['step'], 1))
             else:
                 # the last launch that uses a counter advances it
                 last = {}
@@ -419,17 +470,15 @@ class FusedDenseAdam(torch.optim.Optimizer):
                     last[id(self.state[p]['step'])] = i
                 for i, (p, g) in enumerate(zip(live, grads)):
                     st = self.state[p]
-                    _lib.check(lib.xrd_adam_dense_tick(
-                        _lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']),
-                        _lib.ptr(st['exp_avg_sq']), p.numel(), *args,
-                        _lib.ptr(st['step']),
-                        int(last[id(st['step'])] == i),
-                        _lib.stream_ptr(p.device)), 'xrd_adam_dense_tick')
+                    out.append((p, g, st['exp_avg'], st['exp_avg_sq'],
+                                p.numel(), args, st['step'],
+                                int(last[id(st['step'])] == i)))
             for p in live:
                 # the kernel writes through the raw pointer: torch's version
                 # counter does not see it; consumers that cache a derived
                 # layout (packed decoder weights) watch this counter instead
                 p._xrd_steps = getattr(p, '_xrd_steps', 0) + 1
+        return out
 
 
 @torch.no_grad()

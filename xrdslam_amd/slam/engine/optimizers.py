@@ -246,6 +246,17 @@ class Optimizers:
                     self.config[name]['optimizer'].accum_step is None]
         stepped = FusedCellAdam.step_together(together) \
             if len(together) > 1 else []
+        # ... and the dense tensors that step now (one optimiser a parameter
+        # group: five for SplaTAM's cloud, table + decoder + poses for the
+        # others) in one launch too
+        from ...engine.slam_ops import FusedDenseAdam
+        dense = [opt for name, opt in self.optimizers.items()
+                 if isinstance(opt, FusedDenseAdam) and
+                 self.config[name]['optimizer'].max_norm is None and
+                 self.config[name]['optimizer'].accum_step is None]
+        if len(dense) > 1:
+            FusedDenseAdam.step_together(dense)
+            stepped = list(stepped) + dense
         for name, opt in self.optimizers.items():
             if any(opt is o for o in stepped):
                 continue
