@@ -120,6 +120,33 @@ def test_refreshed_grad_jobs_follow_the_static_selection():
                                torch.full((12 - len(sel), 32), float(r + 1)))
 
 
+def test_exchanged_parameters_follow_the_optimisers_after_surgery():
+    """SplaTAM's growth / pruning REPLACES the Parameter objects inside its
+    optimisers' groups (gaussian_cloud_splatam.py:114-190 like the reference's
+    remove_points / cat_params_to_optimizer).  The gradients the mapping
+    all-reduce exchanges must be those of the live parameters, not of the list
+    the Optimizers object was built with — with the stale list the ranks'
+    clouds drifted apart from the first pruning step of a run (found by a
+    2-rank run in round 6: the all-reduce of the next frame failed on
+    different Gaussian counts)."""
+    from xrdslam_amd.slam.engine.optimizers import (AdamOptimizerConfig,
+                                                    Optimizers)
+    a = torch.nn.Parameter(torch.zeros(5, 3))
+    b = torch.nn.Parameter(torch.zeros(5, 1))
+    cfg = {'means3D': {'optimizer': AdamOptimizerConfig(lr=1e-3)},
+           'logit_opacities': {'optimizer': AdamOptimizerConfig(lr=1e-2)}}
+    opts = Optimizers(cfg, {'means3D': [a], 'logit_opacities': [b]})
+    live = opts.stepping_parameters(0)
+    assert live['means3D'][0] is a and live['logit_opacities'][0] is b
+    # pruning: rows 1, 3 go; the optimiser's group gets a NEW Parameter
+    keep = torch.tensor([0, 2, 4])
+    a2 = torch.nn.Parameter(a.detach()[keep].clone())
+    opts.optimizers['means3D'].param_groups[0]['params'][0] = a2
+    live = opts.stepping_parameters(7)
+    assert live['means3D'][0] is a2
+    assert live['logit_opacities'][0] is b
+
+
 def test_tile_band_partition_covers_the_image_once():
     """SplaTAM's tile-row bands (engine/dist.tile_band): every pixel row is
     owned by exactly one rank, the rendered tile rows cover the owned rows

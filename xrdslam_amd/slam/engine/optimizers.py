@@ -227,8 +227,15 @@ class Optimizers:
         """parameter groups whose optimiser steps at ``step``: gradients of
         an accumulating group (accum_step) stay local until its step, then
         their SUM is exchanged once (the all-reduce is linear)"""
+        # (the LIVE parameters of each optimiser: SplaTAM's growth / pruning
+        # replaces the Parameter objects inside the optimiser's groups, and
+        # the list this object was built with goes stale — its gradients were
+        # exchanged instead of the live ones and the ranks drifted apart from
+        # the first pruning step on)
         return {
-            n: p for n, p in getattr(self, 'parameters', {}).items()
+            n: [p for g in self.optimizers[n].param_groups
+                for p in g['params']]
+            for n in getattr(self, 'parameters', {})
             if n in self.optimizers and (
                 self.config[n]['optimizer'].accum_step is None or
                 (step + 1) % self.config[n]['optimizer'].accum_step == 0)}
