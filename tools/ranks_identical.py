@@ -25,7 +25,7 @@ def _tensors(obj, depth, seen, out, path):
     parameter dict, Point-SLAM's point cloud)"""
     if id(obj) in seen or depth < 0:
         return
-    seen.add(id(obj))
+    seen[id(obj)] = obj    # (kept alive: a freed temporary's id is reused)
     if torch.is_tensor(obj):
         if obj.is_floating_point() and obj.numel():
             out.append((path, obj))
@@ -53,7 +53,7 @@ def _tensors(obj, depth, seen, out, path):
 
 def checksum(algo):
     found = []
-    _tensors(algo.model, 4, set(), found, 'model')
+    _tensors(algo.model, 4, {}, found, 'model')
     found.sort(key=lambda kv: kv[0])
     vals = []
     for _, v in found:
@@ -101,9 +101,16 @@ def main():
                               f'vs {float(o[i])!r}', flush=True)
         else:
             worst = float('nan')
+            allnames = [None] * world
+            dist.all_gather_object(allnames, tnames)
             if rank == 0:
                 print('   the ranks hold different NUMBERS of tensors:',
                       [int(c) for c in cnts], flush=True)
+                for r in range(1, world):
+                    extra = set(allnames[r]) ^ set(allnames[0])
+                    if extra:
+                        print(f'   rank {r} vs rank 0:', sorted(extra),
+                              flush=True)
         if rank == 0:
             print(f'{name}: {n} frames on {world} ranks, ATE '
                   f'{c1_util.ate(est, gt) * 100:.2f} cm, {t.numel()} sums: '
