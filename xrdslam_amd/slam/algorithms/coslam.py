@@ -273,8 +273,12 @@ class CoSLAM(Algorithm):
         cnt = (cam.height - 2 * cfg.tracking_Hedge) * wcrop
         idx = torch.randint(cnt, (1, cfg.tracking_sample), device=dev)
         d_img, c_img = cur.device_images(dev)
+        c2w = cur.get_pose().to(dev)
+        # (the iteration's best-pose bookkeeping reads this pose: one
+        # axis-angle -> matrix launch an iteration instead of two)
+        self._iter_c2w = c2w.detach()
         ro, rd, td, tc, _keep, _dmax = slam_ops.SampleRaysFn.apply(
-            cur.get_pose().to(dev).unsqueeze(0), idx, [d_img], [c_img], cam,
+            c2w.unsqueeze(0), idx, [d_img], [c_img], cam,
             (cfg.tracking_Hedge, cfg.tracking_Wedge, wcrop),
             self.bounding_box.reshape(-1).tolist())
         return {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,

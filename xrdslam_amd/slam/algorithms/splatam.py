@@ -126,6 +126,10 @@ class SplaTAM(Algorithm):
             inp['c2w'] = self._slot.c2w
             return inp
         pose = f.get_pose().to(self.device)
+        if not is_mapping:
+            # the iteration's best-pose bookkeeping reads this pose: one
+            # quaternion -> matrix launch an iteration instead of two
+            self._iter_c2w = pose.detach()
         if pose.is_cuda:
             # the rigid inverse is taken inside the preparation kernel
             # (csrc/gs_prepare.hip) — torch.inverse is an LU factorisation

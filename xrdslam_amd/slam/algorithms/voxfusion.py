@@ -116,7 +116,8 @@ class VoxFusion(Algorithm):
         if sharded and not det:
             n = _dist.state.shard_count(n)
         if torch.device(dev).type == 'cuda' and self.fused_iteration:
-            return self._model_input_kernels(optimize_frames, n, gen, sharded)
+            return self._model_input_kernels(optimize_frames, n, gen, sharded,
+                                             track=not is_mapping)
         ro, rd, gd, gc = [], [], [], []
         for f in optimize_frames:
             o, d, dep, col = get_samples(self.camera, n, f.get_pose(), f.depth,
@@ -133,7 +134,7 @@ class VoxFusion(Algorithm):
                 'target_s': torch.cat(gc), 'target_d': torch.cat(gd),
                 'sharded': sharded}
 
-    def _model_input_kernels(self, frames, n, gen, sharded):
+    def _model_input_kernels(self, frames, n, gen, sharded, track=False):
         """get_samples of every window frame (common.py:188-227: pixels drawn
         with replacement over the whole image, OpenGL rays through the frame's
         pose) as one index draw + one launch per frame, differentiable w.r.t.
@@ -142,7 +143,13 @@ class VoxFusion(Algorithm):
         cam, dev = self.camera, self.model.device
         idx = torch.randint(cam.height * cam.width, (len(frames), n),
                             device=dev, generator=gen)
-        c2ws = torch.stack([f.get_pose().to(dev) for f in frames])
+        poses = [f.get_pose().to(dev) for f in frames]
+        # one frame (tracking, the first mapping calls): a view, no copy
+        c2ws = poses[0].unsqueeze(0) if len(poses) == 1 else torch.stack(poses)
+        if track:
+            # the iteration's best-pose bookkeeping reads this pose: one
+            # quaternion -> matrix launch an iteration instead of two
+            self._iter_c2w = poses[-1].detach()
         imgs = [f.device_images(dev) for f in frames]
         big = 1e30
         ro, rd, td, tc, _, _ = SampleRaysFn.apply(
