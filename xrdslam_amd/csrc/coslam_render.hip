@@ -1020,9 +1020,16 @@ int xrd_coslam_render_bwd_extra(
   if (!dp && !dg) return XRD_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dp) {
-    if ((rc = zero_floats(g_rays_o, (size_t)3 * n_rays, stream)) != XRD_OK ||
-        (rc = zero_floats(g_rays_d, (size_t)3 * n_rays, stream)) != XRD_OK)
+    // (the two ray gradients back to back in one buffer: one fill launch)
+    if (g_rays_d == g_rays_o + (size_t)3 * n_rays) {
+      if ((rc = zero_floats(g_rays_o, (size_t)6 * n_rays, stream)) != XRD_OK)
+        return rc;
+    } else if ((rc = zero_floats(g_rays_o, (size_t)3 * n_rays, stream)) !=
+                   XRD_OK ||
+               (rc = zero_floats(g_rays_d, (size_t)3 * n_rays, stream)) !=
+                   XRD_OK) {
       return rc;
+    }
   }
   if (dg && (rc = zero_floats(g_dw, cs::kDwLen, stream)) != XRD_OK) return rc;
   if (n_rays == 0) return XRD_OK;

@@ -212,8 +212,11 @@ class _CoslamRenderFn(torch.autograd.Function):
         n = ro.shape[0]
         need_rays = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         need_map = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
-        g_o = torch.empty_like(ro) if need_rays else None
-        g_d = torch.empty_like(rd) if need_rays else None
+        g_o = g_d = None
+        if need_rays:
+            # back to back: the kernel's zero-fill of both is one launch
+            g_od = torch.empty(2, n, 3, dtype=torch.float32, device=dev)
+            g_o, g_d = g_od[0], g_od[1]
         g_table = g_dw = None
         if need_map:
             g_table = torch.empty_like(table)  # fully overwritten

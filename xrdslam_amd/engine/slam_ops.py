@@ -95,7 +95,8 @@ class SampleRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, c2ws, idx, depth_imgs: Sequence[torch.Tensor],
-                rgb_imgs: Sequence[torch.Tensor], cam, crop, bound6):
+                rgb_imgs: Sequence[torch.Tensor], cam, crop, bound6,
+                need_dmax=True):
         lib = _lib.lib()
         F, n = idx.shape
         dev = idx.device
@@ -105,7 +106,10 @@ class SampleRaysFn(torch.autograd.Function):
         td = torch.empty(N, 1, dtype=torch.float32, device=dev)
         tc = torch.empty(N, 3, dtype=torch.float32, device=dev)
         keep = torch.empty(N, dtype=torch.uint8, device=dev)
-        dmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        # (callers that do not read the batch's largest kept depth skip its
+        # zero-fill launch; the kernel takes a null pointer)
+        dmax = torch.zeros(1, dtype=torch.float32, device=dev) \
+            if need_dmax else None
         c2ws = c2ws.detach().float().contiguous()
         H0, W0, wcrop = crop
         st = _lib.stream_ptr(dev)
@@ -121,6 +125,8 @@ class SampleRaysFn(torch.autograd.Function):
                 'xrd_sample_rays')
         ctx.args = (cam, crop, F, n)
         ctx.save_for_backward(idx)
+        if dmax is None:
+            dmax = torch.empty(0, dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(td, tc, keep, dmax)
         # gradients of the non-differentiable outputs arrive as None instead
         # of materialised zero tensors (one fill launch each)
@@ -146,7 +152,7 @@ class SampleRaysFn(torch.autograd.Function):
                 C.c_void_p(idx.data_ptr() + 8 * f * n), _off(g_ro, 3 * f * n),
                 _off(g_rd, 3 * f * n), _off(g_c2w, 16 * f), st),
                 'xrd_sample_rays_bwd')
-        return g_c2w, None, None, None, None, None, None
+        return g_c2w, None, None, None, None, None, None, None
 
 
 def sample_rays_poses(idx, depth_imgs, rgb_imgs, cam, crop, bound6, layout,

@@ -280,7 +280,7 @@ class CoSLAM(Algorithm):
         ro, rd, td, tc, _keep, _dmax = slam_ops.SampleRaysFn.apply(
             c2w.unsqueeze(0), idx, [d_img], [c_img], cam,
             (cfg.tracking_Hedge, cfg.tracking_Wedge, wcrop),
-            self.bounding_box.reshape(-1).tolist())
+            self.bounding_box.reshape(-1).tolist(), False)
         return {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
                 'first': False}
 

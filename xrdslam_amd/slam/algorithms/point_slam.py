@@ -246,7 +246,7 @@ class PointSLAM(Algorithm):
             c2ws = torch.stack([p.to(dev) for p in poses])
             ro, rd, td, tc, _, _ = slam_ops.SampleRaysFn.apply(
                 c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
-                (Hedge, Wedge, wcrop), bound6)
+                (Hedge, Wedge, wcrop), bound6, False)
         if not want_radius:
             return ro, rd, td.reshape(-1), tc, idx, wcrop
         rq = None

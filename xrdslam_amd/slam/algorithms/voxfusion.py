@@ -154,7 +154,7 @@ class VoxFusion(Algorithm):
         big = 1e30
         ro, rd, td, tc, _, _ = SampleRaysFn.apply(
             c2ws, idx, [i[0] for i in imgs], [i[1] for i in imgs], cam,
-            (0, 0, cam.width), (-big, big, -big, big, -big, big))
+            (0, 0, cam.width), (-big, big, -big, big, -big, big), False)
         out = {'rays_o': ro, 'rays_d': rd, 'target_s': tc, 'target_d': td,
                'sharded': sharded}
         if sharded and _dist.state.deterministic:
