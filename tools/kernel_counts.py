@@ -71,8 +71,9 @@ def report(tag, p):
                                'aten::masked_fill_', 'aten::index_put_'):
                 fr = [f for f in (e.stack or []) if 'xrdslam_amd' in f or
                       'bench.py' in f]
-                src[(e.name, fr[0].split('xrdslam_amd/')[-1] if fr else '?')] \
-                    += 1
+                where = fr[0].split('xrdslam_amd/')[-1] if fr else \
+                    str(getattr(e, 'input_shapes', ''))[:70]
+                src[(e.name, where)] += 1
         for (op, where), k in src.most_common(60):
             print(f'      {k:3d} {op:22s} {where}')
 
@@ -112,6 +113,8 @@ def run(name):
                 torch.cuda.synchronize()
                 with profile(activities=[ProfilerActivity.CUDA,
                                          ProfilerActivity.CPU],
+                             record_shapes=bool(os.environ.get(
+                                 'XRD_KC_STACK')),
                              with_stack=bool(os.environ.get(
                                  'XRD_KC_STACK'))) as p:
                     out = orig(optimizers, frames, is_mapping, step, *a, **kw)
