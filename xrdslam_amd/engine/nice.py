@@ -112,13 +112,42 @@ def pack_index(kind: str, device) -> torch.Tensor:
     return _pack_index_cache[key]
 
 
+def _zero_tailed(flat: torch.Tensor) -> Optional[torch.Tensor]:
+    """the [n + 1] buffer (last element 0: what the packing index points its
+    padding at) a flat decoder parameter has been re-seated on, if it still
+    sits there"""
+    ext = getattr(flat, '_xrd_ext', None)
+    if ext is not None and ext.device == flat.device and \
+            ext.numel() == flat.numel() + 1 and \
+            ext.data_ptr() == flat.data_ptr() and flat.is_contiguous():
+        return ext
+    return None
+
+
+def seat_on_zero_tail(flat: torch.Tensor) -> None:
+    """re-seat a decoder's flat parameter on a buffer with a trailing zero so
+    that re-packing it (every iteration of a stage that trains the decoder)
+    is ONE gather instead of a fill, a concatenation and a gather.  Values
+    kept; idempotent; done once when the scene is built, before anything is
+    captured."""
+    if _zero_tailed(flat) is not None or flat.dtype != torch.float32 or \
+            flat.dim() != 1:
+        return
+    with torch.no_grad():
+        ext = torch.cat([flat.detach(), flat.new_zeros(1)])
+        flat.data = ext[:-1]
+    flat._xrd_ext = ext
+
+
 def pack_decoder(flat: torch.Tensor, kind: str,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.lib()
     assert flat.numel() == lib.xrd_nice_flat_len(DEC_KINDS[kind]), \
         (kind, flat.numel())
-    ext = torch.cat([flat.detach().float().reshape(-1),
-                     flat.new_zeros(1, dtype=torch.float32)])
+    ext = _zero_tailed(flat)
+    if ext is None:
+        ext = torch.cat([flat.detach().float().reshape(-1),
+                         flat.new_zeros(1, dtype=torch.float32)])
     idx = pack_index(kind, flat.device)
     if out is not None:
         # in place: launches captured in a hipGraph (and graphs captured
@@ -178,6 +207,8 @@ class NiceScene:
         old = self.packed.get(kind)
         if old is not None and old.device != flat.device:
             old = None
+        if old is None and isinstance(flat, torch.nn.Parameter):
+            seat_on_zero_tail(flat)
         self.packed[kind] = pack_decoder(flat, kind, out=old)
 
     def c_struct(self) -> _lib.NiceScene:
