@@ -553,10 +553,9 @@ def test_coslam_mapping_graph_slot(persistent):
         assert set(slots) == {128, 256, 512, 1024, 2048}
         assert all(len(s['graphs']) == 2 for s in slots.values())
     ate = slam.ate_rmse()
-    # (float-atomic order makes the run-to-run ATE of this 60 cm path vary:
-    # 1.3-2.1 cm observed over the round's runs — one of ~10 suite runs sat at
-    # 2.11 cm against the former 2 cm bound; a pose that never moves scores
-    # ~30 cm)
+    # (float-atomic order makes the ATE of this ~60 cm path vary from run to
+    # run: below 2 cm in all but one of the round's ~15 suite runs, 2.11 cm
+    # in that one; a pose that never moves scores tens of centimetres)
     assert ate < 0.03, ate
     # bundle adjustment wrote the keyframe poses back
     kf = algo.keyframe_graph[3]
