@@ -220,3 +220,35 @@ def test_noxyz_chain_emulation():
                 gp[kt] = mfma(a, gD[s >> 2, s & 3], gp[kt])
         np.testing.assert_allclose(from_dlayout(gp), g @ W, rtol=1e-4,
                                    atol=1e-4)
+
+
+@pytest.mark.parametrize('kind', ['coarse', 'middle', 'fine', 'color'])
+def test_repack_of_a_zero_tailed_decoder_is_the_same_gather(kind):
+    """engine/nice.seat_on_zero_tail: a decoder's flat parameter re-seated on
+    a buffer with a trailing zero packs to the same fragments with ONE gather
+    (no fill, no concatenation), follows in-place updates of the parameter
+    (what the fused Adam does), writes into the caller's buffer and is
+    idempotent; a parameter that has left the buffer falls back to the
+    concatenation."""
+    n = _lib.lib().xrd_nice_flat_len(en.DEC_KINDS[kind])
+    torch.manual_seed(3)
+    flat = torch.nn.Parameter(torch.randn(n))
+    ref = en.pack_decoder(flat, kind).clone()
+    before = flat.detach().clone()
+    old_ptr = flat.data_ptr()
+    en.seat_on_zero_tail(flat)
+    assert flat.data_ptr() != old_ptr and torch.equal(flat.detach(), before)
+    ext = en._zero_tailed(flat)
+    assert ext is not None and float(ext[-1]) == 0.0
+    got = en.pack_decoder(flat, kind)
+    assert torch.equal(got, ref)
+    with torch.no_grad():
+        flat.mul_(-0.5)
+    out = en.pack_decoder(flat, kind, out=got)
+    assert out.data_ptr() == got.data_ptr() and torch.equal(out, ref * -0.5)
+    assert float(ext[-1]) == 0.0
+    en.seat_on_zero_tail(flat)                       # idempotent
+    assert en._zero_tailed(flat) is ext
+    flat.data = flat.detach().clone()                # moved away
+    assert en._zero_tailed(flat) is None
+    assert torch.equal(en.pack_decoder(flat, kind), ref * -0.5)
